@@ -1,0 +1,291 @@
+"""ctypes front-end of the CPU parity oracle (oracle/kfx_oracle.c).
+
+TEST INFRASTRUCTURE ONLY.  Importable from tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg; the product package `kangaroo_amd` never imports it.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class KfoImage(C.Structure):
+    # roo::Image field order, Image.h:617-620
+    _fields_ = [("pitch", C.c_size_t), ("ptr", C.c_void_p), ("w", C.c_size_t), ("h", C.c_size_t)]
+
+
+class KfoVolume(C.Structure):
+    # roo::BoundedVolume field order, Volume.h:363-369 + BoundedVolume.h:168
+    _fields_ = [("pitch", C.c_size_t), ("ptr", C.c_void_p), ("w", C.c_size_t), ("h", C.c_size_t),
+                ("img_pitch", C.c_size_t), ("d", C.c_size_t),
+                ("boxmin", C.c_float * 3), ("boxmax", C.c_float * 3)]
+
+
+class KfoRaycastStats(C.Structure):
+    _fields_ = [("rays", C.c_uint64), ("steps", C.c_uint64), ("hits", C.c_uint64)]
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "libkfx_oracle.so")
+    src = os.path.join(_HERE, "kfx_oracle.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "libkfx_oracle.so"], stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        L = C.CDLL(build())
+        PI, PV, PF = C.POINTER(KfoImage), C.POINTER(KfoVolume), C.POINTER(C.c_float)
+        L.kfo_bilateral_f32.argtypes = [PI, PI, C.c_float, C.c_float, C.c_int, C.c_float, C.c_int, C.c_int]
+        L.kfo_bilateral_u16.argtypes = [PI, PI, C.c_float, C.c_float, C.c_int, C.c_ushort, C.c_int]
+        L.kfo_bilateral_u8.argtypes = [PI, PI, C.c_float, C.c_float, C.c_int, C.c_int]
+        L.kfo_depth_to_vbo_f32.argtypes = [PI, PI, PF, C.c_float]
+        L.kfo_depth_to_vbo_u16.argtypes = [PI, PI, PF, C.c_float]
+        L.kfo_normals_from_vbo.argtypes = [PI, PI]
+        L.kfo_sdf_reset.argtypes = [PV, C.c_float]
+        L.kfo_sdf_sphere.argtypes = [PV, PF, C.c_float]
+        L.kfo_sdf_fuse.argtypes = [PV, PI, PI, PF, PF, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int]
+        L.kfo_sdf_fuse.restype = C.c_uint64
+        L.kfo_raycast_sdf.argtypes = [PI, PI, PI, PV, PF, PF, C.c_float, C.c_float, C.c_float, C.c_int,
+                                      C.c_int, C.POINTER(KfoRaycastStats)]
+        L.kfo_raycast_sdf_touch.argtypes = [PI, PI, PI, PV, PF, PF, C.c_float, C.c_float, C.c_float, C.c_int,
+                                            C.c_void_p, C.POINTER(KfoRaycastStats)]
+        L.kfo_raycast_box.argtypes = [PI, PF, PF, PF, PF]
+        L.kfo_raycast_sphere.argtypes = [PI, PI, PF, PF, PF, C.c_float]
+        L.kfo_raycast_plane.argtypes = [PI, PI, PF, PF, PF]
+        L.kfo_render_scene.argtypes = [PI, C.c_int, PF, PF]
+        L.kfo_fit_to_frustum.argtypes = [PF, PF, PF, C.c_float, C.c_float, PF, C.c_float, C.c_float]
+        L.kfo_sub_bounding_volume.argtypes = [PV, PV, PF, PF]
+        L.kfo_se3_inverse.argtypes = [PF, PF]
+        L.kfo_max_threads.restype = C.c_int
+        for f in ("kfo_bilateral_f32", "kfo_bilateral_u16", "kfo_bilateral_u8", "kfo_depth_to_vbo_f32",
+                  "kfo_depth_to_vbo_u16", "kfo_normals_from_vbo", "kfo_sdf_reset", "kfo_sdf_sphere",
+                  "kfo_raycast_sdf", "kfo_raycast_sdf_touch", "kfo_raycast_box", "kfo_raycast_sphere",
+                  "kfo_raycast_plane", "kfo_render_scene", "kfo_fit_to_frustum",
+                  "kfo_sub_bounding_volume", "kfo_se3_inverse"):
+            getattr(L, f).restype = None
+        _LIB = L
+    return _LIB
+
+
+def _fp(a):
+    a = np.ascontiguousarray(a, dtype=np.float32).reshape(-1)
+    return a, a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+class Image:
+    """Pitched host image backed by a numpy array.  `data` has shape (h, w[, ch])."""
+
+    def __init__(self, w, h, dtype=np.float32, channels=1, pitch_bytes=None):
+        self.w, self.h, self.channels = int(w), int(h), int(channels)
+        self.dtype = np.dtype(dtype)
+        elem = self.dtype.itemsize * self.channels
+        self.pitch = int(pitch_bytes) if pitch_bytes else self.w * elem
+        assert self.pitch >= self.w * elem and self.pitch % self.dtype.itemsize == 0
+        self.raw = np.zeros((self.h, self.pitch), dtype=np.uint8)
+        row = self.raw[:, : self.w * elem].view(self.dtype)
+        # view into the pitched storage
+        self.data = np.lib.stride_tricks.as_strided(
+            self.raw.view(self.dtype).reshape(-1),
+            shape=(self.h, self.w, self.channels) if channels > 1 else (self.h, self.w),
+            strides=(self.pitch, elem, self.dtype.itemsize) if channels > 1 else (self.pitch, elem),
+        )
+        del row
+
+    @staticmethod
+    def from_numpy(a, pitch_bytes=None):
+        a = np.asarray(a)
+        ch = a.shape[2] if a.ndim == 3 else 1
+        im = Image(a.shape[1], a.shape[0], a.dtype, ch, pitch_bytes)
+        im.data[...] = a
+        return im
+
+    def struct(self):
+        return KfoImage(self.pitch, self.raw.ctypes.data, self.w, self.h)
+
+    def ref(self):
+        self._s = self.struct()
+        return C.byref(self._s)
+
+
+class Volume:
+    """Pitched host BoundedVolume<SDF_t>.  `data` has shape (d, h, w, 2) = (val, w)."""
+
+    def __init__(self, w, h, d, boxmin=(-1, -1, -1), boxmax=(1, 1, 1), pitch_bytes=None, elem_floats=2):
+        self.w, self.h, self.d = int(w), int(h), int(d)
+        self.ef = elem_floats
+        elem = 4 * elem_floats
+        self.pitch = int(pitch_bytes) if pitch_bytes else self.w * elem
+        self.img_pitch = self.pitch * self.h
+        self.raw = np.zeros(self.img_pitch * self.d, dtype=np.uint8)
+        self.boxmin = np.asarray(boxmin, np.float32)
+        self.boxmax = np.asarray(boxmax, np.float32)
+        self.data = np.lib.stride_tricks.as_strided(
+            self.raw.view(np.float32), shape=(self.d, self.h, self.w, elem_floats),
+            strides=(self.img_pitch, self.pitch, elem, 4))
+
+    def struct(self):
+        s = KfoVolume(self.pitch, self.raw.ctypes.data, self.w, self.h, self.img_pitch, self.d)
+        for i in range(3):
+            s.boxmin[i] = float(self.boxmin[i])
+            s.boxmax[i] = float(self.boxmax[i])
+        return s
+
+    def ref(self):
+        self._s = self.struct()
+        return C.byref(self._s)
+
+    def voxel_size(self):
+        sz = (self.boxmax - self.boxmin).astype(np.float32)
+        return sz / np.array([self.w - 1, self.h - 1, self.d - 1], np.float32)
+
+
+class SubVolume:
+    """Non-owning view produced by sub_bounding_volume (keeps the parent alive)."""
+
+    def __init__(self, parent, s):
+        self.parent, self._s = parent, s
+        self.w, self.h, self.d = s.w, s.h, s.d
+        self.pitch, self.img_pitch = s.pitch, s.img_pitch
+        self.boxmin = np.array(list(s.boxmin), np.float32)
+        self.boxmax = np.array(list(s.boxmax), np.float32)
+        off = s.ptr - parent.raw.ctypes.data
+        self.offset_bytes = off
+        z0, rem = divmod(off, s.img_pitch)
+        y0, rem = divmod(rem, s.pitch)
+        x0 = rem // 8
+        self.origin = (x0, y0, z0)
+        self.data = parent.data[z0:z0 + s.d, y0:y0 + s.h, x0:x0 + s.w]
+
+    def struct(self):
+        return self._s
+
+    def ref(self):
+        return C.byref(self._s)
+
+
+# ---- thin functional API -----------------------------------------------------
+def bilateral(out, inp, gs, gr, size, minval=None, nthreads=1):
+    L = lib()
+    if inp.dtype == np.float32:
+        L.kfo_bilateral_f32(out.ref(), inp.ref(), gs, gr, size, 0.0 if minval is None else minval,
+                            0 if minval is None else 1, nthreads)
+    elif inp.dtype == np.uint16:
+        L.kfo_bilateral_u16(out.ref(), inp.ref(), gs, gr, size, int(minval), nthreads)
+    elif inp.dtype == np.uint8:
+        L.kfo_bilateral_u8(out.ref(), inp.ref(), gs, gr, size, nthreads)
+    else:
+        raise TypeError(inp.dtype)
+
+
+def depth_to_vbo(vbo, depth, K, scale=1.0):
+    _, k = _fp(K)
+    if depth.dtype == np.uint16:
+        lib().kfo_depth_to_vbo_u16(vbo.ref(), depth.ref(), k, scale)
+    else:
+        lib().kfo_depth_to_vbo_f32(vbo.ref(), depth.ref(), k, scale)
+
+
+def normals_from_vbo(nrm, vbo):
+    lib().kfo_normals_from_vbo(nrm.ref(), vbo.ref())
+
+
+def sdf_reset(vol, trunc):
+    lib().kfo_sdf_reset(vol.ref(), trunc)
+
+
+def sdf_sphere(vol, center, r):
+    _, c = _fp(center)
+    lib().kfo_sdf_sphere(vol.ref(), c, r)
+
+
+def sdf_fuse(vol, depth, norm, T_cw, K, trunc, max_w, mincostheta, full_extent=False, nthreads=1):
+    _, t = _fp(T_cw)
+    _, k = _fp(K)
+    return int(lib().kfo_sdf_fuse(vol.ref(), depth.ref(), norm.ref(), t, k, trunc, max_w, mincostheta,
+                                  1 if full_extent else 0, nthreads))
+
+
+def raycast_sdf(depth, norm, img, vol, T_wc, K, near, far, trunc, subpix=True, nthreads=1):
+    _, t = _fp(T_wc)
+    _, k = _fp(K)
+    st = KfoRaycastStats()
+    lib().kfo_raycast_sdf(depth.ref(), norm.ref(), img.ref(), vol.ref(), t, k, near, far, trunc,
+                          1 if subpix else 0, nthreads, C.byref(st))
+    return {"rays": st.rays, "steps": st.steps, "hits": st.hits}
+
+
+def raycast_sdf_touch(depth, norm, img, vol, T_wc, K, near, far, trunc, subpix=True):
+    """Returns (stats, number of distinct voxels touched)."""
+    _, t = _fp(T_wc)
+    _, k = _fp(K)
+    st = KfoRaycastStats()
+    bm = np.zeros((vol.w * vol.h * vol.d + 7) // 8, np.uint8)
+    lib().kfo_raycast_sdf_touch(depth.ref(), norm.ref(), img.ref(), vol.ref(), t, k, near, far, trunc,
+                                1 if subpix else 0, bm.ctypes.data, C.byref(st))
+    touched = int(np.unpackbits(bm).sum())
+    return {"rays": st.rays, "steps": st.steps, "hits": st.hits}, touched
+
+
+def raycast_box(depth, T_wc, K, boxmin, boxmax):
+    _, t = _fp(T_wc)
+    _, k = _fp(K)
+    _, a = _fp(boxmin)
+    _, b = _fp(boxmax)
+    lib().kfo_raycast_box(depth.ref(), t, k, a, b)
+
+
+def raycast_sphere(depth, img, T_wc, K, center, r):
+    _, t = _fp(T_wc)
+    _, k = _fp(K)
+    _, c = _fp(center)
+    null = KfoImage(0, None, 0, 0)
+    lib().kfo_raycast_sphere(depth.ref(), img.ref() if img is not None else C.byref(null), t, k, c, r)
+
+
+def raycast_plane(depth, img, T_wc, K, n_w):
+    _, t = _fp(T_wc)
+    _, k = _fp(K)
+    _, n = _fp(n_w)
+    null = KfoImage(0, None, 0, 0)
+    lib().kfo_raycast_plane(depth.ref(), img.ref() if img is not None else C.byref(null), t, k, n)
+
+
+def render_scene(depth, scene, T_wc, K):
+    _, t = _fp(T_wc)
+    _, k = _fp(K)
+    lib().kfo_render_scene(depth.ref(), {"room": 0, "full": 1}[scene], t, k)
+
+
+def fit_to_frustum(T_wc, w, h, K, near, far):
+    _, t = _fp(T_wc)
+    _, k = _fp(K)
+    lo = (C.c_float * 3)()
+    hi = (C.c_float * 3)()
+    lib().kfo_fit_to_frustum(lo, hi, t, float(w), float(h), k, near, far)
+    return np.array(list(lo), np.float32), np.array(list(hi), np.float32)
+
+
+def sub_bounding_volume(vol, rmin, rmax):
+    _, a = _fp(rmin)
+    _, b = _fp(rmax)
+    out = KfoVolume()
+    lib().kfo_sub_bounding_volume(C.byref(out), vol.ref(), a, b)
+    return SubVolume(vol, out)
+
+
+def se3_inverse(T):
+    _, t = _fp(T)
+    o = (C.c_float * 12)()
+    lib().kfo_se3_inverse(o, t)
+    return np.array(list(o), np.float32).reshape(3, 4)
+
+
+def max_threads():
+    return int(lib().kfo_max_threads())

@@ -1,0 +1,665 @@
+/*
+ * kfx_oracle.c -- CPU restatement (parity oracle) of the KinectFusion volumetric
+ * hot path of arpg/Kangaroo.  TEST INFRASTRUCTURE ONLY -- see kfx_oracle.h.
+ *
+ * Build: gcc -std=c11 -O2 -ffp-contract=off -fno-fast-math -fopenmp -shared -fPIC
+ * Every arithmetic expression keeps the reference's operand order and
+ * association; all arithmetic is IEEE binary32 with no fused multiply-add, so a
+ * HIP kernel built with -ffp-contract=off and correctly rounded div/sqrt can be
+ * compared bit-for-bit.  Citations are paths inside the reference tree.
+ */
+#include "kfx_oracle.h"
+
+#include <math.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+typedef struct { float x, y, z; } f3;
+typedef struct { float x, y, z, w; } f4;
+typedef struct { float val, w; } sdf_t; /* Sdf.h:11-36 */
+
+/* ---- scalar helpers: CUDA_SDK/cutil_math.h ---------------------------------- */
+static inline float lerpf(float a, float b, float t) { return a + t * (b - a); }       /* :80-83 */
+static inline float clampf(float f, float a, float b) { return fmaxf(a, fminf(f, b)); } /* :86-89 */
+static inline float dot3(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }      /* :392-395 */
+static inline float length3(f3 v) { return sqrtf(dot3(v, v)); }                         /* :404-407 */
+static inline f3 mk3(float x, float y, float z) { f3 r = {x, y, z}; return r; }
+static inline f3 add3(f3 a, f3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+static inline f3 sub3(f3 a, f3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+static inline f3 scale3(f3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }       /* :341-352 */
+static inline f3 div33(f3 a, f3 b) { return mk3(a.x / b.x, a.y / b.y, a.z / b.z); }     /* :354-357 */
+/* float3 / float is multiply-by-reciprocal: cutil_math.h:358-362 (quirk Q5) */
+static inline f3 div3s(f3 a, float s) { float inv = 1.0f / s; return scale3(a, inv); }
+static inline f3 lerp3(f3 a, f3 b, float t) { return add3(a, scale3(sub3(b, a), t)); }  /* :375-378 */
+static inline int clampi(int f, int a, int b) { return f < a ? a : (f > b ? b : f); }   /* :653-656 */
+
+/* ---- Mat<float,3,4> helpers: MatUtils.h ------------------------------------- */
+#define T_(r, c) T[(r) * 4 + (c)] /* row-major, Mat.h:36-42 */
+static inline f3 se3_mul(const float* T, f3 p) /* MatUtils.h:117-125 */
+{
+    return mk3(T_(0, 0) * p.x + T_(0, 1) * p.y + T_(0, 2) * p.z + T_(0, 3),
+               T_(1, 0) * p.x + T_(1, 1) * p.y + T_(1, 2) * p.z + T_(1, 3),
+               T_(2, 0) * p.x + T_(2, 1) * p.y + T_(2, 2) * p.z + T_(2, 3));
+}
+static inline f3 so3_mul(const float* T, f3 r) /* MatUtils.h:147-155 */
+{
+    return mk3(T_(0, 0) * r.x + T_(0, 1) * r.y + T_(0, 2) * r.z,
+               T_(1, 0) * r.x + T_(1, 1) * r.y + T_(1, 2) * r.z,
+               T_(2, 0) * r.x + T_(2, 1) * r.y + T_(2, 2) * r.z);
+}
+static inline f3 so3_mul_inv(const float* T, f3 r) /* MatUtils.h:177-185 */
+{
+    return mk3(T_(0, 0) * r.x + T_(1, 0) * r.y + T_(2, 0) * r.z,
+               T_(0, 1) * r.x + T_(1, 1) * r.y + T_(2, 1) * r.z,
+               T_(0, 2) * r.x + T_(1, 2) * r.y + T_(2, 2) * r.z);
+}
+static inline f3 se3_mul_inv(const float* T, f3 r) /* MatUtils.h:192-200 */
+{
+    const float ax = r.x - T_(0, 3), ay = r.y - T_(1, 3), az = r.z - T_(2, 3);
+    return mk3(T_(0, 0) * ax + T_(1, 0) * ay + T_(2, 0) * az,
+               T_(0, 1) * ax + T_(1, 1) * ay + T_(2, 1) * az,
+               T_(0, 2) * ax + T_(1, 2) * ay + T_(2, 2) * az);
+}
+static inline f3 se3_translation(const float* T) { return mk3(T_(0, 3), T_(1, 3), T_(2, 3)); } /* :216-220 */
+
+void kfo_se3_inverse(float o[12], const float T[12]) /* MatUtils.h:202-214 */
+{
+    o[0] = T_(0, 0); o[1] = T_(1, 0); o[2]  = T_(2, 0);
+    o[4] = T_(0, 1); o[5] = T_(1, 1); o[6]  = T_(2, 1);
+    o[8] = T_(0, 2); o[9] = T_(1, 2); o[10] = T_(2, 2);
+    o[3]  = -(o[0] * T_(0, 3) + o[1] * T_(1, 3) + o[2]  * T_(2, 3));
+    o[7]  = -(o[4] * T_(0, 3) + o[5] * T_(1, 3) + o[6]  * T_(2, 3));
+    o[11] = -(o[8] * T_(0, 3) + o[9] * T_(1, 3) + o[10] * T_(2, 3));
+}
+
+/* ---- ImageIntrinsics {fu,fv,u0,v0}: ImageIntrinsics.h ------------------------ */
+#define FU K[0]
+#define FV K[1]
+#define U0 K[2]
+#define V0 K[3]
+static inline f3 unproject1(const float* K, float u, float v) /* :109-113 */
+{
+    return mk3((u - U0) / FU, (v - V0) / FV, 1.0f);
+}
+
+/* ---- pitched containers ------------------------------------------------------ */
+static inline unsigned char* img_row(const kfo_image* im, size_t y) /* Image.h:235-245 */
+{
+    return (unsigned char*)im->ptr + y * im->pitch;
+}
+static inline sdf_t* vol_row(const kfo_volume* v, size_t y, size_t z) /* Volume.h:125-135 */
+{
+    return (sdf_t*)((unsigned char*)v->ptr + z * v->img_pitch + y * v->pitch);
+}
+static inline float vol_val(const kfo_volume* v, int x, int y, int z) /* Volume.h:161-171 + Sdf.h:16-18 */
+{
+    return vol_row(v, (size_t)y, (size_t)z)[x].val;
+}
+static inline f3 box_size(const kfo_volume* v) /* BoundingBox.h:139-143 */
+{
+    return mk3(v->boxmax[0] - v->boxmin[0], v->boxmax[1] - v->boxmin[1], v->boxmax[2] - v->boxmin[2]);
+}
+static inline f3 box_min(const kfo_volume* v) { return mk3(v->boxmin[0], v->boxmin[1], v->boxmin[2]); }
+static inline f3 box_max(const kfo_volume* v) { return mk3(v->boxmax[0], v->boxmax[1], v->boxmax[2]); }
+static inline f3 voxel_size_units(const kfo_volume* v) /* BoundedVolume.h:67-76 */
+{
+    return div33(box_size(v), mk3((float)(v->w - 1), (float)(v->h - 1), (float)(v->d - 1)));
+}
+static inline f3 voxel_position(const kfo_volume* v, int x, int y, int z) /* BoundedVolume.h:115-125 */
+{
+    const f3 s = box_size(v);
+    return mk3(v->boxmin[0] + s.x * (float)x / (float)(v->w - 1),
+               v->boxmin[1] + s.y * (float)y / (float)(v->h - 1),
+               v->boxmin[2] + s.z * (float)z / (float)(v->d - 1));
+}
+
+static int pick_threads(int n)
+{
+#ifdef _OPENMP
+    if (n <= 0) n = omp_get_max_threads();
+    return n;
+#else
+    (void)n;
+    return 1;
+#endif
+}
+int kfo_max_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+/* ============================================================================
+ * BilateralFilter -- src/cu_bilateral.cu
+ * ========================================================================== */
+#define BILATERAL_BODY(TI, READ_MINVAL_TEST_P, READ_MINVAL_TEST_Q)                                \
+    const int W = (int)in->w, H = (int)in->h;                                                     \
+    const int nt = pick_threads(nthreads);                                                        \
+    (void)nt;                                                                                     \
+    _Pragma("omp parallel for num_threads(nt) schedule(static)")                                  \
+    for (int y = 0; y < (int)out->h; ++y) {                                                       \
+        for (int x = 0; x < (int)out->w; ++x) {                                                   \
+            const TI p = ((const TI*)img_row(in, (size_t)y))[x]; /* :21 / :67 */                  \
+            float sum = 0, sumw = 0;                                                              \
+            if (READ_MINVAL_TEST_P) {                                                             \
+                for (int r = -size; r <= size; ++r) {                                             \
+                    for (int c = -size; c <= size; ++c) {                                         \
+                        /* GetWithClampedRange, Image.h:297-303 */                                \
+                        const int qx = clampi(x + c, 0, W - 1), qy = clampi(y + r, 0, H - 1);     \
+                        const TI q = ((const TI*)img_row(in, (size_t)qy))[qx];                    \
+                        if (READ_MINVAL_TEST_Q) {                                                 \
+                            const float sd2 = (float)(r * r + c * c);                             \
+                            const float id = (float)(p - q);                                      \
+                            const float id2 = id * id;                                            \
+                            const float sw = expf(-(sd2) / (2 * gs * gs)); /* __expf, :31-32 */   \
+                            const float iw = expf(-(id2) / (2 * gr * gr));                        \
+                            const float w = sw * iw;                                              \
+                            sumw += w;                                                            \
+                            sum += w * (float)q;                                                  \
+                        }                                                                         \
+                    }                                                                             \
+                }                                                                                 \
+            }                                                                                     \
+            ((float*)img_row(out, (size_t)y))[x] = sum / sumw; /* 0/0 = NaN, :89-90 */            \
+        }                                                                                         \
+    }
+
+void kfo_bilateral_f32(const kfo_image* out, const kfo_image* in, float gs, float gr, int size,
+                       float minval, int use_minval, int nthreads)
+{
+    if (use_minval) { /* cu_bilateral.cu:59-92 */
+        BILATERAL_BODY(float, p >= minval, q >= minval)
+    } else { /* cu_bilateral.cu:13-41 */
+        BILATERAL_BODY(float, 1, 1)
+    }
+}
+void kfo_bilateral_u16(const kfo_image* out, const kfo_image* in, float gs, float gr, int size,
+                       unsigned short minval, int nthreads)
+{
+    BILATERAL_BODY(unsigned short, p >= minval, q >= minval) /* cu_bilateral.cu:59-92,104 */
+}
+void kfo_bilateral_u8(const kfo_image* out, const kfo_image* in, float gs, float gr, int size,
+                      int nthreads)
+{
+    BILATERAL_BODY(unsigned char, 1, 1) /* cu_bilateral.cu:13-41,53 */
+}
+
+/* ============================================================================
+ * DepthToVbo -- src/cu_depth_tools.cu:59-78 ; Unproject ImageIntrinsics.h:127-131
+ * ========================================================================== */
+void kfo_depth_to_vbo_f32(const kfo_image* vbo, const kfo_image* depth, const float K[4], float scale)
+{
+    for (size_t v = 0; v < vbo->h; ++v) {
+        const float* drow = (const float*)img_row(depth, v);
+        f4* orow = (f4*)img_row(vbo, v);
+        for (size_t u = 0; u < vbo->w; ++u) {
+            const float kz = scale * drow[u];
+            f4 P = {kz * ((float)(int)u - U0) / FU, kz * ((float)(int)v - V0) / FV, kz, 1.0f};
+            orow[u] = P;
+        }
+    }
+}
+void kfo_depth_to_vbo_u16(const kfo_image* vbo, const kfo_image* depth, const float K[4], float scale)
+{
+    for (size_t v = 0; v < vbo->h; ++v) {
+        const unsigned short* drow = (const unsigned short*)img_row(depth, v);
+        f4* orow = (f4*)img_row(vbo, v);
+        for (size_t u = 0; u < vbo->w; ++u) {
+            const float kz = scale * (float)drow[u];
+            f4 P = {kz * ((float)(int)u - U0) / FU, kz * ((float)(int)v - V0) / FV, kz, 1.0f};
+            orow[u] = P;
+        }
+    }
+}
+
+/* ============================================================================
+ * NormalsFromVbo -- src/cu_normals.cu:12-45
+ * ========================================================================== */
+void kfo_normals_from_vbo(const kfo_image* nrm, const kfo_image* vbo)
+{
+    const int W = (int)nrm->w, H = (int)nrm->h;
+    for (int v = 0; v < H; ++v) {
+        f4* orow = (f4*)img_row(nrm, (size_t)v);
+        for (int u = 0; u < W; ++u) {
+            if (u + 1 < W && v + 1 < H) {
+                const f4 Vc = ((const f4*)img_row(vbo, (size_t)v))[u];
+                const f4 Vr = ((const f4*)img_row(vbo, (size_t)v))[u + 1];
+                const f4 Vu = ((const f4*)img_row(vbo, (size_t)v + 1))[u];
+                const f3 a = {Vr.x - Vc.x, Vr.y - Vc.y, Vr.z - Vc.z};
+                const f3 b = {Vu.x - Vc.x, Vu.y - Vc.y, Vu.z - Vc.z};
+                const f3 axb = {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+                const float mag = length3(axb);
+                f4 N = {-axb.x / mag, -axb.y / mag, -axb.z / mag, 1.0f};
+                orow[u] = N;
+            } else {
+                f4 Z = {0, 0, 0, 0};
+                orow[u] = Z;
+            }
+        }
+    }
+}
+
+/* ============================================================================
+ * SdfReset / SdfSphere -- src/cu_sdffusion.cu:153-195
+ * ========================================================================== */
+void kfo_sdf_reset(const kfo_volume* vol, float trunc)
+{
+    /* thrust::fill(begin,end) over ptr .. RowPtr(h-1,d-1)+w: contiguous, includes
+     * the pitch padding (Volume.h:343-356). */
+    sdf_t* b = (sdf_t*)vol->ptr;
+    sdf_t* e = vol_row(vol, vol->h - 1, vol->d - 1) + vol->w;
+    const sdf_t v = {trunc, 0.0f};
+    for (; b < e; ++b) *b = v;
+}
+
+void kfo_sdf_sphere(const kfo_volume* vol, const float center[3], float r)
+{
+    /* grid is w/8,h/8,d/8 blocks of 8 (cu_sdffusion.cu:189-191) */
+    const int X = (int)(vol->w / 8) * 8, Y = (int)(vol->h / 8) * 8, Z = (int)(vol->d / 8) * 8;
+    const f3 c = {center[0], center[1], center[2]};
+    for (int z = 0; z < Z; ++z)
+        for (int y = 0; y < Y; ++y) {
+            sdf_t* row = vol_row(vol, (size_t)y, (size_t)z);
+            for (int x = 0; x < X; ++x) {
+                const f3 pos = voxel_position(vol, x, y, z);
+                const float dist = length3(sub3(pos, c));
+                sdf_t s = {dist - r, 1.0f}; /* SDF_t(float v): w = 1, Sdf.h:13 */
+                row[x] = s;
+            }
+        }
+}
+
+/* ============================================================================
+ * SdfFuse -- src/cu_sdffusion.cu:16-61
+ * ========================================================================== */
+static inline int fuse_voxel(const kfo_volume* vol, const kfo_image* depth, const kfo_image* normals,
+                             const float* T, const float* K, float trunc_dist, float max_w,
+                             float mincostheta, int x, int y, int z)
+{
+    const f3 P_w = voxel_position(vol, x, y, z);         /* :22 */
+    const f3 P_c = se3_mul(T, P_w);                       /* :23 */
+    /* K.Project, ImageIntrinsics.h:87-91 */
+    const float pu = U0 + FU * P_c.x / P_c.z;
+    const float pv = V0 + FV * P_c.y / P_c.z;
+    /* depth.InBounds(p_c, 2), Image.h:287-291 */
+    const float border = 2.0f;
+    if (!(border <= pu && pu < ((float)depth->w - border) && border <= pv &&
+          pv < ((float)depth->h - border)))
+        return 0;
+
+    const float vd = P_c.z;
+    /* GetBilinear, Image.h:317-334 (quirk Q6: floorf -> float -> size_t) */
+    const float ix = floorf(pu), iy = floorf(pv);
+    const float fx = pu - ix, fy = pv - iy;
+    const float* dbl = (const float*)img_row(depth, (size_t)iy) + (size_t)ix;
+    const float* dtl = (const float*)img_row(depth, (size_t)(iy + 1)) + (size_t)ix;
+    const float md = lerpf(lerpf(dbl[0], dbl[1], fx), lerpf(dtl[0], dtl[1], fx), fy);
+    const f4* nbl = (const f4*)img_row(normals, (size_t)iy) + (size_t)ix;
+    const f4* ntl = (const f4*)img_row(normals, (size_t)(iy + 1)) + (size_t)ix;
+    f3 mdn;
+    mdn.x = lerpf(lerpf(nbl[0].x, nbl[1].x, fx), lerpf(ntl[0].x, ntl[1].x, fx), fy);
+    mdn.y = lerpf(lerpf(nbl[0].y, nbl[1].y, fx), lerpf(ntl[0].y, ntl[1].y, fx), fy);
+    mdn.z = lerpf(lerpf(nbl[0].z, nbl[1].z, fx), lerpf(ntl[0].z, ntl[1].z, fx), fy);
+
+    const float costheta = dot3(mdn, P_c) / -length3(P_c); /* :35 */
+    const float sd = costheta * (md - vd);                 /* :36 */
+    const float w = costheta * 1.0f / vd;                  /* :37 */
+
+    if (sd <= -trunc_dist) return 0;                       /* :39-42 */
+    if (isfinite(md) && isfinite(w) && costheta > mincostheta) { /* :44 */
+        sdf_t* cell = &vol_row(vol, (size_t)y, (size_t)z)[x];
+        sdf_t s = {clampf(sd, -trunc_dist, trunc_dist), w}; /* :45 */
+        const sdf_t rhs = *cell;                            /* :46, Sdf.h:25-32 */
+        if (rhs.w > 0) {
+            s.val = (s.w * s.val + rhs.w * rhs.val);
+            s.w += rhs.w;
+            s.val /= s.w;
+        }
+        s.w = fminf(s.w, max_w); /* LimitWeight, Sdf.h:22-24 */
+        *cell = s;               /* :49 */
+        return 1;
+    }
+    return 0;
+}
+
+uint64_t kfo_sdf_fuse(const kfo_volume* vol, const kfo_image* depth, const kfo_image* norm,
+                      const float T_cw[12], const float K[4], float trunc, float max_w,
+                      float mincostheta, int full_extent, int nthreads)
+{
+    /* gridDim = (w/8, h/8, d/8), blockDim = (8,8,8): integer division, no tail (quirk Q1) */
+    const int X = full_extent ? (int)vol->w : (int)(vol->w / 8) * 8;
+    const int Y = full_extent ? (int)vol->h : (int)(vol->h / 8) * 8;
+    const int Z = full_extent ? (int)vol->d : (int)(vol->d / 8) * 8;
+    uint64_t updated = 0;
+    const int nt = pick_threads(nthreads);
+    (void)nt;
+#pragma omp parallel for num_threads(nt) schedule(static) reduction(+ : updated)
+    for (int z = 0; z < Z; ++z)
+        for (int y = 0; y < Y; ++y)
+            for (int x = 0; x < X; ++x)
+                updated += (uint64_t)fuse_voxel(vol, depth, norm, T_cw, K, trunc, max_w, mincostheta, x, y, z);
+    return updated;
+}
+
+/* ============================================================================
+ * RaycastSdf -- src/cu_raycast.cu:14-113
+ * ========================================================================== */
+static inline float phong_shade(f3 p_c, f3 n_c) /* cu_raycast.cu:14-28 */
+{
+    const float ambient = (float)0.4, diffuse = (float)0.4, specular = (float)0.2;
+    const f3 eyedir = div3s(scale3(p_c, -1.0f), length3(p_c));
+    const f3 _lightdir = {(float)0.4, (float)0.4, -1.0f};
+    const f3 lightdir = div3s(_lightdir, length3(_lightdir));
+    const float ldotn = dot3(lightdir, n_c);
+    const f3 lightreflect = add3(scale3(n_c, 2 * ldotn), scale3(lightdir, -1.0f));
+    const float edotr = fmaxf(0.0f, dot3(eyedir, lightreflect));
+    const float spec = edotr * edotr * edotr * edotr * edotr * edotr * edotr * edotr * edotr * edotr;
+    return ambient + diffuse * ldotn + specular * spec;
+}
+
+typedef struct {
+    uint8_t* bitmap;
+    const kfo_volume* vol;
+} touch_t;
+static inline void touch(touch_t* t, int x, int y, int z)
+{
+    if (t && t->bitmap) {
+        const size_t i = ((size_t)z * t->vol->h + (size_t)y) * t->vol->w + (size_t)x;
+        t->bitmap[i >> 3] |= (uint8_t)(1u << (i & 7));
+    }
+}
+
+/* BoundedVolume::GetUnitsTrilinearClamped (BoundedVolume.h:93-98) ->
+ * Volume::GetFractionalTrilinearClamped (Volume.h:224-250); quirk Q4: only the
+ * integer cell is clamped, the fraction extrapolates. */
+static inline float trilinear_clamped(const kfo_volume* v, f3 pos_w, touch_t* t)
+{
+    const f3 pos_v = div33(sub3(pos_w, box_min(v)), box_size(v));
+    const f3 pf = {pos_v.x * ((float)v->w - 1.f), pos_v.y * ((float)v->h - 1.f), pos_v.z * ((float)v->d - 1.f)};
+    const int ix = (int)fmaxf(fminf((float)(v->w - 2), floorf(pf.x)), 0);
+    const int iy = (int)fmaxf(fminf((float)(v->h - 2), floorf(pf.y)), 0);
+    const int iz = (int)fmaxf(fminf((float)(v->d - 2), floorf(pf.z)), 0);
+    const float fx = pf.x - (float)ix, fy = pf.y - (float)iy, fz = pf.z - (float)iz;
+    const float v0 = vol_val(v, ix, iy, iz), vx = vol_val(v, ix + 1, iy, iz);
+    const float vy = vol_val(v, ix, iy + 1, iz), vxy = vol_val(v, ix + 1, iy + 1, iz);
+    const float vz = vol_val(v, ix, iy, iz + 1), vxz = vol_val(v, ix + 1, iy, iz + 1);
+    const float vyz = vol_val(v, ix, iy + 1, iz + 1), vxyz = vol_val(v, ix + 1, iy + 1, iz + 1);
+    if (t && t->bitmap)
+        for (int c = 0; c < 8; ++c) touch(t, ix + (c & 1), iy + ((c >> 1) & 1), iz + (c >> 2));
+    return lerpf(lerpf(lerpf(v0, vx, fx), lerpf(vy, vxy, fx), fy),
+                 lerpf(lerpf(vz, vxz, fx), lerpf(vyz, vxyz, fx), fy), fz);
+}
+
+static inline f3 backward_diff(const kfo_volume* v, int x, int y, int z, touch_t* t) /* Volume.h:256-265 */
+{
+    const float v0 = vol_val(v, x, y, z);
+    if (t && t->bitmap) { touch(t, x, y, z); touch(t, x - 1, y, z); touch(t, x, y - 1, z); touch(t, x, y, z - 1); }
+    return mk3(v0 - vol_val(v, x - 1, y, z), v0 - vol_val(v, x, y - 1, z), v0 - vol_val(v, x, y, z - 1));
+}
+
+/* BoundedVolume::GetUnitsBackwardDiffDxDyDz (BoundedVolume.h:100-106) ->
+ * Volume::GetFractionalBackwardDiffDxDyDz (Volume.h:267-295) */
+static inline f3 units_backward_diff(const kfo_volume* v, f3 pos_w, touch_t* t)
+{
+    const f3 pos_v = div33(sub3(pos_w, box_min(v)), box_size(v));
+    const f3 pf = {pos_v.x * ((float)v->w - 1.f), pos_v.y * ((float)v->h - 1.f), pos_v.z * ((float)v->d - 1.f)};
+    const int ix = (int)fmaxf(fminf((float)(v->w - 2), floorf(pf.x)), 1);
+    const int iy = (int)fmaxf(fminf((float)(v->h - 2), floorf(pf.y)), 1);
+    const int iz = (int)fmaxf(fminf((float)(v->d - 2), floorf(pf.z)), 1);
+    const float fx = pf.x - (float)ix, fy = pf.y - (float)iy, fz = pf.z - (float)iz;
+    const f3 g0 = backward_diff(v, ix, iy, iz, t), gx = backward_diff(v, ix + 1, iy, iz, t);
+    const f3 gy = backward_diff(v, ix, iy + 1, iz, t), gxy = backward_diff(v, ix + 1, iy + 1, iz, t);
+    const f3 gz = backward_diff(v, ix, iy, iz + 1, t), gxz = backward_diff(v, ix + 1, iy, iz + 1, t);
+    const f3 gyz = backward_diff(v, ix, iy + 1, iz + 1, t), gxyz = backward_diff(v, ix + 1, iy + 1, iz + 1, t);
+    const f3 deriv = lerp3(lerp3(lerp3(g0, gx, fx), lerp3(gy, gxy, fx), fy),
+                           lerp3(lerp3(gz, gxz, fx), lerp3(gyz, gxyz, fx), fy), fz);
+    return div33(deriv, voxel_size_units(v));
+}
+
+static inline void raycast_pixel(const kfo_image* imgdepth, const kfo_image* norm, const kfo_image* img,
+                                 const kfo_volume* vol, const float* T, const float* K, float near,
+                                 float far, float trunc_dist, int subpix, int u, int v, touch_t* t,
+                                 uint64_t* n_rays, uint64_t* n_steps, uint64_t* n_hits)
+{
+    const f3 c_w = se3_translation(T);                               /* :40 */
+    const f3 ray_c = unproject1(K, (float)u, (float)v);              /* :41 */
+    const f3 ray_w = so3_mul(T, ray_c);                              /* :42 */
+
+    const f3 tminbound = div33(sub3(box_min(vol), c_w), ray_w);      /* :46 */
+    const f3 tmaxbound = div33(sub3(box_max(vol), c_w), ray_w);      /* :47 */
+    const f3 tmin = {fminf(tminbound.x, tmaxbound.x), fminf(tminbound.y, tmaxbound.y), fminf(tminbound.z, tmaxbound.z)};
+    const f3 tmax = {fmaxf(tminbound.x, tmaxbound.x), fmaxf(tminbound.y, tmaxbound.y), fmaxf(tminbound.z, tmaxbound.z)};
+    const float max_tmin = fmaxf(fmaxf(fmaxf(tmin.x, tmin.y), tmin.z), near); /* :50 */
+    const float min_tmax = fminf(fminf(fminf(tmax.x, tmax.y), tmax.z), far);  /* :51 */
+
+    float depth = 0.0f;
+    if (max_tmin < min_tmax) {                                       /* :56 */
+        float lambda = max_tmin;
+        float last_sdf = NAN;                                        /* InvalidValue<float>, :59 */
+        const float min_delta_lambda = voxel_size_units(vol).x;      /* :60 */
+        float delta_lambda = 0;
+        ++*n_rays;
+        while (lambda < min_tmax) {                                  /* :64 */
+            const f3 pos_w = add3(c_w, scale3(ray_w, lambda));
+            const float sdf = trilinear_clamped(vol, pos_w, t);
+            ++*n_steps;
+            if (sdf <= 0) {                                          /* :68 */
+                if (last_sdf > 0) {
+                    if (subpix) lambda = lambda + delta_lambda * sdf / (last_sdf - sdf); /* :72 */
+                    depth = lambda;
+                }
+                break;
+            }
+            delta_lambda = sdf > 0 ? fmaxf(sdf, min_delta_lambda) : trunc_dist; /* :78 */
+            lambda += delta_lambda;
+            last_sdf = sdf;
+        }
+    }
+
+    float* pd = &((float*)img_row(imgdepth, (size_t)v))[u];
+    float* pi = &((float*)img_row(img, (size_t)v))[u];
+    f4* pn = &((f4*)img_row(norm, (size_t)v))[u];
+    if (depth > 0) {                                                 /* :92 */
+        const f3 pos_w = add3(c_w, scale3(ray_w, depth));            /* :85 */
+        const f3 _n_w = units_backward_diff(vol, pos_w, t);          /* :86 */
+        const float len_n_w = length3(_n_w);
+        const f3 n_w = len_n_w > 0 ? div3s(_n_w, len_n_w) : mk3(0, 0, 1); /* :88 */
+        const f3 n_c = so3_mul_inv(T, n_w);                          /* :89 */
+        const f3 p_c = scale3(ray_c, depth);                         /* :90 */
+        *pd = depth;
+        *pi = phong_shade(p_c, n_c);
+        f4 N = {n_c.x, n_c.y, n_c.z, 1.0f};
+        *pn = N;
+        ++*n_hits;
+    } else { /* the reference evaluates the normal here too, but discards it (:85-102) */
+        *pd = NAN;
+        *pi = 0;
+        f4 Z = {0, 0, 0, 0};
+        *pn = Z;
+    }
+}
+
+void kfo_raycast_sdf(const kfo_image* depth, const kfo_image* norm, const kfo_image* img,
+                     const kfo_volume* vol, const float T_wc[12], const float K[4], float near,
+                     float far, float trunc, int subpix, int nthreads, kfo_raycast_stats* stats)
+{
+    uint64_t rays = 0, steps = 0, hits = 0;
+    const int nt = pick_threads(nthreads);
+    (void)nt;
+#pragma omp parallel for num_threads(nt) schedule(dynamic, 4) reduction(+ : rays, steps, hits)
+    for (int v = 0; v < (int)img->h; ++v)
+        for (int u = 0; u < (int)img->w; ++u)
+            raycast_pixel(depth, norm, img, vol, T_wc, K, near, far, trunc, subpix, u, v, NULL, &rays, &steps, &hits);
+    if (stats) { stats->rays = rays; stats->steps = steps; stats->hits = hits; }
+}
+
+void kfo_raycast_sdf_touch(const kfo_image* depth, const kfo_image* norm, const kfo_image* img,
+                           const kfo_volume* vol, const float T_wc[12], const float K[4], float near,
+                           float far, float trunc, int subpix, uint8_t* bitmap, kfo_raycast_stats* stats)
+{
+    uint64_t rays = 0, steps = 0, hits = 0;
+    touch_t t = {bitmap, vol};
+    for (int v = 0; v < (int)img->h; ++v)
+        for (int u = 0; u < (int)img->w; ++u)
+            raycast_pixel(depth, norm, img, vol, T_wc, K, near, far, trunc, subpix, u, v, &t, &rays, &steps, &hits);
+    if (stats) { stats->rays = rays; stats->steps = steps; stats->hits = hits; }
+}
+
+/* ============================================================================
+ * Analytic renderers -- src/cu_raycast.cu:202-310
+ * ========================================================================== */
+void kfo_raycast_box(const kfo_image* imgd, const float T[12], const float K[4], const float bmin[3],
+                     const float bmax[3])
+{
+    const f3 lo = {bmin[0], bmin[1], bmin[2]}, hi = {bmax[0], bmax[1], bmax[2]};
+    for (int v = 0; v < (int)imgd->h; ++v)
+        for (int u = 0; u < (int)imgd->w; ++u) {
+            const f3 c_w = se3_translation(T);
+            const f3 ray_w = so3_mul(T, unproject1(K, (float)u, (float)v));
+            const f3 a = div33(sub3(lo, c_w), ray_w), b = div33(sub3(hi, c_w), ray_w);
+            const f3 tmin = {fminf(a.x, b.x), fminf(a.y, b.y), fminf(a.z, b.z)};
+            const f3 tmax = {fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z)};
+            const float max_tmin = fmaxf(fmaxf(tmin.x, tmin.y), tmin.z);
+            const float min_tmax = fminf(fminf(tmax.x, tmax.y), tmax.z);
+            ((float*)img_row(imgd, (size_t)v))[u] = (max_tmin < min_tmax) ? max_tmin : NAN;
+        }
+}
+
+void kfo_raycast_sphere(const kfo_image* imgd, const kfo_image* img, const float T[12], const float K[4],
+                        const float center[3], float r)
+{
+    const f3 center_c = se3_mul_inv(T, mk3(center[0], center[1], center[2])); /* :276 */
+    for (int v = 0; v < (int)imgd->h; ++v)
+        for (int u = 0; u < (int)imgd->w; ++u) {
+            const f3 ray_c = unproject1(K, (float)u, (float)v);
+            const float ldotc = dot3(ray_c, center_c);
+            const float lsq = dot3(ray_c, ray_c);
+            const float csq = dot3(center_c, center_c);
+            /* `sqrt` of a float argument: the float overload in device code (:256) */
+            const float depth = (ldotc - sqrtf(ldotc * ldotc - lsq * (csq - r * r))) / lsq;
+            float* pd = &((float*)img_row(imgd, (size_t)v))[u];
+            const float prev = *pd;
+            if (depth > 0 && (depth < prev || !isfinite(prev))) {
+                *pd = depth;
+                if (img && img->ptr) {
+                    const f3 p_c = scale3(ray_c, depth);
+                    const f3 n_c = sub3(p_c, center_c);
+                    ((float*)img_row(img, (size_t)v))[u] = phong_shade(p_c, div3s(n_c, length3(n_c)));
+                }
+            }
+        }
+}
+
+void kfo_raycast_plane(const kfo_image* imgd, const kfo_image* img, const float T[12], const float K[4],
+                       const float n_w[3])
+{
+    /* Plane_b_from_a, MatUtils.h:474-488 */
+    const float dn = T_(0, 3) * n_w[0] + T_(1, 3) * n_w[1] + T_(2, 3) * n_w[2] + 1.0f;
+    const f3 n_c = {(T_(0, 0) * n_w[0] + T_(1, 0) * n_w[1] + T_(2, 0) * n_w[2]) / dn,
+                    (T_(0, 1) * n_w[0] + T_(1, 1) * n_w[1] + T_(2, 1) * n_w[2]) / dn,
+                    (T_(0, 2) * n_w[0] + T_(1, 2) * n_w[1] + T_(2, 2) * n_w[2]) / dn};
+    for (int v = 0; v < (int)imgd->h; ++v)
+        for (int u = 0; u < (int)imgd->w; ++u) {
+            const f3 ray_c = unproject1(K, (float)u, (float)v);
+            const float depth = -1 / dot3(n_c, ray_c);
+            float* pd = &((float*)img_row(imgd, (size_t)v))[u];
+            const float prev = *pd;
+            if (depth > 0 && (depth < prev || !isfinite(prev))) {
+                if (img && img->ptr) {
+                    const f3 p_c = scale3(ray_c, depth);
+                    ((float*)img_row(img, (size_t)v))[u] = phong_shade(p_c, div3s(n_c, length3(n_c)));
+                }
+                *pd = depth;
+            }
+        }
+}
+
+/* ============================================================================
+ * Synthetic scenes of SURVEY 8(d) (own code, not reference)
+ * ========================================================================== */
+void kfo_render_scene(const kfo_image* depth, int scene, const float T[12], const float K[4])
+{
+    for (int v = 0; v < (int)depth->h; ++v)
+        for (int u = 0; u < (int)depth->w; ++u) {
+            const f3 c = se3_translation(T);
+            const f3 r = so3_mul(T, unproject1(K, (float)u, (float)v));
+            float best = INFINITY;
+            if (scene == 0) {
+                /* room: exit distance from box x,y in [-0.9,0.9], z in [-10,3.8] */
+                const f3 lo = {-0.9f, -0.9f, -10.0f}, hi = {0.9f, 0.9f, 3.8f};
+                const f3 a = div33(sub3(lo, c), r), b = div33(sub3(hi, c), r);
+                const float tx = fmaxf(a.x, b.x), ty = fmaxf(a.y, b.y), tz = fmaxf(a.z, b.z);
+                const float texit = fminf(fminf(tx, ty), tz);
+                if (texit > 0) best = texit;
+                /* sphere c=(0,0,3) r=0.5 */
+                const f3 sc = {0.0f, 0.0f, 3.0f};
+                const f3 oc = sub3(sc, c);
+                const float ldotc = dot3(r, oc), lsq = dot3(r, r), csq = dot3(oc, oc);
+                const float disc = ldotc * ldotc - lsq * (csq - 0.5f * 0.5f);
+                if (disc >= 0) {
+                    const float ts = (ldotc - sqrtf(disc)) / lsq;
+                    if (ts > 0 && ts < best) best = ts;
+                }
+            } else {
+                /* wall z = 5.95 */
+                const float t = (5.95f - c.z) / r.z;
+                if (t > 0) best = t;
+            }
+            ((float*)img_row(depth, (size_t)v))[u] = isfinite(best) ? best : NAN;
+        }
+}
+
+/* ============================================================================
+ * Host-side ROI helpers
+ * ========================================================================== */
+void kfo_fit_to_frustum(float bmin[3], float bmax[3], const float T[12], float w, float h,
+                        const float K[4], float near, float far) /* BoundingBox.h:72-96 */
+{
+    const f3 c_w = se3_translation(T);
+    const f3 rays[4] = {so3_mul(T, mk3((0 - U0) / FU, (0 - V0) / FV, 1)), so3_mul(T, mk3((w - U0) / FU, (0 - V0) / FV, 1)),
+                        so3_mul(T, mk3((0 - U0) / FU, (h - V0) / FV, 1)), so3_mul(T, mk3((w - U0) / FU, (h - V0) / FV, 1))};
+    f3 lo = {3.402823466e+38f, 3.402823466e+38f, 3.402823466e+38f};
+    f3 hi = {-3.402823466e+38f, -3.402823466e+38f, -3.402823466e+38f};
+    const float ds[2] = {near, far};
+    for (int k = 0; k < 2; ++k)
+        for (int i = 0; i < 4; ++i) {
+            const f3 p = add3(c_w, scale3(rays[i], ds[k]));
+            hi = mk3(fmaxf(p.x, hi.x), fmaxf(p.y, hi.y), fmaxf(p.z, hi.z));
+            lo = mk3(fminf(p.x, lo.x), fminf(p.y, lo.y), fminf(p.z, lo.z));
+        }
+    bmin[0] = lo.x; bmin[1] = lo.y; bmin[2] = lo.z;
+    bmax[0] = hi.x; bmax[1] = hi.y; bmax[2] = hi.z;
+}
+
+void kfo_sub_bounding_volume(kfo_volume* out, const kfo_volume* vol, const float rmin[3],
+                             const float rmax[3]) /* BoundedVolume.h:137-165 */
+{
+    const f3 bs = box_size(vol);
+    const f3 min_fv = div33(sub3(mk3(rmin[0], rmin[1], rmin[2]), box_min(vol)), bs);
+    const f3 max_fv = div33(sub3(mk3(rmax[0], rmax[1], rmax[2]), box_min(vol)), bs);
+    const float W1 = (float)(vol->w - 1), H1 = (float)(vol->h - 1), D1 = (float)(vol->d - 1);
+    const int min_v[3] = {(int)fmaxf(W1 * min_fv.x, 0), (int)fmaxf(H1 * min_fv.y, 0), (int)fmaxf(D1 * min_fv.z, 0)};
+    const int max_v[3] = {(int)fminf(ceilf(W1 * max_fv.x), W1), (int)fminf(ceilf(H1 * max_fv.y), H1),
+                          (int)fminf(ceilf(D1 * max_fv.z), D1)};
+    int size_v[3];
+    for (int i = 0; i < 3; ++i) {
+        size_v[i] = (max_v[i] - min_v[i]) + 1;
+        if (size_v[i] < 0) size_v[i] = 0;
+    }
+    const f3 nlo = voxel_position(vol, min_v[0], min_v[1], min_v[2]);
+    const f3 nhi = voxel_position(vol, max_v[0], max_v[1], max_v[2]);
+    /* Volume::SubVolume (Volume.h:305-311): same pitches, offset pointer */
+    out->pitch = vol->pitch;
+    out->img_pitch = vol->img_pitch;
+    out->ptr = (void*)&vol_row(vol, (size_t)min_v[1], (size_t)min_v[2])[min_v[0]];
+    out->w = (size_t)size_v[0];
+    out->h = (size_t)size_v[1];
+    out->d = (size_t)size_v[2];
+    out->boxmin[0] = nlo.x; out->boxmin[1] = nlo.y; out->boxmin[2] = nlo.z;
+    out->boxmax[0] = nhi.x; out->boxmax[1] = nhi.y; out->boxmax[2] = nhi.z;
+}

@@ -1,0 +1,123 @@
+/*
+ * kfx_oracle.h -- CPU restatement of the KinectFusion volumetric hot path of
+ * arpg/Kangaroo.  TEST INFRASTRUCTURE ONLY.
+ *
+ * This is the parity oracle: a plain-C, IEEE-fp32, no-FMA restatement of the
+ * reference's algorithm, each function citing the reference file:line it
+ * follows (paths relative to the reference tree).  Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it; the
+ * product (kangaroo_amd/, include/) never links, imports or calls it.
+ *
+ * Pinning status: the reference ships no tests / golden vectors for this path
+ * (SURVEY.md section 4).  The helper arithmetic is pinned against the
+ * reference's own headers compiled in place (oracle/_ref, see
+ * oracle/ref_harness.cpp); the CUDA kernels themselves (*.cu) need nvcc and
+ * are unbuildable here, so the kernel-level control flow is restated by
+ * reading and is otherwise "parity unpinned".  See DESIGN.md section 3.
+ *
+ * Semantics: CUDA *device* semantics for fminf/fmaxf (IEEE minNum/maxNum, C99
+ * fminf/fmaxf) -- the reference's host fallbacks in cutil_math.h:55-63 are
+ * ternaries and differ only when an operand is NaN.
+ */
+#ifndef KFX_ORACLE_H
+#define KFX_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Same field order as roo::Image (include/kangaroo/Image.h:617-620). */
+typedef struct kfo_image {
+    size_t pitch; /* bytes per row */
+    void*  ptr;
+    size_t w;
+    size_t h;
+} kfo_image;
+
+/* Same field order as roo::BoundedVolume (Volume.h:363-369 + BoundedVolume.h:168,
+ * BoundingBox.h:163-164). Element = SDF_t {float val; float w;} (Sdf.h:34-35). */
+typedef struct kfo_volume {
+    size_t pitch;     /* bytes per x-row */
+    void*  ptr;
+    size_t w;
+    size_t h;
+    size_t img_pitch; /* bytes per z-slice */
+    size_t d;
+    float  boxmin[3];
+    float  boxmax[3];
+} kfo_volume;
+
+typedef struct kfo_raycast_stats {
+    uint64_t rays;        /* rays whose segment intersects the box */
+    uint64_t steps;       /* total trilinear samples taken */
+    uint64_t hits;        /* rays with depth > 0 */
+} kfo_raycast_stats;
+
+/* cu_bilateral.cu:13-41 (use_minval=0) and :59-92 (use_minval=1), <float,float> */
+void kfo_bilateral_f32(const kfo_image* out, const kfo_image* in, float gs, float gr,
+                       int size, float minval, int use_minval, int nthreads);
+/* cu_bilateral.cu:59-92 <float,unsigned short> */
+void kfo_bilateral_u16(const kfo_image* out, const kfo_image* in, float gs, float gr,
+                       int size, unsigned short minval, int nthreads);
+/* cu_bilateral.cu:13-41 <float,unsigned char> */
+void kfo_bilateral_u8(const kfo_image* out, const kfo_image* in, float gs, float gr,
+                      int size, int nthreads);
+/* cu_depth_tools.cu:59-78 <float> / <unsigned short> */
+void kfo_depth_to_vbo_f32(const kfo_image* vbo, const kfo_image* depth, const float K[4], float scale);
+void kfo_depth_to_vbo_u16(const kfo_image* vbo, const kfo_image* depth, const float K[4], float scale);
+/* cu_normals.cu:12-45 */
+void kfo_normals_from_vbo(const kfo_image* nrm, const kfo_image* vbo);
+/* cu_sdffusion.cu:153-164 (Volume.h:343-356: contiguous span incl. pitch padding) */
+void kfo_sdf_reset(const kfo_volume* vol, float trunc);
+/* cu_sdffusion.cu:175-195 */
+void kfo_sdf_sphere(const kfo_volume* vol, const float center[3], float r);
+/* cu_sdffusion.cu:16-61. full_extent=0 reproduces the reference's w/8,h/8,d/8
+ * integer-division grid (quirk Q1); returns number of voxels updated. */
+uint64_t kfo_sdf_fuse(const kfo_volume* vol, const kfo_image* depth, const kfo_image* norm,
+                      const float T_cw[12], const float K[4], float trunc, float max_w,
+                      float mincostheta, int full_extent, int nthreads);
+/* cu_raycast.cu:14-113 */
+void kfo_raycast_sdf(const kfo_image* depth, const kfo_image* norm, const kfo_image* img,
+                     const kfo_volume* vol, const float T_wc[12], const float K[4],
+                     float near, float far, float trunc, int subpix, int nthreads,
+                     kfo_raycast_stats* stats);
+/* Like kfo_raycast_sdf but also marks every distinct voxel the rays touch
+ * (trilinear corners + normal stencil) in `bitmap` (1 bit per voxel, index
+ * (z*h + y)*w + x), for the algorithmic-bytes figure of SURVEY 8(d). */
+void kfo_raycast_sdf_touch(const kfo_image* depth, const kfo_image* norm, const kfo_image* img,
+                           const kfo_volume* vol, const float T_wc[12], const float K[4],
+                           float near, float far, float trunc, int subpix,
+                           uint8_t* bitmap, kfo_raycast_stats* stats);
+
+/* Analytic depth renderers, cu_raycast.cu:202-310 */
+void kfo_raycast_box(const kfo_image* depth, const float T_wc[12], const float K[4],
+                     const float boxmin[3], const float boxmax[3]);
+void kfo_raycast_sphere(const kfo_image* depth, const kfo_image* img /* may have ptr NULL */,
+                        const float T_wc[12], const float K[4], const float center[3], float r);
+void kfo_raycast_plane(const kfo_image* depth, const kfo_image* img, const float T_wc[12],
+                       const float K[4], const float n_w[3]);
+
+/* Synthetic scenes of SURVEY 8(d) (not reference code): depth in metres, NaN = invalid.
+ * scene 0 = S_room (box interior x,y in +-0.9, back wall z=3.8, sphere c=(0,0,3) r=0.5),
+ * scene 1 = S_full (flat wall z = 5.95). Rays are cast from pose T_wc (camera->world). */
+void kfo_render_scene(const kfo_image* depth, int scene, const float T_wc[12], const float K[4]);
+
+/* BoundedVolume::SubBoundingVolume (BoundedVolume.h:137-165) and
+ * BoundingBox::FitToFrustum (BoundingBox.h:72-96): host-side ROI helpers. */
+void kfo_fit_to_frustum(float boxmin[3], float boxmax[3], const float T_wc[12], float w, float h,
+                        const float K[4], float near, float far);
+void kfo_sub_bounding_volume(kfo_volume* out, const kfo_volume* vol, const float rmin[3],
+                             const float rmax[3]);
+
+/* SE3inv (MatUtils.h:202-214) */
+void kfo_se3_inverse(float out[12], const float T[12]);
+
+int kfo_max_threads(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,259 @@
+// ref_harness.cpp -- drives the REFERENCE'S OWN header code on the CPU.
+// TEST INFRASTRUCTURE ONLY (built by `make -C oracle ref` into oracle/_ref/).
+//
+// What this is: the reference keeps most of the hot path's arithmetic in
+// __host__ __device__ header methods: voxel positions,
+// SE3 products, pinhole projection, bounds tests, bilinear / trilinear sampling,
+// backward-difference gradients, the SDF_t running average, the ROI helpers.
+// Those headers are ordinary C++ once <cuda_runtime.h> resolves (the genuine CUDA
+// 12.8 headers ship inside this image's triton wheel) and kangaroo/config.h
+// exists (generated from the reference's config.h.in by gen_ref_config.cmake).
+// This file #includes them where they lie under /root/reference -- nothing is
+// copied -- and exposes them through a C ABI that takes the same POD structs as
+// oracle/kfx_oracle.h, so tests can demand bit-equality between the plain-C
+// restatement and the reference's compiled code.
+//
+// What this is NOT: the __global__ kernels in src/cu_*.cu need nvcc (absent) and
+// are not built.  The per-element drivers below are this repo's own loops; every
+// arithmetic step inside them is a call into reference code.  Host fminf/fmaxf
+// are the reference's ternary fallbacks (CUDA_SDK/cutil_math.h:55-63): identical
+// to device semantics unless an operand is NaN.
+#include <kangaroo/BoundedVolume.h>
+#include <kangaroo/Image.h>
+#include <kangaroo/ImageIntrinsics.h>
+#include <kangaroo/InvalidValue.h>
+#include <kangaroo/MatUtils.h>
+#include <kangaroo/Sdf.h>
+
+#include "kfx_oracle.h"
+
+using namespace roo;
+
+typedef Image<float, TargetHost, DontManage> HImgF;
+typedef Image<float4, TargetHost, DontManage> HImgF4;
+typedef BoundedVolume<SDF_t, TargetHost, DontManage> HVol;
+
+static HImgF imf(const kfo_image* p) { return HImgF((float*)p->ptr, p->w, p->h, p->pitch); }
+static HImgF4 imf4(const kfo_image* p) { return HImgF4((float4*)p->ptr, p->w, p->h, p->pitch); }
+static HVol mkvol(const kfo_volume* p)
+{
+    Volume<SDF_t, TargetHost, DontManage> v((SDF_t*)p->ptr, p->w, p->h, p->d, p->pitch, p->img_pitch);
+    return HVol(v, BoundingBox(make_float3(p->boxmin[0], p->boxmin[1], p->boxmin[2]),
+                               make_float3(p->boxmax[0], p->boxmax[1], p->boxmax[2])));
+}
+static Mat<float, 3, 4> mkT(const float* t)
+{
+    Mat<float, 3, 4> T;
+    for (int i = 0; i < 12; ++i) T.m[i] = t[i];
+    return T;
+}
+static ImageIntrinsics mkK(const float* k) { return ImageIntrinsics(k[0], k[1], k[2], k[3]); }
+
+extern "C" {
+
+// layouts the C-ABI mirrors
+void ref_sizeof(size_t out[8])
+{
+    out[0] = sizeof(Image<float>);
+    out[1] = sizeof(Volume<SDF_t>);
+    out[2] = sizeof(BoundedVolume<SDF_t>);
+    out[3] = sizeof(SDF_t);
+    out[4] = sizeof(Mat<float, 3, 4>);
+    out[5] = sizeof(ImageIntrinsics);
+    out[6] = sizeof(BoundingBox);
+    out[7] = sizeof(float4);
+}
+
+void ref_voxel_position(const kfo_volume* v, int x, int y, int z, float out[3])
+{
+    const float3 p = mkvol(v).VoxelPositionInUnits(x, y, z);
+    out[0] = p.x; out[1] = p.y; out[2] = p.z;
+}
+
+void ref_voxel_size(const kfo_volume* v, float out[3])
+{
+    const float3 p = mkvol(v).VoxelSizeUnits();
+    out[0] = p.x; out[1] = p.y; out[2] = p.z;
+}
+
+// Per-voxel TSDF integration, every step a reference header call:
+// VoxelPositionInUnits, Mat*float3, Project, InBounds, GetBilinear, dot, length,
+// clamp, SDF_t::operator+=, LimitWeight.
+uint64_t ref_sdf_fuse(const kfo_volume* pv, const kfo_image* pd, const kfo_image* pn, const float* t,
+                      const float* k, float trunc_dist, float max_w, float mincostheta, int full_extent)
+{
+    HVol vol = mkvol(pv);
+    HImgF depth = imf(pd);
+    HImgF4 normals = imf4(pn);
+    const Mat<float, 3, 4> T_cw = mkT(t);
+    const ImageIntrinsics K = mkK(k);
+    const int X = full_extent ? (int)vol.w : (int)(vol.w / 8) * 8;
+    const int Y = full_extent ? (int)vol.h : (int)(vol.h / 8) * 8;
+    const int Z = full_extent ? (int)vol.d : (int)(vol.d / 8) * 8;
+    uint64_t n = 0;
+    for (int z = 0; z < Z; ++z)
+        for (int y = 0; y < Y; ++y)
+            for (int x = 0; x < X; ++x) {
+                const float3 P_c = T_cw * vol.VoxelPositionInUnits(x, y, z);
+                const float2 p_c = K.Project(P_c);
+                if (!depth.InBounds(p_c, 2)) continue;
+                const float md = depth.GetBilinear<float>(p_c);
+                const float3 mdn = make_float3(normals.GetBilinear<float4>(p_c));
+                const float costheta = dot(mdn, P_c) / -length(P_c);
+                const float sd = costheta * (md - P_c.z);
+                const float w = costheta * 1.0f / P_c.z;
+                if (sd <= -trunc_dist) continue;
+                if (std::isfinite(md) && std::isfinite(w) && costheta > mincostheta) {
+                    SDF_t s(clamp(sd, -trunc_dist, trunc_dist), w);
+                    s += vol(x, y, z);
+                    s.LimitWeight(max_w);
+                    vol(x, y, z) = s;
+                    ++n;
+                }
+            }
+    return n;
+}
+
+// Trilinear sample and gradient at a world position (BoundedVolume.h:93-106)
+float ref_trilinear(const kfo_volume* pv, const float pos[3])
+{
+    return mkvol(pv).GetUnitsTrilinearClamped(make_float3(pos[0], pos[1], pos[2]));
+}
+void ref_backward_diff(const kfo_volume* pv, const float pos[3], float out[3])
+{
+    const float3 g = mkvol(pv).GetUnitsBackwardDiffDxDyDz(make_float3(pos[0], pos[1], pos[2]));
+    out[0] = g.x; out[1] = g.y; out[2] = g.z;
+}
+
+// Ray march with the reference's samplers.  Outputs depth (0 = miss) and the
+// camera-frame normal; shading (PhongShade lives in the .cu) is not covered.
+void ref_raycast_geom(const kfo_image* pdepth, const kfo_image* pnorm, const kfo_volume* pv, const float* t,
+                      const float* k, float near, float far, float trunc_dist, int subpix)
+{
+    HVol vol = mkvol(pv);
+    HImgF imgdepth = imf(pdepth);
+    HImgF4 norm = imf4(pnorm);
+    const Mat<float, 3, 4> T_wc = mkT(t);
+    const ImageIntrinsics K = mkK(k);
+    for (int v = 0; v < (int)imgdepth.h; ++v)
+        for (int u = 0; u < (int)imgdepth.w; ++u) {
+            const float3 c_w = SE3Translation(T_wc);
+            const float3 ray_c = K.Unproject(u, v);
+            const float3 ray_w = mulSO3(T_wc, ray_c);
+            const float3 ta = (vol.bbox.Min() - c_w) / ray_w;
+            const float3 tb = (vol.bbox.Max() - c_w) / ray_w;
+            const float3 tmin = fminf(ta, tb);
+            const float3 tmax = fmaxf(ta, tb);
+            const float max_tmin = fmaxf(fmaxf(fmaxf(tmin.x, tmin.y), tmin.z), near);
+            const float min_tmax = fminf(fminf(fminf(tmax.x, tmax.y), tmax.z), far);
+            float depth = 0.0f;
+            if (max_tmin < min_tmax) {
+                float lambda = max_tmin;
+                float last_sdf = InvalidValue<float>::Value();
+                const float min_step = vol.VoxelSizeUnits().x;
+                float step = 0;
+                while (lambda < min_tmax) {
+                    const float sdf = vol.GetUnitsTrilinearClamped(c_w + lambda * ray_w);
+                    if (sdf <= 0) {
+                        if (last_sdf > 0) {
+                            if (subpix) lambda = lambda + step * sdf / (last_sdf - sdf);
+                            depth = lambda;
+                        }
+                        break;
+                    }
+                    step = sdf > 0 ? fmaxf(sdf, min_step) : trunc_dist;
+                    lambda += step;
+                    last_sdf = sdf;
+                }
+            }
+            if (depth > 0) {
+                const float3 g = vol.GetUnitsBackwardDiffDxDyDz(c_w + depth * ray_w);
+                const float len = length(g);
+                const float3 n_w = len > 0 ? g / len : make_float3(0, 0, 1);
+                imgdepth(u, v) = depth;
+                norm(u, v) = make_float4(mulSO3inv(T_wc, n_w), 1);
+            } else {
+                imgdepth(u, v) = InvalidValue<float>::Value();
+                norm(u, v) = make_float4(0, 0, 0, 0);
+            }
+        }
+}
+
+void ref_depth_to_vbo(const kfo_image* pvbo, const kfo_image* pd, const float* k, float scale)
+{
+    HImgF4 vbo = imf4(pvbo);
+    HImgF d = imf(pd);
+    const ImageIntrinsics K = mkK(k);
+    for (int v = 0; v < (int)vbo.h; ++v)
+        for (int u = 0; u < (int)vbo.w; ++u) {
+            const float3 P = K.Unproject(u, v, scale * d(u, v));
+            vbo(u, v) = make_float4(P.x, P.y, P.z, 1);
+        }
+}
+
+// Bilateral weights use expf here (the reference's __expf is a device intrinsic).
+void ref_bilateral_f32(const kfo_image* pout, const kfo_image* pin, float gs, float gr, int size,
+                       float minval, int use_minval)
+{
+    HImgF out = imf(pout);
+    HImgF in = imf(pin);
+    for (unsigned y = 0; y < out.h; ++y)
+        for (unsigned x = 0; x < out.w; ++x) {
+            if (!out.InBounds((int)x, (int)y)) continue;
+            const float p = in(x, y);
+            float sum = 0, sumw = 0;
+            if (!use_minval || p >= minval)
+                for (int r = -size; r <= size; ++r)
+                    for (int c = -size; c <= size; ++c) {
+                        const float q = in.GetWithClampedRange(x + c, y + r);
+                        if (use_minval && !(q >= minval)) continue;
+                        const float sd2 = r * r + c * c;
+                        const float id = p - q;
+                        const float w = expf(-(sd2) / (2 * gs * gs)) * expf(-(id * id) / (2 * gr * gr));
+                        sumw += w;
+                        sum += w * q;
+                    }
+            out(x, y) = sum / sumw;
+        }
+}
+
+void ref_fit_to_frustum(float lo[3], float hi[3], const float* t, float w, float h, const float* k,
+                        float near, float far)
+{
+    BoundingBox bb(mkT(t), w, h, mkK(k), near, far);
+    lo[0] = bb.Min().x; lo[1] = bb.Min().y; lo[2] = bb.Min().z;
+    hi[0] = bb.Max().x; hi[1] = bb.Max().y; hi[2] = bb.Max().z;
+}
+
+void ref_sub_bounding_volume(kfo_volume* out, const kfo_volume* pv, const float rmin[3], const float rmax[3])
+{
+    HVol vol = mkvol(pv);
+    HVol s = vol.SubBoundingVolume(BoundingBox(make_float3(rmin[0], rmin[1], rmin[2]),
+                                               make_float3(rmax[0], rmax[1], rmax[2])));
+    out->pitch = s.pitch; out->ptr = s.ptr; out->w = s.w; out->h = s.h;
+    out->img_pitch = s.img_pitch; out->d = s.d;
+    out->boxmin[0] = s.bbox.Min().x; out->boxmin[1] = s.bbox.Min().y; out->boxmin[2] = s.bbox.Min().z;
+    out->boxmax[0] = s.bbox.Max().x; out->boxmax[1] = s.bbox.Max().y; out->boxmax[2] = s.bbox.Max().z;
+}
+
+void ref_se3_inverse(float o[12], const float* t)
+{
+    const Mat<float, 3, 4> r = SE3inv(mkT(t));
+    for (int i = 0; i < 12; ++i) o[i] = r.m[i];
+}
+
+void ref_intrinsics_level(float o[4], const float* k, int level)
+{
+    const ImageIntrinsics r = mkK(k)[level];
+    o[0] = r.fu; o[1] = r.fv; o[2] = r.u0; o[3] = r.v0;
+}
+
+void ref_sdf_accumulate(float val, float w, float old_val, float old_w, float max_w, float out[2])
+{
+    SDF_t s(val, w);
+    s += SDF_t(old_val, old_w);
+    s.LimitWeight(max_w);
+    out[0] = s.val; out[1] = s.w;
+}
+
+} // extern "C"
