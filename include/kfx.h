@@ -1,0 +1,159 @@
+/*
+ * kfx.h -- C ABI of libkfx: the MI355X (gfx950) KinectFusion volumetric path.
+ *
+ * This is the drop-in boundary for the hot path of arpg/Kangaroo
+ * (BilateralFilter -> DepthToVbo -> NormalsFromVbo -> SdfFuse -> RaycastSdf).
+ * The reference has no FFI: its boundary is a set of C++ free functions in
+ * namespace roo taking pitched view structs by value.  Each
+ * entry point below replaces one of those functions; the header-only wrappers
+ * in include/kangaroo/cu_*.h keep the reference signatures verbatim and forward
+ * here.  Plain pointers and sizes only -- no C++ or torch types.
+ *
+ * Conventions
+ *  - kfx_image / kfx_volume have exactly the memory layout of roo::Image<T> and
+ *    roo::BoundedVolume<T> (reference include/kangaroo/Image.h:617-620,
+ *    Volume.h:363-369, BoundedVolume.h:168, BoundingBox.h:163-164), so a
+ *    roo:: view can be passed by address without conversion.
+ *  - All image/volume pointers are DEVICE pointers (HBM).  Views are non-owning
+ *    (reference Memory.h:152-164 "DontManage"); the library never allocates or
+ *    frees behind the caller's back and keeps no scratch state.
+ *  - Poses are row-major 3x4 float (roo::Mat<float,3,4>, Mat.h:33-163);
+ *    intrinsics are {fu, fv, u0, v0} (ImageIntrinsics.h:51-200).
+ *  - `stream` is a hipStream_t (NULL = default stream).  Launches are
+ *    asynchronous, ordered on that stream, like the reference's default-stream
+ *    launches (launch_utils.h:8: no sync).
+ *  - Return value: 0 = ok; > 0 = hipError_t from the launch; < 0 = argument
+ *    error (KFX_E_*).  Never exits the process: the roo:: wrappers map non-zero
+ *    to the reference's print-and-exit(-1) convention (launch_utils.h:29-47).
+ *  - Arithmetic is IEEE binary32, no FMA contraction, correctly rounded div and
+ *    sqrt, in the reference's operation order ("exact" build): results are
+ *    bit-identical to the CPU oracle for every op except the bilateral filter,
+ *    whose __expf is a hardware approximation as in the reference.
+ */
+#ifndef KFX_H
+#define KFX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KFX_VERSION_MAJOR 0
+#define KFX_VERSION_MINOR 1
+
+/* argument errors */
+#define KFX_E_NULL      (-1) /* null struct or data pointer */
+#define KFX_E_SHAPE     (-2) /* inconsistent / zero / too small dimensions */
+#define KFX_E_ALIGN     (-3) /* pointer or pitch not aligned for the element type */
+#define KFX_E_RANGE     (-4) /* parameter out of supported range */
+#define KFX_E_NODEVICE  (-5) /* no HIP device */
+
+/* roo::Image<T,Target,Management>: {size_t pitch; T* ptr; size_t w; size_t h;} */
+typedef struct kfx_image {
+    size_t pitch; /* bytes per row */
+    void*  ptr;
+    size_t w;
+    size_t h;
+} kfx_image;
+
+/* roo::BoundedVolume<T,...>: Volume {pitch, ptr, w, h, img_pitch, d} + BoundingBox {boxmin, boxmax}.
+ * For the TSDF volume T = SDF_t {float val; float w;} (8 bytes, Sdf.h:11-36), x fastest. */
+typedef struct kfx_volume {
+    size_t pitch;     /* bytes per x-row */
+    void*  ptr;
+    size_t w;
+    size_t h;
+    size_t img_pitch; /* bytes per z-slice */
+    size_t d;
+    float  boxmin[3];
+    float  boxmax[3];
+} kfx_volume;
+
+typedef void* kfx_stream; /* hipStream_t */
+
+/* flags for kfx_sdf_fuse */
+#define KFX_FUSE_FULL_EXTENT 1u /* also integrate the trailing dim%8 voxels the reference's
+                                   integer-division grid skips (cu_sdffusion.cu:57-59) */
+
+/* ---- the hot path ------------------------------------------------------------ */
+
+/* roo::SdfFuse(BoundedVolume<SDF_t>, Image<float>, Image<float4>, Mat<float,3,4> T_cw,
+ *              ImageIntrinsics, float trunc_dist, float maxw, float mincostheta)
+ * reference: include/kangaroo/cu_sdffusion.h:13-14, src/cu_sdffusion.cu:16-61 */
+int kfx_sdf_fuse(const kfx_volume* vol, const kfx_image* depth, const kfx_image* norm,
+                 const float T_cw[12], const float K[4], float trunc_dist, float max_w,
+                 float mincostheta, unsigned flags, kfx_stream stream);
+
+/* Diagnostics (no reference counterpart): number of voxels kfx_sdf_fuse would update for
+ * this frame -- the same projection / lookup / predicate (cu_sdffusion.cu:22-44) evaluated
+ * without touching the volume data.  *d_count is a DEVICE uint64 the caller zeroes; the count
+ * is added to it.  bench.py uses it for the algorithmic-bytes figure 16 B x N_updated. */
+int kfx_sdf_fuse_count(const kfx_volume* vol, const kfx_image* depth, const kfx_image* norm,
+                       const float T_cw[12], const float K[4], float trunc_dist,
+                       float mincostheta, unsigned flags, unsigned long long* d_count,
+                       kfx_stream stream);
+
+/* roo::RaycastSdf(Image<float> depth, Image<float4> norm, Image<float> img,
+ *                 const BoundedVolume<SDF_t>, const Mat<float,3,4> T_wc, ImageIntrinsics,
+ *                 float near, float far, float trunc_dist, bool subpix)
+ * reference: include/kangaroo/cu_raycast.h:13-14, src/cu_raycast.cu:14-113 */
+int kfx_raycast_sdf(const kfx_image* depth, const kfx_image* norm, const kfx_image* img,
+                    const kfx_volume* vol, const float T_wc[12], const float K[4], float near,
+                    float far, float trunc_dist, int subpix, kfx_stream stream);
+
+/* roo::BilateralFilter<float,float>(Image<float>, Image<float>, gs, gr, size[, minval])
+ * reference: include/kangaroo/cu_bilateral.h:9-19, src/cu_bilateral.cu:13-53 (use_minval=0),
+ * :59-104 (use_minval=1) */
+int kfx_bilateral_f32(const kfx_image* out, const kfx_image* in, float gs, float gr, unsigned size,
+                      float minval, int use_minval, kfx_stream stream);
+/* roo::BilateralFilter<float,unsigned short>(..., unsigned short minval): cu_bilateral.cu:104 */
+int kfx_bilateral_u16(const kfx_image* out, const kfx_image* in, float gs, float gr, unsigned size,
+                      unsigned short minval, kfx_stream stream);
+/* roo::BilateralFilter<float,unsigned char>(...): cu_bilateral.cu:53 */
+int kfx_bilateral_u8(const kfx_image* out, const kfx_image* in, float gs, float gr, unsigned size,
+                     kfx_stream stream);
+
+/* roo::DepthToVbo<float|unsigned short>(Image<float4>, Image<T>, ImageIntrinsics, float scale)
+ * reference: include/kangaroo/cu_depth_tools.h:19-27, src/cu_depth_tools.cu:59-78,216-217 */
+int kfx_depth_to_vbo_f32(const kfx_image* vbo, const kfx_image* depth, const float K[4], float scale,
+                         kfx_stream stream);
+int kfx_depth_to_vbo_u16(const kfx_image* vbo, const kfx_image* depth, const float K[4], float scale,
+                         kfx_stream stream);
+
+/* roo::NormalsFromVbo(Image<float4> dN, Image<float4> dV)
+ * reference: include/kangaroo/cu_normals.h:9-10, src/cu_normals.cu:12-45 */
+int kfx_normals_from_vbo(const kfx_image* nrm, const kfx_image* vbo, kfx_stream stream);
+
+/* roo::SdfReset(BoundedVolume<SDF_t>, float trunc_dist): fills (trunc_dist, 0) over the
+ * contiguous span ptr .. RowPtr(h-1,d-1)+w including pitch padding
+ * reference: cu_sdffusion.h:20, src/cu_sdffusion.cu:153-164, Volume.h:343-356 */
+int kfx_sdf_reset(const kfx_volume* vol, float trunc_dist, kfx_stream stream);
+
+/* roo::SdfSphere(BoundedVolume<SDF_t>, float3 center, float r)
+ * reference: cu_sdffusion.h:26, src/cu_sdffusion.cu:175-195 */
+int kfx_sdf_sphere(const kfx_volume* vol, const float center[3], float r, kfx_stream stream);
+
+/* ---- device allocator: roo::TargetDevice (Memory.h:59-84) ----------------------- */
+
+/* AllocatePitchedMem: rows padded to a multiple of 256 bytes (512 B coalescing
+ * segments stay aligned); *pitch receives the row stride in bytes. */
+int kfx_alloc_pitched(void** dev_ptr, size_t* pitch, size_t width_bytes, size_t rows);
+int kfx_free(void* dev_ptr);
+/* 2-D copies behind Image::CopyFrom / MemcpyFromHost / MemcpyToHost (Image.h:174-213).
+ * kind: 0 host->host, 1 host->device, 2 device->host, 3 device->device, 4 default */
+int kfx_memcpy_2d(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width_bytes,
+                  size_t rows, int kind, kfx_stream stream);
+int kfx_stream_synchronize(kfx_stream stream);
+
+/* ---- diagnostics --------------------------------------------------------------- */
+const char* kfx_last_error_string(void); /* thread-local, never NULL */
+const char* kfx_error_name(int code);    /* hipGetErrorString for >0, KFX_E_* names for <0 */
+int kfx_version(void);                   /* major*100 + minor */
+int kfx_device_count(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KFX_H */

@@ -1,0 +1,78 @@
+"""ctypes loader for libkfx.so (the gfx950 HIP kernels behind the C ABI of include/kfx.h).
+
+There is no CPU fallback: if the shared library is missing or fails to load, importing the
+ops raises.  Build it with `python -c "import __graft_entry__ as g; g.build()"` or
+`make -C kangaroo_amd/csrc`.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libkfx.so")
+
+
+class KfxImage(C.Structure):
+    """kfx_image == roo::Image<T> (include/kfx.h)."""
+    _fields_ = [("pitch", C.c_size_t), ("ptr", C.c_void_p), ("w", C.c_size_t), ("h", C.c_size_t)]
+
+
+class KfxVolume(C.Structure):
+    """kfx_volume == roo::BoundedVolume<T> (include/kfx.h)."""
+    _fields_ = [("pitch", C.c_size_t), ("ptr", C.c_void_p), ("w", C.c_size_t), ("h", C.c_size_t),
+                ("img_pitch", C.c_size_t), ("d", C.c_size_t),
+                ("boxmin", C.c_float * 3), ("boxmax", C.c_float * 3)]
+
+
+class KfxError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libkfx error %d: %s" % (code, msg))
+        self.code = code
+
+
+PI, PV, PF = C.POINTER(KfxImage), C.POINTER(KfxVolume), C.POINTER(C.c_float)
+
+# name -> (restype, argtypes); every symbol include/kfx.h declares
+SIGNATURES = {
+    "kfx_sdf_fuse": (C.c_int, [PV, PI, PI, PF, PF, C.c_float, C.c_float, C.c_float, C.c_uint, C.c_void_p]),
+    "kfx_sdf_fuse_count": (C.c_int, [PV, PI, PI, PF, PF, C.c_float, C.c_float, C.c_uint, C.c_void_p, C.c_void_p]),
+    "kfx_raycast_sdf": (C.c_int, [PI, PI, PI, PV, PF, PF, C.c_float, C.c_float, C.c_float, C.c_int, C.c_void_p]),
+    "kfx_bilateral_f32": (C.c_int, [PI, PI, C.c_float, C.c_float, C.c_uint, C.c_float, C.c_int, C.c_void_p]),
+    "kfx_bilateral_u16": (C.c_int, [PI, PI, C.c_float, C.c_float, C.c_uint, C.c_ushort, C.c_void_p]),
+    "kfx_bilateral_u8": (C.c_int, [PI, PI, C.c_float, C.c_float, C.c_uint, C.c_void_p]),
+    "kfx_depth_to_vbo_f32": (C.c_int, [PI, PI, PF, C.c_float, C.c_void_p]),
+    "kfx_depth_to_vbo_u16": (C.c_int, [PI, PI, PF, C.c_float, C.c_void_p]),
+    "kfx_normals_from_vbo": (C.c_int, [PI, PI, C.c_void_p]),
+    "kfx_sdf_reset": (C.c_int, [PV, C.c_float, C.c_void_p]),
+    "kfx_sdf_sphere": (C.c_int, [PV, PF, C.c_float, C.c_void_p]),
+    "kfx_alloc_pitched": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_size_t, C.c_size_t]),
+    "kfx_free": (C.c_int, [C.c_void_p]),
+    "kfx_memcpy_2d": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p]),
+    "kfx_stream_synchronize": (C.c_int, [C.c_void_p]),
+    "kfx_last_error_string": (C.c_char_p, []),
+    "kfx_error_name": (C.c_char_p, [C.c_int]),
+    "kfx_version": (C.c_int, []),
+    "kfx_device_count": (C.c_int, []),
+}
+
+_lib = None
+
+
+def load():
+    """Load libkfx.so and bind every entry point; raises if anything is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "kangaroo_amd: %s not found -- the HIP extension is required (no CPU fallback). "
+                "Run `make -C kangaroo_amd/csrc` or __graft_entry__.build()." % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            f = getattr(L, name)  # AttributeError if the symbol is not exported
+            f.restype, f.argtypes = res, args
+        _lib = L
+    return _lib
+
+
+def check(code):
+    if code != 0:
+        raise KfxError(code, load().kfx_last_error_string().decode())

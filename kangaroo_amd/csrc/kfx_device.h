@@ -1,0 +1,91 @@
+// kfx_device.h -- shared device-side helpers for the gfx950 kernels.
+//
+// Numerics contract ("exact" build): this translation unit is compiled with
+// -ffp-contract=off and HIP's default correctly rounded fp32 divide/sqrt, and
+// every expression keeps the reference's operand order and association, so the
+// kernels are bit-comparable with the CPU oracle (oracle/kfx_oracle.c).
+// Reference citations are paths inside the reference tree.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/kfx.h"
+
+namespace kfx {
+
+struct V3 { float x, y, z; };
+
+__device__ __forceinline__ V3 v3(float x, float y, float z) { return V3{x, y, z}; }
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return V3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return V3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ V3 operator*(V3 a, float s) { return V3{a.x * s, a.y * s, a.z * s}; }
+// float3 / float3 is a true division (CUDA_SDK/cutil_math.h:354-357)
+__device__ __forceinline__ V3 div_cw(V3 a, V3 b) { return V3{a.x / b.x, a.y / b.y, a.z / b.z}; }
+// float3 / float is multiply-by-reciprocal (cutil_math.h:358-362)
+__device__ __forceinline__ V3 div_s(V3 a, float s) { const float inv = 1.0f / s; return a * inv; }
+__device__ __forceinline__ float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ float length(V3 a) { return sqrtf(dot(a, a)); }
+// lerp = a + t*(b-a) (cutil_math.h:80-83, :375-378)
+__device__ __forceinline__ float lerp(float a, float b, float t) { return a + t * (b - a); }
+__device__ __forceinline__ V3 lerp(V3 a, V3 b, float t) { return a + (b - a) * t; }
+// clamp = fmaxf(a, fminf(f, b)) (cutil_math.h:86-89)
+__device__ __forceinline__ float clampf(float f, float a, float b) { return fmaxf(a, fminf(f, b)); }
+
+// Row-major 3x4 pose, roo::Mat<float,3,4> (Mat.h:33-163)
+struct Pose { float m[12]; };
+// ImageIntrinsics {fu, fv, u0, v0} (ImageIntrinsics.h:51-200)
+struct Intr { float fu, fv, u0, v0; };
+
+// T * p (MatUtils.h:117-125)
+__device__ __forceinline__ V3 se3_mul(const Pose& T, V3 p)
+{
+    return V3{T.m[0] * p.x + T.m[1] * p.y + T.m[2] * p.z + T.m[3],
+              T.m[4] * p.x + T.m[5] * p.y + T.m[6] * p.z + T.m[7],
+              T.m[8] * p.x + T.m[9] * p.y + T.m[10] * p.z + T.m[11]};
+}
+// mulSO3 (MatUtils.h:147-155)
+__device__ __forceinline__ V3 so3_mul(const Pose& T, V3 r)
+{
+    return V3{T.m[0] * r.x + T.m[1] * r.y + T.m[2] * r.z,
+              T.m[4] * r.x + T.m[5] * r.y + T.m[6] * r.z,
+              T.m[8] * r.x + T.m[9] * r.y + T.m[10] * r.z};
+}
+// mulSO3inv (MatUtils.h:177-185)
+__device__ __forceinline__ V3 so3_mul_inv(const Pose& T, V3 r)
+{
+    return V3{T.m[0] * r.x + T.m[4] * r.y + T.m[8] * r.z,
+              T.m[1] * r.x + T.m[5] * r.y + T.m[9] * r.z,
+              T.m[2] * r.x + T.m[6] * r.y + T.m[10] * r.z};
+}
+
+// Device view of a pitched image.
+struct ImgView {
+    const unsigned char* ptr;
+    size_t pitch;
+    int w, h;
+};
+template <typename T>
+__device__ __forceinline__ const T* row(const ImgView& im, size_t y)
+{
+    return reinterpret_cast<const T*>(im.ptr + y * im.pitch);
+}
+
+// Device view of BoundedVolume<SDF_t>.
+struct VolView {
+    unsigned char* ptr;
+    size_t pitch, img_pitch;
+    int w, h, d;
+    V3 bmin, bmax;
+};
+
+__host__ __device__ inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+} // namespace kfx
+
+// ---- host-side launch helpers (capi.hip) --------------------------------------
+namespace kfx {
+int set_error(int code, const char* what);
+int check_launch(const char* what);
+} // namespace kfx

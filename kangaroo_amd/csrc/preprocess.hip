@@ -1,0 +1,265 @@
+// preprocess.hip -- depth-map preprocessing for gfx950: BilateralFilter, DepthToVbo,
+// NormalsFromVbo.
+//
+// Reference behaviour: src/cu_bilateral.cu:13-104, src/cu_depth_tools.cu:59-78,
+// src/cu_normals.cu:12-45.  New kernels: the bilateral window is served from an LDS
+// tile (workgroup tile + apron, loaded once with clamped coordinates, which is exactly
+// Image::GetWithClampedRange) and the (2r+1)^2 spatial weights are evaluated once per
+// workgroup into LDS instead of once per tap per pixel.
+#include "kfx_device.h"
+
+namespace kfx {
+
+constexpr int BIL_TX = 32, BIL_TY = 8; // workgroup tile (256 threads): wave = 32x2 pixels
+constexpr int BIL_MAX_R = 16;          // LDS path up to a 33x33 window
+
+struct BilParams {
+    const unsigned char* in;
+    size_t in_pitch;
+    unsigned char* out;
+    size_t out_pitch;
+    int w, h;       // output extent (dOut.InBounds, cu_bilateral.cu:20,66)
+    int iw, ih;     // input extent used for clamping (Image.h:297-303)
+    int R;
+    float gs, gr;
+    float minval;
+    int use_minval;
+};
+
+template <typename Ti>
+__device__ __forceinline__ float load_clamped(const BilParams& p, int x, int y)
+{
+    x = min(max(x, 0), p.iw - 1);
+    y = min(max(y, 0), p.ih - 1);
+    return (float)reinterpret_cast<const Ti*>(p.in + (size_t)y * p.in_pitch)[x];
+}
+
+// Integer inputs are held as float in LDS: every uchar/ushort value and every
+// difference of two is exactly representable, so (float)(p - q), q >= minval and w * q
+// give the reference's results.
+template <typename Ti>
+__global__ __launch_bounds__(BIL_TX * BIL_TY) void k_bilateral(const BilParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int R = p.R, D = 2 * R + 1;
+    const int TW = BIL_TX + 2 * R, TH = BIL_TY + 2 * R;
+    float* tile = lds;          // TH x TW
+    float* sw = lds + TW * TH;  // D x D spatial weights
+    const int tid = threadIdx.x;
+    const int bx = blockIdx.x * BIL_TX, by = blockIdx.y * BIL_TY;
+
+    for (int i = tid; i < TW * TH; i += BIL_TX * BIL_TY) {
+        const int ty = i / TW, tx = i - ty * TW;
+        tile[i] = load_clamped<Ti>(p, bx + tx - R, by + ty - R);
+    }
+    for (int i = tid; i < D * D; i += BIL_TX * BIL_TY) {
+        const int r = i / D - R, c = i % D - R;
+        const float sd2 = (float)(r * r + c * c);
+        sw[i] = __expf(-(sd2) / (2 * p.gs * p.gs));
+    }
+    __syncthreads();
+
+    const int lx = tid % BIL_TX, ly = tid / BIL_TX;
+    const int x = bx + lx, y = by + ly;
+    if (x >= p.w || y >= p.h) return;
+
+    const float pc = tile[(ly + R) * TW + lx + R];
+    float sum = 0.f, sumw = 0.f;
+    if (!p.use_minval || pc >= p.minval) {
+        const float inv2gr = 2 * p.gr * p.gr;
+        for (int r = 0; r < D; ++r) {
+            const float* trow = tile + (ly + r) * TW + lx;
+            const float* srow = sw + r * D;
+            for (int c = 0; c < D; ++c) {
+                const float q = trow[c];
+                if (!p.use_minval || q >= p.minval) {
+                    const float id = pc - q;
+                    const float id2 = id * id;
+                    const float iw = __expf(-(id2) / inv2gr);
+                    const float w = srow[c] * iw;
+                    sumw += w;
+                    sum += w * q;
+                }
+            }
+        }
+    }
+    reinterpret_cast<float*>(p.out + (size_t)y * p.out_pitch)[x] = sum / sumw;
+}
+
+// Window too large for the LDS tile: straight global gathers.
+template <typename Ti>
+__global__ __launch_bounds__(256) void k_bilateral_global(const BilParams p)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= p.w || y >= p.h) return;
+    const float pc = (float)reinterpret_cast<const Ti*>(p.in + (size_t)y * p.in_pitch)[x];
+    float sum = 0.f, sumw = 0.f;
+    if (!p.use_minval || pc >= p.minval) {
+        for (int r = -p.R; r <= p.R; ++r)
+            for (int c = -p.R; c <= p.R; ++c) {
+                const float q = load_clamped<Ti>(p, x + c, y + r);
+                if (!p.use_minval || q >= p.minval) {
+                    const float sd2 = (float)(r * r + c * c);
+                    const float id = pc - q;
+                    const float id2 = id * id;
+                    const float w = __expf(-(sd2) / (2 * p.gs * p.gs)) * __expf(-(id2) / (2 * p.gr * p.gr));
+                    sumw += w;
+                    sum += w * q;
+                }
+            }
+    }
+    reinterpret_cast<float*>(p.out + (size_t)y * p.out_pitch)[x] = sum / sumw;
+}
+
+struct VboParams {
+    const unsigned char* in;
+    size_t in_pitch;
+    unsigned char* out;
+    size_t out_pitch;
+    int w, h;
+    Intr K;
+    float scale;
+};
+
+// KernDepthToVbo (cu_depth_tools.cu:59-70), Unproject(u,v,z) (ImageIntrinsics.h:127-131)
+template <typename Ti>
+__global__ __launch_bounds__(256) void k_depth_to_vbo(const VboParams p)
+{
+    const int u = blockIdx.x * 64 + (threadIdx.x & 63), v = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (u >= p.w || v >= p.h) return;
+    const float kz = p.scale * (float)reinterpret_cast<const Ti*>(p.in + (size_t)v * p.in_pitch)[u];
+    const float4 P = make_float4(kz * ((float)u - p.K.u0) / p.K.fu, kz * ((float)v - p.K.v0) / p.K.fv, kz, 1.0f);
+    reinterpret_cast<float4*>(p.out + (size_t)v * p.out_pitch)[u] = P;
+}
+
+struct NrmParams {
+    const unsigned char* in;
+    size_t in_pitch;
+    unsigned char* out;
+    size_t out_pitch;
+    int w, h;
+};
+
+// KernNormalsFromVbo (cu_normals.cu:12-38)
+__global__ __launch_bounds__(256) void k_normals_from_vbo(const NrmParams p)
+{
+    const int u = blockIdx.x * 64 + (threadIdx.x & 63), v = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (u >= p.w || v >= p.h) return;
+    float4 N = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (u + 1 < p.w && v + 1 < p.h) {
+        const float4* r0 = reinterpret_cast<const float4*>(p.in + (size_t)v * p.in_pitch);
+        const float4* r1 = reinterpret_cast<const float4*>(p.in + (size_t)(v + 1) * p.in_pitch);
+        const float4 Vc = r0[u], Vr = r0[u + 1], Vu = r1[u];
+        const V3 a = v3(Vr.x - Vc.x, Vr.y - Vc.y, Vr.z - Vc.z);
+        const V3 b = v3(Vu.x - Vc.x, Vu.y - Vc.y, Vu.z - Vc.z);
+        const V3 axb = v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+        const float mag = length(axb);
+        N = make_float4(-axb.x / mag, -axb.y / mag, -axb.z / mag, 1.0f);
+    }
+    reinterpret_cast<float4*>(p.out + (size_t)v * p.out_pitch)[u] = N;
+}
+
+} // namespace kfx
+
+using namespace kfx;
+
+static int check_image(const kfx_image* im, size_t elem, const char* what)
+{
+    if (!im || !im->ptr) return set_error(KFX_E_NULL, what);
+    if (im->pitch < im->w * elem) return set_error(KFX_E_SHAPE, what);
+    const size_t al = elem >= 16 ? 16 : elem;
+    if (((uintptr_t)im->ptr | im->pitch) & (al - 1)) return set_error(KFX_E_ALIGN, what);
+    if (im->w > (1u << 30) || im->h > (1u << 30)) return set_error(KFX_E_SHAPE, what);
+    return 0;
+}
+
+template <typename Ti>
+static int bilateral_launch(const kfx_image* out, const kfx_image* in, float gs, float gr, unsigned size,
+                            float minval, int use_minval, kfx_stream stream)
+{
+    if (int e = check_image(out, 4, "BilateralFilter: output image")) return e;
+    if (int e = check_image(in, sizeof(Ti), "BilateralFilter: input image")) return e;
+    if (out->w == 0 || out->h == 0) return 0;
+    if (in->w == 0 || in->h == 0) return set_error(KFX_E_SHAPE, "BilateralFilter: empty input");
+    if (in->w < out->w || in->h < out->h) return set_error(KFX_E_SHAPE, "BilateralFilter: input smaller than output");
+    if (size > 1024) return set_error(KFX_E_RANGE, "BilateralFilter: window radius");
+    BilParams p;
+    p.in = (const unsigned char*)in->ptr;
+    p.in_pitch = in->pitch;
+    p.out = (unsigned char*)out->ptr;
+    p.out_pitch = out->pitch;
+    p.w = (int)out->w;
+    p.h = (int)out->h;
+    p.iw = (int)in->w;
+    p.ih = (int)in->h;
+    p.R = (int)size;
+    p.gs = gs;
+    p.gr = gr;
+    p.minval = minval;
+    p.use_minval = use_minval;
+    hipStream_t s = (hipStream_t)stream;
+    if (p.R <= BIL_MAX_R) {
+        const int D = 2 * p.R + 1;
+        const size_t lds = (size_t)((BIL_TX + 2 * p.R) * (BIL_TY + 2 * p.R) + D * D) * sizeof(float);
+        dim3 grid(ceil_div(p.w, BIL_TX), ceil_div(p.h, BIL_TY));
+        hipLaunchKernelGGL(k_bilateral<Ti>, grid, dim3(BIL_TX * BIL_TY), lds, s, p);
+    } else {
+        dim3 grid(ceil_div(p.w, 64), ceil_div(p.h, 4));
+        hipLaunchKernelGGL(k_bilateral_global<Ti>, grid, dim3(256), 0, s, p);
+    }
+    return check_launch("kfx_bilateral");
+}
+
+extern "C" int kfx_bilateral_f32(const kfx_image* out, const kfx_image* in, float gs, float gr, unsigned size,
+                                 float minval, int use_minval, kfx_stream stream)
+{
+    return bilateral_launch<float>(out, in, gs, gr, size, minval, use_minval ? 1 : 0, stream);
+}
+extern "C" int kfx_bilateral_u16(const kfx_image* out, const kfx_image* in, float gs, float gr, unsigned size,
+                                 unsigned short minval, kfx_stream stream)
+{
+    return bilateral_launch<unsigned short>(out, in, gs, gr, size, (float)minval, 1, stream);
+}
+extern "C" int kfx_bilateral_u8(const kfx_image* out, const kfx_image* in, float gs, float gr, unsigned size,
+                                kfx_stream stream)
+{
+    return bilateral_launch<unsigned char>(out, in, gs, gr, size, 0.f, 0, stream);
+}
+
+template <typename Ti>
+static int vbo_launch(const kfx_image* vbo, const kfx_image* depth, const float K[4], float scale, kfx_stream stream)
+{
+    if (int e = check_image(vbo, 16, "DepthToVbo: vbo image")) return e;
+    if (int e = check_image(depth, sizeof(Ti), "DepthToVbo: depth image")) return e;
+    if (!K) return set_error(KFX_E_NULL, "DepthToVbo: null intrinsics");
+    if (vbo->w == 0 || vbo->h == 0) return 0;
+    if (depth->w < vbo->w || depth->h < vbo->h) return set_error(KFX_E_SHAPE, "DepthToVbo: depth smaller than vbo");
+    VboParams p{(const unsigned char*)depth->ptr, depth->pitch, (unsigned char*)vbo->ptr, vbo->pitch,
+                (int)vbo->w, (int)vbo->h, Intr{K[0], K[1], K[2], K[3]}, scale};
+    dim3 grid(ceil_div(p.w, 64), ceil_div(p.h, 4));
+    hipLaunchKernelGGL(k_depth_to_vbo<Ti>, grid, dim3(256), 0, (hipStream_t)stream, p);
+    return check_launch("kfx_depth_to_vbo");
+}
+
+extern "C" int kfx_depth_to_vbo_f32(const kfx_image* vbo, const kfx_image* depth, const float K[4], float scale,
+                                    kfx_stream stream)
+{
+    return vbo_launch<float>(vbo, depth, K, scale, stream);
+}
+extern "C" int kfx_depth_to_vbo_u16(const kfx_image* vbo, const kfx_image* depth, const float K[4], float scale,
+                                    kfx_stream stream)
+{
+    return vbo_launch<unsigned short>(vbo, depth, K, scale, stream);
+}
+
+extern "C" int kfx_normals_from_vbo(const kfx_image* nrm, const kfx_image* vbo, kfx_stream stream)
+{
+    if (int e = check_image(nrm, 16, "NormalsFromVbo: normal image")) return e;
+    if (int e = check_image(vbo, 16, "NormalsFromVbo: vbo image")) return e;
+    if (nrm->w == 0 || nrm->h == 0) return 0;
+    if (vbo->w < nrm->w || vbo->h < nrm->h) return set_error(KFX_E_SHAPE, "NormalsFromVbo: vbo smaller than normals");
+    NrmParams p{(const unsigned char*)vbo->ptr, vbo->pitch, (unsigned char*)nrm->ptr, nrm->pitch, (int)nrm->w, (int)nrm->h};
+    dim3 grid(ceil_div(p.w, 64), ceil_div(p.h, 4));
+    hipLaunchKernelGGL(k_normals_from_vbo, grid, dim3(256), 0, (hipStream_t)stream, p);
+    return check_launch("kfx_normals_from_vbo");
+}

@@ -1,0 +1,238 @@
+// raycast.hip -- per-pixel sphere-traced ray-march of the TSDF (roo::RaycastSdf) for gfx950.
+//
+// Reference behaviour: src/cu_raycast.cu:14-113 (PhongShade, KernRaycastSdf) with the
+// samplers of BoundedVolume.h:93-106 / Volume.h:224-295.  New kernel: a wave64 owns an
+// 8x8 pixel tile (coherent rays -> the 8 trilinear corners of neighbouring lanes share
+// cache lines), a workgroup is 2x2 such tiles; each trilinear sample is four 16-byte
+// loads (the x and x+1 cells of an AoS row are contiguous) instead of eight 8-byte ones;
+// the gradient stencil is 20 distinct cells instead of 32 loads; missed rays skip the
+// (discarded) normal evaluation of the reference.
+#include "kfx_device.h"
+
+namespace kfx {
+
+struct RayParams {
+    VolView vol;
+    V3 size;          // bbox.Size()
+    V3 dims1;         // (w-1.f, h-1.f, d-1.f)           Volume.h:226
+    V3 hi2;           // ((float)(w-2), (float)(h-2), (float)(d-2))   Volume.h:229-231
+    V3 voxel;         // VoxelSizeUnits()                BoundedVolume.h:67-76
+    Pose T;           // T_wc
+    Intr K;
+    unsigned char *dptr, *nptr, *iptr;
+    size_t dpitch, npitch, ipitch;
+    int w, h;
+    float near, far, trunc;
+    int subpix;
+};
+
+__device__ __forceinline__ const float* cellp(const VolView& v, int x, int y, int z)
+{
+    return reinterpret_cast<const float*>(v.ptr + (size_t)z * v.img_pitch + (size_t)y * v.pitch) + 2 * x;
+}
+__device__ __forceinline__ float vval(const VolView& v, int x, int y, int z) { return *cellp(v, x, y, z); }
+
+struct __attribute__((aligned(8))) Pair { float v0, w0, v1, w1; }; // cells x and x+1 of one row
+
+// BoundedVolume::GetUnitsTrilinearClamped -> Volume::GetFractionalTrilinearClamped
+__device__ __forceinline__ float trilinear(const RayParams& p, const V3 pos_w)
+{
+    const V3 pos_v = div_cw(pos_w - p.vol.bmin, p.size);
+    const V3 pf = v3(pos_v.x * p.dims1.x, pos_v.y * p.dims1.y, pos_v.z * p.dims1.z);
+    const int ix = (int)fmaxf(fminf(p.hi2.x, floorf(pf.x)), 0.f);
+    const int iy = (int)fmaxf(fminf(p.hi2.y, floorf(pf.y)), 0.f);
+    const int iz = (int)fmaxf(fminf(p.hi2.z, floorf(pf.z)), 0.f);
+    const float fx = pf.x - (float)ix, fy = pf.y - (float)iy, fz = pf.z - (float)iz;
+    const unsigned char* b = p.vol.ptr + (size_t)iz * p.vol.img_pitch + (size_t)iy * p.vol.pitch + (size_t)ix * 8;
+    const Pair c00 = *reinterpret_cast<const Pair*>(b);
+    const Pair c10 = *reinterpret_cast<const Pair*>(b + p.vol.pitch);
+    const Pair c01 = *reinterpret_cast<const Pair*>(b + p.vol.img_pitch);
+    const Pair c11 = *reinterpret_cast<const Pair*>(b + p.vol.img_pitch + p.vol.pitch);
+    return lerp(lerp(lerp(c00.v0, c00.v1, fx), lerp(c10.v0, c10.v1, fx), fy),
+                lerp(lerp(c01.v0, c01.v1, fx), lerp(c11.v0, c11.v1, fx), fy), fz);
+}
+
+// BoundedVolume::GetUnitsBackwardDiffDxDyDz -> Volume::GetFractionalBackwardDiffDxDyDz.
+// Corner (cx,cy,cz) gradient = v(c) - v(c - e_axis); the 8 corners need the 20 cells of
+// {-1,0,1}^3 (relative to the clamped base) that have at most one coordinate equal to -1.
+__device__ __forceinline__ V3 gradient(const RayParams& p, const V3 pos_w)
+{
+    const V3 pos_v = div_cw(pos_w - p.vol.bmin, p.size);
+    const V3 pf = v3(pos_v.x * p.dims1.x, pos_v.y * p.dims1.y, pos_v.z * p.dims1.z);
+    const int ix = (int)fmaxf(fminf(p.hi2.x, floorf(pf.x)), 1.f);
+    const int iy = (int)fmaxf(fminf(p.hi2.y, floorf(pf.y)), 1.f);
+    const int iz = (int)fmaxf(fminf(p.hi2.z, floorf(pf.z)), 1.f);
+    const float fx = pf.x - (float)ix, fy = pf.y - (float)iy, fz = pf.z - (float)iz;
+    const VolView& v = p.vol;
+    // c[dz][dy][dx] for dx,dy,dz in {0,1}; mx/my/mz = the cells one step back along x/y/z.
+    float c[2][2][2], mx[2][2], my[2][2], mz[2][2];
+#pragma unroll
+    for (int dz = 0; dz < 2; ++dz)
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy) {
+            const float* r = cellp(v, ix - 1, iy + dy, iz + dz);
+            mx[dz][dy] = r[0];
+            c[dz][dy][0] = r[2];
+            c[dz][dy][1] = r[4];
+        }
+#pragma unroll
+    for (int dz = 0; dz < 2; ++dz) {
+        const float* r = cellp(v, ix, iy - 1, iz + dz);
+        my[dz][0] = r[0];
+        my[dz][1] = r[2];
+    }
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy) {
+        const float* r = cellp(v, ix, iy + dy, iz - 1);
+        mz[dy][0] = r[0];
+        mz[dy][1] = r[2];
+    }
+    V3 g[2][2][2];
+#pragma unroll
+    for (int dz = 0; dz < 2; ++dz)
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                const float v0 = c[dz][dy][dx];
+                const float bx = dx ? c[dz][dy][0] : mx[dz][dy];
+                const float by = dy ? c[dz][0][dx] : my[dz][dx];
+                const float bz = dz ? c[0][dy][dx] : mz[dy][dx];
+                g[dz][dy][dx] = v3(v0 - bx, v0 - by, v0 - bz);
+            }
+    const V3 deriv = lerp(lerp(lerp(g[0][0][0], g[0][0][1], fx), lerp(g[0][1][0], g[0][1][1], fx), fy),
+                          lerp(lerp(g[1][0][0], g[1][0][1], fx), lerp(g[1][1][0], g[1][1][1], fx), fy), fz);
+    return div_cw(deriv, p.voxel);
+}
+
+// PhongShade (cu_raycast.cu:14-28)
+__device__ __forceinline__ float phong(const V3 p_c, const V3 n_c)
+{
+    const float ambient = (float)0.4, diffuse = (float)0.4, specular = (float)0.2;
+    const V3 eyedir = div_s(p_c * -1.0f, length(p_c));
+    const V3 l0 = v3((float)0.4, (float)0.4, -1.0f);
+    const V3 lightdir = div_s(l0, length(l0));
+    const float ldotn = dot(lightdir, n_c);
+    const V3 lightreflect = n_c * (2 * ldotn) + lightdir * -1.0f;
+    const float edotr = fmaxf(0.0f, dot(eyedir, lightreflect));
+    const float spec = edotr * edotr * edotr * edotr * edotr * edotr * edotr * edotr * edotr * edotr;
+    return ambient + diffuse * ldotn + specular * spec;
+}
+
+__global__ __launch_bounds__(256) void k_raycast_sdf(const RayParams p)
+{
+    // wave -> 8x8 tile; workgroup -> 16x16 pixels
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int u = blockIdx.x * 16 + (wv & 1) * 8 + (lane & 7);
+    const int v = blockIdx.y * 16 + (wv >> 1) * 8 + (lane >> 3);
+    if (u >= p.w || v >= p.h) return;
+
+    const V3 c_w = v3(p.T.m[3], p.T.m[7], p.T.m[11]);                              // SE3Translation
+    const V3 ray_c = v3(((float)u - p.K.u0) / p.K.fu, ((float)v - p.K.v0) / p.K.fv, 1.0f); // Unproject
+    const V3 ray_w = so3_mul(p.T, ray_c);
+
+    // slab test against the volume's box (cu_raycast.cu:46-51)
+    const V3 ta = div_cw(p.vol.bmin - c_w, ray_w);
+    const V3 tb = div_cw(p.vol.bmax - c_w, ray_w);
+    const V3 tmin = v3(fminf(ta.x, tb.x), fminf(ta.y, tb.y), fminf(ta.z, tb.z));
+    const V3 tmax = v3(fmaxf(ta.x, tb.x), fmaxf(ta.y, tb.y), fmaxf(ta.z, tb.z));
+    const float max_tmin = fmaxf(fmaxf(fmaxf(tmin.x, tmin.y), tmin.z), p.near);
+    const float min_tmax = fminf(fminf(fminf(tmax.x, tmax.y), tmax.z), p.far);
+
+    float depth = 0.0f;
+    if (max_tmin < min_tmax) {
+        float lambda = max_tmin;
+        float last_sdf = __builtin_nanf("");
+        const float min_delta = p.voxel.x;
+        float delta = 0.f;
+        while (lambda < min_tmax) {
+            const float sdf = trilinear(p, c_w + ray_w * lambda);
+            if (sdf <= 0) {
+                if (last_sdf > 0) {
+                    if (p.subpix) lambda = lambda + delta * sdf / (last_sdf - sdf);
+                    depth = lambda;
+                }
+                break;
+            }
+            delta = sdf > 0 ? fmaxf(sdf, min_delta) : p.trunc;
+            lambda += delta;
+            last_sdf = sdf;
+        }
+    }
+
+    float* pd = reinterpret_cast<float*>(p.dptr + (size_t)v * p.dpitch) + u;
+    float* pi = reinterpret_cast<float*>(p.iptr + (size_t)v * p.ipitch) + u;
+    float4* pn = reinterpret_cast<float4*>(p.nptr + (size_t)v * p.npitch) + u;
+    if (depth > 0) {
+        const V3 g = gradient(p, c_w + ray_w * depth);
+        const float len = length(g);
+        const V3 n_w = len > 0 ? div_s(g, len) : v3(0.f, 0.f, 1.f);
+        const V3 n_c = so3_mul_inv(p.T, n_w);
+        const V3 p_c = ray_c * depth;
+        *pd = depth;
+        *pi = phong(p_c, n_c);
+        *pn = make_float4(n_c.x, n_c.y, n_c.z, 1.0f);
+    } else {
+        *pd = __builtin_nanf("");
+        *pi = 0.f;
+        *pn = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+
+} // namespace kfx
+
+using namespace kfx;
+
+extern "C" int kfx_raycast_sdf(const kfx_image* depth, const kfx_image* norm, const kfx_image* img,
+                               const kfx_volume* vol, const float T_wc[12], const float K[4], float near,
+                               float far, float trunc_dist, int subpix, kfx_stream stream)
+{
+    if (!depth || !norm || !img || !vol || !T_wc || !K || !depth->ptr || !norm->ptr || !img->ptr || !vol->ptr)
+        return set_error(KFX_E_NULL, "RaycastSdf: null argument");
+    if (img->w == 0 || img->h == 0) return 0;
+    if (depth->w < img->w || depth->h < img->h || norm->w < img->w || norm->h < img->h)
+        return set_error(KFX_E_SHAPE, "RaycastSdf: output images smaller than img");
+    if (depth->pitch < img->w * 4 || img->pitch < img->w * 4 || norm->pitch < img->w * 16)
+        return set_error(KFX_E_SHAPE, "RaycastSdf: image pitch");
+    if ((((uintptr_t)depth->ptr | depth->pitch | (uintptr_t)img->ptr | img->pitch) & 3) ||
+        (((uintptr_t)norm->ptr | norm->pitch) & 15) || (((uintptr_t)vol->ptr | vol->pitch | vol->img_pitch) & 7))
+        return set_error(KFX_E_ALIGN, "RaycastSdf: alignment");
+    // the gradient stencil reads cells [1-1, (dim-2)+1] (Volume.h:271-273)
+    if (vol->w < 3 || vol->h < 3 || vol->d < 3 || vol->w > 65535 || vol->h > 65535 || vol->d > 65535)
+        return set_error(KFX_E_SHAPE, "RaycastSdf: volume dimensions");
+    if (vol->pitch < vol->w * 8 || vol->img_pitch < vol->pitch * (vol->h - 1) + vol->w * 8)
+        return set_error(KFX_E_SHAPE, "RaycastSdf: volume pitch");
+
+    RayParams p;
+    p.vol.ptr = (unsigned char*)vol->ptr;
+    p.vol.pitch = vol->pitch;
+    p.vol.img_pitch = vol->img_pitch;
+    p.vol.w = (int)vol->w;
+    p.vol.h = (int)vol->h;
+    p.vol.d = (int)vol->d;
+    p.vol.bmin = V3{vol->boxmin[0], vol->boxmin[1], vol->boxmin[2]};
+    p.vol.bmax = V3{vol->boxmax[0], vol->boxmax[1], vol->boxmax[2]};
+    p.size = V3{vol->boxmax[0] - vol->boxmin[0], vol->boxmax[1] - vol->boxmin[1], vol->boxmax[2] - vol->boxmin[2]};
+    p.dims1 = V3{(float)vol->w - 1.f, (float)vol->h - 1.f, (float)vol->d - 1.f};
+    p.hi2 = V3{(float)(vol->w - 2), (float)(vol->h - 2), (float)(vol->d - 2)};
+    // VoxelSizeUnits = Size / make_float3(w-1,h-1,d-1) (size_t -> float), BoundedVolume.h:67-76
+    p.voxel = V3{p.size.x / (float)(vol->w - 1), p.size.y / (float)(vol->h - 1), p.size.z / (float)(vol->d - 1)};
+    for (int i = 0; i < 12; ++i) p.T.m[i] = T_wc[i];
+    p.K = Intr{K[0], K[1], K[2], K[3]};
+    p.dptr = (unsigned char*)depth->ptr;
+    p.nptr = (unsigned char*)norm->ptr;
+    p.iptr = (unsigned char*)img->ptr;
+    p.dpitch = depth->pitch;
+    p.npitch = norm->pitch;
+    p.ipitch = img->pitch;
+    p.w = (int)img->w; // the reference bounds the launch by img (cu_raycast.cu:39,110)
+    p.h = (int)img->h;
+    p.near = near;
+    p.far = far;
+    p.trunc = trunc_dist;
+    p.subpix = subpix ? 1 : 0;
+
+    dim3 grid(ceil_div(p.w, 16), ceil_div(p.h, 16));
+    hipLaunchKernelGGL(k_raycast_sdf, grid, dim3(256), 0, (hipStream_t)stream, p);
+    return check_launch("kfx_raycast_sdf");
+}

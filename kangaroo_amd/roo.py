@@ -1,0 +1,278 @@
+"""Python mirror of the reference's `roo::` interface for the KinectFusion hot path.
+
+Same names and argument order as the reference's C++ free functions
+(include/kangaroo/cu_sdffusion.h:13-26, cu_raycast.h:13-14, cu_bilateral.h:9-19,
+cu_normals.h:9-10, cu_depth_tools.h:19-21), same container semantics (pitched, non-owning
+views passed by value; `Image`/`BoundedVolume` here own torch storage the way the
+reference's `...,TargetDevice,Manage>` objects own cudaMallocPitch memory).  Every op
+calls the HIP kernels through the C ABI in libkfx.so -- there is no other execution path.
+
+torch is used only for device memory and stream plumbing.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import KfxError, KfxImage, KfxVolume  # noqa: F401
+
+_ELEM = {
+    "f32": (np.float32, 1), "f32x4": (np.float32, 4), "u16": (np.uint16, 1), "u8": (np.uint8, 1),
+}
+PITCH_ALIGN = 256  # same policy as kfx_alloc_pitched
+
+
+def _stream(stream):
+    if stream is not None:
+        return C.c_void_p(int(stream))
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _fp(a, n):
+    a = np.ascontiguousarray(np.asarray(a, dtype=np.float32).reshape(-1))
+    if a.size != n:
+        raise ValueError("expected %d floats, got %d" % (n, a.size))
+    return a.ctypes.data_as(_lib.PF), a
+
+
+class Image:
+    """roo::Image<T, TargetDevice, Manage>: pitched 2-D device image (Image.h:43-621)."""
+
+    def __init__(self, w, h, kind="f32", device="cuda", pitch=None, _storage=None, _offset=0):
+        self.w, self.h, self.kind = int(w), int(h), kind
+        self.np_dtype, self.channels = _ELEM[kind]
+        self.elem = np.dtype(self.np_dtype).itemsize * self.channels
+        if _storage is None:
+            self.pitch = int(pitch) if pitch else (self.w * self.elem + PITCH_ALIGN - 1) // PITCH_ALIGN * PITCH_ALIGN
+            self.storage = torch.zeros(max(self.pitch * self.h, 1), dtype=torch.uint8, device=device)
+            self.offset = 0
+        else:
+            self.pitch, self.storage, self.offset = int(pitch), _storage, int(_offset)
+
+    @property
+    def ptr(self):
+        return self.storage.data_ptr() + self.offset
+
+    def view(self):
+        return KfxImage(self.pitch, self.ptr, self.w, self.h)
+
+    def ref(self):
+        self._v = self.view()
+        return C.byref(self._v)
+
+    def SubImage(self, x, y, w, h):
+        """Image::SubImage (Image.h:423-454): same pitch, offset pointer."""
+        assert x + w <= self.w and y + h <= self.h
+        return Image(w, h, self.kind, pitch=self.pitch, _storage=self.storage,
+                     _offset=self.offset + y * self.pitch + x * self.elem)
+
+    def MemcpyFromHost(self, arr):
+        """Image::MemcpyFromHost (Image.h:181-197)."""
+        arr = np.ascontiguousarray(arr, dtype=self.np_dtype)
+        rowbytes = self.w * self.elem
+        assert arr.nbytes == rowbytes * self.h, (arr.shape, self.w, self.h, self.kind)
+        host = torch.from_numpy(arr.view(np.uint8).reshape(self.h, rowbytes))
+        dst = self.storage[self.offset: self.offset + self.pitch * (self.h - 1) + rowbytes]
+        dst = torch.as_strided(dst, (self.h, rowbytes), (self.pitch, 1))
+        dst.copy_(host)
+        return self
+
+    def MemcpyToHost(self):
+        """Image::MemcpyToHost (Image.h:199-213) -> numpy (h, w[, 4])."""
+        rowbytes = self.w * self.elem
+        src = self.storage[self.offset: self.offset + self.pitch * (self.h - 1) + rowbytes]
+        src = torch.as_strided(src, (self.h, rowbytes), (self.pitch, 1))
+        out = src.cpu().numpy().copy().view(self.np_dtype)
+        return out.reshape(self.h, self.w, self.channels) if self.channels > 1 else out.reshape(self.h, self.w)
+
+    def tensor(self):
+        """Strided torch view (h, w[, ch]) of the pixels, for device-side comparisons."""
+        tdt = {np.float32: torch.float32, np.uint16: torch.uint16, np.uint8: torch.uint8}[self.np_dtype]
+        isz = np.dtype(self.np_dtype).itemsize
+        flat = self.storage[self.offset:].view(tdt) if (self.offset % isz == 0) else None
+        if self.channels > 1:
+            return torch.as_strided(flat, (self.h, self.w, self.channels), (self.pitch // isz, self.channels, 1))
+        return torch.as_strided(flat, (self.h, self.w), (self.pitch // isz, 1))
+
+
+class BoundedVolume:
+    """roo::BoundedVolume<SDF_t, TargetDevice, Manage> (BoundedVolume.h:10-170): x-fastest AoS
+    {val, w} cells, row `pitch`, slice `img_pitch = pitch*h` (Memory.h:70-78)."""
+
+    ELEM = 8
+
+    def __init__(self, w, h, d, boxmin=(-1, -1, -1), boxmax=(1, 1, 1), device="cuda", pitch=None,
+                 _storage=None, _offset=0, _img_pitch=None):
+        self.w, self.h, self.d = int(w), int(h), int(d)
+        self.boxmin = np.asarray(boxmin, np.float32).copy()
+        self.boxmax = np.asarray(boxmax, np.float32).copy()
+        if _storage is None:
+            self.pitch = int(pitch) if pitch else (self.w * self.ELEM + PITCH_ALIGN - 1) // PITCH_ALIGN * PITCH_ALIGN
+            self.img_pitch = self.pitch * self.h
+            self.storage = torch.zeros(max(self.img_pitch * self.d, 1), dtype=torch.uint8, device=device)
+            self.offset = 0
+        else:
+            self.pitch, self.img_pitch, self.storage, self.offset = int(pitch), int(_img_pitch), _storage, int(_offset)
+
+    @property
+    def ptr(self):
+        return self.storage.data_ptr() + self.offset
+
+    def view(self):
+        v = KfxVolume(self.pitch, self.ptr, self.w, self.h, self.img_pitch, self.d)
+        for i in range(3):
+            v.boxmin[i] = float(self.boxmin[i])
+            v.boxmax[i] = float(self.boxmax[i])
+        return v
+
+    def ref(self):
+        self._v = self.view()
+        return C.byref(self._v)
+
+    def IsValid(self):
+        """BoundedVolume::IsValid (BoundedVolume.h:83-87)."""
+        return self.w >= 8 and self.h >= 8 and self.d >= 8
+
+    def VoxelSizeUnits(self):
+        """BoundedVolume::VoxelSizeUnits (BoundedVolume.h:67-76), float32."""
+        return ((self.boxmax - self.boxmin) / np.array([self.w - 1, self.h - 1, self.d - 1], np.float32)).astype(np.float32)
+
+    def VoxelPositionInUnits(self, x, y, z):
+        """BoundedVolume::VoxelPositionInUnits (BoundedVolume.h:115-125), float32."""
+        s = (self.boxmax - self.boxmin).astype(np.float32)
+        f = np.float32
+        return np.array([self.boxmin[0] + s[0] * f(x) / f(self.w - 1), self.boxmin[1] + s[1] * f(y) / f(self.h - 1),
+                         self.boxmin[2] + s[2] * f(z) / f(self.d - 1)], np.float32)
+
+    def SubVolume(self, start, size):
+        """Volume::SubVolume (Volume.h:305-311): same pitches, offset pointer."""
+        off = self.offset + start[2] * self.img_pitch + start[1] * self.pitch + start[0] * self.ELEM
+        return BoundedVolume(size[0], size[1], size[2], self.boxmin, self.boxmax, pitch=self.pitch,
+                             _storage=self.storage, _offset=off, _img_pitch=self.img_pitch)
+
+    def SubBoundingVolume(self, rmin, rmax):
+        """BoundedVolume::SubBoundingVolume (BoundedVolume.h:137-165) in float32 host arithmetic."""
+        f = np.float32
+        rmin, rmax = np.asarray(rmin, f), np.asarray(rmax, f)
+        size = (self.boxmax - self.boxmin).astype(f)
+        min_fv = ((rmin - self.boxmin) / size).astype(f)
+        max_fv = ((rmax - self.boxmin) / size).astype(f)
+        dims1 = np.array([self.w - 1, self.h - 1, self.d - 1], f)
+        with np.errstate(invalid="ignore"):
+            min_v = np.maximum(dims1 * min_fv, f(0)).astype(np.int32)           # float -> int truncation
+            max_v = np.minimum(np.ceil(dims1 * max_fv), dims1).astype(np.int32)
+        size_v = np.maximum((max_v - min_v) + 1, 0)
+        sub = self.SubVolume(tuple(int(v) for v in min_v), tuple(int(v) for v in size_v))
+        sub.boxmin = self.VoxelPositionInUnits(*min_v)
+        sub.boxmax = self.VoxelPositionInUnits(*max_v)
+        return sub
+
+    def ZSlab(self, z0, z1):
+        """View of slices [z0, z1) with the bbox of its first/last plane (what SubBoundingVolume
+        produces for an axis-aligned slab, BoundedVolume.h:156-164)."""
+        sub = self.SubVolume((0, 0, z0), (self.w, self.h, z1 - z0))
+        sub.boxmin = self.VoxelPositionInUnits(0, 0, z0)
+        sub.boxmax = self.VoxelPositionInUnits(self.w - 1, self.h - 1, z1 - 1)
+        return sub
+
+    def tensor(self):
+        """Strided float32 torch view (d, h, w, 2) of the cells."""
+        flat = self.storage[self.offset:].view(torch.float32)
+        return torch.as_strided(flat, (self.d, self.h, self.w, 2), (self.img_pitch // 4, self.pitch // 4, 2, 1))
+
+    def MemcpyToHost(self):
+        return self.tensor().cpu().numpy().copy()
+
+    def MemcpyFromHost(self, arr):
+        self.tensor().copy_(torch.from_numpy(np.ascontiguousarray(arr, np.float32)))
+        return self
+
+
+def FitToFrustum(T_wc, w, h, K, near, far):
+    """BoundingBox::FitToFrustum (BoundingBox.h:72-96), float32 host arithmetic."""
+    f = np.float32
+    T = np.asarray(T_wc, f).reshape(3, 4)
+    K = np.asarray(K, f)
+    c = T[:, 3]
+    lo = np.full(3, np.finfo(f).max, f)
+    hi = np.full(3, -np.finfo(f).max, f)
+    for dist in (f(near), f(far)):
+        for (u, v) in ((0, 0), (w, 0), (0, h), (w, h)):
+            r = np.array([(f(u) - K[2]) / K[0], (f(v) - K[3]) / K[1], f(1)], f)
+            rw = np.array([T[i, 0] * r[0] + T[i, 1] * r[1] + T[i, 2] * r[2] for i in range(3)], f)
+            p = (c + dist * rw).astype(f)
+            hi = np.maximum(p, hi)
+            lo = np.minimum(p, lo)
+    return lo, hi
+
+
+# ---- operators ------------------------------------------------------------------
+
+def SdfFuse(vol, depth, norm, T_cw, K, trunc_dist, maxw, mincostheta, full_extent=False, stream=None):
+    """roo::SdfFuse (cu_sdffusion.h:13-14)."""
+    t, _t = _fp(T_cw, 12)
+    k, _k = _fp(K, 4)
+    _lib.check(_lib.load().kfx_sdf_fuse(vol.ref(), depth.ref(), norm.ref(), t, k, trunc_dist, maxw, mincostheta,
+                                        1 if full_extent else 0, _stream(stream)))
+
+
+def SdfFuseCount(vol, depth, norm, T_cw, K, trunc_dist, mincostheta, full_extent=False, stream=None):
+    """Diagnostics: number of voxels SdfFuse would update for this frame (kfx_sdf_fuse_count)."""
+    t, _t = _fp(T_cw, 12)
+    k, _k = _fp(K, 4)
+    cnt = torch.zeros(1, dtype=torch.int64, device=vol.storage.device)
+    _lib.check(_lib.load().kfx_sdf_fuse_count(vol.ref(), depth.ref(), norm.ref(), t, k, trunc_dist, mincostheta,
+                                              1 if full_extent else 0, C.c_void_p(cnt.data_ptr()), _stream(stream)))
+    return int(cnt.item())
+
+
+def RaycastSdf(depth, norm, img, vol, T_wc, K, near, far, trunc_dist, subpix=True, stream=None):
+    """roo::RaycastSdf (cu_raycast.h:13-14)."""
+    t, _t = _fp(T_wc, 12)
+    k, _k = _fp(K, 4)
+    _lib.check(_lib.load().kfx_raycast_sdf(depth.ref(), norm.ref(), img.ref(), vol.ref(), t, k, near, far,
+                                           trunc_dist, 1 if subpix else 0, _stream(stream)))
+
+
+def BilateralFilter(dOut, dIn, gs, gr, size, minval=None, stream=None):
+    """roo::BilateralFilter<float,Ti> (cu_bilateral.h:9-19); minval=None selects the overload
+    without the validity threshold."""
+    L = _lib.load()
+    if dIn.kind == "f32":
+        _lib.check(L.kfx_bilateral_f32(dOut.ref(), dIn.ref(), gs, gr, size, 0.0 if minval is None else minval,
+                                       0 if minval is None else 1, _stream(stream)))
+    elif dIn.kind == "u16":
+        if minval is None:
+            raise TypeError("BilateralFilter<float,unsigned short> is only instantiated with minval (cu_bilateral.cu:104)")
+        _lib.check(L.kfx_bilateral_u16(dOut.ref(), dIn.ref(), gs, gr, size, int(minval), _stream(stream)))
+    elif dIn.kind == "u8":
+        if minval is not None:
+            raise TypeError("BilateralFilter<float,unsigned char> is only instantiated without minval (cu_bilateral.cu:53)")
+        _lib.check(L.kfx_bilateral_u8(dOut.ref(), dIn.ref(), gs, gr, size, _stream(stream)))
+    else:
+        raise TypeError(dIn.kind)
+
+
+def DepthToVbo(dVbo, dDepth, K, scale=1.0, stream=None):
+    """roo::DepthToVbo<T> (cu_depth_tools.h:19-21)."""
+    k, _k = _fp(K, 4)
+    L = _lib.load()
+    fn = {"f32": L.kfx_depth_to_vbo_f32, "u16": L.kfx_depth_to_vbo_u16}[dDepth.kind]
+    _lib.check(fn(dVbo.ref(), dDepth.ref(), k, scale, _stream(stream)))
+
+
+def NormalsFromVbo(dN, dV, stream=None):
+    """roo::NormalsFromVbo (cu_normals.h:9-10)."""
+    _lib.check(_lib.load().kfx_normals_from_vbo(dN.ref(), dV.ref(), _stream(stream)))
+
+
+def SdfReset(vol, trunc_dist, stream=None):
+    """roo::SdfReset(BoundedVolume<SDF_t>, float) (cu_sdffusion.h:20)."""
+    _lib.check(_lib.load().kfx_sdf_reset(vol.ref(), trunc_dist, _stream(stream)))
+
+
+def SdfSphere(vol, center, r, stream=None):
+    """roo::SdfSphere (cu_sdffusion.h:26)."""
+    c, _c = _fp(center, 3)
+    _lib.check(_lib.load().kfx_sdf_sphere(vol.ref(), c, r, _stream(stream)))

@@ -64,6 +64,16 @@ def lib():
         L.kfo_sub_bounding_volume.argtypes = [PV, PV, PF, PF]
         L.kfo_se3_inverse.argtypes = [PF, PF]
         L.kfo_max_threads.restype = C.c_int
+        L.kfo_trilinear.argtypes = [PV, PF]
+        L.kfo_trilinear.restype = C.c_float
+        L.kfo_gradient.argtypes = [PV, PF, PF]
+        L.kfo_gradient.restype = None
+        L.kfo_sdf_accumulate.argtypes = [C.c_float] * 5 + [PF]
+        L.kfo_sdf_accumulate.restype = None
+        L.kfo_intrinsics_level.argtypes = [PF, PF, C.c_int]
+        L.kfo_intrinsics_level.restype = None
+        L.kfo_voxel_position.argtypes = [PV, C.c_int, C.c_int, C.c_int, PF]
+        L.kfo_voxel_position.restype = None
         for f in ("kfo_bilateral_f32", "kfo_bilateral_u16", "kfo_bilateral_u8", "kfo_depth_to_vbo_f32",
                   "kfo_depth_to_vbo_u16", "kfo_normals_from_vbo", "kfo_sdf_reset", "kfo_sdf_sphere",
                   "kfo_raycast_sdf", "kfo_raycast_sdf_touch", "kfo_raycast_box", "kfo_raycast_sphere",
@@ -289,3 +299,34 @@ def se3_inverse(T):
 
 def max_threads():
     return int(lib().kfo_max_threads())
+
+
+def trilinear(vol, pos):
+    _, q = _fp(pos)
+    return float(lib().kfo_trilinear(vol.ref(), q))
+
+
+def gradient(vol, pos):
+    _, q = _fp(pos)
+    o = (C.c_float * 3)()
+    lib().kfo_gradient(vol.ref(), q, o)
+    return np.array(list(o), np.float32)
+
+
+def sdf_accumulate(val, w, old_val, old_w, max_w):
+    o = (C.c_float * 2)()
+    lib().kfo_sdf_accumulate(val, w, old_val, old_w, max_w, o)
+    return np.array(list(o), np.float32)
+
+
+def intrinsics_level(K, level):
+    _, k = _fp(K)
+    o = (C.c_float * 4)()
+    lib().kfo_intrinsics_level(o, k, level)
+    return np.array(list(o), np.float32)
+
+
+def voxel_position(vol, x, y, z):
+    o = (C.c_float * 3)()
+    lib().kfo_voxel_position(vol.ref(), x, y, z, o)
+    return np.array(list(o), np.float32)

@@ -663,3 +663,38 @@ void kfo_sub_bounding_volume(kfo_volume* out, const kfo_volume* vol, const float
     out->boxmin[0] = nlo.x; out->boxmin[1] = nlo.y; out->boxmin[2] = nlo.z;
     out->boxmax[0] = nhi.x; out->boxmax[1] = nhi.y; out->boxmax[2] = nhi.z;
 }
+
+/* ============================================================================
+ * Point-wise helper exports (tests pin these against the reference headers)
+ * ========================================================================== */
+float kfo_trilinear(const kfo_volume* vol, const float pos_w[3])
+{
+    return trilinear_clamped(vol, mk3(pos_w[0], pos_w[1], pos_w[2]), NULL);
+}
+void kfo_gradient(const kfo_volume* vol, const float pos_w[3], float out[3])
+{
+    const f3 g = units_backward_diff(vol, mk3(pos_w[0], pos_w[1], pos_w[2]), NULL);
+    out[0] = g.x; out[1] = g.y; out[2] = g.z;
+}
+void kfo_sdf_accumulate(float val, float w, float old_val, float old_w, float max_w, float out[2])
+{
+    /* Sdf.h:25-32 then :22-24 */
+    if (old_w > 0) {
+        val = (w * val + old_w * old_val);
+        w += old_w;
+        val /= w;
+    }
+    w = fminf(w, max_w);
+    out[0] = val; out[1] = w;
+}
+void kfo_intrinsics_level(float out[4], const float K[4], int level) /* ImageIntrinsics.h:137-142 */
+{
+    const float scale = 1.0f / (float)(1 << level);
+    out[0] = scale * FU; out[1] = scale * FV;
+    out[2] = scale * (U0 + 0.5f) - 0.5f; out[3] = scale * (V0 + 0.5f) - 0.5f;
+}
+void kfo_voxel_position(const kfo_volume* vol, int x, int y, int z, float out[3])
+{
+    const f3 p = voxel_position(vol, x, y, z);
+    out[0] = p.x; out[1] = p.y; out[2] = p.z;
+}

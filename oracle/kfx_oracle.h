@@ -115,6 +115,16 @@ void kfo_sub_bounding_volume(kfo_volume* out, const kfo_volume* vol, const float
 /* SE3inv (MatUtils.h:202-214) */
 void kfo_se3_inverse(float out[12], const float T[12]);
 
+/* Point-wise helpers (exposed so tests can pin them against the reference headers):
+ * GetUnitsTrilinearClamped (BoundedVolume.h:93-98), GetUnitsBackwardDiffDxDyDz (:100-106),
+ * SDF_t::operator+= + LimitWeight (Sdf.h:22-32), ImageIntrinsics::operator[] (ImageIntrinsics.h:137-142),
+ * VoxelPositionInUnits (BoundedVolume.h:115-125). */
+float kfo_trilinear(const kfo_volume* vol, const float pos_w[3]);
+void kfo_gradient(const kfo_volume* vol, const float pos_w[3], float out[3]);
+void kfo_sdf_accumulate(float val, float w, float old_val, float old_w, float max_w, float out[2]);
+void kfo_intrinsics_level(float out[4], const float K[4], int level);
+void kfo_voxel_position(const kfo_volume* vol, int x, int y, int z, float out[3]);
+
 int kfo_max_threads(void);
 
 #ifdef __cplusplus

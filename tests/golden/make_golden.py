@@ -1,0 +1,218 @@
+#!/usr/bin/env python3
+"""Generates the committed golden fixtures under tests/golden/ -- run in the BUILD container,
+where /root/reference exists:
+
+    make -C oracle all ref && python tests/golden/make_golden.py
+
+Producers (recorded per array in each .npz under the key `producers`):
+  * "ref"    -- the reference's own header code compiled in place (oracle/_ref/libkfx_refhdr.so,
+                see oracle/ref_harness.cpp): voxel positions, SE3/pinhole maths, bilinear/trilinear
+                sampling, gradient stencil, SDF_t running average, ROI helpers.
+  * "oracle" -- the plain-C restatement (oracle/kfx_oracle.c), for the pieces that only exist
+                inside the reference's .cu kernels (bilateral weights, NormalsFromVbo, PhongShade).
+The fixtures are data only: inputs and expected outputs.  No reference source text is stored.
+"""
+import ctypes as C
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import oracle  # noqa: E402
+from kangaroo_amd import scenes  # noqa: E402
+
+REF_SO = os.path.join(ROOT, "oracle", "_ref", "libkfx_refhdr.so")
+PF = C.POINTER(C.c_float)
+
+
+def fp(a):
+    a = np.ascontiguousarray(a, np.float32).reshape(-1)
+    return a, a.ctypes.data_as(PF)
+
+
+def load_ref():
+    R = C.CDLL(REF_SO)
+    R.ref_sdf_fuse.restype = C.c_uint64
+    R.ref_trilinear.restype = C.c_float
+    return R
+
+
+def chain_fixture(R, name, scene, N, w, h, n_frames, dims=None, subpix=True, holes=False, roi=False):
+    """Multi-frame fuse + raycast: volume and raycast geometry from the reference headers."""
+    K = scenes.intrinsics(w, h)
+    bmin, bmax, near, far = scenes.SCENES[scene]
+    dims = dims or (N, N, N)
+    vol = oracle.Volume(dims[0], dims[1], dims[2], bmin, bmax)
+    oracle.sdf_reset(vol, float("nan"))
+    tr = scenes.trunc_dist(bmin, bmax, dims)
+    out = {}
+    prod = {}
+    poses, n_upd = [], []
+    for i in range(n_frames):
+        T_wc = scenes.orbit_pose(i, 8)
+        raw = scenes.render_depth(scene, w, h, T_wc, K)
+        if holes:  # invalid measurements: NaN blocks and a below-minval (0.2 m) stripe
+            raw[10:20, 30:45] = np.nan
+            raw[40:44, :] = 0.1
+        d = oracle.Image.from_numpy(raw)
+        f = oracle.Image(w, h)
+        vbo = oracle.Image(w, h, channels=4)
+        nrm = oracle.Image(w, h, channels=4)
+        oracle.bilateral(f, d, 1.5, 0.1, 3, 0.2)
+        _, k = fp(K)
+        R.ref_depth_to_vbo(vbo.ref(), f.ref(), k, C.c_float(1.0))
+        oracle.normals_from_vbo(nrm, vbo)
+        T_cw = scenes.se3_inverse(T_wc)
+        _, t = fp(T_cw)
+        work = vol
+        if roi:  # the application's ROI view: SubBoundingVolume(FitToFrustum), main.cpp:275-276
+            lo, hi = (C.c_float * 3)(), (C.c_float * 3)()
+            _, twc = fp(T_wc)
+            R.ref_fit_to_frustum(lo, hi, twc, C.c_float(w), C.c_float(h), k, C.c_float(2.2), C.c_float(3.3))
+            sub = oracle.KfoVolume()
+            R.ref_sub_bounding_volume(C.byref(sub), vol.ref(), lo, hi)
+            work = oracle.SubVolume(vol, sub)
+            out["roi_origin_%d" % i] = np.array(work.origin, np.int32)
+            out["roi_dims_%d" % i] = np.array([work.w, work.h, work.d], np.int32)
+            out["roi_boxmin_%d" % i] = work.boxmin
+            out["roi_boxmax_%d" % i] = work.boxmax
+            out["roi_frustum_%d" % i] = np.array(list(lo) + list(hi), np.float32)
+            for key in ("roi_origin_%d", "roi_dims_%d", "roi_boxmin_%d", "roi_boxmax_%d", "roi_frustum_%d"):
+                prod[key % i] = "ref"
+        n = R.ref_sdf_fuse(work.ref(), f.ref(), nrm.ref(), t, k, C.c_float(tr), C.c_float(scenes.MAX_W),
+                           C.c_float(scenes.MIN_COS_THETA), 0)
+        out["raw_%d" % i] = raw; prod["raw_%d" % i] = "input"
+        out["filtered_%d" % i] = f.data.copy(); prod["filtered_%d" % i] = "oracle"
+        out["vbo_%d" % i] = vbo.data.copy(); prod["vbo_%d" % i] = "ref"
+        out["normals_%d" % i] = nrm.data.copy(); prod["normals_%d" % i] = "oracle"
+        poses.append(T_wc)
+        n_upd.append(int(n))
+    out["volume"] = vol.data.copy(); prod["volume"] = "ref"
+    # raycast from the last pose: geometry by the reference headers, shading by the oracle
+    T_wc = poses[-1]
+    rd, rn = oracle.Image(w, h), oracle.Image(w, h, channels=4)
+    _, t = fp(T_wc)
+    _, k = fp(K)
+    R.ref_raycast_geom(rd.ref(), rn.ref(), vol.ref(), t, k, C.c_float(near), C.c_float(far), C.c_float(tr),
+                       1 if subpix else 0)
+    od, on, oi = oracle.Image(w, h), oracle.Image(w, h, channels=4), oracle.Image(w, h)
+    st = oracle.raycast_sdf(od, on, oi, vol, T_wc, K, near, far, tr, subpix)
+    assert np.array_equal(od.data, rd.data, equal_nan=True) and np.array_equal(on.data, rn.data), \
+        "oracle raycast disagrees with the reference-header raycast"
+    out["ray_depth"] = rd.data.copy(); prod["ray_depth"] = "ref"
+    out["ray_norm"] = rn.data.copy(); prod["ray_norm"] = "ref"
+    out["ray_img"] = oi.data.copy(); prod["ray_img"] = "oracle"
+    out["poses"] = np.stack(poses); prod["poses"] = "input"
+    meta = dict(scene=scene, dims=list(dims), w=w, h=h, n_frames=n_frames, K=K.tolist(), boxmin=list(bmin),
+                boxmax=list(bmax), near=near, far=far, trunc=tr, max_w=scenes.MAX_W, mincostheta=scenes.MIN_COS_THETA,
+                subpix=bool(subpix), n_updated=n_upd, raycast_stats={k_: int(v) for k_, v in st.items()},
+                bilateral=scenes.BILATERAL)
+    out["meta"] = np.array(json.dumps(meta))
+    out["producers"] = np.array(json.dumps(prod))
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print("%-28s %8.1f KiB  updated=%s hits=%d" % (name + ".npz", os.path.getsize(path) / 1024, n_upd, st["hits"]))
+
+
+def sphere_fixture(R, name, N, w, h, trunc):
+    """The reference's own synthetic test volume (examples/Raycast.cpp:58,66): SdfSphere + RaycastSdf."""
+    K = scenes.intrinsics(w, h)
+    vol = oracle.Volume(N, N, N, (-1, -1, -1), (1, 1, 1))
+    oracle.sdf_reset(vol, float("nan"))
+    # SdfSphere via reference VoxelPositionInUnits + oracle length/sub (the kernel body is .cu-only)
+    oracle.sdf_sphere(vol, (0.05, -0.1, 0.0), 0.7)
+    pos = (C.c_float * 3)()
+    for (x, y, z) in ((0, 0, 0), (N - 1, N - 1, N - 1), (5, 17, 9), (N // 2, 3, N - 2)):
+        R.ref_voxel_position(vol.ref(), x, y, z, pos)
+        p = np.array(list(pos), np.float32)
+        c = np.array([0.05, -0.1, 0.0], np.float32)
+        d = (p - c).astype(np.float32)
+        dist = np.sqrt(np.float32(np.float32(d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]))
+        assert vol.data[z, y, x, 0] == np.float32(dist - np.float32(0.7)), (x, y, z)
+    T_wc = np.array([[1, 0, 0, 0.1], [0, 1, 0, -0.05], [0, 0, 1, -2.5]], np.float32)
+    rd, rn = oracle.Image(w, h), oracle.Image(w, h, channels=4)
+    _, t = fp(T_wc)
+    _, k = fp(K)
+    R.ref_raycast_geom(rd.ref(), rn.ref(), vol.ref(), t, k, C.c_float(0.1), C.c_float(10.0), C.c_float(trunc), 1)
+    od, on, oi = oracle.Image(w, h), oracle.Image(w, h, channels=4), oracle.Image(w, h)
+    st = oracle.raycast_sdf(od, on, oi, vol, T_wc, K, 0.1, 10.0, trunc, True)
+    assert np.array_equal(od.data, rd.data, equal_nan=True) and np.array_equal(on.data, rn.data)
+    meta = dict(dims=[N, N, N], w=w, h=h, K=K.tolist(), boxmin=[-1, -1, -1], boxmax=[1, 1, 1], near=0.1, far=10.0,
+                trunc=trunc, center=[0.05, -0.1, 0.0], r=0.7, raycast_stats={k_: int(v) for k_, v in st.items()})
+    prod = dict(volume="oracle(+ref voxel positions spot-checked)", ray_depth="ref", ray_norm="ref", ray_img="oracle")
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, volume=vol.data.copy(), T_wc=T_wc, ray_depth=rd.data.copy(), ray_norm=rn.data.copy(),
+                        ray_img=oi.data.copy(), meta=np.array(json.dumps(meta)), producers=np.array(json.dumps(prod)))
+    print("%-28s %8.1f KiB  hits=%d" % (name + ".npz", os.path.getsize(path) / 1024, st["hits"]))
+
+
+def helper_vectors(R, name):
+    """Known-answer vectors of the reference's header helpers on seeded random inputs."""
+    rng = np.random.default_rng(1234)
+    out = {}
+    # SDF_t::operator+= / LimitWeight
+    n = 512
+    a = rng.uniform(-0.05, 0.05, n).astype(np.float32)
+    w = rng.uniform(0.01, 3.0, n).astype(np.float32)
+    ov = rng.uniform(-0.05, 0.05, n).astype(np.float32)
+    ow = rng.uniform(-1.0, 1200.0, n).astype(np.float32)
+    ov[::7] = np.nan
+    ow[::7] = 0.0
+    res = np.zeros((n, 2), np.float32)
+    o2 = (C.c_float * 2)()
+    for i in range(n):
+        R.ref_sdf_accumulate(C.c_float(a[i]), C.c_float(w[i]), C.c_float(ov[i]), C.c_float(ow[i]), C.c_float(1000.0), o2)
+        res[i] = (o2[0], o2[1])
+    out.update(acc_val=a, acc_w=w, acc_old_val=ov, acc_old_w=ow, acc_out=res)
+    # trilinear / gradient at random positions (inside and outside the box) of a random volume
+    N = 12
+    vol = oracle.Volume(N, N + 1, N + 2, (-0.5, -0.25, 1.0), (0.75, 0.5, 2.5))
+    vol.data[...] = rng.normal(0, 1, vol.data.shape).astype(np.float32)
+    pos = rng.uniform([-0.7, -0.4, 0.8], [0.9, 0.7, 2.7], (400, 3)).astype(np.float32)
+    tri = np.zeros(400, np.float32)
+    grad = np.zeros((400, 3), np.float32)
+    g3 = (C.c_float * 3)()
+    for i in range(400):
+        _, p = fp(pos[i])
+        tri[i] = R.ref_trilinear(vol.ref(), p)
+        R.ref_backward_diff(vol.ref(), p, g3)
+        grad[i] = list(g3)
+    out.update(samp_volume=vol.data.copy(), samp_boxmin=vol.boxmin, samp_boxmax=vol.boxmax, samp_pos=pos,
+               samp_trilinear=tri, samp_gradient=grad)
+    # SE3inv, pyramid intrinsics
+    T = scenes.orbit_pose(3, 8)
+    o12 = (C.c_float * 12)()
+    _, t = fp(T)
+    R.ref_se3_inverse(o12, t)
+    out.update(se3_in=T, se3_out=np.array(list(o12), np.float32).reshape(3, 4))
+    K = scenes.intrinsics(640, 480)
+    _, k = fp(K)
+    o4 = (C.c_float * 4)()
+    lv = []
+    for l in range(4):
+        R.ref_intrinsics_level(o4, k, l)
+        lv.append(list(o4))
+    out.update(K=K, K_levels=np.array(lv, np.float32))
+    sz = (C.c_size_t * 8)()
+    R.ref_sizeof(sz)
+    out["sizeof"] = np.array(list(sz), np.int64)  # Image, Volume, BoundedVolume, SDF_t, Mat3x4, Intrinsics, BoundingBox, float4
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print("%-28s %8.1f KiB" % (name + ".npz", os.path.getsize(path) / 1024))
+
+
+if __name__ == "__main__":
+    if not os.path.exists(REF_SO):
+        sys.exit("build oracle/_ref first: make -C oracle ref")
+    R = load_ref()
+    chain_fixture(R, "room32_3frames", "room", 32, 80, 60, 3)
+    chain_fixture(R, "full32_holes", "full", 32, 80, 60, 2, holes=True)
+    chain_fixture(R, "room_ragged_roi", "room", 0, 80, 60, 2, dims=(40, 36, 44), roi=True, subpix=False)
+    sphere_fixture(R, "sphere32_trunc0", 32, 64, 48, 0.0)
+    helper_vectors(R, "ref_helper_vectors")

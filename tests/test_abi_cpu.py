@@ -1,0 +1,87 @@
+"""CPU-side checks of the drop-in boundary: libkfx.so loads without a GPU, exports every
+symbol include/kfx.h declares, mirrors the reference container layouts, and rejects bad
+arguments before touching the device (no compute calls here)."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+
+import kfx_testlib as T
+from kangaroo_amd import _lib
+
+HEADER = os.path.join(T.ROOT, "include", "kfx.h")
+
+
+def declared_symbols():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(kfx_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    L = _lib.load()
+    names = declared_symbols()
+    assert len(names) >= 18
+    for n in names:
+        assert hasattr(L, n), "libkfx.so does not export %s" % n
+        assert n in _lib.SIGNATURES, "python binding missing for %s" % n
+    out = subprocess.check_output(["nm", "-D", "--defined-only", _lib.LIB_PATH]).decode()
+    exported = set(re.findall(r" T (kfx_[a-z0-9_]+)", out))
+    assert set(names) <= exported
+
+
+def test_library_contains_gfx950_code_object():
+    blob = open(_lib.LIB_PATH, "rb").read()
+    assert b"gfx950" in blob and b"k_sdf_fuse" in blob and b"k_raycast_sdf" in blob
+
+
+def test_struct_layouts_match_reference_containers():
+    z = np.load(os.path.join(T.GOLDEN, "ref_helper_vectors.npz"))
+    sizeof = z["sizeof"].tolist()  # measured on the reference headers by make_golden.py
+    assert C.sizeof(_lib.KfxImage) == sizeof[0] == 32
+    assert C.sizeof(_lib.KfxVolume) == sizeof[2] == 72
+    assert _lib.KfxImage.pitch.offset == 0 and _lib.KfxImage.ptr.offset == 8
+    assert _lib.KfxImage.w.offset == 16 and _lib.KfxImage.h.offset == 24
+    assert _lib.KfxVolume.img_pitch.offset == 32 and _lib.KfxVolume.d.offset == 40
+    assert _lib.KfxVolume.boxmin.offset == 48 and _lib.KfxVolume.boxmax.offset == 60
+
+
+def test_argument_errors_are_reported_not_fatal():
+    L = _lib.load()
+    assert L.kfx_version() == 1
+    K = (C.c_float * 4)(500, 500, 31.5, 23.5)
+    Tm = (C.c_float * 12)(1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0)
+    vol = _lib.KfxVolume(0, None, 8, 8, 0, 8)
+    img = _lib.KfxImage(0, None, 8, 8)
+    assert L.kfx_sdf_fuse(C.byref(vol), C.byref(img), C.byref(img), Tm, K, 0.1, 100.0, 0.1, 0, None) == -1
+    assert b"KFX_E_NULL" in L.kfx_last_error_string()
+    assert L.kfx_raycast_sdf(None, None, None, None, Tm, K, 0.1, 1.0, 0.1, 1, None) == -1
+    assert L.kfx_normals_from_vbo(C.byref(img), C.byref(img), None) == -1
+    assert L.kfx_bilateral_f32(C.byref(img), C.byref(img), 1.5, 0.1, 3, 0.2, 1, None) == -1
+    # misaligned / undersized pitch on a fake non-null pointer: rejected before any launch
+    bad = _lib.KfxVolume(60, 0x1000, 8, 8, 480, 8)
+    assert L.kfx_sdf_reset(C.byref(bad), 0.0, None) == -2
+    bad2 = _lib.KfxVolume(68, 0x1000, 8, 8, 68 * 8, 8)
+    assert L.kfx_sdf_reset(C.byref(bad2), 0.0, None) == -3
+    assert L.kfx_error_name(-3) == b"KFX_E_ALIGN" and L.kfx_error_name(0) == b"ok"
+    p, pitch = C.c_void_p(), C.c_size_t()
+    assert L.kfx_alloc_pitched(C.byref(p), C.byref(pitch), 0, 4) == -2
+    assert L.kfx_free(None) == 0
+
+
+def test_product_never_imports_the_oracle():
+    """The product path must not route through oracle/ (tier rule 3)."""
+    pkg = os.path.join(T.ROOT, "kangaroo_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(dp, f)).read()
+                assert not re.search(r'#\s*include\s*[<"][^>"]*oracle', txt), f
+                assert not re.search(r"^\s*(import|from)\s+oracle\b", txt, flags=re.M), f
+                assert "libkfx_oracle" not in txt and "libkfx_refhdr" not in txt, f
+    for f in os.listdir(os.path.join(T.ROOT, "include")):
+        p = os.path.join(T.ROOT, "include", f)
+        if os.path.isfile(p):
+            assert not re.search(r'#\s*include\s*[<"][^>"]*oracle', open(p).read())

@@ -1,0 +1,216 @@
+"""CPU tests of the parity oracle: it must reproduce every committed golden vector (generated
+from the reference's own header code, tests/golden/make_golden.py) bit for bit, and -- when
+oracle/_ref is present (build container / GPU box snapshot) -- agree with the reference
+headers on fresh seeded inputs."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+import kfx_testlib as T
+from kfx_testlib import oracle, scenes
+
+REF_SO = os.path.join(T.ROOT, "oracle", "_ref", "libkfx_refhdr.so")
+
+
+def load_golden(name):
+    z = np.load(os.path.join(T.GOLDEN, name + ".npz"))
+    return z, json.loads(str(z["meta"])) if "meta" in z else None
+
+
+def replay_chain(z, m, fuse=None, raycast=None):
+    """Re-run fuse+raycast from the fixture's inputs with the oracle (or given callables)."""
+    dims = m["dims"]
+    vol = oracle.Volume(dims[0], dims[1], dims[2], m["boxmin"], m["boxmax"])
+    oracle.sdf_reset(vol, float("nan"))
+    K = np.array(m["K"], np.float32)
+    for i in range(m["n_frames"]):
+        f = oracle.Image.from_numpy(z["filtered_%d" % i])
+        nrm = oracle.Image.from_numpy(z["normals_%d" % i])
+        T_cw = scenes.se3_inverse(z["poses"][i])
+        work = vol
+        if "roi_frustum_%d" % i in z:
+            fr = z["roi_frustum_%d" % i]
+            work = oracle.sub_bounding_volume(vol, fr[:3], fr[3:])
+            assert list(work.origin) == z["roi_origin_%d" % i].tolist()
+            assert [work.w, work.h, work.d] == z["roi_dims_%d" % i].tolist()
+            assert np.array_equal(work.boxmin, z["roi_boxmin_%d" % i])
+            assert np.array_equal(work.boxmax, z["roi_boxmax_%d" % i])
+        n = oracle.sdf_fuse(work, f, nrm, T_cw, K, m["trunc"], m["max_w"], m["mincostheta"])
+        assert n == m["n_updated"][i]
+    return vol, K
+
+
+@pytest.mark.parametrize("name", ["room32_3frames", "full32_holes", "room_ragged_roi"])
+def test_oracle_reproduces_golden_chain(name):
+    z, m = load_golden(name)
+    vol, K = replay_chain(z, m)
+    assert T.nan_equal(vol.data, z["volume"]), T.mismatch_report(vol.data, z["volume"])
+    w, h = m["w"], m["h"]
+    rd, rn, ri = oracle.Image(w, h), oracle.Image(w, h, channels=4), oracle.Image(w, h)
+    st = oracle.raycast_sdf(rd, rn, ri, vol, z["poses"][-1], K, m["near"], m["far"], m["trunc"], m["subpix"])
+    assert T.nan_equal(rd.data, z["ray_depth"])
+    assert T.nan_equal(rn.data, z["ray_norm"])
+    assert T.nan_equal(ri.data, z["ray_img"])
+    assert st == m["raycast_stats"]
+
+
+def test_oracle_preprocess_matches_golden():
+    z, m = load_golden("room32_3frames")
+    K = np.array(m["K"], np.float32)
+    b = m["bilateral"]
+    for i in range(m["n_frames"]):
+        f, vbo, nrm = T.preprocess_oracle(z["raw_%d" % i], K, b)
+        assert T.nan_equal(f.data, z["filtered_%d" % i])
+        assert T.nan_equal(vbo.data, z["vbo_%d" % i])      # producer: reference Unproject
+        assert T.nan_equal(nrm.data, z["normals_%d" % i])
+
+
+def test_oracle_sphere_golden():
+    z, m = load_golden("sphere32_trunc0")
+    N = m["dims"][0]
+    vol = oracle.Volume(N, N, N, m["boxmin"], m["boxmax"])
+    oracle.sdf_reset(vol, float("nan"))
+    oracle.sdf_sphere(vol, m["center"], m["r"])
+    assert T.nan_equal(vol.data, z["volume"])
+    w, h = m["w"], m["h"]
+    rd, rn, ri = oracle.Image(w, h), oracle.Image(w, h, channels=4), oracle.Image(w, h)
+    oracle.raycast_sdf(rd, rn, ri, vol, z["T_wc"], np.array(m["K"], np.float32), m["near"], m["far"], m["trunc"], True)
+    assert T.nan_equal(rd.data, z["ray_depth"]) and T.nan_equal(rn.data, z["ray_norm"]) and T.nan_equal(ri.data, z["ray_img"])
+    # analytic check: hit depth close to the true sphere (|c - o| - r along the central ray)
+    hits = np.isfinite(rd.data)
+    assert hits.sum() == m["raycast_stats"]["hits"] > 500
+
+
+def test_oracle_helper_vectors():
+    z, _ = load_golden("ref_helper_vectors")
+    # layouts the C-ABI mirrors: Image 32, Volume 48, BoundedVolume 72, SDF_t 8, Mat3x4 48, K 16, BBox 24, float4 16
+    assert z["sizeof"].tolist() == [32, 48, 72, 8, 48, 16, 24, 16]
+    assert C.sizeof(oracle.KfoImage) == 32 and C.sizeof(oracle.KfoVolume) == 72
+    for i in range(len(z["acc_val"])):
+        got = oracle.sdf_accumulate(z["acc_val"][i], z["acc_w"][i], z["acc_old_val"][i], z["acc_old_w"][i], 1000.0)
+        assert T.nan_equal(got, z["acc_out"][i]), i
+    v = z["samp_volume"]
+    vol = oracle.Volume(v.shape[2], v.shape[1], v.shape[0], z["samp_boxmin"], z["samp_boxmax"])
+    vol.data[...] = v
+    for i, p in enumerate(z["samp_pos"]):
+        assert np.float32(oracle.trilinear(vol, p)) == z["samp_trilinear"][i], i
+        assert np.array_equal(oracle.gradient(vol, p), z["samp_gradient"][i]), i
+    assert np.array_equal(oracle.se3_inverse(z["se3_in"]), z["se3_out"])
+    assert np.array_equal(scenes.se3_inverse(z["se3_in"]), z["se3_out"])
+    for l in range(4):
+        assert np.array_equal(oracle.intrinsics_level(z["K"], l), z["K_levels"][l])
+        assert np.array_equal(scenes.intrinsics_level(z["K"], l), z["K_levels"][l])
+
+
+@pytest.mark.skipif(not os.path.exists(REF_SO), reason="oracle/_ref not built (needs /root/reference)")
+def test_oracle_vs_reference_headers_fresh_seed():
+    """Bit-equality of the restatement with the reference's compiled headers on inputs that are
+    not in the committed fixtures (different size, poses, padded pitches)."""
+    R = C.CDLL(REF_SO)
+    R.ref_sdf_fuse.restype = C.c_uint64
+    PF = C.POINTER(C.c_float)
+
+    def fp(a):
+        a = np.ascontiguousarray(a, np.float32).reshape(-1)
+        return a, a.ctypes.data_as(PF)
+
+    w, h, dims = 96, 72, (48, 40, 56)
+    K = scenes.intrinsics(w, h)
+    bmin, bmax, near, far = scenes.SCENES["room"]
+    tr = scenes.trunc_dist(bmin, bmax, dims)
+    vols = []
+    for which in ("oracle", "ref"):
+        vol = oracle.Volume(dims[0], dims[1], dims[2], bmin, bmax, pitch_bytes=dims[0] * 8 + 64)
+        oracle.sdf_reset(vol, float("nan"))
+        for i in (1, 5, 6):
+            T_wc = scenes.orbit_pose(i, 12, yaw_deg=9.0, trans=0.08)
+            raw = scenes.render_depth("room", w, h, T_wc, K, noise_sigma=0.002, seed=77 + i)
+            f, vbo, nrm = T.preprocess_oracle(raw, K)
+            T_cw = scenes.se3_inverse(T_wc)
+            if which == "oracle":
+                oracle.sdf_fuse(vol, f, nrm, T_cw, K, tr, 1000.0, 0.1, full_extent=True)
+            else:
+                _, t = fp(T_cw)
+                _, k = fp(K)
+                R.ref_sdf_fuse(vol.ref(), f.ref(), nrm.ref(), t, k, C.c_float(tr), C.c_float(1000.0), C.c_float(0.1), 1)
+        rd, rn, ri = oracle.Image(w, h), oracle.Image(w, h, channels=4), oracle.Image(w, h)
+        if which == "oracle":
+            oracle.raycast_sdf(rd, rn, ri, vol, T_wc, K, near, far, tr, True)
+        else:
+            _, t = fp(T_wc)
+            _, k = fp(K)
+            R.ref_raycast_geom(rd.ref(), rn.ref(), vol.ref(), t, k, C.c_float(near), C.c_float(far), C.c_float(tr), 1)
+        vols.append((vol.data.copy(), rd.data.copy(), rn.data.copy()))
+    assert T.nan_equal(vols[0][0], vols[1][0]), T.mismatch_report(vols[0][0], vols[1][0])
+    assert T.nan_equal(vols[0][1], vols[1][1])
+    assert T.nan_equal(vols[0][2], vols[1][2])
+
+
+def test_oracle_threads_do_not_change_results():
+    vol1, vol2 = T.make_volume(32, "room"), T.make_volume(32, "room")
+    T.fuse_frames_oracle(vol1, "room", 80, 60, 2, nthreads=1)
+    T.fuse_frames_oracle(vol2, "room", 80, 60, 2, nthreads=4)
+    assert T.nan_equal(vol1.data, vol2.data)
+
+
+def test_oracle_quirks():
+    # Q1: dims not multiple of 8 leave the tail untouched unless full_extent
+    vol = T.make_volume(0, "full", dims=(20, 17, 13))
+    K, tr, fr = T.fuse_frames_oracle(vol, "full", 80, 60, 1)
+    upd = ~np.isnan(vol.data[..., 0])
+    assert upd[:8, :16, :16].all() and not upd[8:].any() and not upd[:, 16:].any() and not upd[:, :, 16:].any()
+    vol2 = T.make_volume(0, "full", dims=(20, 17, 13))
+    T.fuse_frames_oracle(vol2, "full", 80, 60, 1, full_extent=True)
+    assert (~np.isnan(vol2.data[..., 0])).all()
+    # Q3: first observation overwrites the (NaN, 0) state; second averages and adds weights
+    v = T.make_volume(16, "full")
+    K, tr, f1 = T.fuse_frames_oracle(v, "full", 80, 60, 1, n_orbit=1)
+    a = v.data.copy()
+    T.fuse_frames_oracle(v, "full", 80, 60, 1, n_orbit=1)
+    b = v.data
+    assert np.allclose(b[..., 1], 2 * a[..., 1], rtol=1e-6) and np.allclose(b[..., 0], a[..., 0], atol=1e-6)
+    # SdfReset fills the pitch padding too (thrust::fill over the contiguous span)
+    pv = oracle.Volume(10, 9, 8, pitch_bytes=10 * 8 + 48)
+    oracle.sdf_reset(pv, 0.25)
+    raw = pv.raw.view(np.float32)
+    span = ((pv.d - 1) * pv.img_pitch + (pv.h - 1) * pv.pitch + pv.w * 8) // 4
+    assert (raw[0:span:2] == 0.25).all() and (raw[1:span:2] == 0).all() and (raw[span:] == 0).all()
+
+
+def test_oracle_raycast_recovers_scene_depth():
+    """Fuse then raycast reproduces the input depth (the reference's own visual check,
+    applications/examples/SdfFusion.cpp:130-135): mean |d - gt| well below a voxel."""
+    vol = T.make_volume(64, "room")
+    K, tr, fr = T.fuse_frames_oracle(vol, "room", 160, 120, 1, n_orbit=1)
+    rd, rn, ri = oracle.Image(160, 120), oracle.Image(160, 120, channels=4), oracle.Image(160, 120)
+    st = oracle.raycast_sdf(rd, rn, ri, vol, fr[0]["T_wc"], K, 0.4, 8.0, tr, True)
+    err = np.abs(rd.data - fr[0]["raw"])
+    m = np.isfinite(err)
+    assert st["hits"] > 0.5 * 160 * 120 and np.median(err[m]) < 0.5 * vol.voxel_size()[0]
+    n = rn.data[np.isfinite(rd.data)]
+    assert np.allclose(np.linalg.norm(n[:, :3], axis=1), 1.0, atol=1e-5) and (n[:, 3] == 1).all()
+    miss = ~np.isfinite(rd.data)
+    assert (rn.data[miss] == 0).all() and (ri.data[miss] == 0).all()
+
+
+def test_analytic_renderers_and_roi():
+    w, h = 64, 48
+    K = scenes.intrinsics(w, h)
+    Tid = scenes.identity_pose()
+    d = oracle.Image(w, h)
+    oracle.raycast_box(d, Tid, K, (-0.5, -0.5, 2.0), (0.5, 0.5, 3.0))
+    c = d.data[h // 2, w // 2]
+    assert c == np.float32(2.0) and np.isnan(d.data[0, 0])
+    oracle.raycast_sphere(d, None, Tid, K, (0, 0, 2.0), 0.25)
+    assert abs(d.data[h // 2, w // 2] - 1.75) < 1e-3
+    lo, hi = oracle.fit_to_frustum(Tid, w, h, K, 0.4, 4.0)
+    assert lo[2] == np.float32(0.4) and hi[2] == np.float32(4.0) and lo[0] < 0 < hi[0]
+    vol = oracle.Volume(32, 32, 32, (-1, -1, 0), (1, 1, 4))
+    sub = oracle.sub_bounding_volume(vol, (-0.3, -0.2, 1.0), (0.4, 0.9, 2.0))
+    x0, y0, z0 = sub.origin
+    assert np.array_equal(sub.boxmin, oracle.voxel_position(vol, x0, y0, z0))
+    assert np.array_equal(sub.boxmax, oracle.voxel_position(vol, x0 + sub.w - 1, y0 + sub.h - 1, z0 + sub.d - 1))
+    assert sub.boxmin[0] <= -0.3 + 2 / 31 and sub.boxmax[0] >= 0.4
