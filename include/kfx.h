@@ -147,6 +147,18 @@ int kfx_memcpy_2d(void* dst, size_t dpitch, const void* src, size_t spitch, size
                   size_t rows, int kind, kfx_stream stream);
 int kfx_stream_synchronize(kfx_stream stream);
 
+/* ---- numerics mode --------------------------------------------------------------- */
+/* KFX_MATH_EXACT (default): IEEE fp32, no FMA contraction, correctly rounded div/sqrt, reference
+ * operation order -- bit-identical to the CPU oracle.  KFX_MATH_FAST: hardware rcp/rsq (1 ulp),
+ * FMA, shared reciprocals -- the regime of the reference's own build (-use_fast_math,
+ * CMakeLists.txt:141); within the stated tolerance (TSDF L-inf < 1e-4), not bit-exact.
+ * Process-global; initial value from the environment variable KFX_MATH=exact|fast.
+ * Currently affects kfx_sdf_fuse and kfx_raycast_sdf. */
+#define KFX_MATH_EXACT 0
+#define KFX_MATH_FAST  1
+int kfx_set_math_mode(int mode); /* returns the previous mode, or KFX_E_RANGE */
+int kfx_get_math_mode(void);
+
 /* ---- diagnostics --------------------------------------------------------------- */
 const char* kfx_last_error_string(void); /* thread-local, never NULL */
 const char* kfx_error_name(int code);    /* hipGetErrorString for >0, KFX_E_* names for <0 */

@@ -50,6 +50,8 @@ SIGNATURES = {
     "kfx_stream_synchronize": (C.c_int, [C.c_void_p]),
     "kfx_last_error_string": (C.c_char_p, []),
     "kfx_error_name": (C.c_char_p, [C.c_int]),
+    "kfx_set_math_mode": (C.c_int, [C.c_int]),
+    "kfx_get_math_mode": (C.c_int, []),
     "kfx_version": (C.c_int, []),
     "kfx_device_count": (C.c_int, []),
 }

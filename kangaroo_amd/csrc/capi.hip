@@ -1,7 +1,9 @@
 // capi.hip -- the non-kernel half of the C ABI: error reporting, the pitched device
 // allocator (roo::TargetDevice, reference Memory.h:59-84) and 2-D copies
 // (Image::CopyFrom / MemcpyFromHost / MemcpyToHost, reference Image.h:174-213).
+#include <atomic>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "kfx_device.h"
@@ -28,9 +30,22 @@ int check_launch(const char* what)
     return 0;
 }
 
+static std::atomic<int> g_math{[] {
+    const char* e = getenv("KFX_MATH");
+    return (e && (e[0] == 'f' || e[0] == 'F' || e[0] == '1')) ? KFX_MATH_FAST : KFX_MATH_EXACT;
+}()};
+int math_mode() { return g_math.load(std::memory_order_relaxed); }
+
 } // namespace kfx
 
 using namespace kfx;
+
+extern "C" int kfx_set_math_mode(int mode)
+{
+    if (mode != KFX_MATH_EXACT && mode != KFX_MATH_FAST) return set_error(KFX_E_RANGE, "kfx_set_math_mode: unknown mode");
+    return g_math.exchange(mode);
+}
+extern "C" int kfx_get_math_mode(void) { return math_mode(); }
 
 extern "C" const char* kfx_last_error_string(void) { return g_err; }
 

@@ -1,0 +1,131 @@
+// debug.hip -- measurement aids (not part of the public ABI in include/kfx.h): in-place
+// read-modify-write sweeps of a TSDF volume with no arithmetic, used to find the HBM
+// ceiling of the SdfFuse access pattern on this chip.
+#include "kfx_device.h"
+
+namespace kfx {
+
+// variant 0: linear grid-stride float4 sweep over the contiguous span
+__global__ __launch_bounds__(256) void k_rmw_linear(float4* __restrict__ base, size_t n4)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        float4 c = base[i];
+        c.y += 1.0f;
+        c.w += 1.0f;
+        base[i] = c;
+    }
+}
+
+// variant 1: the tiled fuse kernel's mapping (64 x 8 x ZC brick, 2 voxels per lane, z-march)
+template <int ZC>
+__global__ __launch_bounds__(256) void k_rmw_brick(unsigned char* vptr, size_t pitch, size_t img_pitch, int X, int Y, int Z)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int x0 = (blockIdx.x * 32 + (lane & 31)) * 2;
+    const int y = blockIdx.y * 8 + wv * 2 + (lane >> 5);
+    const int zbeg = blockIdx.z * ZC, zend = min(zbeg + ZC, Z);
+    if (x0 >= X || y >= Y) return;
+    unsigned char* cell = vptr + (size_t)zbeg * img_pitch + (size_t)y * pitch + (size_t)x0 * 8;
+    for (int z = zbeg; z < zend; ++z, cell += img_pitch) {
+        float4 c = *reinterpret_cast<const float4*>(cell);
+        c.y += 1.0f;
+        c.w += 1.0f;
+        *reinterpret_cast<float4*>(cell) = c;
+    }
+}
+
+// variant 2: the first kernels' mapping (128 x 4 x ZC brick: one wave = one 1 KiB row segment)
+template <int ZC>
+__global__ __launch_bounds__(256) void k_rmw_rows(unsigned char* vptr, size_t pitch, size_t img_pitch, int X, int Y, int Z)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int x0 = (blockIdx.x * 64 + lane) * 2;
+    const int y = blockIdx.y * 4 + wv;
+    const int zbeg = blockIdx.z * ZC, zend = min(zbeg + ZC, Z);
+    if (x0 >= X || y >= Y) return;
+    unsigned char* cell = vptr + (size_t)zbeg * img_pitch + (size_t)y * pitch + (size_t)x0 * 8;
+    for (int z = zbeg; z < zend; ++z, cell += img_pitch) {
+        float4 c = *reinterpret_cast<const float4*>(cell);
+        c.y += 1.0f;
+        c.w += 1.0f;
+        *reinterpret_cast<float4*>(cell) = c;
+    }
+}
+
+// variant 3: z-march, but each workgroup walks the WHOLE z range of its (x,y) footprint
+__global__ __launch_bounds__(256) void k_rmw_column(unsigned char* vptr, size_t pitch, size_t img_pitch, int X, int Y, int Z)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int x0 = (blockIdx.x * 64 + lane) * 2;
+    const int y = blockIdx.y * 4 + wv;
+    if (x0 >= X || y >= Y) return;
+    unsigned char* cell = vptr + (size_t)y * pitch + (size_t)x0 * 8;
+    for (int z = 0; z < Z; ++z, cell += img_pitch) {
+        float4 c = *reinterpret_cast<const float4*>(cell);
+        c.y += 1.0f;
+        c.w += 1.0f;
+        *reinterpret_cast<float4*>(cell) = c;
+    }
+}
+
+// generic: WX waves side by side along x (each 128 voxels = 1 KiB), WY rows, ZC slices, optional
+// nontemporal accesses; WX*WY = 4 waves
+typedef float v4f_dbg __attribute__((ext_vector_type(4)));
+template <int WX, int WY, int ZC, bool NT>
+__global__ __launch_bounds__(256) void k_rmw_gen(unsigned char* vptr, size_t pitch, size_t img_pitch, int X, int Y, int Z)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int x0 = ((blockIdx.x * WX + (wv % WX)) * 64 + lane) * 2;
+    const int y = blockIdx.y * WY + (wv / WX);
+    const int zbeg = blockIdx.z * ZC, zend = min(zbeg + ZC, Z);
+    if (x0 >= X || y >= Y) return;
+    unsigned char* cell = vptr + (size_t)zbeg * img_pitch + (size_t)y * pitch + (size_t)x0 * 8;
+    for (int z = zbeg; z < zend; ++z, cell += img_pitch) {
+        v4f_dbg c;
+        if constexpr (NT) c = __builtin_nontemporal_load(reinterpret_cast<const v4f_dbg*>(cell));
+        else c = *reinterpret_cast<const v4f_dbg*>(cell);
+        c.y += 1.0f;
+        c.w += 1.0f;
+        if constexpr (NT) __builtin_nontemporal_store(c, reinterpret_cast<v4f_dbg*>(cell));
+        else *reinterpret_cast<v4f_dbg*>(cell) = c;
+    }
+}
+
+} // namespace kfx
+
+using namespace kfx;
+
+extern "C" int kfx_debug_rmw(const kfx_volume* vol, int variant, kfx_stream stream)
+{
+    if (!vol || !vol->ptr) return set_error(KFX_E_NULL, "kfx_debug_rmw");
+    hipStream_t s = (hipStream_t)stream;
+    const int X = (int)vol->w, Y = (int)vol->h, Z = (int)vol->d;
+    unsigned char* p = (unsigned char*)vol->ptr;
+    switch (variant) {
+    case 0: {
+        const size_t n4 = ((vol->d - 1) * vol->img_pitch + (vol->h - 1) * vol->pitch + vol->w * 8) / 16;
+        hipLaunchKernelGGL(k_rmw_linear, dim3(256 * 8), dim3(256), 0, s, (float4*)p, n4);
+        break;
+    }
+    case 1: hipLaunchKernelGGL(k_rmw_brick<16>, dim3(ceil_div(X, 64), ceil_div(Y, 8), ceil_div(Z, 16)), dim3(256), 0, s, p, vol->pitch, vol->img_pitch, X, Y, Z); break;
+    case 2: hipLaunchKernelGGL(k_rmw_rows<16>, dim3(ceil_div(X, 128), ceil_div(Y, 4), ceil_div(Z, 16)), dim3(256), 0, s, p, vol->pitch, vol->img_pitch, X, Y, Z); break;
+    case 3: hipLaunchKernelGGL(k_rmw_column, dim3(ceil_div(X, 128), ceil_div(Y, 4), 1), dim3(256), 0, s, p, vol->pitch, vol->img_pitch, X, Y, Z); break;
+    case 4: hipLaunchKernelGGL(k_rmw_brick<64>, dim3(ceil_div(X, 64), ceil_div(Y, 8), ceil_div(Z, 64)), dim3(256), 0, s, p, vol->pitch, vol->img_pitch, X, Y, Z); break;
+    case 5: hipLaunchKernelGGL(k_rmw_rows<4>, dim3(ceil_div(X, 128), ceil_div(Y, 4), ceil_div(Z, 4)), dim3(256), 0, s, p, vol->pitch, vol->img_pitch, X, Y, Z); break;
+#define GEN(ID, WX, WY, ZC, NT) \
+    case ID: hipLaunchKernelGGL((k_rmw_gen<WX, WY, ZC, NT>), dim3(ceil_div(X, 128 * WX), ceil_div(Y, WY), ceil_div(Z, ZC)), dim3(256), 0, s, p, vol->pitch, vol->img_pitch, X, Y, Z); break;
+    GEN(10, 4, 1, 16, false)
+    GEN(11, 2, 2, 16, false)
+    GEN(12, 1, 4, 16, false)
+    GEN(13, 1, 4, 16, true)
+    GEN(14, 4, 1, 16, true)
+    GEN(15, 1, 4, 1, false)
+    GEN(16, 1, 4, 64, false)
+    GEN(17, 4, 1, 4, false)
+    GEN(18, 2, 2, 16, true)
+#undef GEN
+    default: return set_error(KFX_E_RANGE, "kfx_debug_rmw: variant");
+    }
+    return check_launch("kfx_debug_rmw");
+}

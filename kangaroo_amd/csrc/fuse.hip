@@ -2,20 +2,33 @@
 // initialisers (SdfReset, SdfSphere) for gfx950.
 //
 // Reference behaviour: src/cu_sdffusion.cu:16-61 (KernSdfFuse), :153-164 (SdfReset),
-// :175-195 (KernSdfSphere).  This is a new kernel, not a translation: the reference
-// launches (8,8,8) blocks whose warps straddle four rows; here a wave64 owns a
-// contiguous run of 128 voxels of one x-row (two voxels = one 16-byte RMW per lane,
-// 1 KiB per wave instruction), the four waves of a workgroup take four adjacent
-// y-rows, and each lane marches FUSE_ZC z-slices re-using the x/y part of the
-// world->camera transform.  The volume is touched only where the update predicate
-// holds, like the reference (cu_sdffusion.cu:44-49), so HBM traffic is
-// 16 B x updated voxels.
+// :175-195 (KernSdfSphere).  New kernels, not a translation.  The reference launches (8,8,8)
+// blocks whose warps straddle four rows and gathers depth/normals straight from global memory.
+// Here:
+//   * a lane owns two x-adjacent voxels = one 16-byte read-modify-write; a wave64 therefore
+//     moves 512 B - 1 KiB contiguous per instruction, and marches FUSE_ZC slices re-using the
+//     x/y part of the world->camera transform;
+//   * the volume is touched only where the update predicate holds, like the reference
+//     (cu_sdffusion.cu:44-49): HBM traffic is 16 B x updated voxels, streamed nontemporally;
+//   * k_sdf_fuse_tiled stages the pixel rectangle a 64 x 8 x 16 voxel brick projects into
+//     once in LDS, as {nx, ny, nz, depth} texels, and serves all bilinear lookups from LDS.
+//     Measured on MI355X (512^3, 640x480): with global gathers the vector L1 saturates
+//     (288 M line accesses per launch, 0.69 ms regardless of arithmetic); tiled: 35 M accesses.
+//   * two numerics modes (kfx_set_math_mode): exact = IEEE fp32 in the reference's operation
+//     order, bit-identical to the CPU oracle, VALU-bound (five correctly rounded divisions and
+//     a square root per voxel); fast = hardware rcp/rsq + FMA, the regime of the reference's
+//     own -use_fast_math build, memory-bound.
+// Packed v_pk_*_f32 arithmetic was tried for the exact mode and dropped: on gfx950 a packed
+// op issues in 4 cycles, twice a scalar op, so it only saves issue slots (0.755 -> 0.726 ms).
+#include <cstdlib>
+
 #include "kfx_device.h"
 
 namespace kfx {
 
-constexpr int FUSE_ZC = 16;     // z-slices marched per workgroup
-constexpr int FUSE_ROWS = 4;    // y-rows per workgroup (one per wave)
+constexpr int FUSE_ZC = 16;   // z-slices marched per workgroup
+constexpr int FUSE_ROWS = 4;  // generic kernel: y-rows per workgroup (one per wave)
+constexpr int TB_X = 64, TB_Y = 8; // tiled kernel: brick footprint (x: 32 lanes x 2 voxels, y: 4 waves x 2 half-waves)
 
 struct FuseParams {
     unsigned char* vptr;
@@ -29,6 +42,7 @@ struct FuseParams {
     ImgView norm;           // Image<float4>
     float dwb, dhb;         // (float)depth.w - 2, (float)depth.h - 2  (InBounds border, Image.h:287-291)
     float trunc, max_w, mincos;
+    unsigned dpitch, npitch; // image pitches as 32-bit values (valid when `small_images`)
 };
 
 struct Obs {
@@ -36,146 +50,394 @@ struct Obs {
     bool ok;
 };
 
-// One voxel's observation: projection, bilinear depth/normal lookup, signed distance
-// and weight (cu_sdffusion.cu:22-44).  No volume access.
+// {nx, ny, nz, depth} at the four corners of a bilinear cell: (ix,iy) (ix+1,iy) (ix,iy+1) (ix+1,iy+1)
+struct Corners { float4 c00, c01, c10, c11; };
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float lerp_f(float a, float b, float t) { return __builtin_fmaf(t, b - a, a); }
+
+// ---- camera-frame position of a voxel --------------------------------------------------
+// BoundedVolume::VoxelPositionInUnits (BoundedVolume.h:115-125) then T_cw * P_w
+// (MatUtils.h:117-125).  The x/y terms are hoisted out of the z-march; in exact mode they are
+// the leading partial sum T(i,0)*x + T(i,1)*y of the reference expression, so the association
+// is unchanged.
+template <bool FAST>
+struct CamXY {
+    float ax, ay, az;
+    __device__ __forceinline__ void init(const FuseParams& p, float px, float py)
+    {
+        if constexpr (FAST) {
+            ax = __builtin_fmaf(p.T.m[0], px, __builtin_fmaf(p.T.m[1], py, p.T.m[3]));
+            ay = __builtin_fmaf(p.T.m[4], px, __builtin_fmaf(p.T.m[5], py, p.T.m[7]));
+            az = __builtin_fmaf(p.T.m[8], px, __builtin_fmaf(p.T.m[9], py, p.T.m[11]));
+        } else {
+            ax = p.T.m[0] * px + p.T.m[1] * py;
+            ay = p.T.m[4] * px + p.T.m[5] * py;
+            az = p.T.m[8] * px + p.T.m[9] * py;
+        }
+    }
+    __device__ __forceinline__ V3 at(const FuseParams& p, float pz) const
+    {
+        if constexpr (FAST)
+            return v3(__builtin_fmaf(p.T.m[2], pz, ax), __builtin_fmaf(p.T.m[6], pz, ay), __builtin_fmaf(p.T.m[10], pz, az));
+        else
+            return v3(ax + p.T.m[2] * pz + p.T.m[3], ay + p.T.m[6] * pz + p.T.m[7], az + p.T.m[10] * pz + p.T.m[11]);
+    }
+};
+
+// K.Project (ImageIntrinsics.h:87-91); fast mode keeps 1/Z for the weight
+template <bool FAST>
+__device__ __forceinline__ void project(const FuseParams& p, const V3 Pc, float& pu, float& pv, float& iz)
+{
+    if constexpr (FAST) {
+        iz = __builtin_amdgcn_rcpf(Pc.z);
+        pu = __builtin_fmaf(p.K.fu * Pc.x, iz, p.K.u0);
+        pv = __builtin_fmaf(p.K.fv * Pc.y, iz, p.K.v0);
+    } else {
+        iz = 0.f;
+        pu = p.K.u0 + p.K.fu * Pc.x / Pc.z;
+        pv = p.K.v0 + p.K.fv * Pc.y / Pc.z;
+    }
+}
+
+// depth.InBounds(p_c, 2) (Image.h:287-291)
+__device__ __forceinline__ bool in_bounds(const FuseParams& p, float pu, float pv)
+{
+    return 2.0f <= pu && pu < p.dwb && 2.0f <= pv && pv < p.dhb;
+}
+
+// Global-memory corner fetch, any image size (64-bit addressing)
+__device__ __forceinline__ Corners fetch_global64(const FuseParams& p, int ix, int iy)
+{
+    const float* dbl = row<float>(p.depth, (size_t)iy) + ix;
+    const float* dtl = row<float>(p.depth, (size_t)iy + 1) + ix;
+    const float4* nbl = row<float4>(p.norm, (size_t)iy) + ix;
+    const float4* ntl = row<float4>(p.norm, (size_t)iy + 1) + ix;
+    const float4 n00 = nbl[0], n01 = nbl[1], n10 = ntl[0], n11 = ntl[1];
+    Corners c;
+    c.c00 = make_float4(n00.x, n00.y, n00.z, dbl[0]);
+    c.c01 = make_float4(n01.x, n01.y, n01.z, dbl[1]);
+    c.c10 = make_float4(n10.x, n10.y, n10.z, dtl[0]);
+    c.c11 = make_float4(n11.x, n11.y, n11.z, dtl[1]);
+    return c;
+}
+
+// Global-memory corner fetch with a wave-uniform base (SGPR pair) + 32-bit lane offset: the
+// global_load "saddr" form, no 64-bit address arithmetic per lane.
+struct __attribute__((packed, aligned(4))) P2 { float a, b; };
+__device__ __forceinline__ Corners fetch_global32(const FuseParams& p, int ix, int iy)
+{
+    const unsigned od = __umul24((unsigned)iy, p.dpitch) + (unsigned)ix * 4u;
+    const unsigned on = __umul24((unsigned)iy, p.npitch) + (unsigned)ix * 16u;
+    const P2 db = *reinterpret_cast<const P2*>(p.depth.ptr + od);
+    const P2 dt = *reinterpret_cast<const P2*>(p.depth.ptr + p.dpitch + od);
+    const float4* nb = reinterpret_cast<const float4*>(p.norm.ptr + on);
+    const float4* nt = reinterpret_cast<const float4*>(p.norm.ptr + p.npitch + on);
+    const float4 n00 = nb[0], n01 = nb[1], n10 = nt[0], n11 = nt[1];
+    Corners c;
+    c.c00 = make_float4(n00.x, n00.y, n00.z, db.a);
+    c.c01 = make_float4(n01.x, n01.y, n01.z, db.b);
+    c.c10 = make_float4(n10.x, n10.y, n10.z, dt.a);
+    c.c11 = make_float4(n11.x, n11.y, n11.z, dt.b);
+    return c;
+}
+
+// Bilinear lookup (Image::GetBilinear, Image.h:317-334), signed distance, weight and the
+// update predicate (cu_sdffusion.cu:35-44).  No volume access.
+template <bool FAST>
+__device__ __forceinline__ Obs finish(const FuseParams& p, const V3 Pc, float iz, float fx, float fy, const Corners& c)
+{
+    Obs o;
+    o.ok = false;
+    o.val = 0.f;
+    o.w = 0.f;
+    float md, costheta, w;
+    if constexpr (FAST) {
+        md = lerp_f(lerp_f(c.c00.w, c.c01.w, fx), lerp_f(c.c10.w, c.c11.w, fx), fy);
+        const float nx = lerp_f(lerp_f(c.c00.x, c.c01.x, fx), lerp_f(c.c10.x, c.c11.x, fx), fy);
+        const float ny = lerp_f(lerp_f(c.c00.y, c.c01.y, fx), lerp_f(c.c10.y, c.c11.y, fx), fy);
+        const float nz = lerp_f(lerp_f(c.c00.z, c.c01.z, fx), lerp_f(c.c10.z, c.c11.z, fx), fy);
+        const float dotn = __builtin_fmaf(nz, Pc.z, __builtin_fmaf(ny, Pc.y, nx * Pc.x));
+        const float len2 = __builtin_fmaf(Pc.z, Pc.z, __builtin_fmaf(Pc.y, Pc.y, Pc.x * Pc.x));
+        costheta = -dotn * __builtin_amdgcn_rsqf(len2);
+        w = costheta * iz;
+    } else {
+        md = lerp(lerp(c.c00.w, c.c01.w, fx), lerp(c.c10.w, c.c11.w, fx), fy);
+        V3 mdn;
+        mdn.x = lerp(lerp(c.c00.x, c.c01.x, fx), lerp(c.c10.x, c.c11.x, fx), fy);
+        mdn.y = lerp(lerp(c.c00.y, c.c01.y, fx), lerp(c.c10.y, c.c11.y, fx), fy);
+        mdn.z = lerp(lerp(c.c00.z, c.c01.z, fx), lerp(c.c10.z, c.c11.z, fx), fy);
+        costheta = dot(mdn, Pc) / -length(Pc);
+        w = costheta * 1.0f / Pc.z;
+    }
+    const float sd = costheta * (md - Pc.z);
+    if (!(sd <= -p.trunc) && isfinite(md) && isfinite(w) && costheta > p.mincos) {
+        o.ok = true;
+        o.val = clampf(sd, -p.trunc, p.trunc);
+        o.w = w;
+    }
+    return o;
+}
+
+// SDF_t::operator+= then LimitWeight (Sdf.h:22-32): `o` is the new sample, (oval, ow) the stored cell.
+template <bool FAST>
+__device__ __forceinline__ void accumulate(const Obs& o, float max_w, float& oval, float& ow)
+{
+    float val = o.val, w = o.w;
+    if (ow > 0) {
+        if constexpr (FAST) {
+            const float ws = w + ow;
+            val = __builtin_fmaf(w, val, ow * oval) * __builtin_amdgcn_rcpf(ws);
+            w = ws;
+        } else {
+            val = (w * val + ow * oval);
+            w += ow;
+            val /= w;
+        }
+    }
+    oval = val;
+    ow = fminf(w, max_w);
+}
+
+// streaming volume accesses: each cell is touched once per frame, so it is marked nontemporal
+// (measured: in-place RMW sweep of 512^3 5.6 -> 6.0 TB/s)
+__device__ __forceinline__ float4 vol_ld(const unsigned char* q)
+{
+    const v4f t = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(q));
+    return make_float4(t.x, t.y, t.z, t.w);
+}
+__device__ __forceinline__ void vol_st(unsigned char* q, const float4 c)
+{
+    v4f t;
+    t.x = c.x; t.y = c.y; t.z = c.z; t.w = c.w;
+    __builtin_nontemporal_store(t, reinterpret_cast<v4f*>(q));
+}
+
+// One voxel: projection -> bounds test -> corner fetch -> observation.
+template <bool FAST, bool OFF32>
 __device__ __forceinline__ Obs observe(const FuseParams& p, const V3 Pc)
 {
     Obs o;
     o.ok = false;
     o.val = 0.f;
     o.w = 0.f;
-    // K.Project (ImageIntrinsics.h:87-91)
-    const float pu = p.K.u0 + p.K.fu * Pc.x / Pc.z;
-    const float pv = p.K.v0 + p.K.fv * Pc.y / Pc.z;
-    if (2.0f <= pu && pu < p.dwb && 2.0f <= pv && pv < p.dhb) {
-        // Image::GetBilinear (Image.h:317-334)
-        const float fix = floorf(pu), fiy = floorf(pv);
-        const float fx = pu - fix, fy = pv - fiy;
-        const int ix = (int)fix, iy = (int)fiy;
-        const float* dbl = row<float>(p.depth, (size_t)iy) + ix;
-        const float* dtl = row<float>(p.depth, (size_t)iy + 1) + ix;
-        const float d00 = dbl[0], d01 = dbl[1], d10 = dtl[0], d11 = dtl[1];
-        const float4* nbl = row<float4>(p.norm, (size_t)iy) + ix;
-        const float4* ntl = row<float4>(p.norm, (size_t)iy + 1) + ix;
-        const float4 n00 = nbl[0], n01 = nbl[1], n10 = ntl[0], n11 = ntl[1];
-        const float md = lerp(lerp(d00, d01, fx), lerp(d10, d11, fx), fy);
-        V3 mdn;
-        mdn.x = lerp(lerp(n00.x, n01.x, fx), lerp(n10.x, n11.x, fx), fy);
-        mdn.y = lerp(lerp(n00.y, n01.y, fx), lerp(n10.y, n11.y, fx), fy);
-        mdn.z = lerp(lerp(n00.z, n01.z, fx), lerp(n10.z, n11.z, fx), fy);
-
-        const float vd = Pc.z;
-        const float costheta = dot(mdn, Pc) / -length(Pc);
-        const float sd = costheta * (md - vd);
-        const float w = costheta * 1.0f / vd;
-        if (!(sd <= -p.trunc) && isfinite(md) && isfinite(w) && costheta > p.mincos) {
-            o.ok = true;
-            o.val = clampf(sd, -p.trunc, p.trunc);
-            o.w = w;
-        }
+    float pu, pv, iz;
+    project<FAST>(p, Pc, pu, pv, iz);
+    if (in_bounds(p, pu, pv)) {
+        const float fix = floorf(pu), fiy = floorf(pv); // quirk Q6: floorf, then integer conversion
+        const Corners c = OFF32 ? fetch_global32(p, (int)fix, (int)fiy) : fetch_global64(p, (int)fix, (int)fiy);
+        o = finish<FAST>(p, Pc, iz, pu - fix, pv - fiy, c);
     }
     return o;
 }
 
-// SDF_t::operator+= then LimitWeight (Sdf.h:22-32): `o` is the new sample, (oval, ow) the stored cell.
-__device__ __forceinline__ void accumulate(const Obs& o, float max_w, float& oval, float& ow)
-{
-    float val = o.val, w = o.w;
-    if (ow > 0) {
-        val = (w * val + ow * oval);
-        w += ow;
-        val /= w;
-    }
-    w = fminf(w, max_w);
-    oval = val;
-    ow = w;
-}
-
-template <int VEC>
+// ---------------------------------------------------------------------------------------
+// Generic kernel: global gathers, any alignment (VEC = 1: 8-byte cells for sub-volume views
+// with odd x offset / pitch), any image size.  Workgroup = (64*VEC) x 4 x FUSE_ZC voxels.
+// ---------------------------------------------------------------------------------------
+template <int VEC, bool FAST, bool OFF32>
 __global__ __launch_bounds__(256) void k_sdf_fuse(const FuseParams p)
 {
+    __shared__ float s_pz[FUSE_ZC];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int x0 = (blockIdx.x * 64 + lane) * VEC;
     const int y = blockIdx.y * FUSE_ROWS + wv;
-    if (x0 >= p.X || y >= p.Y) return;
     const int zbeg = blockIdx.z * FUSE_ZC;
     const int zend = min(zbeg + FUSE_ZC, p.Z);
+    if (threadIdx.x < FUSE_ZC) // VoxelPositionInUnits z, once per slice
+        s_pz[threadIdx.x] = p.bmin.z + p.size.z * (float)(zbeg + (int)threadIdx.x) / p.d1;
+    __syncthreads();
+    if (x0 >= p.X || y >= p.Y) return;
 
-    // BoundedVolume::VoxelPositionInUnits (BoundedVolume.h:115-125), x/y parts hoisted:
-    // T(i,0)*x + T(i,1)*y is the leading partial sum of MatUtils.h:117-125.
     const float py = p.bmin.y + p.size.y * (float)y / p.h1;
-    float ax[VEC], ay[VEC], az[VEC];
+    CamXY<FAST> cam[VEC];
 #pragma unroll
-    for (int v = 0; v < VEC; ++v) {
-        const float px = p.bmin.x + p.size.x * (float)(x0 + v) / p.w1;
-        ax[v] = p.T.m[0] * px + p.T.m[1] * py;
-        ay[v] = p.T.m[4] * px + p.T.m[5] * py;
-        az[v] = p.T.m[8] * px + p.T.m[9] * py;
-    }
+    for (int v = 0; v < VEC; ++v) cam[v].init(p, p.bmin.x + p.size.x * (float)(x0 + v) / p.w1, py);
 
     unsigned char* cell = p.vptr + (size_t)zbeg * p.vimg_pitch + (size_t)y * p.vpitch + (size_t)x0 * 8;
     for (int z = zbeg; z < zend; ++z, cell += p.vimg_pitch) {
-        const float pz = p.bmin.z + p.size.z * (float)z / p.d1;
+        const float pz = s_pz[z - zbeg];
         Obs o[VEC];
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) {
-            const V3 Pc = v3(ax[v] + p.T.m[2] * pz + p.T.m[3], ay[v] + p.T.m[6] * pz + p.T.m[7],
-                             az[v] + p.T.m[10] * pz + p.T.m[11]);
-            o[v] = observe(p, Pc);
-        }
+        for (int v = 0; v < VEC; ++v) o[v] = observe<FAST, OFF32>(p, cam[v].at(p, pz));
         if constexpr (VEC == 2) {
             if (o[0].ok || o[1].ok) {
-                float4 c = *reinterpret_cast<const float4*>(cell);
-                if (o[0].ok) accumulate(o[0], p.max_w, c.x, c.y);
-                if (o[1].ok) accumulate(o[1], p.max_w, c.z, c.w);
-                *reinterpret_cast<float4*>(cell) = c;
+                float4 c = vol_ld(cell);
+                if (o[0].ok) accumulate<FAST>(o[0], p.max_w, c.x, c.y);
+                if (o[1].ok) accumulate<FAST>(o[1], p.max_w, c.z, c.w);
+                vol_st(cell, c);
             }
         } else {
             if (o[0].ok) {
                 float2 c = *reinterpret_cast<const float2*>(cell);
-                accumulate(o[0], p.max_w, c.x, c.y);
+                accumulate<FAST>(o[0], p.max_w, c.x, c.y);
                 *reinterpret_cast<float2*>(cell) = c;
             }
         }
     }
 }
 
-// Diagnostics: how many voxels k_sdf_fuse would update (same predicate, no volume access).
+// ---------------------------------------------------------------------------------------
+// LDS-tiled kernel.  A workgroup owns a brick of 64 x 8 x FUSE_ZC voxels.  The perspective
+// image of a z-column of voxels is a line segment, so the projections of the brick's first and
+// last slice bound the pixel rectangle all of its voxels sample (given Z > 0 throughout, which
+// the two end slices establish because Z is affine in z).  That rectangle, plus one texel of
+// slack, is staged once in LDS as {nx, ny, nz, depth}; every bilinear lookup is then four
+// ds_read_b128.  Bricks whose rectangle misses the in-bounds band of the image are skipped;
+// bricks too close to the camera for the rectangle to fit `cap_px` texels, or straddling the
+// camera plane, take the global-gather path (per lane, so a texel outside the staged
+// rectangle can never be read from LDS).  Texel values are copies, so results are identical
+// to the generic kernel in either numerics mode.
+// ---------------------------------------------------------------------------------------
+template <bool FAST>
+__global__ __launch_bounds__(256) void k_sdf_fuse_tiled(const FuseParams p, const int cap_px)
+{
+    extern __shared__ __attribute__((aligned(16))) float4 s_tile[];
+    __shared__ float s_pz[FUSE_ZC];
+    __shared__ float s_box[4][4];
+    __shared__ int s_bad[4];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int x0 = (blockIdx.x * 32 + (lane & 31)) * 2;
+    const int y = blockIdx.y * TB_Y + wv * 2 + (lane >> 5);
+    const int zbeg = blockIdx.z * FUSE_ZC;
+    const int zend = min(zbeg + FUSE_ZC, p.Z);
+    const bool live = x0 < p.X && y < p.Y;
+    if (tid < FUSE_ZC) s_pz[tid] = p.bmin.z + p.size.z * (float)(zbeg + tid) / p.d1;
+    __syncthreads();
+
+    const float py = p.bmin.y + p.size.y * (float)y / p.h1;
+    CamXY<FAST> cam[2];
+#pragma unroll
+    for (int v = 0; v < 2; ++v) cam[v].init(p, p.bmin.x + p.size.x * (float)(x0 + v) / p.w1, py);
+
+    // ---- pixel rectangle of the brick: projections of its first and last slice ----
+    float umin = __builtin_inff(), umax = -__builtin_inff(), vmin = __builtin_inff(), vmax = -__builtin_inff();
+    bool bad = false;
+    if (live) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const float pz = s_pz[e ? (zend - 1 - zbeg) : 0];
+#pragma unroll
+            for (int v = 0; v < 2; ++v) {
+                const V3 Pc = cam[v].at(p, pz);
+                float pu, pv, iz;
+                project<FAST>(p, Pc, pu, pv, iz);
+                bad = bad || !(Pc.z > 0.f) || !(fabsf(pu) < 1e9f) || !(fabsf(pv) < 1e9f);
+                umin = fminf(umin, pu); umax = fmaxf(umax, pu);
+                vmin = fminf(vmin, pv); vmax = fmaxf(vmax, pv);
+            }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { // wave64 butterfly
+        umin = fminf(umin, __shfl_xor(umin, off, 64)); umax = fmaxf(umax, __shfl_xor(umax, off, 64));
+        vmin = fminf(vmin, __shfl_xor(vmin, off, 64)); vmax = fmaxf(vmax, __shfl_xor(vmax, off, 64));
+    }
+    const bool wave_bad = __ballot(bad) != 0ull;
+    if (lane == 0) {
+        s_box[wv][0] = umin; s_box[wv][1] = umax; s_box[wv][2] = vmin; s_box[wv][3] = vmax;
+        s_bad[wv] = wave_bad ? 1 : 0;
+    }
+    __syncthreads();
+    umin = fminf(fminf(s_box[0][0], s_box[1][0]), fminf(s_box[2][0], s_box[3][0]));
+    umax = fmaxf(fmaxf(s_box[0][1], s_box[1][1]), fmaxf(s_box[2][1], s_box[3][1]));
+    vmin = fminf(fminf(s_box[0][2], s_box[1][2]), fminf(s_box[2][2], s_box[3][2]));
+    vmax = fmaxf(fmaxf(s_box[0][3], s_box[1][3]), fmaxf(s_box[2][3], s_box[3][3]));
+    const bool any_bad = (s_bad[0] | s_bad[1] | s_bad[2] | s_bad[3]) != 0;
+
+    bool use_tile = false;
+    int tx0 = 0, ty0 = 0, tw = 0, th = 0;
+    if (!any_bad) {
+        // every sample needs 2 <= pu < w-2 and 2 <= pv < h-2: a rectangle that misses that band
+        // means no voxel of the brick can pass InBounds (workgroup-uniform exit)
+        if (umax < 2.0f || !(umin < p.dwb) || vmax < 2.0f || !(vmin < p.dhb)) return;
+        // bilinear cells (ix, ix+1) x (iy, iy+1) of every sample, one texel of slack per side
+        const float fx0 = fmaxf(floorf(umin) - 1.f, 0.f), fx1 = fminf(floorf(umax) + 2.f, (float)(p.depth.w - 1));
+        const float fy0 = fmaxf(floorf(vmin) - 1.f, 0.f), fy1 = fminf(floorf(vmax) + 2.f, (float)(p.depth.h - 1));
+        tx0 = (int)fx0; ty0 = (int)fy0;
+        tw = (int)fx1 - tx0 + 1; th = (int)fy1 - ty0 + 1;
+        use_tile = tw > 1 && th > 1 && tw * th <= cap_px;
+    }
+    if (use_tile) { // cooperative, row-coalesced staging
+        for (int r = wv; r < th; r += 4) {
+            const float* drow = row<float>(p.depth, (size_t)(ty0 + r)) + tx0;
+            const float4* nrow = row<float4>(p.norm, (size_t)(ty0 + r)) + tx0;
+            for (int c = lane; c < tw; c += 64) {
+                const float4 n = nrow[c];
+                s_tile[r * tw + c] = make_float4(n.x, n.y, n.z, drow[c]);
+            }
+        }
+    }
+    __syncthreads();
+    if (!live) return;
+
+    unsigned char* cell = p.vptr + (size_t)zbeg * p.vimg_pitch + (size_t)y * p.vpitch + (size_t)x0 * 8;
+    for (int z = zbeg; z < zend; ++z, cell += p.vimg_pitch) {
+        const float pz = s_pz[z - zbeg];
+        Obs o[2];
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+            o[v].ok = false;
+            const V3 Pc = cam[v].at(p, pz);
+            float pu, pv, iz;
+            project<FAST>(p, Pc, pu, pv, iz);
+            if (in_bounds(p, pu, pv)) {
+                const float fix = floorf(pu), fiy = floorf(pv);
+                const int ix = (int)fix, iy = (int)fiy;
+                const unsigned rx = (unsigned)(ix - tx0), ry = (unsigned)(iy - ty0);
+                Corners c;
+                if (use_tile && rx < (unsigned)(tw - 1) && ry < (unsigned)(th - 1)) {
+                    const float4* t = s_tile + (ry * (unsigned)tw + rx);
+                    c.c00 = t[0]; c.c01 = t[1]; c.c10 = t[tw]; c.c11 = t[tw + 1];
+                } else {
+                    c = fetch_global32(p, ix, iy);
+                }
+                o[v] = finish<FAST>(p, Pc, iz, pu - fix, pv - fiy, c);
+            }
+        }
+        if (o[0].ok || o[1].ok) {
+            float4 c = vol_ld(cell);
+            if (o[0].ok) accumulate<FAST>(o[0], p.max_w, c.x, c.y);
+            if (o[1].ok) accumulate<FAST>(o[1], p.max_w, c.z, c.w);
+            vol_st(cell, c);
+        }
+    }
+}
+
+// Diagnostics: how many voxels the fuse kernels would update (same predicate, no volume access).
+template <bool FAST>
 __global__ __launch_bounds__(256) void k_sdf_fuse_count(const FuseParams p, unsigned long long* __restrict__ count)
 {
+    __shared__ float s_pz[FUSE_ZC];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int x = blockIdx.x * 64 + lane;
     const int y = blockIdx.y * FUSE_ROWS + wv;
     const bool live = x < p.X && y < p.Y;
     const int zbeg = blockIdx.z * FUSE_ZC;
     const int zend = min(zbeg + FUSE_ZC, p.Z);
-    const float py = p.bmin.y + p.size.y * (float)y / p.h1;
-    const float px = p.bmin.x + p.size.x * (float)x / p.w1;
-    const float ax = p.T.m[0] * px + p.T.m[1] * py;
-    const float ay = p.T.m[4] * px + p.T.m[5] * py;
-    const float az = p.T.m[8] * px + p.T.m[9] * py;
+    if (threadIdx.x < FUSE_ZC) s_pz[threadIdx.x] = p.bmin.z + p.size.z * (float)(zbeg + (int)threadIdx.x) / p.d1;
+    __syncthreads();
+    CamXY<FAST> cam;
+    cam.init(p, p.bmin.x + p.size.x * (float)x / p.w1, p.bmin.y + p.size.y * (float)y / p.h1);
     unsigned n = 0;
     if (live)
-        for (int z = zbeg; z < zend; ++z) {
-            const float pz = p.bmin.z + p.size.z * (float)z / p.d1;
-            const V3 Pc = v3(ax + p.T.m[2] * pz + p.T.m[3], ay + p.T.m[6] * pz + p.T.m[7], az + p.T.m[10] * pz + p.T.m[11]);
-            n += observe(p, Pc).ok ? 1u : 0u;
-        }
-    // wave64 butterfly sum, one atomic per wave
+        for (int z = zbeg; z < zend; ++z) n += observe<FAST, false>(p, cam.at(p, s_pz[z - zbeg])).ok ? 1u : 0u;
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) n += __shfl_xor(n, off, 64);
-    if (lane == 0 && n) atomicAdd(count, (unsigned long long)n);
+    for (int off = 32; off > 0; off >>= 1) n += __shfl_xor(n, off, 64); // wave64 butterfly sum
+    if (lane == 0 && n) atomicAdd(count, (unsigned long long)n);        // one atomic per wave
 }
 
 // SdfReset: contiguous fill of (trunc, 0) over [ptr, RowPtr(h-1,d-1)+w) (Volume.h:343-356).
 __global__ __launch_bounds__(256) void k_fill_sdf(float2* __restrict__ base, size_t n_cells, float val, float w)
 {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t n2 = n_cells / 2;
-    float4* b4 = reinterpret_cast<float4*>(base);
-    const float4 v4 = make_float4(val, w, val, w);
-    for (size_t j = i; j < n2; j += stride) b4[j] = v4;
+    v4f* b4 = reinterpret_cast<v4f*>(base);
+    v4f v4;
+    v4.x = val; v4.y = w; v4.z = val; v4.w = w;
+    for (size_t j = i; j < n2; j += stride) __builtin_nontemporal_store(v4, b4 + j);
     if (i == 0 && (n_cells & 1)) base[n_cells - 1] = make_float2(val, w);
 }
 __global__ __launch_bounds__(256) void k_fill_sdf_unaligned(float2* __restrict__ base, size_t n_cells, float val, float w)
@@ -229,9 +491,10 @@ static VolView vol_view(const kfx_volume* vol)
     return v;
 }
 
-static int fuse_params(FuseParams& p, const kfx_volume* vol, const kfx_image* depth, const kfx_image* norm,
-                       const float T_cw[12], const float K[4], float trunc_dist, float max_w, float mincostheta,
-                       unsigned flags)
+// Fills the kernel parameters; *small_images tells whether the 32-bit image offsets are usable.
+static int fuse_params(FuseParams& p, bool* small_images, const kfx_volume* vol, const kfx_image* depth,
+                       const kfx_image* norm, const float T_cw[12], const float K[4], float trunc_dist, float max_w,
+                       float mincostheta, unsigned flags)
 {
     if (int e = check_volume(vol)) return e;
     if (!depth || !norm || !depth->ptr || !norm->ptr || !T_cw || !K) return set_error(KFX_E_NULL, "SdfFuse: null argument");
@@ -261,6 +524,11 @@ static int fuse_params(FuseParams& p, const kfx_volume* vol, const kfx_image* de
     p.trunc = trunc_dist;
     p.max_w = max_w;
     p.mincos = mincostheta;
+    // 32-bit image offsets (saddr loads, 24-bit multiplies) need images below these limits
+    *small_images = depth->pitch * depth->h < (1ull << 31) && norm->pitch * norm->h < (1ull << 31) &&
+                    depth->pitch < (1u << 24) && norm->pitch < (1u << 24) && depth->h < (1u << 24);
+    p.dpitch = *small_images ? (unsigned)depth->pitch : 0u;
+    p.npitch = *small_images ? (unsigned)norm->pitch : 0u;
     return 0;
 }
 
@@ -269,16 +537,33 @@ extern "C" int kfx_sdf_fuse(const kfx_volume* vol, const kfx_image* depth, const
                             float mincostheta, unsigned flags, kfx_stream stream)
 {
     FuseParams p;
-    if (int e = fuse_params(p, vol, depth, norm, T_cw, K, trunc_dist, max_w, mincostheta, flags)) return e;
+    bool small_images = false;
+    if (int e = fuse_params(p, &small_images, vol, depth, norm, T_cw, K, trunc_dist, max_w, mincostheta, flags)) return e;
     if (p.X == 0 || p.Y == 0 || p.Z == 0) return 0; // reference launches an empty grid
     const bool vec2 = (p.X % 2 == 0) && ((((uintptr_t)vol->ptr | vol->pitch | vol->img_pitch) & 15) == 0);
+    const bool fast = math_mode() == KFX_MATH_FAST;
     hipStream_t s = (hipStream_t)stream;
-    if (vec2) {
+    // tuning / A-B knobs (read once): KFX_FUSE_TILED=0 forces the global-gather kernel,
+    // KFX_FUSE_CAP sets the LDS tile capacity in texels (16 B each)
+    static const int tiled = [] { const char* e = getenv("KFX_FUSE_TILED"); return e ? atoi(e) : 1; }();
+    static const int cap_px = [] { const char* e = getenv("KFX_FUSE_CAP"); const int v = e ? atoi(e) : 1536; return v < 64 ? 64 : (v > 8192 ? 8192 : v); }();
+    if (tiled && vec2 && small_images) {
+        dim3 grid(ceil_div(p.X, TB_X), ceil_div(p.Y, TB_Y), ceil_div(p.Z, FUSE_ZC));
+        const size_t lds = (size_t)cap_px * sizeof(float4);
+        if (fast) hipLaunchKernelGGL(k_sdf_fuse_tiled<true>, grid, dim3(256), lds, s, p, cap_px);
+        else hipLaunchKernelGGL(k_sdf_fuse_tiled<false>, grid, dim3(256), lds, s, p, cap_px);
+    } else if (vec2) {
         dim3 grid(ceil_div(p.X, 128), ceil_div(p.Y, FUSE_ROWS), ceil_div(p.Z, FUSE_ZC));
-        hipLaunchKernelGGL(k_sdf_fuse<2>, grid, dim3(256), 0, s, p);
+        if (fast && small_images) hipLaunchKernelGGL((k_sdf_fuse<2, true, true>), grid, dim3(256), 0, s, p);
+        else if (fast) hipLaunchKernelGGL((k_sdf_fuse<2, true, false>), grid, dim3(256), 0, s, p);
+        else if (small_images) hipLaunchKernelGGL((k_sdf_fuse<2, false, true>), grid, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((k_sdf_fuse<2, false, false>), grid, dim3(256), 0, s, p);
     } else {
         dim3 grid(ceil_div(p.X, 64), ceil_div(p.Y, FUSE_ROWS), ceil_div(p.Z, FUSE_ZC));
-        hipLaunchKernelGGL(k_sdf_fuse<1>, grid, dim3(256), 0, s, p);
+        if (fast && small_images) hipLaunchKernelGGL((k_sdf_fuse<1, true, true>), grid, dim3(256), 0, s, p);
+        else if (fast) hipLaunchKernelGGL((k_sdf_fuse<1, true, false>), grid, dim3(256), 0, s, p);
+        else if (small_images) hipLaunchKernelGGL((k_sdf_fuse<1, false, true>), grid, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((k_sdf_fuse<1, false, false>), grid, dim3(256), 0, s, p);
     }
     return check_launch("kfx_sdf_fuse");
 }
@@ -289,10 +574,12 @@ extern "C" int kfx_sdf_fuse_count(const kfx_volume* vol, const kfx_image* depth,
 {
     if (!d_count) return set_error(KFX_E_NULL, "kfx_sdf_fuse_count: null counter");
     FuseParams p;
-    if (int e = fuse_params(p, vol, depth, norm, T_cw, K, trunc_dist, 0.f, mincostheta, flags)) return e;
+    bool small_images = false;
+    if (int e = fuse_params(p, &small_images, vol, depth, norm, T_cw, K, trunc_dist, 0.f, mincostheta, flags)) return e;
     if (p.X == 0 || p.Y == 0 || p.Z == 0) return 0;
     dim3 grid(ceil_div(p.X, 64), ceil_div(p.Y, FUSE_ROWS), ceil_div(p.Z, FUSE_ZC));
-    hipLaunchKernelGGL(k_sdf_fuse_count, grid, dim3(256), 0, (hipStream_t)stream, p, d_count);
+    if (math_mode() == KFX_MATH_FAST) hipLaunchKernelGGL(k_sdf_fuse_count<true>, grid, dim3(256), 0, (hipStream_t)stream, p, d_count);
+    else hipLaunchKernelGGL(k_sdf_fuse_count<false>, grid, dim3(256), 0, (hipStream_t)stream, p, d_count);
     return check_launch("kfx_sdf_fuse_count");
 }
 

@@ -88,4 +88,5 @@ __host__ __device__ inline int ceil_div(int a, int b) { return (a + b - 1) / b; 
 namespace kfx {
 int set_error(int code, const char* what);
 int check_launch(const char* what);
+int math_mode(); // KFX_MATH_EXACT / KFX_MATH_FAST
 } // namespace kfx

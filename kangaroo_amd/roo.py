@@ -207,6 +207,22 @@ def FitToFrustum(T_wc, w, h, K, near, far):
     return lo, hi
 
 
+MATH_EXACT, MATH_FAST = 0, 1
+
+
+def set_math_mode(mode):
+    """kfx_set_math_mode: 'exact' (default, bit-identical to the oracle) or 'fast' (perf build)."""
+    m = {"exact": MATH_EXACT, "fast": MATH_FAST}.get(mode, mode)
+    prev = _lib.load().kfx_set_math_mode(int(m))
+    if prev < 0:
+        _lib.check(prev)
+    return "fast" if prev == MATH_FAST else "exact"
+
+
+def get_math_mode():
+    return "fast" if _lib.load().kfx_get_math_mode() == MATH_FAST else "exact"
+
+
 # ---- operators ------------------------------------------------------------------
 
 def SdfFuse(vol, depth, norm, T_cw, K, trunc_dist, maxw, mincostheta, full_extent=False, stream=None):

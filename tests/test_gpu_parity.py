@@ -304,6 +304,76 @@ def test_gpu_empty_and_tiny_inputs(roo):
 
 
 # ---------------------------------------------------------------------------------
+# fast-math ("perf build") mode: stated tolerance instead of bit equality
+# ---------------------------------------------------------------------------------
+FAST_TSDF_TOL = 1e-4        # BASELINE.json north_star: TSDF L-inf < 1e-4 vs reference
+FAST_FLIP_FRACTION = 2e-6   # voxels allowed to be classified differently (update / bilinear-cell flips)
+
+
+def _fast_vs_oracle(roo, scene, N, w, h, frames):
+    ovol = T.make_volume(N, scene)
+    K, tr, fr = T.fuse_frames_oracle(ovol, scene, w, h, frames)
+    bmin, bmax, near, far = scenes.SCENES[scene]
+    vol = roo.BoundedVolume(N, N, N, bmin, bmax)
+    roo.SdfReset(vol, float("nan"))
+    prev = roo.set_math_mode("fast")
+    try:
+        assert roo.get_math_mode() == "fast"
+        for f in fr:
+            roo.SdfFuse(vol, T.upload_image(roo, f["filtered"]), T.upload_image(roo, f["normals"]), f["T_cw"], K, tr,
+                        scenes.MAX_W, scenes.MIN_COS_THETA)
+        got = vol.MemcpyToHost()
+    finally:
+        roo.set_math_mode(prev)
+    exp = ovol.data
+    nan_g, nan_e = np.isnan(got[..., 0]), np.isnan(exp[..., 0])
+    flips = int((nan_g != nan_e).sum())
+    both = ~nan_g & ~nan_e
+    dv = np.abs(got[..., 0][both] - exp[..., 0][both])
+    dw = np.abs(got[..., 1][both] - exp[..., 1][both]) / np.maximum(np.abs(exp[..., 1][both]), 1e-12)
+    outliers = int((dv > FAST_TSDF_TOL).sum())
+    return dict(n=N ** 3, flips=flips, outliers=outliers, linf=float(dv[dv <= FAST_TSDF_TOL].max()),
+                w_rel=float(np.median(dw)), w_rel_p999=float(np.quantile(dw, 0.999)))
+
+
+@pytest.mark.parametrize("scene,N,w,h,frames", [("room", 64, 160, 120, 4), ("full", 64, 160, 120, 2),
+                                                ("room", 128, 640, 480, 3)])
+def test_gpu_fast_mode_within_tolerance(roo, scene, N, w, h, frames):
+    """KFX_MATH_FAST (rcp/rsq/FMA) vs the exact oracle: TSDF values within 1e-4 on identically
+    classified voxels; the number of differently classified voxels (update flips at predicate
+    boundaries, bilinear-cell flips at depth edges) is counted and must stay negligible."""
+    r = _fast_vs_oracle(roo, scene, N, w, h, frames)
+    budget = max(3, int(FAST_FLIP_FRACTION * r["n"] * frames))
+    assert r["flips"] <= budget and r["outliers"] <= budget, r
+    assert r["linf"] <= FAST_TSDF_TOL and r["w_rel_p999"] < 1e-4, r
+
+
+def test_gpu_fast_mode_unaligned_and_default_restored(roo):
+    """The fast generic kernel (8-byte cells, odd pitch) agrees with the fast tiled kernel's
+    tolerance, and the default mode is exact again afterwards."""
+    dims, w, h = (44, 40, 32), 96, 72
+    ovol = oracle.Volume(dims[0], dims[1], dims[2], *scenes.SCENES["room"][:2], pitch_bytes=dims[0] * 8 + 8)
+    oracle.sdf_reset(ovol, float("nan"))
+    K, tr, fr = T.fuse_frames_oracle(ovol, "room", w, h, 2)
+    vol = roo.BoundedVolume(dims[0], dims[1], dims[2], ovol.boxmin, ovol.boxmax, pitch=ovol.pitch)
+    roo.SdfReset(vol, float("nan"))
+    prev = roo.set_math_mode("fast")
+    try:
+        for f in fr:
+            roo.SdfFuse(vol, T.upload_image(roo, f["filtered"]), T.upload_image(roo, f["normals"]), f["T_cw"], K, tr,
+                        scenes.MAX_W, scenes.MIN_COS_THETA)
+    finally:
+        roo.set_math_mode(prev)
+    assert roo.get_math_mode() == "exact"
+    got, exp = vol.MemcpyToHost(), ovol.data
+    same = np.isnan(got[..., 0]) == np.isnan(exp[..., 0])
+    assert (~same).sum() <= 3
+    both = ~np.isnan(got[..., 0]) & ~np.isnan(exp[..., 0])
+    d = np.abs(got[..., 0][both] - exp[..., 0][both])
+    assert (d > FAST_TSDF_TOL).sum() <= 3 and np.median(d) < 1e-7
+
+
+# ---------------------------------------------------------------------------------
 # full-size (BASELINE config C2) size-independent properties
 # ---------------------------------------------------------------------------------
 def test_gpu_full_size_properties(roo):
