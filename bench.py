@@ -35,6 +35,9 @@ def parse():
     ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--scene", default="room", choices=["room", "full"])
+    ap.add_argument("--math", default="fast", choices=["fast", "exact"],
+                    help="numerics mode of SdfFuse: fast = rcp/rsq/FMA perf build (reference's own -use_fast_math regime, "
+                         "tolerance-tested), exact = IEEE, bit-identical to the oracle")
     ap.add_argument("--res", type=int, default=512, help="volume resolution N (N^3 voxels)")
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
@@ -95,6 +98,7 @@ def main():
     from kangaroo_amd import roo, scenes
     from kangaroo_amd.pipeline import FramePipeline, SlabPipeline
 
+    roo.set_math_mode(args.math)
     N, w, h = args.res, args.width, args.height
     scene = args.scene
     bmin, bmax, near, far = scenes.SCENES[scene]
@@ -160,6 +164,31 @@ def main():
     hits = int(torch.isfinite(pipe.ray_d.tensor()).sum())
     assert hits > 0, "raycast produced no hits"
 
+    # the other numerics mode, same frames, SdfFuse only (reported beside the headline; not part of `value`)
+    other = "exact" if args.math == "fast" else "fast"
+    roo.set_math_mode(other)
+    n_other = min(args.steps, 20)
+    ev2 = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_other)]
+    for s in range(n_other):
+        i = (args.warmup + s) % N_ORBIT
+        pipe.preprocess(frames[i])
+        ev2[s][0].record()
+        pipe.fuse(poses[i])
+        ev2[s][1].record()
+    torch.cuda.synchronize()
+    other_ms = float(np.mean([a.elapsed_time(b) for a, b in ev2]))
+    other_bytes = float(np.mean([16.0 * n_updated[(args.warmup + s) % N_ORBIT] + 20.0 * w * h for s in range(n_other)]))
+    roo.set_math_mode(args.math)
+
+    traffic = None  # HBM bytes per launch from the committed PMC passes of this same command (profiles/)
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fh:
+            traffic = json.load(fh).get("%s_%s" % (scene, args.math), {}).get("traffic_bytes")
+    except (OSError, ValueError):
+        pass
+    if distributed or (N, w, h) != (512, 640, 480):
+        traffic = None
+
     if rank == 0:
         fps = args.steps / elapsed
         out = {
@@ -182,16 +211,18 @@ def main():
                                 N, 8.0 * N ** 3 / 2 ** 30, w, h, scene, N_ORBIT),
                 "volume": [N, N, N], "image": [w, h], "scene": scene,
                 "partition": "z-slabs x%d" % n_gpus if distributed else "single volume",
-                "math": "exact (IEEE fp32, no FMA contraction, reference operation order)",
+                "math": {"fast": "fast (fp32 rcp/rsq + FMA: the reference's own -use_fast_math regime; TSDF within 1e-4 of the exact path, "
+                                 "tests/test_gpu_parity.py::test_gpu_fast_mode_within_tolerance)",
+                         "exact": "exact (IEEE fp32, no FMA contraction, reference operation order; bit-identical to the oracle)"}[args.math],
             },
             "roofline": {
-                "kernel": "k_sdf_fuse (SdfFuse)",
+                "kernel": "k_sdf_fuse_tiled<%s> (SdfFuse, %s math)" % ("true" if args.math == "fast" else "false", args.math),
                 "bound": "hbm",
                 "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": None,
+                "traffic": traffic,
                 "algorithmic_bytes_per_launch": round(bytes_avg),
                 "avg_launch_ms": round(fuse_avg_ms, 5),
                 "updated_fraction": round(float(np.mean([n_updated[i] for i in idx])) / local_voxels, 4),
@@ -201,6 +232,9 @@ def main():
             "kernels_ms": {"sdf_fuse": round(fuse_avg_ms, 5), "raycast_sdf%s" % ("+composite" if distributed else ""): round(float(np.mean(ray_ms)), 5),
                            "frame_total": round(1e3 * elapsed / args.steps, 5)},
         }
+        out["sdf_fuse_other_mode"] = {"math": other, "avg_launch_ms": round(other_ms, 5),
+                                      "achieved_GBps": round(other_bytes / (other_ms * 1e-3) / 1e9, 1),
+                                      "frac": round(other_bytes / (other_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
         if not args.no_cpu_baseline and n_gpus == 1:
             try:
                 out["cpu_baseline"] = cpu_baseline(args, scene, args.cpu_frames)
