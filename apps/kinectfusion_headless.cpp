@@ -1,0 +1,131 @@
+// kinectfusion_headless.cpp -- the KinectFusion frame loop of the reference application
+// (applications/kinectfusion/main.cpp:190-393) without its GUI, sensor and ICP: a synthetic camera
+// with known poses orbits a synthetic room, and every frame runs the same roo:: calls in the same
+// order on the same container types:
+//
+//   BilateralFilter -> DepthToVbo -> NormalsFromVbo                        (main.cpp:209-215)
+//   [first frame] SdfReset(vol, NaN); SdfFuse                              (main.cpp:224-242)
+//   roi = BoundingBox(T_wl, w, h, K, knear, kfar); work_vol = vol.SubBoundingVolume(roi)   (:275-276)
+//   RaycastSdf(ray_d, ray_n, ray_i, work_vol, T_wl, K, knear, kfar, trunc_dist, true)      (:286)
+//   SdfFuse(work_vol, kin_d, kin_n, T_wl^-1, K, trunc_dist, max_w, mincostheta)            (:345-356)
+//
+// Host code only; all device work happens in libkfx behind the roo:: wrappers.
+// Usage: kinectfusion_headless [--res N] [--frames F] [--width W] [--height H] [--fast]
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include <kangaroo/kangaroo.h>
+
+using namespace roo;
+
+// analytic depth of the synthetic room (box interior x,y in [-0.9,0.9], back wall z = 3.8, sphere
+// c = (0,0,3) r = 0.5), z-depth along rays with ray_c.z = 1 -- same scene as kangaroo_amd/scenes.py
+static void RenderRoom(std::vector<float>& out, int w, int h, const Mat<float,3,4>& T_wc, const ImageIntrinsics& K)
+{
+    out.resize((size_t)w * h);
+    const float3 c = SE3Translation(T_wc);
+    for (int v = 0; v < h; ++v)
+        for (int u = 0; u < w; ++u) {
+            const float3 r = mulSO3(T_wc, K.Unproject((float)u, (float)v));
+            float best = INFINITY;
+            const float3 lo = make_float3(-0.9f, -0.9f, -10.f), hi = make_float3(0.9f, 0.9f, 3.8f);
+            const float3 a = div_cw(sub(lo, c), r), b = div_cw(sub(hi, c), r);
+            const float texit = fminf(fminf(fmaxf(a.x, b.x), fmaxf(a.y, b.y)), fmaxf(a.z, b.z));
+            if (texit > 0) best = texit;
+            const float3 oc = sub(make_float3(0, 0, 3.0f), c);
+            const float ldotc = dot(r, oc), lsq = dot(r, r), csq = dot(oc, oc);
+            const float disc = ldotc * ldotc - lsq * (csq - 0.25f);
+            if (disc >= 0) {
+                const float ts = (ldotc - sqrtf(disc)) / lsq;
+                if (ts > 0 && ts < best) best = ts;
+            }
+            out[(size_t)v * w + u] = std::isfinite(best) ? best : NAN;
+        }
+}
+
+static Mat<float,3,4> OrbitPose(int i, int n)
+{
+    const float ph = 2.0f * (float)M_PI * i / n;
+    const float yaw = 5.0f * (float)M_PI / 180.0f * sinf(ph);
+    const float c = cosf(yaw), s = sinf(yaw);
+    Mat<float,3,4> T = SE3Identity();
+    T(0,0) = c; T(0,2) = s; T(2,0) = -s; T(2,2) = c;
+    T(0,3) = 0.05f * sinf(ph);
+    T(1,3) = 0.025f * (1.0f - cosf(ph)) - 0.025f;
+    return T;
+}
+
+int main(int argc, char** argv)
+{
+    int volres = 256, frames = 30, w = 640, h = 480;   // the application's defaults (main.cpp:90-91)
+    bool fast = false;
+    for (int i = 1; i < argc; ++i) {
+        if (!strcmp(argv[i], "--res") && i + 1 < argc) volres = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--frames") && i + 1 < argc) frames = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--width") && i + 1 < argc) w = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--height") && i + 1 < argc) h = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--fast")) fast = true;
+    }
+    if (kfx_device_count() < 1) { fprintf(stderr, "no HIP device\n"); return 2; }
+    kfx_set_math_mode(fast ? KFX_MATH_FAST : KFX_MATH_EXACT);
+
+    // generic camera model based on image dimensions (main.cpp:63-64)
+    const double depth_focal = w * 570.342 / 640.0;
+    const ImageIntrinsics K(depth_focal, depth_focal, w / 2.0 - 0.5, h / 2.0 - 0.5);
+    const float knear = 0.4f, kfar = 4.0f;              // main.cpp:80-81
+    const float bigs = 1.5f, bigr = 0.1f; const int biwin = 3;   // main.cpp:149-151
+    const float trunc_dist_factor = 2.0f, max_w = 1000.0f, mincostheta = 0.1f;  // main.cpp:155-158
+    const BoundingBox reset_bb(make_float3(-1, -1, 2), make_float3(1, 1, 4));
+
+    Image<float, TargetDevice, Manage> dKinectMeters(w, h);
+    Image<float, TargetDevice, Manage> kin_d(w, h);
+    Image<float4, TargetDevice, Manage> kin_v(w, h), kin_n(w, h);
+    Image<float, TargetDevice, Manage> ray_i(w, h), ray_d(w, h);
+    Image<float4, TargetDevice, Manage> ray_n(w, h);
+    BoundedVolume<SDF_t, TargetDevice, Manage> vol(volres, volres, volres, reset_bb);
+
+    const float3 vs = vol.VoxelSizeUnits();
+    const float trunc_dist = trunc_dist_factor * length(vs);   // main.cpp:221
+
+    std::vector<std::vector<float> > depth_frames(frames);
+    std::vector<Mat<float,3,4> > poses(frames);
+    for (int f = 0; f < frames; ++f) {
+        poses[f] = OrbitPose(f, 30);
+        RenderRoom(depth_frames[f], w, h, poses[f], K);
+    }
+
+    std::vector<float> hdepth((size_t)w * h);
+    double total_ms = 0;
+    size_t hits = 0;
+    for (int f = 0; f < frames; ++f) {
+        const Mat<float,3,4> T_wl = poses[f];
+        dKinectMeters.MemcpyFromHost(depth_frames[f].data());   // the host->device boundary of main.cpp:203
+        const auto t0 = std::chrono::steady_clock::now();
+        BilateralFilter<float,float>(kin_d, dKinectMeters, bigs, bigr, biwin, 0.2f);
+        DepthToVbo<float>(kin_v, kin_d, K);
+        NormalsFromVbo(kin_n, kin_v);
+        if (f == 0) {
+            SdfReset(vol, std::numeric_limits<float>::quiet_NaN());
+            SdfFuse(vol, kin_d, kin_n, SE3inv(T_wl), K, trunc_dist, max_w, mincostheta);
+        }
+        const BoundingBox roi(T_wl, w, h, K, knear, kfar);
+        BoundedVolume<SDF_t> work_vol = vol.SubBoundingVolume(roi);
+        if (work_vol.IsValid()) {
+            RaycastSdf(ray_d, ray_n, ray_i, work_vol, T_wl, K, knear, kfar, trunc_dist, true);
+            if (f > 0) SdfFuse(work_vol, kin_d, kin_n, SE3inv(T_wl), K, trunc_dist, max_w, mincostheta);
+        }
+        kfx_stream_synchronize(0);
+        total_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        if (f == frames - 1) {
+            ray_d.MemcpyToHost(hdepth.data());
+            for (float d : hdepth) hits += std::isfinite(d) ? 1 : 0;
+        }
+    }
+    printf("kinectfusion_headless: %d^3 volume, %dx%d, %d frames, %s math: %.3f ms/frame (%.1f fps), last raycast hits %zu/%d\n",
+           volres, w, h, frames, fast ? "fast" : "exact", total_ms / frames, 1e3 * frames / total_ms, hits, w * h);
+    return hits > (size_t)(w * h) / 4 ? 0 : 1;
+}

@@ -1,0 +1,152 @@
+// roo_api_test.cpp -- exercises the roo:: containers and operators from C++ the way a Kangaroo
+// application does, and checks device results against the containers' own host-side methods
+// (the same header code, run on TargetHost copies).  Exit code 0 = all checks passed.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include <kangaroo/kangaroo.h>
+
+using namespace roo;
+
+static int g_fail = 0;
+#define CHECK(cond)                                                                   \
+    do {                                                                              \
+        if (!(cond)) { ++g_fail; fprintf(stderr, "CHECK failed %s:%d: %s\n", __FILE__, __LINE__, #cond); } \
+    } while (0)
+
+static bool same(float a, float b) { return (a == b) || (std::isnan(a) && std::isnan(b)); }
+
+int main()
+{
+    // ---- layouts the C ABI relies on ----
+    CHECK(sizeof(Image<float>) == 32);
+    CHECK(sizeof(Volume<SDF_t>) == 48);
+    CHECK(sizeof(BoundedVolume<SDF_t>) == 72);
+    CHECK(sizeof(SDF_t) == 8 && alignof(SDF_t) == 8);
+    CHECK((sizeof(Mat<float,3,4>) == 48));
+    CHECK(sizeof(ImageIntrinsics) == 16 && sizeof(BoundingBox) == 24);
+
+    // ---- ownership policy: allocating a non-owning container throws ----
+    bool threw = false;
+    try { Image<float> bad(4, 4); } catch (const HipException&) { threw = true; }
+    CHECK(threw);
+
+    // ---- SDF_t running average ----
+    SDF_t a(0.5f, 2.0f);
+    a += SDF_t(NAN, 0.0f);                 // never-observed cell: untouched
+    CHECK(a.val == 0.5f && a.w == 2.0f);
+    a += SDF_t(-0.5f, 2.0f);
+    CHECK(a.val == 0.0f && a.w == 4.0f);
+    a.LimitWeight(3.0f);
+    CHECK(a.w == 3.0f);
+
+    if (kfx_device_count() < 1) {
+        printf("roo_api_test: host-only checks %s (no HIP device)\n", g_fail ? "FAILED" : "passed");
+        return g_fail ? 1 : 0;
+    }
+
+    const int N = 32, w = 64, h = 48;
+    const ImageIntrinsics K(500, 500, w / 2, h / 2);
+    BoundedVolume<SDF_t, TargetDevice, Manage> vol(N, N, N, make_float3(-1, -1, -1), make_float3(1, 1, 1));
+    BoundedVolume<SDF_t, TargetHost, Manage> hvol(N, N, N, make_float3(-1, -1, -1), make_float3(1, 1, 1));
+    CHECK(vol.pitch % 256 == 0 && vol.img_pitch == vol.pitch * N);
+
+    // ---- SdfSphere on the device vs VoxelPositionInUnits on the host ----
+    SdfReset(vol, NAN);
+    SdfSphere(vol, make_float3(0, 0, 0), 0.9f);
+    // device volume is pitched; copy row by row into the packed host volume
+    CHECK(kfx_memcpy_2d(hvol.ptr, hvol.pitch, vol.ptr, vol.pitch, N * sizeof(SDF_t), (size_t)N * N, 2, 0) == 0);
+    int bad = 0;
+    for (int z = 0; z < N; ++z)
+        for (int y = 0; y < N; ++y)
+            for (int x = 0; x < N; ++x) {
+                const float3 p = hvol.VoxelPositionInUnits(x, y, z);
+                const float expect = length(p) - 0.9f;
+                if (!(hvol(x, y, z).val == expect && hvol(x, y, z).w == 1.0f)) ++bad;
+            }
+    CHECK(bad == 0);
+
+    // ---- RaycastSdf on the device vs the same march with the host containers ----
+    Image<float, TargetDevice, Manage> depth(w, h), img(w, h);
+    Image<float4, TargetDevice, Manage> norm(w, h);
+    Mat<float,3,4> T_wc = SE3Identity();
+    T_wc(2, 3) = -3.0f;
+    RaycastSdf(depth, norm, img, vol, T_wc, K, 0.1f, 10.0f, 0.0f, true);
+    std::vector<float> hd((size_t)w * h);
+    std::vector<float4> hn((size_t)w * h);
+    depth.MemcpyToHost(hd.data());
+    norm.MemcpyToHost(hn.data());
+    int mism = 0, nhit = 0;
+    for (int v = 0; v < h; ++v)
+        for (int u = 0; u < w; ++u) {
+            const float3 c_w = SE3Translation(T_wc);
+            const float3 ray_c = K.Unproject((float)u, (float)v);
+            const float3 ray_w = mulSO3(T_wc, ray_c);
+            const float3 ta = div_cw(sub(hvol.bbox.Min(), c_w), ray_w), tb = div_cw(sub(hvol.bbox.Max(), c_w), ray_w);
+            const float3 tmin = min3(ta, tb), tmax = max3(ta, tb);
+            const float t0 = fmaxf(fmaxf(fmaxf(tmin.x, tmin.y), tmin.z), 0.1f);
+            const float t1 = fminf(fminf(fminf(tmax.x, tmax.y), tmax.z), 10.0f);
+            float d = 0.f;
+            if (t0 < t1) {
+                float lambda = t0, last = NAN, step = 0;
+                const float min_step = hvol.VoxelSizeUnits().x;
+                while (lambda < t1) {
+                    const float sdf = hvol.GetUnitsTrilinearClamped(add(c_w, scaled(ray_w, lambda)));
+                    if (sdf <= 0) {
+                        if (last > 0) { lambda = lambda + step * sdf / (last - sdf); d = lambda; }
+                        break;
+                    }
+                    step = sdf > 0 ? fmaxf(sdf, min_step) : 0.0f;
+                    lambda += step;
+                    last = sdf;
+                }
+            }
+            const float got = hd[(size_t)v * w + u];
+            if (d > 0) {
+                ++nhit;
+                const float3 g = hvol.GetUnitsBackwardDiffDxDyDz(add(c_w, scaled(ray_w, d)));
+                const float len = length(g);
+                const float3 n_w = len > 0 ? div_by(g, len) : make_float3(0, 0, 1);
+                const float3 n_c = mulSO3inv(T_wc, n_w);
+                const float4 gn = hn[(size_t)v * w + u];
+                if (!(same(got, d) && gn.x == n_c.x && gn.y == n_c.y && gn.z == n_c.z && gn.w == 1.0f)) ++mism;
+            } else if (!std::isnan(got)) ++mism;
+        }
+    CHECK(nhit > w * h / 8);
+    CHECK(mism == 0);
+
+    // ---- DepthToVbo / NormalsFromVbo vs the host formulas ----
+    std::vector<float> hdep((size_t)w * h);
+    for (int v = 0; v < h; ++v)
+        for (int u = 0; u < w; ++u) hdep[(size_t)v * w + u] = 2.0f + 0.01f * u + 0.02f * v + ((u * 7 + v * 3) % 11 == 0 ? NAN : 0.f);
+    Image<float, TargetDevice, Manage> dd(w, h);
+    Image<float4, TargetDevice, Manage> vbo(w, h), nrm(w, h);
+    dd.MemcpyFromHost(hdep.data());
+    DepthToVbo<float>(vbo, dd, K);
+    NormalsFromVbo(nrm, vbo);
+    std::vector<float4> hv((size_t)w * h), hnn((size_t)w * h);
+    vbo.MemcpyToHost(hv.data());
+    nrm.MemcpyToHost(hnn.data());
+    int vb = 0;
+    for (int v = 0; v < h; ++v)
+        for (int u = 0; u < w; ++u) {
+            const float3 P = K.Unproject((float)u, (float)v, hdep[(size_t)v * w + u]);
+            const float4 g = hv[(size_t)v * w + u];
+            if (!(same(g.x, P.x) && same(g.y, P.y) && same(g.z, P.z) && g.w == 1.0f)) ++vb;
+        }
+    CHECK(vb == 0);
+    CHECK(hnn[(size_t)(h - 1) * w].w == 0.0f && hnn[w - 1].w == 0.0f && hnn[0].w == 1.0f);
+
+    // ---- ROI view: SubBoundingVolume of the frustum, fuse through it ----
+    const BoundingBox roi(T_wc, w, h, K, 2.2f, 3.5f);
+    BoundedVolume<SDF_t> work = vol.SubBoundingVolume(roi);
+    CHECK(work.w <= (size_t)N && work.pitch == vol.pitch && work.img_pitch == vol.img_pitch);
+    CHECK(work.bbox.Min().z >= vol.bbox.Min().z && work.bbox.Max().z <= vol.bbox.Max().z);
+    if (work.IsValid()) SdfFuse(work, dd, nrm, SE3inv(T_wc), K, 0.1f, 100.0f, 0.1f);
+    CHECK(kfx_stream_synchronize(0) == 0);
+
+    printf("roo_api_test: %s (%d ray hits checked)\n", g_fail ? "FAILED" : "all checks passed", nhit);
+    return g_fail ? 1 : 0;
+}

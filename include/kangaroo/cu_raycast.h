@@ -1,0 +1,21 @@
+// cu_raycast.h -- roo::RaycastSdf with the reference's signature (include/kangaroo/cu_raycast.h:13-14).
+#pragma once
+
+#include <kangaroo/BoundedVolume.h>
+#include <kangaroo/Image.h>
+#include <kangaroo/ImageIntrinsics.h>
+#include <kangaroo/Mat.h>
+#include <kangaroo/Sdf.h>
+#include <kangaroo/launch_utils.h>
+#include <kangaroo/platform.h>
+
+namespace roo
+{
+
+KANGAROO_EXPORT inline
+void RaycastSdf(Image<float> depth, Image<float4> norm, Image<float> img, const BoundedVolume<SDF_t> vol, const Mat<float,3,4> T_wc, ImageIntrinsics K, float near, float far, float trunc_dist, bool subpix = true)
+{
+    GpuCheckStatus(kfx_raycast_sdf(depth.abi(), norm.abi(), img.abi(), vol.abi(), T_wc.m, &K.fu, near, far, trunc_dist, subpix ? 1 : 0, 0));
+}
+
+}

@@ -1,0 +1,35 @@
+// cu_sdffusion.h -- roo::SdfFuse / SdfReset / SdfSphere with the reference's signatures
+// (include/kangaroo/cu_sdffusion.h:13-26), forwarding to the gfx950 kernels behind include/kfx.h.
+#pragma once
+
+#include <kangaroo/BoundedVolume.h>
+#include <kangaroo/Image.h>
+#include <kangaroo/ImageIntrinsics.h>
+#include <kangaroo/Mat.h>
+#include <kangaroo/Sdf.h>
+#include <kangaroo/launch_utils.h>
+#include <kangaroo/platform.h>
+
+namespace roo
+{
+
+KANGAROO_EXPORT inline
+void SdfFuse(BoundedVolume<SDF_t> vol, Image<float> depth, Image<float4> norm, Mat<float,3,4> T_cw, ImageIntrinsics K, float trunc_dist, float maxw, float mincostheta )
+{
+    GpuCheckStatus(kfx_sdf_fuse(vol.abi(), depth.abi(), norm.abi(), T_cw.m, &K.fu, trunc_dist, maxw, mincostheta, 0, 0));
+}
+
+KANGAROO_EXPORT inline
+void SdfReset(BoundedVolume<SDF_t> vol, float trunc_dist)
+{
+    GpuCheckStatus(kfx_sdf_reset(vol.abi(), trunc_dist, 0));
+}
+
+KANGAROO_EXPORT inline
+void SdfSphere(BoundedVolume<SDF_t> vol, float3 center, float r)
+{
+    const float c[3] = {center.x, center.y, center.z};
+    GpuCheckStatus(kfx_sdf_sphere(vol.abi(), c, r, 0));
+}
+
+}

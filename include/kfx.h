@@ -141,6 +141,9 @@ int kfx_sdf_sphere(const kfx_volume* vol, const float center[3], float r, kfx_st
  * segments stay aligned); *pitch receives the row stride in bytes. */
 int kfx_alloc_pitched(void** dev_ptr, size_t* pitch, size_t width_bytes, size_t rows);
 int kfx_free(void* dev_ptr);
+/* roo::TargetHost (Memory.h:32-57): page-locked host memory, pitch = width (no padding). */
+int kfx_alloc_host(void** host_ptr, size_t bytes);
+int kfx_free_host(void* host_ptr);
 /* 2-D copies behind Image::CopyFrom / MemcpyFromHost / MemcpyToHost (Image.h:174-213).
  * kind: 0 host->host, 1 host->device, 2 device->host, 3 device->device, 4 default */
 int kfx_memcpy_2d(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width_bytes,

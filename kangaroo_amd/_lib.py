@@ -46,6 +46,8 @@ SIGNATURES = {
     "kfx_sdf_sphere": (C.c_int, [PV, PF, C.c_float, C.c_void_p]),
     "kfx_alloc_pitched": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_size_t, C.c_size_t]),
     "kfx_free": (C.c_int, [C.c_void_p]),
+    "kfx_alloc_host": (C.c_int, [C.POINTER(C.c_void_p), C.c_size_t]),
+    "kfx_free_host": (C.c_int, [C.c_void_p]),
     "kfx_memcpy_2d": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p]),
     "kfx_stream_synchronize": (C.c_int, [C.c_void_p]),
     "kfx_last_error_string": (C.c_char_p, []),

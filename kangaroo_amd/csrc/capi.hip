@@ -108,6 +108,32 @@ extern "C" int kfx_free(void* dev_ptr)
     return 0;
 }
 
+extern "C" int kfx_alloc_host(void** host_ptr, size_t bytes)
+{
+    if (!host_ptr) return set_error(KFX_E_NULL, "kfx_alloc_host: null out pointer");
+    if (bytes == 0) return set_error(KFX_E_SHAPE, "kfx_alloc_host: empty allocation");
+    void* h = nullptr;
+    const hipError_t e = hipHostMalloc(&h, bytes, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        *host_ptr = nullptr;
+        return set_error((int)e, "kfx_alloc_host: hipHostMalloc");
+    }
+    *host_ptr = h;
+    return 0;
+}
+
+extern "C" int kfx_free_host(void* host_ptr)
+{
+    if (!host_ptr) return 0;
+    const hipError_t e = hipHostFree(host_ptr);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return set_error((int)e, "kfx_free_host: hipHostFree");
+    }
+    return 0;
+}
+
 extern "C" int kfx_memcpy_2d(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width_bytes,
                              size_t rows, int kind, kfx_stream stream)
 {
