@@ -41,6 +41,9 @@ def parse():
     ap.add_argument("--res", type=int, default=512, help="volume resolution N (N^3 voxels)")
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
+    ap.add_argument("--halo", default="recompute", choices=["recompute", "exchange"],
+                    help="N > 1: how ghost planes are kept current -- recomputed by each rank (no traffic) or "
+                         "exchanged with the neighbours over RCCL point-to-point after each SdfFuse")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=2)
     return ap.parse_args()
@@ -104,7 +107,7 @@ def main():
     bmin, bmax, near, far = scenes.SCENES[scene]
     K = scenes.intrinsics(w, h)
     if distributed:
-        pipe = SlabPipeline(roo, dist, (N, N, N), bmin, bmax, w, h, K=K, near=near, far=far)
+        pipe = SlabPipeline(roo, dist, (N, N, N), bmin, bmax, w, h, halo=args.halo, K=K, near=near, far=far)
     else:
         pipe = FramePipeline(roo, (N, N, N), bmin, bmax, w, h, K=K, near=near, far=far)
 
@@ -210,7 +213,8 @@ def main():
                             "-> DepthToVbo -> NormalsFromVbo -> SdfFuse -> RaycastSdf" % (
                                 N, 8.0 * N ** 3 / 2 ** 30, w, h, scene, N_ORBIT),
                 "volume": [N, N, N], "image": [w, h], "scene": scene,
-                "partition": "z-slabs x%d" % n_gpus if distributed else "single volume",
+                "partition": ("z-slabs x%d, ghost planes %s, raycast composite = all_reduce(MIN key) + all_reduce(SUM payload)" % (n_gpus, args.halo))
+                             if distributed else "single volume",
                 "math": {"fast": "fast (fp32 rcp/rsq + FMA: the reference's own -use_fast_math regime; TSDF within 1e-4 of the exact path, "
                                  "tests/test_gpu_parity.py::test_gpu_fast_mode_within_tolerance)",
                          "exact": "exact (IEEE fp32, no FMA contraction, reference operation order; bit-identical to the oracle)"}[args.math],

@@ -94,7 +94,13 @@ class SlabPipeline(FramePipeline):
 
     GHOST = 2  # >= 1 for the trilinear z+1 corner and the gradient's z-1 / z+1 cells (Volume.h:240-289)
 
-    def __init__(self, ops, dist, dims, boxmin, boxmax, w, h, **kw):
+    def __init__(self, ops, dist, dims, boxmin, boxmax, w, h, halo="exchange", **kw):
+        """halo = "exchange": every rank integrates only the planes it owns and the ghost planes are
+        refreshed from the two neighbours after each SdfFuse (point-to-point send/recv: one xGMI link
+        per direction); halo = "recompute": every rank integrates its ghost planes itself (the update is
+        deterministic per voxel, so no traffic is needed) -- the cross-check of the exchange path."""
+        assert halo in ("exchange", "recompute")
+        self.halo = halo
         self.dist = dist
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
         self.full_boxmin = np.asarray(boxmin, np.float32)
@@ -117,9 +123,34 @@ class SlabPipeline(FramePipeline):
         return self.ops.BoundedVolume(W, H, self.s1 - self.s0, lo, hi)
 
     def fuse(self, T_wc):
-        # the local view may have a plane count that is not a multiple of 8: integrate all of it
-        self.ops.SdfFuse(self.vol, self.filtered, self.normals, scenes.se3_inverse(T_wc), self.K, self.trunc,
+        # views may have a plane count that is not a multiple of 8: integrate all of it (full_extent)
+        if self.halo == "recompute" or self.world == 1:
+            target = self.vol
+        else:
+            target = self.vol.ZSlab(self.z0 - self.s0, self.z1 - self.s0)  # owned planes only
+        self.ops.SdfFuse(target, self.filtered, self.normals, scenes.se3_inverse(T_wc), self.K, self.trunc,
                          self.max_w, self.mincostheta, full_extent=True)
+        if target is not self.vol:
+            self.exchange_halos()
+
+    def exchange_halos(self):
+        """Refresh the ghost planes from the neighbours' owned planes (contiguous img_pitch-sized
+        slices): rank r sends its first / last G owned planes down / up and receives the matching
+        planes of its neighbours.  One batched group of point-to-point operations."""
+        dist = self.dist
+        ops = []
+        lo_ghost = self.z0 - self.s0              # planes [s0, z0) come from rank-1
+        hi_ghost = self.s1 - self.z1              # planes [z1, s1) come from rank+1
+        own0, own1 = self.z0 - self.s0, self.z1 - self.s0   # local indices of the owned range
+        if self.rank > 0 and lo_ghost > 0:
+            ops.append(dist.P2POp(dist.isend, self.vol.planes(own0, own0 + lo_ghost), self.rank - 1))
+            ops.append(dist.P2POp(dist.irecv, self.vol.planes(0, lo_ghost), self.rank - 1))
+        if self.rank < self.world - 1 and hi_ghost > 0:
+            ops.append(dist.P2POp(dist.isend, self.vol.planes(own1 - hi_ghost, own1), self.rank + 1))
+            ops.append(dist.P2POp(dist.irecv, self.vol.planes(own1, own1 + hi_ghost), self.rank + 1))
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
 
     def raycast(self, T_wc):
         super().raycast(T_wc)

@@ -176,6 +176,11 @@ class BoundedVolume:
         sub.boxmax = self.VoxelPositionInUnits(self.w - 1, self.h - 1, z1 - 1)
         return sub
 
+    def planes(self, z0, z1):
+        """Contiguous uint8 view of the z-slices [z0, z1) (img_pitch bytes each), for halo exchange."""
+        assert self.img_pitch == self.pitch * self.h
+        return self.storage[self.offset + z0 * self.img_pitch: self.offset + z1 * self.img_pitch]
+
     def tensor(self):
         """Strided float32 torch view (d, h, w, 2) of the cells."""
         flat = self.storage[self.offset:].view(torch.float32)

@@ -436,3 +436,40 @@ def test_gpu_full_size_properties(roo):
         assert np.median(err[ok]) < 0.5 * voxel
         del vol, a, c
         torch.cuda.empty_cache()
+
+
+# ---------------------------------------------------------------------------------
+# multi-GPU plumbing on one GPU: the slab pipeline's device-side tensor code and RCCL calls
+# ---------------------------------------------------------------------------------
+def test_gpu_slab_pipeline_single_rank_rccl(roo):
+    """World-size-1 RCCL group on the single GPU: exercises SlabPipeline's device tensor code
+    (key packing, MIN / SUM all-reduces, halo plane views) with the real HIP operators; with one
+    rank the composite must reproduce the local raycast exactly."""
+    import torch
+    import torch.distributed as dist
+    from kangaroo_amd.pipeline import FramePipeline, SlabPipeline
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29531")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        N, w, h = 64, 160, 120
+        bmin, bmax, near, far = scenes.SCENES["room"]
+        slab = SlabPipeline(roo, dist, (N, N, N), bmin, bmax, w, h, halo="exchange", near=near, far=far)
+        mono = FramePipeline(roo, (N, N, N), bmin, bmax, w, h, near=near, far=far)
+        for i in range(2):
+            T_wc = scenes.orbit_pose(i, 8)
+            raw = scenes.render_depth("room", w, h, T_wc, slab.K)
+            slab.raw.MemcpyFromHost(raw)
+            mono.raw.MemcpyFromHost(raw)
+            slab.step(T_wc)
+            mono.step(T_wc)
+        assert T.nan_equal(slab.vol.MemcpyToHost(), mono.vol.MemcpyToHost())
+        before = (slab.ray_d.MemcpyToHost(), slab.ray_n.MemcpyToHost(), slab.ray_i.MemcpyToHost())
+        assert T.nan_equal(before[0], mono.ray_d.MemcpyToHost())
+        slab.composite()  # one rank: the winner is always rank 0
+        torch.cuda.synchronize()
+        assert T.nan_equal(slab.ray_d.MemcpyToHost(), before[0])
+        assert T.nan_equal(slab.ray_n.MemcpyToHost(), before[1]) and T.nan_equal(slab.ray_i.MemcpyToHost(), before[2])
+        assert slab.vol.planes(1, 3).numel() == 2 * slab.vol.img_pitch
+    finally:
+        dist.destroy_process_group()

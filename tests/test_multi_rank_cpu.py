@@ -28,13 +28,13 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, halo):
     import oracle_ops as ops
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     bmin, bmax, near, far = scenes.SCENES["room"]
-    pipe = SlabPipeline(ops, dist, (N, N, N), bmin, bmax, W, H, near=near, far=far)
+    pipe = SlabPipeline(ops, dist, (N, N, N), bmin, bmax, W, H, halo=halo, near=near, far=far)
     K = pipe.K
     for i in range(FRAMES):
         T_wc = scenes.orbit_pose(i, 8)
@@ -56,10 +56,10 @@ def test_slab_range_partitions_every_plane_once():
             assert max(sizes) - min(sizes) <= 1
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_slab_pipeline_matches_single_volume(tmp_path, world):
+@pytest.mark.parametrize("world,halo", [(2, "exchange"), (2, "recompute"), (3, "exchange")])
+def test_slab_pipeline_matches_single_volume(tmp_path, world, halo):
     import oracle_ops as ops
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), halo), nprocs=world, join=True)
     # single-process reference: the same frames through the monolithic pipeline
     bmin, bmax, near, far = scenes.SCENES["room"]
     ref = FramePipeline(ops, (N, N, N), bmin, bmax, W, H, near=near, far=far)
