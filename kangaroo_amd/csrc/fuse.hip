@@ -290,12 +290,13 @@ __global__ __launch_bounds__(256) void k_sdf_fuse(const FuseParams p)
 // rectangle can never be read from LDS).  Texel values are copies, so results are identical
 // to the generic kernel in either numerics mode.
 // ---------------------------------------------------------------------------------------
-template <bool FAST>
+template <bool FAST, int ZU>
 __global__ __launch_bounds__(256) void k_sdf_fuse_tiled(const FuseParams p, const int cap_px)
 {
     extern __shared__ __attribute__((aligned(16))) float4 s_tile[];
     __shared__ float s_pz[FUSE_ZC];
-    __shared__ float s_box[4][4];
+    __shared__ float s_box[4][5];
+    __shared__ float s_dmax[4];
     __shared__ int s_bad[4];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int x0 = (blockIdx.x * 32 + (lane & 31)) * 2;
@@ -313,6 +314,7 @@ __global__ __launch_bounds__(256) void k_sdf_fuse_tiled(const FuseParams p, cons
 
     // ---- pixel rectangle of the brick: projections of its first and last slice ----
     float umin = __builtin_inff(), umax = -__builtin_inff(), vmin = __builtin_inff(), vmax = -__builtin_inff();
+    float zmin = __builtin_inff(); // nearest camera-space Z of the brick (Z is affine along a column: ends suffice)
     bool bad = false;
     if (live) {
 #pragma unroll
@@ -326,6 +328,7 @@ __global__ __launch_bounds__(256) void k_sdf_fuse_tiled(const FuseParams p, cons
                 bad = bad || !(Pc.z > 0.f) || !(fabsf(pu) < 1e9f) || !(fabsf(pv) < 1e9f);
                 umin = fminf(umin, pu); umax = fmaxf(umax, pu);
                 vmin = fminf(vmin, pv); vmax = fmaxf(vmax, pv);
+                zmin = fminf(zmin, Pc.z);
             }
         }
     }
@@ -333,13 +336,15 @@ __global__ __launch_bounds__(256) void k_sdf_fuse_tiled(const FuseParams p, cons
     for (int off = 32; off > 0; off >>= 1) { // wave64 butterfly
         umin = fminf(umin, __shfl_xor(umin, off, 64)); umax = fmaxf(umax, __shfl_xor(umax, off, 64));
         vmin = fminf(vmin, __shfl_xor(vmin, off, 64)); vmax = fmaxf(vmax, __shfl_xor(vmax, off, 64));
+        zmin = fminf(zmin, __shfl_xor(zmin, off, 64));
     }
     const bool wave_bad = __ballot(bad) != 0ull;
     if (lane == 0) {
-        s_box[wv][0] = umin; s_box[wv][1] = umax; s_box[wv][2] = vmin; s_box[wv][3] = vmax;
+        s_box[wv][0] = umin; s_box[wv][1] = umax; s_box[wv][2] = vmin; s_box[wv][3] = vmax; s_box[wv][4] = zmin;
         s_bad[wv] = wave_bad ? 1 : 0;
     }
     __syncthreads();
+    zmin = fminf(fminf(s_box[0][4], s_box[1][4]), fminf(s_box[2][4], s_box[3][4]));
     umin = fminf(fminf(s_box[0][0], s_box[1][0]), fminf(s_box[2][0], s_box[3][0]));
     umax = fmaxf(fmaxf(s_box[0][1], s_box[1][1]), fmaxf(s_box[2][1], s_box[3][1]));
     vmin = fminf(fminf(s_box[0][2], s_box[1][2]), fminf(s_box[2][2], s_box[3][2]));
@@ -359,49 +364,87 @@ __global__ __launch_bounds__(256) void k_sdf_fuse_tiled(const FuseParams p, cons
         tw = (int)fx1 - tx0 + 1; th = (int)fy1 - ty0 + 1;
         use_tile = tw > 1 && th > 1 && tw * th <= cap_px;
     }
+    float dmax = -__builtin_inff(); // farthest finite depth in the rectangle (fmaxf skips NaN texels)
     if (use_tile) { // cooperative, row-coalesced staging
         for (int r = wv; r < th; r += 4) {
             const float* drow = row<float>(p.depth, (size_t)(ty0 + r)) + tx0;
             const float4* nrow = row<float4>(p.norm, (size_t)(ty0 + r)) + tx0;
             for (int c = lane; c < tw; c += 64) {
                 const float4 n = nrow[c];
-                s_tile[r * tw + c] = make_float4(n.x, n.y, n.z, drow[c]);
+                const float d = drow[c];
+                s_tile[r * tw + c] = make_float4(n.x, n.y, n.z, d);
+                dmax = fmaxf(dmax, d);
             }
         }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) dmax = fmaxf(dmax, __shfl_xor(dmax, off, 64));
+        if (lane == 0) s_dmax[wv] = dmax;
     }
     __syncthreads();
+    // Occlusion culling of the whole brick.  An update needs costheta > mincos and
+    // costheta * (md - Z) > -trunc, hence md - Z > -trunc / mincos; md is a convex combination of
+    // texels of the staged rectangle, so md <= dmax, and Z >= zmin.  If even dmax - zmin lies below
+    // that bound (with a relative margin far above the rounding of the per-voxel expression), no voxel
+    // of the brick can change: skip it before any volume traffic or per-voxel arithmetic.
+    if (use_tile && p.mincos > 0.f && p.trunc > 0.f) {
+        dmax = fmaxf(fmaxf(s_dmax[0], s_dmax[1]), fmaxf(s_dmax[2], s_dmax[3]));
+        const float bound = -(p.trunc / p.mincos) * 1.001f;
+        if (dmax + fabsf(dmax) * 1e-5f - zmin < bound) return; // also when every texel is NaN (dmax = -inf)
+    }
     if (!live) return;
 
+    // one voxel's observation, corners from the LDS tile when the cell lies inside it
+    auto observe_tile = [&](int v, float pz) -> Obs {
+        Obs o;
+        o.ok = false;
+        o.val = 0.f;
+        o.w = 0.f;
+        const V3 Pc = cam[v].at(p, pz);
+        float pu, pv, iz;
+        project<FAST>(p, Pc, pu, pv, iz);
+        if (in_bounds(p, pu, pv)) {
+            const float fix = floorf(pu), fiy = floorf(pv);
+            const int ix = (int)fix, iy = (int)fiy;
+            const unsigned rx = (unsigned)(ix - tx0), ry = (unsigned)(iy - ty0);
+            Corners c;
+            if (use_tile && rx < (unsigned)(tw - 1) && ry < (unsigned)(th - 1)) {
+                const float4* t = s_tile + (ry * (unsigned)tw + rx);
+                c.c00 = t[0]; c.c01 = t[1]; c.c10 = t[tw]; c.c11 = t[tw + 1];
+            } else {
+                c = fetch_global32(p, ix, iy);
+            }
+            o = finish<FAST>(p, Pc, iz, pu - fix, pv - fiy, c);
+        }
+        return o;
+    };
+
+    // ZU slices per iteration: their volume cells are requested together, so a wave keeps ZU
+    // 16-byte reads per lane in flight
     unsigned char* cell = p.vptr + (size_t)zbeg * p.vimg_pitch + (size_t)y * p.vpitch + (size_t)x0 * 8;
-    for (int z = zbeg; z < zend; ++z, cell += p.vimg_pitch) {
-        const float pz = s_pz[z - zbeg];
-        Obs o[2];
+    for (int z = zbeg; z < zend; z += ZU, cell += (size_t)ZU * p.vimg_pitch) {
+        Obs o[ZU][2];
+        bool any[ZU];
 #pragma unroll
-        for (int v = 0; v < 2; ++v) {
-            o[v].ok = false;
-            const V3 Pc = cam[v].at(p, pz);
-            float pu, pv, iz;
-            project<FAST>(p, Pc, pu, pv, iz);
-            if (in_bounds(p, pu, pv)) {
-                const float fix = floorf(pu), fiy = floorf(pv);
-                const int ix = (int)fix, iy = (int)fiy;
-                const unsigned rx = (unsigned)(ix - tx0), ry = (unsigned)(iy - ty0);
-                Corners c;
-                if (use_tile && rx < (unsigned)(tw - 1) && ry < (unsigned)(th - 1)) {
-                    const float4* t = s_tile + (ry * (unsigned)tw + rx);
-                    c.c00 = t[0]; c.c01 = t[1]; c.c10 = t[tw]; c.c11 = t[tw + 1];
-                } else {
-                    c = fetch_global32(p, ix, iy);
-                }
-                o[v] = finish<FAST>(p, Pc, iz, pu - fix, pv - fiy, c);
+        for (int k = 0; k < ZU; ++k) {
+            any[k] = false;
+            if (z + k < zend) {
+                const float pz = s_pz[z + k - zbeg];
+                o[k][0] = observe_tile(0, pz);
+                o[k][1] = observe_tile(1, pz);
+                any[k] = o[k][0].ok || o[k][1].ok;
             }
         }
-        if (o[0].ok || o[1].ok) {
-            float4 c = vol_ld(cell);
-            if (o[0].ok) accumulate<FAST>(o[0], p.max_w, c.x, c.y);
-            if (o[1].ok) accumulate<FAST>(o[1], p.max_w, c.z, c.w);
-            vol_st(cell, c);
-        }
+        float4 c[ZU];
+#pragma unroll
+        for (int k = 0; k < ZU; ++k)
+            if (any[k]) c[k] = vol_ld(cell + (size_t)k * p.vimg_pitch);
+#pragma unroll
+        for (int k = 0; k < ZU; ++k)
+            if (any[k]) {
+                if (o[k][0].ok) accumulate<FAST>(o[k][0], p.max_w, c[k].x, c[k].y);
+                if (o[k][1].ok) accumulate<FAST>(o[k][1], p.max_w, c[k].z, c[k].w);
+                vol_st(cell + (size_t)k * p.vimg_pitch, c[k]);
+            }
     }
 }
 
@@ -550,8 +593,13 @@ extern "C" int kfx_sdf_fuse(const kfx_volume* vol, const kfx_image* depth, const
     if (tiled && vec2 && small_images) {
         dim3 grid(ceil_div(p.X, TB_X), ceil_div(p.Y, TB_Y), ceil_div(p.Z, FUSE_ZC));
         const size_t lds = (size_t)cap_px * sizeof(float4);
-        if (fast) hipLaunchKernelGGL(k_sdf_fuse_tiled<true>, grid, dim3(256), lds, s, p, cap_px);
-        else hipLaunchKernelGGL(k_sdf_fuse_tiled<false>, grid, dim3(256), lds, s, p, cap_px);
+        // slices per iteration: 2 in fast mode (memory-bound: more reads in flight), 1 in exact mode (VALU-bound)
+        static const int zu_env = [] { const char* e = getenv("KFX_FUSE_ZU"); return e ? atoi(e) : 0; }();
+        const int zu = zu_env ? zu_env : (fast ? 2 : 1);
+        if (fast && zu == 2) hipLaunchKernelGGL((k_sdf_fuse_tiled<true, 2>), grid, dim3(256), lds, s, p, cap_px);
+        else if (fast) hipLaunchKernelGGL((k_sdf_fuse_tiled<true, 1>), grid, dim3(256), lds, s, p, cap_px);
+        else if (zu == 2) hipLaunchKernelGGL((k_sdf_fuse_tiled<false, 2>), grid, dim3(256), lds, s, p, cap_px);
+        else hipLaunchKernelGGL((k_sdf_fuse_tiled<false, 1>), grid, dim3(256), lds, s, p, cap_px);
     } else if (vec2) {
         dim3 grid(ceil_div(p.X, 128), ceil_div(p.Y, FUSE_ROWS), ceil_div(p.Z, FUSE_ZC));
         if (fast && small_images) hipLaunchKernelGGL((k_sdf_fuse<2, true, true>), grid, dim3(256), 0, s, p);
