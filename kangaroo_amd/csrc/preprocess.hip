@@ -6,12 +6,13 @@
 // tile (workgroup tile + apron, loaded once with clamped coordinates, which is exactly
 // Image::GetWithClampedRange) and the (2r+1)^2 spatial weights are evaluated once per
 // workgroup into LDS instead of once per tap per pixel.
+#include <cstdlib>
+
 #include "kfx_device.h"
 
 namespace kfx {
 
-constexpr int BIL_TX = 32, BIL_TY = 8; // workgroup tile (256 threads): wave = 32x2 pixels
-constexpr int BIL_MAX_R = 16;          // LDS path up to a 33x33 window
+constexpr int BIL_MAX_R = 16; // LDS path up to a 33x33 window
 
 struct BilParams {
     const unsigned char* in;
@@ -34,56 +35,64 @@ __device__ __forceinline__ float load_clamped(const BilParams& p, int x, int y)
     return (float)reinterpret_cast<const Ti*>(p.in + (size_t)y * p.in_pitch)[x];
 }
 
-// Integer inputs are held as float in LDS: every uchar/ushort value and every
-// difference of two is exactly representable, so (float)(p - q), q >= minval and w * q
-// give the reference's results.
-template <typename Ti>
-__global__ __launch_bounds__(BIL_TX * BIL_TY) void k_bilateral(const BilParams p)
+// Workgroup = TX x TY threads (256), each thread filters PY pixels of one column, so the LDS
+// tile is (TX + 2R) x (TY*PY + 2R): taller tiles amortise the apron (7x7 window at TX x TY*PY =
+// 32x8: 2.1 loads per output pixel, 32x32: 1.4).  Integer inputs are held as float in LDS: every
+// uchar/ushort value and every difference of two is exactly representable, so (float)(p - q),
+// q >= minval and w * q give the reference's results.
+template <typename Ti, int TX, int TY, int PY>
+__global__ __launch_bounds__(TX * TY) void k_bilateral(const BilParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int NT = TX * TY;
     const int R = p.R, D = 2 * R + 1;
-    const int TW = BIL_TX + 2 * R, TH = BIL_TY + 2 * R;
+    const int TW = TX + 2 * R, TH = TY * PY + 2 * R;
     float* tile = lds;          // TH x TW
     float* sw = lds + TW * TH;  // D x D spatial weights
     const int tid = threadIdx.x;
-    const int bx = blockIdx.x * BIL_TX, by = blockIdx.y * BIL_TY;
+    const int bx = blockIdx.x * TX, by = blockIdx.y * (TY * PY);
 
-    for (int i = tid; i < TW * TH; i += BIL_TX * BIL_TY) {
+    for (int i = tid; i < TW * TH; i += NT) {
         const int ty = i / TW, tx = i - ty * TW;
         tile[i] = load_clamped<Ti>(p, bx + tx - R, by + ty - R);
     }
-    for (int i = tid; i < D * D; i += BIL_TX * BIL_TY) {
+    for (int i = tid; i < D * D; i += NT) {
         const int r = i / D - R, c = i % D - R;
         const float sd2 = (float)(r * r + c * c);
         sw[i] = __expf(-(sd2) / (2 * p.gs * p.gs));
     }
     __syncthreads();
 
-    const int lx = tid % BIL_TX, ly = tid / BIL_TX;
-    const int x = bx + lx, y = by + ly;
-    if (x >= p.w || y >= p.h) return;
-
-    const float pc = tile[(ly + R) * TW + lx + R];
-    float sum = 0.f, sumw = 0.f;
-    if (!p.use_minval || pc >= p.minval) {
-        const float inv2gr = 2 * p.gr * p.gr;
-        for (int r = 0; r < D; ++r) {
-            const float* trow = tile + (ly + r) * TW + lx;
-            const float* srow = sw + r * D;
-            for (int c = 0; c < D; ++c) {
-                const float q = trow[c];
-                if (!p.use_minval || q >= p.minval) {
-                    const float id = pc - q;
-                    const float id2 = id * id;
-                    const float iw = __expf(-(id2) / inv2gr);
-                    const float w = srow[c] * iw;
-                    sumw += w;
-                    sum += w * q;
+    const int lx = tid % TX, ly0 = tid / TX;
+    const int x = bx + lx;
+    if (x >= p.w) return;
+    const float inv2gr = 2 * p.gr * p.gr;
+#pragma unroll
+    for (int k = 0; k < PY; ++k) {
+        const int ly = ly0 + k * TY; // rows of one thread are TY apart: a wave still reads whole LDS rows
+        const int y = by + ly;
+        if (y >= p.h) break;
+        const float pc = tile[(ly + R) * TW + lx + R];
+        float sum = 0.f, sumw = 0.f;
+        if (!p.use_minval || pc >= p.minval) {
+            for (int r = 0; r < D; ++r) {
+                const float* trow = tile + (ly + r) * TW + lx;
+                const float* srow = sw + r * D;
+                for (int c = 0; c < D; ++c) {
+                    const float q = trow[c];
+                    if (!p.use_minval || q >= p.minval) {
+                        const float id = pc - q;
+                        const float id2 = id * id;
+                        const float iw = __expf(-(id2) / inv2gr);
+                        const float w = srow[c] * iw;
+                        sumw += w;
+                        sum += w * q;
+                    }
                 }
             }
         }
+        reinterpret_cast<float*>(p.out + (size_t)y * p.out_pitch)[x] = sum / sumw;
     }
-    reinterpret_cast<float*>(p.out + (size_t)y * p.out_pitch)[x] = sum / sumw;
 }
 
 // Window too large for the LDS tile: straight global gathers.
@@ -200,9 +209,23 @@ static int bilateral_launch(const kfx_image* out, const kfx_image* in, float gs,
     hipStream_t s = (hipStream_t)stream;
     if (p.R <= BIL_MAX_R) {
         const int D = 2 * p.R + 1;
-        const size_t lds = (size_t)((BIL_TX + 2 * p.R) * (BIL_TY + 2 * p.R) + D * D) * sizeof(float);
-        dim3 grid(ceil_div(p.w, BIL_TX), ceil_div(p.h, BIL_TY));
-        hipLaunchKernelGGL(k_bilateral<Ti>, grid, dim3(BIL_TX * BIL_TY), lds, s, p);
+        // tile shape (config C3 sweep, scripts/config_sweep.py): KFX_BILATERAL_TILE = 0..5
+        static const int shape = [] { const char* e = getenv("KFX_BILATERAL_TILE"); return e ? atoi(e) : 2; }();
+#define KFX_BIL(TX_, TY_, PY_)                                                                                   \
+    do {                                                                                                        \
+        const size_t lds = (size_t)((TX_ + 2 * p.R) * (TY_ * PY_ + 2 * p.R) + D * D) * sizeof(float);           \
+        dim3 grid(ceil_div(p.w, TX_), ceil_div(p.h, TY_ * PY_));                                                \
+        hipLaunchKernelGGL((k_bilateral<Ti, TX_, TY_, PY_>), grid, dim3(TX_ * TY_), lds, s, p);                 \
+    } while (0)
+        switch (shape) {
+        case 0: KFX_BIL(32, 8, 1); break;
+        case 1: KFX_BIL(64, 4, 1); break;
+        case 3: KFX_BIL(32, 8, 2); break;
+        case 4: KFX_BIL(32, 8, 4); break;
+        case 5: KFX_BIL(64, 4, 4); break;
+        default: KFX_BIL(16, 16, 1); break; // best of the sweep at 1280x960 (profiles/r01_config_sweep.txt)
+        }
+#undef KFX_BIL
     } else {
         dim3 grid(ceil_div(p.w, 64), ceil_div(p.h, 4));
         hipLaunchKernelGGL(k_bilateral_global<Ti>, grid, dim3(256), 0, s, p);
