@@ -139,6 +139,35 @@ int main()
     CHECK(vb == 0);
     CHECK(hnn[(size_t)(h - 1) * w].w == 0.0f && hnn[w - 1].w == 0.0f && hnn[0].w == 1.0f);
 
+    // ---- fp16 cells (config C5): SdfSphere + RaycastSdf on BoundedVolume<SDF_h> ----
+    {
+        CHECK(sizeof(SDF_h) == 4 && sizeof(BoundedVolume<SDF_h>) == 72);
+        BoundedVolume<SDF_h, TargetDevice, Manage> volh(N, N, N, make_float3(-1, -1, -1), make_float3(1, 1, 1));
+        BoundedVolume<SDF_h, TargetHost, Manage> hvolh(N, N, N, make_float3(-1, -1, -1), make_float3(1, 1, 1));
+        SdfReset(volh, NAN);
+        SdfSphere(volh, make_float3(0, 0, 0), 0.9f);
+        CHECK(kfx_memcpy_2d(hvolh.ptr, hvolh.pitch, volh.ptr, volh.pitch, N * sizeof(SDF_h), (size_t)N * N, 2, 0) == 0);
+        int badh = 0;
+        for (int z = 0; z < N; ++z)
+            for (int y = 0; y < N; ++y)
+                for (int x = 0; x < N; ++x) {
+                    const SDF_h expect(length(hvolh.VoxelPositionInUnits(x, y, z)) - 0.9f);
+                    if (hvolh(x, y, z).val != expect.val || hvolh(x, y, z).w != expect.w) ++badh;
+                }
+        CHECK(badh == 0);
+        RaycastSdf(depth, norm, img, volh, T_wc, K, 0.1f, 10.0f, 0.0f, true);
+        std::vector<float> hdh((size_t)w * h);
+        depth.MemcpyToHost(hdh.data());
+        int nh = 0;
+        for (float d : hdh) nh += std::isfinite(d) ? 1 : 0;
+        CHECK(nh > w * h / 8);
+        // the half volume's surface is within half precision of the fp32 one
+        float worst = 0;
+        for (size_t i = 0; i < hdh.size(); ++i)
+            if (std::isfinite(hdh[i]) && std::isfinite(hd[i])) worst = fmaxf(worst, fabsf(hdh[i] - hd[i]));
+        CHECK(worst < 5e-3f);
+    }
+
     // ---- ROI view: SubBoundingVolume of the frustum, fuse through it ----
     const BoundingBox roi(T_wc, w, h, K, 2.2f, 3.5f);
     BoundedVolume<SDF_t> work = vol.SubBoundingVolume(roi);

@@ -18,4 +18,12 @@ void RaycastSdf(Image<float> depth, Image<float4> norm, Image<float> img, const 
     GpuCheckStatus(kfx_raycast_sdf(depth.abi(), norm.abi(), img.abi(), vol.abi(), T_wc.m, &K.fu, near, far, trunc_dist, subpix ? 1 : 0, 0));
 }
 
+
+// fp16-cell overload (config C5)
+KANGAROO_EXPORT inline
+void RaycastSdf(Image<float> depth, Image<float4> norm, Image<float> img, const BoundedVolume<SDF_h> vol, const Mat<float,3,4> T_wc, ImageIntrinsics K, float near, float far, float trunc_dist, bool subpix = true)
+{
+    GpuCheckStatus(kfx_raycast_sdf_h(depth.abi(), norm.abi(), img.abi(), vol.abi(), T_wc.m, &K.fu, near, far, trunc_dist, subpix ? 1 : 0, 0));
+}
+
 }

@@ -25,6 +25,26 @@ void SdfReset(BoundedVolume<SDF_t> vol, float trunc_dist)
     GpuCheckStatus(kfx_sdf_reset(vol.abi(), trunc_dist, 0));
 }
 
+// fp16-cell overloads (config C5)
+KANGAROO_EXPORT inline
+void SdfFuse(BoundedVolume<SDF_h> vol, Image<float> depth, Image<float4> norm, Mat<float,3,4> T_cw, ImageIntrinsics K, float trunc_dist, float maxw, float mincostheta )
+{
+    GpuCheckStatus(kfx_sdf_fuse_h(vol.abi(), depth.abi(), norm.abi(), T_cw.m, &K.fu, trunc_dist, maxw, mincostheta, 0, 0));
+}
+
+KANGAROO_EXPORT inline
+void SdfReset(BoundedVolume<SDF_h> vol, float trunc_dist)
+{
+    GpuCheckStatus(kfx_sdf_reset_h(vol.abi(), trunc_dist, 0));
+}
+
+KANGAROO_EXPORT inline
+void SdfSphere(BoundedVolume<SDF_h> vol, float3 center, float r)
+{
+    const float c[3] = {center.x, center.y, center.z};
+    GpuCheckStatus(kfx_sdf_sphere_h(vol.abi(), c, r, 0));
+}
+
 KANGAROO_EXPORT inline
 void SdfSphere(BoundedVolume<SDF_t> vol, float3 center, float r)
 {

@@ -135,6 +135,19 @@ int kfx_sdf_reset(const kfx_volume* vol, float trunc_dist, kfx_stream stream);
  * reference: cu_sdffusion.h:26, src/cu_sdffusion.cu:175-195 */
 int kfx_sdf_sphere(const kfx_volume* vol, const float center[3], float r, kfx_stream stream);
 
+/* ---- fp16 TSDF (BASELINE config C5) ---------------------------------------------------------
+ * Same operators on a volume of roo::SDF_h {half val; half w;} cells (4 bytes, include/kangaroo/Sdf.h):
+ * the arithmetic of the reference's commented-out half SDF_t (Sdf.h:38-62), every intermediate of the
+ * running average rounded to half (round-to-nearest-even).  2048^3 = 32 GiB fits one MI355X. */
+int kfx_sdf_fuse_h(const kfx_volume* vol, const kfx_image* depth, const kfx_image* norm,
+                   const float T_cw[12], const float K[4], float trunc_dist, float max_w,
+                   float mincostheta, unsigned flags, kfx_stream stream);
+int kfx_raycast_sdf_h(const kfx_image* depth, const kfx_image* norm, const kfx_image* img,
+                      const kfx_volume* vol, const float T_wc[12], const float K[4], float near,
+                      float far, float trunc_dist, int subpix, kfx_stream stream);
+int kfx_sdf_reset_h(const kfx_volume* vol, float trunc_dist, kfx_stream stream);
+int kfx_sdf_sphere_h(const kfx_volume* vol, const float center[3], float r, kfx_stream stream);
+
 /* ---- device allocator: roo::TargetDevice (Memory.h:59-84) ----------------------- */
 
 /* AllocatePitchedMem: rows padded to a multiple of 256 bytes (512 B coalescing

@@ -35,6 +35,10 @@ PI, PV, PF = C.POINTER(KfxImage), C.POINTER(KfxVolume), C.POINTER(C.c_float)
 SIGNATURES = {
     "kfx_sdf_fuse": (C.c_int, [PV, PI, PI, PF, PF, C.c_float, C.c_float, C.c_float, C.c_uint, C.c_void_p]),
     "kfx_sdf_fuse_count": (C.c_int, [PV, PI, PI, PF, PF, C.c_float, C.c_float, C.c_uint, C.c_void_p, C.c_void_p]),
+    "kfx_sdf_fuse_h": (C.c_int, [PV, PI, PI, PF, PF, C.c_float, C.c_float, C.c_float, C.c_uint, C.c_void_p]),
+    "kfx_raycast_sdf_h": (C.c_int, [PI, PI, PI, PV, PF, PF, C.c_float, C.c_float, C.c_float, C.c_int, C.c_void_p]),
+    "kfx_sdf_reset_h": (C.c_int, [PV, C.c_float, C.c_void_p]),
+    "kfx_sdf_sphere_h": (C.c_int, [PV, PF, C.c_float, C.c_void_p]),
     "kfx_raycast_sdf": (C.c_int, [PI, PI, PI, PV, PF, PF, C.c_float, C.c_float, C.c_float, C.c_int, C.c_void_p]),
     "kfx_bilateral_f32": (C.c_int, [PI, PI, C.c_float, C.c_float, C.c_uint, C.c_float, C.c_int, C.c_void_p]),
     "kfx_bilateral_u16": (C.c_int, [PI, PI, C.c_float, C.c_float, C.c_uint, C.c_ushort, C.c_void_p]),

@@ -22,6 +22,8 @@
 // op issues in 4 cycles, twice a scalar op, so it only saves issue slots (0.755 -> 0.726 ms).
 #include <cstdlib>
 
+#include <hip/hip_fp16.h>
+
 #include "kfx_device.h"
 
 namespace kfx {
@@ -180,38 +182,79 @@ __device__ __forceinline__ Obs finish(const FuseParams& p, const V3 Pc, float iz
     return o;
 }
 
+// ---- cell storage policies ----------------------------------------------------------------
+// CellF32: roo::SDF_t {float val; float w;} (Sdf.h:11-36).  CellF16: roo::SDF_h {half val; half w;},
+// the 4-byte cell of BASELINE config C5 -- the arithmetic of the reference's commented-out half
+// variant (Sdf.h:38-62): every intermediate of the running average is rounded to half
+// (round-to-nearest-even) before the next operation.  ld2/st2 move two x-adjacent cells as
+// (val0, w0, val1, w1); the volume is streamed nontemporally (each cell is touched once per frame;
+// measured: in-place RMW sweep of 512^3 5.6 -> 6.0 TB/s).
+struct CellF32 {
+    static constexpr int BYTES = 8;
+    __device__ static __forceinline__ float q(float x) { return x; }
+    __device__ static __forceinline__ float4 ld2(const unsigned char* p)
+    {
+        const v4f t = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(p));
+        return make_float4(t.x, t.y, t.z, t.w);
+    }
+    __device__ static __forceinline__ void st2(unsigned char* p, const float4 c)
+    {
+        v4f t;
+        t.x = c.x; t.y = c.y; t.z = c.z; t.w = c.w;
+        __builtin_nontemporal_store(t, reinterpret_cast<v4f*>(p));
+    }
+    __device__ static __forceinline__ float2 ld1(const unsigned char* p) { return *reinterpret_cast<const float2*>(p); }
+    __device__ static __forceinline__ void st1(unsigned char* p, const float2 c) { *reinterpret_cast<float2*>(p) = c; }
+};
+
+typedef unsigned int v2u __attribute__((ext_vector_type(2)));
+struct CellF16 {
+    static constexpr int BYTES = 4;
+    __device__ static __forceinline__ float q(float x) { return __half2float(__float2half_rn(x)); }
+    __device__ static __forceinline__ float2 unpack(unsigned u)
+    {
+        return make_float2(__half2float(__ushort_as_half((unsigned short)(u & 0xffffu))), __half2float(__ushort_as_half((unsigned short)(u >> 16))));
+    }
+    __device__ static __forceinline__ unsigned pack(float val, float w)
+    {
+        return (unsigned)__half_as_ushort(__float2half_rn(val)) | ((unsigned)__half_as_ushort(__float2half_rn(w)) << 16);
+    }
+    __device__ static __forceinline__ float4 ld2(const unsigned char* p)
+    {
+        const v2u t = __builtin_nontemporal_load(reinterpret_cast<const v2u*>(p));
+        const float2 a = unpack(t.x), b = unpack(t.y);
+        return make_float4(a.x, a.y, b.x, b.y);
+    }
+    __device__ static __forceinline__ void st2(unsigned char* p, const float4 c)
+    {
+        v2u t;
+        t.x = pack(c.x, c.y);
+        t.y = pack(c.z, c.w);
+        __builtin_nontemporal_store(t, reinterpret_cast<v2u*>(p));
+    }
+    __device__ static __forceinline__ float2 ld1(const unsigned char* p) { return unpack(*reinterpret_cast<const unsigned*>(p)); }
+    __device__ static __forceinline__ void st1(unsigned char* p, const float2 c) { *reinterpret_cast<unsigned*>(p) = pack(c.x, c.y); }
+};
+
 // SDF_t::operator+= then LimitWeight (Sdf.h:22-32): `o` is the new sample, (oval, ow) the stored cell.
-template <bool FAST>
+// CELL::q rounds to the storage precision after every operation (identity for fp32 cells).
+template <bool FAST, typename CELL>
 __device__ __forceinline__ void accumulate(const Obs& o, float max_w, float& oval, float& ow)
 {
-    float val = o.val, w = o.w;
+    float val = CELL::q(o.val), w = CELL::q(o.w);
     if (ow > 0) {
         if constexpr (FAST) {
-            const float ws = w + ow;
-            val = __builtin_fmaf(w, val, ow * oval) * __builtin_amdgcn_rcpf(ws);
+            const float ws = CELL::q(w + ow);
+            val = CELL::q(CELL::q(__builtin_fmaf(w, val, ow * oval)) * __builtin_amdgcn_rcpf(ws));
             w = ws;
         } else {
-            val = (w * val + ow * oval);
-            w += ow;
-            val /= w;
+            val = CELL::q(w * val + ow * oval);
+            w = CELL::q(w + ow);
+            val = CELL::q(val / w);
         }
     }
     oval = val;
-    ow = fminf(w, max_w);
-}
-
-// streaming volume accesses: each cell is touched once per frame, so it is marked nontemporal
-// (measured: in-place RMW sweep of 512^3 5.6 -> 6.0 TB/s)
-__device__ __forceinline__ float4 vol_ld(const unsigned char* q)
-{
-    const v4f t = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(q));
-    return make_float4(t.x, t.y, t.z, t.w);
-}
-__device__ __forceinline__ void vol_st(unsigned char* q, const float4 c)
-{
-    v4f t;
-    t.x = c.x; t.y = c.y; t.z = c.z; t.w = c.w;
-    __builtin_nontemporal_store(t, reinterpret_cast<v4f*>(q));
+    ow = CELL::q(fminf(w, max_w));
 }
 
 // One voxel: projection -> bounds test -> corner fetch -> observation.
@@ -236,7 +279,7 @@ __device__ __forceinline__ Obs observe(const FuseParams& p, const V3 Pc)
 // Generic kernel: global gathers, any alignment (VEC = 1: 8-byte cells for sub-volume views
 // with odd x offset / pitch), any image size.  Workgroup = (64*VEC) x 4 x FUSE_ZC voxels.
 // ---------------------------------------------------------------------------------------
-template <int VEC, bool FAST, bool OFF32>
+template <int VEC, bool FAST, bool OFF32, typename CELL>
 __global__ __launch_bounds__(256) void k_sdf_fuse(const FuseParams p)
 {
     __shared__ float s_pz[FUSE_ZC];
@@ -255,7 +298,7 @@ __global__ __launch_bounds__(256) void k_sdf_fuse(const FuseParams p)
 #pragma unroll
     for (int v = 0; v < VEC; ++v) cam[v].init(p, p.bmin.x + p.size.x * (float)(x0 + v) / p.w1, py);
 
-    unsigned char* cell = p.vptr + (size_t)zbeg * p.vimg_pitch + (size_t)y * p.vpitch + (size_t)x0 * 8;
+    unsigned char* cell = p.vptr + (size_t)zbeg * p.vimg_pitch + (size_t)y * p.vpitch + (size_t)x0 * CELL::BYTES;
     for (int z = zbeg; z < zend; ++z, cell += p.vimg_pitch) {
         const float pz = s_pz[z - zbeg];
         Obs o[VEC];
@@ -263,16 +306,16 @@ __global__ __launch_bounds__(256) void k_sdf_fuse(const FuseParams p)
         for (int v = 0; v < VEC; ++v) o[v] = observe<FAST, OFF32>(p, cam[v].at(p, pz));
         if constexpr (VEC == 2) {
             if (o[0].ok || o[1].ok) {
-                float4 c = vol_ld(cell);
-                if (o[0].ok) accumulate<FAST>(o[0], p.max_w, c.x, c.y);
-                if (o[1].ok) accumulate<FAST>(o[1], p.max_w, c.z, c.w);
-                vol_st(cell, c);
+                float4 c = CELL::ld2(cell);
+                if (o[0].ok) accumulate<FAST, CELL>(o[0], p.max_w, c.x, c.y);
+                if (o[1].ok) accumulate<FAST, CELL>(o[1], p.max_w, c.z, c.w);
+                CELL::st2(cell, c);
             }
         } else {
             if (o[0].ok) {
-                float2 c = *reinterpret_cast<const float2*>(cell);
-                accumulate<FAST>(o[0], p.max_w, c.x, c.y);
-                *reinterpret_cast<float2*>(cell) = c;
+                float2 c = CELL::ld1(cell);
+                accumulate<FAST, CELL>(o[0], p.max_w, c.x, c.y);
+                CELL::st1(cell, c);
             }
         }
     }
@@ -290,7 +333,7 @@ __global__ __launch_bounds__(256) void k_sdf_fuse(const FuseParams p)
 // rectangle can never be read from LDS).  Texel values are copies, so results are identical
 // to the generic kernel in either numerics mode.
 // ---------------------------------------------------------------------------------------
-template <bool FAST, int ZU>
+template <bool FAST, int ZU, typename CELL>
 __global__ __launch_bounds__(256) void k_sdf_fuse_tiled(const FuseParams p, const int cap_px)
 {
     extern __shared__ __attribute__((aligned(16))) float4 s_tile[];
@@ -420,7 +463,7 @@ __global__ __launch_bounds__(256) void k_sdf_fuse_tiled(const FuseParams p, cons
 
     // ZU slices per iteration: their volume cells are requested together, so a wave keeps ZU
     // 16-byte reads per lane in flight
-    unsigned char* cell = p.vptr + (size_t)zbeg * p.vimg_pitch + (size_t)y * p.vpitch + (size_t)x0 * 8;
+    unsigned char* cell = p.vptr + (size_t)zbeg * p.vimg_pitch + (size_t)y * p.vpitch + (size_t)x0 * CELL::BYTES;
     for (int z = zbeg; z < zend; z += ZU, cell += (size_t)ZU * p.vimg_pitch) {
         Obs o[ZU][2];
         bool any[ZU];
@@ -437,13 +480,13 @@ __global__ __launch_bounds__(256) void k_sdf_fuse_tiled(const FuseParams p, cons
         float4 c[ZU];
 #pragma unroll
         for (int k = 0; k < ZU; ++k)
-            if (any[k]) c[k] = vol_ld(cell + (size_t)k * p.vimg_pitch);
+            if (any[k]) c[k] = CELL::ld2(cell + (size_t)k * p.vimg_pitch);
 #pragma unroll
         for (int k = 0; k < ZU; ++k)
             if (any[k]) {
-                if (o[k][0].ok) accumulate<FAST>(o[k][0], p.max_w, c[k].x, c[k].y);
-                if (o[k][1].ok) accumulate<FAST>(o[k][1], p.max_w, c[k].z, c[k].w);
-                vol_st(cell + (size_t)k * p.vimg_pitch, c[k]);
+                if (o[k][0].ok) accumulate<FAST, CELL>(o[k][0], p.max_w, c[k].x, c[k].y);
+                if (o[k][1].ok) accumulate<FAST, CELL>(o[k][1], p.max_w, c[k].z, c[k].w);
+                CELL::st2(cell + (size_t)k * p.vimg_pitch, c[k]);
             }
     }
 }
@@ -490,7 +533,15 @@ __global__ __launch_bounds__(256) void k_fill_sdf_unaligned(float2* __restrict__
         base[j] = make_float2(val, w);
 }
 
+// 4-byte (fp16) cells: fill the contiguous span with one 32-bit pattern
+__global__ __launch_bounds__(256) void k_fill_u32(unsigned* __restrict__ base, size_t n, unsigned pattern)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) base[j] = pattern;
+}
+
 // SdfSphere (cu_sdffusion.cu:175-195): val = |pos - c| - r, w = 1.
+template <typename CELL>
 __global__ __launch_bounds__(256) void k_sdf_sphere(VolView v, int X, int Y, int Z, V3 c, float r)
 {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
@@ -501,22 +552,21 @@ __global__ __launch_bounds__(256) void k_sdf_sphere(VolView v, int X, int Y, int
     const V3 pos = v3(v.bmin.x + size.x * (float)x / (float)(v.w - 1), v.bmin.y + size.y * (float)y / (float)(v.h - 1),
                       v.bmin.z + size.z * (float)z / (float)(v.d - 1));
     const float dist = length(pos - c);
-    float2* cell = reinterpret_cast<float2*>(v.ptr + (size_t)z * v.img_pitch + (size_t)y * v.pitch) + x;
-    *cell = make_float2(dist - r, 1.0f);
+    CELL::st1(v.ptr + (size_t)z * v.img_pitch + (size_t)y * v.pitch + (size_t)x * CELL::BYTES, make_float2(dist - r, 1.0f));
 }
 
 } // namespace kfx
 
 using namespace kfx;
 
-static int check_volume(const kfx_volume* vol)
+static int check_volume(const kfx_volume* vol, size_t cell = 8)
 {
     if (!vol || !vol->ptr) return set_error(KFX_E_NULL, "volume is null");
     if (vol->w == 0 || vol->h == 0 || vol->d == 0 || vol->w > 65535 || vol->h > 65535 || vol->d > 65535)
         return set_error(KFX_E_SHAPE, "volume dimensions");
-    if (vol->pitch < vol->w * 8 || vol->img_pitch < vol->pitch * (vol->h - 1) + vol->w * 8)
+    if (vol->pitch < vol->w * cell || vol->img_pitch < vol->pitch * (vol->h - 1) + vol->w * cell)
         return set_error(KFX_E_SHAPE, "volume pitch smaller than a row / slice");
-    if (((uintptr_t)vol->ptr | vol->pitch | vol->img_pitch) & 7) return set_error(KFX_E_ALIGN, "volume not 8-byte aligned");
+    if (((uintptr_t)vol->ptr | vol->pitch | vol->img_pitch) & (cell - 1)) return set_error(KFX_E_ALIGN, "volume not aligned to its cell size");
     return 0;
 }
 
@@ -537,9 +587,9 @@ static VolView vol_view(const kfx_volume* vol)
 // Fills the kernel parameters; *small_images tells whether the 32-bit image offsets are usable.
 static int fuse_params(FuseParams& p, bool* small_images, const kfx_volume* vol, const kfx_image* depth,
                        const kfx_image* norm, const float T_cw[12], const float K[4], float trunc_dist, float max_w,
-                       float mincostheta, unsigned flags)
+                       float mincostheta, unsigned flags, size_t cell = 8)
 {
-    if (int e = check_volume(vol)) return e;
+    if (int e = check_volume(vol, cell)) return e;
     if (!depth || !norm || !depth->ptr || !norm->ptr || !T_cw || !K) return set_error(KFX_E_NULL, "SdfFuse: null argument");
     if (depth->w < 4 || depth->h < 4 || norm->w < depth->w || norm->h < depth->h)
         return set_error(KFX_E_SHAPE, "SdfFuse: depth/normal image dimensions");
@@ -575,15 +625,16 @@ static int fuse_params(FuseParams& p, bool* small_images, const kfx_volume* vol,
     return 0;
 }
 
-extern "C" int kfx_sdf_fuse(const kfx_volume* vol, const kfx_image* depth, const kfx_image* norm,
-                            const float T_cw[12], const float K[4], float trunc_dist, float max_w,
-                            float mincostheta, unsigned flags, kfx_stream stream)
+template <typename CELL>
+static int fuse_launch(const kfx_volume* vol, const kfx_image* depth, const kfx_image* norm, const float T_cw[12],
+                       const float K[4], float trunc_dist, float max_w, float mincostheta, unsigned flags, kfx_stream stream)
 {
     FuseParams p;
     bool small_images = false;
-    if (int e = fuse_params(p, &small_images, vol, depth, norm, T_cw, K, trunc_dist, max_w, mincostheta, flags)) return e;
+    if (int e = fuse_params(p, &small_images, vol, depth, norm, T_cw, K, trunc_dist, max_w, mincostheta, flags, CELL::BYTES)) return e;
     if (p.X == 0 || p.Y == 0 || p.Z == 0) return 0; // reference launches an empty grid
-    const bool vec2 = (p.X % 2 == 0) && ((((uintptr_t)vol->ptr | vol->pitch | vol->img_pitch) & 15) == 0);
+    // two cells per lane need an even extent and a pointer / pitches aligned to the cell pair
+    const bool vec2 = (p.X % 2 == 0) && ((((uintptr_t)vol->ptr | vol->pitch | vol->img_pitch) & (2 * CELL::BYTES - 1)) == 0);
     const bool fast = math_mode() == KFX_MATH_FAST;
     hipStream_t s = (hipStream_t)stream;
     // tuning / A-B knobs (read once): KFX_FUSE_TILED=0 forces the global-gather kernel,
@@ -596,24 +647,38 @@ extern "C" int kfx_sdf_fuse(const kfx_volume* vol, const kfx_image* depth, const
         // slices per iteration: 2 in fast mode (memory-bound: more reads in flight), 1 in exact mode (VALU-bound)
         static const int zu_env = [] { const char* e = getenv("KFX_FUSE_ZU"); return e ? atoi(e) : 0; }();
         const int zu = zu_env ? zu_env : (fast ? 2 : 1);
-        if (fast && zu == 2) hipLaunchKernelGGL((k_sdf_fuse_tiled<true, 2>), grid, dim3(256), lds, s, p, cap_px);
-        else if (fast) hipLaunchKernelGGL((k_sdf_fuse_tiled<true, 1>), grid, dim3(256), lds, s, p, cap_px);
-        else if (zu == 2) hipLaunchKernelGGL((k_sdf_fuse_tiled<false, 2>), grid, dim3(256), lds, s, p, cap_px);
-        else hipLaunchKernelGGL((k_sdf_fuse_tiled<false, 1>), grid, dim3(256), lds, s, p, cap_px);
+        if (fast && zu == 2) hipLaunchKernelGGL((k_sdf_fuse_tiled<true, 2, CELL>), grid, dim3(256), lds, s, p, cap_px);
+        else if (fast) hipLaunchKernelGGL((k_sdf_fuse_tiled<true, 1, CELL>), grid, dim3(256), lds, s, p, cap_px);
+        else if (zu == 2) hipLaunchKernelGGL((k_sdf_fuse_tiled<false, 2, CELL>), grid, dim3(256), lds, s, p, cap_px);
+        else hipLaunchKernelGGL((k_sdf_fuse_tiled<false, 1, CELL>), grid, dim3(256), lds, s, p, cap_px);
     } else if (vec2) {
         dim3 grid(ceil_div(p.X, 128), ceil_div(p.Y, FUSE_ROWS), ceil_div(p.Z, FUSE_ZC));
-        if (fast && small_images) hipLaunchKernelGGL((k_sdf_fuse<2, true, true>), grid, dim3(256), 0, s, p);
-        else if (fast) hipLaunchKernelGGL((k_sdf_fuse<2, true, false>), grid, dim3(256), 0, s, p);
-        else if (small_images) hipLaunchKernelGGL((k_sdf_fuse<2, false, true>), grid, dim3(256), 0, s, p);
-        else hipLaunchKernelGGL((k_sdf_fuse<2, false, false>), grid, dim3(256), 0, s, p);
+        if (fast && small_images) hipLaunchKernelGGL((k_sdf_fuse<2, true, true, CELL>), grid, dim3(256), 0, s, p);
+        else if (fast) hipLaunchKernelGGL((k_sdf_fuse<2, true, false, CELL>), grid, dim3(256), 0, s, p);
+        else if (small_images) hipLaunchKernelGGL((k_sdf_fuse<2, false, true, CELL>), grid, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((k_sdf_fuse<2, false, false, CELL>), grid, dim3(256), 0, s, p);
     } else {
         dim3 grid(ceil_div(p.X, 64), ceil_div(p.Y, FUSE_ROWS), ceil_div(p.Z, FUSE_ZC));
-        if (fast && small_images) hipLaunchKernelGGL((k_sdf_fuse<1, true, true>), grid, dim3(256), 0, s, p);
-        else if (fast) hipLaunchKernelGGL((k_sdf_fuse<1, true, false>), grid, dim3(256), 0, s, p);
-        else if (small_images) hipLaunchKernelGGL((k_sdf_fuse<1, false, true>), grid, dim3(256), 0, s, p);
-        else hipLaunchKernelGGL((k_sdf_fuse<1, false, false>), grid, dim3(256), 0, s, p);
+        if (fast && small_images) hipLaunchKernelGGL((k_sdf_fuse<1, true, true, CELL>), grid, dim3(256), 0, s, p);
+        else if (fast) hipLaunchKernelGGL((k_sdf_fuse<1, true, false, CELL>), grid, dim3(256), 0, s, p);
+        else if (small_images) hipLaunchKernelGGL((k_sdf_fuse<1, false, true, CELL>), grid, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((k_sdf_fuse<1, false, false, CELL>), grid, dim3(256), 0, s, p);
     }
     return check_launch("kfx_sdf_fuse");
+}
+
+extern "C" int kfx_sdf_fuse(const kfx_volume* vol, const kfx_image* depth, const kfx_image* norm,
+                            const float T_cw[12], const float K[4], float trunc_dist, float max_w,
+                            float mincostheta, unsigned flags, kfx_stream stream)
+{
+    return fuse_launch<CellF32>(vol, depth, norm, T_cw, K, trunc_dist, max_w, mincostheta, flags, stream);
+}
+
+extern "C" int kfx_sdf_fuse_h(const kfx_volume* vol, const kfx_image* depth, const kfx_image* norm,
+                              const float T_cw[12], const float K[4], float trunc_dist, float max_w,
+                              float mincostheta, unsigned flags, kfx_stream stream)
+{
+    return fuse_launch<CellF16>(vol, depth, norm, T_cw, K, trunc_dist, max_w, mincostheta, flags, stream);
 }
 
 extern "C" int kfx_sdf_fuse_count(const kfx_volume* vol, const kfx_image* depth, const kfx_image* norm,
@@ -652,7 +717,30 @@ extern "C" int kfx_sdf_sphere(const kfx_volume* vol, const float center[3], floa
     const int X = (int)(vol->w / 8) * 8, Y = (int)(vol->h / 8) * 8, Z = (int)(vol->d / 8) * 8;
     if (X == 0 || Y == 0 || Z == 0) return 0;
     dim3 grid(ceil_div(X, 64), ceil_div(Y, 4), Z);
-    hipLaunchKernelGGL(k_sdf_sphere, grid, dim3(256), 0, (hipStream_t)stream, vol_view(vol), X, Y, Z,
+    hipLaunchKernelGGL(k_sdf_sphere<CellF32>, grid, dim3(256), 0, (hipStream_t)stream, vol_view(vol), X, Y, Z,
                        V3{center[0], center[1], center[2]}, r);
     return check_launch("kfx_sdf_sphere");
+}
+
+extern "C" int kfx_sdf_reset_h(const kfx_volume* vol, float trunc_dist, kfx_stream stream)
+{
+    if (int e = check_volume(vol, 4)) return e;
+    const size_t span_bytes = (vol->d - 1) * vol->img_pitch + (vol->h - 1) * vol->pitch + vol->w * 4;
+    const size_t n = span_bytes / 4;
+    const unsigned pattern = (unsigned)__half_as_ushort(__float2half_rn(trunc_dist)); // {val = trunc, w = 0}
+    const int blocks = (int)std::min<size_t>((n + 255) / 256, 256 * 16);
+    hipLaunchKernelGGL(k_fill_u32, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (unsigned*)vol->ptr, n, pattern);
+    return check_launch("kfx_sdf_reset_h");
+}
+
+extern "C" int kfx_sdf_sphere_h(const kfx_volume* vol, const float center[3], float r, kfx_stream stream)
+{
+    if (int e = check_volume(vol, 4)) return e;
+    if (!center) return set_error(KFX_E_NULL, "SdfSphere: null center");
+    const int X = (int)(vol->w / 8) * 8, Y = (int)(vol->h / 8) * 8, Z = (int)(vol->d / 8) * 8;
+    if (X == 0 || Y == 0 || Z == 0) return 0;
+    dim3 grid(ceil_div(X, 64), ceil_div(Y, 4), Z);
+    hipLaunchKernelGGL(k_sdf_sphere<CellF16>, grid, dim3(256), 0, (hipStream_t)stream, vol_view(vol), X, Y, Z,
+                       V3{center[0], center[1], center[2]}, r);
+    return check_launch("kfx_sdf_sphere_h");
 }

@@ -7,6 +7,8 @@
 // loads (the x and x+1 cells of an AoS row are contiguous) instead of eight 8-byte ones;
 // the gradient stencil is 20 distinct cells instead of 32 loads; missed rays skip the
 // (discarded) normal evaluation of the reference.
+#include <hip/hip_fp16.h>
+
 #include "kfx_device.h"
 
 namespace kfx {
@@ -26,15 +28,36 @@ struct RayParams {
     int subpix;
 };
 
-__device__ __forceinline__ const float* cellp(const VolView& v, int x, int y, int z)
+// ---- cell readers: RayF32 = roo::SDF_t {float val; float w;}, RayF16 = roo::SDF_h {half val; half w;} ----
+struct __attribute__((aligned(8))) Pair { float v0, w0, v1, w1; }; // fp32 cells x and x+1 of one row
+struct RayF32 {
+    static constexpr int BYTES = 8;
+    // values of cells x and x+1 of the row starting at byte address `row`
+    __device__ static __forceinline__ float2 pair(const unsigned char* row, int x)
+    {
+        const Pair c = *reinterpret_cast<const Pair*>(row + (size_t)x * 8);
+        return make_float2(c.v0, c.v1);
+    }
+    __device__ static __forceinline__ float val(const unsigned char* row, int x) { return *reinterpret_cast<const float*>(row + (size_t)x * 8); }
+};
+struct __attribute__((aligned(4))) PairH { unsigned a, b; };
+struct RayF16 {
+    static constexpr int BYTES = 4;
+    __device__ static __forceinline__ float h(unsigned u) { return __half2float(__ushort_as_half((unsigned short)(u & 0xffffu))); }
+    __device__ static __forceinline__ float2 pair(const unsigned char* row, int x)
+    {
+        const PairH c = *reinterpret_cast<const PairH*>(row + (size_t)x * 4);
+        return make_float2(h(c.a), h(c.b));
+    }
+    __device__ static __forceinline__ float val(const unsigned char* row, int x) { return h(*reinterpret_cast<const unsigned*>(row + (size_t)x * 4)); }
+};
+__device__ __forceinline__ const unsigned char* rowp(const VolView& v, int y, int z)
 {
-    return reinterpret_cast<const float*>(v.ptr + (size_t)z * v.img_pitch + (size_t)y * v.pitch) + 2 * x;
+    return v.ptr + (size_t)z * v.img_pitch + (size_t)y * v.pitch;
 }
-__device__ __forceinline__ float vval(const VolView& v, int x, int y, int z) { return *cellp(v, x, y, z); }
-
-struct __attribute__((aligned(8))) Pair { float v0, w0, v1, w1; }; // cells x and x+1 of one row
 
 // BoundedVolume::GetUnitsTrilinearClamped -> Volume::GetFractionalTrilinearClamped
+template <typename CELL>
 __device__ __forceinline__ float trilinear(const RayParams& p, const V3 pos_w)
 {
     const V3 pos_v = div_cw(pos_w - p.vol.bmin, p.size);
@@ -43,18 +66,19 @@ __device__ __forceinline__ float trilinear(const RayParams& p, const V3 pos_w)
     const int iy = (int)fmaxf(fminf(p.hi2.y, floorf(pf.y)), 0.f);
     const int iz = (int)fmaxf(fminf(p.hi2.z, floorf(pf.z)), 0.f);
     const float fx = pf.x - (float)ix, fy = pf.y - (float)iy, fz = pf.z - (float)iz;
-    const unsigned char* b = p.vol.ptr + (size_t)iz * p.vol.img_pitch + (size_t)iy * p.vol.pitch + (size_t)ix * 8;
-    const Pair c00 = *reinterpret_cast<const Pair*>(b);
-    const Pair c10 = *reinterpret_cast<const Pair*>(b + p.vol.pitch);
-    const Pair c01 = *reinterpret_cast<const Pair*>(b + p.vol.img_pitch);
-    const Pair c11 = *reinterpret_cast<const Pair*>(b + p.vol.img_pitch + p.vol.pitch);
-    return lerp(lerp(lerp(c00.v0, c00.v1, fx), lerp(c10.v0, c10.v1, fx), fy),
-                lerp(lerp(c01.v0, c01.v1, fx), lerp(c11.v0, c11.v1, fx), fy), fz);
+    const unsigned char* b = rowp(p.vol, iy, iz);
+    const float2 c00 = CELL::pair(b, ix);
+    const float2 c10 = CELL::pair(b + p.vol.pitch, ix);
+    const float2 c01 = CELL::pair(b + p.vol.img_pitch, ix);
+    const float2 c11 = CELL::pair(b + p.vol.img_pitch + p.vol.pitch, ix);
+    return lerp(lerp(lerp(c00.x, c00.y, fx), lerp(c10.x, c10.y, fx), fy),
+                lerp(lerp(c01.x, c01.y, fx), lerp(c11.x, c11.y, fx), fy), fz);
 }
 
 // BoundedVolume::GetUnitsBackwardDiffDxDyDz -> Volume::GetFractionalBackwardDiffDxDyDz.
 // Corner (cx,cy,cz) gradient = v(c) - v(c - e_axis); the 8 corners need the 20 cells of
 // {-1,0,1}^3 (relative to the clamped base) that have at most one coordinate equal to -1.
+template <typename CELL>
 __device__ __forceinline__ V3 gradient(const RayParams& p, const V3 pos_w)
 {
     const V3 pos_v = div_cw(pos_w - p.vol.bmin, p.size);
@@ -70,22 +94,23 @@ __device__ __forceinline__ V3 gradient(const RayParams& p, const V3 pos_w)
     for (int dz = 0; dz < 2; ++dz)
 #pragma unroll
         for (int dy = 0; dy < 2; ++dy) {
-            const float* r = cellp(v, ix - 1, iy + dy, iz + dz);
-            mx[dz][dy] = r[0];
-            c[dz][dy][0] = r[2];
-            c[dz][dy][1] = r[4];
+            const unsigned char* r = rowp(v, iy + dy, iz + dz);
+            mx[dz][dy] = CELL::val(r, ix - 1);
+            const float2 cc = CELL::pair(r, ix);
+            c[dz][dy][0] = cc.x;
+            c[dz][dy][1] = cc.y;
         }
 #pragma unroll
     for (int dz = 0; dz < 2; ++dz) {
-        const float* r = cellp(v, ix, iy - 1, iz + dz);
-        my[dz][0] = r[0];
-        my[dz][1] = r[2];
+        const float2 cc = CELL::pair(rowp(v, iy - 1, iz + dz), ix);
+        my[dz][0] = cc.x;
+        my[dz][1] = cc.y;
     }
 #pragma unroll
     for (int dy = 0; dy < 2; ++dy) {
-        const float* r = cellp(v, ix, iy + dy, iz - 1);
-        mz[dy][0] = r[0];
-        mz[dy][1] = r[2];
+        const float2 cc = CELL::pair(rowp(v, iy + dy, iz - 1), ix);
+        mz[dy][0] = cc.x;
+        mz[dy][1] = cc.y;
     }
     V3 g[2][2][2];
 #pragma unroll
@@ -119,6 +144,7 @@ __device__ __forceinline__ float phong(const V3 p_c, const V3 n_c)
     return ambient + diffuse * ldotn + specular * spec;
 }
 
+template <typename CELL>
 __global__ __launch_bounds__(256) void k_raycast_sdf(const RayParams p)
 {
     // wave -> 8x8 tile; workgroup -> 16x16 pixels
@@ -146,7 +172,7 @@ __global__ __launch_bounds__(256) void k_raycast_sdf(const RayParams p)
         const float min_delta = p.voxel.x;
         float delta = 0.f;
         while (lambda < min_tmax) {
-            const float sdf = trilinear(p, c_w + ray_w * lambda);
+            const float sdf = trilinear<CELL>(p, c_w + ray_w * lambda);
             if (sdf <= 0) {
                 if (last_sdf > 0) {
                     if (p.subpix) lambda = lambda + delta * sdf / (last_sdf - sdf);
@@ -164,7 +190,7 @@ __global__ __launch_bounds__(256) void k_raycast_sdf(const RayParams p)
     float* pi = reinterpret_cast<float*>(p.iptr + (size_t)v * p.ipitch) + u;
     float4* pn = reinterpret_cast<float4*>(p.nptr + (size_t)v * p.npitch) + u;
     if (depth > 0) {
-        const V3 g = gradient(p, c_w + ray_w * depth);
+        const V3 g = gradient<CELL>(p, c_w + ray_w * depth);
         const float len = length(g);
         const V3 n_w = len > 0 ? div_s(g, len) : v3(0.f, 0.f, 1.f);
         const V3 n_c = so3_mul_inv(p.T, n_w);
@@ -183,9 +209,10 @@ __global__ __launch_bounds__(256) void k_raycast_sdf(const RayParams p)
 
 using namespace kfx;
 
-extern "C" int kfx_raycast_sdf(const kfx_image* depth, const kfx_image* norm, const kfx_image* img,
-                               const kfx_volume* vol, const float T_wc[12], const float K[4], float near,
-                               float far, float trunc_dist, int subpix, kfx_stream stream)
+template <typename CELL>
+static int raycast_launch(const kfx_image* depth, const kfx_image* norm, const kfx_image* img,
+                          const kfx_volume* vol, const float T_wc[12], const float K[4], float near,
+                          float far, float trunc_dist, int subpix, kfx_stream stream)
 {
     if (!depth || !norm || !img || !vol || !T_wc || !K || !depth->ptr || !norm->ptr || !img->ptr || !vol->ptr)
         return set_error(KFX_E_NULL, "RaycastSdf: null argument");
@@ -195,12 +222,12 @@ extern "C" int kfx_raycast_sdf(const kfx_image* depth, const kfx_image* norm, co
     if (depth->pitch < img->w * 4 || img->pitch < img->w * 4 || norm->pitch < img->w * 16)
         return set_error(KFX_E_SHAPE, "RaycastSdf: image pitch");
     if ((((uintptr_t)depth->ptr | depth->pitch | (uintptr_t)img->ptr | img->pitch) & 3) ||
-        (((uintptr_t)norm->ptr | norm->pitch) & 15) || (((uintptr_t)vol->ptr | vol->pitch | vol->img_pitch) & 7))
+        (((uintptr_t)norm->ptr | norm->pitch) & 15) || (((uintptr_t)vol->ptr | vol->pitch | vol->img_pitch) & (CELL::BYTES - 1)))
         return set_error(KFX_E_ALIGN, "RaycastSdf: alignment");
     // the gradient stencil reads cells [1-1, (dim-2)+1] (Volume.h:271-273)
     if (vol->w < 3 || vol->h < 3 || vol->d < 3 || vol->w > 65535 || vol->h > 65535 || vol->d > 65535)
         return set_error(KFX_E_SHAPE, "RaycastSdf: volume dimensions");
-    if (vol->pitch < vol->w * 8 || vol->img_pitch < vol->pitch * (vol->h - 1) + vol->w * 8)
+    if (vol->pitch < vol->w * CELL::BYTES || vol->img_pitch < vol->pitch * (vol->h - 1) + vol->w * CELL::BYTES)
         return set_error(KFX_E_SHAPE, "RaycastSdf: volume pitch");
 
     RayParams p;
@@ -233,6 +260,20 @@ extern "C" int kfx_raycast_sdf(const kfx_image* depth, const kfx_image* norm, co
     p.subpix = subpix ? 1 : 0;
 
     dim3 grid(ceil_div(p.w, 16), ceil_div(p.h, 16));
-    hipLaunchKernelGGL(k_raycast_sdf, grid, dim3(256), 0, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(k_raycast_sdf<CELL>, grid, dim3(256), 0, (hipStream_t)stream, p);
     return check_launch("kfx_raycast_sdf");
+}
+
+extern "C" int kfx_raycast_sdf(const kfx_image* depth, const kfx_image* norm, const kfx_image* img,
+                               const kfx_volume* vol, const float T_wc[12], const float K[4], float near,
+                               float far, float trunc_dist, int subpix, kfx_stream stream)
+{
+    return raycast_launch<RayF32>(depth, norm, img, vol, T_wc, K, near, far, trunc_dist, subpix, stream);
+}
+
+extern "C" int kfx_raycast_sdf_h(const kfx_image* depth, const kfx_image* norm, const kfx_image* img,
+                                 const kfx_volume* vol, const float T_wc[12], const float K[4], float near,
+                                 float far, float trunc_dist, int subpix, kfx_stream stream)
+{
+    return raycast_launch<RayF16>(depth, norm, img, vol, T_wc, K, near, far, trunc_dist, subpix, stream);
 }

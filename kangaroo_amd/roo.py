@@ -100,10 +100,11 @@ class BoundedVolume:
     """roo::BoundedVolume<SDF_t, TargetDevice, Manage> (BoundedVolume.h:10-170): x-fastest AoS
     {val, w} cells, row `pitch`, slice `img_pitch = pitch*h` (Memory.h:70-78)."""
 
-    ELEM = 8
-
     def __init__(self, w, h, d, boxmin=(-1, -1, -1), boxmax=(1, 1, 1), device="cuda", pitch=None,
-                 _storage=None, _offset=0, _img_pitch=None):
+                 _storage=None, _offset=0, _img_pitch=None, kind="f32"):
+        """kind = "f32": SDF_t {float val; float w;} (8 B); kind = "f16": SDF_h {half val; half w;} (4 B)."""
+        self.kind = kind
+        self.ELEM = {"f32": 8, "f16": 4}[kind]
         self.w, self.h, self.d = int(w), int(h), int(d)
         self.boxmin = np.asarray(boxmin, np.float32).copy()
         self.boxmax = np.asarray(boxmax, np.float32).copy()
@@ -149,7 +150,7 @@ class BoundedVolume:
         """Volume::SubVolume (Volume.h:305-311): same pitches, offset pointer."""
         off = self.offset + start[2] * self.img_pitch + start[1] * self.pitch + start[0] * self.ELEM
         return BoundedVolume(size[0], size[1], size[2], self.boxmin, self.boxmax, pitch=self.pitch,
-                             _storage=self.storage, _offset=off, _img_pitch=self.img_pitch)
+                             _storage=self.storage, _offset=off, _img_pitch=self.img_pitch, kind=self.kind)
 
     def SubBoundingVolume(self, rmin, rmax):
         """BoundedVolume::SubBoundingVolume (BoundedVolume.h:137-165) in float32 host arithmetic."""
@@ -182,7 +183,10 @@ class BoundedVolume:
         return self.storage[self.offset + z0 * self.img_pitch: self.offset + z1 * self.img_pitch]
 
     def tensor(self):
-        """Strided float32 torch view (d, h, w, 2) of the cells."""
+        """Strided torch view (d, h, w, 2) of the cells (float32 or float16)."""
+        if self.kind == "f16":
+            flat = self.storage[self.offset:].view(torch.float16)
+            return torch.as_strided(flat, (self.d, self.h, self.w, 2), (self.img_pitch // 2, self.pitch // 2, 2, 1))
         flat = self.storage[self.offset:].view(torch.float32)
         return torch.as_strided(flat, (self.d, self.h, self.w, 2), (self.img_pitch // 4, self.pitch // 4, 2, 1))
 
@@ -190,7 +194,7 @@ class BoundedVolume:
         return self.tensor().cpu().numpy().copy()
 
     def MemcpyFromHost(self, arr):
-        self.tensor().copy_(torch.from_numpy(np.ascontiguousarray(arr, np.float32)))
+        self.tensor().copy_(torch.from_numpy(np.ascontiguousarray(arr, np.float16 if self.kind == "f16" else np.float32)))
         return self
 
 
@@ -234,8 +238,9 @@ def SdfFuse(vol, depth, norm, T_cw, K, trunc_dist, maxw, mincostheta, full_exten
     """roo::SdfFuse (cu_sdffusion.h:13-14)."""
     t, _t = _fp(T_cw, 12)
     k, _k = _fp(K, 4)
-    _lib.check(_lib.load().kfx_sdf_fuse(vol.ref(), depth.ref(), norm.ref(), t, k, trunc_dist, maxw, mincostheta,
-                                        1 if full_extent else 0, _stream(stream)))
+    fn = _lib.load().kfx_sdf_fuse_h if vol.kind == "f16" else _lib.load().kfx_sdf_fuse
+    _lib.check(fn(vol.ref(), depth.ref(), norm.ref(), t, k, trunc_dist, maxw, mincostheta,
+                  1 if full_extent else 0, _stream(stream)))
 
 
 def SdfFuseCount(vol, depth, norm, T_cw, K, trunc_dist, mincostheta, full_extent=False, stream=None):
@@ -252,8 +257,9 @@ def RaycastSdf(depth, norm, img, vol, T_wc, K, near, far, trunc_dist, subpix=Tru
     """roo::RaycastSdf (cu_raycast.h:13-14)."""
     t, _t = _fp(T_wc, 12)
     k, _k = _fp(K, 4)
-    _lib.check(_lib.load().kfx_raycast_sdf(depth.ref(), norm.ref(), img.ref(), vol.ref(), t, k, near, far,
-                                           trunc_dist, 1 if subpix else 0, _stream(stream)))
+    fn = _lib.load().kfx_raycast_sdf_h if vol.kind == "f16" else _lib.load().kfx_raycast_sdf
+    _lib.check(fn(depth.ref(), norm.ref(), img.ref(), vol.ref(), t, k, near, far, trunc_dist, 1 if subpix else 0,
+                  _stream(stream)))
 
 
 def BilateralFilter(dOut, dIn, gs, gr, size, minval=None, stream=None):
@@ -290,10 +296,12 @@ def NormalsFromVbo(dN, dV, stream=None):
 
 def SdfReset(vol, trunc_dist, stream=None):
     """roo::SdfReset(BoundedVolume<SDF_t>, float) (cu_sdffusion.h:20)."""
-    _lib.check(_lib.load().kfx_sdf_reset(vol.ref(), trunc_dist, _stream(stream)))
+    fn = _lib.load().kfx_sdf_reset_h if vol.kind == "f16" else _lib.load().kfx_sdf_reset
+    _lib.check(fn(vol.ref(), trunc_dist, _stream(stream)))
 
 
 def SdfSphere(vol, center, r, stream=None):
     """roo::SdfSphere (cu_sdffusion.h:26)."""
     c, _c = _fp(center, 3)
-    _lib.check(_lib.load().kfx_sdf_sphere(vol.ref(), c, r, _stream(stream)))
+    fn = _lib.load().kfx_sdf_sphere_h if vol.kind == "f16" else _lib.load().kfx_sdf_sphere
+    _lib.check(fn(vol.ref(), c, r, _stream(stream)))

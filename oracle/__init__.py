@@ -63,6 +63,14 @@ def lib():
         L.kfo_fit_to_frustum.argtypes = [PF, PF, PF, C.c_float, C.c_float, PF, C.c_float, C.c_float]
         L.kfo_sub_bounding_volume.argtypes = [PV, PV, PF, PF]
         L.kfo_se3_inverse.argtypes = [PF, PF]
+        L.kfo_sdf_fuse_h.argtypes = L.kfo_sdf_fuse.argtypes
+        L.kfo_sdf_fuse_h.restype = C.c_uint64
+        L.kfo_raycast_sdf_h.argtypes = L.kfo_raycast_sdf.argtypes
+        L.kfo_raycast_sdf_h.restype = None
+        L.kfo_sdf_reset_h.argtypes = [PV, C.c_float]
+        L.kfo_sdf_reset_h.restype = None
+        L.kfo_sdf_sphere_h.argtypes = [PV, PF, C.c_float]
+        L.kfo_sdf_sphere_h.restype = None
         L.kfo_max_threads.restype = C.c_int
         L.kfo_trilinear.argtypes = [PV, PF]
         L.kfo_trilinear.restype = C.c_float
@@ -156,6 +164,25 @@ class Volume:
         return sz / np.array([self.w - 1, self.h - 1, self.d - 1], np.float32)
 
 
+class VolumeH:
+    """Pitched host BoundedVolume<SDF_h>: cells {half val; half w;}.  `data` is float16 (d, h, w, 2)."""
+    half = True
+
+    def __init__(self, w, h, d, boxmin=(-1, -1, -1), boxmax=(1, 1, 1), pitch_bytes=None):
+        self.w, self.h, self.d = int(w), int(h), int(d)
+        self.pitch = int(pitch_bytes) if pitch_bytes else self.w * 4
+        self.img_pitch = self.pitch * self.h
+        self.raw = np.zeros(self.img_pitch * self.d, dtype=np.uint8)
+        self.boxmin = np.asarray(boxmin, np.float32)
+        self.boxmax = np.asarray(boxmax, np.float32)
+        self.data = np.lib.stride_tricks.as_strided(
+            self.raw.view(np.float16), shape=(self.d, self.h, self.w, 2), strides=(self.img_pitch, self.pitch, 4, 2))
+
+    struct = Volume.struct
+    ref = Volume.ref
+    voxel_size = Volume.voxel_size
+
+
 class SubVolume:
     """Non-owning view produced by sub_bounding_volume (keeps the parent alive)."""
 
@@ -206,28 +233,32 @@ def normals_from_vbo(nrm, vbo):
     lib().kfo_normals_from_vbo(nrm.ref(), vbo.ref())
 
 
+def _is_half(vol):
+    return bool(getattr(vol, "half", False))
+
+
 def sdf_reset(vol, trunc):
-    lib().kfo_sdf_reset(vol.ref(), trunc)
+    (lib().kfo_sdf_reset_h if _is_half(vol) else lib().kfo_sdf_reset)(vol.ref(), trunc)
 
 
 def sdf_sphere(vol, center, r):
     _, c = _fp(center)
-    lib().kfo_sdf_sphere(vol.ref(), c, r)
+    (lib().kfo_sdf_sphere_h if _is_half(vol) else lib().kfo_sdf_sphere)(vol.ref(), c, r)
 
 
 def sdf_fuse(vol, depth, norm, T_cw, K, trunc, max_w, mincostheta, full_extent=False, nthreads=1):
     _, t = _fp(T_cw)
     _, k = _fp(K)
-    return int(lib().kfo_sdf_fuse(vol.ref(), depth.ref(), norm.ref(), t, k, trunc, max_w, mincostheta,
-                                  1 if full_extent else 0, nthreads))
+    fn = lib().kfo_sdf_fuse_h if _is_half(vol) else lib().kfo_sdf_fuse
+    return int(fn(vol.ref(), depth.ref(), norm.ref(), t, k, trunc, max_w, mincostheta, 1 if full_extent else 0, nthreads))
 
 
 def raycast_sdf(depth, norm, img, vol, T_wc, K, near, far, trunc, subpix=True, nthreads=1):
     _, t = _fp(T_wc)
     _, k = _fp(K)
     st = KfoRaycastStats()
-    lib().kfo_raycast_sdf(depth.ref(), norm.ref(), img.ref(), vol.ref(), t, k, near, far, trunc,
-                          1 if subpix else 0, nthreads, C.byref(st))
+    fn = lib().kfo_raycast_sdf_h if _is_half(vol) else lib().kfo_raycast_sdf
+    fn(depth.ref(), norm.ref(), img.ref(), vol.ref(), t, k, near, far, trunc, 1 if subpix else 0, nthreads, C.byref(st))
     return {"rays": st.rays, "steps": st.steps, "hits": st.hits}
 
 

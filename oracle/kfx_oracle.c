@@ -10,6 +10,7 @@
  */
 #include "kfx_oracle.h"
 
+#include <immintrin.h>
 #include <math.h>
 #include <string.h>
 #ifdef _OPENMP
@@ -93,10 +94,23 @@ static inline sdf_t* vol_row(const kfo_volume* v, size_t y, size_t z) /* Volume.
 {
     return (sdf_t*)((unsigned char*)v->ptr + z * v->img_pitch + y * v->pitch);
 }
-static inline float vol_val(const kfo_volume* v, int x, int y, int z) /* Volume.h:161-171 + Sdf.h:16-18 */
+/* fp16 cells (BASELINE config C5): {half val; half w;}, 4 bytes, the arithmetic of the reference's
+ * commented-out half variant (Sdf.h:38-62): every intermediate is rounded to half, round-to-nearest-even.
+ * F16C conversions (vcvtps2ph / vcvtph2ps) are exact IEEE binary16 <-> binary32. */
+typedef struct { uint16_t val, w; } sdfh_t;
+static inline uint16_t f2h(float x) { return (uint16_t)_cvtss_sh(x, _MM_FROUND_TO_NEAREST_INT | _MM_FROUND_NO_EXC); }
+static inline float h2f(uint16_t h) { return _cvtsh_ss(h); }
+static inline float qh(float x) { return h2f(f2h(x)); }
+static inline sdfh_t* volh_row(const kfo_volume* v, size_t y, size_t z)
 {
-    return vol_row(v, (size_t)y, (size_t)z)[x].val;
+    return (sdfh_t*)((unsigned char*)v->ptr + z * v->img_pitch + y * v->pitch);
 }
+/* `half` selects the cell type of the volume behind the (layout-identical) kfo_volume view */
+static inline float vol_val_c(const kfo_volume* v, int x, int y, int z, int half)
+{
+    return half ? h2f(volh_row(v, (size_t)y, (size_t)z)[x].val) : vol_row(v, (size_t)y, (size_t)z)[x].val;
+}
+#define vol_val(v, x, y, z) vol_val_c(v, x, y, z, half) /* Volume.h:161-171 + Sdf.h:16-18 */
 static inline f3 box_size(const kfo_volume* v) /* BoundingBox.h:139-143 */
 {
     return mk3(v->boxmax[0] - v->boxmin[0], v->boxmax[1] - v->boxmin[1], v->boxmax[2] - v->boxmin[2]);
@@ -279,7 +293,7 @@ void kfo_sdf_sphere(const kfo_volume* vol, const float center[3], float r)
  * ========================================================================== */
 static inline int fuse_voxel(const kfo_volume* vol, const kfo_image* depth, const kfo_image* normals,
                              const float* T, const float* K, float trunc_dist, float max_w,
-                             float mincostheta, int x, int y, int z)
+                             float mincostheta, int x, int y, int z, int half)
 {
     const f3 P_w = voxel_position(vol, x, y, z);         /* :22 */
     const f3 P_c = se3_mul(T, P_w);                       /* :23 */
@@ -311,6 +325,21 @@ static inline int fuse_voxel(const kfo_volume* vol, const kfo_image* depth, cons
     const float w = costheta * 1.0f / vd;                  /* :37 */
 
     if (sd <= -trunc_dist) return 0;                       /* :39-42 */
+    if (half && isfinite(md) && isfinite(w) && costheta > mincostheta) {
+        /* same update on a half cell: SDF_t(v, w) rounds both to half, then Sdf.h:52-58 */
+        sdfh_t* cell = &volh_row(vol, (size_t)y, (size_t)z)[x];
+        float sval = qh(clampf(sd, -trunc_dist, trunc_dist)), sw = qh(w);
+        const float rval = h2f(cell->val), rw = h2f(cell->w);
+        if (rw > 0) {
+            sval = qh(sw * sval + rw * rval);
+            sw = qh(sw + rw);
+            sval = qh(sval / sw);
+        }
+        sw = qh(fminf(sw, max_w));
+        cell->val = f2h(sval);
+        cell->w = f2h(sw);
+        return 1;
+    }
     if (isfinite(md) && isfinite(w) && costheta > mincostheta) { /* :44 */
         sdf_t* cell = &vol_row(vol, (size_t)y, (size_t)z)[x];
         sdf_t s = {clampf(sd, -trunc_dist, trunc_dist), w}; /* :45 */
@@ -327,9 +356,9 @@ static inline int fuse_voxel(const kfo_volume* vol, const kfo_image* depth, cons
     return 0;
 }
 
-uint64_t kfo_sdf_fuse(const kfo_volume* vol, const kfo_image* depth, const kfo_image* norm,
-                      const float T_cw[12], const float K[4], float trunc, float max_w,
-                      float mincostheta, int full_extent, int nthreads)
+static uint64_t sdf_fuse_any(const kfo_volume* vol, const kfo_image* depth, const kfo_image* norm,
+                             const float T_cw[12], const float K[4], float trunc, float max_w,
+                             float mincostheta, int full_extent, int nthreads, int half)
 {
     /* gridDim = (w/8, h/8, d/8), blockDim = (8,8,8): integer division, no tail (quirk Q1) */
     const int X = full_extent ? (int)vol->w : (int)(vol->w / 8) * 8;
@@ -342,8 +371,21 @@ uint64_t kfo_sdf_fuse(const kfo_volume* vol, const kfo_image* depth, const kfo_i
     for (int z = 0; z < Z; ++z)
         for (int y = 0; y < Y; ++y)
             for (int x = 0; x < X; ++x)
-                updated += (uint64_t)fuse_voxel(vol, depth, norm, T_cw, K, trunc, max_w, mincostheta, x, y, z);
+                updated += (uint64_t)fuse_voxel(vol, depth, norm, T_cw, K, trunc, max_w, mincostheta, x, y, z, half);
     return updated;
+}
+
+uint64_t kfo_sdf_fuse(const kfo_volume* vol, const kfo_image* depth, const kfo_image* norm,
+                      const float T_cw[12], const float K[4], float trunc, float max_w,
+                      float mincostheta, int full_extent, int nthreads)
+{
+    return sdf_fuse_any(vol, depth, norm, T_cw, K, trunc, max_w, mincostheta, full_extent, nthreads, 0);
+}
+uint64_t kfo_sdf_fuse_h(const kfo_volume* vol, const kfo_image* depth, const kfo_image* norm,
+                        const float T_cw[12], const float K[4], float trunc, float max_w,
+                        float mincostheta, int full_extent, int nthreads)
+{
+    return sdf_fuse_any(vol, depth, norm, T_cw, K, trunc, max_w, mincostheta, full_extent, nthreads, 1);
 }
 
 /* ============================================================================
@@ -377,7 +419,7 @@ static inline void touch(touch_t* t, int x, int y, int z)
 /* BoundedVolume::GetUnitsTrilinearClamped (BoundedVolume.h:93-98) ->
  * Volume::GetFractionalTrilinearClamped (Volume.h:224-250); quirk Q4: only the
  * integer cell is clamped, the fraction extrapolates. */
-static inline float trilinear_clamped(const kfo_volume* v, f3 pos_w, touch_t* t)
+static inline float trilinear_clamped(const kfo_volume* v, f3 pos_w, touch_t* t, int half)
 {
     const f3 pos_v = div33(sub3(pos_w, box_min(v)), box_size(v));
     const f3 pf = {pos_v.x * ((float)v->w - 1.f), pos_v.y * ((float)v->h - 1.f), pos_v.z * ((float)v->d - 1.f)};
@@ -395,7 +437,7 @@ static inline float trilinear_clamped(const kfo_volume* v, f3 pos_w, touch_t* t)
                  lerpf(lerpf(vz, vxz, fx), lerpf(vyz, vxyz, fx), fy), fz);
 }
 
-static inline f3 backward_diff(const kfo_volume* v, int x, int y, int z, touch_t* t) /* Volume.h:256-265 */
+static inline f3 backward_diff(const kfo_volume* v, int x, int y, int z, touch_t* t, int half) /* Volume.h:256-265 */
 {
     const float v0 = vol_val(v, x, y, z);
     if (t && t->bitmap) { touch(t, x, y, z); touch(t, x - 1, y, z); touch(t, x, y - 1, z); touch(t, x, y, z - 1); }
@@ -404,7 +446,7 @@ static inline f3 backward_diff(const kfo_volume* v, int x, int y, int z, touch_t
 
 /* BoundedVolume::GetUnitsBackwardDiffDxDyDz (BoundedVolume.h:100-106) ->
  * Volume::GetFractionalBackwardDiffDxDyDz (Volume.h:267-295) */
-static inline f3 units_backward_diff(const kfo_volume* v, f3 pos_w, touch_t* t)
+static inline f3 units_backward_diff(const kfo_volume* v, f3 pos_w, touch_t* t, int half)
 {
     const f3 pos_v = div33(sub3(pos_w, box_min(v)), box_size(v));
     const f3 pf = {pos_v.x * ((float)v->w - 1.f), pos_v.y * ((float)v->h - 1.f), pos_v.z * ((float)v->d - 1.f)};
@@ -412,10 +454,10 @@ static inline f3 units_backward_diff(const kfo_volume* v, f3 pos_w, touch_t* t)
     const int iy = (int)fmaxf(fminf((float)(v->h - 2), floorf(pf.y)), 1);
     const int iz = (int)fmaxf(fminf((float)(v->d - 2), floorf(pf.z)), 1);
     const float fx = pf.x - (float)ix, fy = pf.y - (float)iy, fz = pf.z - (float)iz;
-    const f3 g0 = backward_diff(v, ix, iy, iz, t), gx = backward_diff(v, ix + 1, iy, iz, t);
-    const f3 gy = backward_diff(v, ix, iy + 1, iz, t), gxy = backward_diff(v, ix + 1, iy + 1, iz, t);
-    const f3 gz = backward_diff(v, ix, iy, iz + 1, t), gxz = backward_diff(v, ix + 1, iy, iz + 1, t);
-    const f3 gyz = backward_diff(v, ix, iy + 1, iz + 1, t), gxyz = backward_diff(v, ix + 1, iy + 1, iz + 1, t);
+    const f3 g0 = backward_diff(v, ix, iy, iz, t, half), gx = backward_diff(v, ix + 1, iy, iz, t, half);
+    const f3 gy = backward_diff(v, ix, iy + 1, iz, t, half), gxy = backward_diff(v, ix + 1, iy + 1, iz, t, half);
+    const f3 gz = backward_diff(v, ix, iy, iz + 1, t, half), gxz = backward_diff(v, ix + 1, iy, iz + 1, t, half);
+    const f3 gyz = backward_diff(v, ix, iy + 1, iz + 1, t, half), gxyz = backward_diff(v, ix + 1, iy + 1, iz + 1, t, half);
     const f3 deriv = lerp3(lerp3(lerp3(g0, gx, fx), lerp3(gy, gxy, fx), fy),
                            lerp3(lerp3(gz, gxz, fx), lerp3(gyz, gxyz, fx), fy), fz);
     return div33(deriv, voxel_size_units(v));
@@ -424,7 +466,7 @@ static inline f3 units_backward_diff(const kfo_volume* v, f3 pos_w, touch_t* t)
 static inline void raycast_pixel(const kfo_image* imgdepth, const kfo_image* norm, const kfo_image* img,
                                  const kfo_volume* vol, const float* T, const float* K, float near,
                                  float far, float trunc_dist, int subpix, int u, int v, touch_t* t,
-                                 uint64_t* n_rays, uint64_t* n_steps, uint64_t* n_hits)
+                                 uint64_t* n_rays, uint64_t* n_steps, uint64_t* n_hits, int half)
 {
     const f3 c_w = se3_translation(T);                               /* :40 */
     const f3 ray_c = unproject1(K, (float)u, (float)v);              /* :41 */
@@ -446,7 +488,7 @@ static inline void raycast_pixel(const kfo_image* imgdepth, const kfo_image* nor
         ++*n_rays;
         while (lambda < min_tmax) {                                  /* :64 */
             const f3 pos_w = add3(c_w, scale3(ray_w, lambda));
-            const float sdf = trilinear_clamped(vol, pos_w, t);
+            const float sdf = trilinear_clamped(vol, pos_w, t, half);
             ++*n_steps;
             if (sdf <= 0) {                                          /* :68 */
                 if (last_sdf > 0) {
@@ -466,7 +508,7 @@ static inline void raycast_pixel(const kfo_image* imgdepth, const kfo_image* nor
     f4* pn = &((f4*)img_row(norm, (size_t)v))[u];
     if (depth > 0) {                                                 /* :92 */
         const f3 pos_w = add3(c_w, scale3(ray_w, depth));            /* :85 */
-        const f3 _n_w = units_backward_diff(vol, pos_w, t);          /* :86 */
+        const f3 _n_w = units_backward_diff(vol, pos_w, t, half);          /* :86 */
         const float len_n_w = length3(_n_w);
         const f3 n_w = len_n_w > 0 ? div3s(_n_w, len_n_w) : mk3(0, 0, 1); /* :88 */
         const f3 n_c = so3_mul_inv(T, n_w);                          /* :89 */
@@ -484,9 +526,9 @@ static inline void raycast_pixel(const kfo_image* imgdepth, const kfo_image* nor
     }
 }
 
-void kfo_raycast_sdf(const kfo_image* depth, const kfo_image* norm, const kfo_image* img,
-                     const kfo_volume* vol, const float T_wc[12], const float K[4], float near,
-                     float far, float trunc, int subpix, int nthreads, kfo_raycast_stats* stats)
+static void raycast_any(const kfo_image* depth, const kfo_image* norm, const kfo_image* img,
+                        const kfo_volume* vol, const float T_wc[12], const float K[4], float near,
+                        float far, float trunc, int subpix, int nthreads, kfo_raycast_stats* stats, int half)
 {
     uint64_t rays = 0, steps = 0, hits = 0;
     const int nt = pick_threads(nthreads);
@@ -494,8 +536,21 @@ void kfo_raycast_sdf(const kfo_image* depth, const kfo_image* norm, const kfo_im
 #pragma omp parallel for num_threads(nt) schedule(dynamic, 4) reduction(+ : rays, steps, hits)
     for (int v = 0; v < (int)img->h; ++v)
         for (int u = 0; u < (int)img->w; ++u)
-            raycast_pixel(depth, norm, img, vol, T_wc, K, near, far, trunc, subpix, u, v, NULL, &rays, &steps, &hits);
+            raycast_pixel(depth, norm, img, vol, T_wc, K, near, far, trunc, subpix, u, v, NULL, &rays, &steps, &hits, half);
     if (stats) { stats->rays = rays; stats->steps = steps; stats->hits = hits; }
+}
+
+void kfo_raycast_sdf(const kfo_image* depth, const kfo_image* norm, const kfo_image* img,
+                     const kfo_volume* vol, const float T_wc[12], const float K[4], float near,
+                     float far, float trunc, int subpix, int nthreads, kfo_raycast_stats* stats)
+{
+    raycast_any(depth, norm, img, vol, T_wc, K, near, far, trunc, subpix, nthreads, stats, 0);
+}
+void kfo_raycast_sdf_h(const kfo_image* depth, const kfo_image* norm, const kfo_image* img,
+                       const kfo_volume* vol, const float T_wc[12], const float K[4], float near,
+                       float far, float trunc, int subpix, int nthreads, kfo_raycast_stats* stats)
+{
+    raycast_any(depth, norm, img, vol, T_wc, K, near, far, trunc, subpix, nthreads, stats, 1);
 }
 
 void kfo_raycast_sdf_touch(const kfo_image* depth, const kfo_image* norm, const kfo_image* img,
@@ -506,7 +561,7 @@ void kfo_raycast_sdf_touch(const kfo_image* depth, const kfo_image* norm, const 
     touch_t t = {bitmap, vol};
     for (int v = 0; v < (int)img->h; ++v)
         for (int u = 0; u < (int)img->w; ++u)
-            raycast_pixel(depth, norm, img, vol, T_wc, K, near, far, trunc, subpix, u, v, &t, &rays, &steps, &hits);
+            raycast_pixel(depth, norm, img, vol, T_wc, K, near, far, trunc, subpix, u, v, &t, &rays, &steps, &hits, 0);
     if (stats) { stats->rays = rays; stats->steps = steps; stats->hits = hits; }
 }
 
@@ -669,11 +724,11 @@ void kfo_sub_bounding_volume(kfo_volume* out, const kfo_volume* vol, const float
  * ========================================================================== */
 float kfo_trilinear(const kfo_volume* vol, const float pos_w[3])
 {
-    return trilinear_clamped(vol, mk3(pos_w[0], pos_w[1], pos_w[2]), NULL);
+    return trilinear_clamped(vol, mk3(pos_w[0], pos_w[1], pos_w[2]), NULL, 0);
 }
 void kfo_gradient(const kfo_volume* vol, const float pos_w[3], float out[3])
 {
-    const f3 g = units_backward_diff(vol, mk3(pos_w[0], pos_w[1], pos_w[2]), NULL);
+    const f3 g = units_backward_diff(vol, mk3(pos_w[0], pos_w[1], pos_w[2]), NULL, 0);
     out[0] = g.x; out[1] = g.y; out[2] = g.z;
 }
 void kfo_sdf_accumulate(float val, float w, float old_val, float old_w, float max_w, float out[2])
@@ -697,4 +752,30 @@ void kfo_voxel_position(const kfo_volume* vol, int x, int y, int z, float out[3]
 {
     const f3 p = voxel_position(vol, x, y, z);
     out[0] = p.x; out[1] = p.y; out[2] = p.z;
+}
+
+/* ============================================================================
+ * fp16-cell volume initialisers (config C5)
+ * ========================================================================== */
+void kfo_sdf_reset_h(const kfo_volume* vol, float trunc)
+{
+    sdfh_t* b = (sdfh_t*)vol->ptr;
+    sdfh_t* e = volh_row(vol, vol->h - 1, vol->d - 1) + vol->w;
+    const sdfh_t v = {f2h(trunc), f2h(0.0f)};
+    for (; b < e; ++b) *b = v;
+}
+
+void kfo_sdf_sphere_h(const kfo_volume* vol, const float center[3], float r)
+{
+    const int X = (int)(vol->w / 8) * 8, Y = (int)(vol->h / 8) * 8, Z = (int)(vol->d / 8) * 8;
+    const f3 c = {center[0], center[1], center[2]};
+    for (int z = 0; z < Z; ++z)
+        for (int y = 0; y < Y; ++y) {
+            sdfh_t* row = volh_row(vol, (size_t)y, (size_t)z);
+            for (int x = 0; x < X; ++x) {
+                const float dist = length3(sub3(voxel_position(vol, x, y, z), c));
+                sdfh_t s = {f2h(dist - r), f2h(1.0f)};
+                row[x] = s;
+            }
+        }
 }

@@ -84,6 +84,18 @@ void kfo_raycast_sdf(const kfo_image* depth, const kfo_image* norm, const kfo_im
                      const kfo_volume* vol, const float T_wc[12], const float K[4],
                      float near, float far, float trunc, int subpix, int nthreads,
                      kfo_raycast_stats* stats);
+/* fp16-cell variants (BASELINE config C5): volume cells are {half val; half w;} (4 bytes), the
+ * arithmetic of the reference's commented-out half SDF_t (Sdf.h:38-62). */
+uint64_t kfo_sdf_fuse_h(const kfo_volume* vol, const kfo_image* depth, const kfo_image* norm,
+                        const float T_cw[12], const float K[4], float trunc, float max_w,
+                        float mincostheta, int full_extent, int nthreads);
+void kfo_raycast_sdf_h(const kfo_image* depth, const kfo_image* norm, const kfo_image* img,
+                       const kfo_volume* vol, const float T_wc[12], const float K[4],
+                       float near, float far, float trunc, int subpix, int nthreads,
+                       kfo_raycast_stats* stats);
+void kfo_sdf_reset_h(const kfo_volume* vol, float trunc);
+void kfo_sdf_sphere_h(const kfo_volume* vol, const float center[3], float r);
+
 /* Like kfo_raycast_sdf but also marks every distinct voxel the rays touch
  * (trilinear corners + normal stencil) in `bitmap` (1 bit per voxel, index
  * (z*h + y)*w + x), for the algorithmic-bytes figure of SURVEY 8(d). */

@@ -214,3 +214,26 @@ def test_analytic_renderers_and_roi():
     assert np.array_equal(sub.boxmin, oracle.voxel_position(vol, x0, y0, z0))
     assert np.array_equal(sub.boxmax, oracle.voxel_position(vol, x0 + sub.w - 1, y0 + sub.h - 1, z0 + sub.d - 1))
     assert sub.boxmin[0] <= -0.3 + 2 / 31 and sub.boxmax[0] >= 0.4
+
+
+def test_oracle_half_cells():
+    """fp16 cells: F16C round-to-nearest-even conversions; first observation stores half(val), the
+    running average rounds every intermediate (Sdf.h:52-58)."""
+    v = oracle.VolumeH(16, 16, 16, *scenes.SCENES["full"][:2])
+    oracle.sdf_reset(v, float("nan"))
+    assert np.isnan(v.data[..., 0]).all() and (v.data[..., 1] == 0).all()
+    K = scenes.intrinsics(80, 60)
+    f, vbo, nrm = T.preprocess_oracle(scenes.render_depth("full", 80, 60, None, K), K)
+    tr = scenes.trunc_dist(v.boxmin, v.boxmax, (16, 16, 16))
+    v32 = T.make_volume(16, "full")
+    n16 = oracle.sdf_fuse(v, f, nrm, scenes.identity_pose(), K, tr, 1000.0, 0.1)
+    n32 = oracle.sdf_fuse(v32, f, nrm, scenes.identity_pose(), K, tr, 1000.0, 0.1)
+    assert n16 == n32 > 0
+    assert np.array_equal(v.data, v32.data.astype(np.float16), equal_nan=True)  # first observation = rounding only
+    oracle.sdf_fuse(v, f, nrm, scenes.identity_pose(), K, tr, 1000.0, 0.1)
+    w1 = v32.data[..., 1].astype(np.float16)
+    upd = ~np.isnan(v.data[..., 0])
+    assert np.array_equal(v.data[..., 1][upd], (w1[upd] + w1[upd]).astype(np.float16))
+    rd, rn, ri = oracle.Image(80, 60), oracle.Image(80, 60, channels=4), oracle.Image(80, 60)
+    st = oracle.raycast_sdf(rd, rn, ri, v, scenes.identity_pose(), K, 0.4, 8.0, tr, True)
+    assert st["rays"] > 0
