@@ -3,10 +3,12 @@
 // with known poses orbits a synthetic room, and every frame runs the same roo:: calls in the same
 // order on the same container types:
 //
-//   BilateralFilter -> DepthToVbo -> NormalsFromVbo                        (main.cpp:209-215)
+//   ElementwiseScaleBias (mm -> m) -> BilateralFilter -> BoxReduceIgnoreInvalid -> per level
+//   DepthToVbo -> NormalsFromVbo                                            (main.cpp:208-215)
 //   [first frame] SdfReset(vol, NaN); SdfFuse                              (main.cpp:224-242)
 //   roi = BoundingBox(T_wl, w, h, K, knear, kfar); work_vol = vol.SubBoundingVolume(roi)   (:275-276)
-//   RaycastSdf(ray_d, ray_n, ray_i, work_vol, T_wl, K, knear, kfar, trunc_dist, true)      (:286)
+//   for levels with its[l] > 0: RaycastSdf(ray_d[l], ray_n[l], ray_i[l], work_vol, T_wl, K[l], ...);
+//                               DepthToVbo(ray_v[l], ray_d[l], K[l])                       (:280-288)
 //   SdfFuse(work_vol, kin_d, kin_n, T_wl^-1, K, trunc_dist, max_w, mincostheta)            (:345-356)
 //
 // Host code only; all device work happens in libkfx behind the roo:: wrappers.
@@ -81,11 +83,13 @@ int main(int argc, char** argv)
     const float trunc_dist_factor = 2.0f, max_w = 1000.0f, mincostheta = 0.1f;  // main.cpp:155-158
     const BoundingBox reset_bb(make_float3(-1, -1, 2), make_float3(1, 1, 4));
 
+    const int MaxLevels = 4;
+    const int its[] = {1, 0, 2, 3};                      // main.cpp:51-52
     Image<float, TargetDevice, Manage> dKinectMeters(w, h);
-    Image<float, TargetDevice, Manage> kin_d(w, h);
-    Image<float4, TargetDevice, Manage> kin_v(w, h), kin_n(w, h);
-    Image<float, TargetDevice, Manage> ray_i(w, h), ray_d(w, h);
-    Image<float4, TargetDevice, Manage> ray_n(w, h);
+    Pyramid<float, MaxLevels, TargetDevice, Manage> kin_d(w, h);
+    Pyramid<float4, MaxLevels, TargetDevice, Manage> kin_v(w, h), kin_n(w, h);
+    Pyramid<float, MaxLevels, TargetDevice, Manage> ray_i(w, h), ray_d(w, h);
+    Pyramid<float4, MaxLevels, TargetDevice, Manage> ray_n(w, h), ray_v(w, h);
     BoundedVolume<SDF_t, TargetDevice, Manage> vol(volres, volres, volres, reset_bb);
 
     const float3 vs = vol.VoxelSizeUnits();
@@ -96,6 +100,7 @@ int main(int argc, char** argv)
     for (int f = 0; f < frames; ++f) {
         poses[f] = OrbitPose(f, 30);
         RenderRoom(depth_frames[f], w, h, poses[f], K);
+        for (float& d : depth_frames[f]) d *= 1000.0f;   // the sensor delivers millimetres (main.cpp:208)
     }
 
     std::vector<float> hdepth((size_t)w * h);
@@ -105,23 +110,34 @@ int main(int argc, char** argv)
         const Mat<float,3,4> T_wl = poses[f];
         dKinectMeters.MemcpyFromHost(depth_frames[f].data());   // the host->device boundary of main.cpp:203
         const auto t0 = std::chrono::steady_clock::now();
-        BilateralFilter<float,float>(kin_d, dKinectMeters, bigs, bigr, biwin, 0.2f);
-        DepthToVbo<float>(kin_v, kin_d, K);
-        NormalsFromVbo(kin_n, kin_v);
+        ElementwiseScaleBias<float,float,float>(dKinectMeters, dKinectMeters, 1.0f / 1000.0f);
+        BilateralFilter<float,float>(kin_d[0], dKinectMeters, bigs, bigr, biwin, 0.2f);
+        BoxReduceIgnoreInvalid<float,MaxLevels,float>(kin_d);
+        for (int l = 0; l < MaxLevels; ++l) {
+            DepthToVbo<float>(kin_v[l], kin_d[l], K[l]);
+            NormalsFromVbo(kin_n[l], kin_v[l]);
+        }
         if (f == 0) {
             SdfReset(vol, std::numeric_limits<float>::quiet_NaN());
-            SdfFuse(vol, kin_d, kin_n, SE3inv(T_wl), K, trunc_dist, max_w, mincostheta);
+            SdfFuse(vol, kin_d[0], kin_n[0], SE3inv(T_wl), K, trunc_dist, max_w, mincostheta);
         }
         const BoundingBox roi(T_wl, w, h, K, knear, kfar);
         BoundedVolume<SDF_t> work_vol = vol.SubBoundingVolume(roi);
         if (work_vol.IsValid()) {
-            RaycastSdf(ray_d, ray_n, ray_i, work_vol, T_wl, K, knear, kfar, trunc_dist, true);
-            if (f > 0) SdfFuse(work_vol, kin_d, kin_n, SE3inv(T_wl), K, trunc_dist, max_w, mincostheta);
+            for (int l = 0; l < MaxLevels; ++l) {
+                if (its[l] > 0) {
+                    const ImageIntrinsics Kl = K[l];
+                    RaycastSdf(ray_d[l], ray_n[l], ray_i[l], work_vol, T_wl, Kl, knear, kfar, trunc_dist, true);
+                    DepthToVbo<float>(ray_v[l], ray_d[l], Kl);
+                }
+            }
+            // (the ICP pose refinement of main.cpp:301-337 would run here; poses are known)
+            if (f > 0) SdfFuse(work_vol, kin_d[0], kin_n[0], SE3inv(T_wl), K, trunc_dist, max_w, mincostheta);
         }
         kfx_stream_synchronize(0);
         total_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         if (f == frames - 1) {
-            ray_d.MemcpyToHost(hdepth.data());
+            ray_d[0].MemcpyToHost(hdepth.data());
             for (float d : hdepth) hits += std::isfinite(d) ? 1 : 0;
         }
     }

@@ -16,8 +16,12 @@
 #include <kangaroo/Sdf.h>
 #include <kangaroo/Volume.h>
 #include <kangaroo/BoundedVolume.h>
+#include <kangaroo/Pyramid.h>
 #include <kangaroo/launch_utils.h>
 
+#include <kangaroo/cu_operations.h>
+#include <kangaroo/cu_resample.h>
+#include <kangaroo/reduce.h>
 #include <kangaroo/cu_bilateral.h>
 #include <kangaroo/cu_depth_tools.h>
 #include <kangaroo/cu_normals.h>

@@ -126,6 +126,14 @@ int kfx_depth_to_vbo_u16(const kfx_image* vbo, const kfx_image* depth, const flo
  * reference: include/kangaroo/cu_normals.h:9-10, src/cu_normals.cu:12-45 */
 int kfx_normals_from_vbo(const kfx_image* nrm, const kfx_image* vbo, kfx_stream stream);
 
+/* Frame pre-amble of the application around the path:
+ * roo::ElementwiseScaleBias<float,float,float>(b, a, s, offset): b = s*a + offset (millimetres -> metres,
+ *   applications/kinectfusion/main.cpp:208) -- reference: src/cu_operations.cu:39-57
+ * roo::BoxHalfIgnoreInvalid<float,float,float>(out, in): 2x2 mean of the finite samples, NaN if none; one level
+ *   of roo::BoxReduceIgnoreInvalid (main.cpp:211) -- reference: src/cu_resample.cu:89-120, reduce.h:48-59 */
+int kfx_elementwise_scale_bias_f32(const kfx_image* out, const kfx_image* in, float s, float offset, kfx_stream stream);
+int kfx_box_half_ignore_invalid_f32(const kfx_image* out, const kfx_image* in, kfx_stream stream);
+
 /* roo::SdfReset(BoundedVolume<SDF_t>, float trunc_dist): fills (trunc_dist, 0) over the
  * contiguous span ptr .. RowPtr(h-1,d-1)+w including pitch padding
  * reference: cu_sdffusion.h:20, src/cu_sdffusion.cu:153-164, Volume.h:343-356 */

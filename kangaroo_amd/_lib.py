@@ -46,6 +46,8 @@ SIGNATURES = {
     "kfx_depth_to_vbo_f32": (C.c_int, [PI, PI, PF, C.c_float, C.c_void_p]),
     "kfx_depth_to_vbo_u16": (C.c_int, [PI, PI, PF, C.c_float, C.c_void_p]),
     "kfx_normals_from_vbo": (C.c_int, [PI, PI, C.c_void_p]),
+    "kfx_elementwise_scale_bias_f32": (C.c_int, [PI, PI, C.c_float, C.c_float, C.c_void_p]),
+    "kfx_box_half_ignore_invalid_f32": (C.c_int, [PI, PI, C.c_void_p]),
     "kfx_sdf_reset": (C.c_int, [PV, C.c_float, C.c_void_p]),
     "kfx_sdf_sphere": (C.c_int, [PV, PF, C.c_float, C.c_void_p]),
     "kfx_alloc_pitched": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_size_t, C.c_size_t]),

@@ -168,6 +168,41 @@ __global__ __launch_bounds__(256) void k_normals_from_vbo(const NrmParams p)
     reinterpret_cast<float4*>(p.out + (size_t)v * p.out_pitch)[u] = N;
 }
 
+struct EwParams {
+    const unsigned char* in;
+    size_t in_pitch;
+    unsigned char* out;
+    size_t out_pitch;
+    int w, h;
+    float s, offset;
+};
+
+// KernElementwiseScaleBias<float,float,float> (cu_operations.cu:39-49): b = s*a + offset
+__global__ __launch_bounds__(256) void k_scale_bias_f32(const EwParams p)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= p.w || y >= p.h) return;
+    const float v1 = reinterpret_cast<const float*>(p.in + (size_t)y * p.in_pitch)[x];
+    reinterpret_cast<float*>(p.out + (size_t)y * p.out_pitch)[x] = p.s * v1 + p.offset;
+}
+
+// KernBoxHalfIgnoreInvalid<float,float,float> (cu_resample.cu:89-111): mean of the finite samples of
+// each 2x2 block, NaN if none; samples are added in the order tl, tr, bl, br
+__global__ __launch_bounds__(256) void k_box_half_ignore_invalid_f32(const EwParams p)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= p.w || y >= p.h) return;
+    const float2 t = *reinterpret_cast<const float2*>(p.in + (size_t)(2 * y) * p.in_pitch + (size_t)(2 * x) * 4);
+    const float2 b = *reinterpret_cast<const float2*>(p.in + (size_t)(2 * y + 1) * p.in_pitch + (size_t)(2 * x) * 4);
+    int n = 0;
+    float sum = 0;
+    if (isfinite(t.x)) { sum += t.x; n++; }
+    if (isfinite(t.y)) { sum += t.y; n++; }
+    if (isfinite(b.x)) { sum += b.x; n++; }
+    if (isfinite(b.y)) { sum += b.y; n++; }
+    reinterpret_cast<float*>(p.out + (size_t)y * p.out_pitch)[x] = n > 0 ? (sum / n) : __builtin_nanf("");
+}
+
 } // namespace kfx
 
 using namespace kfx;
@@ -285,4 +320,29 @@ extern "C" int kfx_normals_from_vbo(const kfx_image* nrm, const kfx_image* vbo, 
     dim3 grid(ceil_div(p.w, 64), ceil_div(p.h, 4));
     hipLaunchKernelGGL(k_normals_from_vbo, grid, dim3(256), 0, (hipStream_t)stream, p);
     return check_launch("kfx_normals_from_vbo");
+}
+
+extern "C" int kfx_elementwise_scale_bias_f32(const kfx_image* out, const kfx_image* in, float s, float offset, kfx_stream stream)
+{
+    if (int e = check_image(out, 4, "ElementwiseScaleBias: output image")) return e;
+    if (int e = check_image(in, 4, "ElementwiseScaleBias: input image")) return e;
+    if (out->w == 0 || out->h == 0) return 0;
+    if (in->w < out->w || in->h < out->h) return set_error(KFX_E_SHAPE, "ElementwiseScaleBias: input smaller than output");
+    EwParams p{(const unsigned char*)in->ptr, in->pitch, (unsigned char*)out->ptr, out->pitch, (int)out->w, (int)out->h, s, offset};
+    dim3 grid(ceil_div(p.w, 64), ceil_div(p.h, 4));
+    hipLaunchKernelGGL(k_scale_bias_f32, grid, dim3(256), 0, (hipStream_t)stream, p);
+    return check_launch("kfx_elementwise_scale_bias_f32");
+}
+
+extern "C" int kfx_box_half_ignore_invalid_f32(const kfx_image* out, const kfx_image* in, kfx_stream stream)
+{
+    if (int e = check_image(out, 4, "BoxHalfIgnoreInvalid: output image")) return e;
+    if (int e = check_image(in, 4, "BoxHalfIgnoreInvalid: input image")) return e;
+    if (out->w == 0 || out->h == 0) return 0;
+    if (in->w < 2 * out->w || in->h < 2 * out->h) return set_error(KFX_E_SHAPE, "BoxHalfIgnoreInvalid: input smaller than 2x output");
+    if (((uintptr_t)in->ptr | in->pitch) & 7) return set_error(KFX_E_ALIGN, "BoxHalfIgnoreInvalid: input not 8-byte aligned");
+    EwParams p{(const unsigned char*)in->ptr, in->pitch, (unsigned char*)out->ptr, out->pitch, (int)out->w, (int)out->h, 0.f, 0.f};
+    dim3 grid(ceil_div(p.w, 64), ceil_div(p.h, 4));
+    hipLaunchKernelGGL(k_box_half_ignore_invalid_f32, grid, dim3(256), 0, (hipStream_t)stream, p);
+    return check_launch("kfx_box_half_ignore_invalid_f32");
 }

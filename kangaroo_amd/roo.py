@@ -305,3 +305,32 @@ def SdfSphere(vol, center, r, stream=None):
     c, _c = _fp(center, 3)
     fn = _lib.load().kfx_sdf_sphere_h if vol.kind == "f16" else _lib.load().kfx_sdf_sphere
     _lib.check(fn(vol.ref(), c, r, _stream(stream)))
+
+
+def ElementwiseScaleBias(b, a, s, offset=0.0, stream=None):
+    """roo::ElementwiseScaleBias<float,float,float> (cu_operations.h; main.cpp:208): b = s*a + offset."""
+    _lib.check(_lib.load().kfx_elementwise_scale_bias_f32(b.ref(), a.ref(), s, offset, _stream(stream)))
+
+
+def BoxHalfIgnoreInvalid(out, inp, stream=None):
+    """roo::BoxHalfIgnoreInvalid<float,float,float> (cu_resample.h): NaN-aware 2x2 mean."""
+    _lib.check(_lib.load().kfx_box_half_ignore_invalid_f32(out.ref(), inp.ref(), _stream(stream)))
+
+
+class Pyramid:
+    """roo::Pyramid<T, Levels, TargetDevice, Manage> (Pyramid.h:9-137): level l is (w >> l) x (h >> l)."""
+
+    def __init__(self, w, h, levels, kind="f32"):
+        self.imgs = [Image(w >> l, h >> l, kind) for l in range(levels) if (w >> l) > 0 and (h >> l) > 0]
+
+    def __getitem__(self, l):
+        return self.imgs[l]
+
+    def __len__(self):
+        return len(self.imgs)
+
+
+def BoxReduceIgnoreInvalid(pyramid, stream=None):
+    """roo::BoxReduceIgnoreInvalid<T,Levels,UpType> (reduce.h:48-59): fill levels 1.. from level 0."""
+    for l in range(1, len(pyramid)):
+        BoxHalfIgnoreInvalid(pyramid[l], pyramid[l - 1], stream)

@@ -71,6 +71,10 @@ def lib():
         L.kfo_sdf_reset_h.restype = None
         L.kfo_sdf_sphere_h.argtypes = [PV, PF, C.c_float]
         L.kfo_sdf_sphere_h.restype = None
+        L.kfo_elementwise_scale_bias_f32.argtypes = [PI, PI, C.c_float, C.c_float]
+        L.kfo_elementwise_scale_bias_f32.restype = None
+        L.kfo_box_half_ignore_invalid_f32.argtypes = [PI, PI]
+        L.kfo_box_half_ignore_invalid_f32.restype = None
         L.kfo_max_threads.restype = C.c_int
         L.kfo_trilinear.argtypes = [PV, PF]
         L.kfo_trilinear.restype = C.c_float
@@ -361,3 +365,11 @@ def voxel_position(vol, x, y, z):
     o = (C.c_float * 3)()
     lib().kfo_voxel_position(vol.ref(), x, y, z, o)
     return np.array(list(o), np.float32)
+
+
+def elementwise_scale_bias(b, a, s, offset=0.0):
+    lib().kfo_elementwise_scale_bias_f32(b.ref(), a.ref(), s, offset)
+
+
+def box_half_ignore_invalid(out, inp):
+    lib().kfo_box_half_ignore_invalid_f32(out.ref(), inp.ref())

@@ -779,3 +779,28 @@ void kfo_sdf_sphere_h(const kfo_volume* vol, const float center[3], float r)
             }
         }
 }
+
+/* ============================================================================
+ * Frame pre-amble: ElementwiseScaleBias, BoxHalfIgnoreInvalid
+ * ========================================================================== */
+void kfo_elementwise_scale_bias_f32(const kfo_image* b, const kfo_image* a, float s, float offset) /* cu_operations.cu:39-49 */
+{
+    for (size_t y = 0; y < b->h; ++y)
+        for (size_t x = 0; x < b->w; ++x)
+            ((float*)img_row(b, y))[x] = s * ((const float*)img_row(a, y))[x] + offset;
+}
+
+void kfo_box_half_ignore_invalid_f32(const kfo_image* out, const kfo_image* in) /* cu_resample.cu:89-111 */
+{
+    for (size_t y = 0; y < out->h; ++y)
+        for (size_t x = 0; x < out->w; ++x) {
+            const float* tl = (const float*)img_row(in, 2 * y) + 2 * x;
+            const float* bl = (const float*)img_row(in, 2 * y + 1) + 2 * x;
+            const float v[4] = {tl[0], tl[1], bl[0], bl[1]};
+            int n = 0;
+            float sum = 0;
+            for (int i = 0; i < 4; ++i)
+                if (isfinite(v[i])) { sum += v[i]; n++; }
+            ((float*)img_row(out, y))[x] = n > 0 ? (sum / n) : NAN;
+        }
+}

@@ -137,6 +137,10 @@ void kfo_sdf_accumulate(float val, float w, float old_val, float old_w, float ma
 void kfo_intrinsics_level(float out[4], const float K[4], int level);
 void kfo_voxel_position(const kfo_volume* vol, int x, int y, int z, float out[3]);
 
+/* cu_operations.cu:39-57 <float,float,float>; cu_resample.cu:89-120 <float,float,float> */
+void kfo_elementwise_scale_bias_f32(const kfo_image* b, const kfo_image* a, float s, float offset);
+void kfo_box_half_ignore_invalid_f32(const kfo_image* out, const kfo_image* in);
+
 int kfo_max_threads(void);
 
 #ifdef __cplusplus

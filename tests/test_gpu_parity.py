@@ -547,3 +547,32 @@ def test_gpu_half_cells_fast_mode(roo):
     # (ulp of a value near trunc is trunc * 2^-10): rare, and never more than two ulps apart
     d = np.abs(a[..., 0][both] - b[..., 0][both])
     assert (d > 0).mean() < 0.01 and (d > tr * 2.0 ** -9).sum() <= 3
+
+
+# ---------------------------------------------------------------------------------
+# frame pre-amble: mm -> m conversion and the NaN-aware depth pyramid
+# ---------------------------------------------------------------------------------
+def test_gpu_scale_bias_and_pyramid(roo):
+    w, h = 160, 120
+    mm = scenes.render_depth("room", w, h) * np.float32(1000.0)
+    mm[10:14, 20:40] = np.nan
+    mm[50, :] = np.nan
+    om, omm = oracle.Image(w, h), oracle.Image.from_numpy(mm)
+    oracle.elementwise_scale_bias(om, omm, 1.0 / 1000.0, 0.0)
+    pyr = roo.Pyramid(w, h, 4)
+    gmm = T.upload_image(roo, mm)
+    roo.ElementwiseScaleBias(pyr[0], gmm, 1.0 / 1000.0)
+    assert T.nan_equal(pyr[0].MemcpyToHost(), om.data)
+    roo.ElementwiseScaleBias(gmm, gmm, 0.5, 3.0)  # in place, with a bias
+    exp = oracle.Image(w, h)
+    oracle.elementwise_scale_bias(exp, omm, 0.5, 3.0)
+    assert T.nan_equal(gmm.MemcpyToHost(), exp.data)
+    roo.BoxReduceIgnoreInvalid(pyr)
+    prev = om
+    for l in range(1, 4):
+        nxt = oracle.Image(w >> l, h >> l)
+        oracle.box_half_ignore_invalid(nxt, prev)
+        got = pyr[l].MemcpyToHost()
+        assert got.shape == (h >> l, w >> l) and T.nan_equal(got, nxt.data), l
+        prev = nxt
+    assert np.isnan(pyr[1].MemcpyToHost()[5:7, 10:20]).all()  # fully invalid 2x2 blocks stay invalid
