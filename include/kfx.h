@@ -25,10 +25,12 @@
  *  - Return value: 0 = ok; > 0 = hipError_t from the launch; < 0 = argument
  *    error (KFX_E_*).  Never exits the process: the roo:: wrappers map non-zero
  *    to the reference's print-and-exit(-1) convention (launch_utils.h:29-47).
- *  - Arithmetic is IEEE binary32, no FMA contraction, correctly rounded div and
- *    sqrt, in the reference's operation order ("exact" build): results are
- *    bit-identical to the CPU oracle for every op except the bilateral filter,
+ *  - Default arithmetic (KFX_MATH_EXACT) is IEEE binary32, no FMA contraction,
+ *    correctly rounded div and sqrt, in the reference's operation order: results
+ *    are bit-identical to the CPU oracle for every op except the bilateral filter,
  *    whose __expf is a hardware approximation as in the reference.
+ *    kfx_set_math_mode(KFX_MATH_FAST) switches kfx_sdf_fuse[_h] to hardware
+ *    rcp/rsq + FMA (the regime of the reference's own -use_fast_math build).
  */
 #ifndef KFX_H
 #define KFX_H
