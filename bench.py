@@ -2,7 +2,7 @@
 """bench.py -- KinectFusion frames/s (640x480 depth -> 512^3 TSDF) on MI355X, plus the SdfFuse
 HBM roofline and the CPU baseline.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--scene room|full] [--no-cpu-baseline]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--scene full|room] [--math fast|exact] [--no-cpu-baseline]
 
 A "step" is one frame of the headless KinectFusion loop on synthetic depth that is already
 resident in HBM: BilateralFilter -> DepthToVbo -> NormalsFromVbo -> SdfFuse -> RaycastSdf
@@ -34,7 +34,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--scene", default="room", choices=["room", "full"])
+    ap.add_argument("--scene", default="full", choices=["room", "full"],
+                    help="full (default) = S_full of SURVEY 8(d), the roofline scene: a wall behind the volume, ~98 %% of the "
+                         "voxels are updated every frame (the heaviest SdfFuse traffic); room = S_room, a furnished room "
+                         "(61 %% updated)")
     ap.add_argument("--math", default="fast", choices=["fast", "exact"],
                     help="numerics mode of SdfFuse: fast = rcp/rsq/FMA perf build (reference's own -use_fast_math regime, "
                          "tolerance-tested), exact = IEEE, bit-identical to the oracle")

@@ -88,6 +88,21 @@ int kfx_sdf_fuse(const kfx_volume* vol, const kfx_image* depth, const kfx_image*
                  const float T_cw[12], const float K[4], float trunc_dist, float max_w,
                  float mincostheta, unsigned flags, kfx_stream stream);
 
+/* Z-slab of a larger volume (multi-GPU partition): `vol` holds planes
+ * [z_offset, z_offset + vol->d) of a volume with `full_d` planes whose box spans [full_zmin, full_zmax]
+ * in z (x/y extents and box are those of `vol`).  Voxel positions are evaluated with the FULL volume's
+ * expression (BoundedVolume.h:115-125), so a slab is integrated bit-identically to the same planes of the
+ * monolithic volume.  Pass KFX_FUSE_FULL_EXTENT when vol->d is not a multiple of 8. */
+typedef struct kfx_slab {
+    size_t full_d;
+    size_t z_offset;
+    float  full_zmin;
+    float  full_zmax;
+} kfx_slab;
+int kfx_sdf_fuse_slab(const kfx_volume* vol, const kfx_slab* slab, const kfx_image* depth, const kfx_image* norm,
+                      const float T_cw[12], const float K[4], float trunc_dist, float max_w,
+                      float mincostheta, unsigned flags, kfx_stream stream);
+
 /* Diagnostics (no reference counterpart): number of voxels kfx_sdf_fuse would update for
  * this frame -- the same projection / lookup / predicate (cu_sdffusion.cu:22-44) evaluated
  * without touching the volume data.  *d_count is a DEVICE uint64 the caller zeroes; the count

@@ -23,6 +23,11 @@ class KfxVolume(C.Structure):
                 ("boxmin", C.c_float * 3), ("boxmax", C.c_float * 3)]
 
 
+class KfxSlab(C.Structure):
+    """kfx_slab (include/kfx.h): Z-slab of a larger volume."""
+    _fields_ = [("full_d", C.c_size_t), ("z_offset", C.c_size_t), ("full_zmin", C.c_float), ("full_zmax", C.c_float)]
+
+
 class KfxError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__("libkfx error %d: %s" % (code, msg))
@@ -34,6 +39,7 @@ PI, PV, PF = C.POINTER(KfxImage), C.POINTER(KfxVolume), C.POINTER(C.c_float)
 # name -> (restype, argtypes); every symbol include/kfx.h declares
 SIGNATURES = {
     "kfx_sdf_fuse": (C.c_int, [PV, PI, PI, PF, PF, C.c_float, C.c_float, C.c_float, C.c_uint, C.c_void_p]),
+    "kfx_sdf_fuse_slab": (C.c_int, [PV, C.POINTER(KfxSlab), PI, PI, PF, PF, C.c_float, C.c_float, C.c_float, C.c_uint, C.c_void_p]),
     "kfx_sdf_fuse_count": (C.c_int, [PV, PI, PI, PF, PF, C.c_float, C.c_float, C.c_uint, C.c_void_p, C.c_void_p]),
     "kfx_sdf_fuse_h": (C.c_int, [PV, PI, PI, PF, PF, C.c_float, C.c_float, C.c_float, C.c_uint, C.c_void_p]),
     "kfx_raycast_sdf_h": (C.c_int, [PI, PI, PI, PV, PF, PF, C.c_float, C.c_float, C.c_float, C.c_int, C.c_void_p]),

@@ -36,6 +36,7 @@ struct FuseParams {
     unsigned char* vptr;
     size_t vpitch, vimg_pitch;
     int X, Y, Z;            // extents to integrate (reference: (dim/8)*8, quirk Q1)
+    int zoff;               // global z index of local plane 0 (Z-slab of a larger volume, else 0)
     float w1, h1, d1;       // (float)(w-1), (float)(h-1), (float)(d-1)
     V3 bmin, size;          // bbox.Min(), bbox.Size()
     Pose T;                 // T_cw
@@ -289,7 +290,7 @@ __global__ __launch_bounds__(256) void k_sdf_fuse(const FuseParams p)
     const int zbeg = blockIdx.z * FUSE_ZC;
     const int zend = min(zbeg + FUSE_ZC, p.Z);
     if (threadIdx.x < FUSE_ZC) // VoxelPositionInUnits z, once per slice
-        s_pz[threadIdx.x] = p.bmin.z + p.size.z * (float)(zbeg + (int)threadIdx.x) / p.d1;
+        s_pz[threadIdx.x] = p.bmin.z + p.size.z * (float)(zbeg + (int)threadIdx.x + p.zoff) / p.d1;
     __syncthreads();
     if (x0 >= p.X || y >= p.Y) return;
 
@@ -347,7 +348,7 @@ __global__ __launch_bounds__(256) void k_sdf_fuse_tiled(const FuseParams p, cons
     const int zbeg = blockIdx.z * FUSE_ZC;
     const int zend = min(zbeg + FUSE_ZC, p.Z);
     const bool live = x0 < p.X && y < p.Y;
-    if (tid < FUSE_ZC) s_pz[tid] = p.bmin.z + p.size.z * (float)(zbeg + tid) / p.d1;
+    if (tid < FUSE_ZC) s_pz[tid] = p.bmin.z + p.size.z * (float)(zbeg + tid + p.zoff) / p.d1;
     __syncthreads();
 
     const float py = p.bmin.y + p.size.y * (float)y / p.h1;
@@ -502,7 +503,7 @@ __global__ __launch_bounds__(256) void k_sdf_fuse_count(const FuseParams p, unsi
     const bool live = x < p.X && y < p.Y;
     const int zbeg = blockIdx.z * FUSE_ZC;
     const int zend = min(zbeg + FUSE_ZC, p.Z);
-    if (threadIdx.x < FUSE_ZC) s_pz[threadIdx.x] = p.bmin.z + p.size.z * (float)(zbeg + (int)threadIdx.x) / p.d1;
+    if (threadIdx.x < FUSE_ZC) s_pz[threadIdx.x] = p.bmin.z + p.size.z * (float)(zbeg + (int)threadIdx.x + p.zoff) / p.d1;
     __syncthreads();
     CamXY<FAST> cam;
     cam.init(p, p.bmin.x + p.size.x * (float)x / p.w1, p.bmin.y + p.size.y * (float)y / p.h1);
@@ -587,7 +588,7 @@ static VolView vol_view(const kfx_volume* vol)
 // Fills the kernel parameters; *small_images tells whether the 32-bit image offsets are usable.
 static int fuse_params(FuseParams& p, bool* small_images, const kfx_volume* vol, const kfx_image* depth,
                        const kfx_image* norm, const float T_cw[12], const float K[4], float trunc_dist, float max_w,
-                       float mincostheta, unsigned flags, size_t cell = 8)
+                       float mincostheta, unsigned flags, size_t cell = 8, const kfx_slab* slab = nullptr)
 {
     if (int e = check_volume(vol, cell)) return e;
     if (!depth || !norm || !depth->ptr || !norm->ptr || !T_cw || !K) return set_error(KFX_E_NULL, "SdfFuse: null argument");
@@ -606,8 +607,19 @@ static int fuse_params(FuseParams& p, bool* small_images, const kfx_volume* vol,
     p.w1 = (float)(vol->w - 1);
     p.h1 = (float)(vol->h - 1);
     p.d1 = (float)(vol->d - 1);
+    p.zoff = 0;
     p.bmin = V3{vol->boxmin[0], vol->boxmin[1], vol->boxmin[2]};
     p.size = V3{vol->boxmax[0] - vol->boxmin[0], vol->boxmax[1] - vol->boxmin[1], vol->boxmax[2] - vol->boxmin[2]};
+    if (slab) {
+        // the local volume is planes [z_offset, z_offset + d) of a volume with full_d planes spanning
+        // [full_zmin, full_zmax]: voxel positions are computed with the FULL volume's expression, so a
+        // slab integrates bit-identically to the same planes of the monolithic volume
+        if (slab->full_d < 2 || slab->z_offset + vol->d > slab->full_d) return set_error(KFX_E_SHAPE, "SdfFuse: slab outside the full volume");
+        p.d1 = (float)(slab->full_d - 1);
+        p.zoff = (int)slab->z_offset;
+        p.bmin.z = slab->full_zmin;
+        p.size.z = slab->full_zmax - slab->full_zmin;
+    }
     for (int i = 0; i < 12; ++i) p.T.m[i] = T_cw[i];
     p.K = Intr{K[0], K[1], K[2], K[3]};
     p.depth = ImgView{(const unsigned char*)depth->ptr, depth->pitch, (int)depth->w, (int)depth->h};
@@ -627,11 +639,12 @@ static int fuse_params(FuseParams& p, bool* small_images, const kfx_volume* vol,
 
 template <typename CELL>
 static int fuse_launch(const kfx_volume* vol, const kfx_image* depth, const kfx_image* norm, const float T_cw[12],
-                       const float K[4], float trunc_dist, float max_w, float mincostheta, unsigned flags, kfx_stream stream)
+                       const float K[4], float trunc_dist, float max_w, float mincostheta, unsigned flags, kfx_stream stream,
+                       const kfx_slab* slab = nullptr)
 {
     FuseParams p;
     bool small_images = false;
-    if (int e = fuse_params(p, &small_images, vol, depth, norm, T_cw, K, trunc_dist, max_w, mincostheta, flags, CELL::BYTES)) return e;
+    if (int e = fuse_params(p, &small_images, vol, depth, norm, T_cw, K, trunc_dist, max_w, mincostheta, flags, CELL::BYTES, slab)) return e;
     if (p.X == 0 || p.Y == 0 || p.Z == 0) return 0; // reference launches an empty grid
     // two cells per lane need an even extent and a pointer / pitches aligned to the cell pair
     const bool vec2 = (p.X % 2 == 0) && ((((uintptr_t)vol->ptr | vol->pitch | vol->img_pitch) & (2 * CELL::BYTES - 1)) == 0);
@@ -672,6 +685,14 @@ extern "C" int kfx_sdf_fuse(const kfx_volume* vol, const kfx_image* depth, const
                             float mincostheta, unsigned flags, kfx_stream stream)
 {
     return fuse_launch<CellF32>(vol, depth, norm, T_cw, K, trunc_dist, max_w, mincostheta, flags, stream);
+}
+
+extern "C" int kfx_sdf_fuse_slab(const kfx_volume* vol, const kfx_slab* slab, const kfx_image* depth, const kfx_image* norm,
+                                 const float T_cw[12], const float K[4], float trunc_dist, float max_w,
+                                 float mincostheta, unsigned flags, kfx_stream stream)
+{
+    if (!slab) return set_error(KFX_E_NULL, "kfx_sdf_fuse_slab: null slab");
+    return fuse_launch<CellF32>(vol, depth, norm, T_cw, K, trunc_dist, max_w, mincostheta, flags, stream, slab);
 }
 
 extern "C" int kfx_sdf_fuse_h(const kfx_volume* vol, const kfx_image* depth, const kfx_image* norm,

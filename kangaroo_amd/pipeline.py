@@ -124,12 +124,16 @@ class SlabPipeline(FramePipeline):
 
     def fuse(self, T_wc):
         # views may have a plane count that is not a multiple of 8: integrate all of it (full_extent)
+        D = self.dims[2]
+        zmin, zmax = float(self.full_boxmin[2]), float(self.full_boxmax[2])
         if self.halo == "recompute" or self.world == 1:
-            target = self.vol
+            target, first = self.vol, self.s0
         else:
-            target = self.vol.ZSlab(self.z0 - self.s0, self.z1 - self.s0)  # owned planes only
+            target, first = self.vol.ZSlab(self.z0 - self.s0, self.z1 - self.s0), self.z0  # owned planes only
+        # slab entry point: voxel positions by the FULL volume's expression, so every plane is integrated
+        # bit-identically to the same plane of a single-GPU volume
         self.ops.SdfFuse(target, self.filtered, self.normals, scenes.se3_inverse(T_wc), self.K, self.trunc,
-                         self.max_w, self.mincostheta, full_extent=True)
+                         self.max_w, self.mincostheta, full_extent=True, slab=(D, first, zmin, zmax))
         if target is not self.vol:
             self.exchange_halos()
 

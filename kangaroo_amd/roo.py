@@ -234,10 +234,18 @@ def get_math_mode():
 
 # ---- operators ------------------------------------------------------------------
 
-def SdfFuse(vol, depth, norm, T_cw, K, trunc_dist, maxw, mincostheta, full_extent=False, stream=None):
-    """roo::SdfFuse (cu_sdffusion.h:13-14)."""
+def SdfFuse(vol, depth, norm, T_cw, K, trunc_dist, maxw, mincostheta, full_extent=False, stream=None, slab=None):
+    """roo::SdfFuse (cu_sdffusion.h:13-14).  slab = (full_d, z_offset, full_zmin, full_zmax) integrates `vol`
+    as planes [z_offset, z_offset + d) of a larger volume (kfx_sdf_fuse_slab), bit-identically to the same
+    planes of the monolithic volume."""
     t, _t = _fp(T_cw, 12)
     k, _k = _fp(K, 4)
+    if slab is not None:
+        assert vol.kind == "f32"
+        sl = _lib.KfxSlab(int(slab[0]), int(slab[1]), float(slab[2]), float(slab[3]))
+        _lib.check(_lib.load().kfx_sdf_fuse_slab(vol.ref(), C.byref(sl), depth.ref(), norm.ref(), t, k, trunc_dist, maxw,
+                                                 mincostheta, 1 if full_extent else 0, _stream(stream)))
+        return
     fn = _lib.load().kfx_sdf_fuse_h if vol.kind == "f16" else _lib.load().kfx_sdf_fuse
     _lib.check(fn(vol.ref(), depth.ref(), norm.ref(), t, k, trunc_dist, maxw, mincostheta,
                   1 if full_extent else 0, _stream(stream)))

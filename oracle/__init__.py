@@ -25,6 +25,10 @@ class KfoVolume(C.Structure):
                 ("boxmin", C.c_float * 3), ("boxmax", C.c_float * 3)]
 
 
+class KfoSlab(C.Structure):
+    _fields_ = [("full_d", C.c_size_t), ("z_offset", C.c_size_t), ("full_zmin", C.c_float), ("full_zmax", C.c_float)]
+
+
 class KfoRaycastStats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("steps", C.c_uint64), ("hits", C.c_uint64)]
 
@@ -63,6 +67,8 @@ def lib():
         L.kfo_fit_to_frustum.argtypes = [PF, PF, PF, C.c_float, C.c_float, PF, C.c_float, C.c_float]
         L.kfo_sub_bounding_volume.argtypes = [PV, PV, PF, PF]
         L.kfo_se3_inverse.argtypes = [PF, PF]
+        L.kfo_sdf_fuse_slab.argtypes = [PV, C.POINTER(KfoSlab), PI, PI, PF, PF, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int]
+        L.kfo_sdf_fuse_slab.restype = C.c_uint64
         L.kfo_sdf_fuse_h.argtypes = L.kfo_sdf_fuse.argtypes
         L.kfo_sdf_fuse_h.restype = C.c_uint64
         L.kfo_raycast_sdf_h.argtypes = L.kfo_raycast_sdf.argtypes
@@ -250,9 +256,14 @@ def sdf_sphere(vol, center, r):
     (lib().kfo_sdf_sphere_h if _is_half(vol) else lib().kfo_sdf_sphere)(vol.ref(), c, r)
 
 
-def sdf_fuse(vol, depth, norm, T_cw, K, trunc, max_w, mincostheta, full_extent=False, nthreads=1):
+def sdf_fuse(vol, depth, norm, T_cw, K, trunc, max_w, mincostheta, full_extent=False, nthreads=1, slab=None):
+    """slab = (full_d, z_offset, full_zmin, full_zmax): integrate `vol` as a Z-slab of a larger volume."""
     _, t = _fp(T_cw)
     _, k = _fp(K)
+    if slab is not None:
+        sl = KfoSlab(int(slab[0]), int(slab[1]), float(slab[2]), float(slab[3]))
+        return int(lib().kfo_sdf_fuse_slab(vol.ref(), C.byref(sl), depth.ref(), norm.ref(), t, k, trunc, max_w, mincostheta,
+                                           1 if full_extent else 0, nthreads))
     fn = lib().kfo_sdf_fuse_h if _is_half(vol) else lib().kfo_sdf_fuse
     return int(fn(vol.ref(), depth.ref(), norm.ref(), t, k, trunc, max_w, mincostheta, 1 if full_extent else 0, nthreads))
 

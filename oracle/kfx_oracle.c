@@ -293,9 +293,11 @@ void kfo_sdf_sphere(const kfo_volume* vol, const float center[3], float r)
  * ========================================================================== */
 static inline int fuse_voxel(const kfo_volume* vol, const kfo_image* depth, const kfo_image* normals,
                              const float* T, const float* K, float trunc_dist, float max_w,
-                             float mincostheta, int x, int y, int z, int half)
+                             float mincostheta, int x, int y, int z, int half, const kfo_slab* slab)
 {
-    const f3 P_w = voxel_position(vol, x, y, z);         /* :22 */
+    f3 P_w = voxel_position(vol, x, y, z);               /* :22 */
+    if (slab) /* Z-slab of a larger volume: z position by the FULL volume's expression (BoundedVolume.h:115-125) */
+        P_w.z = slab->full_zmin + (slab->full_zmax - slab->full_zmin) * (float)(z + (int)slab->z_offset) / (float)(slab->full_d - 1);
     const f3 P_c = se3_mul(T, P_w);                       /* :23 */
     /* K.Project, ImageIntrinsics.h:87-91 */
     const float pu = U0 + FU * P_c.x / P_c.z;
@@ -358,7 +360,7 @@ static inline int fuse_voxel(const kfo_volume* vol, const kfo_image* depth, cons
 
 static uint64_t sdf_fuse_any(const kfo_volume* vol, const kfo_image* depth, const kfo_image* norm,
                              const float T_cw[12], const float K[4], float trunc, float max_w,
-                             float mincostheta, int full_extent, int nthreads, int half)
+                             float mincostheta, int full_extent, int nthreads, int half, const kfo_slab* slab)
 {
     /* gridDim = (w/8, h/8, d/8), blockDim = (8,8,8): integer division, no tail (quirk Q1) */
     const int X = full_extent ? (int)vol->w : (int)(vol->w / 8) * 8;
@@ -371,7 +373,7 @@ static uint64_t sdf_fuse_any(const kfo_volume* vol, const kfo_image* depth, cons
     for (int z = 0; z < Z; ++z)
         for (int y = 0; y < Y; ++y)
             for (int x = 0; x < X; ++x)
-                updated += (uint64_t)fuse_voxel(vol, depth, norm, T_cw, K, trunc, max_w, mincostheta, x, y, z, half);
+                updated += (uint64_t)fuse_voxel(vol, depth, norm, T_cw, K, trunc, max_w, mincostheta, x, y, z, half, slab);
     return updated;
 }
 
@@ -379,13 +381,19 @@ uint64_t kfo_sdf_fuse(const kfo_volume* vol, const kfo_image* depth, const kfo_i
                       const float T_cw[12], const float K[4], float trunc, float max_w,
                       float mincostheta, int full_extent, int nthreads)
 {
-    return sdf_fuse_any(vol, depth, norm, T_cw, K, trunc, max_w, mincostheta, full_extent, nthreads, 0);
+    return sdf_fuse_any(vol, depth, norm, T_cw, K, trunc, max_w, mincostheta, full_extent, nthreads, 0, NULL);
+}
+uint64_t kfo_sdf_fuse_slab(const kfo_volume* vol, const kfo_slab* slab, const kfo_image* depth, const kfo_image* norm,
+                           const float T_cw[12], const float K[4], float trunc, float max_w,
+                           float mincostheta, int full_extent, int nthreads)
+{
+    return sdf_fuse_any(vol, depth, norm, T_cw, K, trunc, max_w, mincostheta, full_extent, nthreads, 0, slab);
 }
 uint64_t kfo_sdf_fuse_h(const kfo_volume* vol, const kfo_image* depth, const kfo_image* norm,
                         const float T_cw[12], const float K[4], float trunc, float max_w,
                         float mincostheta, int full_extent, int nthreads)
 {
-    return sdf_fuse_any(vol, depth, norm, T_cw, K, trunc, max_w, mincostheta, full_extent, nthreads, 1);
+    return sdf_fuse_any(vol, depth, norm, T_cw, K, trunc, max_w, mincostheta, full_extent, nthreads, 1, NULL);
 }
 
 /* ============================================================================

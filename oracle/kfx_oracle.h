@@ -79,6 +79,17 @@ void kfo_sdf_sphere(const kfo_volume* vol, const float center[3], float r);
 uint64_t kfo_sdf_fuse(const kfo_volume* vol, const kfo_image* depth, const kfo_image* norm,
                       const float T_cw[12], const float K[4], float trunc, float max_w,
                       float mincostheta, int full_extent, int nthreads);
+/* Z-slab of a larger volume (multi-GPU partition): `vol` holds planes [z_offset, z_offset + d) of a volume
+ * with full_d planes spanning [full_zmin, full_zmax]; z positions use the full volume's expression. */
+typedef struct kfo_slab {
+    size_t full_d;
+    size_t z_offset;
+    float  full_zmin;
+    float  full_zmax;
+} kfo_slab;
+uint64_t kfo_sdf_fuse_slab(const kfo_volume* vol, const kfo_slab* slab, const kfo_image* depth, const kfo_image* norm,
+                           const float T_cw[12], const float K[4], float trunc, float max_w,
+                           float mincostheta, int full_extent, int nthreads);
 /* cu_raycast.cu:14-113 */
 void kfo_raycast_sdf(const kfo_image* depth, const kfo_image* norm, const kfo_image* img,
                      const kfo_volume* vol, const float T_wc[12], const float K[4],

@@ -78,8 +78,8 @@ def NormalsFromVbo(n, v):
     oracle.normals_from_vbo(n, v)
 
 
-def SdfFuse(vol, depth, norm, T_cw, K, trunc, maxw, mincostheta, full_extent=False):
-    oracle.sdf_fuse(vol, depth, norm, T_cw, K, trunc, maxw, mincostheta, full_extent=full_extent)
+def SdfFuse(vol, depth, norm, T_cw, K, trunc, maxw, mincostheta, full_extent=False, slab=None):
+    oracle.sdf_fuse(vol, depth, norm, T_cw, K, trunc, maxw, mincostheta, full_extent=full_extent, slab=slab)
 
 
 def RaycastSdf(depth, norm, img, vol, T_wc, K, near, far, trunc, subpix=True):

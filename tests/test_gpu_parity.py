@@ -404,15 +404,20 @@ def test_gpu_full_size_properties(roo):
             assert 0.97 * N ** 3 < updated < 0.995 * N ** 3
         else:
             assert 0.3 * N ** 3 < updated < 0.9 * N ** 3
-        # (1) slabs
+        # (1) slabs: through the slab entry point (voxel positions by the full volume's expression) the
+        #     decomposition is BIT-IDENTICAL to the monolithic fuse
         vol2 = roo.BoundedVolume(N, N, N, bmin, bmax)
         roo.SdfReset(vol2, float("nan"))
         for z0 in range(0, N, 64):
-            roo.SdfFuse(vol2.ZSlab(z0, z0 + 64), f, nrm, Tid, K, tr, scenes.MAX_W, scenes.MIN_COS_THETA)
+            roo.SdfFuse(vol2.ZSlab(z0, z0 + 64), f, nrm, Tid, K, tr, scenes.MAX_W, scenes.MIN_COS_THETA,
+                        slab=(N, z0, bmin[2], bmax[2]))
         b = vol2.tensor()
-        # slab bboxes are recomputed from voxel positions (as SubBoundingVolume does), so voxel
-        # positions can differ in the last ulp: identical classification almost everywhere, and
-        # values within 1e-4 (depth edges amplify a 1-ulp position change) where both sides were updated
+        assert bool(((a == b) | (torch.isnan(a) & torch.isnan(b))).all())
+        # ... while plain sub-volume views (bbox recomputed from voxel positions, as SubBoundingVolume does)
+        # differ by a 1-ulp position change: same classification almost everywhere, values within 1e-4
+        roo.SdfReset(vol2, float("nan"))
+        for z0 in range(0, N, 64):
+            roo.SdfFuse(vol2.ZSlab(z0, z0 + 64), f, nrm, Tid, K, tr, scenes.MAX_W, scenes.MIN_COS_THETA)
         same_class = (torch.isnan(a[..., 0]) == torch.isnan(b[..., 0])).float().mean().item()
         assert same_class > 0.9999
         both = ~torch.isnan(a[..., 0]) & ~torch.isnan(b[..., 0])
