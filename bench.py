@@ -94,11 +94,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (the product path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
+    ndev = torch.cuda.device_count()
+    dev = local_rank % max(ndev, 1)
+    torch.cuda.set_device(dev)
     distributed = world > 1
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # RCCL needs one GPU per rank; KFX_BENCH_BACKEND=gloo lets several ranks share a GPU to smoke-test the
+        # distributed code path on a 1-GPU box (never used for reported numbers)
+        backend = os.environ.get("KFX_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group(backend)
     n_gpus = world if distributed else 1
 
     from kangaroo_amd import roo, scenes
@@ -216,6 +224,7 @@ def main():
                             "-> DepthToVbo -> NormalsFromVbo -> SdfFuse -> RaycastSdf" % (
                                 N, 8.0 * N ** 3 / 2 ** 30, w, h, scene, N_ORBIT),
                 "volume": [N, N, N], "image": [w, h], "scene": scene,
+                "backend": os.environ.get("KFX_BENCH_BACKEND", "nccl (RCCL)") if distributed else None,
                 "partition": ("z-slabs x%d, ghost planes %s, raycast composite = all_reduce(MIN key) + all_reduce(SUM payload)" % (n_gpus, args.halo))
                              if distributed else "single volume",
                 "math": {"fast": "fast (fp32 rcp/rsq + FMA: the reference's own -use_fast_math regime; TSDF within 1e-4 of the exact path, "
