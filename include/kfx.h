@@ -188,6 +188,18 @@ int kfx_memcpy_2d(void* dst, size_t dpitch, const void* src, size_t spitch, size
                   size_t rows, int kind, kfx_stream stream);
 int kfx_stream_synchronize(kfx_stream stream);
 
+/* ---- multi-GPU raycast composite (no reference counterpart) ------------------------
+ * Per-pixel glue around the two collectives of kangaroo_amd/pipeline.py::SlabPipeline.composite:
+ *   pack:   key[v*w+u] = (bits(depth or +inf) << 8) | rank                    then all_reduce(MIN, key)
+ *   select: payload[(v*w+u)*5 ..] = this rank won ? {n.x,n.y,n.z,n.w, shade} : 0   then all_reduce(SUM, payload)
+ *   unpack: depth = key's depth (NaN if no rank hit), norm / img = payload
+ * key (w*h int64) and payload (w*h*5 float) are dense device buffers owned by the caller. */
+int kfx_composite_pack(const kfx_image* depth, const kfx_image* norm, const kfx_image* img, long long* key, int rank, kfx_stream stream);
+int kfx_composite_select(const kfx_image* depth, const kfx_image* norm, const kfx_image* img, const long long* key,
+                         float* payload, int rank, kfx_stream stream);
+int kfx_composite_unpack(const kfx_image* depth, const kfx_image* norm, const kfx_image* img, const long long* key,
+                         const float* payload, kfx_stream stream);
+
 /* ---- numerics mode --------------------------------------------------------------- */
 /* KFX_MATH_EXACT (default): IEEE fp32, no FMA contraction, correctly rounded div/sqrt, reference
  * operation order -- bit-identical to the CPU oracle.  KFX_MATH_FAST: hardware rcp/rsq (1 ulp),

@@ -164,9 +164,22 @@ class SlabPipeline(FramePipeline):
     def composite(self):
         """Nearest hit over all slabs.  key = depth bits (positive floats order like ints) in the
         high word, rank in the low byte; misses use +inf.  One MIN all-reduce picks the winner,
-        one SUM all-reduce broadcasts its depth / normal / shade."""
+        one SUM all-reduce broadcasts its normal / shade (the depth travels in the key).  With the HIP
+        operator set the per-pixel glue is three fused kernels; operator sets without them (the
+        oracle-backed CPU stand-in of the tests) use the equivalent tensor expressions below."""
         import torch
         dist = self.dist
+        if hasattr(self.ops, "CompositePack"):
+            dev = self.ray_d.storage.device
+            if getattr(self, "_key", None) is None:
+                self._key = torch.empty(self.w * self.h, dtype=torch.int64, device=dev)
+                self._payload = torch.empty(self.w * self.h * 5, dtype=torch.float32, device=dev)
+            self.ops.CompositePack(self.ray_d, self.ray_n, self.ray_i, self._key, self.rank)
+            dist.all_reduce(self._key, op=dist.ReduceOp.MIN)
+            self.ops.CompositeSelect(self.ray_d, self.ray_n, self.ray_i, self._key, self._payload, self.rank)
+            dist.all_reduce(self._payload, op=dist.ReduceOp.SUM)
+            self.ops.CompositeUnpack(self.ray_d, self.ray_n, self.ray_i, self._key, self._payload)
+            return
         d = self.ray_d.tensor()
         n = self.ray_n.tensor()
         i = self.ray_i.tensor()
@@ -175,12 +188,12 @@ class SlabPipeline(FramePipeline):
         key = (bits << 8) | self.rank
         dist.all_reduce(key, op=dist.ReduceOp.MIN)
         mine = hit & ((key & 0xFF) == self.rank) & ((key >> 8) == bits)
-        payload = torch.zeros((self.h, self.w, 6), dtype=torch.float32, device=d.device)
-        payload[..., 0] = torch.where(mine, d, torch.zeros_like(d))
-        payload[..., 1:5] = torch.where(mine.unsqueeze(-1), n, torch.zeros_like(n))
-        payload[..., 5] = torch.where(mine, i, torch.zeros_like(i))
+        payload = torch.zeros((self.h, self.w, 5), dtype=torch.float32, device=d.device)
+        payload[..., 0:4] = torch.where(mine.unsqueeze(-1), n, torch.zeros_like(n))
+        payload[..., 4] = torch.where(mine, i, torch.zeros_like(i))
         dist.all_reduce(payload, op=dist.ReduceOp.SUM)
-        any_hit = (key >> 8) < 0x7F800000
-        d.copy_(torch.where(any_hit, payload[..., 0], torch.full_like(d, float("nan"))))
-        n.copy_(payload[..., 1:5])
-        i.copy_(payload[..., 5])
+        win_bits = (key >> 8).to(torch.int32)
+        any_hit = win_bits < 0x7F800000
+        d.copy_(torch.where(any_hit, win_bits.view(torch.float32), torch.full_like(d, float("nan"))))
+        n.copy_(payload[..., 0:4])
+        i.copy_(payload[..., 4])

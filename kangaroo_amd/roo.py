@@ -342,3 +342,20 @@ def BoxReduceIgnoreInvalid(pyramid, stream=None):
     """roo::BoxReduceIgnoreInvalid<T,Levels,UpType> (reduce.h:48-59): fill levels 1.. from level 0."""
     for l in range(1, len(pyramid)):
         BoxHalfIgnoreInvalid(pyramid[l], pyramid[l - 1], stream)
+
+
+def CompositePack(depth, norm, img, key, rank, stream=None):
+    """kfx_composite_pack: key (int64 tensor, w*h) = (depth bits << 8) | rank, +inf for misses."""
+    _lib.check(_lib.load().kfx_composite_pack(depth.ref(), norm.ref(), img.ref(), C.c_void_p(key.data_ptr()), rank, _stream(stream)))
+
+
+def CompositeSelect(depth, norm, img, key, payload, rank, stream=None):
+    """kfx_composite_select: payload (float32 tensor, w*h*5) = winner's {normal, shade}, zero elsewhere."""
+    _lib.check(_lib.load().kfx_composite_select(depth.ref(), norm.ref(), img.ref(), C.c_void_p(key.data_ptr()),
+                                                C.c_void_p(payload.data_ptr()), rank, _stream(stream)))
+
+
+def CompositeUnpack(depth, norm, img, key, payload, stream=None):
+    """kfx_composite_unpack: write the merged depth / normal / shade images."""
+    _lib.check(_lib.load().kfx_composite_unpack(depth.ref(), norm.ref(), img.ref(), C.c_void_p(key.data_ptr()),
+                                                C.c_void_p(payload.data_ptr()), _stream(stream)))

@@ -581,3 +581,58 @@ def test_gpu_scale_bias_and_pyramid(roo):
         assert got.shape == (h >> l, w >> l) and T.nan_equal(got, nxt.data), l
         prev = nxt
     assert np.isnan(pyr[1].MemcpyToHost()[5:7, 10:20]).all()  # fully invalid 2x2 blocks stay invalid
+
+
+def test_gpu_composite_kernels_match_tensor_expressions(roo):
+    """The fused pack / select / unpack kernels of the multi-GPU raycast composite, with the two
+    all-reduces emulated on one GPU (elementwise min / sum over two 'ranks'), against the plain tensor
+    expressions SlabPipeline.composite falls back to -- and against a single-volume raycast."""
+    import torch
+    N, w, h = 64, 160, 120
+    ovol = T.make_volume(N, "room")
+    K, tr, fr = T.fuse_frames_oracle(ovol, "room", w, h, 2)
+    vol = T.upload_volume(roo, ovol)
+    bmin, bmax, near, far = scenes.SCENES["room"]
+    T_wc = fr[-1]["T_wc"]
+    ranks = []
+    for (z0, z1) in ((0, 34), (30, 64)):  # two overlapping slabs
+        rd, rn, ri = roo.Image(w, h, pitch=w * 4), roo.Image(w, h, "f32x4", pitch=w * 16), roo.Image(w, h, pitch=w * 4)
+        roo.RaycastSdf(rd, rn, ri, vol.ZSlab(z0, z1), T_wc, K, near, far, tr, True)
+        ranks.append((rd, rn, ri))
+    # tensor-expression reference (what pipeline.composite does without the fused kernels)
+    keys, bits_l = [], []
+    for r, (rd, rn, ri) in enumerate(ranks):
+        d = rd.tensor()
+        hit = torch.isfinite(d)
+        bits = torch.where(hit, d, torch.full_like(d, float("inf"))).contiguous().view(torch.int32).to(torch.int64)
+        keys.append((bits << 8) | r)
+        bits_l.append((hit, bits))
+    key_ref = torch.minimum(keys[0], keys[1])
+    pay_ref = torch.zeros((h, w, 5), device=key_ref.device)
+    for r, (rd, rn, ri) in enumerate(ranks):
+        hit, bits = bits_l[r]
+        mine = hit & ((key_ref & 0xFF) == r) & ((key_ref >> 8) == bits)
+        pay_ref[..., 0:4] += torch.where(mine.unsqueeze(-1), rn.tensor(), torch.zeros_like(rn.tensor()))
+        pay_ref[..., 4] += torch.where(mine, ri.tensor(), torch.zeros_like(ri.tensor()))
+    # fused kernels
+    kbuf = [torch.empty(w * h, dtype=torch.int64, device="cuda") for _ in ranks]
+    for r, (rd, rn, ri) in enumerate(ranks):
+        roo.CompositePack(rd, rn, ri, kbuf[r], r)
+    key = torch.minimum(kbuf[0], kbuf[1])
+    assert torch.equal(key.view(h, w), key_ref)
+    pbuf = [torch.empty(w * h * 5, dtype=torch.float32, device="cuda") for _ in ranks]
+    for r, (rd, rn, ri) in enumerate(ranks):
+        roo.CompositeSelect(rd, rn, ri, key, pbuf[r], r)
+    pay = pbuf[0] + pbuf[1]
+    assert torch.equal(pay.view(h, w, 5), pay_ref)
+    rd, rn, ri = ranks[0]
+    roo.CompositeUnpack(rd, rn, ri, key, pay)
+    d = rd.MemcpyToHost()
+    # merged image vs the single-volume raycast: same hits up to boundary pixels, depth within a fraction of a voxel
+    od, on, oi = oracle.Image(w, h), oracle.Image(w, h, channels=4), oracle.Image(w, h)
+    oracle.raycast_sdf(od, on, oi, ovol, T_wc, K, near, far, tr, True)
+    both = np.isfinite(d) & np.isfinite(od.data)
+    assert (np.isfinite(d) != np.isfinite(od.data)).mean() < 0.01
+    assert np.median(np.abs(d[both] - od.data[both])) < 0.05 * (bmax[0] - bmin[0]) / (N - 1)
+    n = rn.MemcpyToHost()
+    assert (n[~np.isfinite(d)] == 0).all() and (n[np.isfinite(d)][:, 3] == 1).all()
