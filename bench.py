@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--res", type=int, default=512, help="volume resolution N (N^3 voxels)")
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
+    ap.add_argument("--raycast", default="composite", choices=["composite", "exact"],
+                    help="multi-GPU raycast: per-slab march + nearest-hit composite, or the bit-exact march-state hand-over")
     ap.add_argument("--halo", default="recompute", choices=["recompute", "exchange"],
                     help="N > 1: how ghost planes are kept current -- recomputed by each rank (no traffic) or "
                          "exchanged with the neighbours over RCCL point-to-point after each SdfFuse")
@@ -118,7 +120,7 @@ def main():
     bmin, bmax, near, far = scenes.SCENES[scene]
     K = scenes.intrinsics(w, h)
     if distributed:
-        pipe = SlabPipeline(roo, dist, (N, N, N), bmin, bmax, w, h, halo=args.halo, K=K, near=near, far=far)
+        pipe = SlabPipeline(roo, dist, (N, N, N), bmin, bmax, w, h, halo=args.halo, raycast=args.raycast, K=K, near=near, far=far)
     else:
         pipe = FramePipeline(roo, (N, N, N), bmin, bmax, w, h, K=K, near=near, far=far)
 
@@ -225,7 +227,7 @@ def main():
                                 N, 8.0 * N ** 3 / 2 ** 30, w, h, scene, N_ORBIT),
                 "volume": [N, N, N], "image": [w, h], "scene": scene,
                 "backend": os.environ.get("KFX_BENCH_BACKEND", "nccl (RCCL)") if distributed else None,
-                "partition": ("z-slabs x%d, ghost planes %s, raycast composite = all_reduce(MIN key) + all_reduce(SUM payload)" % (n_gpus, args.halo))
+                "partition": ("z-slabs x%d, ghost planes %s, raycast %s" % (n_gpus, args.halo, "composite = all_reduce(MIN key) + all_reduce(SUM payload)" if args.raycast == "composite" else "exact = march state handed from slab to slab, one SUM all_reduce per round"))
                              if distributed else "single volume",
                 "math": {"fast": "fast (fp32 rcp/rsq + FMA: the reference's own -use_fast_math regime; TSDF within 1e-4 of the exact path, "
                                  "tests/test_gpu_parity.py::test_gpu_fast_mode_within_tolerance)",

@@ -200,6 +200,21 @@ int kfx_composite_select(const kfx_image* depth, const kfx_image* norm, const kf
 int kfx_composite_unpack(const kfx_image* depth, const kfx_image* norm, const kfx_image* img, const long long* key,
                          const float* payload, kfx_stream stream);
 
+/* Exact multi-GPU march ("exact variant").  One round of one rank: rays whose current sample
+ * falls into a trilinear base cell this rank owns, [own_lo, own_hi) (global plane indices), are advanced until
+ * they hit, leave the volume, or step into another rank's cells; lambda / last_sdf / delta travel in `state`
+ * (KFX_RAY_STATE_PLANES dense planes of h*w floats: 0 lambda, 1 last_sdf, 2 delta, 3 status {0 marching, 1 hit,
+ * 2 miss, 3 hit awaiting its normal}, 4 touched in this call, 5-7 normal, 8 shade; a hit's depth is its lambda).  `vol` holds planes [slab->z_offset, slab->z_offset + vol->d) of the
+ * full volume described by `slab`.  Every sample is taken at the position and from the cells of the
+ * single-volume march (cu_raycast.cu:58-81), so the final images are bit-identical to kfx_raycast_sdf on the
+ * whole volume.  The host merges the per-rank states between rounds (kangaroo_amd/pipeline.py). */
+#define KFX_RAY_STATE_PLANES 9
+int kfx_raycast_sdf_slab(float* state, int init, const kfx_volume* vol, const kfx_slab* slab, int own_lo, int own_hi,
+                         int w, int h, const float T_wc[12], const float K[4], float near, float far,
+                         float trunc_dist, int subpix, kfx_stream stream);
+int kfx_raycast_state_to_images(const kfx_image* depth, const kfx_image* norm, const kfx_image* img, const float* state,
+                                kfx_stream stream);
+
 /* ---- numerics mode --------------------------------------------------------------- */
 /* KFX_MATH_EXACT (default): IEEE fp32, no FMA contraction, correctly rounded div/sqrt, reference
  * operation order -- bit-identical to the CPU oracle.  KFX_MATH_FAST: hardware rcp/rsq (1 ulp),

@@ -56,6 +56,9 @@ SIGNATURES = {
     "kfx_box_half_ignore_invalid_f32": (C.c_int, [PI, PI, C.c_void_p]),
     "kfx_sdf_reset": (C.c_int, [PV, C.c_float, C.c_void_p]),
     "kfx_sdf_sphere": (C.c_int, [PV, PF, C.c_float, C.c_void_p]),
+    "kfx_raycast_sdf_slab": (C.c_int, [C.c_void_p, C.c_int, PV, C.POINTER(KfxSlab), C.c_int, C.c_int, C.c_int, C.c_int, PF, PF,
+                                       C.c_float, C.c_float, C.c_float, C.c_int, C.c_void_p]),
+    "kfx_raycast_state_to_images": (C.c_int, [PI, PI, PI, C.c_void_p, C.c_void_p]),
     "kfx_composite_pack": (C.c_int, [PI, PI, PI, C.c_void_p, C.c_int, C.c_void_p]),
     "kfx_composite_select": (C.c_int, [PI, PI, PI, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "kfx_composite_unpack": (C.c_int, [PI, PI, PI, C.c_void_p, C.c_void_p, C.c_void_p]),

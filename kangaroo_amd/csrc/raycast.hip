@@ -205,6 +205,124 @@ __global__ __launch_bounds__(256) void k_raycast_sdf(const RayParams p)
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// Exact multi-GPU march ("exact variant").  The volume is split into Z-slabs; a ray's
+// march state (lambda, last_sdf, delta) is carried from slab to slab in ray order, so every sample is
+// taken at exactly the position, and from exactly the cells, of the single-volume march.  `p` describes
+// the FULL volume's geometry with a virtual base pointer (local storage - z_offset planes), so
+// trilinear() / gradient() address global plane indices unchanged.  A rank advances a ray while the
+// trilinear base cell iz of the current sample lies in the cells it owns, [own_lo, own_hi), and the
+// planes it needs are stored locally, [avail_lo, avail_hi).
+// State: 9 dense planes of h*w floats (structure of arrays): 0 lambda, 1 last_sdf, 2 delta, 3 status,
+// 4 touched-this-round, 5-7 normal, 8 shade.  status: 0 marching, 1 hit (final), 2 miss (final),
+// 3 hit found, normal pending (computed by the rank that owns the gradient's base plane).  A hit's depth is
+// its lambda.  Exactly one rank touches a pixel per round (ownership is disjoint), so the host merges the
+// ranks' states with one integer SUM all-reduce of the touched pixels' planes 0-4.
+// ---------------------------------------------------------------------------------------
+struct SlabRay {
+    float* state;       // 9 planes of h*w floats
+    int own_lo, own_hi; // owned trilinear base cells (global plane indices)
+    int avail_lo, avail_hi; // planes stored locally (global indices)
+    int init;           // 1: (re)initialise the state from the ray / box intersection
+};
+
+__device__ __forceinline__ int cell_z(const RayParams& p, const V3 pos_w)
+{
+    const float pfz = ((pos_w.z - p.vol.bmin.z) / p.size.z) * p.dims1.z;
+    return (int)fmaxf(fminf(p.hi2.z, floorf(pfz)), 0.f);
+}
+__device__ __forceinline__ int grad_cell_z(const RayParams& p, const V3 pos_w)
+{
+    const float pfz = ((pos_w.z - p.vol.bmin.z) / p.size.z) * p.dims1.z;
+    return (int)fmaxf(fminf(p.hi2.z, floorf(pfz)), 1.f);
+}
+
+template <typename CELL>
+__global__ __launch_bounds__(256) void k_raycast_sdf_slab(const RayParams p, const SlabRay sl)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int u = blockIdx.x * 16 + (wv & 1) * 8 + (lane & 7);
+    const int v = blockIdx.y * 16 + (wv >> 1) * 8 + (lane >> 3);
+    if (u >= p.w || v >= p.h) return;
+    const size_t plane = (size_t)p.w * p.h;
+    float* st = sl.state + (size_t)v * p.w + u; // plane k at st[k * plane]
+
+    const V3 c_w = v3(p.T.m[3], p.T.m[7], p.T.m[11]);
+    const V3 ray_c = v3(((float)u - p.K.u0) / p.K.fu, ((float)v - p.K.v0) / p.K.fv, 1.0f);
+    const V3 ray_w = so3_mul(p.T, ray_c);
+    const V3 ta = div_cw(p.vol.bmin - c_w, ray_w);
+    const V3 tb = div_cw(p.vol.bmax - c_w, ray_w);
+    const V3 tmin = v3(fminf(ta.x, tb.x), fminf(ta.y, tb.y), fminf(ta.z, tb.z));
+    const V3 tmax = v3(fmaxf(ta.x, tb.x), fmaxf(ta.y, tb.y), fmaxf(ta.z, tb.z));
+    const float max_tmin = fmaxf(fmaxf(fmaxf(tmin.x, tmin.y), tmin.z), p.near);
+    const float min_tmax = fminf(fminf(fminf(tmax.x, tmax.y), tmax.z), p.far);
+
+    float lambda, last_sdf, delta, status;
+    if (sl.init) {
+        lambda = max_tmin;
+        last_sdf = __builtin_nanf("");
+        delta = 0.f;
+        status = (max_tmin < min_tmax) ? 0.f : 2.f;
+        st[5 * plane] = 0.f; st[6 * plane] = 0.f; st[7 * plane] = 0.f; st[8 * plane] = 0.f;
+    } else {
+        lambda = st[0]; last_sdf = st[plane]; delta = st[2 * plane]; status = st[3 * plane];
+    }
+    const float lambda_in = lambda, status_in = status;
+
+    if (status == 0.f) {
+        const float min_delta = p.voxel.x;
+        while (true) {
+            if (!(lambda < min_tmax)) { status = 2.f; break; }
+            const V3 pos = c_w + ray_w * lambda;
+            const int iz = cell_z(p, pos);
+            if (iz < sl.own_lo || iz >= sl.own_hi || iz < sl.avail_lo || iz + 1 >= sl.avail_hi) break; // another rank's sample
+            const float sdf = trilinear<CELL>(p, pos);
+            if (sdf <= 0) {
+                if (last_sdf > 0) {
+                    if (p.subpix) lambda = lambda + delta * sdf / (last_sdf - sdf);
+                    status = 3.f;
+                } else {
+                    status = 2.f;
+                }
+                break;
+            }
+            delta = sdf > 0 ? fmaxf(sdf, min_delta) : p.trunc;
+            lambda += delta;
+            last_sdf = sdf;
+        }
+    }
+    if (status == 3.f) { // hit: the rank owning the gradient's base plane gz evaluates the normal
+        const V3 pos = c_w + ray_w * lambda;
+        const int gz = grad_cell_z(p, pos);
+        if (gz >= sl.own_lo && gz < sl.own_hi && gz - 1 >= sl.avail_lo && gz + 1 < sl.avail_hi) {
+            const V3 g = gradient<CELL>(p, pos);
+            const float len = length(g);
+            const V3 n_w = len > 0 ? div_s(g, len) : v3(0.f, 0.f, 1.f);
+            const V3 n_c = so3_mul_inv(p.T, n_w);
+            st[5 * plane] = n_c.x; st[6 * plane] = n_c.y; st[7 * plane] = n_c.z;
+            st[8 * plane] = phong(ray_c * lambda, n_c);
+            status = 1.f;
+        }
+    }
+    st[0] = lambda; st[plane] = last_sdf; st[2 * plane] = delta; st[3 * plane] = status;
+    st[4 * plane] = (lambda != lambda_in || status != status_in) ? 1.0f : 0.0f;
+}
+
+// state -> the three output images (hit: depth / normal / shade; otherwise NaN / 0 / 0)
+__global__ __launch_bounds__(256) void k_raycast_state_to_images(const RayParams p, const float* __restrict__ state)
+{
+    const int u = blockIdx.x * 64 + (threadIdx.x & 63), v = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (u >= p.w || v >= p.h) return;
+    const size_t plane = (size_t)p.w * p.h;
+    const float* st = state + (size_t)v * p.w + u;
+    const float depth = st[0];
+    const bool hit = st[3 * plane] == 1.f && depth > 0.f;
+    *(reinterpret_cast<float*>(p.dptr + (size_t)v * p.dpitch) + u) = hit ? depth : __builtin_nanf("");
+    *(reinterpret_cast<float*>(p.iptr + (size_t)v * p.ipitch) + u) = hit ? st[8 * plane] : 0.f;
+    *(reinterpret_cast<float4*>(p.nptr + (size_t)v * p.npitch) + u) =
+        hit ? make_float4(st[5 * plane], st[6 * plane], st[7 * plane], 1.0f) : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
 } // namespace kfx
 
 using namespace kfx;
@@ -276,4 +394,60 @@ extern "C" int kfx_raycast_sdf_h(const kfx_image* depth, const kfx_image* norm, 
                                  float far, float trunc_dist, int subpix, kfx_stream stream)
 {
     return raycast_launch<RayF16>(depth, norm, img, vol, T_wc, K, near, far, trunc_dist, subpix, stream);
+}
+
+// Exact multi-GPU march: one round of a rank (see k_raycast_sdf_slab).  `vol` holds planes
+// [slab->z_offset, slab->z_offset + vol->d) of the full volume described by `slab`; the rank owns the
+// trilinear base cells [own_lo, own_hi).  `state` is KFX_RAY_STATE_PLANES dense planes of h*w floats; init != 0 starts the rays.
+extern "C" int kfx_raycast_sdf_slab(float* state, int init, const kfx_volume* vol, const kfx_slab* slab, int own_lo, int own_hi,
+                                    int w, int h, const float T_wc[12], const float K[4], float near, float far,
+                                    float trunc_dist, int subpix, kfx_stream stream)
+{
+    if (!state || !vol || !vol->ptr || !slab || !T_wc || !K) return set_error(KFX_E_NULL, "RaycastSdf(slab): null argument");
+    if (w <= 0 || h <= 0) return 0;
+    if (slab->full_d < 3 || slab->z_offset + vol->d > slab->full_d || vol->w < 3 || vol->h < 3)
+        return set_error(KFX_E_SHAPE, "RaycastSdf(slab): slab outside the full volume");
+    if ((((uintptr_t)vol->ptr | vol->pitch | vol->img_pitch) & 7) || ((uintptr_t)state & 3)) return set_error(KFX_E_ALIGN, "RaycastSdf(slab): alignment");
+    RayParams p;
+    // full-volume geometry, virtual base pointer (never dereferenced outside [avail_lo, avail_hi))
+    p.vol.ptr = (unsigned char*)vol->ptr - (ptrdiff_t)slab->z_offset * (ptrdiff_t)vol->img_pitch;
+    p.vol.pitch = vol->pitch;
+    p.vol.img_pitch = vol->img_pitch;
+    p.vol.w = (int)vol->w;
+    p.vol.h = (int)vol->h;
+    p.vol.d = (int)slab->full_d;
+    p.vol.bmin = V3{vol->boxmin[0], vol->boxmin[1], slab->full_zmin};
+    p.vol.bmax = V3{vol->boxmax[0], vol->boxmax[1], slab->full_zmax};
+    p.size = V3{vol->boxmax[0] - vol->boxmin[0], vol->boxmax[1] - vol->boxmin[1], slab->full_zmax - slab->full_zmin};
+    p.dims1 = V3{(float)vol->w - 1.f, (float)vol->h - 1.f, (float)slab->full_d - 1.f};
+    p.hi2 = V3{(float)(vol->w - 2), (float)(vol->h - 2), (float)(slab->full_d - 2)};
+    p.voxel = V3{p.size.x / (float)(vol->w - 1), p.size.y / (float)(vol->h - 1), p.size.z / (float)(slab->full_d - 1)};
+    for (int i = 0; i < 12; ++i) p.T.m[i] = T_wc[i];
+    p.K = Intr{K[0], K[1], K[2], K[3]};
+    p.dptr = p.nptr = p.iptr = nullptr;
+    p.dpitch = p.npitch = p.ipitch = 0;
+    p.w = w;
+    p.h = h;
+    p.near = near;
+    p.far = far;
+    p.trunc = trunc_dist;
+    p.subpix = subpix ? 1 : 0;
+    SlabRay sl{state, own_lo, own_hi, (int)slab->z_offset, (int)(slab->z_offset + vol->d), init ? 1 : 0};
+    dim3 grid(ceil_div(w, 16), ceil_div(h, 16));
+    hipLaunchKernelGGL(k_raycast_sdf_slab<RayF32>, grid, dim3(256), 0, (hipStream_t)stream, p, sl);
+    return check_launch("kfx_raycast_sdf_slab");
+}
+
+extern "C" int kfx_raycast_state_to_images(const kfx_image* depth, const kfx_image* norm, const kfx_image* img, const float* state,
+                                           kfx_stream stream)
+{
+    if (!depth || !norm || !img || !state || !depth->ptr || !norm->ptr || !img->ptr) return set_error(KFX_E_NULL, "raycast state: null argument");
+    if (img->w == 0 || img->h == 0) return 0;
+    if (depth->w < img->w || depth->h < img->h || norm->w < img->w || norm->h < img->h) return set_error(KFX_E_SHAPE, "raycast state: image sizes");
+    RayParams p{};
+    p.dptr = (unsigned char*)depth->ptr; p.nptr = (unsigned char*)norm->ptr; p.iptr = (unsigned char*)img->ptr;
+    p.dpitch = depth->pitch; p.npitch = norm->pitch; p.ipitch = img->pitch;
+    p.w = (int)img->w; p.h = (int)img->h;
+    hipLaunchKernelGGL(k_raycast_state_to_images, dim3(ceil_div(p.w, 64), ceil_div(p.h, 4)), dim3(256), 0, (hipStream_t)stream, p, state);
+    return check_launch("kfx_raycast_state_to_images");
 }

@@ -94,13 +94,16 @@ class SlabPipeline(FramePipeline):
 
     GHOST = 2  # >= 1 for the trilinear z+1 corner and the gradient's z-1 / z+1 cells (Volume.h:240-289)
 
-    def __init__(self, ops, dist, dims, boxmin, boxmax, w, h, halo="exchange", **kw):
+    def __init__(self, ops, dist, dims, boxmin, boxmax, w, h, halo="exchange", raycast="composite", **kw):
         """halo = "exchange": every rank integrates only the planes it owns and the ghost planes are
         refreshed from the two neighbours after each SdfFuse (point-to-point send/recv: one xGMI link
         per direction); halo = "recompute": every rank integrates its ghost planes itself (the update is
         deterministic per voxel, so no traffic is needed) -- the cross-check of the exchange path."""
         assert halo in ("exchange", "recompute")
+        assert raycast in ("composite", "exact")
         self.halo = halo
+        self.raycast_mode = raycast
+        self._state = None
         self.dist = dist
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
         self.full_boxmin = np.asarray(boxmin, np.float32)
@@ -157,9 +160,50 @@ class SlabPipeline(FramePipeline):
                 req.wait()
 
     def raycast(self, T_wc):
+        """raycast = "composite": every rank marches its own slab from the slab's entry point and the nearest
+        hit wins (one MIN + one SUM all-reduce; rays re-enter each slab with a fresh step, so depths can differ
+        from the single-volume march in the last bits).  raycast = "exact": the march state travels with the
+        ray from slab to slab (raycast_exact), bit-identical to RaycastSdf on the whole volume."""
+        if self.raycast_mode == "exact":
+            self.raycast_exact(T_wc)
+            return
         super().raycast(T_wc)
         if self.world > 1:
             self.composite()
+
+    def raycast_exact(self, T_wc):
+        """Rounds of kfx_raycast_sdf_slab.  In a round exactly one rank advances a given ray (the owner of the
+        trilinear base plane of its current sample), so the merge is one integer SUM all-reduce of the touched
+        pixels' march planes (lambda, last_sdf, delta, status, touched); untouched pixels are identical on all
+        ranks already.  A ray crosses the slabs monotonically in z: at most world + 2 rounds.  The normals
+        (planes 5-8, written by one rank per pixel) are merged once at the end."""
+        import torch
+        dist, o = self.dist, self.ops
+        D = self.dims[2]
+        slab = (D, self.s0, float(self.full_boxmin[2]), float(self.full_boxmax[2]))
+        if self._state is None:
+            self._state = torch.empty((9, self.h, self.w), dtype=torch.float32, device=self.ray_d.tensor().device)
+        st = self._state
+        march = st[0:5].view(torch.int32)   # contiguous planes 0..4
+        rounds = 0
+        while True:
+            o.RaycastSdfSlab(st, rounds == 0, self.vol, slab, self.z0, self.z1, self.w, self.h, T_wc, self.K,
+                             self.near, self.far, self.trunc, True)
+            rounds += 1
+            if self.world > 1:
+                touched = march[4] != 0
+                contrib = torch.where(touched.unsqueeze(0), march, torch.zeros_like(march))
+                dist.all_reduce(contrib, op=dist.ReduceOp.SUM)
+                march.copy_(torch.where((contrib[4] != 0).unsqueeze(0), contrib, march))
+            status = st[3]
+            if not bool(((status == 0) | (status == 3)).any()):
+                break
+            assert rounds <= self.world + 3, "slab march did not terminate"
+        if self.world > 1:
+            out = st[5:9].view(torch.int32)
+            dist.all_reduce(out, op=dist.ReduceOp.SUM)
+        self.rounds = rounds
+        o.RaycastStateToImages(self.ray_d, self.ray_n, self.ray_i, st)
 
     def composite(self):
         """Nearest hit over all slabs.  key = depth bits (positive floats order like ints) in the

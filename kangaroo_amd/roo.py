@@ -359,3 +359,18 @@ def CompositeUnpack(depth, norm, img, key, payload, stream=None):
     """kfx_composite_unpack: write the merged depth / normal / shade images."""
     _lib.check(_lib.load().kfx_composite_unpack(depth.ref(), norm.ref(), img.ref(), C.c_void_p(key.data_ptr()),
                                                 C.c_void_p(payload.data_ptr()), _stream(stream)))
+
+
+def RaycastSdfSlab(state, init, vol, slab, own_lo, own_hi, w, h, T_wc, K, near, far, trunc_dist, subpix=True, stream=None):
+    """kfx_raycast_sdf_slab: one round of the exact multi-GPU march; `state` is a dense float32 tensor (9, h, w)."""
+    assert state.dtype == torch.float32 and state.is_contiguous() and tuple(state.shape) == (9, h, w)
+    t, _t = _fp(T_wc, 12)
+    k, _k = _fp(K, 4)
+    sl = _lib.KfxSlab(int(slab[0]), int(slab[1]), float(slab[2]), float(slab[3]))
+    _lib.check(_lib.load().kfx_raycast_sdf_slab(C.c_void_p(state.data_ptr()), 1 if init else 0, vol.ref(), C.byref(sl), own_lo, own_hi,
+                                                w, h, t, k, near, far, trunc_dist, 1 if subpix else 0, _stream(stream)))
+
+
+def RaycastStateToImages(depth, norm, img, state, stream=None):
+    """kfx_raycast_state_to_images: final march state -> depth / normal / shade images."""
+    _lib.check(_lib.load().kfx_raycast_state_to_images(depth.ref(), norm.ref(), img.ref(), C.c_void_p(state.data_ptr()), _stream(stream)))

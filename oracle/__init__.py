@@ -69,6 +69,9 @@ def lib():
         L.kfo_se3_inverse.argtypes = [PF, PF]
         L.kfo_sdf_fuse_slab.argtypes = [PV, C.POINTER(KfoSlab), PI, PI, PF, PF, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int]
         L.kfo_sdf_fuse_slab.restype = C.c_uint64
+        L.kfo_raycast_sdf_slab.argtypes = [C.c_void_p, C.c_int, PV, C.POINTER(KfoSlab), C.c_int, C.c_int, C.c_int, C.c_int, PF, PF,
+                                           C.c_float, C.c_float, C.c_float, C.c_int]
+        L.kfo_raycast_sdf_slab.restype = None
         L.kfo_sdf_fuse_h.argtypes = L.kfo_sdf_fuse.argtypes
         L.kfo_sdf_fuse_h.restype = C.c_uint64
         L.kfo_raycast_sdf_h.argtypes = L.kfo_raycast_sdf.argtypes
@@ -384,3 +387,13 @@ def elementwise_scale_bias(b, a, s, offset=0.0):
 
 def box_half_ignore_invalid(out, inp):
     lib().kfo_box_half_ignore_invalid_f32(out.ref(), inp.ref())
+
+
+def raycast_sdf_slab(state, init, vol, slab, own_lo, own_hi, w, h, T_wc, K, near, far, trunc, subpix=True):
+    """One round of the exact multi-GPU march; `state` is a C-contiguous float32 array (9, h, w)."""
+    assert state.dtype == np.float32 and state.flags["C_CONTIGUOUS"] and state.shape == (9, h, w)
+    _, t = _fp(T_wc)
+    _, k = _fp(K)
+    sl = KfoSlab(int(slab[0]), int(slab[1]), float(slab[2]), float(slab[3]))
+    lib().kfo_raycast_sdf_slab(state.ctypes.data, 1 if init else 0, vol.ref(), C.byref(sl), own_lo, own_hi, w, h, t, k,
+                               near, far, trunc, 1 if subpix else 0)

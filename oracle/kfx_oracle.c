@@ -812,3 +812,83 @@ void kfo_box_half_ignore_invalid_f32(const kfo_image* out, const kfo_image* in) 
             ((float*)img_row(out, y))[x] = n > 0 ? (sum / n) : NAN;
         }
 }
+
+/* ============================================================================
+ * Exact multi-GPU march (SURVEY 8(e) "exact variant"): one round of one rank.
+ * The march of cu_raycast.cu:58-81 with its state (lambda, last_sdf, delta) carried between Z-slabs:
+ * a rank advances a ray while the trilinear base cell of the current sample is one it owns.
+ * State: 9 dense planes of h*w floats: 0 lambda, 1 last_sdf, 2 delta, 3 status (0 marching, 1 hit, 2 miss,
+ * 3 hit awaiting its normal), 4 touched-this-round, 5-7 normal, 8 shade.  A hit's depth is its lambda; the
+ * normal is evaluated by the rank that owns the gradient's base plane.
+ * ========================================================================== */
+void kfo_raycast_sdf_slab(float* state, int init, const kfo_volume* vol, const kfo_slab* slab, int own_lo, int own_hi,
+                          int w, int h, const float T[12], const float K[4], float near, float far,
+                          float trunc_dist, int subpix)
+{
+    const int half = 0;
+    kfo_volume fv = *vol; /* full-volume geometry over a virtual base pointer */
+    fv.ptr = (unsigned char*)vol->ptr - (ptrdiff_t)slab->z_offset * (ptrdiff_t)vol->img_pitch;
+    fv.d = slab->full_d;
+    fv.boxmin[2] = slab->full_zmin;
+    fv.boxmax[2] = slab->full_zmax;
+    const int avail_lo = (int)slab->z_offset, avail_hi = (int)(slab->z_offset + vol->d);
+    for (int v = 0; v < h; ++v)
+        for (int u = 0; u < w; ++u) {
+            const size_t P = (size_t)w * (size_t)h;
+            float* st = state + (size_t)v * (size_t)w + (size_t)u;
+            const f3 c_w = se3_translation(T);
+            const f3 ray_c = unproject1(K, (float)u, (float)v);
+            const f3 ray_w = so3_mul(T, ray_c);
+            const f3 ta = div33(sub3(box_min(&fv), c_w), ray_w), tb = div33(sub3(box_max(&fv), c_w), ray_w);
+            const float max_tmin = fmaxf(fmaxf(fmaxf(fminf(ta.x, tb.x), fminf(ta.y, tb.y)), fminf(ta.z, tb.z)), near);
+            const float min_tmax = fminf(fminf(fminf(fmaxf(ta.x, tb.x), fmaxf(ta.y, tb.y)), fmaxf(ta.z, tb.z)), far);
+            float lambda, last_sdf, delta, status;
+            if (init) {
+                lambda = max_tmin; last_sdf = NAN; delta = 0.f;
+                status = (max_tmin < min_tmax) ? 0.f : 2.f;
+                for (int i = 5; i < 9; ++i) st[i * P] = 0.f;
+            } else {
+                lambda = st[0]; last_sdf = st[P]; delta = st[2 * P]; status = st[3 * P];
+            }
+            const float lambda_in = lambda, status_in = status;
+            if (status == 0.f) {
+                const float min_delta = voxel_size_units(&fv).x;
+                for (;;) {
+                    if (!(lambda < min_tmax)) { status = 2.f; break; }
+                    const f3 pos = add3(c_w, scale3(ray_w, lambda));
+                    const float pfz = ((pos.z - fv.boxmin[2]) / (fv.boxmax[2] - fv.boxmin[2])) * ((float)fv.d - 1.f);
+                    const int iz = (int)fmaxf(fminf((float)(fv.d - 2), floorf(pfz)), 0);
+                    if (iz < own_lo || iz >= own_hi || iz < avail_lo || iz + 1 >= avail_hi) break;
+                    const float sdf = trilinear_clamped(&fv, pos, NULL, half);
+                    if (sdf <= 0) {
+                        if (last_sdf > 0) {
+                            if (subpix) lambda = lambda + delta * sdf / (last_sdf - sdf);
+                            status = 3.f;
+                        } else {
+                            status = 2.f;
+                        }
+                        break;
+                    }
+                    delta = sdf > 0 ? fmaxf(sdf, min_delta) : trunc_dist;
+                    lambda += delta;
+                    last_sdf = sdf;
+                }
+            }
+            if (status == 3.f) {
+                const f3 pos = add3(c_w, scale3(ray_w, lambda));
+                const float pfz = ((pos.z - fv.boxmin[2]) / (fv.boxmax[2] - fv.boxmin[2])) * ((float)fv.d - 1.f);
+                const int gz = (int)fmaxf(fminf((float)(fv.d - 2), floorf(pfz)), 1);
+                if (gz >= own_lo && gz < own_hi && gz - 1 >= avail_lo && gz + 1 < avail_hi) {
+                    const f3 g = units_backward_diff(&fv, pos, NULL, half);
+                    const float len = length3(g);
+                    const f3 n_w = len > 0 ? div3s(g, len) : mk3(0, 0, 1);
+                    const f3 n_c = so3_mul_inv(T, n_w);
+                    st[5 * P] = n_c.x; st[6 * P] = n_c.y; st[7 * P] = n_c.z;
+                    st[8 * P] = phong_shade(scale3(ray_c, lambda), n_c);
+                    status = 1.f;
+                }
+            }
+            st[0] = lambda; st[P] = last_sdf; st[2 * P] = delta; st[3 * P] = status;
+            st[4 * P] = (lambda != lambda_in || status != status_in) ? 1.0f : 0.0f;
+        }
+}

@@ -90,6 +90,10 @@ typedef struct kfo_slab {
 uint64_t kfo_sdf_fuse_slab(const kfo_volume* vol, const kfo_slab* slab, const kfo_image* depth, const kfo_image* norm,
                            const float T_cw[12], const float K[4], float trunc, float max_w,
                            float mincostheta, int full_extent, int nthreads);
+/* One round of the exact multi-GPU march (state carried across Z-slabs); see kfx_oracle.c */
+void kfo_raycast_sdf_slab(float* state, int init, const kfo_volume* vol, const kfo_slab* slab, int own_lo, int own_hi,
+                          int w, int h, const float T_wc[12], const float K[4], float near, float far,
+                          float trunc_dist, int subpix);
 /* cu_raycast.cu:14-113 */
 void kfo_raycast_sdf(const kfo_image* depth, const kfo_image* norm, const kfo_image* img,
                      const kfo_volume* vol, const float T_wc[12], const float K[4],

@@ -84,3 +84,16 @@ def SdfFuse(vol, depth, norm, T_cw, K, trunc, maxw, mincostheta, full_extent=Fal
 
 def RaycastSdf(depth, norm, img, vol, T_wc, K, near, far, trunc, subpix=True):
     oracle.raycast_sdf(depth, norm, img, vol, T_wc, K, near, far, trunc, subpix)
+
+
+def RaycastSdfSlab(state, init, vol, slab, own_lo, own_hi, w, h, T_wc, K, near, far, trunc, subpix=True):
+    oracle.raycast_sdf_slab(state.numpy(), init, vol, slab, own_lo, own_hi, w, h, T_wc, K, near, far, trunc, subpix)
+
+
+def RaycastStateToImages(depth, norm, img, state):
+    st = state.numpy()
+    hit = (st[3] == 1.0) & (st[0] > 0)
+    depth.data[...] = np.where(hit, st[0], np.float32("nan"))
+    img.data[...] = np.where(hit, st[8], np.float32(0))
+    n = np.stack([st[5], st[6], st[7], np.ones_like(st[0])], axis=-1)
+    norm.data[...] = np.where(hit[..., None], n, np.float32(0))

@@ -636,3 +636,67 @@ def test_gpu_composite_kernels_match_tensor_expressions(roo):
     assert np.median(np.abs(d[both] - od.data[both])) < 0.05 * (bmax[0] - bmin[0]) / (N - 1)
     n = rn.MemcpyToHost()
     assert (n[~np.isfinite(d)] == 0).all() and (n[np.isfinite(d)][:, 3] == 1).all()
+
+
+@pytest.mark.parametrize("world,ghost", [(2, 2), (4, 1), (5, 3)])
+def test_gpu_exact_slab_raycast_rounds(roo, world, ghost):
+    """SURVEY 8(e) exact variant: `world` slabs of one volume marched in rounds with the state merge of
+    SlabPipeline.raycast_exact (emulated in-process: per-slab states, integer-sum merge of the touched
+    pixels).  Every round of every slab is compared with the oracle's slab march on the same input state,
+    and the final images must equal RaycastSdf on the whole volume bit for bit."""
+    import torch
+    from kangaroo_amd.pipeline import slab_range
+    N, w, h, scene = 64, 160, 120, "room"
+    ovol = T.make_volume(N, scene)
+    K, tr, fr = T.fuse_frames_oracle(ovol, scene, w, h, 3)
+    bmin, bmax, near, far = scenes.SCENES[scene]
+    vol = T.upload_volume(roo, ovol)
+    T_wc = fr[-1]["T_wc"]
+    rd, rn, ri = roo.Image(w, h), roo.Image(w, h, "f32x4"), roo.Image(w, h)
+    roo.RaycastSdf(rd, rn, ri, vol, T_wc, K, near, far, tr, True)
+    want = (rd.MemcpyToHost(), rn.MemcpyToHost(), ri.MemcpyToHost())
+    assert np.isfinite(want[0]).mean() > 0.3
+
+    spans = [slab_range(N, r, world) for r in range(world)]
+    stored = [(max(z0 - ghost, 0), min(z1 + ghost, N)) for z0, z1 in spans]
+    views = [vol.ZSlab(s0, s1) for s0, s1 in stored]
+
+    def oslab(s0, s1):  # planes [s0, s1) of the oracle volume as a non-owning view (x/y box of the parent)
+        st = oracle.KfoVolume(ovol.pitch, ovol.raw.ctypes.data + s0 * ovol.img_pitch, ovol.w, ovol.h, ovol.img_pitch, s1 - s0)
+        for i in range(3):
+            st.boxmin[i], st.boxmax[i] = float(ovol.boxmin[i]), float(ovol.boxmax[i])
+        return oracle.SubVolume(ovol, st)
+    oviews = [oslab(s0, s1) for s0, s1 in stored]
+    states = [torch.empty((9, h, w), dtype=torch.float32, device="cuda") for _ in range(world)]
+    rounds = 0
+    while True:
+        for r in range(world):
+            slab = (N, stored[r][0], float(bmin[2]), float(bmax[2]))
+            ost = states[r].cpu().numpy().copy()
+            roo.RaycastSdfSlab(states[r], rounds == 0, views[r], slab, spans[r][0], spans[r][1], w, h, T_wc, K, near, far, tr, True)
+            oracle.raycast_sdf_slab(ost, rounds == 0, oviews[r], slab, spans[r][0], spans[r][1], w, h, T_wc, K, near, far, tr, True)
+            got = states[r].cpu().numpy()
+            assert T.nan_equal(got, ost), (rounds, r, T.mismatch_report(got, ost))
+        rounds += 1
+        march = [s[0:5].view(torch.int32) for s in states]
+        total = torch.zeros_like(march[0])
+        for m in march:
+            total += torch.where((m[4] != 0).unsqueeze(0), m, torch.zeros_like(m))
+        # one toucher per pixel and round: the touched plane sums to exactly one 1.0f or to zero
+        assert bool(((total[4] == 0) | (total[4] == 0x3F800000)).all())
+        for m in march:
+            m.copy_(torch.where((total[4] != 0).unsqueeze(0), total, m))
+        status = states[0][3]
+        if not bool(((status == 0) | (status == 3)).any()):
+            break
+        assert rounds <= world + 3
+    assert rounds > 1
+    out = torch.zeros((4, h, w), dtype=torch.int32, device="cuda")
+    for s in states:
+        out += s[5:9].view(torch.int32)
+    states[0][5:9].view(torch.int32).copy_(out)
+    gd, gn, gi = roo.Image(w, h), roo.Image(w, h, "f32x4"), roo.Image(w, h)
+    roo.RaycastStateToImages(gd, gn, gi, states[0])
+    assert T.nan_equal(gd.MemcpyToHost(), want[0]), T.mismatch_report(gd.MemcpyToHost(), want[0])
+    assert T.nan_equal(gn.MemcpyToHost(), want[1]), T.mismatch_report(gn.MemcpyToHost(), want[1])
+    assert T.nan_equal(gi.MemcpyToHost(), want[2]), T.mismatch_report(gi.MemcpyToHost(), want[2])

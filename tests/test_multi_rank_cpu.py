@@ -28,19 +28,19 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out_dir, halo):
+def _worker(rank, world, port, out_dir, halo, raycast="composite"):
     import oracle_ops as ops
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     bmin, bmax, near, far = scenes.SCENES["room"]
-    pipe = SlabPipeline(ops, dist, (N, N, N), bmin, bmax, W, H, halo=halo, near=near, far=far)
+    pipe = SlabPipeline(ops, dist, (N, N, N), bmin, bmax, W, H, halo=halo, raycast=raycast, near=near, far=far)
     K = pipe.K
     for i in range(FRAMES):
         T_wc = scenes.orbit_pose(i, 8)
         pipe.raw.MemcpyFromHost(scenes.render_depth("room", W, H, T_wc, K))
         pipe.step(T_wc)
-    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), vol=pipe.vol.data, s0=pipe.s0, s1=pipe.s1, z0=pipe.z0, z1=pipe.z1,
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), rounds=getattr(pipe, "rounds", 0), vol=pipe.vol.data, s0=pipe.s0, s1=pipe.s1, z0=pipe.z0, z1=pipe.z1,
              depth=pipe.ray_d.data, norm=pipe.ray_n.data, img=pipe.ray_i.data)
     dist.barrier()
     dist.destroy_process_group()
@@ -101,3 +101,27 @@ def test_slab_pipeline_matches_single_volume(tmp_path, world, halo):
     n_ref, n_got = ref.ray_n.data[both], ranks[0]["norm"][both]
     assert (np.abs(n_ref - n_got).max(axis=1) < 0.05).mean() > 0.98
     assert (ranks[0]["norm"][~hit_got] == 0).all() and (ranks[0]["img"][~hit_got] == 0).all()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_exact_slab_raycast_is_bit_identical_to_single_volume(tmp_path, world):
+    """raycast="exact": the march state travels with the ray across the slabs, so depth, normals and shade
+    equal the single-volume RaycastSdf bit for bit on every rank."""
+    import oracle_ops as ops
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), "exchange", "exact"), nprocs=world, join=True)
+    bmin, bmax, near, far = scenes.SCENES["room"]
+    ref = FramePipeline(ops, (N, N, N), bmin, bmax, W, H, near=near, far=far)
+    for i in range(FRAMES):
+        T_wc = scenes.orbit_pose(i, 8)
+        ref.raw.MemcpyFromHost(scenes.render_depth("room", W, H, T_wc, ref.K))
+        ref.preprocess()
+        ops.SdfFuse(ref.vol, ref.filtered, ref.normals, scenes.se3_inverse(T_wc), ref.K, ref.trunc, ref.max_w,
+                    ref.mincostheta, full_extent=True)
+        ref.raycast(T_wc)
+    assert np.isfinite(ref.ray_d.data).mean() > 0.3
+    for r in range(world):
+        got = np.load(os.path.join(str(tmp_path), "rank%d.npz" % r))
+        assert 1 < int(got["rounds"]) <= world + 3
+        assert T.nan_equal(got["depth"], ref.ray_d.data), T.mismatch_report(got["depth"], ref.ray_d.data)
+        assert T.nan_equal(got["norm"], ref.ray_n.data), T.mismatch_report(got["norm"], ref.ray_n.data)
+        assert T.nan_equal(got["img"], ref.ray_i.data), T.mismatch_report(got["img"], ref.ray_i.data)
