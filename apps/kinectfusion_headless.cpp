@@ -1,7 +1,7 @@
 // kinectfusion_headless.cpp -- the KinectFusion frame loop of the reference application
-// (applications/kinectfusion/main.cpp:190-393) without its GUI, sensor and ICP: a synthetic camera
-// with known poses orbits a synthetic room, and every frame runs the same roo:: calls in the same
-// order on the same container types:
+// (applications/kinectfusion/main.cpp:190-393) without its GUI and sensor: a synthetic camera orbits a
+// synthetic room, and every frame runs the same roo:: calls in the same order on the same container
+// types (poses: known by default; --track estimates them with the projective ICP of main.cpp:299-343):
 //
 //   ElementwiseScaleBias (mm -> m) -> BilateralFilter -> BoxReduceIgnoreInvalid -> per level
 //   DepthToVbo -> NormalsFromVbo                                            (main.cpp:208-215)
@@ -9,10 +9,12 @@
 //   roi = BoundingBox(T_wl, w, h, K, knear, kfar); work_vol = vol.SubBoundingVolume(roi)   (:275-276)
 //   for levels with its[l] > 0: RaycastSdf(ray_d[l], ray_n[l], ray_i[l], work_vol, T_wl, K[l], ...);
 //                               DepthToVbo(ray_v[l], ray_d[l], K[l])                       (:280-288)
+//   [--track] for l = MaxLevels-1 .. 0, its[l] times: lss = PoseRefinementProjectiveIcpPointPlane(kin_v[l],
+//             ray_v[l], ray_n[l], K[l]*T_lp, T_lp^-1, icp_c, dScratch, dDebug); solve; T_lp *= exp(x)  (:301-337)
 //   SdfFuse(work_vol, kin_d, kin_n, T_wl^-1, K, trunc_dist, max_w, mincostheta)            (:345-356)
 //
 // Host code only; all device work happens in libkfx behind the roo:: wrappers.
-// Usage: kinectfusion_headless [--res N] [--frames F] [--width W] [--height H] [--fast]
+// Usage: kinectfusion_headless [--res N] [--frames F] [--width W] [--height H] [--fast] [--track]
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -21,6 +23,8 @@
 #include <vector>
 
 #include <kangaroo/kangaroo.h>
+
+#include "pose_solve.h"
 
 using namespace roo;
 
@@ -64,13 +68,14 @@ static Mat<float,3,4> OrbitPose(int i, int n)
 int main(int argc, char** argv)
 {
     int volres = 256, frames = 30, w = 640, h = 480;   // the application's defaults (main.cpp:90-91)
-    bool fast = false;
+    bool fast = false, track = false;
     for (int i = 1; i < argc; ++i) {
         if (!strcmp(argv[i], "--res") && i + 1 < argc) volres = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--frames") && i + 1 < argc) frames = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--width") && i + 1 < argc) w = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--height") && i + 1 < argc) h = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--fast")) fast = true;
+        else if (!strcmp(argv[i], "--track")) track = true;
     }
     if (kfx_device_count() < 1) { fprintf(stderr, "no HIP device\n"); return 2; }
     kfx_set_math_mode(fast ? KFX_MATH_FAST : KFX_MATH_EXACT);
@@ -91,6 +96,9 @@ int main(int argc, char** argv)
     Pyramid<float, MaxLevels, TargetDevice, Manage> ray_i(w, h), ray_d(w, h);
     Pyramid<float4, MaxLevels, TargetDevice, Manage> ray_n(w, h), ray_v(w, h);
     BoundedVolume<SDF_t, TargetDevice, Manage> vol(volres, volres, volres, reset_bb);
+    Image<float4, TargetDevice, Manage> dDebug(w, h);                                             // main.cpp:110
+    Image<unsigned char, TargetDevice, Manage> dScratch(w * sizeof(LeastSquaresSystem<float,12>), h);  // main.cpp:111
+    const float icp_c = 0.1f, max_rmse = 0.10f;                                                   // main.cpp:154,162
 
     const float3 vs = vol.VoxelSizeUnits();
     const float trunc_dist = trunc_dist_factor * length(vs);   // main.cpp:221
@@ -104,10 +112,16 @@ int main(int argc, char** argv)
     }
 
     std::vector<float> hdepth((size_t)w * h);
-    double total_ms = 0;
+    double total_ms = 0, worst_pos_err = 0, rmse = 0;
     size_t hits = 0;
+    int lost = 0;
+    posesolve::SE3d T_wl_est;   // tracked pose (double, as Sophus::SE3d in the application)
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j) T_wl_est.R[i][j] = poses[0](i, j);
+        T_wl_est.t[i] = poses[0](i, 3);
+    }
     for (int f = 0; f < frames; ++f) {
-        const Mat<float,3,4> T_wl = poses[f];
+        Mat<float,3,4> T_wl = track ? T_wl_est.matrix3x4<Mat<float,3,4> >() : poses[f];
         dKinectMeters.MemcpyFromHost(depth_frames[f].data());   // the host->device boundary of main.cpp:203
         const auto t0 = std::chrono::steady_clock::now();
         ElementwiseScaleBias<float,float,float>(dKinectMeters, dKinectMeters, 1.0f / 1000.0f);
@@ -131,8 +145,53 @@ int main(int argc, char** argv)
                     DepthToVbo<float>(ray_v[l], ray_d[l], Kl);
                 }
             }
-            // (the ICP pose refinement of main.cpp:301-337 would run here; poses are known)
-            if (f > 0) SdfFuse(work_vol, kin_d[0], kin_n[0], SE3inv(T_wl), K, trunc_dist, max_w, mincostheta);
+            bool tracking_good = true;
+            if (track && f > 0) {   // main.cpp:299-341
+                posesolve::SE3d T_lp;
+                for (int l = MaxLevels - 1; l >= 0; --l) {
+                    const ImageIntrinsics Kl = K[l];
+                    for (int i = 0; i < its[l]; ++i) {
+                        Mat<float,3,4> KT_lp, T_pl = T_lp.inverse().matrix3x4<Mat<float,3,4> >();
+                        for (int c = 0; c < 4; ++c) {   // K * [R | t] in double, then to float
+                            const double r0 = c < 3 ? T_lp.R[0][c] : T_lp.t[0], r1 = c < 3 ? T_lp.R[1][c] : T_lp.t[1],
+                                         r2 = c < 3 ? T_lp.R[2][c] : T_lp.t[2];
+                            KT_lp(0, c) = (float)((double)Kl.fu * r0 + (double)Kl.u0 * r2);
+                            KT_lp(1, c) = (float)((double)Kl.fv * r1 + (double)Kl.v0 * r2);
+                            KT_lp(2, c) = (float)r2;
+                        }
+                        const LeastSquaresSystem<float,6> lss = PoseRefinementProjectiveIcpPointPlane(
+                            kin_v[l], ray_v[l], ray_n[l], KT_lp, T_pl, icp_c, dScratch, dDebug.SubImage(0, 0, w >> l, h >> l));
+                        const Mat<double,6,6> JTJf = lss.JTJ;
+                        double sysJTJ[36], sysJTy[6], x[6] = {0, 0, 0, 0, 0, 0};
+                        for (int a = 0; a < 36; ++a) sysJTJ[a] = JTJf.m[a];
+                        for (int a = 0; a < 6; ++a) { sysJTy[a] = lss.JTy.m[a]; sysJTJ[a * 7] += 0.1 / 0.2; }  // weak pose prior
+                        rmse = sqrt(lss.sqErr / lss.obs);
+                        tracking_good = rmse < max_rmse;
+                        if (l == MaxLevels - 1 && MaxLevels > 1) {   // coarsest level: rotation only
+                            double A3[9], b3[3];
+                            for (int a = 0; a < 3; ++a) {
+                                b3[a] = sysJTy[3 + a];
+                                for (int b = 0; b < 3; ++b) A3[a * 3 + b] = sysJTJ[(3 + a) * 6 + 3 + b];
+                            }
+                            posesolve::FullPivLuSolve<3>(A3, b3, x + 3);
+                            for (int a = 3; a < 6; ++a) x[a] = -x[a];
+                            T_lp = T_lp * posesolve::Exp(x, true);
+                        } else {
+                            posesolve::FullPivLuSolve<6>(sysJTJ, sysJTy, x);
+                            bool finite = true;
+                            for (int a = 0; a < 6; ++a) { x[a] = -x[a]; finite = finite && std::isfinite(x[a]); }
+                            if (finite) T_lp = T_lp * posesolve::Exp(x);
+                        }
+                    }
+                }
+                if (tracking_good) T_wl_est = T_wl_est * T_lp.inverse();
+                else ++lost;
+                T_wl = T_wl_est.matrix3x4<Mat<float,3,4> >();
+                double e = 0;
+                for (int i = 0; i < 3; ++i) e += (T_wl(i, 3) - poses[f](i, 3)) * (T_wl(i, 3) - poses[f](i, 3));
+                worst_pos_err = std::fmax(worst_pos_err, std::sqrt(e));
+            }
+            if (f > 0 && tracking_good) SdfFuse(work_vol, kin_d[0], kin_n[0], SE3inv(T_wl), K, trunc_dist, max_w, mincostheta);
         }
         kfx_stream_synchronize(0);
         total_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -141,7 +200,10 @@ int main(int argc, char** argv)
             for (float d : hdepth) hits += std::isfinite(d) ? 1 : 0;
         }
     }
-    printf("kinectfusion_headless: %d^3 volume, %dx%d, %d frames, %s math: %.3f ms/frame (%.1f fps), last raycast hits %zu/%d\n",
-           volres, w, h, frames, fast ? "fast" : "exact", total_ms / frames, 1e3 * frames / total_ms, hits, w * h);
+    printf("kinectfusion_headless: %d^3 volume, %dx%d, %d frames, %s math, %s poses: %.3f ms/frame (%.1f fps), last raycast hits %zu/%d\n",
+           volres, w, h, frames, fast ? "fast" : "exact", track ? "ICP-tracked" : "known", total_ms / frames, 1e3 * frames / total_ms, hits, w * h);
+    if (track) printf("  tracking: worst position error %.2f mm over the orbit (step between poses up to %.1f mm), final rmse %.4f, %d frames lost\n",
+                      1e3 * worst_pos_err, 1e3 * 0.0105, rmse, lost);
+    if (track && (lost > 0 || worst_pos_err > 0.02)) return 1;
     return hits > (size_t)(w * h) / 4 ? 0 : 1;
 }

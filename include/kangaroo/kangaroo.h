@@ -27,3 +27,5 @@
 #include <kangaroo/cu_normals.h>
 #include <kangaroo/cu_sdffusion.h>
 #include <kangaroo/cu_raycast.h>
+#include <kangaroo/reweighting.h>
+#include <kangaroo/cu_model_refinement.h>

@@ -188,6 +188,27 @@ int kfx_memcpy_2d(void* dst, size_t dpitch, const void* src, size_t spitch, size
                   size_t rows, int kind, kfx_stream stream);
 int kfx_stream_synchronize(kfx_stream stream);
 
+/* ---- projective point-to-plane ICP ------------------------------------------
+ * roo::LeastSquaresSystem<float,6> (Mat.h:483-520): JTy, the 21 unique elements of the symmetric JTJ in
+ * row-major lower-triangle order (Mat.h:353-365), the squared error and the observation count. */
+typedef struct kfx_lss6 {
+    float JTy[6];
+    float JTJ[21];
+    float sqErr;
+    unsigned obs;
+} kfx_lss6;
+
+/* roo::PoseRefinementProjectiveIcpPointPlane (cu_model_refinement.cu:541-608, decl cu_model_refinement.h:58-64).
+ * For every pixel of the model-view vertex map dPr with a valid normal (dNr.w == 1): project it with KT_lr
+ * into the live vertex map dPl (nearest neighbour, 3-pixel border), residual y = (T_rl * Pl - Pr) . Nr, Jacobian
+ * -(gen_i * _Pr) . Nr, weight Tukey(y, c) / Pr.z; the per-pixel systems are summed (per 16x16 block in the
+ * reference's tree order, then over the blocks in a fixed order) and returned in *out (host memory).
+ * `workspace`: device bytes, pitch*h >= (w/gcd(w,16)) * (h/gcd(h,16)) * sizeof(kfx_lss6); `debug` (float4, may
+ * be NULL) receives the reference's per-pixel debug colours.  Blocks until the result is in *out. */
+int kfx_icp_point_plane(const kfx_image* Pl, const kfx_image* Pr, const kfx_image* Nr, const float KT_lr[12],
+                        const float T_rl[12], float c, const kfx_image* workspace, const kfx_image* debug,
+                        kfx_lss6* out, kfx_stream stream);
+
 /* ---- multi-GPU raycast composite (no reference counterpart) ------------------------
  * Per-pixel glue around the two collectives of kangaroo_amd/pipeline.py::SlabPipeline.composite:
  *   pack:   key[v*w+u] = (bits(depth or +inf) << 8) | rank                    then all_reduce(MIN, key)

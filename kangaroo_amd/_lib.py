@@ -23,6 +23,11 @@ class KfxVolume(C.Structure):
                 ("boxmin", C.c_float * 3), ("boxmax", C.c_float * 3)]
 
 
+class KfxLss6(C.Structure):
+    """roo::LeastSquaresSystem<float,6> (Mat.h:483-520)."""
+    _fields_ = [("JTy", C.c_float * 6), ("JTJ", C.c_float * 21), ("sqErr", C.c_float), ("obs", C.c_uint)]
+
+
 class KfxSlab(C.Structure):
     """kfx_slab (include/kfx.h): Z-slab of a larger volume."""
     _fields_ = [("full_d", C.c_size_t), ("z_offset", C.c_size_t), ("full_zmin", C.c_float), ("full_zmax", C.c_float)]
@@ -59,6 +64,7 @@ SIGNATURES = {
     "kfx_raycast_sdf_slab": (C.c_int, [C.c_void_p, C.c_int, PV, C.POINTER(KfxSlab), C.c_int, C.c_int, C.c_int, C.c_int, PF, PF,
                                        C.c_float, C.c_float, C.c_float, C.c_int, C.c_void_p]),
     "kfx_raycast_state_to_images": (C.c_int, [PI, PI, PI, C.c_void_p, C.c_void_p]),
+    "kfx_icp_point_plane": (C.c_int, [PI, PI, PI, PF, PF, C.c_float, PI, PI, C.POINTER(KfxLss6), C.c_void_p]),
     "kfx_composite_pack": (C.c_int, [PI, PI, PI, C.c_void_p, C.c_int, C.c_void_p]),
     "kfx_composite_select": (C.c_int, [PI, PI, PI, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "kfx_composite_unpack": (C.c_int, [PI, PI, PI, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -79,6 +79,71 @@ class FramePipeline:
         self.raycast(T_wc)
 
 
+class TrackingPipeline(FramePipeline):
+    """The reference application's loop with pose estimation switched on (main.cpp:200-356): depth pyramid,
+    per-level vertex / normal maps, raycast of the model at the last pose on every level that has ICP
+    iterations, coarse-to-fine projective point-plane ICP (kangaroo_amd/tracking.py around the HIP operator),
+    then SdfFuse at the refined pose when tracking is good."""
+
+    LEVELS = 4
+
+    def __init__(self, ops, dims, boxmin, boxmax, w, h, its=None, icp_c=0.1, max_rmse=0.10, **kw):
+        from . import tracking
+        super().__init__(ops, dims, boxmin, boxmax, w, h, **kw)
+        self.tracking = tracking
+        self.its = tuple(tracking.DEFAULT_ITS if its is None else its)
+        self.icp_c, self.max_rmse = float(icp_c), float(max_rmse)
+        L = self.LEVELS
+        P = ops.Pyramid
+        self.kin_d, self.kin_v, self.kin_n = P(w, h, L, "f32"), P(w, h, L, "f32x4"), P(w, h, L, "f32x4")
+        self.pyr_d, self.pyr_i = P(w, h, L, "f32"), P(w, h, L, "f32")
+        self.pyr_n, self.pyr_v = P(w, h, L, "f32x4"), P(w, h, L, "f32x4")
+        self.K_levels = [scenes.intrinsics_level(self.K, l) for l in range(L)]
+        # main.cpp:110-111: debug image and a scratch image of w * sizeof(LeastSquaresSystem<float,12>) x h bytes
+        self.debug = ops.Image(w, h, "f32x4")
+        self.scratch = ops.Image(w * 232, h, "u8")
+        self.T_wl = np.eye(4)
+        self.frame = 0
+        self.rmse, self.tracking_good = 0.0, True
+
+    def preprocess(self, raw_image=None):
+        o = self.ops
+        src = self.raw if raw_image is None else raw_image
+        o.BilateralFilter(self.kin_d[0], src, self.bil["gs"], self.bil["gr"], self.bil["size"], self.bil["minval"])
+        o.BoxReduceIgnoreInvalid(self.kin_d)
+        for l in range(self.LEVELS):
+            o.DepthToVbo(self.kin_v[l], self.kin_d[l], self.K_levels[l])
+            o.NormalsFromVbo(self.kin_n[l], self.kin_v[l])
+
+    def step(self, T_wl_init=None, raw_image=None):
+        """One frame.  The first frame is fused at T_wl_init (identity if None); later frames are tracked
+        against the model.  Returns the current T_wl (4x4 float64)."""
+        o, tr = self.ops, self.tracking
+        self.preprocess(raw_image)
+        if self.frame == 0:
+            if T_wl_init is not None:
+                self.T_wl = np.vstack([np.asarray(T_wl_init, np.float64).reshape(3, 4), [0, 0, 0, 1]])
+            self._fuse_at(self.T_wl)
+        else:
+            T34 = self.T_wl[:3].astype(np.float32)
+            for l in range(self.LEVELS):
+                if self.its[l] > 0:
+                    o.RaycastSdf(self.pyr_d[l], self.pyr_n[l], self.pyr_i[l], self.vol, T34, self.K_levels[l], self.near,
+                                 self.far, self.trunc, True)
+                    o.DepthToVbo(self.pyr_v[l], self.pyr_d[l], self.K_levels[l])
+            T_lp, self.rmse, self.tracking_good = tr.refine_pose(o, self.kin_v, self.pyr_v, self.pyr_n, self.K_levels,
+                                                                 self.scratch, self.debug, self.its, self.icp_c, self.max_rmse)
+            if self.tracking_good:
+                self.T_wl = self.T_wl @ tr.se3_inv(T_lp)
+                self._fuse_at(self.T_wl)
+        self.frame += 1
+        return self.T_wl
+
+    def _fuse_at(self, T_wl):
+        T_cw = self.tracking.se3_inv(T_wl)[:3].astype(np.float32)
+        self.ops.SdfFuse(self.vol, self.kin_d[0], self.kin_n[0], T_cw, self.K, self.trunc, self.max_w, self.mincostheta)
+
+
 def slab_range(d, rank, world):
     """Z-planes [z0, z1) owned by `rank`: contiguous, sizes differ by at most one plane."""
     base, rem = divmod(d, world)

@@ -374,3 +374,32 @@ def RaycastSdfSlab(state, init, vol, slab, own_lo, own_hi, w, h, T_wc, K, near, 
 def RaycastStateToImages(depth, norm, img, state, stream=None):
     """kfx_raycast_state_to_images: final march state -> depth / normal / shade images."""
     _lib.check(_lib.load().kfx_raycast_state_to_images(depth.ref(), norm.ref(), img.ref(), C.c_void_p(state.data_ptr()), _stream(stream)))
+
+
+class LeastSquaresSystem:
+    """roo::LeastSquaresSystem<float,6> (Mat.h:483-520) on the host: JTy (6,), JTJ expanded to the symmetric
+    6x6 matrix (SymMat -> Mat conversion, Mat.h:359-372), sqErr, obs; `raw` keeps the 21 unique elements."""
+
+    def __init__(self, JTy, JTJ21, sqErr, obs):
+        self.JTy = np.array(JTy, np.float32)
+        self.raw = np.array(JTJ21, np.float32)
+        self.JTJ = np.zeros((6, 6), np.float32)
+        i = 0
+        for r in range(6):
+            for c in range(r + 1):
+                self.JTJ[r, c] = self.JTJ[c, r] = self.raw[i]
+                i += 1
+        self.sqErr = np.float32(sqErr)
+        self.obs = int(obs)
+
+
+def PoseRefinementProjectiveIcpPointPlane(dPl, dPr, dNr, KT_lr, T_rl, c, dWorkspace, dDebug=None, stream=None):
+    """cu_model_refinement.h:58-64 -> kfx_icp_point_plane.  dPl: live vertex map, dPr / dNr: model vertex map and
+    normals (float4 images), dWorkspace: u8 image of >= (w/gcd(w,16))*(h/gcd(h,16))*116 bytes, dDebug: float4 image
+    or None.  Returns the summed LeastSquaresSystem (blocking, as the reference's thrust::reduce is)."""
+    kt, _kt = _fp(KT_lr, 12)
+    t, _t = _fp(T_rl, 12)
+    out = _lib.KfxLss6()
+    _lib.check(_lib.load().kfx_icp_point_plane(dPl.ref(), dPr.ref(), dNr.ref(), kt, t, c, dWorkspace.ref(),
+                                               dDebug.ref() if dDebug is not None else None, C.byref(out), _stream(stream)))
+    return LeastSquaresSystem(list(out.JTy), list(out.JTJ), out.sqErr, out.obs)

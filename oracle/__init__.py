@@ -29,6 +29,10 @@ class KfoSlab(C.Structure):
     _fields_ = [("full_d", C.c_size_t), ("z_offset", C.c_size_t), ("full_zmin", C.c_float), ("full_zmax", C.c_float)]
 
 
+class KfoLss6(C.Structure):
+    _fields_ = [("JTy", C.c_float * 6), ("JTJ", C.c_float * 21), ("sqErr", C.c_float), ("obs", C.c_uint)]
+
+
 class KfoRaycastStats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("steps", C.c_uint64), ("hits", C.c_uint64)]
 
@@ -72,6 +76,10 @@ def lib():
         L.kfo_raycast_sdf_slab.argtypes = [C.c_void_p, C.c_int, PV, C.POINTER(KfoSlab), C.c_int, C.c_int, C.c_int, C.c_int, PF, PF,
                                            C.c_float, C.c_float, C.c_float, C.c_int]
         L.kfo_raycast_sdf_slab.restype = None
+        L.kfo_icp_point_plane.argtypes = [PI, PI, PI, PF, PF, C.c_float, PI, C.POINTER(KfoLss6), C.c_void_p]
+        L.kfo_icp_point_plane.restype = None
+        L.kfo_icp_block_dims.argtypes = [C.c_size_t, C.c_size_t, C.POINTER(C.c_uint)]
+        L.kfo_icp_block_dims.restype = None
         L.kfo_sdf_fuse_h.argtypes = L.kfo_sdf_fuse.argtypes
         L.kfo_sdf_fuse_h.restype = C.c_uint64
         L.kfo_raycast_sdf_h.argtypes = L.kfo_raycast_sdf.argtypes
@@ -397,3 +405,28 @@ def raycast_sdf_slab(state, init, vol, slab, own_lo, own_hi, w, h, T_wc, K, near
     sl = KfoSlab(int(slab[0]), int(slab[1]), float(slab[2]), float(slab[3]))
     lib().kfo_raycast_sdf_slab(state.ctypes.data, 1 if init else 0, vol.ref(), C.byref(sl), own_lo, own_hi, w, h, t, k,
                                near, far, trunc, 1 if subpix else 0)
+
+
+LSS_DTYPE = np.dtype([("JTy", np.float32, 6), ("JTJ", np.float32, 21), ("sqErr", np.float32), ("obs", np.uint32)])
+
+
+def icp_block_dims(w, h):
+    out = (C.c_uint * 4)()
+    lib().kfo_icp_block_dims(w, h, out)
+    return tuple(out)
+
+
+def icp_point_plane(Pl, Pr, Nr, KT_lr, T_rl, c, debug=None, want_blocks=False, fn=None):
+    """PoseRefinementProjectiveIcpPointPlane: returns the summed system as a LSS_DTYPE scalar (and the
+    per-block systems when want_blocks).  `fn` swaps in another implementation with the same C signature
+    (the reference-header harness)."""
+    _, kt = _fp(KT_lr)
+    _, t = _fp(T_rl)
+    out = KfoLss6()
+    bx, by, gx, gy = icp_block_dims(Pl.w, Pl.h)
+    blocks = np.zeros(gx * gy, LSS_DTYPE) if want_blocks else None
+    f = lib().kfo_icp_point_plane if fn is None else fn
+    f(Pl.ref(), Pr.ref(), Nr.ref(), kt, t, C.c_float(c), debug.ref() if debug is not None else None, C.byref(out),
+      blocks.ctypes.data if blocks is not None else None)
+    res = np.frombuffer(bytes(out), LSS_DTYPE)[0]
+    return (res, blocks) if want_blocks else res

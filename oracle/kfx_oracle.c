@@ -892,3 +892,103 @@ void kfo_raycast_sdf_slab(float* state, int init, const kfo_volume* vol, const k
             st[4 * P] = (lambda != lambda_in || status != status_in) ? 1.0f : 0.0f;
         }
 }
+
+/* ============================================================================
+ * Projective point-to-plane ICP: cu_model_refinement.cu:541-608.
+ * Per-pixel system as KernPoseRefinementProjectiveIcpPointPlane builds it, block sum in the order of
+ * SumLeastSquaresSystem::ReducePutBlock (LeastSquareSum.h:71-85: s[t] += s[t+S], S = n/2 .. 1), block
+ * geometry of InitDimFromOutputImage(dPl, 16, 16) (launch_utils.h:61-65).  The reference sums the blocks
+ * with thrust::reduce (order unspecified); the order fixed here is the one the HIP path uses: 256 partial
+ * sums, partial t = 0 + block t + block t+256 + ..., then the same tree over the 256 partials.
+ * ========================================================================== */
+static void lss_add(kfo_lss6* a, const kfo_lss6* b) /* LeastSquaresSystem::operator+= (Mat.h:496-504) */
+{
+    for (int i = 0; i < 6; ++i) a->JTy[i] += b->JTy[i];
+    for (int i = 0; i < 21; ++i) a->JTJ[i] += b->JTJ[i];
+    a->sqErr += b->sqErr;
+    a->obs += b->obs;
+}
+static void lss_tree(kfo_lss6* s, unsigned n)
+{
+    for (unsigned S = n / 2; S > 0; S >>= 1)
+        for (unsigned t = 0; t < S; ++t) lss_add(&s[t], &s[t + S]);
+}
+static unsigned gcd_u(unsigned a, unsigned b) { return b == 0 ? a : gcd_u(b, a % b); }
+
+void kfo_icp_block_dims(size_t w, size_t h, unsigned out[4])
+{
+    out[0] = gcd_u((unsigned)w, 16);
+    out[1] = gcd_u((unsigned)h, 16);
+    out[2] = (unsigned)(w / out[0]);
+    out[3] = (unsigned)(h / out[1]);
+}
+
+void kfo_icp_point_plane(const kfo_image* Pl, const kfo_image* Pr_img, const kfo_image* Nr_img, const float KT_lr[12],
+                         const float T_rl[12], float c, const kfo_image* debug, kfo_lss6* out, kfo_lss6* block_sums)
+{
+    unsigned g[4];
+    memset(out, 0, sizeof(*out));
+    if (Pl->w == 0 || Pl->h == 0) return;
+    kfo_icp_block_dims(Pl->w, Pl->h, g);
+    const unsigned bx = g[0], by = g[1], gx = g[2], gy = g[3], n = bx * by;
+    kfo_lss6 partial[256];
+    memset(partial, 0, sizeof(partial));
+    for (unsigned bj = 0; bj < gy; ++bj)
+        for (unsigned bi = 0; bi < gx; ++bi) {
+            kfo_lss6 s[256];
+            memset(s, 0, sizeof(s)); /* ZeroThisObs */
+            for (unsigned ty = 0; ty < by; ++ty)
+                for (unsigned tx = 0; tx < bx; ++tx) {
+                    const unsigned u = bi * bx + tx, v = bj * by + ty;
+                    kfo_lss6* sum = &s[ty * bx + tx];
+                    const f4 Pr = *((const f4*)((const unsigned char*)Pr_img->ptr + (size_t)v * Pr_img->pitch) + u);
+                    const f4 Nr = *((const f4*)((const unsigned char*)Nr_img->ptr + (size_t)v * Nr_img->pitch) + u);
+                    const f3 KPl = se3_mul(KT_lr, mk3(Pr.x, Pr.y, Pr.z));
+                    const float plx = KPl.x / KPl.z, ply = KPl.y / KPl.z; /* dn(): Mat.h:623-627 */
+                    f4 dbg;
+                    if (isfinite(Pr.z) && Nr.w == 1.0f && 3.0f <= plx && plx < ((float)Pl->w - 3.0f) && 3.0f <= ply &&
+                        ply < ((float)Pl->h - 3.0f)) { /* Image::InBounds(pl, 3), Image.h:288-291 */
+                        /* GetNearestNeighbour = Get(u + 0.5, v + 0.5): double sum truncated to int (Image.h:337-340) */
+                        const int nx = (int)((double)plx + 0.5), ny = (int)((double)ply + 0.5);
+                        const f4 P = *((const f4*)((const unsigned char*)Pl->ptr + (size_t)ny * Pl->pitch) + nx);
+                        if (isfinite(P.z)) {
+                            const f3 _Pr = se3_mul(T_rl, mk3(P.x, P.y, P.z));
+                            const f3 Dr = mk3(_Pr.x - Pr.x, _Pr.y - Pr.y, _Pr.z - Pr.z);
+                            const f3 N = mk3(Nr.x, Nr.y, Nr.z);
+                            const float y = dot3(Dr, N);
+                            float J[6]; /* -dot(SE3gen_i mul _Pr, Nr): MatUtils.h:379-402 */
+                            J[0] = -dot3(mk3(1.f, 0.f, 0.f), N);
+                            J[1] = -dot3(mk3(0.f, 1.f, 0.f), N);
+                            J[2] = -dot3(mk3(0.f, 0.f, 1.f), N);
+                            J[3] = -dot3(mk3(0.f, -_Pr.z, _Pr.y), N);
+                            J[4] = -dot3(mk3(_Pr.z, 0.f, -_Pr.x), N);
+                            J[5] = -dot3(mk3(-_Pr.y, _Pr.x, 0.f), N);
+                            const float absr = fabsf(y); /* LSReweightTukey, reweighting.h:22-28 */
+                            const float roc = y / c;
+                            const float omroc2 = 1.0f - roc * roc;
+                            const float tukey = (absr <= c) ? omroc2 * omroc2 : 0.0f;
+                            const float w = (1.0f / Pr.z) * tukey;
+                            const float yw = y * w;
+                            int i = 0;
+                            for (int r = 0; r < 6; ++r) sum->JTy[r] = J[r] * yw;          /* mul_aTb, Mat.h:263-275 */
+                            for (int r = 0; r < 6; ++r)
+                                for (int cc = 0; cc <= r; ++cc) sum->JTJ[i++] = J[r] * J[cc] * w; /* OuterProduct, Mat.h:457-468 */
+                            sum->obs = 1;
+                            sum->sqErr = y * y;
+                            dbg.x = dbg.y = dbg.z = absr; dbg.w = 1.f;
+                        } else {
+                            dbg.x = 0.f; dbg.y = 0.f; dbg.z = 1.f; dbg.w = 1.f;
+                        }
+                    } else {
+                        dbg.x = 1.f; dbg.y = 0.f; dbg.z = 0.f; dbg.w = 1.f;
+                    }
+                    if (debug && debug->ptr) *((f4*)((unsigned char*)debug->ptr + (size_t)v * debug->pitch) + u) = dbg;
+                }
+            lss_tree(s, n);
+            const unsigned bid = bj * gx + bi;
+            if (block_sums) block_sums[bid] = s[0];
+            lss_add(&partial[bid % 256], &s[0]);
+        }
+    lss_tree(partial, 256);
+    *out = partial[0];
+}

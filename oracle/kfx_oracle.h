@@ -90,6 +90,18 @@ typedef struct kfo_slab {
 uint64_t kfo_sdf_fuse_slab(const kfo_volume* vol, const kfo_slab* slab, const kfo_image* depth, const kfo_image* norm,
                            const float T_cw[12], const float K[4], float trunc, float max_w,
                            float mincostheta, int full_extent, int nthreads);
+/* roo::LeastSquaresSystem<float,6> (Mat.h:483-520) */
+typedef struct kfo_lss6 {
+    float JTy[6];
+    float JTJ[21]; /* lower triangle, row-major (Mat.h:353-365) */
+    float sqErr;
+    unsigned obs;
+} kfo_lss6;
+/* cu_model_refinement.cu:541-608 + LeastSquareSum.h:71-85; block_sums (may be NULL): one system per 16x16 block */
+void kfo_icp_block_dims(size_t w, size_t h, unsigned out[4]);
+void kfo_icp_point_plane(const kfo_image* Pl, const kfo_image* Pr, const kfo_image* Nr, const float KT_lr[12],
+                         const float T_rl[12], float c, const kfo_image* debug, kfo_lss6* out, kfo_lss6* block_sums);
+
 /* One round of the exact multi-GPU march (state carried across Z-slabs); see kfx_oracle.c */
 void kfo_raycast_sdf_slab(float* state, int init, const kfo_volume* vol, const kfo_slab* slab, int own_lo, int own_hi,
                           int w, int h, const float T_wc[12], const float K[4], float near, float far,

@@ -22,8 +22,13 @@
 #include <kangaroo/Image.h>
 #include <kangaroo/ImageIntrinsics.h>
 #include <kangaroo/InvalidValue.h>
+#include <kangaroo/Mat.h>
 #include <kangaroo/MatUtils.h>
 #include <kangaroo/Sdf.h>
+#include <kangaroo/launch_utils.h>
+#include <kangaroo/reweighting.h>
+
+#include <cstring>
 
 #include "kfx_oracle.h"
 
@@ -256,4 +261,71 @@ void ref_sdf_accumulate(float val, float w, float old_val, float old_w, float ma
     out[0] = s.val; out[1] = s.w;
 }
 
-} // extern "C"
+// Projective point-to-plane ICP: the body of KernPoseRefinementProjectiveIcpPointPlane
+// (cu_model_refinement.cu:541-593) with every arithmetic step a call into the reference's headers
+// (Mat*float4, dn, InBounds, GetNearestNeighbour, float3-float4, dot, SE3gen*mul, LSReweightTukey,
+// OuterProduct, mul_aTb) and the sums taken with LeastSquaresSystem::operator+= in ReducePutBlock's order
+// (LeastSquareSum.h:71-85; that header itself needs thrust and is not included).  Block geometry as
+// InitDimFromOutputImage(dPl,16,16); blocks are then summed in the order documented in kfx_oracle.c.
+void ref_icp_point_plane(const kfo_image* pPl, const kfo_image* pPr, const kfo_image* pNr, const float* kt, const float* trl,
+                         float c, const kfo_image* pdbg, kfo_lss6* out, kfo_lss6* block_sums)
+{
+    typedef LeastSquaresSystem<float, 6> LSS;
+    static_assert(sizeof(LSS) == sizeof(kfo_lss6), "LeastSquaresSystem<float,6> layout");
+    HImgF4 dPl = imf4(pPl), dPr = imf4(pPr), dNr = imf4(pNr);
+    HImgF4 dDebug = pdbg ? imf4(pdbg) : HImgF4();
+    const Mat<float, 3, 4> KT_lr = mkT(kt), T_rl = mkT(trl);
+    const unsigned bx = Gcd<unsigned>(dPl.w, 16), by = Gcd<unsigned>(dPl.h, 16);
+    const unsigned gx = dPl.w / bx, gy = dPl.h / by, n = bx * by;
+    LSS partial[256];
+    for (int i = 0; i < 256; ++i) partial[i].SetZero();
+    for (unsigned bj = 0; bj < gy; ++bj)
+        for (unsigned bi = 0; bi < gx; ++bi) {
+            LSS sReduce[256];
+            for (unsigned ty = 0; ty < by; ++ty)
+                for (unsigned tx = 0; tx < bx; ++tx) {
+                    const unsigned u = bi * bx + tx, v = bj * by + ty;
+                    LSS& sum = sReduce[ty * bx + tx];
+                    sum.SetZero();
+                    const float4 Pr = dPr(u, v);
+                    const float4 Nr = dNr(u, v);
+                    const float3 KPl = KT_lr * Pr;
+                    const float2 pl = dn(KPl);
+                    float4 dbg;
+                    if (std::isfinite(Pr.z) && Nr.w == 1.0f && dPl.InBounds(pl, 3)) {
+                        const float4 _Pl = dPl.GetNearestNeighbour(pl);
+                        if (std::isfinite(_Pl.z)) {
+                            const float3 _Pr = T_rl * _Pl;
+                            const float3 Dr = _Pr - Pr;
+                            const float DrDotNr = dot(Dr, Nr);
+                            const float y = DrDotNr;
+                            const Mat<float, 1, 6> Jr = {
+                                -dot(SE3gen0mul(_Pr), Nr), -dot(SE3gen1mul(_Pr), Nr), -dot(SE3gen2mul(_Pr), Nr),
+                                -dot(SE3gen3mul(_Pr), Nr), -dot(SE3gen4mul(_Pr), Nr), -dot(SE3gen5mul(_Pr), Nr)};
+                            const float w = (1.0f / Pr.z) * LSReweightTukey(y, c);
+                            sum.JTJ = OuterProduct(Jr, w);
+                            sum.JTy = mul_aTb(Jr, y * w);
+                            sum.obs = 1;
+                            sum.sqErr = y * y;
+                            const float db = fabs(y);
+                            dbg = make_float4(db, db, db, 1);
+                        } else {
+                            dbg = make_float4(0, 0, 1, 1);
+                        }
+                    } else {
+                        dbg = make_float4(1, 0, 0, 1);
+                    }
+                    if (pdbg) dDebug(u, v) = dbg;
+                }
+            for (unsigned S = n / 2; S > 0; S >>= 1)
+                for (unsigned tid = 0; tid < S; ++tid) sReduce[tid] += sReduce[tid + S];
+            const unsigned bid = bj * gx + bi;
+            if (block_sums) memcpy(&block_sums[bid], &sReduce[0], sizeof(LSS));
+            partial[bid % 256] += sReduce[0];
+        }
+    for (unsigned S = 128; S > 0; S >>= 1)
+        for (unsigned tid = 0; tid < S; ++tid) partial[tid] += partial[tid + S];
+    memcpy(out, &partial[0], sizeof(LSS));
+}
+
+}

@@ -21,6 +21,15 @@ class Image(oracle.Image):
         self.data[...] = arr
         return self
 
+    def SubImage(self, x, y, w, h):
+        """Top-left sub-rectangle sharing the parent's storage (only x = y = 0 is needed by the pipelines)."""
+        assert x == 0 and y == 0 and w <= self.w and h <= self.h
+        sub = Image.__new__(Image)
+        sub.__dict__.update(self.__dict__)
+        sub.w, sub.h = int(w), int(h)
+        sub.data = self.data[:h, :w]
+        return sub
+
     def MemcpyToHost(self):
         return self.data.copy()
 
@@ -97,3 +106,41 @@ def RaycastStateToImages(depth, norm, img, state):
     img.data[...] = np.where(hit, st[8], np.float32(0))
     n = np.stack([st[5], st[6], st[7], np.ones_like(st[0])], axis=-1)
     norm.data[...] = np.where(hit[..., None], n, np.float32(0))
+
+
+class LeastSquaresSystem:
+    def __init__(self, rec):
+        self.JTy = np.array(rec["JTy"], np.float32)
+        self.raw = np.array(rec["JTJ"], np.float32)
+        self.JTJ = np.zeros((6, 6), np.float32)
+        i = 0
+        for r in range(6):
+            for c in range(r + 1):
+                self.JTJ[r, c] = self.JTJ[c, r] = self.raw[i]
+                i += 1
+        self.sqErr = np.float32(rec["sqErr"])
+        self.obs = int(rec["obs"])
+
+
+def PoseRefinementProjectiveIcpPointPlane(dPl, dPr, dNr, KT_lr, T_rl, c, dWorkspace=None, dDebug=None):
+    return LeastSquaresSystem(oracle.icp_point_plane(dPl, dPr, dNr, KT_lr, T_rl, c, dDebug))
+
+
+class Pyramid:
+    def __init__(self, w, h, levels, kind="f32"):
+        self.imgs = [Image(w >> l, h >> l, kind) for l in range(levels) if (w >> l) > 0 and (h >> l) > 0]
+
+    def __getitem__(self, l):
+        return self.imgs[l]
+
+    def __len__(self):
+        return len(self.imgs)
+
+
+def BoxHalfIgnoreInvalid(out, inp):
+    oracle.box_half_ignore_invalid(out, inp)
+
+
+def BoxReduceIgnoreInvalid(pyramid):
+    for l in range(1, len(pyramid)):
+        BoxHalfIgnoreInvalid(pyramid[l], pyramid[l - 1])

@@ -40,6 +40,43 @@ def test_reference_signatures_are_declared_verbatim():
             in open(os.path.join(inc, "cu_depth_tools.h")).read())
 
 
+    icp = " ".join(open(os.path.join(inc, "cu_model_refinement.h")).read().split())
+    assert ("LeastSquaresSystem<float,6> PoseRefinementProjectiveIcpPointPlane( const Image<float4> dPl, const Image<float4> dPr, "
+            "const Image<float4> dNr, const Mat<float,3,4> KT_lr, const Mat<float,3,4> T_rl, float c, "
+            "Image<unsigned char> dWorkspace, Image<float4> dDebug )") in icp
+
+
+def test_host_pose_solve_matches_python():
+    """apps/pose_solve.h (C++) and kangaroo_amd/tracking.py (numpy) restate the same Eigen / Sophus steps."""
+    import numpy as np
+    from kangaroo_amd import tracking
+    src = r'''
+#include <cstdio>
+#include "pose_solve.h"
+int main() {
+    const double A[36] = {4,1,0,0,2,0, 1,5,1,0,0,0, 0,1,6,1,0,1, 0,0,1,7,1,0, 2,0,0,1,8,1, 0,0,1,0,1,9};
+    const double b[6] = {1,-2,3,-4,5,-6};
+    double x[6];
+    posesolve::FullPivLuSolve<6>(A, b, x);
+    for (int i = 0; i < 6; ++i) printf("%.17g\n", x[i]);
+    const double t[6] = {0.1,-0.2,0.3,0.2,-0.1,0.15};
+    posesolve::SE3d T = posesolve::Exp(t);
+    for (int i = 0; i < 3; ++i) printf("%.17g %.17g %.17g %.17g\n", T.R[i][0], T.R[i][1], T.R[i][2], T.t[i]);
+    return 0;
+}
+'''
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "t.cpp"), "w").write(src)
+        subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", APPS, os.path.join(d, "t.cpp"), "-o", os.path.join(d, "t")])
+        vals = [float(v) for v in subprocess.check_output([os.path.join(d, "t")], text=True).split()]
+    A = np.array([4,1,0,0,2,0, 1,5,1,0,0,0, 0,1,6,1,0,1, 0,0,1,7,1,0, 2,0,0,1,8,1, 0,0,1,0,1,9], float).reshape(6, 6)
+    x = tracking.full_piv_lu_solve(A, [1, -2, 3, -4, 5, -6])
+    assert np.allclose(vals[:6], x, rtol=1e-13, atol=1e-15)
+    Tm = tracking.se3_exp([0.1, -0.2, 0.3, 0.2, -0.1, 0.15])
+    assert np.allclose(np.array(vals[6:]).reshape(3, 4), Tm[:3], rtol=1e-13, atol=1e-15)
+
+
 @pytest.mark.gpu
 def test_cpp_api_on_device():
     _build()
@@ -48,7 +85,7 @@ def test_cpp_api_on_device():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("extra", [[], ["--fast"]])
+@pytest.mark.parametrize("extra", [[], ["--fast"], ["--track"]])
 def test_headless_kinectfusion_app(extra):
     _build()
     out = subprocess.run([os.path.join(APPS, "kinectfusion_headless"), "--res", "128", "--frames", "8"] + extra,

@@ -700,3 +700,78 @@ def test_gpu_exact_slab_raycast_rounds(roo, world, ghost):
     assert T.nan_equal(gd.MemcpyToHost(), want[0]), T.mismatch_report(gd.MemcpyToHost(), want[0])
     assert T.nan_equal(gn.MemcpyToHost(), want[1]), T.mismatch_report(gn.MemcpyToHost(), want[1])
     assert T.nan_equal(gi.MemcpyToHost(), want[2]), T.mismatch_report(gi.MemcpyToHost(), want[2])
+
+
+# ---------------------------------------------------------------------------------
+# projective point-plane ICP
+# ---------------------------------------------------------------------------------
+@pytest.mark.parametrize("w,h,holes", [(640, 480, True), (160, 120, False), (80, 60, True), (20, 15, True), (96, 72, True),
+                                       (16, 16, False), (48, 3, True)])
+def test_gpu_icp_point_plane_vs_oracle(roo, w, h, holes):
+    """kfx_icp_point_plane against the oracle: the summed system, every per-block system left in the
+    workspace and the debug image are bit-identical (block tree in the reference's order, fixed final order)."""
+    import test_tracking_cpu as TT
+    from kangaroo_amd import tracking
+    K, Pl, Pr, Nr, _, _ = TT.icp_inputs("room", w, h, holes)
+    T_lp = tracking.se3_exp([0.004, -0.003, 0.002, 0.003, -0.002, 0.001])
+    KT = (tracking.k_matrix(K) @ T_lp[:3]).astype(np.float32)
+    T_pl = tracking.se3_inv(T_lp)[:3].astype(np.float32)
+    odbg = oracle.Image(w, h, channels=4)
+    want, blocks = oracle.icp_point_plane(Pl, Pr, Nr, KT, T_pl, 0.1, odbg, want_blocks=True)
+    gPl, gPr, gNr = T.upload_image(roo, Pl.data), T.upload_image(roo, Pr.data), T.upload_image(roo, Nr.data)
+    ws = roo.Image(116 * max(len(blocks), 1), 1, "u8")
+    dbg = roo.Image(w, h, "f32x4")
+    got = roo.PoseRefinementProjectiveIcpPointPlane(gPl, gPr, gNr, KT, T_pl, 0.1, ws, dbg)
+    assert got.obs == int(want["obs"]) and (w < 64 or got.obs > 0)
+    assert got.JTy.tobytes() == want["JTy"].tobytes() and got.raw.tobytes() == want["JTJ"].tobytes()
+    assert got.sqErr.tobytes() == want["sqErr"].tobytes()
+    assert T.nan_equal(dbg.MemcpyToHost(), odbg.data)
+    left = np.frombuffer(ws.MemcpyToHost().tobytes()[:116 * len(blocks)], oracle.LSS_DTYPE)
+    assert left[1:].tobytes() == blocks[1:].tobytes()       # slot 0 holds the final sum
+    assert left[0].tobytes() == want.tobytes()
+    # the debug image is optional
+    again = roo.PoseRefinementProjectiveIcpPointPlane(gPl, gPr, gNr, KT, T_pl, 0.1, ws, None)
+    assert again.raw.tobytes() == got.raw.tobytes() and again.obs == got.obs
+
+
+def test_gpu_icp_argument_errors_and_tracking_loop(roo):
+    import oracle_ops
+    import test_tracking_cpu as TT
+    from kangaroo_amd import tracking
+    from kangaroo_amd._lib import KfxError
+    w, h = 160, 120
+    K = scenes.intrinsics(w, h)
+    T_wp, T_wl = scenes.orbit_pose(0, 60), scenes.orbit_pose(1, 60)
+    _, ray_v, ray_n, Ks = TT.pyramid_maps("room", w, h, T_wp, K)
+    _, kin_v, _, _ = TT.pyramid_maps("room", w, h, T_wl, K)
+    up = lambda imgs: [T.upload_image(roo, im.data) for im in imgs]
+    g_kin, g_rv, g_rn = up(kin_v), up(ray_v), up(ray_n)
+    small = roo.Image(115, 1, "u8")
+    with pytest.raises(KfxError):
+        roo.PoseRefinementProjectiveIcpPointPlane(g_kin[3], g_rv[3], g_rn[3], np.eye(4)[:3], np.eye(4)[:3], 0.1, small)
+    with pytest.raises(KfxError):   # dPr smaller than dPl
+        roo.PoseRefinementProjectiveIcpPointPlane(g_kin[0], g_rv[1], g_rn[0], np.eye(4)[:3], np.eye(4)[:3], 0.1, roo.Image(1 << 16, 1, "u8"))
+    ws = roo.Image(w * 232, h, "u8")          # main.cpp:111: w * sizeof(LeastSquaresSystem<float,12>) x h
+    dbg = roo.Image(w, h, "f32x4")
+    got = tracking.refine_pose(roo, g_kin, g_rv, g_rn, Ks, ws, dbg)
+    want = tracking.refine_pose(oracle_ops, kin_v, ray_v, ray_n, Ks, None)
+    assert np.array_equal(got[0], want[0]) and got[1] == want[1] and got[2] == want[2]
+    truth = tracking.se3_inv(np.vstack([T_wl, [0, 0, 0, 1]])) @ np.vstack([T_wp, [0, 0, 0, 1]])
+    assert np.linalg.norm((tracking.se3_inv(truth) @ got[0])[:3, 3]) < 0.2 * np.linalg.norm(truth[:3, 3])
+
+
+def test_gpu_tracking_pipeline_follows_the_orbit(roo):
+    """End-to-end tracked KinectFusion on the GPU (no pose given after frame 0) at the application's image size."""
+    from kangaroo_amd.pipeline import TrackingPipeline
+    N, w, h, frames = 128, 640, 480, 8
+    bmin, bmax, near, far = scenes.SCENES["room"]
+    pipe = TrackingPipeline(roo, (N, N, N), bmin, bmax, w, h, near=near, far=far)
+    worst = 0.0
+    for i in range(frames):
+        T_true = scenes.orbit_pose(i, 30)
+        pipe.raw.MemcpyFromHost(scenes.render_depth("room", w, h, T_true, pipe.K))
+        T_est = pipe.step(T_wl_init=T_true if i == 0 else None)
+        assert pipe.tracking_good and np.isfinite(pipe.rmse)
+        worst = max(worst, float(np.linalg.norm(T_est[:3, 3] - T_true[:3, 3])))
+    drift_if_static = float(np.linalg.norm(scenes.orbit_pose(frames - 1, 30)[:3, 3] - scenes.orbit_pose(0, 30)[:3, 3]))
+    assert worst < 0.2 * drift_if_static, (worst, drift_if_static)
