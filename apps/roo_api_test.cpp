@@ -176,6 +176,43 @@ int main()
     if (work.IsValid()) SdfFuse(work, dd, nrm, SE3inv(T_wc), K, 0.1f, 100.0f, 0.1f);
     CHECK(kfx_stream_synchronize(0) == 0);
 
+    // ---- colour path: SdfReset(BoundedVolume<float>), colour SdfFuse and colour RaycastSdf ----
+    {
+        CHECK(sizeof(uchar3) == 3 && sizeof(Image<uchar3>) == 32 && sizeof(BoundedVolume<float>) == 72);
+        BoundedVolume<SDF_t, TargetDevice, Manage> cv(N, N, N, make_float3(-1, -1, 2), make_float3(1, 1, 4));
+        BoundedVolume<float, TargetDevice, Manage> colorVol(N, N, N, make_float3(-1, -1, 2), make_float3(1, 1, 4));
+        BoundedVolume<float, TargetHost, Manage> hcol(N, N, N, make_float3(-1, -1, 2), make_float3(1, 1, 4));
+        SdfReset(cv, NAN);
+        SdfReset(colorVol);
+        Image<uchar3, TargetDevice, Manage> rgb(w, h);
+        std::vector<uchar3> hrgb((size_t)w * h);
+        for (auto& px : hrgb) px = make_uchar3(51, 51, 51);            // grey 0.2
+        rgb.MemcpyFromHost(hrgb.data());
+        std::vector<float> flat((size_t)w * h, 3.0f);                   // a wall at z = 3 m
+        dd.MemcpyFromHost(flat.data());
+        DepthToVbo<float>(vbo, dd, K);
+        NormalsFromVbo(nrm, vbo);
+        const Mat<float,3,4> I = SE3Identity();
+        SdfFuse(cv, colorVol, dd, nrm, I, K, rgb, I, K, 0.3f, 100.0f, 0.1f);
+        CHECK(kfx_memcpy_2d(hcol.ptr, hcol.pitch, colorVol.ptr, colorVol.pitch, N * sizeof(float), (size_t)N * N, 2, 0) == 0);
+        int fused = 0, wrong = 0;
+        for (int z = 0; z < N; ++z)
+            for (int y = 0; y < N; ++y)
+                for (int x = 0; x < N; ++x) {
+                    const float c = hcol(x, y, z);
+                    if (c != 0.5f) { ++fused; if (std::fabs(c - 0.2f) > 1e-6f) ++wrong; }
+                }
+        CHECK(fused > N * N && wrong == 0);
+        RaycastSdf(depth, norm, img, cv, colorVol, I, K, 0.5f, 10.0f, 0.3f, true);
+        std::vector<float> hi((size_t)w * h), hdc((size_t)w * h);
+        img.MemcpyToHost(hi.data());
+        depth.MemcpyToHost(hdc.data());
+        int chit = 0, cbad = 0;
+        for (size_t i = 0; i < hi.size(); ++i)
+            if (std::isfinite(hdc[i])) { ++chit; if (std::fabs(hi[i] - 0.2f) > 1e-5f || std::fabs(hdc[i] - 3.0f) > 0.05f) ++cbad; }
+        CHECK(chit > w * h / 8 && cbad == 0);
+    }
+
     printf("roo_api_test: %s (%d ray hits checked)\n", g_fail ? "FAILED" : "all checks passed", nhit);
     return g_fail ? 1 : 0;
 }

@@ -19,6 +19,13 @@ void RaycastSdf(Image<float> depth, Image<float4> norm, Image<float> img, const 
 }
 
 
+// colour overload (reference cu_raycast.h:16-17, kernel cu_raycast.cu:119-196): img = colour volume sampled at the hit
+KANGAROO_EXPORT inline
+void RaycastSdf(Image<float> depth, Image<float4> norm, Image<float> img, const BoundedVolume<SDF_t> vol, const BoundedVolume<float> colorVol, const Mat<float,3,4> T_wc, ImageIntrinsics K, float near, float far, float trunc_dist, bool subpix = true)
+{
+    GpuCheckStatus(kfx_raycast_sdf_color(depth.abi(), norm.abi(), img.abi(), vol.abi(), colorVol.abi(), T_wc.m, &K.fu, near, far, trunc_dist, subpix ? 1 : 0, 0));
+}
+
 // fp16-cell overload (config C5)
 KANGAROO_EXPORT inline
 void RaycastSdf(Image<float> depth, Image<float4> norm, Image<float> img, const BoundedVolume<SDF_h> vol, const Mat<float,3,4> T_wc, ImageIntrinsics K, float near, float far, float trunc_dist, bool subpix = true)

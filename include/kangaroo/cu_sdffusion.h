@@ -25,6 +25,27 @@ void SdfReset(BoundedVolume<SDF_t> vol, float trunc_dist)
     GpuCheckStatus(kfx_sdf_reset(vol.abi(), trunc_dist, 0));
 }
 
+// colour fusion (reference cu_sdffusion.h:16-22, kernel cu_sdffusion.cu:70-138): colorVol holds grey levels in
+// [0,1]; img is the RGB frame of a camera at T_iw with intrinsics Kimg
+KANGAROO_EXPORT inline
+void SdfFuse(
+    BoundedVolume<SDF_t> vol, BoundedVolume<float> colorVol,
+    Image<float> depth, Image<float4> norm, Mat<float,3,4> T_cw, ImageIntrinsics K,
+    Image<uchar3> img, Mat<float,3,4> T_iw, ImageIntrinsics Kimg,
+    float trunc_dist, float max_w, float mincostheta
+)
+{
+    GpuCheckStatus(kfx_sdf_fuse_color(vol.abi(), colorVol.abi(), depth.abi(), norm.abi(), T_cw.m, &K.fu, img.abi(), T_iw.m, &Kimg.fu,
+                                      trunc_dist, max_w, mincostheta, 0, 0));
+}
+
+// SdfReset(BoundedVolume<float>) fills with 0.5 (cu_sdffusion.cu:166-169)
+KANGAROO_EXPORT inline
+void SdfReset(BoundedVolume<float> vol)
+{
+    GpuCheckStatus(kfx_color_reset(vol.abi(), 0));
+}
+
 // fp16-cell overloads (config C5)
 KANGAROO_EXPORT inline
 void SdfFuse(BoundedVolume<SDF_h> vol, Image<float> depth, Image<float4> norm, Mat<float,3,4> T_cw, ImageIntrinsics K, float trunc_dist, float maxw, float mincostheta )

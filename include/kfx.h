@@ -188,6 +188,25 @@ int kfx_memcpy_2d(void* dst, size_t dpitch, const void* src, size_t spitch, size
                   size_t rows, int kind, kfx_stream stream);
 int kfx_stream_synchronize(kfx_stream stream);
 
+/* ---- colour fusion / colour raycast ------------------------------------------
+ * `colorvol` is a roo::BoundedVolume<float> (4-byte grey cells in [0,1], same struct, same dims as `vol`);
+ * `img` a roo::Image<uchar3> (3-byte pixels).
+ * kfx_sdf_fuse_color: SdfFuse(vol, colorVol, depth, norm, T_cw, K, img, T_iw, Kimg, ...) (cu_sdffusion.cu:70-138) --
+ *   voxels whose projections fall inside both images get the SDF update of kfx_sdf_fuse and
+ *   colour = (w*c + colour*w_old) / (w + w_old), c = bilinear RGB mean / 255.  Extents as the reference's launch:
+ *   x, y truncated to multiples of 16, every z slice (KFX_FUSE_FULL_EXTENT lifts the truncation).  Always IEEE
+ *   arithmetic (no fast variant).
+ * kfx_raycast_sdf_color: RaycastSdf(depth, norm, img, vol, colorVol, ...) (cu_raycast.cu:119-196) -- as
+ *   kfx_raycast_sdf, but img = trilinear sample of the colour volume at the hit instead of the Phong shade.
+ * kfx_color_reset: SdfReset(BoundedVolume<float>) = Fill(0.5) including pitch padding (cu_sdffusion.cu:166-169). */
+int kfx_sdf_fuse_color(const kfx_volume* vol, const kfx_volume* colorvol, const kfx_image* depth, const kfx_image* norm,
+                       const float T_cw[12], const float K[4], const kfx_image* img, const float T_iw[12], const float Kimg[4],
+                       float trunc_dist, float max_w, float mincostheta, unsigned flags, kfx_stream stream);
+int kfx_raycast_sdf_color(const kfx_image* depth, const kfx_image* norm, const kfx_image* img, const kfx_volume* vol,
+                          const kfx_volume* colorvol, const float T_wc[12], const float K[4], float near, float far,
+                          float trunc_dist, int subpix, kfx_stream stream);
+int kfx_color_reset(const kfx_volume* colorvol, kfx_stream stream);
+
 /* ---- projective point-to-plane ICP ------------------------------------------
  * roo::LeastSquaresSystem<float,6> (Mat.h:483-520): JTy, the 21 unique elements of the symmetric JTJ in
  * row-major lower-triangle order (Mat.h:353-365), the squared error and the observation count. */

@@ -556,6 +556,97 @@ __global__ __launch_bounds__(256) void k_sdf_sphere(VolView v, int X, int Y, int
     CELL::st1(v.ptr + (size_t)z * v.img_pitch + (size_t)y * v.pitch + (size_t)x * CELL::BYTES, make_float2(dist - r, 1.0f));
 }
 
+
+// ---------------------------------------------------------------------------------------
+// Colour TSDF fusion: cu_sdffusion.cu:70-138.  Besides the SDF update the kernel keeps a
+// grey-level volume (BoundedVolume<float>) as the weighted running mean of the RGB image sampled at the
+// voxel's projection into the colour camera (T_iw, Kimg).  Reference launch: 16x16 threads over x/y, all of z
+// in a loop -- so x/y extents are (dim/16)*16 and every slice is visited.  IEEE arithmetic in the reference's
+// order in both numerics modes (the colour path has no fast variant).  A lane owns one voxel column segment:
+// 8-byte SDF cells and 4-byte colour cells are both contiguous across the wave.
+// ---------------------------------------------------------------------------------------
+struct ColorParams {
+    unsigned char* cptr;        // BoundedVolume<float>
+    size_t cpitch, cimg_pitch;
+    Pose Ti;                    // T_iw
+    Intr Ki;                    // Kimg
+    ImgView img;                // Image<uchar3>
+    float iwb, ihb;             // (float)img.w - 2, (float)img.h - 2
+};
+
+struct __attribute__((packed)) U3 { unsigned char x, y, z; };
+
+// Image<uchar3>::GetBilinear<float3> (Image.h:317-334) with lerp(uchar3, uchar3, float) of sampling.h:23-30
+// (integer difference, converted to float, times t, plus the first value) and the float3 lerp of
+// cutil_math.h:375-378 across rows; then ConvertPixel<float,float3> (pixel_convert.h:159-165) and the
+// application's "/ 255.0", a double division rounded back to float (cu_sdffusion.cu:98).
+__device__ __forceinline__ float grey_bilinear(const ColorParams& q, float u, float v)
+{
+    const float ix = floorf(u), iy = floorf(v);
+    const float fx = u - ix, fy = v - iy;
+    const U3* bl = reinterpret_cast<const U3*>(q.img.ptr + (size_t)iy * q.img.pitch) + (size_t)ix;
+    const U3* tl = reinterpret_cast<const U3*>(q.img.ptr + (size_t)(iy + 1) * q.img.pitch) + (size_t)ix;
+    const U3 b0 = bl[0], b1 = bl[1], t0 = tl[0], t1 = tl[1];
+    const V3 lo = v3((float)b0.x + fx * (float)((int)b1.x - (int)b0.x), (float)b0.y + fx * (float)((int)b1.y - (int)b0.y),
+                     (float)b0.z + fx * (float)((int)b1.z - (int)b0.z));
+    const V3 hi = v3((float)t0.x + fx * (float)((int)t1.x - (int)t0.x), (float)t0.y + fx * (float)((int)t1.y - (int)t0.y),
+                     (float)t0.z + fx * (float)((int)t1.z - (int)t0.z));
+    const V3 c = v3(lo.x + fy * (hi.x - lo.x), lo.y + fy * (hi.y - lo.y), lo.z + fy * (hi.z - lo.z));
+    const float grey = (c.x + c.y + c.z) / 3.0f;
+    return (float)((double)grey / 255.0);
+}
+
+__global__ __launch_bounds__(256) void k_sdf_fuse_color(const FuseParams p, const ColorParams q)
+{
+    __shared__ float s_pz[FUSE_ZC];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int x = blockIdx.x * 64 + lane;
+    const int y = blockIdx.y * FUSE_ROWS + wv;
+    const int zbeg = blockIdx.z * FUSE_ZC;
+    const int zend = min(zbeg + FUSE_ZC, p.Z);
+    if (threadIdx.x < FUSE_ZC) s_pz[threadIdx.x] = p.bmin.z + p.size.z * (float)(zbeg + (int)threadIdx.x) / p.d1;
+    __syncthreads();
+    if (x >= p.X || y >= p.Y) return;
+
+    const float px = p.bmin.x + p.size.x * (float)x / p.w1;
+    const float py = p.bmin.y + p.size.y * (float)y / p.h1;
+    CamXY<false> cam;
+    cam.init(p, px, py);
+    // T_iw * P_w with the same hoisting: leading partial sums of the reference expression
+    const float ix0 = q.Ti.m[0] * px + q.Ti.m[1] * py, iy0 = q.Ti.m[4] * px + q.Ti.m[5] * py, iz0 = q.Ti.m[8] * px + q.Ti.m[9] * py;
+
+    unsigned char* cell = p.vptr + (size_t)zbeg * p.vimg_pitch + (size_t)y * p.vpitch + (size_t)x * 8;
+    unsigned char* ccell = q.cptr + (size_t)zbeg * q.cimg_pitch + (size_t)y * q.cpitch + (size_t)x * 4;
+    for (int z = zbeg; z < zend; ++z, cell += p.vimg_pitch, ccell += q.cimg_pitch) {
+        const float pz = s_pz[z - zbeg];
+        const V3 Pc = cam.at(p, pz);
+        float pu, pv, unused;
+        project<false>(p, Pc, pu, pv, unused);
+        const V3 Pi = v3(ix0 + q.Ti.m[2] * pz + q.Ti.m[3], iy0 + q.Ti.m[6] * pz + q.Ti.m[7], iz0 + q.Ti.m[10] * pz + q.Ti.m[11]);
+        const float qu = q.Ki.u0 + q.Ki.fu * Pi.x / Pi.z, qv = q.Ki.v0 + q.Ki.fv * Pi.y / Pi.z;
+        if (in_bounds(p, pu, pv) && 2.0f <= qu && qu < q.iwb && 2.0f <= qv && qv < q.ihb) {
+            const float fix = floorf(pu), fiy = floorf(pv);
+            const Corners c = fetch_global64(p, (int)fix, (int)fiy);
+            const Obs o = finish<false>(p, Pc, 0.f, pu - fix, pv - fiy, c);
+            if (o.ok) {
+                const float grey = grey_bilinear(q, qu, qv);
+                float2 cur = *reinterpret_cast<const float2*>(cell);
+                const float curw = cur.y;
+                accumulate<false, CellF32>(o, p.max_w, cur.x, cur.y);
+                *reinterpret_cast<float2*>(cell) = cur;
+                float* cc = reinterpret_cast<float*>(ccell);
+                *cc = (o.w * grey + *cc * curw) / (o.w + curw);
+            }
+        }
+    }
+}
+
+// SdfReset(BoundedVolume<float>): vol.Fill(0.5) over the contiguous span (cu_sdffusion.cu:166-169, Volume.h:343-356)
+__global__ __launch_bounds__(256) void k_fill_f32(float* __restrict__ base, size_t n, float v)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) base[i] = v;
+}
+
 } // namespace kfx
 
 using namespace kfx;
@@ -764,4 +855,45 @@ extern "C" int kfx_sdf_sphere_h(const kfx_volume* vol, const float center[3], fl
     hipLaunchKernelGGL(k_sdf_sphere<CellF16>, grid, dim3(256), 0, (hipStream_t)stream, vol_view(vol), X, Y, Z,
                        V3{center[0], center[1], center[2]}, r);
     return check_launch("kfx_sdf_sphere_h");
+}
+
+// SdfFuse(vol, colorVol, depth, norm, T_cw, K, img, T_iw, Kimg, trunc_dist, max_w, mincostheta) (cu_sdffusion.cu:120-138)
+extern "C" int kfx_sdf_fuse_color(const kfx_volume* vol, const kfx_volume* colorvol, const kfx_image* depth, const kfx_image* norm,
+                                  const float T_cw[12], const float K[4], const kfx_image* img, const float T_iw[12], const float Kimg[4],
+                                  float trunc_dist, float max_w, float mincostheta, unsigned flags, kfx_stream stream)
+{
+    FuseParams p;
+    bool small_images = false;
+    if (int e = fuse_params(p, &small_images, vol, depth, norm, T_cw, K, trunc_dist, max_w, mincostheta, flags | KFX_FUSE_FULL_EXTENT)) return e;
+    if (int e = check_volume(colorvol, 4)) return e;
+    if (!img || !img->ptr || !T_iw || !Kimg) return set_error(KFX_E_NULL, "SdfFuse(colour): null argument");
+    if (colorvol->w < vol->w || colorvol->h < vol->h || colorvol->d < vol->d) return set_error(KFX_E_SHAPE, "SdfFuse(colour): colour volume smaller than the SDF volume");
+    if (img->w < 4 || img->h < 4 || img->pitch < img->w * 3) return set_error(KFX_E_SHAPE, "SdfFuse(colour): rgb image dimensions");
+    if (!(flags & KFX_FUSE_FULL_EXTENT)) { // the reference's 16x16 launch over x / y, all of z (cu_sdffusion.cu:132-135)
+        p.X = (int)(vol->w / 16) * 16;
+        p.Y = (int)(vol->h / 16) * 16;
+    }
+    if (p.X == 0 || p.Y == 0 || p.Z == 0) return 0;
+    ColorParams q;
+    q.cptr = (unsigned char*)colorvol->ptr;
+    q.cpitch = colorvol->pitch;
+    q.cimg_pitch = colorvol->img_pitch;
+    for (int i = 0; i < 12; ++i) q.Ti.m[i] = T_iw[i];
+    q.Ki = Intr{Kimg[0], Kimg[1], Kimg[2], Kimg[3]};
+    q.img = ImgView{(const unsigned char*)img->ptr, img->pitch, (int)img->w, (int)img->h};
+    q.iwb = (float)img->w - 2.0f;
+    q.ihb = (float)img->h - 2.0f;
+    dim3 grid(ceil_div(p.X, 64), ceil_div(p.Y, FUSE_ROWS), ceil_div(p.Z, FUSE_ZC));
+    hipLaunchKernelGGL(k_sdf_fuse_color, grid, dim3(256), 0, (hipStream_t)stream, p, q);
+    return check_launch("kfx_sdf_fuse_color");
+}
+
+// SdfReset(BoundedVolume<float>) (cu_sdffusion.cu:166-169): every cell of the span, padding included, = 0.5
+extern "C" int kfx_color_reset(const kfx_volume* colorvol, kfx_stream stream)
+{
+    if (int e = check_volume(colorvol, 4)) return e;
+    const size_t n = ((colorvol->d - 1) * colorvol->img_pitch + (colorvol->h - 1) * colorvol->pitch + colorvol->w * 4) / 4;
+    const int blocks = (int)std::min<size_t>((n + 255) / 256, 256 * 16);
+    hipLaunchKernelGGL(k_fill_f32, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (float*)colorvol->ptr, n, 0.5f);
+    return check_launch("kfx_color_reset");
 }

@@ -56,9 +56,26 @@ __device__ __forceinline__ const unsigned char* rowp(const VolView& v, int y, in
     return v.ptr + (size_t)z * v.img_pitch + (size_t)y * v.pitch;
 }
 
+// grey-level cells of a BoundedVolume<float> (colour raycast, cu_raycast.cu:119-189)
+struct __attribute__((packed, aligned(4))) PairC { float a, b; };
+struct RayC32 {
+    static constexpr int BYTES = 4;
+    __device__ static __forceinline__ float2 pair(const unsigned char* row, int x)
+    {
+        const PairC c = *reinterpret_cast<const PairC*>(row + (size_t)x * 4);
+        return make_float2(c.a, c.b);
+    }
+    __device__ static __forceinline__ float val(const unsigned char* row, int x) { return *reinterpret_cast<const float*>(row + (size_t)x * 4); }
+};
+// geometry of a second volume sampled with trilinear<>() (same member names as RayParams)
+struct ColorGeom {
+    VolView vol;
+    V3 size, dims1, hi2;
+};
+
 // BoundedVolume::GetUnitsTrilinearClamped -> Volume::GetFractionalTrilinearClamped
-template <typename CELL>
-__device__ __forceinline__ float trilinear(const RayParams& p, const V3 pos_w)
+template <typename CELL, typename GEOM>
+__device__ __forceinline__ float trilinear(const GEOM& p, const V3 pos_w)
 {
     const V3 pos_v = div_cw(pos_w - p.vol.bmin, p.size);
     const V3 pf = v3(pos_v.x * p.dims1.x, pos_v.y * p.dims1.y, pos_v.z * p.dims1.z);
@@ -144,8 +161,8 @@ __device__ __forceinline__ float phong(const V3 p_c, const V3 n_c)
     return ambient + diffuse * ldotn + specular * spec;
 }
 
-template <typename CELL>
-__global__ __launch_bounds__(256) void k_raycast_sdf(const RayParams p)
+template <typename CELL, bool COLOR>
+__global__ __launch_bounds__(256) void k_raycast_sdf(const RayParams p, const ColorGeom cv)
 {
     // wave -> 8x8 tile; workgroup -> 16x16 pixels
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -196,7 +213,9 @@ __global__ __launch_bounds__(256) void k_raycast_sdf(const RayParams p)
         const V3 n_c = so3_mul_inv(p.T, n_w);
         const V3 p_c = ray_c * depth;
         *pd = depth;
-        *pi = phong(p_c, n_c);
+        // colour variant: img = colorVol.GetUnitsTrilinearClamped(pos_w) instead of the Phong shade (cu_raycast.cu:172,179)
+        if constexpr (COLOR) *pi = trilinear<RayC32>(cv, c_w + ray_w * depth);
+        else *pi = phong(p_c, n_c);
         *pn = make_float4(n_c.x, n_c.y, n_c.z, 1.0f);
     } else {
         *pd = __builtin_nanf("");
@@ -330,7 +349,7 @@ using namespace kfx;
 template <typename CELL>
 static int raycast_launch(const kfx_image* depth, const kfx_image* norm, const kfx_image* img,
                           const kfx_volume* vol, const float T_wc[12], const float K[4], float near,
-                          float far, float trunc_dist, int subpix, kfx_stream stream)
+                          float far, float trunc_dist, int subpix, kfx_stream stream, const kfx_volume* colorvol = nullptr)
 {
     if (!depth || !norm || !img || !vol || !T_wc || !K || !depth->ptr || !norm->ptr || !img->ptr || !vol->ptr)
         return set_error(KFX_E_NULL, "RaycastSdf: null argument");
@@ -378,7 +397,28 @@ static int raycast_launch(const kfx_image* depth, const kfx_image* norm, const k
     p.subpix = subpix ? 1 : 0;
 
     dim3 grid(ceil_div(p.w, 16), ceil_div(p.h, 16));
-    hipLaunchKernelGGL(k_raycast_sdf<CELL>, grid, dim3(256), 0, (hipStream_t)stream, p);
+    ColorGeom cv{};
+    if (colorvol) {
+        if (!colorvol->ptr) return set_error(KFX_E_NULL, "RaycastSdf(colour): null colour volume");
+        if (colorvol->w < 2 || colorvol->h < 2 || colorvol->d < 2 || colorvol->pitch < colorvol->w * 4 ||
+            colorvol->img_pitch < colorvol->pitch * (colorvol->h - 1) + colorvol->w * 4)
+            return set_error(KFX_E_SHAPE, "RaycastSdf(colour): colour volume dimensions / pitch");
+        if (((uintptr_t)colorvol->ptr | colorvol->pitch | colorvol->img_pitch) & 3) return set_error(KFX_E_ALIGN, "RaycastSdf(colour): alignment");
+        cv.vol.ptr = (unsigned char*)colorvol->ptr;
+        cv.vol.pitch = colorvol->pitch;
+        cv.vol.img_pitch = colorvol->img_pitch;
+        cv.vol.w = (int)colorvol->w;
+        cv.vol.h = (int)colorvol->h;
+        cv.vol.d = (int)colorvol->d;
+        cv.vol.bmin = V3{colorvol->boxmin[0], colorvol->boxmin[1], colorvol->boxmin[2]};
+        cv.vol.bmax = V3{colorvol->boxmax[0], colorvol->boxmax[1], colorvol->boxmax[2]};
+        cv.size = V3{colorvol->boxmax[0] - colorvol->boxmin[0], colorvol->boxmax[1] - colorvol->boxmin[1], colorvol->boxmax[2] - colorvol->boxmin[2]};
+        cv.dims1 = V3{(float)colorvol->w - 1.f, (float)colorvol->h - 1.f, (float)colorvol->d - 1.f};
+        cv.hi2 = V3{(float)(colorvol->w - 2), (float)(colorvol->h - 2), (float)(colorvol->d - 2)};
+        hipLaunchKernelGGL((k_raycast_sdf<CELL, true>), grid, dim3(256), 0, (hipStream_t)stream, p, cv);
+    } else {
+        hipLaunchKernelGGL((k_raycast_sdf<CELL, false>), grid, dim3(256), 0, (hipStream_t)stream, p, cv);
+    }
     return check_launch("kfx_raycast_sdf");
 }
 
@@ -394,6 +434,15 @@ extern "C" int kfx_raycast_sdf_h(const kfx_image* depth, const kfx_image* norm, 
                                  float far, float trunc_dist, int subpix, kfx_stream stream)
 {
     return raycast_launch<RayF16>(depth, norm, img, vol, T_wc, K, near, far, trunc_dist, subpix, stream);
+}
+
+// RaycastSdf(depth, norm, img, vol, colorVol, T_wc, K, near, far, trunc_dist, subpix) (cu_raycast.cu:119-196)
+extern "C" int kfx_raycast_sdf_color(const kfx_image* depth, const kfx_image* norm, const kfx_image* img, const kfx_volume* vol,
+                                     const kfx_volume* colorvol, const float T_wc[12], const float K[4], float near, float far,
+                                     float trunc_dist, int subpix, kfx_stream stream)
+{
+    if (!colorvol) return set_error(KFX_E_NULL, "RaycastSdf(colour): null colour volume");
+    return raycast_launch<RayF32>(depth, norm, img, vol, T_wc, K, near, far, trunc_dist, subpix, stream, colorvol);
 }
 
 // Exact multi-GPU march: one round of a rank (see k_raycast_sdf_slab).  `vol` holds planes

@@ -19,6 +19,7 @@ from ._lib import KfxError, KfxImage, KfxVolume  # noqa: F401
 
 _ELEM = {
     "f32": (np.float32, 1), "f32x4": (np.float32, 4), "u16": (np.uint16, 1), "u8": (np.uint8, 1),
+    "u8x3": (np.uint8, 3),   # Image<uchar3>: the RGB frame of the colour path
 }
 PITCH_ALIGN = 256  # same policy as kfx_alloc_pitched
 
@@ -102,9 +103,10 @@ class BoundedVolume:
 
     def __init__(self, w, h, d, boxmin=(-1, -1, -1), boxmax=(1, 1, 1), device="cuda", pitch=None,
                  _storage=None, _offset=0, _img_pitch=None, kind="f32"):
-        """kind = "f32": SDF_t {float val; float w;} (8 B); kind = "f16": SDF_h {half val; half w;} (4 B)."""
+        """kind = "f32": SDF_t {float val; float w;} (8 B); kind = "f16": SDF_h {half val; half w;} (4 B);
+        kind = "c32": BoundedVolume<float>, the grey-level colour volume (4 B)."""
         self.kind = kind
-        self.ELEM = {"f32": 8, "f16": 4}[kind]
+        self.ELEM = {"f32": 8, "f16": 4, "c32": 4}[kind]
         self.w, self.h, self.d = int(w), int(h), int(d)
         self.boxmin = np.asarray(boxmin, np.float32).copy()
         self.boxmax = np.asarray(boxmax, np.float32).copy()
@@ -183,7 +185,10 @@ class BoundedVolume:
         return self.storage[self.offset + z0 * self.img_pitch: self.offset + z1 * self.img_pitch]
 
     def tensor(self):
-        """Strided torch view (d, h, w, 2) of the cells (float32 or float16)."""
+        """Strided torch view (d, h, w, 2) of the cells (float32 or float16); (d, h, w, 1) for a colour volume."""
+        if self.kind == "c32":
+            flat = self.storage[self.offset:].view(torch.float32)
+            return torch.as_strided(flat, (self.d, self.h, self.w, 1), (self.img_pitch // 4, self.pitch // 4, 1, 1))
         if self.kind == "f16":
             flat = self.storage[self.offset:].view(torch.float16)
             return torch.as_strided(flat, (self.d, self.h, self.w, 2), (self.img_pitch // 2, self.pitch // 2, 2, 1))
@@ -403,3 +408,27 @@ def PoseRefinementProjectiveIcpPointPlane(dPl, dPr, dNr, KT_lr, T_rl, c, dWorksp
     _lib.check(_lib.load().kfx_icp_point_plane(dPl.ref(), dPr.ref(), dNr.ref(), kt, t, c, dWorkspace.ref(),
                                                dDebug.ref() if dDebug is not None else None, C.byref(out), _stream(stream)))
     return LeastSquaresSystem(list(out.JTy), list(out.JTJ), out.sqErr, out.obs)
+
+
+def SdfFuseColor(vol, colorVol, depth, norm, T_cw, K, img, T_iw, Kimg, trunc_dist, max_w, mincostheta, full_extent=False, stream=None):
+    """SdfFuse(vol, colorVol, depth, norm, T_cw, K, img, T_iw, Kimg, trunc_dist, max_w, mincostheta)
+    (cu_sdffusion.h colour overload, cu_sdffusion.cu:70-138).  colorVol: BoundedVolume(kind="c32"), img: Image("u8x3")."""
+    t, _t = _fp(T_cw, 12)
+    k, _k = _fp(K, 4)
+    ti, _ti = _fp(T_iw, 12)
+    ki, _ki = _fp(Kimg, 4)
+    _lib.check(_lib.load().kfx_sdf_fuse_color(vol.ref(), colorVol.ref(), depth.ref(), norm.ref(), t, k, img.ref(), ti, ki, trunc_dist,
+                                              max_w, mincostheta, 1 if full_extent else 0, _stream(stream)))
+
+
+def RaycastSdfColor(depth, norm, img, vol, colorVol, T_wc, K, near, far, trunc_dist, subpix=True, stream=None):
+    """RaycastSdf(depth, norm, img, vol, colorVol, T_wc, K, near, far, trunc_dist, subpix) (cu_raycast.cu:119-196)."""
+    t, _t = _fp(T_wc, 12)
+    k, _k = _fp(K, 4)
+    _lib.check(_lib.load().kfx_raycast_sdf_color(depth.ref(), norm.ref(), img.ref(), vol.ref(), colorVol.ref(), t, k, near, far,
+                                                 trunc_dist, 1 if subpix else 0, _stream(stream)))
+
+
+def ColorReset(colorVol, stream=None):
+    """SdfReset(BoundedVolume<float>) = Fill(0.5) (cu_sdffusion.cu:166-169)."""
+    _lib.check(_lib.load().kfx_color_reset(colorVol.ref(), _stream(stream)))

@@ -76,6 +76,12 @@ def lib():
         L.kfo_raycast_sdf_slab.argtypes = [C.c_void_p, C.c_int, PV, C.POINTER(KfoSlab), C.c_int, C.c_int, C.c_int, C.c_int, PF, PF,
                                            C.c_float, C.c_float, C.c_float, C.c_int]
         L.kfo_raycast_sdf_slab.restype = None
+        L.kfo_color_reset.argtypes = [PV]
+        L.kfo_color_reset.restype = None
+        L.kfo_sdf_fuse_color.argtypes = [PV, PV, PI, PI, PF, PF, PI, PF, PF, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int]
+        L.kfo_sdf_fuse_color.restype = C.c_uint64
+        L.kfo_raycast_sdf_color.argtypes = [PI, PI, PI, PV, PV, PF, PF, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int]
+        L.kfo_raycast_sdf_color.restype = None
         L.kfo_icp_point_plane.argtypes = [PI, PI, PI, PF, PF, C.c_float, PI, C.POINTER(KfoLss6), C.c_void_p]
         L.kfo_icp_point_plane.restype = None
         L.kfo_icp_block_dims.argtypes = [C.c_size_t, C.c_size_t, C.POINTER(C.c_uint)]
@@ -430,3 +436,28 @@ def icp_point_plane(Pl, Pr, Nr, KT_lr, T_rl, c, debug=None, want_blocks=False, f
       blocks.ctypes.data if blocks is not None else None)
     res = np.frombuffer(bytes(out), LSS_DTYPE)[0]
     return (res, blocks) if want_blocks else res
+
+
+def ColorVolume(w, h, d, boxmin=(-1, -1, -1), boxmax=(1, 1, 1), pitch_bytes=None):
+    """BoundedVolume<float>: grey-level colour volume, `data` shape (d, h, w, 1)."""
+    return Volume(w, h, d, boxmin, boxmax, pitch_bytes=pitch_bytes, elem_floats=1)
+
+
+def color_reset(cvol):
+    lib().kfo_color_reset(cvol.ref())
+
+
+def sdf_fuse_color(vol, cvol, depth, norm, T_cw, K, img, T_iw, Kimg, trunc, max_w, mincostheta, full_extent=False, nthreads=1):
+    _, t = _fp(T_cw)
+    _, k = _fp(K)
+    _, ti = _fp(T_iw)
+    _, ki = _fp(Kimg)
+    return int(lib().kfo_sdf_fuse_color(vol.ref(), cvol.ref(), depth.ref(), norm.ref(), t, k, img.ref(), ti, ki, trunc, max_w,
+                                        mincostheta, 1 if full_extent else 0, nthreads))
+
+
+def raycast_sdf_color(depth, norm, img, vol, cvol, T_wc, K, near, far, trunc, subpix=True, nthreads=1):
+    _, t = _fp(T_wc)
+    _, k = _fp(K)
+    lib().kfo_raycast_sdf_color(depth.ref(), norm.ref(), img.ref(), vol.ref(), cvol.ref(), t, k, near, far, trunc,
+                                1 if subpix else 0, nthreads)

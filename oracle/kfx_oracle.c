@@ -992,3 +992,125 @@ void kfo_icp_point_plane(const kfo_image* Pl, const kfo_image* Pr_img, const kfo
     lss_tree(partial, 256);
     *out = partial[0];
 }
+
+/* ============================================================================
+ * Colour fusion / colour raycast.
+ * ========================================================================== */
+static inline float* cvol_row(const kfo_volume* v, size_t y, size_t z)
+{
+    return (float*)((unsigned char*)v->ptr + z * v->img_pitch + y * v->pitch);
+}
+
+/* SdfReset(BoundedVolume<float>) = vol.Fill(0.5) over the contiguous span (cu_sdffusion.cu:166-169, Volume.h:343-356) */
+void kfo_color_reset(const kfo_volume* cv)
+{
+    const size_t n = ((cv->d - 1) * cv->img_pitch + (cv->h - 1) * cv->pitch + cv->w * 4) / 4;
+    float* p = (float*)cv->ptr;
+    for (size_t i = 0; i < n; ++i) p[i] = 0.5f;
+}
+
+typedef struct { unsigned char x, y, z; } uc3;
+/* lerp(uchar3, uchar3, float), sampling.h:23-30: a.x + t*(b.x - a.x) with the difference taken in int */
+static inline f3 lerp_uc3(uc3 a, uc3 b, float t)
+{
+    return mk3((float)a.x + t * (float)((int)b.x - (int)a.x), (float)a.y + t * (float)((int)b.y - (int)a.y),
+               (float)a.z + t * (float)((int)b.z - (int)a.z));
+}
+
+/* KernSdfFuse with colour, cu_sdffusion.cu:70-118; launch (16,16) over x,y, z loop over all of vol.d (:132-135) */
+uint64_t kfo_sdf_fuse_color(const kfo_volume* vol, const kfo_volume* cvol, const kfo_image* depth, const kfo_image* normals,
+                            const float T[12], const float K[4], const kfo_image* img, const float T_iw[12], const float Kimg[4],
+                            float trunc_dist, float max_w, float mincostheta, int full_extent, int nthreads)
+{
+    const int X = full_extent ? (int)vol->w : (int)(vol->w / 16) * 16;
+    const int Y = full_extent ? (int)vol->h : (int)(vol->h / 16) * 16;
+    const int Z = (int)vol->d;
+    uint64_t updated = 0;
+    const int nt = pick_threads(nthreads);
+    (void)nt;
+#pragma omp parallel for num_threads(nt) schedule(static) reduction(+ : updated)
+    for (int z = 0; z < Z; ++z)
+        for (int y = 0; y < Y; ++y)
+            for (int x = 0; x < X; ++x) {
+                const f3 P_w = voxel_position(vol, x, y, z);
+                const f3 P_c = se3_mul(T, P_w);
+                const float pu = U0 + FU * P_c.x / P_c.z, pv = V0 + FV * P_c.y / P_c.z;  /* K.Project */
+                const f3 P_i = se3_mul(T_iw, P_w);
+                const float qu = Kimg[2] + Kimg[0] * P_i.x / P_i.z, qv = Kimg[3] + Kimg[1] * P_i.y / P_i.z;
+                const float b = 2.0f;
+                if (!(b <= pu && pu < ((float)depth->w - b) && b <= pv && pv < ((float)depth->h - b))) continue;
+                if (!(b <= qu && qu < ((float)img->w - b) && b <= qv && qv < ((float)img->h - b))) continue;
+                const float vd = P_c.z;
+                const float ix = floorf(pu), iy = floorf(pv);
+                const float fx = pu - ix, fy = pv - iy;
+                const float* dbl = (const float*)img_row(depth, (size_t)iy) + (size_t)ix;
+                const float* dtl = (const float*)img_row(depth, (size_t)(iy + 1)) + (size_t)ix;
+                const float md = lerpf(lerpf(dbl[0], dbl[1], fx), lerpf(dtl[0], dtl[1], fx), fy);
+                const f4* nbl = (const f4*)img_row(normals, (size_t)iy) + (size_t)ix;
+                const f4* ntl = (const f4*)img_row(normals, (size_t)(iy + 1)) + (size_t)ix;
+                f3 mdn;
+                mdn.x = lerpf(lerpf(nbl[0].x, nbl[1].x, fx), lerpf(ntl[0].x, ntl[1].x, fx), fy);
+                mdn.y = lerpf(lerpf(nbl[0].y, nbl[1].y, fx), lerpf(ntl[0].y, ntl[1].y, fx), fy);
+                mdn.z = lerpf(lerpf(nbl[0].z, nbl[1].z, fx), lerpf(ntl[0].z, ntl[1].z, fx), fy);
+                /* c = ConvertPixel<float,float3>(img.GetBilinear<float3>(p_i)) / 255.0  (:98; the division is in double) */
+                const float jx = floorf(qu), jy = floorf(qv);
+                const float gx = qu - jx, gy = qv - jy;
+                const uc3* cbl = (const uc3*)img_row(img, (size_t)jy) + (size_t)jx;
+                const uc3* ctl = (const uc3*)img_row(img, (size_t)(jy + 1)) + (size_t)jx;
+                const f3 rgb = lerp3(lerp_uc3(cbl[0], cbl[1], gx), lerp_uc3(ctl[0], ctl[1], gx), gy);
+                const float c = (float)((double)((rgb.x + rgb.y + rgb.z) / 3.0f) / 255.0);
+
+                const float costheta = dot3(mdn, P_c) / -length3(P_c);
+                const float sd = costheta * (md - vd);
+                const float w = costheta * 1.0f / vd;
+                if (sd <= -trunc_dist) continue;
+                if (isfinite(md) && isfinite(w) && costheta > mincostheta) {
+                    sdf_t* cell = &vol_row(vol, (size_t)y, (size_t)z)[x];
+                    const sdf_t curvol = *cell;
+                    sdf_t sdf = {clampf(sd, -trunc_dist, trunc_dist), w};
+                    if (curvol.w > 0) {
+                        sdf.val = (sdf.w * sdf.val + curvol.w * curvol.val);
+                        sdf.w += curvol.w;
+                        sdf.val /= sdf.w;
+                    }
+                    sdf.w = fminf(sdf.w, max_w);
+                    *cell = sdf;
+                    float* cc = &cvol_row(cvol, (size_t)y, (size_t)z)[x];
+                    *cc = (w * c + *cc * curvol.w) / (w + curvol.w);
+                    ++updated;
+                }
+            }
+    return updated;
+}
+
+/* Volume<float>::GetFractionalTrilinearClamped through BoundedVolume<float>::GetUnitsTrilinearClamped */
+static inline float trilinear_clamped_f32(const kfo_volume* v, f3 pos_w)
+{
+    const f3 pos_v = div33(sub3(pos_w, box_min(v)), box_size(v));
+    const f3 pf = {pos_v.x * ((float)v->w - 1.f), pos_v.y * ((float)v->h - 1.f), pos_v.z * ((float)v->d - 1.f)};
+    const int ix = (int)fmaxf(fminf((float)(v->w - 2), floorf(pf.x)), 0);
+    const int iy = (int)fmaxf(fminf((float)(v->h - 2), floorf(pf.y)), 0);
+    const int iz = (int)fmaxf(fminf((float)(v->d - 2), floorf(pf.z)), 0);
+    const float fx = pf.x - (float)ix, fy = pf.y - (float)iy, fz = pf.z - (float)iz;
+    const float* r00 = cvol_row(v, (size_t)iy, (size_t)iz), *r10 = cvol_row(v, (size_t)iy + 1, (size_t)iz);
+    const float* r01 = cvol_row(v, (size_t)iy, (size_t)iz + 1), *r11 = cvol_row(v, (size_t)iy + 1, (size_t)iz + 1);
+    return lerpf(lerpf(lerpf(r00[ix], r00[ix + 1], fx), lerpf(r10[ix], r10[ix + 1], fx), fy),
+                 lerpf(lerpf(r01[ix], r01[ix + 1], fx), lerpf(r11[ix], r11[ix + 1], fx), fy), fz);
+}
+
+/* KernRaycastSdf with colour, cu_raycast.cu:119-189: the march and the normal of the grey variant; on a hit
+ * img = colorVol.GetUnitsTrilinearClamped(c_w + depth * ray_w) instead of the Phong shade. */
+void kfo_raycast_sdf_color(const kfo_image* depth, const kfo_image* norm, const kfo_image* img, const kfo_volume* vol,
+                           const kfo_volume* cvol, const float T[12], const float K[4], float near, float far, float trunc,
+                           int subpix, int nthreads)
+{
+    raycast_any(depth, norm, img, vol, T, K, near, far, trunc, subpix, nthreads, NULL, 0);
+    for (int v = 0; v < (int)img->h; ++v)
+        for (int u = 0; u < (int)img->w; ++u) {
+            const float d = ((const float*)img_row(depth, (size_t)v))[u];
+            if (!(d > 0)) continue; /* miss: depth NaN, img already 0 */
+            const f3 c_w = se3_translation(T);
+            const f3 ray_w = so3_mul(T, unproject1(K, (float)u, (float)v));
+            ((float*)img_row(img, (size_t)v))[u] = trilinear_clamped_f32(cvol, add3(c_w, scale3(ray_w, d)));
+        }
+}

@@ -90,6 +90,16 @@ typedef struct kfo_slab {
 uint64_t kfo_sdf_fuse_slab(const kfo_volume* vol, const kfo_slab* slab, const kfo_image* depth, const kfo_image* norm,
                            const float T_cw[12], const float K[4], float trunc, float max_w,
                            float mincostheta, int full_extent, int nthreads);
+/* colour fusion / raycast: cvol is a BoundedVolume<float> (4-byte cells), img an Image<uchar3>.
+ * cu_sdffusion.cu:70-138, :166-169; cu_raycast.cu:119-196 */
+void kfo_color_reset(const kfo_volume* cvol);
+uint64_t kfo_sdf_fuse_color(const kfo_volume* vol, const kfo_volume* cvol, const kfo_image* depth, const kfo_image* normals,
+                            const float T_cw[12], const float K[4], const kfo_image* img, const float T_iw[12], const float Kimg[4],
+                            float trunc_dist, float max_w, float mincostheta, int full_extent, int nthreads);
+void kfo_raycast_sdf_color(const kfo_image* depth, const kfo_image* norm, const kfo_image* img, const kfo_volume* vol,
+                           const kfo_volume* cvol, const float T_wc[12], const float K[4], float near, float far, float trunc,
+                           int subpix, int nthreads);
+
 /* roo::LeastSquaresSystem<float,6> (Mat.h:483-520) */
 typedef struct kfo_lss6 {
     float JTy[6];

@@ -26,6 +26,7 @@
 #include <kangaroo/MatUtils.h>
 #include <kangaroo/Sdf.h>
 #include <kangaroo/launch_utils.h>
+#include <kangaroo/pixel_convert.h>
 #include <kangaroo/reweighting.h>
 
 #include <cstring>
@@ -326,6 +327,67 @@ void ref_icp_point_plane(const kfo_image* pPl, const kfo_image* pPr, const kfo_i
     for (unsigned S = 128; S > 0; S >>= 1)
         for (unsigned tid = 0; tid < S; ++tid) partial[tid] += partial[tid + S];
     memcpy(out, &partial[0], sizeof(LSS));
+}
+
+// Colour fusion: the body of the colour KernSdfFuse (cu_sdffusion.cu:70-118), every arithmetic step a
+// reference header call (Image<uchar3>::GetBilinear<float3> -> sampling.h lerp, ConvertPixel<float,float3>,
+// the double "/ 255.0", SDF_t::operator+=, LimitWeight).  Extents of the (16,16) launch with its z loop.
+uint64_t ref_sdf_fuse_color(const kfo_volume* pv, const kfo_volume* pc, const kfo_image* pd, const kfo_image* pn, const float* t,
+                            const float* k, const kfo_image* pimg, const float* tiw, const float* kimg, float trunc_dist,
+                            float max_w, float mincostheta, int full_extent)
+{
+    HVol vol = mkvol(pv);
+    Volume<float, TargetHost, DontManage> cv0((float*)pc->ptr, pc->w, pc->h, pc->d, pc->pitch, pc->img_pitch);
+    BoundedVolume<float, TargetHost, DontManage> colorVol(cv0, BoundingBox(make_float3(pc->boxmin[0], pc->boxmin[1], pc->boxmin[2]),
+                                                                        make_float3(pc->boxmax[0], pc->boxmax[1], pc->boxmax[2])));
+    HImgF depth = imf(pd);
+    HImgF4 normals = imf4(pn);
+    Image<uchar3, TargetHost, DontManage> img((uchar3*)pimg->ptr, pimg->w, pimg->h, pimg->pitch);
+    const Mat<float, 3, 4> T_cw = mkT(t), T_iw = mkT(tiw);
+    const ImageIntrinsics K = mkK(k), Kimg = mkK(kimg);
+    const int X = full_extent ? (int)vol.w : (int)(vol.w / 16) * 16;
+    const int Y = full_extent ? (int)vol.h : (int)(vol.h / 16) * 16;
+    uint64_t n = 0;
+    for (int z = 0; z < (int)vol.d; ++z)
+        for (int y = 0; y < Y; ++y)
+            for (int x = 0; x < X; ++x) {
+                const float3 P_w = vol.VoxelPositionInUnits(x, y, z);
+                const float3 P_c = T_cw * P_w;
+                const float2 p_c = K.Project(P_c);
+                const float3 P_i = T_iw * P_w;
+                const float2 p_i = Kimg.Project(P_i);
+                if (depth.InBounds(p_c, 2) && img.InBounds(p_i, 2)) {
+                    const float vd = P_c.z;
+                    const float md = depth.GetBilinear<float>(p_c);
+                    const float3 mdn = make_float3(normals.GetBilinear<float4>(p_c));
+                    const float c = ConvertPixel<float, float3>(img.GetBilinear<float3>(p_i)) / 255.0;
+                    const float costheta = dot(mdn, P_c) / -length(P_c);
+                    const float sd = costheta * (md - vd);
+                    const float w = costheta * 1.0f / vd;
+                    if (sd <= -trunc_dist) {
+                    } else {
+                        if (std::isfinite(md) && std::isfinite(w) && costheta > mincostheta) {
+                            const SDF_t curvol = vol(x, y, z);
+                            SDF_t sdf(clamp(sd, -trunc_dist, trunc_dist), w);
+                            sdf += curvol;
+                            sdf.LimitWeight(max_w);
+                            vol(x, y, z) = sdf;
+                            colorVol(x, y, z) = (w * c + colorVol(x, y, z) * curvol.w) / (w + curvol.w);
+                            ++n;
+                        }
+                    }
+                }
+            }
+    return n;
+}
+
+// BoundedVolume<float>::GetUnitsTrilinearClamped, the colour sample of the colour raycast (cu_raycast.cu:172)
+float ref_color_trilinear(const kfo_volume* pc, const float pos[3])
+{
+    Volume<float, TargetHost, DontManage> cv0((float*)pc->ptr, pc->w, pc->h, pc->d, pc->pitch, pc->img_pitch);
+    BoundedVolume<float, TargetHost, DontManage> colorVol(cv0, BoundingBox(make_float3(pc->boxmin[0], pc->boxmin[1], pc->boxmin[2]),
+                                                                        make_float3(pc->boxmax[0], pc->boxmax[1], pc->boxmax[2])));
+    return colorVol.GetUnitsTrilinearClamped(make_float3(pos[0], pos[1], pos[2]));
 }
 
 }

@@ -40,6 +40,14 @@ def test_reference_signatures_are_declared_verbatim():
             in open(os.path.join(inc, "cu_depth_tools.h")).read())
 
 
+    fuse1 = " ".join(fuse.split())
+    assert ("void SdfFuse( BoundedVolume<SDF_t> vol, BoundedVolume<float> colorVol, Image<float> depth, Image<float4> norm, "
+            "Mat<float,3,4> T_cw, ImageIntrinsics K, Image<uchar3> img, Mat<float,3,4> T_iw, ImageIntrinsics Kimg, "
+            "float trunc_dist, float max_w, float mincostheta )") in fuse1
+    assert "void SdfReset(BoundedVolume<float> vol)" in fuse
+    assert ("void RaycastSdf(Image<float> depth, Image<float4> norm, Image<float> img, const BoundedVolume<SDF_t> vol, "
+            "const BoundedVolume<float> colorVol, const Mat<float,3,4> T_wc, ImageIntrinsics K, float near, float far, "
+            "float trunc_dist, bool subpix = true)") in ray
     icp = " ".join(open(os.path.join(inc, "cu_model_refinement.h")).read().split())
     assert ("LeastSquaresSystem<float,6> PoseRefinementProjectiveIcpPointPlane( const Image<float4> dPl, const Image<float4> dPr, "
             "const Image<float4> dNr, const Mat<float,3,4> KT_lr, const Mat<float,3,4> T_rl, float c, "

@@ -775,3 +775,43 @@ def test_gpu_tracking_pipeline_follows_the_orbit(roo):
         worst = max(worst, float(np.linalg.norm(T_est[:3, 3] - T_true[:3, 3])))
     drift_if_static = float(np.linalg.norm(scenes.orbit_pose(frames - 1, 30)[:3, 3] - scenes.orbit_pose(0, 30)[:3, 3]))
     assert worst < 0.2 * drift_if_static, (worst, drift_if_static)
+
+
+# ---------------------------------------------------------------------------------
+# colour fusion / colour raycast
+# ---------------------------------------------------------------------------------
+@pytest.mark.parametrize("dims,w,h,cw,ch,full", [((64, 64, 64), 160, 120, 160, 120, False), ((40, 24, 19), 80, 60, 96, 72, False),
+                                                  ((21, 18, 9), 80, 60, 96, 72, True), ((128, 128, 128), 640, 480, 640, 480, False)])
+def test_gpu_colour_fusion_and_raycast_vs_oracle(roo, dims, w, h, cw, ch, full):
+    """kfx_sdf_fuse_color / kfx_raycast_sdf_color / kfx_color_reset against the oracle: SDF cells, colour
+    cells and the three raycast images bit-identical (extents of the reference's 16x16 launch with its z loop)."""
+    import test_color_cpu as TC
+    ovol, ocvol, K, Kimg, tr, near, far, inputs = TC.color_setup(0, w, h, cw, ch, dims=dims)
+    bmin, bmax = scenes.SCENES["room"][0], scenes.SCENES["room"][1]
+    vol = roo.BoundedVolume(dims[0], dims[1], dims[2], bmin, bmax)
+    cvol = roo.BoundedVolume(dims[0], dims[1], dims[2], bmin, bmax, kind="c32")
+    roo.SdfReset(vol, float("nan"))
+    roo.ColorReset(cvol)
+    # Fill(0.5) covers the pitch padding of the span too
+    span = (dims[2] - 1) * cvol.img_pitch + (dims[1] - 1) * cvol.pitch + dims[0] * 4
+    raw = cvol.storage[:span].view(dtype=__import__("torch").float32).cpu().numpy()
+    assert (raw == 0.5).all()
+    for fr in inputs:
+        n = oracle.sdf_fuse_color(ovol, ocvol, fr["f"], fr["nrm"], fr["T_cw"], K, fr["rgb"], fr["T_iw"], Kimg, tr, scenes.MAX_W,
+                                  scenes.MIN_COS_THETA, full_extent=full, nthreads=0)
+        assert n > 0
+        rgb = roo.Image(cw, ch, "u8x3")
+        rgb.MemcpyFromHost(fr["rgb"].data)
+        roo.SdfFuseColor(vol, cvol, T.upload_image(roo, fr["f"].data), T.upload_image(roo, fr["nrm"].data), fr["T_cw"], K, rgb,
+                         fr["T_iw"], Kimg, tr, scenes.MAX_W, scenes.MIN_COS_THETA, full_extent=full)
+    got_v, got_c = vol.MemcpyToHost(), cvol.MemcpyToHost()
+    assert T.nan_equal(got_v, ovol.data), T.mismatch_report(got_v, ovol.data)
+    assert T.nan_equal(got_c, ocvol.data), T.mismatch_report(got_c, ocvol.data)
+    assert ((got_c != 0.5) & (got_c >= 0) & (got_c <= 1)).any()
+    od, on, oi = oracle.Image(w, h), oracle.Image(w, h, channels=4), oracle.Image(w, h)
+    oracle.raycast_sdf_color(od, on, oi, ovol, ocvol, inputs[-1]["T_wc"], K, near, far, tr, True, nthreads=0)
+    rd, rn, ri = roo.Image(w, h), roo.Image(w, h, "f32x4"), roo.Image(w, h)
+    roo.RaycastSdfColor(rd, rn, ri, vol, cvol, inputs[-1]["T_wc"], K, near, far, tr, True)
+    assert T.nan_equal(rd.MemcpyToHost(), od.data) and T.nan_equal(rn.MemcpyToHost(), on.data)
+    assert T.nan_equal(ri.MemcpyToHost(), oi.data), T.mismatch_report(ri.MemcpyToHost(), oi.data)
+    assert np.isfinite(od.data).mean() > 0.2
