@@ -7,6 +7,7 @@
 #include <vector>
 
 #include <kangaroo/kangaroo.h>
+#include <kangaroo/extra/SavePPM.h>
 
 using namespace roo;
 
@@ -67,6 +68,27 @@ int main()
                 if (!(hvol(x, y, z).val == expect && hvol(x, y, z).w == 1.0f)) ++bad;
             }
     CHECK(bad == 0);
+
+    // ---- persistence: SavePXM of the device volume, LoadPXM into a fresh one (extra/SavePPM.h) ----
+    {
+        const std::string path = "/tmp/roo_api_test_save.vol";
+        SavePXM(path, vol);
+        BoundedVolume<SDF_t, TargetDevice, Manage> vol2;
+        CHECK(LoadPXM(path, vol2));
+        CHECK(vol2.w == (size_t)N && vol2.h == (size_t)N && vol2.d == (size_t)N);
+        CHECK(vol2.bbox.Min().x == -1.0f && vol2.bbox.Max().z == 1.0f);
+        BoundedVolume<SDF_t, TargetHost, Manage> h2(N, N, N, make_float3(-1, -1, -1), make_float3(1, 1, 1));
+        CHECK(kfx_memcpy_2d(h2.ptr, h2.pitch, vol2.ptr, vol2.pitch, N * sizeof(SDF_t), (size_t)N * N, 2, 0) == 0);
+        int diff = 0;
+        for (int z = 0; z < N; ++z)
+            for (int y = 0; y < N; ++y)
+                for (int x = 0; x < N; ++x)
+                    if (!(h2(x, y, z).val == hvol(x, y, z).val && h2(x, y, z).w == hvol(x, y, z).w)) ++diff;
+        CHECK(diff == 0);
+        BoundedVolume<SDF_t, TargetDevice, Manage> missing;
+        CHECK(!LoadPXM("/tmp/roo_api_test_no_such_file.vol", missing));
+        remove(path.c_str());
+    }
 
     // ---- RaycastSdf on the device vs the same march with the host containers ----
     Image<float, TargetDevice, Manage> depth(w, h), img(w, h);

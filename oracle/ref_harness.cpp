@@ -28,6 +28,7 @@
 #include <kangaroo/launch_utils.h>
 #include <kangaroo/pixel_convert.h>
 #include <kangaroo/reweighting.h>
+#include <kangaroo/extra/SavePPM.h>
 
 #include <cstring>
 
@@ -388,6 +389,27 @@ float ref_color_trilinear(const kfo_volume* pc, const float pos[3])
     BoundedVolume<float, TargetHost, DontManage> colorVol(cv0, BoundingBox(make_float3(pc->boxmin[0], pc->boxmin[1], pc->boxmin[2]),
                                                                         make_float3(pc->boxmax[0], pc->boxmax[1], pc->boxmax[2])));
     return colorVol.GetUnitsTrilinearClamped(make_float3(pos[0], pos[1], pos[2]));
+}
+
+// Volume persistence: the reference's own host writer SavePXM(std::ofstream&, Volume<T,TargetHost,Manage>&)
+// (extra/SavePPM.h:46-58) behind the two bbox lines its BoundedVolume overload emits first (:79-87; that
+// overload itself takes a device volume and copies it with the CUDA runtime, so it cannot run here).
+int ref_save_pxm(const char* path, const kfo_volume* pv, int elem_bytes)
+{
+    std::ofstream bFile(path, std::ios::out | std::ios::binary);
+    const BoundingBox bbox(make_float3(pv->boxmin[0], pv->boxmin[1], pv->boxmin[2]), make_float3(pv->boxmax[0], pv->boxmax[1], pv->boxmax[2]));
+    bFile << bbox.boxmin.x << " " << bbox.boxmin.y << " " << bbox.boxmin.z << std::endl;
+    bFile << bbox.boxmax.x << " " << bbox.boxmax.y << " " << bbox.boxmax.z << std::endl;
+    if (elem_bytes == 8) {
+        Volume<SDF_t, TargetHost, DontManage> v((SDF_t*)pv->ptr, pv->w, pv->h, pv->d, pv->pitch, pv->img_pitch);
+        SavePXM<SDF_t, DontManage>(bFile, v);
+    } else if (elem_bytes == 4) {
+        Volume<float, TargetHost, DontManage> v((float*)pv->ptr, pv->w, pv->h, pv->d, pv->pitch, pv->img_pitch);
+        SavePXM<float, DontManage>(bFile, v);
+    } else {
+        return -1;
+    }
+    return 0;
 }
 
 }
