@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libkfx.so")
+# KFX_LIB_PATH: load another build of the same library (A/B of compiler flags in scripts/); default = the in-tree build
+LIB_PATH = os.environ.get("KFX_LIB_PATH") or os.path.join(_HERE, "libkfx.so")
 
 
 class KfxImage(C.Structure):
