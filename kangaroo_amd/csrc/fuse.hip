@@ -175,11 +175,10 @@ __device__ __forceinline__ Obs finish(const FuseParams& p, const V3 Pc, float iz
         w = costheta * 1.0f / Pc.z;
     }
     const float sd = costheta * (md - Pc.z);
-    if (!(sd <= -p.trunc) && isfinite(md) && isfinite(w) && costheta > p.mincos) {
-        o.ok = true;
-        o.val = clampf(sd, -p.trunc, p.trunc);
-        o.w = w;
-    }
+    // unconditional: val / w are only read when ok is set, and selects are cheaper than divergent branches
+    o.ok = ((int)!(sd <= -p.trunc) & (int)isfinite(md) & (int)isfinite(w) & (int)(costheta > p.mincos)) != 0;
+    o.val = clampf(sd, -p.trunc, p.trunc);
+    o.w = w;
     return o;
 }
 
@@ -466,78 +465,66 @@ __global__ __launch_bounds__(256) void k_sdf_fuse_tiled(const FuseParams p, cons
     // 16-byte reads per lane in flight
     unsigned char* cell = p.vptr + (size_t)zbeg * p.vimg_pitch + (size_t)y * p.vpitch + (size_t)x0 * CELL::BYTES;
 
-    if constexpr (FAST) {
-        // Fast mode is co-limited by VALU issue and HBM (about 90 VALU ops per voxel against 16 B), so the
-        // tiled brick runs branch-free: tile indices are clamped into the staged rectangle (always a valid
-        // LDS address), every lane evaluates the observation, and the bounds / predicate results only gate
-        // the update.  A sample that is in bounds but outside the rectangle -- impossible with the one-texel
-        // slack, kept as a guard -- sends the wave through the generic per-lane path for that iteration.
-        if (use_tile) {
-            const int cxmax = tw - 2, cymax = th - 2;
-            for (int z = zbeg; z < zend; z += ZU, cell += (size_t)ZU * p.vimg_pitch) {
-                Obs o[ZU][2];
-                bool any[ZU];
-                bool stray = false;
+    // Tiled bricks run branch-free: tile indices are clamped into the staged rectangle (always a valid LDS
+    // address), every lane evaluates the observation, and the bounds / predicate results only gate the
+    // update.  (Fast mode is co-limited by VALU issue and HBM -- about 75 VALU ops per voxel against 16 B --
+    // and divergent early-outs cost more issue slots than they save.)  A sample that is in bounds but outside
+    // the rectangle -- impossible with the one-texel slack, kept as a guard -- sends the wave through the
+    // generic per-lane path for that iteration.  Values are the same expressions as the generic path.
+    if (use_tile) {
+        const int cxmax = tw - 2, cymax = th - 2;
+        for (int z = zbeg; z < zend; z += ZU, cell += (size_t)ZU * p.vimg_pitch) {
+            Obs o[ZU][2];
+            bool any[ZU];
+            bool stray = false;
 #pragma unroll
-                for (int k = 0; k < ZU; ++k) {
-                    any[k] = false;
-                    if (z + k < zend) { // uniform
-                        const float pz = s_pz[z + k - zbeg];
+            for (int k = 0; k < ZU; ++k) {
+                any[k] = false;
+                if (z + k < zend) { // uniform
+                    const float pz = s_pz[z + k - zbeg];
 #pragma unroll
-                        for (int v = 0; v < 2; ++v) {
-                            const V3 Pc = cam[v].at(p, pz);
-                            float pu, pv, iz;
-                            project<true>(p, Pc, pu, pv, iz);
-                            const bool inb = in_bounds(p, pu, pv);
-                            const float fix = floorf(pu), fiy = floorf(pv);
-                            const int rx = (int)fix - tx0, ry = (int)fiy - ty0;
-                            const bool inside = (unsigned)rx <= (unsigned)cxmax && (unsigned)ry <= (unsigned)cymax;
-                            const int cx = min(max(rx, 0), cxmax), cy = min(max(ry, 0), cymax);
-                            const float4* t = s_tile + (cy * tw + cx);
-                            Corners c;
-                            c.c00 = t[0]; c.c01 = t[1]; c.c10 = t[tw]; c.c11 = t[tw + 1];
-                            const float fx = pu - fix, fy = pv - fiy;
-                            const float md = lerp_f(lerp_f(c.c00.w, c.c01.w, fx), lerp_f(c.c10.w, c.c11.w, fx), fy);
-                            const float nx = lerp_f(lerp_f(c.c00.x, c.c01.x, fx), lerp_f(c.c10.x, c.c11.x, fx), fy);
-                            const float ny = lerp_f(lerp_f(c.c00.y, c.c01.y, fx), lerp_f(c.c10.y, c.c11.y, fx), fy);
-                            const float nz = lerp_f(lerp_f(c.c00.z, c.c01.z, fx), lerp_f(c.c10.z, c.c11.z, fx), fy);
-                            const float dotn = __builtin_fmaf(nz, Pc.z, __builtin_fmaf(ny, Pc.y, nx * Pc.x));
-                            const float len2 = __builtin_fmaf(Pc.z, Pc.z, __builtin_fmaf(Pc.y, Pc.y, Pc.x * Pc.x));
-                            const float costheta = -dotn * __builtin_amdgcn_rsqf(len2);
-                            const float w = costheta * iz;
-                            const float sd = costheta * (md - Pc.z);
-                            o[k][v].val = clampf(sd, -p.trunc, p.trunc);
-                            o[k][v].w = w;
-                            o[k][v].ok = ((int)inb & (int)inside & (int)!(sd <= -p.trunc) & (int)isfinite(md) & (int)isfinite(w) & (int)(costheta > p.mincos)) != 0;
-                            stray |= ((int)inb & (int)!inside) != 0;
-                        }
-                        any[k] = ((int)o[k][0].ok | (int)o[k][1].ok) != 0;
+                    for (int v = 0; v < 2; ++v) {
+                        const V3 Pc = cam[v].at(p, pz);
+                        float pu, pv, iz;
+                        project<FAST>(p, Pc, pu, pv, iz);
+                        const bool inb = in_bounds(p, pu, pv);
+                        const float fix = floorf(pu), fiy = floorf(pv);
+                        const int rx = (int)fix - tx0, ry = (int)fiy - ty0;
+                        const bool inside = (unsigned)rx <= (unsigned)cxmax && (unsigned)ry <= (unsigned)cymax;
+                        const int cx = min(max(rx, 0), cxmax), cy = min(max(ry, 0), cymax);
+                        const float4* t = s_tile + (cy * tw + cx);
+                        Corners c;
+                        c.c00 = t[0]; c.c01 = t[1]; c.c10 = t[tw]; c.c11 = t[tw + 1];
+                        o[k][v] = finish<FAST>(p, Pc, iz, pu - fix, pv - fiy, c);
+                        o[k][v].ok = ((int)o[k][v].ok & (int)inb & (int)inside) != 0;
+                        stray |= ((int)inb & (int)!inside) != 0;
                     }
+                    any[k] = ((int)o[k][0].ok | (int)o[k][1].ok) != 0;
                 }
-                if (__builtin_expect(__ballot(stray) != 0ull, 0)) {
-#pragma unroll
-                    for (int k = 0; k < ZU; ++k)
-                        if (z + k < zend) {
-                            const float pz = s_pz[z + k - zbeg];
-                            o[k][0] = observe<true, true>(p, cam[0].at(p, pz));
-                            o[k][1] = observe<true, true>(p, cam[1].at(p, pz));
-                            any[k] = o[k][0].ok || o[k][1].ok;
-                        }
-                }
-                float4 c[ZU];
+            }
+            if (__builtin_expect(__ballot(stray) != 0ull, 0)) {
 #pragma unroll
                 for (int k = 0; k < ZU; ++k)
-                    if (any[k]) c[k] = CELL::ld2(cell + (size_t)k * p.vimg_pitch);
-#pragma unroll
-                for (int k = 0; k < ZU; ++k)
-                    if (any[k]) {
-                        if (o[k][0].ok) accumulate<true, CELL>(o[k][0], p.max_w, c[k].x, c[k].y);
-                        if (o[k][1].ok) accumulate<true, CELL>(o[k][1], p.max_w, c[k].z, c[k].w);
-                        CELL::st2(cell + (size_t)k * p.vimg_pitch, c[k]);
+                    if (z + k < zend) {
+                        const float pz = s_pz[z + k - zbeg];
+                        o[k][0] = observe<FAST, true>(p, cam[0].at(p, pz));
+                        o[k][1] = observe<FAST, true>(p, cam[1].at(p, pz));
+                        any[k] = o[k][0].ok || o[k][1].ok;
                     }
             }
-            return;
+            float4 c[ZU];
+#pragma unroll
+            for (int k = 0; k < ZU; ++k)
+                if (any[k]) c[k] = CELL::ld2(cell + (size_t)k * p.vimg_pitch);
+#pragma unroll
+            for (int k = 0; k < ZU; ++k)
+                if (any[k]) {
+                    if (o[k][0].ok) accumulate<FAST, CELL>(o[k][0], p.max_w, c[k].x, c[k].y);
+                    if (o[k][1].ok) accumulate<FAST, CELL>(o[k][1], p.max_w, c[k].z, c[k].w);
+                    CELL::st2(cell + (size_t)k * p.vimg_pitch, c[k]);
+                }
         }
+        return;
     }
     for (int z = zbeg; z < zend; z += ZU, cell += (size_t)ZU * p.vimg_pitch) {
         Obs o[ZU][2];
