@@ -207,6 +207,61 @@ def helper_vectors(R, name):
     print("%-28s %8.1f KiB" % (name + ".npz", os.path.getsize(path) / 1024))
 
 
+def next_rows_fixture(R, name):
+    """SURVEY 8(f) rows, all from the reference's own headers (oracle/ref_harness.cpp): the ICP normal equations
+    (per-block and summed), two frames of colour fusion, and the bytes of a saved volume file."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import test_color_cpu as TC
+    import test_tracking_cpu as TT
+    from kangaroo_amd import tracking
+    out = {}
+    # ---- ICP ----
+    R.ref_icp_point_plane.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, PF, PF, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
+    R.ref_icp_point_plane.restype = None
+    w, h = 80, 60
+    K, Pl, Pr, Nr, _, _ = TT.icp_inputs("room", w, h, True)
+    T_lp = tracking.se3_exp([0.004, -0.003, 0.002, 0.003, -0.002, 0.001])
+    KT = (tracking.k_matrix(K) @ T_lp[:3]).astype(np.float32)
+    T_pl = tracking.se3_inv(T_lp)[:3].astype(np.float32)
+    dbg = oracle.Image(w, h, channels=4)
+    lss, blocks = oracle.icp_point_plane(Pl, Pr, Nr, KT, T_pl, 0.1, dbg, want_blocks=True, fn=R.ref_icp_point_plane)
+    out.update(icp_Pl=Pl.data.copy(), icp_Pr=Pr.data.copy(), icp_Nr=Nr.data.copy(), icp_KT=KT, icp_T_pl=T_pl, icp_c=np.float32(0.1),
+               icp_lss=np.frombuffer(lss.tobytes(), np.uint8).copy(), icp_blocks=np.frombuffer(blocks.tobytes(), np.uint8).copy(),
+               icp_debug=dbg.data.copy())
+    # ---- colour fusion ----
+    R.ref_sdf_fuse_color.restype = C.c_uint64
+    R.ref_sdf_fuse_color.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, PF, PF, C.c_void_p, PF, PF, C.c_float, C.c_float,
+                                     C.c_float, C.c_int]
+    dims, cw, ch = (24, 20, 18), 96, 72
+    vol, cvol, K, Kimg, tr, near, far, inputs = TC.color_setup(0, w, h, cw, ch, dims=dims)
+    counts = []
+    for i, fr in enumerate(inputs):
+        keep = [np.ascontiguousarray(a, np.float32).reshape(-1) for a in (fr["T_cw"], K, fr["T_iw"], Kimg)]
+        counts.append(R.ref_sdf_fuse_color(vol.ref(), cvol.ref(), fr["f"].ref(), fr["nrm"].ref(), keep[0].ctypes.data_as(PF),
+                                           keep[1].ctypes.data_as(PF), fr["rgb"].ref(), keep[2].ctypes.data_as(PF),
+                                           keep[3].ctypes.data_as(PF), tr, 1000.0, 0.1, 0))
+        out["col_depth%d" % i] = fr["f"].data.copy()
+        out["col_normals%d" % i] = fr["nrm"].data.copy()
+        out["col_rgb%d" % i] = fr["rgb"].data.copy()
+        out["col_T_cw%d" % i] = fr["T_cw"]
+        out["col_T_iw%d" % i] = fr["T_iw"]
+    out.update(col_K=K, col_Kimg=Kimg, col_trunc=np.float32(tr), col_dims=np.array(dims), col_counts=np.array(counts),
+               col_volume=vol.data.copy(), col_colour=cvol.data.copy())
+    # ---- SavePXM bytes ----
+    import tempfile
+    R.ref_save_pxm.argtypes = [C.c_char_p, C.c_void_p, C.c_int]
+    small = oracle.Volume(6, 5, 4, (-1.25, -0.333333343, 2.0), (1.0, 0.1, 4.000001), pitch_bytes=6 * 8 + 16)
+    small.data[...] = np.random.default_rng(5).standard_normal(small.data.shape).astype(np.float32)
+    with tempfile.TemporaryDirectory() as d:
+        fn = os.path.join(d, "v.vol")
+        assert R.ref_save_pxm(fn.encode(), small.ref(), 8) == 0
+        out.update(pxm_volume=small.data.copy(), pxm_boxmin=small.boxmin, pxm_boxmax=small.boxmax,
+                   pxm_bytes=np.frombuffer(open(fn, "rb").read(), np.uint8).copy())
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print("%-28s %8.1f KiB" % (name + ".npz", os.path.getsize(path) / 1024))
+
+
 if __name__ == "__main__":
     if not os.path.exists(REF_SO):
         sys.exit("build oracle/_ref first: make -C oracle ref")
@@ -216,3 +271,4 @@ if __name__ == "__main__":
     chain_fixture(R, "room_ragged_roi", "room", 0, 80, 60, 2, dims=(40, 36, 44), roi=True, subpix=False)
     sphere_fixture(R, "sphere32_trunc0", 32, 64, 48, 0.0)
     helper_vectors(R, "ref_helper_vectors")
+    next_rows_fixture(R, "ref_next_rows")
