@@ -1,12 +1,15 @@
 // raycast.hip -- per-pixel sphere-traced ray-march of the TSDF (roo::RaycastSdf) for gfx950.
 //
 // Reference behaviour: src/cu_raycast.cu:14-113 (PhongShade, KernRaycastSdf) with the
-// samplers of BoundedVolume.h:93-106 / Volume.h:224-295.  New kernel: a wave64 owns an
-// 8x8 pixel tile (coherent rays -> the 8 trilinear corners of neighbouring lanes share
-// cache lines), a workgroup is 2x2 such tiles; each trilinear sample is four 16-byte
+// samplers of BoundedVolume.h:93-106 / Volume.h:224-295.  New kernel: a wave64 owns a
+// 32x2 pixel tile (coherent rays: the kernel is bound by the number of distinct 64-byte lines a
+// wave touches per step, and cells are contiguous along x -- 8x8 tiles were 18 % slower, A/B in
+// scripts/raycast_ab.py), a workgroup is 2x2 such tiles; each trilinear sample is four 16-byte
 // loads (the x and x+1 cells of an AoS row are contiguous) instead of eight 8-byte ones;
 // the gradient stencil is 20 distinct cells instead of 32 loads; missed rays skip the
 // (discarded) normal evaluation of the reference.
+#include <cstdlib>
+
 #include <hip/hip_fp16.h>
 
 #include "kfx_device.h"
@@ -26,6 +29,8 @@ struct RayParams {
     int w, h;
     float near, far, trunc;
     int subpix;
+    int tile_log2w;   // log2 of the wave's pixel-tile width (3: 8x8, 4: 16x4, 5: 32x2)
+    int wg_log2x;     // log2 of the number of wave tiles side by side in a workgroup (0: 1x4, 1: 2x2, 2: 4x1)
 };
 
 // ---- cell readers: RayF32 = roo::SDF_t {float val; float w;}, RayF16 = roo::SDF_h {half val; half w;} ----
@@ -164,10 +169,12 @@ __device__ __forceinline__ float phong(const V3 p_c, const V3 n_c)
 template <typename CELL, bool COLOR>
 __global__ __launch_bounds__(256) void k_raycast_sdf(const RayParams p, const ColorGeom cv)
 {
-    // wave -> 8x8 tile; workgroup -> 16x16 pixels
+    // wave -> (1 << tile_log2w) x (64 >> tile_log2w) pixel tile; workgroup -> 2 x 2 such tiles
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int u = blockIdx.x * 16 + (wv & 1) * 8 + (lane & 7);
-    const int v = blockIdx.y * 16 + (wv >> 1) * 8 + (lane >> 3);
+    const int tw = 1 << p.tile_log2w, th = 64 >> p.tile_log2w;
+    const int wgx = 1 << p.wg_log2x, wgy = 4 >> p.wg_log2x; // waves per workgroup along x / y
+    const int u = (blockIdx.x * wgx + (wv & (wgx - 1))) * tw + (lane & (tw - 1));
+    const int v = (blockIdx.y * wgy + (wv >> p.wg_log2x)) * th + (lane >> p.tile_log2w);
     if (u >= p.w || v >= p.h) return;
 
     const V3 c_w = v3(p.T.m[3], p.T.m[7], p.T.m[11]);                              // SE3Translation
@@ -260,8 +267,8 @@ template <typename CELL>
 __global__ __launch_bounds__(256) void k_raycast_sdf_slab(const RayParams p, const SlabRay sl)
 {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int u = blockIdx.x * 16 + (wv & 1) * 8 + (lane & 7);
-    const int v = blockIdx.y * 16 + (wv >> 1) * 8 + (lane >> 3);
+    const int u = blockIdx.x * 64 + (wv & 1) * 32 + (lane & 31); // wave = 32 x 2 pixels, as k_raycast_sdf's default
+    const int v = blockIdx.y * 4 + (wv >> 1) * 2 + (lane >> 5);
     if (u >= p.w || v >= p.h) return;
     const size_t plane = (size_t)p.w * p.h;
     float* st = sl.state + (size_t)v * p.w + u; // plane k at st[k * plane]
@@ -396,7 +403,11 @@ static int raycast_launch(const kfx_image* depth, const kfx_image* norm, const k
     p.trunc = trunc_dist;
     p.subpix = subpix ? 1 : 0;
 
-    dim3 grid(ceil_div(p.w, 16), ceil_div(p.h, 16));
+    static const int tile_env = [] { const char* e = getenv("KFX_RAYCAST_TILE"); const int v = e ? atoi(e) : 5; return v < 0 ? 0 : (v > 6 ? 6 : v); }();
+    static const int wg_env = [] { const char* e = getenv("KFX_RAYCAST_WG"); const int v = e ? atoi(e) : 1; return v < 0 ? 0 : (v > 2 ? 2 : v); }();
+    p.tile_log2w = tile_env;
+    p.wg_log2x = wg_env;
+    dim3 grid(ceil_div(p.w, (1 << p.wg_log2x) << p.tile_log2w), ceil_div(p.h, (4 >> p.wg_log2x) * (64 >> p.tile_log2w)));
     ColorGeom cv{};
     if (colorvol) {
         if (!colorvol->ptr) return set_error(KFX_E_NULL, "RaycastSdf(colour): null colour volume");
@@ -481,8 +492,10 @@ extern "C" int kfx_raycast_sdf_slab(float* state, int init, const kfx_volume* vo
     p.far = far;
     p.trunc = trunc_dist;
     p.subpix = subpix ? 1 : 0;
+    p.tile_log2w = 3;
+    p.wg_log2x = 1;
     SlabRay sl{state, own_lo, own_hi, (int)slab->z_offset, (int)(slab->z_offset + vol->d), init ? 1 : 0};
-    dim3 grid(ceil_div(w, 16), ceil_div(h, 16));
+    dim3 grid(ceil_div(w, 64), ceil_div(h, 4));
     hipLaunchKernelGGL(k_raycast_sdf_slab<RayF32>, grid, dim3(256), 0, (hipStream_t)stream, p, sl);
     return check_launch("kfx_raycast_sdf_slab");
 }
