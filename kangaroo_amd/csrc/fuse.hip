@@ -805,17 +805,52 @@ static int fuse_launch(const kfx_volume* vol, const kfx_image* depth, const kfx_
     // tuning / A-B knobs (read once): KFX_FUSE_TILED=0 forces the global-gather kernel,
     // KFX_FUSE_CAP sets the LDS tile capacity in texels (16 B each)
     static const int tiled = [] { const char* e = getenv("KFX_FUSE_TILED"); return e ? atoi(e) : 1; }();
-    static const int cap_px = [] { const char* e = getenv("KFX_FUSE_CAP"); const int v = e ? atoi(e) : 1536; return v < 64 ? 64 : (v > 8192 ? 8192 : v); }();
+    static const int cap_env = [] { const char* e = getenv("KFX_FUSE_CAP"); const int v = e ? atoi(e) : 0; return v <= 0 ? 0 : (v < 64 ? 64 : (v > 8192 ? 8192 : v)); }();
     if (tiled && vec2 && small_images) {
-        dim3 grid(ceil_div(p.X, TB_X), ceil_div(p.Y, TB_Y), ceil_div(p.Z, FUSE_ZC));
-        const size_t lds = (size_t)cap_px * sizeof(float4);
         // slices per iteration: 2 in fast mode (memory-bound: more reads in flight), 1 in exact mode (VALU-bound)
         static const int zu_env = [] { const char* e = getenv("KFX_FUSE_ZU"); return e ? atoi(e) : 0; }();
         const int zu = zu_env ? zu_env : (fast ? 2 : 1);
-        if (fast && zu == 2) hipLaunchKernelGGL((k_sdf_fuse_tiled<true, 2, CELL>), grid, dim3(256), lds, s, p, cap_px);
-        else if (fast) hipLaunchKernelGGL((k_sdf_fuse_tiled<true, 1, CELL>), grid, dim3(256), lds, s, p, cap_px);
-        else if (zu == 2) hipLaunchKernelGGL((k_sdf_fuse_tiled<false, 2, CELL>), grid, dim3(256), lds, s, p, cap_px);
-        else hipLaunchKernelGGL((k_sdf_fuse_tiled<false, 1, CELL>), grid, dim3(256), lds, s, p, cap_px);
+        // LDS tile capacity per z-range.  A brick's pixel rectangle grows with the pixels-per-voxel ratio
+        // r = f * voxel / Z: 1536 texels (24 KiB, 6 workgroups per CU) hold it up to r ~ 1.3; beyond that more
+        // bricks would fall back to global gathers, so the capacity grows with r^2 up to 3072 texels (48 KiB,
+        // 3 workgroups per CU) -- measured at 512^3, 1280x960, 2-4 m: 0.80 ms (1536) / 0.62 ms (3072), while at
+        // r < 1.2 the larger tile only costs occupancy (0.39 -> 0.51 ms).  r is evaluated at the centre of each
+        // 64-slice range and ranges with equal capacity share a launch.
+        auto cap_for = [&](int z0, int z1) -> int {
+            if (cap_env) return cap_env;
+            const float cx = p.bmin.x + 0.5f * p.size.x, cy = p.bmin.y + 0.5f * p.size.y;
+            const float cz = p.bmin.z + p.size.z * (0.5f * (float)(z0 + z1 - 1) + (float)p.zoff) / p.d1;
+            const float Zc = p.T.m[8] * cx + p.T.m[9] * cy + p.T.m[10] * cz + p.T.m[11];
+            if (!(Zc > 0.f)) return 1536;
+            const float voxel = fmaxf(p.size.x / p.w1, p.size.y / p.h1);
+            const float r = fmaxf(fabsf(p.K.fu), fabsf(p.K.fv)) * voxel / Zc;
+            if (!(r > 1.3f)) return 1536;
+            const float want = 1536.f * (r / 1.05f) * (r / 1.05f);
+            const int c = want >= 3072.f ? 3072 : ((int)want + 511) / 512 * 512;
+            return c < 1536 ? 1536 : c;
+        };
+        const int zstep = 64;
+        int z0 = 0;
+        while (z0 < p.Z) {
+            int z1 = z0 + zstep < p.Z ? z0 + zstep : p.Z;
+            const int cap_px = cap_for(z0, z1);
+            while (z1 < p.Z) { // extend over following ranges that want the same capacity
+                const int z2 = z1 + zstep < p.Z ? z1 + zstep : p.Z;
+                if (cap_for(z1, z2) != cap_px) break;
+                z1 = z2;
+            }
+            FuseParams q = p;
+            q.vptr = p.vptr + (size_t)z0 * p.vimg_pitch;
+            q.zoff = p.zoff + z0;
+            q.Z = z1 - z0;
+            dim3 grid(ceil_div(q.X, TB_X), ceil_div(q.Y, TB_Y), ceil_div(q.Z, FUSE_ZC));
+            const size_t lds = (size_t)cap_px * sizeof(float4);
+            if (fast && zu == 2) hipLaunchKernelGGL((k_sdf_fuse_tiled<true, 2, CELL>), grid, dim3(256), lds, s, q, cap_px);
+            else if (fast) hipLaunchKernelGGL((k_sdf_fuse_tiled<true, 1, CELL>), grid, dim3(256), lds, s, q, cap_px);
+            else if (zu == 2) hipLaunchKernelGGL((k_sdf_fuse_tiled<false, 2, CELL>), grid, dim3(256), lds, s, q, cap_px);
+            else hipLaunchKernelGGL((k_sdf_fuse_tiled<false, 1, CELL>), grid, dim3(256), lds, s, q, cap_px);
+            z0 = z1;
+        }
     } else if (vec2) {
         dim3 grid(ceil_div(p.X, 128), ceil_div(p.Y, FUSE_ROWS), ceil_div(p.Z, FUSE_ZC));
         if (fast && small_images) hipLaunchKernelGGL((k_sdf_fuse<2, true, true, CELL>), grid, dim3(256), 0, s, p);

@@ -98,7 +98,10 @@ def test_gpu_preprocess_golden(roo):
 # seeded oracle comparisons at sizes the oracle finishes in seconds
 # ---------------------------------------------------------------------------------
 @pytest.mark.parametrize("scene,N,w,h,frames", [("room", 64, 160, 120, 4), ("full", 64, 160, 120, 2),
-                                                ("room", 128, 640, 480, 2)])
+                                                ("room", 128, 640, 480, 2),
+                                                # pixels per voxel cross 1.3 inside the volume: SdfFuse splits into two
+                                                # launches with different LDS tile capacities (fuse.hip, cap_for)
+                                                ("room", 192, 400, 300, 2)])
 def test_gpu_fuse_raycast_vs_oracle(roo, scene, N, w, h, frames):
     ovol = T.make_volume(N, scene)
     K, tr, fr = T.fuse_frames_oracle(ovol, scene, w, h, frames)
