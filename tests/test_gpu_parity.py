@@ -818,3 +818,114 @@ def test_gpu_colour_fusion_and_raycast_vs_oracle(roo, dims, w, h, cw, ch, full):
     assert T.nan_equal(rd.MemcpyToHost(), od.data) and T.nan_equal(rn.MemcpyToHost(), on.data)
     assert T.nan_equal(ri.MemcpyToHost(), oi.data), T.mismatch_report(ri.MemcpyToHost(), oi.data)
     assert np.isfinite(od.data).mean() > 0.2
+
+
+# ---------------------------------------------------------------------------------
+# BASELINE configs C4 / C5 at full size on one GPU (size-independent properties)
+# ---------------------------------------------------------------------------------
+def test_gpu_c4_1024_cubed_in_eight_slabs(roo):
+    """Config C4 (1024^3 over 8 GPUs) with the eight ranks emulated on one MI355X: each 'rank' owns a separately
+    allocated slab (128 planes + 2 ghost planes per side) and integrates it through kfx_sdf_fuse_slab; the planes
+    must be bit-identical to the monolithic 8 GiB volume, and the exact slab march (state handed from slab to
+    slab, merged as SlabPipeline.raycast_exact does) must reproduce the monolithic RaycastSdf bit for bit."""
+    import torch
+    from kangaroo_amd.pipeline import slab_range
+    N, w, h, world, G, scene = 1024, 640, 480, 8, 2, "room"
+    bmin, bmax, near, far = scenes.SCENES[scene]
+    K = scenes.intrinsics(w, h)
+    tr = scenes.trunc_dist(bmin, bmax, (N, N, N))
+    full = roo.BoundedVolume(N, N, N, bmin, bmax)
+    roo.SdfReset(full, float("nan"))
+    spans = [slab_range(N, r, world) for r in range(world)]
+    stored = [(max(z0 - G, 0), min(z1 + G, N)) for z0, z1 in spans]
+    f32 = np.float32
+    size_z = f32(bmax[2]) - f32(bmin[2])
+    slabs = []
+    for s0, s1 in stored:  # the bbox SlabPipeline._alloc_volume gives a rank's volume
+        lo = (bmin[0], bmin[1], float(f32(bmin[2]) + size_z * f32(s0) / f32(N - 1)))
+        hi = (bmax[0], bmax[1], float(f32(bmin[2]) + size_z * f32(s1 - 1) / f32(N - 1)))
+        v = roo.BoundedVolume(N, N, s1 - s0, lo, hi)
+        roo.SdfReset(v, float("nan"))
+        slabs.append(v)
+    f, vbo, nrm = roo.Image(w, h), roo.Image(w, h, "f32x4"), roo.Image(w, h, "f32x4")
+    for i in range(2):
+        T_wc = scenes.orbit_pose(i, 30)
+        graw = T.upload_image(roo, scenes.render_depth(scene, w, h, T_wc, K))
+        roo.BilateralFilter(f, graw, **scenes.BILATERAL)
+        roo.DepthToVbo(vbo, f, K)
+        roo.NormalsFromVbo(nrm, vbo)
+        T_cw = scenes.se3_inverse(T_wc)
+        roo.SdfFuse(full, f, nrm, T_cw, K, tr, scenes.MAX_W, scenes.MIN_COS_THETA)
+        for v, (s0, s1) in zip(slabs, stored):
+            roo.SdfFuse(v, f, nrm, T_cw, K, tr, scenes.MAX_W, scenes.MIN_COS_THETA, full_extent=True, slab=(N, s0, bmin[2], bmax[2]))
+    ft = full.tensor().view(torch.int32)
+    for v, (s0, s1) in zip(slabs, stored):
+        assert torch.equal(v.tensor().view(torch.int32), ft[s0:s1]), (s0, s1)
+    assert int((~torch.isnan(full.tensor()[..., 0])).sum()) > 0.3 * N ** 3
+    # exact march over the eight slabs
+    rd, rn, ri = roo.Image(w, h), roo.Image(w, h, "f32x4"), roo.Image(w, h)
+    roo.RaycastSdf(rd, rn, ri, full, T_wc, K, near, far, tr, True)
+    want = (rd.MemcpyToHost(), rn.MemcpyToHost(), ri.MemcpyToHost())
+    assert np.isfinite(want[0]).mean() > 0.5
+    states = [torch.empty((9, h, w), dtype=torch.float32, device="cuda") for _ in range(world)]
+    rounds = 0
+    while True:
+        for r in range(world):
+            roo.RaycastSdfSlab(states[r], rounds == 0, slabs[r], (N, stored[r][0], float(bmin[2]), float(bmax[2])), spans[r][0], spans[r][1],
+                               w, h, T_wc, K, near, far, tr, True)
+        rounds += 1
+        march = [s[0:5].view(torch.int32) for s in states]
+        total = torch.zeros_like(march[0])
+        for m in march:
+            total += torch.where((m[4] != 0).unsqueeze(0), m, torch.zeros_like(m))
+        for m in march:
+            m.copy_(torch.where((total[4] != 0).unsqueeze(0), total, m))
+        if not bool(((states[0][3] == 0) | (states[0][3] == 3)).any()):
+            break
+        assert rounds <= world + 3
+    out = torch.zeros((4, h, w), dtype=torch.int32, device="cuda")
+    for s in states:
+        out += s[5:9].view(torch.int32)
+    states[0][5:9].view(torch.int32).copy_(out)
+    gd, gn, gi = roo.Image(w, h), roo.Image(w, h, "f32x4"), roo.Image(w, h)
+    roo.RaycastStateToImages(gd, gn, gi, states[0])
+    assert T.nan_equal(gd.MemcpyToHost(), want[0]) and T.nan_equal(gn.MemcpyToHost(), want[1]) and T.nan_equal(gi.MemcpyToHost(), want[2])
+    del full, slabs, states, ft
+    torch.cuda.empty_cache()
+
+
+def test_gpu_c5_2048_cubed_half_volume_raycast(roo):
+    """Config C5: a 2048^3 fp16 TSDF (32 GiB, one MI355X holds it) ray-cast against the analytic sphere it encodes
+    (SdfSphere, the reference's own synthetic volume): depth within a voxel + half precision of the exact
+    ray-sphere intersection, camera-frame normals pointing back along the sphere's radius."""
+    import torch
+    N, w, h = 2048, 640, 480
+    K = scenes.intrinsics(w, h)
+    vol = roo.BoundedVolume(N, N, N, (-1, -1, -1), (1, 1, 1), kind="f16")
+    assert vol.img_pitch * N == 32 * 2 ** 30
+    R = 0.9
+    roo.SdfSphere(vol, (0.0, 0.0, 0.0), R)
+    T_wc = np.array([[1, 0, 0, 0.05], [0, 1, 0, -0.02], [0, 0, 1, -2.6]], np.float32)
+    tr = float(2.0 * np.linalg.norm(vol.VoxelSizeUnits()))
+    rd, rn, ri = roo.Image(w, h), roo.Image(w, h, "f32x4"), roo.Image(w, h)
+    roo.RaycastSdf(rd, rn, ri, vol, T_wc, K, 0.1, 10.0, tr, True)
+    d, n = rd.MemcpyToHost(), rn.MemcpyToHost()
+    u, v = np.meshgrid(np.arange(w, dtype=np.float64), np.arange(h, dtype=np.float64))
+    ray = np.stack([(u - K[2]) / K[0], (v - K[3]) / K[1], np.ones_like(u)], -1)
+    c = T_wc[:, 3].astype(np.float64)
+    b = (ray * c).sum(-1)
+    a = (ray * ray).sum(-1)
+    disc = b * b - a * (c @ c - R * R)
+    lam = np.where(disc > 0, (-b - np.sqrt(np.maximum(disc, 0))) / a, np.nan)
+    inner = disc > a * (R * 0.05) ** 2 * 4            # stay off the silhouette, where the march grazes the surface
+    hit = np.isfinite(d)
+    assert (hit[inner]).all() and hit.sum() > 0.3 * w * h
+    voxel = 2.0 / (N - 1)
+    err = np.abs(d[inner] - lam[inner])
+    assert err.max() < 2 * voxel + 2e-3, err.max()      # half cells: 11-bit significand on |sdf| <~ 1
+    pos = c + ray * d[..., None]
+    radial = pos / np.linalg.norm(pos, axis=-1, keepdims=True)   # world = camera axes (identity rotation)
+    cosang = (n[..., :3] * radial).sum(-1)
+    assert (cosang[inner] > 0.97).mean() > 0.99
+    del vol
+    torch.cuda.empty_cache()
