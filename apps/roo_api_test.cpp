@@ -90,6 +90,31 @@ int main()
         remove(path.c_str());
     }
 
+    // ---- mesh extraction: SaveMesh of the sphere (MarchingCubes.h) -- triangle count, vertices on the sphere ----
+    {
+        const size_t ntri = SaveMesh("/tmp/roo_api_test_mesh", vol);
+        CHECK(ntri > 1000);
+        FILE* f = fopen("/tmp/roo_api_test_mesh.ply", "rb");
+        CHECK(f != nullptr);
+        if (f) {
+            char line[256];
+            size_t nv = 0;
+            while (fgets(line, sizeof line, f) && strncmp(line, "end_header", 10) != 0)
+                if (sscanf(line, "element vertex %zu", &nv) == 1) {}
+            CHECK(nv == 3 * ntri);
+            float rec[6];
+            int off_sphere = 0;
+            for (size_t i = 0; i < nv && fread(rec, 4, 6, f) == 6; ++i) {
+                const float r = sqrtf(rec[0] * rec[0] + rec[1] * rec[1] + rec[2] * rec[2]);
+                const float nr = (rec[0] * rec[3] + rec[1] * rec[4] + rec[2] * rec[5]) / r;
+                if (fabsf(r - 0.9f) > 0.01f || nr < 0.95f) ++off_sphere;
+            }
+            CHECK(off_sphere == 0);
+            fclose(f);
+            remove("/tmp/roo_api_test_mesh.ply");
+        }
+    }
+
     // ---- RaycastSdf on the device vs the same march with the host containers ----
     Image<float, TargetDevice, Manage> depth(w, h), img(w, h);
     Image<float4, TargetDevice, Manage> norm(w, h);

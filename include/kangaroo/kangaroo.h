@@ -29,3 +29,4 @@
 #include <kangaroo/cu_raycast.h>
 #include <kangaroo/reweighting.h>
 #include <kangaroo/cu_model_refinement.h>
+#include <kangaroo/MarchingCubes.h>

@@ -82,6 +82,8 @@ def lib():
         L.kfo_sdf_fuse_color.restype = C.c_uint64
         L.kfo_raycast_sdf_color.argtypes = [PI, PI, PI, PV, PV, PF, PF, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int]
         L.kfo_raycast_sdf_color.restype = None
+        L.kfo_marching_cubes.argtypes = [PV, PV, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.kfo_marching_cubes.restype = C.c_uint64
         L.kfo_icp_point_plane.argtypes = [PI, PI, PI, PF, PF, C.c_float, PI, C.POINTER(KfoLss6), C.c_void_p]
         L.kfo_icp_point_plane.restype = None
         L.kfo_icp_block_dims.argtypes = [C.c_size_t, C.c_size_t, C.POINTER(C.c_uint)]
@@ -461,3 +463,19 @@ def raycast_sdf_color(depth, norm, img, vol, cvol, T_wc, K, near, far, trunc, su
     _, k = _fp(K)
     lib().kfo_raycast_sdf_color(depth.ref(), norm.ref(), img.ref(), vol.ref(), cvol.ref(), t, k, near, far, trunc,
                                 1 if subpix else 0, nthreads)
+
+
+def marching_cubes(vol, cvol, ntris, emask, tris):
+    """SaveMesh's extraction with the given case tables (ntris[256] u8, emask[256] u16, tris[256, k] i8).
+    Returns (verts (3T,3), norms (3T,3), colors (3T,4) or None)."""
+    ntris = np.ascontiguousarray(ntris, np.uint8)
+    emask = np.ascontiguousarray(emask, np.uint16)
+    tris = np.ascontiguousarray(tris, np.int8)
+    L = lib()
+    cref = cvol.ref() if cvol is not None else None
+    nt = int(L.kfo_marching_cubes(vol.ref(), cref, ntris.ctypes.data, emask.ctypes.data, tris.ctypes.data, tris.shape[1], None, None, None))
+    verts, norms = np.zeros((3 * nt, 3), np.float32), np.zeros((3 * nt, 3), np.float32)
+    colors = np.zeros((3 * nt, 4), np.float32) if cvol is not None else None
+    L.kfo_marching_cubes(vol.ref(), cref, ntris.ctypes.data, emask.ctypes.data, tris.ctypes.data, tris.shape[1], verts.ctypes.data,
+                         norms.ctypes.data, colors.ctypes.data if colors is not None else None)
+    return verts, norms, colors

@@ -1114,3 +1114,64 @@ void kfo_raycast_sdf_color(const kfo_image* depth, const kfo_image* norm, const 
             ((float*)img_row(img, (size_t)v))[u] = trilinear_clamped_f32(cvol, add3(c_w, scale3(ray_w, d)));
         }
 }
+
+/* ============================================================================
+ * Marching cubes: MarchingCubes.h:43-143 inside SaveMesh's loop nest (:226-232).
+ * The case tables are passed in (the product's generated tables; tests also pass the reference's own).
+ * verts / norms: 3 floats per vertex, colors: 4 floats per vertex, three vertices per triangle, emitted in the
+ * reference's order (x outer, y, z inner).  With verts == NULL only counts.  Returns the number of triangles.
+ * ========================================================================== */
+uint64_t kfo_marching_cubes(const kfo_volume* vol, const kfo_volume* cvol, const unsigned char* ntris, const unsigned short* emask,
+                            const signed char* tris, int tri_stride, float* verts, float* norms, float* colors)
+{
+    static const int OFF[8][3] = {{0, 0, 0}, {1, 0, 0}, {1, 1, 0}, {0, 1, 0}, {0, 0, 1}, {1, 0, 1}, {1, 1, 1}, {0, 1, 1}};
+    static const int EC[12][2] = {{0, 1}, {1, 2}, {2, 3}, {3, 0}, {4, 5}, {5, 6}, {6, 7}, {7, 4}, {0, 4}, {1, 5}, {2, 6}, {3, 7}};
+    const int half = 0;
+    const int color_valid = cvol && cvol->ptr && cvol->w >= 8 && cvol->h >= 8 && cvol->d >= 8; /* BoundedVolume::IsValid */
+    uint64_t nt = 0;
+    const f3 fScale = voxel_size_units(vol);
+    for (int x = 0; x < (int)vol->w - 1; ++x)
+        for (int y = 0; y < (int)vol->h - 1; ++y)
+            for (int z = 0; z < (int)vol->d - 1; ++z) {
+                const f3 p = voxel_position(vol, x, y, z);
+                float v[8];
+                int finite = 1, flag = 0;
+                for (int i = 0; i < 8; ++i) {
+                    v[i] = vol_val(vol, x + OFF[i][0], y + OFF[i][1], z + OFF[i][2]);
+                    if (!isfinite(v[i])) { finite = 0; break; }
+                }
+                if (!finite) continue;
+                for (int i = 0; i < 8; ++i)
+                    if (v[i] <= 0.0f) flag |= 1 << i;
+                const int mask = emask[flag];
+                if (mask == 0) continue;
+                f3 ev[12], en[12];
+                for (int e = 0; e < 12; ++e) {
+                    if (!(mask & (1 << e))) continue;
+                    const int c0 = EC[e][0], c1 = EC[e][1];
+                    const double fDelta = v[c1] - v[c0];                                   /* fGetOffset :25-32 */
+                    const float fOffset = fDelta == 0.0 ? 0.5f : (float)((0.0f - v[c0]) / fDelta);
+                    const float dir[3] = {(float)(OFF[c1][0] - OFF[c0][0]), (float)(OFF[c1][1] - OFF[c0][1]), (float)(OFF[c1][2] - OFF[c0][2])};
+                    ev[e] = mk3(p.x + ((float)OFF[c0][0] + fOffset * dir[0]) * fScale.x, p.y + ((float)OFF[c0][1] + fOffset * dir[1]) * fScale.y,
+                                p.z + ((float)OFF[c0][2] + fOffset * dir[2]) * fScale.z);
+                    const f3 deriv = units_backward_diff(vol, ev[e], NULL, half);
+                    en[e] = div3s(deriv, length3(deriv));
+                    if (!isfinite(en[e].x) || !isfinite(en[e].y) || !isfinite(en[e].z)) en[e] = mk3(0, 0, 0);
+                }
+                for (int t = 0; t < ntris[flag]; ++t) {
+                    if (verts)
+                        for (int c = 0; c < 3; ++c) {
+                            const int e = tris[flag * tri_stride + 3 * t + c];
+                            const uint64_t o = nt * 3 + (uint64_t)c;
+                            verts[o * 3 + 0] = ev[e].x; verts[o * 3 + 1] = ev[e].y; verts[o * 3 + 2] = ev[e].z;
+                            norms[o * 3 + 0] = en[e].x; norms[o * 3 + 1] = en[e].y; norms[o * 3 + 2] = en[e].z;
+                            if (color_valid && colors) {
+                                const float cc = trilinear_clamped_f32(cvol, ev[e]);
+                                colors[o * 4 + 0] = cc; colors[o * 4 + 1] = cc; colors[o * 4 + 2] = cc; colors[o * 4 + 3] = 1.0f;
+                            }
+                        }
+                    ++nt;
+                }
+            }
+    return nt;
+}

@@ -29,6 +29,7 @@
 #include <kangaroo/pixel_convert.h>
 #include <kangaroo/reweighting.h>
 #include <kangaroo/extra/SavePPM.h>
+#include <kangaroo/MarchingCubesTables.h>
 
 #include <cstring>
 
@@ -410,6 +411,16 @@ int ref_save_pxm(const char* path, const kfo_volume* pv, int elem_bytes)
         return -1;
     }
     return 0;
+}
+
+// The reference's marching-cubes case tables (MarchingCubesTables.h:61-348), exposed so that tests can compare
+// the topology of this repo's independently derived tables with them case by case.
+void ref_mc_tables(int edge_flags[256], int tris[256 * 16])
+{
+    for (int i = 0; i < 256; ++i) {
+        edge_flags[i] = aiCubeEdgeFlags[i];
+        for (int j = 0; j < 16; ++j) tris[i * 16 + j] = a2iTriangleConnectionTable[i][j];
+    }
 }
 
 }

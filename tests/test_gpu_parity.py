@@ -929,3 +929,45 @@ def test_gpu_c5_2048_cubed_half_volume_raycast(roo):
     assert (cosang[inner] > 0.97).mean() > 0.99
     del vol
     torch.cuda.empty_cache()
+
+
+# ---------------------------------------------------------------------------------
+# mesh extraction
+# ---------------------------------------------------------------------------------
+@pytest.mark.parametrize("case", ["sphere", "fused_room_colour", "ragged_unobserved"])
+def test_gpu_marching_cubes_vs_oracle(roo, tmp_path, case):
+    """kfx_mc_count / kfx_mc_emit against the oracle's host marching cubes with the same case tables: vertices,
+    normals and colours bit-identical and in the reference's emission order (x outer, y, z inner)."""
+    import test_color_cpu as TC
+    import test_mesh_cpu as TM
+    from kangaroo_amd import mesh
+    ntri, mask, tri = TM.tables()
+    ocvol = None
+    if case == "sphere":
+        ovol = TM.sphere_volume(48, 0.7)
+    elif case == "fused_room_colour":
+        ovol, ocvol, K, Kimg, tr, near, far, inputs = TC.color_setup(0, 160, 120, 160, 120, dims=(64, 64, 64))
+        for fr in inputs:
+            oracle.sdf_fuse_color(ovol, ocvol, fr["f"], fr["nrm"], fr["T_cw"], K, fr["rgb"], fr["T_iw"], Kimg, tr, 1000.0, 0.1, nthreads=0)
+    else:
+        ovol = oracle.Volume(21, 13, 34, (-1, -0.5, -1), (1, 0.7, 1.5), pitch_bytes=21 * 8 + 40)
+        oracle.sdf_sphere(ovol, (0.1, 0.0, 0.2), 0.45)
+        ovol.data[:, :, :, 0][(np.add.outer(np.add.outer(np.arange(34), np.arange(13)), np.arange(21)) % 7) == 0] = np.nan
+    want_v, want_n, want_c = oracle.marching_cubes(ovol, ocvol, ntri, mask, tri)
+    assert len(want_v) > 300
+    vol = roo.BoundedVolume(ovol.w, ovol.h, ovol.d, ovol.boxmin, ovol.boxmax, pitch=ovol.pitch if case == "ragged_unobserved" else None)
+    vol.MemcpyFromHost(ovol.data)
+    cvol = None
+    if ocvol is not None:
+        cvol = roo.BoundedVolume(ocvol.w, ocvol.h, ocvol.d, ocvol.boxmin, ocvol.boxmax, kind="c32")
+        cvol.MemcpyFromHost(ocvol.data)
+    v, n, c = mesh.ExtractMesh(vol, cvol)
+    assert v.shape == want_v.shape
+    assert T.nan_equal(v.cpu().numpy(), want_v) and T.nan_equal(n.cpu().numpy(), want_n)
+    if ocvol is not None:
+        assert T.nan_equal(c.cpu().numpy(), want_c) and (want_c[:, :3] != 0.5).any()
+    else:
+        assert c is None
+    nt = mesh.SaveMesh(str(tmp_path / "m"), vol, cvol)
+    raw = open(str(tmp_path / "m.ply"), "rb").read()
+    assert nt == len(want_v) // 3 and raw.startswith(b"ply\nformat binary_little_endian 1.0") and b"element face %d" % nt in raw[:600]
