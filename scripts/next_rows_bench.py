@@ -81,4 +81,17 @@ T_wc = scenes.orbit_pose(0, 30)
 out["color_raycast_ms"] = round(timed(lambda: roo.RaycastSdfColor(rd, rn, ri, vol, cvol, T_wc, K, near, far, tr, True)), 4)
 out["grey_raycast_ms"] = round(timed(lambda: roo.RaycastSdf(rd, rn, ri, vol, T_wc, K, near, far, tr, True)), 4)
 out["grey_fuse_exact_ms"] = round(timed(lambda: roo.SdfFuse(vol, f, nrm, T_cw, K, tr, scenes.MAX_W, scenes.MIN_COS_THETA)), 4)
+# ---- mesh extraction (f-4): count + prefix sum + emit on the fused 512^3 volume, then PCIe + file ----
+from kangaroo_amd import mesh  # noqa: E402
+mesh.ExtractMesh(vol, cvol)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+v, n, c = mesh.ExtractMesh(vol, cvol)
+torch.cuda.synchronize()
+out["mesh_extract_ms"] = round((time.perf_counter() - t0) * 1e3, 3)
+out["mesh_triangles"] = int(v.shape[0] // 3)
+t0 = time.perf_counter()
+mesh.SaveMesh("/tmp/next_rows_mesh", vol, cvol)
+out["mesh_save_ply_ms"] = round((time.perf_counter() - t0) * 1e3, 1)
+os.remove("/tmp/next_rows_mesh.ply")
 print(json.dumps(out))
