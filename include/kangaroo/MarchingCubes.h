@@ -41,24 +41,31 @@ inline size_t SaveMesh(std::string filename, BoundedVolume<SDF_t,TargetDevice,Ma
     GpuCheckStatus(kfx_mc_count(vol.abi(), dcounts, 0));
     std::vector<unsigned char> counts(ncubes);
     GpuCheckStatus(kfx_memcpy_2d(counts.data(), ncubes, dcounts, ncubes, ncubes, 1, 2, 0));
-    std::vector<unsigned> offsets(ncubes);
+    std::vector<long long> active;     // cubes with triangles, in emission order
+    std::vector<unsigned> tri_offset;  // triangles emitted before each of them
     size_t ntri = 0;
-    for (size_t i = 0; i < ncubes; ++i) { offsets[i] = (unsigned)ntri; ntri += counts[i]; }
-    unsigned* doffsets = (unsigned*)mesh_detail::DeviceBytes(ncubes * sizeof(unsigned));
-    GpuCheckStatus(kfx_memcpy_2d(doffsets, ncubes * 4, offsets.data(), ncubes * 4, ncubes * 4, 1, 1, 0));
+    for (size_t i = 0; i < ncubes; ++i)
+        if (counts[i]) { active.push_back((long long)i); tri_offset.push_back((unsigned)ntri); ntri += counts[i]; }
+    const size_t na = active.size();
+    long long* dactive = (long long*)mesh_detail::DeviceBytes(na * 8);
+    unsigned* doffsets = (unsigned*)mesh_detail::DeviceBytes(na * 4);
+    if (na) {
+        GpuCheckStatus(kfx_memcpy_2d(dactive, na * 8, active.data(), na * 8, na * 8, 1, 1, 0));
+        GpuCheckStatus(kfx_memcpy_2d(doffsets, na * 4, tri_offset.data(), na * 4, na * 4, 1, 1, 0));
+    }
     const bool color = volColor && volColor->IsValid();
     const size_t nv = 3 * ntri;
     float* dv = (float*)mesh_detail::DeviceBytes(nv * 12);
     float* dn = (float*)mesh_detail::DeviceBytes(nv * 12);
     float* dc = color ? (float*)mesh_detail::DeviceBytes(nv * 16) : nullptr;
-    if (ntri) GpuCheckStatus(kfx_mc_emit(vol.abi(), color ? volColor->abi() : nullptr, doffsets, dv, dn, dc, 0));
+    if (ntri) GpuCheckStatus(kfx_mc_emit(vol.abi(), color ? volColor->abi() : nullptr, dactive, doffsets, (long long)na, dv, dn, dc, 0));
     std::vector<float> v(nv * 3), n(nv * 3), c(color ? nv * 4 : 0);
     if (nv) {
         GpuCheckStatus(kfx_memcpy_2d(v.data(), nv * 12, dv, nv * 12, nv * 12, 1, 2, 0));
         GpuCheckStatus(kfx_memcpy_2d(n.data(), nv * 12, dn, nv * 12, nv * 12, 1, 2, 0));
         if (color) GpuCheckStatus(kfx_memcpy_2d(c.data(), nv * 16, dc, nv * 16, nv * 16, 1, 2, 0));
     }
-    kfx_free(dcounts); kfx_free(doffsets); kfx_free(dv); kfx_free(dn);
+    kfx_free(dcounts); kfx_free(dactive); kfx_free(doffsets); kfx_free(dv); kfx_free(dn);
     if (dc) kfx_free(dc);
 
     FILE* f = fopen((filename + ".ply").c_str(), "wb");

@@ -211,13 +211,16 @@ int kfx_color_reset(const kfx_volume* colorvol, kfx_stream stream);
  * Marching cubes over the (w-1)(h-1)(d-1) cubes of a BoundedVolume<SDF_t>, as roo::SaveMesh performs it on the host
  * (MarchingCubes.h:43-143, loop nest :226-232), in two device passes:
  *   kfx_mc_count: counts[(x*(h-1) + y)*(d-1) + z] = triangles of cube (x,y,z) (0..5; 0 when a corner is not finite);
- *   kfx_mc_emit:  given the exclusive prefix sum `offsets` of counts, writes for every triangle three vertices
- *                 (verts / norms: 3 floats each; colors: 4 floats, only when `colorvol` has every dimension >= 8, the
- *                 reference's IsValid) to slot 3*offsets[cube] + ..., i.e. in the reference's emission order.
- * All pointers are device memory; the caller does the prefix sum (kangaroo_amd/mesh.py uses torch.cumsum). */
+ *   kfx_mc_emit:  for the n_active cubes listed in cube_index (linear indices as above, ascending = emission order)
+ *                 with tri_offset[i] = number of triangles emitted before cube i (exclusive prefix sum of counts at
+ *                 that cube), writes for every triangle three vertices (verts / norms: 3 floats each; colors: 4
+ *                 floats, only when `colorvol` has every dimension >= 8, the reference's IsValid) to slot
+ *                 3*tri_offset[i] + ..., i.e. in the reference's emission order.
+ * All pointers are device memory; the caller does the prefix sum and the compaction (kangaroo_amd/mesh.py uses
+ * torch.cumsum / torch.nonzero, include/kangaroo/MarchingCubes.h a host loop over the one-byte counts). */
 int kfx_mc_count(const kfx_volume* vol, unsigned char* counts, kfx_stream stream);
-int kfx_mc_emit(const kfx_volume* vol, const kfx_volume* colorvol, const unsigned* offsets, float* verts, float* norms,
-                float* colors, kfx_stream stream);
+int kfx_mc_emit(const kfx_volume* vol, const kfx_volume* colorvol, const long long* cube_index, const unsigned* tri_offset,
+                long long n_active, float* verts, float* norms, float* colors, kfx_stream stream);
 
 /* ---- projective point-to-plane ICP ------------------------------------------
  * roo::LeastSquaresSystem<float,6> (Mat.h:483-520): JTy, the 21 unique elements of the symmetric JTJ in

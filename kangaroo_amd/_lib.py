@@ -69,7 +69,7 @@ SIGNATURES = {
     "kfx_raycast_sdf_color": (C.c_int, [PI, PI, PI, PV, PV, PF, PF, C.c_float, C.c_float, C.c_float, C.c_int, C.c_void_p]),
     "kfx_color_reset": (C.c_int, [PV, C.c_void_p]),
     "kfx_mc_count": (C.c_int, [PV, C.c_void_p, C.c_void_p]),
-    "kfx_mc_emit": (C.c_int, [PV, PV, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "kfx_mc_emit": (C.c_int, [PV, PV, C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "kfx_icp_point_plane": (C.c_int, [PI, PI, PI, PF, PF, C.c_float, PI, PI, C.POINTER(KfxLss6), C.c_void_p]),
     "kfx_composite_pack": (C.c_int, [PI, PI, PI, C.c_void_p, C.c_int, C.c_void_p]),
     "kfx_composite_select": (C.c_int, [PI, PI, PI, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),

@@ -8,12 +8,14 @@
 //
 // Here the volume never leaves HBM.  Two passes over the (w-1)(h-1)(d-1) cubes:
 //   k_mc_count  one thread per cube, x fastest (coalesced corner rows): number of triangles of the cube's case,
-//               written at the cube's position in the REFERENCE's emission order ((x*(h-1) + y)*(d-1) + z);
-//   (an exclusive prefix sum over that array gives every cube its output slot -- torch.cumsum on the host side)
-//   k_mc_emit   same mapping, only cubes with triangles do work: edge vertices, normals, colours, written to
-//               their slots.  The vertex / normal / colour arithmetic keeps the reference's expressions
-//               (double division in fGetOffset, multiply-by-reciprocal normalisation), so the output arrays are
-//               bit-identical to the CPU oracle's and arrive in the reference's order.
+//               written at the cube's position in the REFERENCE's emission order ((x*(h-1) + y)*(d-1) + z)
+//               through an LDS transpose (the order is z-fastest);
+//   (host side: exclusive prefix sum of the counts = every cube's output slot; the non-zero positions = the list
+//    of active cubes, already in emission order -- torch.cumsum / torch.nonzero, or a host loop in the C++ header)
+//   k_mc_emit   one thread per active cube: edge vertices, normals, colours, written to the cube's slots.  The
+//               vertex / normal / colour arithmetic keeps the reference's expressions (double division in
+//               fGetOffset, multiply-by-reciprocal normalisation), so the output arrays are bit-identical to the
+//               CPU oracle's and arrive in the reference's order.
 // The case tables (mc_tables.inc) are derived by scripts/gen_mc_tables.py from the cube's topology; their boundary
 // loops and winding equal the classic tables' in all 256 cases (tests/test_mesh_cpu.py).
 #include "kfx_device.h"
@@ -58,26 +60,49 @@ __device__ __forceinline__ bool cube_case(const MeshParams& p, int x, int y, int
     return finite;
 }
 
+// Workgroup = 64 cubes along x, 16 along z, one y.  Corner rows are read x-fastest (coalesced); the counts go
+// through an LDS tile so that each x-row's 16 z-consecutive bytes leave as one segment (the output order is z-fastest).
 __global__ __launch_bounds__(256) void k_mc_count(const MeshParams p, unsigned char* __restrict__ counts)
 {
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    const int z = blockIdx.z;
-    if (x >= p.cx || y >= p.cy) return;
-    float v[8];
-    int flag;
-    const bool ok = cube_case(p, x, y, z, v, flag);
-    counts[((size_t)x * p.cy + y) * p.cz + z] = ok ? c_num_tris[flag] : 0;
+    __shared__ unsigned char tile[64][17];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int x0 = blockIdx.x * 64, y = blockIdx.y, z0 = blockIdx.z * 16;
+    const int x = x0 + lane;
+    for (int zz = wv; zz < 16; zz += 4) {
+        const int z = z0 + zz;
+        unsigned char n = 0;
+        if (x < p.cx && z < p.cz) {
+            float v[8];
+            int flag;
+            if (cube_case(p, x, y, z, v, flag)) n = c_num_tris[flag];
+        }
+        tile[lane][zz] = n;
+    }
+    __syncthreads();
+    const int xr = threadIdx.x >> 2, q = threadIdx.x & 3;
+    if (x0 + xr < p.cx) {
+        unsigned char* dst = counts + ((size_t)(x0 + xr) * p.cy + y) * p.cz;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int z = z0 + q * 4 + b;
+            if (z < p.cz) dst[z] = tile[xr][q * 4 + b];
+        }
+    }
 }
 
-__global__ __launch_bounds__(256) void k_mc_emit(const MeshParams p, const ColorGeom cv, const int has_color,
-                                                 const unsigned* __restrict__ offsets, float* __restrict__ verts,
+// One thread per ACTIVE cube (cube_index lists the cubes with triangles in emission order; tri_offset their first
+// triangle): dense lanes instead of the ~1 % active lanes of a thread-per-cube sweep.
+__global__ __launch_bounds__(128) void k_mc_emit(const MeshParams p, const ColorGeom cv, const int has_color,
+                                                 const long long* __restrict__ cube_index, const unsigned* __restrict__ tri_offset,
+                                                 const long long n_active, float* __restrict__ verts,
                                                  float* __restrict__ norms, float* __restrict__ colors)
 {
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    const int z = blockIdx.z;
-    if (x >= p.cx || y >= p.cy) return;
+    const long long t_id = (long long)blockIdx.x * 128 + threadIdx.x;
+    if (t_id >= n_active) return;
+    const long long ci = cube_index[t_id];
+    const int z = (int)(ci % p.cz);
+    const int y = (int)((ci / p.cz) % p.cy);
+    const int x = (int)(ci / ((long long)p.cz * p.cy));
     float v[8];
     int flag;
     if (!cube_case(p, x, y, z, v, flag)) return;
@@ -108,7 +133,7 @@ __global__ __launch_bounds__(256) void k_mc_emit(const MeshParams p, const Color
         en[e] = n;
         ec[e] = has_color ? trilinear<RayC32>(cv, pos) : 0.f;
     }
-    size_t o = (size_t)offsets[((size_t)x * p.cy + y) * p.cz + z] * 3; // first output vertex of this cube
+    size_t o = (size_t)tri_offset[t_id] * 3; // first output vertex of this cube
     for (int t = 0; t < ntri * 3; ++t, ++o) {
         const int e = c_tris[flag][t];
         V3 P = v3(0.f, 0.f, 0.f), N = P;
@@ -170,17 +195,18 @@ extern "C" int kfx_mc_count(const kfx_volume* vol, unsigned char* counts, kfx_st
     if (int e = mesh_params(p, vol)) return e;
     if (!counts) return set_error(KFX_E_NULL, "SaveMesh: null counts");
     if (int e = load_tables()) return e;
-    dim3 grid(ceil_div(p.cx, 64), ceil_div(p.cy, 4), p.cz);
+    dim3 grid(ceil_div(p.cx, 64), p.cy, ceil_div(p.cz, 16));
     hipLaunchKernelGGL(k_mc_count, grid, dim3(256), 0, (hipStream_t)stream, p, counts);
     return check_launch("kfx_mc_count");
 }
 
-extern "C" int kfx_mc_emit(const kfx_volume* vol, const kfx_volume* colorvol, const unsigned* offsets, float* verts, float* norms,
-                           float* colors, kfx_stream stream)
+extern "C" int kfx_mc_emit(const kfx_volume* vol, const kfx_volume* colorvol, const long long* cube_index, const unsigned* tri_offset,
+                           long long n_active, float* verts, float* norms, float* colors, kfx_stream stream)
 {
     MeshParams p;
     if (int e = mesh_params(p, vol)) return e;
-    if (!offsets || !verts || !norms) return set_error(KFX_E_NULL, "SaveMesh: null output");
+    if (n_active <= 0) return 0;
+    if (!cube_index || !tri_offset || !verts || !norms) return set_error(KFX_E_NULL, "SaveMesh: null output");
     if (int e = load_tables()) return e;
     ColorGeom cv{};
     // the reference samples the colour volume only when it IsValid(): every dimension >= 8 (BoundedVolume.h:84-87)
@@ -199,7 +225,8 @@ extern "C" int kfx_mc_emit(const kfx_volume* vol, const kfx_volume* colorvol, co
         cv.dims1 = V3{(float)colorvol->w - 1.f, (float)colorvol->h - 1.f, (float)colorvol->d - 1.f};
         cv.hi2 = V3{(float)(colorvol->w - 2), (float)(colorvol->h - 2), (float)(colorvol->d - 2)};
     }
-    dim3 grid(ceil_div(p.cx, 64), ceil_div(p.cy, 4), p.cz);
-    hipLaunchKernelGGL(k_mc_emit, grid, dim3(256), 0, (hipStream_t)stream, p, cv, has_color, offsets, verts, norms, colors);
+    if (n_active > 0x7fffffffLL * 128) return set_error(KFX_E_RANGE, "SaveMesh: too many active cubes");
+    hipLaunchKernelGGL(k_mc_emit, dim3((unsigned)((n_active + 127) / 128)), dim3(128), 0, (hipStream_t)stream, p, cv, has_color,
+                       cube_index, tri_offset, n_active, verts, norms, colors);
     return check_launch("kfx_mc_emit");
 }

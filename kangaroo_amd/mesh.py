@@ -2,7 +2,8 @@
 
 The reference copies the volume to the host, marches the (w-1)(h-1)(d-1) cubes one by one and hands the lists to
 Assimp's PLY exporter.  Here: kfx_mc_count (triangles per cube, in the reference's emission order) -> exclusive
-prefix sum (torch.cumsum on the device) -> kfx_mc_emit (vertices, normals, grey colours into their slots).  The
+prefix sum and compaction of the active cubes (torch.cumsum / torch.nonzero on the device) -> kfx_mc_emit (one
+thread per active cube: vertices, normals, grey colours into their slots).  The
 arrays equal the host algorithm's element for element (tests compare with the oracle); only the finished arrays
 cross PCIe.
 
@@ -35,15 +36,16 @@ def ExtractMesh(vol, colorVol=None, stream=None):
     ntri = int(incl[-1].item()) if incl.numel() else 0
     if ntri >= 2 ** 32 // 3:
         raise ValueError("mesh too large for 32-bit vertex offsets")
-    offsets = (incl - counts).to(torch.int32)          # exclusive prefix sum (values < 2^31 checked above)
+    active = torch.nonzero(counts).reshape(-1)                        # cubes with triangles, ascending = emission order
+    tri_offset = (incl[active] - counts[active]).to(torch.int32)     # exclusive prefix sum at those cubes
     verts = torch.empty((3 * ntri, 3), dtype=torch.float32, device=dev)
     norms = torch.empty((3 * ntri, 3), dtype=torch.float32, device=dev)
     has_color = colorVol is not None and min(colorVol.w, colorVol.h, colorVol.d) >= 8
     colors = torch.empty((3 * ntri, 4), dtype=torch.float32, device=dev) if has_color else None
     if ntri:
-        _lib.check(L.kfx_mc_emit(vol.ref(), colorVol.ref() if has_color else None, C.c_void_p(offsets.data_ptr()),
-                                 C.c_void_p(verts.data_ptr()), C.c_void_p(norms.data_ptr()),
-                                 C.c_void_p(colors.data_ptr()) if has_color else None, _stream(stream)))
+        _lib.check(L.kfx_mc_emit(vol.ref(), colorVol.ref() if has_color else None, C.c_void_p(active.data_ptr()),
+                                 C.c_void_p(tri_offset.data_ptr()), int(active.numel()), C.c_void_p(verts.data_ptr()),
+                                 C.c_void_p(norms.data_ptr()), C.c_void_p(colors.data_ptr()) if has_color else None, _stream(stream)))
     return verts, norms, colors
 
 
