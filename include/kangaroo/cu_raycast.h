@@ -2,6 +2,7 @@
 #pragma once
 
 #include <kangaroo/BoundedVolume.h>
+#include <kangaroo/BoundingBox.h>
 #include <kangaroo/Image.h>
 #include <kangaroo/ImageIntrinsics.h>
 #include <kangaroo/Mat.h>
@@ -24,6 +25,29 @@ KANGAROO_EXPORT inline
 void RaycastSdf(Image<float> depth, Image<float4> norm, Image<float> img, const BoundedVolume<SDF_t> vol, const BoundedVolume<float> colorVol, const Mat<float,3,4> T_wc, ImageIntrinsics K, float near, float far, float trunc_dist, bool subpix = true)
 {
     GpuCheckStatus(kfx_raycast_sdf_color(depth.abi(), norm.abi(), img.abi(), vol.abi(), colorVol.abi(), T_wc.m, &K.fu, near, far, trunc_dist, subpix ? 1 : 0, 0));
+}
+
+// analytic renderers (reference cu_raycast.h:19-26, kernels cu_raycast.cu:202-310)
+KANGAROO_EXPORT inline
+void RaycastBox(Image<float> imgd, const Mat<float,3,4> T_wc, ImageIntrinsics K, const BoundingBox bbox )
+{
+    const float3 lo = bbox.Min(), hi = bbox.Max();
+    const float a[3] = {lo.x, lo.y, lo.z}, b[3] = {hi.x, hi.y, hi.z};
+    GpuCheckStatus(kfx_raycast_box(imgd.abi(), T_wc.m, &K.fu, a, b, 0));
+}
+
+KANGAROO_EXPORT inline
+void RaycastSphere(Image<float> imgd, Image<float> img, const Mat<float,3,4> T_wc, ImageIntrinsics K, float3 center, float r)
+{
+    const float c[3] = {center.x, center.y, center.z};
+    GpuCheckStatus(kfx_raycast_sphere(imgd.abi(), img.abi(), T_wc.m, &K.fu, c, r, 0));
+}
+
+KANGAROO_EXPORT inline
+void RaycastPlane(Image<float> imgd, Image<float> img, const Mat<float,3,4> T_wc, ImageIntrinsics K, const float3 n_w )
+{
+    const float n[3] = {n_w.x, n_w.y, n_w.z};
+    GpuCheckStatus(kfx_raycast_plane(imgd.abi(), img.abi(), T_wc.m, &K.fu, n, 0));
 }
 
 // fp16-cell overload (config C5)

@@ -46,6 +46,13 @@ void SdfReset(BoundedVolume<float> vol)
     GpuCheckStatus(kfx_color_reset(vol.abi(), 0));
 }
 
+// TSDF value at every pixel's back-projected depth (reference cu_sdffusion.h:30-31, kernel cu_sdffusion.cu:200-225)
+KANGAROO_EXPORT inline
+void SdfDistance(Image<float> dist, Image<float> depth, BoundedVolume<SDF_t> vol, const Mat<float,3,4> T_wc, ImageIntrinsics K, float trunc_distance)
+{
+    GpuCheckStatus(kfx_sdf_distance(dist.abi(), depth.abi(), vol.abi(), T_wc.m, &K.fu, trunc_distance, 0));
+}
+
 // fp16-cell overloads (config C5)
 KANGAROO_EXPORT inline
 void SdfFuse(BoundedVolume<SDF_h> vol, Image<float> depth, Image<float4> norm, Mat<float,3,4> T_cw, ImageIntrinsics K, float trunc_dist, float maxw, float mincostheta )

@@ -188,6 +188,22 @@ int kfx_memcpy_2d(void* dst, size_t dpitch, const void* src, size_t spitch, size
                   size_t rows, int kind, kfx_stream stream);
 int kfx_stream_synchronize(kfx_stream stream);
 
+/* ---- the rest of cu_raycast.h / cu_sdffusion.h ---------------------------------------------------------
+ * kfx_raycast_box:    RaycastBox(imgd, T_wc, K, bbox) (cu_raycast.cu:202-240) -- entry depth into the box, NaN on a miss.
+ * kfx_raycast_sphere: RaycastSphere(imgd, img, T_wc, K, center, r) (:246-279) -- a sphere hit nearer than the depth already
+ *                     in imgd (or where that is not finite) overwrites imgd and, if img->ptr, img with its Phong shade.
+ * kfx_raycast_plane:  RaycastPlane(imgd, img, T_wc, K, n_w) (:285-310) -- the plane n_w . x = -1, same overwrite rule.
+ * kfx_sdf_distance:   SdfDistance(dist, depth, vol, T_wc, K, trunc_distance) (cu_sdffusion.cu:200-225) -- the trilinear
+ *                     TSDF value at every pixel's back-projected depth point. */
+int kfx_raycast_box(const kfx_image* imgd, const float T_wc[12], const float K[4], const float boxmin[3], const float boxmax[3],
+                    kfx_stream stream);
+int kfx_raycast_sphere(const kfx_image* imgd, const kfx_image* img, const float T_wc[12], const float K[4], const float center[3],
+                       float r, kfx_stream stream);
+int kfx_raycast_plane(const kfx_image* imgd, const kfx_image* img, const float T_wc[12], const float K[4], const float n_w[3],
+                      kfx_stream stream);
+int kfx_sdf_distance(const kfx_image* dist, const kfx_image* depth, const kfx_volume* vol, const float T_wc[12], const float K[4],
+                     float trunc_distance, kfx_stream stream);
+
 /* ---- colour fusion / colour raycast ------------------------------------------
  * `colorvol` is a roo::BoundedVolume<float> (4-byte grey cells in [0,1], same struct, same dims as `vol`);
  * `img` a roo::Image<uchar3> (3-byte pixels).

@@ -432,3 +432,35 @@ def RaycastSdfColor(depth, norm, img, vol, colorVol, T_wc, K, near, far, trunc_d
 def ColorReset(colorVol, stream=None):
     """SdfReset(BoundedVolume<float>) = Fill(0.5) (cu_sdffusion.cu:166-169)."""
     _lib.check(_lib.load().kfx_color_reset(colorVol.ref(), _stream(stream)))
+
+
+def RaycastBox(imgd, T_wc, K, boxmin, boxmax, stream=None):
+    """RaycastBox(imgd, T_wc, K, bbox) (cu_raycast.h, cu_raycast.cu:202-240)."""
+    t, _t = _fp(T_wc, 12)
+    k, _k = _fp(K, 4)
+    a, _a = _fp(boxmin, 3)
+    b, _b = _fp(boxmax, 3)
+    _lib.check(_lib.load().kfx_raycast_box(imgd.ref(), t, k, a, b, _stream(stream)))
+
+
+def RaycastSphere(imgd, img, T_wc, K, center, r, stream=None):
+    """RaycastSphere(imgd, img, T_wc, K, center, r) (cu_raycast.cu:246-279); img may be None."""
+    t, _t = _fp(T_wc, 12)
+    k, _k = _fp(K, 4)
+    c, _c = _fp(center, 3)
+    _lib.check(_lib.load().kfx_raycast_sphere(imgd.ref(), img.ref() if img is not None else None, t, k, c, r, _stream(stream)))
+
+
+def RaycastPlane(imgd, img, T_wc, K, n_w, stream=None):
+    """RaycastPlane(imgd, img, T_wc, K, n_w) (cu_raycast.cu:285-310): the plane n_w . x = -1."""
+    t, _t = _fp(T_wc, 12)
+    k, _k = _fp(K, 4)
+    n, _n = _fp(n_w, 3)
+    _lib.check(_lib.load().kfx_raycast_plane(imgd.ref(), img.ref(), t, k, n, _stream(stream)))
+
+
+def SdfDistance(dist, depth, vol, T_wc, K, trunc_distance=0.0, stream=None):
+    """SdfDistance(dist, depth, vol, T_wc, K, trunc_distance) (cu_sdffusion.cu:200-225)."""
+    t, _t = _fp(T_wc, 12)
+    k, _k = _fp(K, 4)
+    _lib.check(_lib.load().kfx_sdf_distance(dist.ref(), depth.ref(), vol.ref(), t, k, trunc_distance, _stream(stream)))

@@ -82,6 +82,8 @@ def lib():
         L.kfo_sdf_fuse_color.restype = C.c_uint64
         L.kfo_raycast_sdf_color.argtypes = [PI, PI, PI, PV, PV, PF, PF, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int]
         L.kfo_raycast_sdf_color.restype = None
+        L.kfo_sdf_distance.argtypes = [PI, PI, PV, PF, PF]
+        L.kfo_sdf_distance.restype = None
         L.kfo_marching_cubes.argtypes = [PV, PV, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.kfo_marching_cubes.restype = C.c_uint64
         L.kfo_icp_point_plane.argtypes = [PI, PI, PI, PF, PF, C.c_float, PI, C.POINTER(KfoLss6), C.c_void_p]
@@ -479,3 +481,9 @@ def marching_cubes(vol, cvol, ntris, emask, tris):
     L.kfo_marching_cubes(vol.ref(), cref, ntris.ctypes.data, emask.ctypes.data, tris.ctypes.data, tris.shape[1], verts.ctypes.data,
                          norms.ctypes.data, colors.ctypes.data if colors is not None else None)
     return verts, norms, colors
+
+
+def sdf_distance(dist, depth, vol, T_wc, K):
+    _, t = _fp(T_wc)
+    _, k = _fp(K)
+    lib().kfo_sdf_distance(dist.ref(), depth.ref(), vol.ref(), t, k)

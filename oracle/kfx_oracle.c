@@ -1175,3 +1175,16 @@ uint64_t kfo_marching_cubes(const kfo_volume* vol, const kfo_volume* cvol, const
             }
     return nt;
 }
+
+/* SdfDistance, cu_sdffusion.cu:200-225: dist(u,v) = vol.GetUnitsTrilinearClamped(T_wc * (depth(u,v) * K.Unproject(u,v))) */
+void kfo_sdf_distance(const kfo_image* dist, const kfo_image* depth, const kfo_volume* vol, const float T[12], const float K[4])
+{
+    const int half = 0;
+    for (int v = 0; v < (int)depth->h; ++v)
+        for (int u = 0; u < (int)depth->w; ++u) {
+            const float z = ((const float*)img_row(depth, (size_t)v))[u];
+            const f3 p_c = scale3(unproject1(K, (float)u, (float)v), z);
+            const f3 p_w = se3_mul(T, p_c);
+            ((float*)img_row(dist, (size_t)v))[u] = trilinear_clamped(vol, p_w, NULL, half);
+        }
+}

@@ -100,6 +100,9 @@ void kfo_raycast_sdf_color(const kfo_image* depth, const kfo_image* norm, const 
                            const kfo_volume* cvol, const float T_wc[12], const float K[4], float near, float far, float trunc,
                            int subpix, int nthreads);
 
+/* cu_sdffusion.cu:200-225 */
+void kfo_sdf_distance(const kfo_image* dist, const kfo_image* depth, const kfo_volume* vol, const float T_wc[12], const float K[4]);
+
 /* MarchingCubes.h:43-143 in SaveMesh's loop nest (:226-232); case tables supplied by the caller */
 uint64_t kfo_marching_cubes(const kfo_volume* vol, const kfo_volume* cvol, const unsigned char* ntris, const unsigned short* emask,
                             const signed char* tris, int tri_stride, float* verts, float* norms, float* colors);

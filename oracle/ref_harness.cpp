@@ -423,4 +423,50 @@ void ref_mc_tables(int edge_flags[256], int tris[256 * 16])
     }
 }
 
+// SdfDistance (cu_sdffusion.cu:200-217) and the analytic renderers' per-pixel arithmetic (cu_raycast.cu:202-310), every
+// step a reference header call (Unproject, float*float3, Mat*float3, GetUnitsTrilinearClamped, mulSO3, mulSE3inv,
+// Plane_b_from_a, fminf/fmaxf(float3), dot, length); PhongShade lives in the .cu and is not covered.
+void ref_sdf_distance(const kfo_image* pdist, const kfo_image* pdepth, const kfo_volume* pv, const float* t, const float* k)
+{
+    HImgF dist = imf(pdist), depth = imf(pdepth);
+    HVol vol = mkvol(pv);
+    const Mat<float, 3, 4> T_wc = mkT(t);
+    const ImageIntrinsics K = mkK(k);
+    for (int v = 0; v < (int)depth.h; ++v)
+        for (int u = 0; u < (int)depth.w; ++u) {
+            const float z = depth(u, v);
+            const float3 p_c = z * K.Unproject(u, v);
+            const float3 p_w = T_wc * p_c;
+            dist(u, v) = vol.GetUnitsTrilinearClamped(p_w);
+        }
+}
+void ref_analytic_depths(const kfo_image* pbox, const kfo_image* psph, const kfo_image* ppl, const float* t, const float* k,
+                         const float* bmin, const float* bmax, const float* center, float r, const float* n_w)
+{
+    HImgF ibox = imf(pbox), isph = imf(psph), ipl = imf(ppl);
+    const Mat<float, 3, 4> T_wc = mkT(t);
+    const ImageIntrinsics K = mkK(k);
+    const BoundingBox bbox(make_float3(bmin[0], bmin[1], bmin[2]), make_float3(bmax[0], bmax[1], bmax[2]));
+    const float3 center_c = mulSE3inv(T_wc, make_float3(center[0], center[1], center[2]));
+    const float3 n_c = Plane_b_from_a(T_wc, make_float3(n_w[0], n_w[1], n_w[2]));
+    for (int v = 0; v < (int)ibox.h; ++v)
+        for (int u = 0; u < (int)ibox.w; ++u) {
+            const float3 c_w = SE3Translation(T_wc);
+            const float3 ray_c = K.Unproject(u, v);
+            const float3 ray_w = mulSO3(T_wc, ray_c);
+            const float3 tminbound = (bbox.Min() - c_w) / ray_w;
+            const float3 tmaxbound = (bbox.Max() - c_w) / ray_w;
+            const float3 tmin = fminf(tminbound, tmaxbound);
+            const float3 tmax = fmaxf(tminbound, tmaxbound);
+            const float max_tmin = fmaxf(fmaxf(tmin.x, tmin.y), tmin.z);
+            const float min_tmax = fminf(fminf(tmax.x, tmax.y), tmax.z);
+            ibox(u, v) = (max_tmin < min_tmax) ? max_tmin : InvalidValue<float>::Value();
+            const float ldotc = dot(ray_c, center_c);
+            const float lsq = dot(ray_c, ray_c);
+            const float csq = dot(center_c, center_c);
+            isph(u, v) = (ldotc - sqrtf(ldotc * ldotc - lsq * (csq - r * r))) / lsq;
+            ipl(u, v) = -1 / dot(n_c, ray_c);
+        }
+}
+
 }

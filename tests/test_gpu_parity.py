@@ -971,3 +971,43 @@ def test_gpu_marching_cubes_vs_oracle(roo, tmp_path, case):
     nt = mesh.SaveMesh(str(tmp_path / "m"), vol, cvol)
     raw = open(str(tmp_path / "m.ply"), "rb").read()
     assert nt == len(want_v) // 3 and raw.startswith(b"ply\nformat binary_little_endian 1.0") and b"element face %d" % nt in raw[:600]
+
+
+# ---------------------------------------------------------------------------------
+# the rest of cu_raycast.h / cu_sdffusion.h: analytic renderers and SdfDistance
+# ---------------------------------------------------------------------------------
+@pytest.mark.parametrize("w,h", [(160, 120), (67, 45)])
+def test_gpu_analytic_renderers_and_sdf_distance(roo, w, h):
+    K = scenes.intrinsics(w, h)
+    T_wc = scenes.orbit_pose(2, 8)
+    # box
+    od, gd = oracle.Image(w, h), roo.Image(w, h)
+    oracle.raycast_box(od, T_wc, K, (-0.5, -0.4, 2.0), (0.6, 0.5, 3.0))
+    roo.RaycastBox(gd, T_wc, K, (-0.5, -0.4, 2.0), (0.6, 0.5, 3.0))
+    assert T.nan_equal(gd.MemcpyToHost(), od.data) and np.isfinite(od.data).any() and np.isnan(od.data).any()
+    # sphere then plane composited into the same depth / shade images (nearer hit wins, NaN = empty)
+    oi, gi = oracle.Image(w, h), roo.Image(w, h)
+    od.data[...] = np.nan
+    gd.MemcpyFromHost(od.data)
+    for c, r in (((0.1, 0.0, 3.0), 0.5), ((-0.4, 0.2, 2.5), 0.3)):
+        oracle.raycast_sphere(od, oi, T_wc, K, c, r)
+        roo.RaycastSphere(gd, gi, T_wc, K, c, r)
+    oracle.raycast_plane(od, oi, T_wc, K, (0.0, 0.0, -1.0 / 3.8))
+    roo.RaycastPlane(gd, gi, T_wc, K, (0.0, 0.0, -1.0 / 3.8))
+    assert T.nan_equal(gd.MemcpyToHost(), od.data) and T.nan_equal(gi.MemcpyToHost(), oi.data)
+    assert np.isfinite(od.data).mean() > 0.9
+    # depth only (img = None) for the sphere
+    od2, gd2 = oracle.Image(w, h), roo.Image(w, h)
+    od2.data[...] = np.nan
+    gd2.MemcpyFromHost(od2.data)
+    oracle.raycast_sphere(od2, None, T_wc, K, (0.1, 0.0, 3.0), 0.5)
+    roo.RaycastSphere(gd2, None, T_wc, K, (0.1, 0.0, 3.0), 0.5)
+    assert T.nan_equal(gd2.MemcpyToHost(), od2.data)
+    # SdfDistance of the rendered depth against a fused volume
+    ovol = T.make_volume(48, "room")
+    Kf, tr, fr = T.fuse_frames_oracle(ovol, "room", w, h, 2)
+    vol = T.upload_volume(roo, ovol)
+    odist, gdist = oracle.Image(w, h), roo.Image(w, h)
+    oracle.sdf_distance(odist, od, ovol, T_wc, K)
+    roo.SdfDistance(gdist, gd, vol, T_wc, K, tr)
+    assert T.nan_equal(gdist.MemcpyToHost(), odist.data) and np.isfinite(odist.data).any()

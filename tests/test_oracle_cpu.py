@@ -237,3 +237,38 @@ def test_oracle_half_cells():
     rd, rn, ri = oracle.Image(80, 60), oracle.Image(80, 60, channels=4), oracle.Image(80, 60)
     st = oracle.raycast_sdf(rd, rn, ri, v, scenes.identity_pose(), K, 0.4, 8.0, tr, True)
     assert st["rays"] > 0
+
+
+@pytest.mark.skipif(not os.path.exists(REF_SO), reason="oracle/_ref not built (needs /root/reference)")
+def test_oracle_analytic_renderers_and_sdf_distance_vs_reference_headers():
+    """RaycastBox / RaycastSphere / RaycastPlane depths and SdfDistance: the restatement against the same per-pixel
+    arithmetic evaluated with the reference's header functions (first-hit depths: images start empty)."""
+    R = C.CDLL(REF_SO)
+    PF = C.POINTER(C.c_float)
+    w, h = 96, 72
+    K = scenes.intrinsics(w, h)
+    T_wc = scenes.orbit_pose(3, 8)
+    fp = lambda a: np.ascontiguousarray(a, np.float32).reshape(-1)
+    t, k = fp(T_wc), fp(K)
+    bmin, bmax, center, n_w, r = fp((-0.5, -0.4, 2.0)), fp((0.6, 0.5, 3.0)), fp((0.1, 0.0, 3.0)), fp((0.0, 0.1, -1.0 / 3.8)), 0.5
+    rb, rs, rp = oracle.Image(w, h), oracle.Image(w, h), oracle.Image(w, h)
+    R.ref_analytic_depths(rb.ref(), rs.ref(), rp.ref(), t.ctypes.data_as(PF), k.ctypes.data_as(PF), bmin.ctypes.data_as(PF),
+                          bmax.ctypes.data_as(PF), center.ctypes.data_as(PF), C.c_float(r), n_w.ctypes.data_as(PF))
+    ob = oracle.Image(w, h)
+    oracle.raycast_box(ob, T_wc, K, bmin, bmax)
+    assert T.nan_equal(ob.data, rb.data)
+    for ref_img, fn in ((rs, lambda d: oracle.raycast_sphere(d, None, T_wc, K, center, r)), (rp, lambda d: oracle.raycast_plane(d, None, T_wc, K, n_w))):
+        d = oracle.Image(w, h)
+        d.data[...] = np.nan
+        fn(d)
+        want = np.where(ref_img.data > 0, ref_img.data, np.float32("nan"))   # the kernels keep only positive depths
+        assert T.nan_equal(d.data, want)
+    vol = T.make_volume(32, "room")
+    T.fuse_frames_oracle(vol, "room", w, h, 2)
+    depth = oracle.Image(w, h)
+    depth.data[...] = scenes.render_depth("room", w, h, T_wc, K)
+    depth.data[::9, ::7] = np.nan
+    od, rd = oracle.Image(w, h), oracle.Image(w, h)
+    oracle.sdf_distance(od, depth, vol, T_wc, K)
+    R.ref_sdf_distance(rd.ref(), depth.ref(), vol.ref(), t.ctypes.data_as(PF), k.ctypes.data_as(PF))
+    assert T.nan_equal(od.data, rd.data) and np.isfinite(od.data).any()
