@@ -188,6 +188,15 @@ int kfx_memcpy_2d(void* dst, size_t dpitch, const void* src, size_t spitch, size
                   size_t rows, int kind, kfx_stream stream);
 int kfx_stream_synchronize(kfx_stream stream);
 
+/* ---- the small per-pixel tools of cu_depth_tools.h -----------------------------------------------------
+ * kfx_disp2depth:           Disp2Depth(dIn, dOut, fu, fBaseline, fMinDisp) (cu_depth_tools.cu:15-30)
+ * kfx_filter_bad_kinect_*:  FilterBadKinectData(dFiltered, dKinectDepth) for float / unsigned short readings (:32-53)
+ * kfx_colour_vbo:           ColourVbo(dId, dPd, dIc, KT_cd) (:86-119): uchar4 colour per vertex from an Image<uchar3> */
+int kfx_disp2depth(const kfx_image* in, const kfx_image* out, float fu, float baseline, float min_disp, kfx_stream stream);
+int kfx_filter_bad_kinect_f32(const kfx_image* out, const kfx_image* in, kfx_stream stream);
+int kfx_filter_bad_kinect_u16(const kfx_image* out, const kfx_image* in, kfx_stream stream);
+int kfx_colour_vbo(const kfx_image* id, const kfx_image* vbo, const kfx_image* rgb, const float KT_cd[12], kfx_stream stream);
+
 /* ---- the rest of cu_raycast.h / cu_sdffusion.h ---------------------------------------------------------
  * kfx_raycast_box:    RaycastBox(imgd, T_wc, K, bbox) (cu_raycast.cu:202-240) -- entry depth into the box, NaN on a miss.
  * kfx_raycast_sphere: RaycastSphere(imgd, img, T_wc, K, center, r) (:246-279) -- a sphere hit nearer than the depth already

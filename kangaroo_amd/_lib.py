@@ -68,6 +68,10 @@ SIGNATURES = {
     "kfx_sdf_fuse_color": (C.c_int, [PV, PV, PI, PI, PF, PF, PI, PF, PF, C.c_float, C.c_float, C.c_float, C.c_uint, C.c_void_p]),
     "kfx_raycast_sdf_color": (C.c_int, [PI, PI, PI, PV, PV, PF, PF, C.c_float, C.c_float, C.c_float, C.c_int, C.c_void_p]),
     "kfx_color_reset": (C.c_int, [PV, C.c_void_p]),
+    "kfx_disp2depth": (C.c_int, [PI, PI, C.c_float, C.c_float, C.c_float, C.c_void_p]),
+    "kfx_filter_bad_kinect_f32": (C.c_int, [PI, PI, C.c_void_p]),
+    "kfx_filter_bad_kinect_u16": (C.c_int, [PI, PI, C.c_void_p]),
+    "kfx_colour_vbo": (C.c_int, [PI, PI, PI, PF, C.c_void_p]),
     "kfx_raycast_box": (C.c_int, [PI, PF, PF, PF, PF, C.c_void_p]),
     "kfx_raycast_sphere": (C.c_int, [PI, PI, PF, PF, PF, C.c_float, C.c_void_p]),
     "kfx_raycast_plane": (C.c_int, [PI, PI, PF, PF, PF, C.c_void_p]),

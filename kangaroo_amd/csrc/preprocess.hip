@@ -203,6 +203,77 @@ __global__ __launch_bounds__(256) void k_box_half_ignore_invalid_f32(const EwPar
     reinterpret_cast<float*>(p.out + (size_t)y * p.out_pitch)[x] = n > 0 ? (sum / n) : __builtin_nanf("");
 }
 
+
+// ---- the small per-pixel tools of cu_depth_tools.h ------------------------------------------------------------
+struct PixIO {
+    const unsigned char* in;
+    size_t ipitch;
+    unsigned char* out;
+    size_t opitch;
+    int w, h;
+};
+
+// Disp2Depth (cu_depth_tools.cu:15-23): depth = fu * baseline / disparity, NaN below the minimum disparity
+__global__ __launch_bounds__(256) void k_disp2depth(const PixIO p, float fu, float baseline, float min_disp)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= p.w || y >= p.h) return;
+    const float d = *(reinterpret_cast<const float*>(p.in + (size_t)y * p.ipitch) + x);
+    *(reinterpret_cast<float*>(p.out + (size_t)y * p.opitch) + x) = d >= min_disp ? fu * baseline / d : __builtin_nanf("");
+}
+
+// FilterBadKinectData (cu_depth_tools.cu:32-39): millimetre readings below 200 become NaN
+template <typename Ti>
+__global__ __launch_bounds__(256) void k_filter_bad_kinect(const PixIO p)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= p.w || y >= p.h) return;
+    const float z_mm = (float)*(reinterpret_cast<const Ti*>(p.in + (size_t)y * p.ipitch) + x);
+    *(reinterpret_cast<float*>(p.out + (size_t)y * p.opitch) + x) = z_mm >= 200 ? z_mm : __builtin_nanf("");
+}
+
+struct ColourVboParams {
+    const unsigned char* vbo;   // Image<float4>
+    size_t vpitch;
+    const unsigned char* rgb;   // Image<uchar3>
+    size_t rpitch;
+    int rw, rh;
+    unsigned char* out;         // Image<uchar4>
+    size_t opitch;
+    int w, h;
+    Pose KT;                    // KT_cd
+};
+struct __attribute__((packed)) Rgb3 { unsigned char x, y, z; };
+
+// ColourVbo (cu_depth_tools.cu:86-112): project every vertex with KT_cd, bilinear RGB (sampling.h lerp(uchar3...):
+// integer difference, converted, times t, plus the first value; rows blended as float3), truncated to bytes
+__global__ __launch_bounds__(256) void k_colour_vbo(const ColourVboParams p)
+{
+    const int u = blockIdx.x * 64 + (threadIdx.x & 63), v = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (u >= p.w || v >= p.h) return;
+    const float4 Pd = *(reinterpret_cast<const float4*>(p.vbo + (size_t)v * p.vpitch) + u);
+    // Mat<3,4> * Mat<4,1> with w = 1: row . (x, y, z, 1), summed left to right (Mat.h operator*)
+    const float k0 = p.KT.m[0] * Pd.x + p.KT.m[1] * Pd.y + p.KT.m[2] * Pd.z + p.KT.m[3] * 1.0f;
+    const float k1 = p.KT.m[4] * Pd.x + p.KT.m[5] * Pd.y + p.KT.m[6] * Pd.z + p.KT.m[7] * 1.0f;
+    const float k2 = p.KT.m[8] * Pd.x + p.KT.m[9] * Pd.y + p.KT.m[10] * Pd.z + p.KT.m[11] * 1.0f;
+    const float pu = k0 / k2, pv = k1 / k2;
+    uchar4 id = make_uchar4(0, 0, 0, 0);
+    if (1.0f <= pu && pu < ((float)p.rw - 1.0f) && 1.0f <= pv && pv < ((float)p.rh - 1.0f)) {
+        const float ix = floorf(pu), iy = floorf(pv);
+        const float fx = pu - ix, fy = pv - iy;
+        const Rgb3* bl = reinterpret_cast<const Rgb3*>(p.rgb + (size_t)iy * p.rpitch) + (size_t)ix;
+        const Rgb3* tl = reinterpret_cast<const Rgb3*>(p.rgb + (size_t)(iy + 1) * p.rpitch) + (size_t)ix;
+        const Rgb3 b0 = bl[0], b1 = bl[1], t0 = tl[0], t1 = tl[1];
+        const V3 lo = v3((float)b0.x + fx * (float)((int)b1.x - (int)b0.x), (float)b0.y + fx * (float)((int)b1.y - (int)b0.y),
+                         (float)b0.z + fx * (float)((int)b1.z - (int)b0.z));
+        const V3 hi = v3((float)t0.x + fx * (float)((int)t1.x - (int)t0.x), (float)t0.y + fx * (float)((int)t1.y - (int)t0.y),
+                         (float)t0.z + fx * (float)((int)t1.z - (int)t0.z));
+        const V3 c = v3(lo.x + fy * (hi.x - lo.x), lo.y + fy * (hi.y - lo.y), lo.z + fy * (hi.z - lo.z));
+        id = make_uchar4((unsigned char)c.x, (unsigned char)c.y, (unsigned char)c.z, 255);
+    }
+    *(reinterpret_cast<uchar4*>(p.out + (size_t)v * p.opitch) + u) = id;
+}
+
 } // namespace kfx
 
 using namespace kfx;
@@ -345,4 +416,56 @@ extern "C" int kfx_box_half_ignore_invalid_f32(const kfx_image* out, const kfx_i
     dim3 grid(ceil_div(p.w, 64), ceil_div(p.h, 4));
     hipLaunchKernelGGL(k_box_half_ignore_invalid_f32, grid, dim3(256), 0, (hipStream_t)stream, p);
     return check_launch("kfx_box_half_ignore_invalid_f32");
+}
+
+// Disp2Depth(dIn, dOut, fu, fBaseline, fMinDisp) (cu_depth_tools.cu:15-30; the launch is bounded by dOut)
+extern "C" int kfx_disp2depth(const kfx_image* in, const kfx_image* out, float fu, float baseline, float min_disp, kfx_stream stream)
+{
+    if (int e = check_image(out, 4, "Disp2Depth: output image")) return e;
+    if (int e = check_image(in, 4, "Disp2Depth: input image")) return e;
+    if (out->w == 0 || out->h == 0) return 0;
+    if (in->w < out->w || in->h < out->h) return set_error(KFX_E_SHAPE, "Disp2Depth: input smaller than output");
+    PixIO p{(const unsigned char*)in->ptr, in->pitch, (unsigned char*)out->ptr, out->pitch, (int)out->w, (int)out->h};
+    hipLaunchKernelGGL(k_disp2depth, dim3(ceil_div(p.w, 64), ceil_div(p.h, 4)), dim3(256), 0, (hipStream_t)stream, p, fu, baseline, min_disp);
+    return check_launch("kfx_disp2depth");
+}
+
+// FilterBadKinectData(dFiltered, dKinectDepth) (cu_depth_tools.cu:32-53), float and unsigned short readings
+extern "C" int kfx_filter_bad_kinect_f32(const kfx_image* out, const kfx_image* in, kfx_stream stream)
+{
+    if (int e = check_image(out, 4, "FilterBadKinectData: output image")) return e;
+    if (int e = check_image(in, 4, "FilterBadKinectData: input image")) return e;
+    if (out->w == 0 || out->h == 0) return 0;
+    if (in->w < out->w || in->h < out->h) return set_error(KFX_E_SHAPE, "FilterBadKinectData: input smaller than output");
+    PixIO p{(const unsigned char*)in->ptr, in->pitch, (unsigned char*)out->ptr, out->pitch, (int)out->w, (int)out->h};
+    hipLaunchKernelGGL(k_filter_bad_kinect<float>, dim3(ceil_div(p.w, 64), ceil_div(p.h, 4)), dim3(256), 0, (hipStream_t)stream, p);
+    return check_launch("kfx_filter_bad_kinect_f32");
+}
+extern "C" int kfx_filter_bad_kinect_u16(const kfx_image* out, const kfx_image* in, kfx_stream stream)
+{
+    if (int e = check_image(out, 4, "FilterBadKinectData: output image")) return e;
+    if (int e = check_image(in, 2, "FilterBadKinectData: input image")) return e;
+    if (out->w == 0 || out->h == 0) return 0;
+    if (in->w < out->w || in->h < out->h) return set_error(KFX_E_SHAPE, "FilterBadKinectData: input smaller than output");
+    PixIO p{(const unsigned char*)in->ptr, in->pitch, (unsigned char*)out->ptr, out->pitch, (int)out->w, (int)out->h};
+    hipLaunchKernelGGL(k_filter_bad_kinect<unsigned short>, dim3(ceil_div(p.w, 64), ceil_div(p.h, 4)), dim3(256), 0, (hipStream_t)stream, p);
+    return check_launch("kfx_filter_bad_kinect_u16");
+}
+
+// ColourVbo(dId, dPd, dIc, KT_cd) (cu_depth_tools.cu:86-119)
+extern "C" int kfx_colour_vbo(const kfx_image* id, const kfx_image* vbo, const kfx_image* rgb, const float KT_cd[12], kfx_stream stream)
+{
+    if (int e = check_image(id, 4, "ColourVbo: output image")) return e;
+    if (int e = check_image(vbo, 16, "ColourVbo: vbo image")) return e;
+    if (int e = check_image(rgb, 1, "ColourVbo: rgb image")) return e;
+    if (!KT_cd) return set_error(KFX_E_NULL, "ColourVbo: null transform");
+    if (id->w == 0 || id->h == 0) return 0;
+    if (vbo->w < id->w || vbo->h < id->h || rgb->pitch < rgb->w * 3) return set_error(KFX_E_SHAPE, "ColourVbo: image sizes");
+    ColourVboParams p;
+    p.vbo = (const unsigned char*)vbo->ptr; p.vpitch = vbo->pitch;
+    p.rgb = (const unsigned char*)rgb->ptr; p.rpitch = rgb->pitch; p.rw = (int)rgb->w; p.rh = (int)rgb->h;
+    p.out = (unsigned char*)id->ptr; p.opitch = id->pitch; p.w = (int)id->w; p.h = (int)id->h;
+    for (int i = 0; i < 12; ++i) p.KT.m[i] = KT_cd[i];
+    hipLaunchKernelGGL(k_colour_vbo, dim3(ceil_div(p.w, 64), ceil_div(p.h, 4)), dim3(256), 0, (hipStream_t)stream, p);
+    return check_launch("kfx_colour_vbo");
 }

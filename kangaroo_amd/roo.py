@@ -20,6 +20,7 @@ from ._lib import KfxError, KfxImage, KfxVolume  # noqa: F401
 _ELEM = {
     "f32": (np.float32, 1), "f32x4": (np.float32, 4), "u16": (np.uint16, 1), "u8": (np.uint8, 1),
     "u8x3": (np.uint8, 3),   # Image<uchar3>: the RGB frame of the colour path
+    "u8x4": (np.uint8, 4),   # Image<uchar4>: ColourVbo output
 }
 PITCH_ALIGN = 256  # same policy as kfx_alloc_pitched
 
@@ -464,3 +465,21 @@ def SdfDistance(dist, depth, vol, T_wc, K, trunc_distance=0.0, stream=None):
     t, _t = _fp(T_wc, 12)
     k, _k = _fp(K, 4)
     _lib.check(_lib.load().kfx_sdf_distance(dist.ref(), depth.ref(), vol.ref(), t, k, trunc_distance, _stream(stream)))
+
+
+def Disp2Depth(dIn, dOut, fu, fBaseline, fMinDisp=0.0, stream=None):
+    """Disp2Depth(dIn, dOut, fu, fBaseline, fMinDisp) (cu_depth_tools.h:11)."""
+    _lib.check(_lib.load().kfx_disp2depth(dIn.ref(), dOut.ref(), fu, fBaseline, fMinDisp, _stream(stream)))
+
+
+def FilterBadKinectData(dFiltered, dKinectDepth, stream=None):
+    """FilterBadKinectData(dFiltered, dKinectDepth) (cu_depth_tools.h:14-17): float or unsigned short millimetres."""
+    L = _lib.load()
+    fn = L.kfx_filter_bad_kinect_u16 if dKinectDepth.kind == "u16" else L.kfx_filter_bad_kinect_f32
+    _lib.check(fn(dFiltered.ref(), dKinectDepth.ref(), _stream(stream)))
+
+
+def ColourVbo(dId, dPd, dIc, KT_cd, stream=None):
+    """ColourVbo(dId, dPd, dIc, KT_cd) (cu_depth_tools.h:30): dId Image("u8x4"), dPd float4 vertices, dIc Image("u8x3")."""
+    t, _t = _fp(KT_cd, 12)
+    _lib.check(_lib.load().kfx_colour_vbo(dId.ref(), dPd.ref(), dIc.ref(), t, _stream(stream)))

@@ -82,6 +82,12 @@ def lib():
         L.kfo_sdf_fuse_color.restype = C.c_uint64
         L.kfo_raycast_sdf_color.argtypes = [PI, PI, PI, PV, PV, PF, PF, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int]
         L.kfo_raycast_sdf_color.restype = None
+        L.kfo_disp2depth.argtypes = [PI, PI, C.c_float, C.c_float, C.c_float]
+        L.kfo_disp2depth.restype = None
+        L.kfo_filter_bad_kinect.argtypes = [PI, PI, C.c_int]
+        L.kfo_filter_bad_kinect.restype = None
+        L.kfo_colour_vbo.argtypes = [PI, PI, PI, PF]
+        L.kfo_colour_vbo.restype = None
         L.kfo_sdf_distance.argtypes = [PI, PI, PV, PF, PF]
         L.kfo_sdf_distance.restype = None
         L.kfo_marching_cubes.argtypes = [PV, PV, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -487,3 +493,16 @@ def sdf_distance(dist, depth, vol, T_wc, K):
     _, t = _fp(T_wc)
     _, k = _fp(K)
     lib().kfo_sdf_distance(dist.ref(), depth.ref(), vol.ref(), t, k)
+
+
+def disp2depth(inp, out, fu, baseline, min_disp=0.0):
+    lib().kfo_disp2depth(inp.ref(), out.ref(), fu, baseline, min_disp)
+
+
+def filter_bad_kinect(out, inp):
+    lib().kfo_filter_bad_kinect(out.ref(), inp.ref(), 1 if inp.dtype == np.uint16 else 0)
+
+
+def colour_vbo(idimg, vbo, rgb, KT_cd):
+    _, t = _fp(KT_cd)
+    lib().kfo_colour_vbo(idimg.ref(), vbo.ref(), rgb.ref(), t)

@@ -1188,3 +1188,43 @@ void kfo_sdf_distance(const kfo_image* dist, const kfo_image* depth, const kfo_v
             ((float*)img_row(dist, (size_t)v))[u] = trilinear_clamped(vol, p_w, NULL, half);
         }
 }
+
+/* ---- cu_depth_tools.cu:15-53, :86-112 ---------------------------------------------------------------------- */
+void kfo_disp2depth(const kfo_image* in, const kfo_image* out, float fu, float baseline, float min_disp)
+{
+    for (size_t y = 0; y < out->h; ++y)
+        for (size_t x = 0; x < out->w; ++x) {
+            const float d = ((const float*)img_row(in, y))[x];
+            ((float*)img_row(out, y))[x] = d >= min_disp ? fu * baseline / d : NAN;
+        }
+}
+void kfo_filter_bad_kinect(const kfo_image* out, const kfo_image* in, int in_is_u16)
+{
+    for (size_t y = 0; y < out->h; ++y)
+        for (size_t x = 0; x < out->w; ++x) {
+            const float z_mm = in_is_u16 ? (float)((const uint16_t*)img_row(in, y))[x] : ((const float*)img_row(in, y))[x];
+            ((float*)img_row(out, y))[x] = z_mm >= 200 ? z_mm : NAN;
+        }
+}
+void kfo_colour_vbo(const kfo_image* id, const kfo_image* vbo, const kfo_image* rgb, const float T[12])
+{
+    for (size_t v = 0; v < id->h; ++v)
+        for (size_t u = 0; u < id->w; ++u) {
+            const f4 Pd = ((const f4*)img_row(vbo, v))[u];
+            const float k0 = T_(0, 0) * Pd.x + T_(0, 1) * Pd.y + T_(0, 2) * Pd.z + T_(0, 3) * 1.0f;
+            const float k1 = T_(1, 0) * Pd.x + T_(1, 1) * Pd.y + T_(1, 2) * Pd.z + T_(1, 3) * 1.0f;
+            const float k2 = T_(2, 0) * Pd.x + T_(2, 1) * Pd.y + T_(2, 2) * Pd.z + T_(2, 3) * 1.0f;
+            const float pu = k0 / k2, pv = k1 / k2;
+            unsigned char* o = img_row(id, v) + 4 * u;
+            if (1.0f <= pu && pu < ((float)rgb->w - 1.0f) && 1.0f <= pv && pv < ((float)rgb->h - 1.0f)) { /* InBounds(x,y,1) */
+                const float jx = floorf(pu), jy = floorf(pv);
+                const float gx = pu - jx, gy = pv - jy;
+                const uc3* cbl = (const uc3*)img_row(rgb, (size_t)jy) + (size_t)jx;
+                const uc3* ctl = (const uc3*)img_row(rgb, (size_t)(jy + 1)) + (size_t)jx;
+                const f3 c = lerp3(lerp_uc3(cbl[0], cbl[1], gx), lerp_uc3(ctl[0], ctl[1], gx), gy);
+                o[0] = (unsigned char)c.x; o[1] = (unsigned char)c.y; o[2] = (unsigned char)c.z; o[3] = 255;
+            } else {
+                o[0] = o[1] = o[2] = o[3] = 0;
+            }
+        }
+}

@@ -100,6 +100,11 @@ void kfo_raycast_sdf_color(const kfo_image* depth, const kfo_image* norm, const 
                            const kfo_volume* cvol, const float T_wc[12], const float K[4], float near, float far, float trunc,
                            int subpix, int nthreads);
 
+/* cu_depth_tools.cu:15-53, :86-119 */
+void kfo_disp2depth(const kfo_image* in, const kfo_image* out, float fu, float baseline, float min_disp);
+void kfo_filter_bad_kinect(const kfo_image* out, const kfo_image* in, int in_is_u16);
+void kfo_colour_vbo(const kfo_image* id, const kfo_image* vbo, const kfo_image* rgb, const float KT_cd[12]);
+
 /* cu_sdffusion.cu:200-225 */
 void kfo_sdf_distance(const kfo_image* dist, const kfo_image* depth, const kfo_volume* vol, const float T_wc[12], const float K[4]);
 

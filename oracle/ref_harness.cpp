@@ -469,4 +469,29 @@ void ref_analytic_depths(const kfo_image* pbox, const kfo_image* psph, const kfo
         }
 }
 
+// ColourVbo's per-pixel body (cu_depth_tools.cu:91-110) with the reference's Mat product, InBounds, GetBilinear<float3>
+// and the float -> unsigned char narrowing of make_uchar4
+void ref_colour_vbo(const kfo_image* pid, const kfo_image* pvbo, const kfo_image* prgb, const float* kt)
+{
+    Image<uchar4, TargetHost, DontManage> dId((uchar4*)pid->ptr, pid->w, pid->h, pid->pitch);
+    HImgF4 dPd = imf4(pvbo);
+    Image<uchar3, TargetHost, DontManage> dIc((uchar3*)prgb->ptr, prgb->w, prgb->h, prgb->pitch);
+    const Mat<float, 3, 4> KT_cd = mkT(kt);
+    for (int v = 0; v < (int)dId.h; ++v)
+        for (int u = 0; u < (int)dId.w; ++u) {
+            const float4 Pd4 = dPd(u, v);
+            const Mat<float, 4, 1> Pd = {Pd4.x, Pd4.y, Pd4.z, 1};
+            const Mat<float, 3, 1> KPc = KT_cd * Pd;
+            const Mat<float, 2, 1> pc = {KPc(0) / KPc(2), KPc(1) / KPc(2)};
+            uchar4 Id;
+            if (dIc.InBounds(pc(0), pc(1), 1)) {
+                const float3 c = dIc.GetBilinear<float3>(pc(0), pc(1));
+                Id = make_uchar4(c.x, c.y, c.z, 255);
+            } else {
+                Id = make_uchar4(0, 0, 0, 0);
+            }
+            dId(u, v) = Id;
+        }
+}
+
 }

@@ -1011,3 +1011,34 @@ def test_gpu_analytic_renderers_and_sdf_distance(roo, w, h):
     oracle.sdf_distance(odist, od, ovol, T_wc, K)
     roo.SdfDistance(gdist, gd, vol, T_wc, K, tr)
     assert T.nan_equal(gdist.MemcpyToHost(), odist.data) and np.isfinite(odist.data).any()
+
+
+def test_gpu_depth_tools(roo):
+    """Disp2Depth, FilterBadKinectData (float / unsigned short) and ColourVbo against the oracle, bit / byte exact."""
+    from test_oracle_cpu import depth_tool_inputs
+    rng = np.random.default_rng(9)
+    w, h = 83, 41
+    disp = rng.uniform(0.0, 64.0, (h, w)).astype(np.float32)
+    disp[::7, ::3] = 0.0
+    od, gd = oracle.Image(w, h), roo.Image(w, h)
+    di = oracle.Image(w, h)
+    di.data[...] = disp
+    oracle.disp2depth(di, od, 570.0, 0.075, 1.0)
+    roo.Disp2Depth(T.upload_image(roo, disp), gd, 570.0, 0.075, 1.0)
+    assert T.nan_equal(gd.MemcpyToHost(), od.data) and np.isnan(od.data).any() and np.isfinite(od.data).any()
+    mm = rng.integers(0, 5000, (h, w)).astype(np.uint16)
+    for arr in (mm, mm.astype(np.float32)):
+        oi = oracle.Image(w, h, arr.dtype)
+        oi.data[...] = arr
+        oo, go = oracle.Image(w, h), roo.Image(w, h)
+        oracle.filter_bad_kinect(oo, oi)
+        roo.FilterBadKinectData(go, T.upload_image(roo, arr))
+        assert T.nan_equal(go.MemcpyToHost(), oo.data) and np.isnan(oo.data).any()
+    vbo, rgb, KT = depth_tool_inputs()
+    want = oracle.Image(vbo.w, vbo.h, np.uint8, 4)
+    oracle.colour_vbo(want, vbo, rgb, KT)
+    grgb = roo.Image(rgb.w, rgb.h, "u8x3")
+    grgb.MemcpyFromHost(rgb.data)
+    gid = roo.Image(vbo.w, vbo.h, "u8x4")
+    roo.ColourVbo(gid, T.upload_image(roo, vbo.data), grgb, KT)
+    assert np.array_equal(gid.MemcpyToHost(), want.data)

@@ -272,3 +272,31 @@ def test_oracle_analytic_renderers_and_sdf_distance_vs_reference_headers():
     oracle.sdf_distance(od, depth, vol, T_wc, K)
     R.ref_sdf_distance(rd.ref(), depth.ref(), vol.ref(), t.ctypes.data_as(PF), k.ctypes.data_as(PF))
     assert T.nan_equal(od.data, rd.data) and np.isfinite(od.data).any()
+
+
+def depth_tool_inputs(w=96, h=72, cw=80, ch=64, seed=3):
+    rng = np.random.default_rng(seed)
+    K = scenes.intrinsics(w, h)
+    depth = scenes.render_depth("room", w, h, scenes.orbit_pose(1, 8), K)
+    vbo = oracle.Image(w, h, channels=4)
+    d = oracle.Image(w, h)
+    d.data[...] = depth
+    d.data[::11, ::5] = np.nan
+    oracle.depth_to_vbo(vbo, d, K)
+    rgb = oracle.Image(cw, ch, np.uint8, 3)
+    rgb.data[...] = rng.integers(0, 256, (ch, cw, 3), dtype=np.uint8)
+    Kc = scenes.intrinsics(cw, ch)
+    T_cd = np.array([[1, 0, 0, 0.025], [0, 1, 0, -0.01], [0, 0, 1, 0.0]], np.float64)
+    KT = (np.array([[Kc[0], 0, Kc[2]], [0, Kc[1], Kc[3]], [0, 0, 1]], np.float64) @ T_cd).astype(np.float32)
+    return vbo, rgb, KT
+
+
+@pytest.mark.skipif(not os.path.exists(REF_SO), reason="oracle/_ref not built (needs /root/reference)")
+def test_oracle_colour_vbo_vs_reference_headers():
+    R = C.CDLL(REF_SO)
+    vbo, rgb, KT = depth_tool_inputs()
+    got, want = oracle.Image(vbo.w, vbo.h, np.uint8, 4), oracle.Image(vbo.w, vbo.h, np.uint8, 4)
+    oracle.colour_vbo(got, vbo, rgb, KT)
+    kt = np.ascontiguousarray(KT, np.float32).reshape(-1)
+    R.ref_colour_vbo(want.ref(), vbo.ref(), rgb.ref(), kt.ctypes.data_as(C.POINTER(C.c_float)))
+    assert np.array_equal(got.data, want.data) and (got.data[..., 3] == 255).mean() > 0.3 and (got.data[..., 3] == 0).any()
