@@ -19,6 +19,21 @@ template<typename To, typename Ti>
 KANGAROO_EXPORT
 void BilateralFilter(Image<To> dOut, const Image<Ti> dIn, float gs, float gr, uint size, Ti minval);
 
+// joint bilateral filter with a guide image (reference cu_bilateral.h:21-25; src/cu_bilateral.cu:110-155,
+// instantiated for <float,float,unsigned char> and <float,float,float>)
+template<typename To, typename Ti, typename Ti2>
+KANGAROO_EXPORT
+void BilateralFilter(Image<To> dOut, const Image<Ti> dIn, const Image<Ti2> dImg, float gs, float gr, float gc, uint size);
+
+template<> inline void BilateralFilter(Image<float> dOut, const Image<float> dIn, const Image<unsigned char> dImg, float gs, float gr, float gc, uint size)
+{
+    GpuNoteStatus(kfx_bilateral_guided_u8(dOut.abi(), dIn.abi(), dImg.abi(), gs, gr, gc, size, 0));
+}
+template<> inline void BilateralFilter(Image<float> dOut, const Image<float> dIn, const Image<float> dImg, float gs, float gr, float gc, uint size)
+{
+    GpuNoteStatus(kfx_bilateral_guided_f32(dOut.abi(), dIn.abi(), dImg.abi(), gs, gr, gc, size, 0));
+}
+
 template<> inline void BilateralFilter(Image<float> dOut, const Image<float> dIn, float gs, float gr, uint size)
 {
     GpuNoteStatus(kfx_bilateral_f32(dOut.abi(), dIn.abi(), gs, gr, size, 0.f, 0, 0));

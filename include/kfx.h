@@ -188,6 +188,13 @@ int kfx_memcpy_2d(void* dst, size_t dpitch, const void* src, size_t spitch, size
                   size_t rows, int kind, kfx_stream stream);
 int kfx_stream_synchronize(kfx_stream stream);
 
+/* BilateralFilter(dOut, dIn, dImg, gs, gr, gc, size) (cu_bilateral.cu:110-155): joint bilateral filter of a float image
+ * with a float / unsigned char guide image (third weight exp(-(guide difference)^2 / 2 gc^2)); sumw == 0 keeps the input. */
+int kfx_bilateral_guided_f32(const kfx_image* out, const kfx_image* in, const kfx_image* guide, float gs, float gr, float gc,
+                             unsigned size, kfx_stream stream);
+int kfx_bilateral_guided_u8(const kfx_image* out, const kfx_image* in, const kfx_image* guide, float gs, float gr, float gc,
+                            unsigned size, kfx_stream stream);
+
 /* ---- the small per-pixel tools of cu_depth_tools.h -----------------------------------------------------
  * kfx_disp2depth:           Disp2Depth(dIn, dOut, fu, fBaseline, fMinDisp) (cu_depth_tools.cu:15-30)
  * kfx_filter_bad_kinect_*:  FilterBadKinectData(dFiltered, dKinectDepth) for float / unsigned short readings (:32-53)

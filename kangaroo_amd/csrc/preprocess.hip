@@ -120,6 +120,42 @@ __global__ __launch_bounds__(256) void k_bilateral_global(const BilParams p)
     reinterpret_cast<float*>(p.out + (size_t)y * p.out_pitch)[x] = sum / sumw;
 }
 
+// Joint ("cross") bilateral filter with an external guide image (cu_bilateral.cu:110-143): weights
+// exp(-sd2 / 2gs^2) * exp(-rd2 / 2gr^2) * exp(-cd2 / 2gc^2) with cd the guide difference; sumw == 0 keeps the input.
+struct GuidedParams {
+    BilParams b;
+    const unsigned char* guide;
+    size_t gpitch;
+    int gw, gh;
+    float gc;
+};
+template <typename Tg>
+__global__ __launch_bounds__(256) void k_bilateral_guided(const GuidedParams g)
+{
+    const BilParams& p = g.b;
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= p.w || y >= p.h) return;
+    const float pv = reinterpret_cast<const float*>(p.in + (size_t)y * p.in_pitch)[x];
+    const float pcv = (float)reinterpret_cast<const Tg*>(g.guide + (size_t)y * g.gpitch)[x];
+    float sum = 0.f, sumw = 0.f;
+    for (int r = -p.R; r <= p.R; ++r)
+        for (int c = -p.R; c <= p.R; ++c) {
+            const float q = load_clamped<float>(p, x + c, y + r);
+            const int gx = min(max(x + c, 0), g.gw - 1), gy = min(max(y + r, 0), g.gh - 1);
+            const float qc = (float)reinterpret_cast<const Tg*>(g.guide + (size_t)gy * g.gpitch)[gx];
+            const float rd = pv - q, cd = pcv - qc;
+            const float sd2 = (float)(r * r + c * c);
+            const float rd2 = rd * rd, cd2 = cd * cd;
+            const float sw = __expf(-(sd2) / (2 * p.gs * p.gs));
+            const float rw = __expf(-(rd2) / (2 * p.gr * p.gr));
+            const float cw = __expf(-(cd2) / (2 * g.gc * g.gc));
+            const float w = sw * rw * cw;
+            sumw += w;
+            sum += w * q;
+        }
+    reinterpret_cast<float*>(p.out + (size_t)y * p.out_pitch)[x] = sumw == 0 ? pv : sum / sumw;
+}
+
 struct VboParams {
     const unsigned char* in;
     size_t in_pitch;
@@ -468,4 +504,38 @@ extern "C" int kfx_colour_vbo(const kfx_image* id, const kfx_image* vbo, const k
     for (int i = 0; i < 12; ++i) p.KT.m[i] = KT_cd[i];
     hipLaunchKernelGGL(k_colour_vbo, dim3(ceil_div(p.w, 64), ceil_div(p.h, 4)), dim3(256), 0, (hipStream_t)stream, p);
     return check_launch("kfx_colour_vbo");
+}
+
+// BilateralFilter(dOut, dIn, dImg, gs, gr, gc, size) (cu_bilateral.cu:145-155): guide image float or unsigned char
+template <typename Tg>
+static int guided_launch(const kfx_image* out, const kfx_image* in, const kfx_image* guide, float gs, float gr, float gc, unsigned size,
+                         kfx_stream stream)
+{
+    if (int e = check_image(out, 4, "BilateralFilter(guided): output image")) return e;
+    if (int e = check_image(in, 4, "BilateralFilter(guided): input image")) return e;
+    if (int e = check_image(guide, sizeof(Tg), "BilateralFilter(guided): guide image")) return e;
+    if (out->w == 0 || out->h == 0) return 0;
+    if (in->w < out->w || in->h < out->h || guide->w < out->w || guide->h < out->h)
+        return set_error(KFX_E_SHAPE, "BilateralFilter(guided): inputs smaller than the output");
+    if (size > 64) return set_error(KFX_E_RANGE, "BilateralFilter(guided): window too large");
+    GuidedParams g;
+    g.b = BilParams{(const unsigned char*)in->ptr, in->pitch, (unsigned char*)out->ptr, out->pitch, (int)out->w, (int)out->h,
+                    (int)in->w, (int)in->h, (int)size, gs, gr, 0.f, 0};
+    g.guide = (const unsigned char*)guide->ptr;
+    g.gpitch = guide->pitch;
+    g.gw = (int)guide->w;
+    g.gh = (int)guide->h;
+    g.gc = gc;
+    hipLaunchKernelGGL(k_bilateral_guided<Tg>, dim3(ceil_div(g.b.w, 64), ceil_div(g.b.h, 4)), dim3(256), 0, (hipStream_t)stream, g);
+    return check_launch("kfx_bilateral_guided");
+}
+extern "C" int kfx_bilateral_guided_f32(const kfx_image* out, const kfx_image* in, const kfx_image* guide, float gs, float gr, float gc,
+                                        unsigned size, kfx_stream stream)
+{
+    return guided_launch<float>(out, in, guide, gs, gr, gc, size, stream);
+}
+extern "C" int kfx_bilateral_guided_u8(const kfx_image* out, const kfx_image* in, const kfx_image* guide, float gs, float gr, float gc,
+                                       unsigned size, kfx_stream stream)
+{
+    return guided_launch<unsigned char>(out, in, guide, gs, gr, gc, size, stream);
 }

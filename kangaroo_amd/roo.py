@@ -483,3 +483,10 @@ def ColourVbo(dId, dPd, dIc, KT_cd, stream=None):
     """ColourVbo(dId, dPd, dIc, KT_cd) (cu_depth_tools.h:30): dId Image("u8x4"), dPd float4 vertices, dIc Image("u8x3")."""
     t, _t = _fp(KT_cd, 12)
     _lib.check(_lib.load().kfx_colour_vbo(dId.ref(), dPd.ref(), dIc.ref(), t, _stream(stream)))
+
+
+def BilateralFilterGuided(dOut, dIn, dImg, gs, gr, gc, size, stream=None):
+    """BilateralFilter(dOut, dIn, dImg, gs, gr, gc, size) (cu_bilateral.h:21-25): joint bilateral, guide f32 or u8."""
+    L = _lib.load()
+    fn = L.kfx_bilateral_guided_u8 if dImg.kind == "u8" else L.kfx_bilateral_guided_f32
+    _lib.check(fn(dOut.ref(), dIn.ref(), dImg.ref(), gs, gr, gc, size, _stream(stream)))

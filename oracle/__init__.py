@@ -82,6 +82,8 @@ def lib():
         L.kfo_sdf_fuse_color.restype = C.c_uint64
         L.kfo_raycast_sdf_color.argtypes = [PI, PI, PI, PV, PV, PF, PF, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int]
         L.kfo_raycast_sdf_color.restype = None
+        L.kfo_bilateral_guided.argtypes = [PI, PI, PI, C.c_int, C.c_float, C.c_float, C.c_float, C.c_int]
+        L.kfo_bilateral_guided.restype = None
         L.kfo_disp2depth.argtypes = [PI, PI, C.c_float, C.c_float, C.c_float]
         L.kfo_disp2depth.restype = None
         L.kfo_filter_bad_kinect.argtypes = [PI, PI, C.c_int]
@@ -506,3 +508,7 @@ def filter_bad_kinect(out, inp):
 def colour_vbo(idimg, vbo, rgb, KT_cd):
     _, t = _fp(KT_cd)
     lib().kfo_colour_vbo(idimg.ref(), vbo.ref(), rgb.ref(), t)
+
+
+def bilateral_guided(out, inp, guide, gs, gr, gc, size):
+    lib().kfo_bilateral_guided(out.ref(), inp.ref(), guide.ref(), 1 if guide.dtype == np.uint8 else 0, gs, gr, gc, size)

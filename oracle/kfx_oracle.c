@@ -1228,3 +1228,32 @@ void kfo_colour_vbo(const kfo_image* id, const kfo_image* vbo, const kfo_image* 
             }
         }
 }
+
+/* Joint bilateral filter with a guide image, cu_bilateral.cu:110-143 (guide float or unsigned char) */
+void kfo_bilateral_guided(const kfo_image* out, const kfo_image* in, const kfo_image* guide, int guide_is_u8, float gs, float gr, float gc,
+                          int size)
+{
+    const int W = (int)in->w, H = (int)in->h, GW = (int)guide->w, GH = (int)guide->h;
+    for (int y = 0; y < (int)out->h; ++y)
+        for (int x = 0; x < (int)out->w; ++x) {
+            const float p = ((const float*)img_row(in, (size_t)y))[x];
+            const float pc = guide_is_u8 ? (float)img_row(guide, (size_t)y)[x] : ((const float*)img_row(guide, (size_t)y))[x];
+            float sum = 0, sumw = 0;
+            for (int r = -size; r <= size; ++r)
+                for (int c = -size; c <= size; ++c) {
+                    const float q = ((const float*)img_row(in, (size_t)clampi(y + r, 0, H - 1)))[clampi(x + c, 0, W - 1)];
+                    const int gx = clampi(x + c, 0, GW - 1), gy = clampi(y + r, 0, GH - 1);
+                    const float qc = guide_is_u8 ? (float)img_row(guide, (size_t)gy)[gx] : ((const float*)img_row(guide, (size_t)gy))[gx];
+                    const float rd = p - q, cd = pc - qc;
+                    const float sd2 = (float)(r * r + c * c);
+                    const float rd2 = rd * rd, cd2 = cd * cd;
+                    const float sw = expf(-(sd2) / (2 * gs * gs));
+                    const float rw = expf(-(rd2) / (2 * gr * gr));
+                    const float cw = expf(-(cd2) / (2 * gc * gc));
+                    const float w = sw * rw * cw;
+                    sumw += w;
+                    sum += w * q;
+                }
+            ((float*)img_row(out, (size_t)y))[x] = sumw == 0 ? p : sum / sumw;
+        }
+}

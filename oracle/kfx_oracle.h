@@ -100,6 +100,10 @@ void kfo_raycast_sdf_color(const kfo_image* depth, const kfo_image* norm, const 
                            const kfo_volume* cvol, const float T_wc[12], const float K[4], float near, float far, float trunc,
                            int subpix, int nthreads);
 
+/* cu_bilateral.cu:110-155 */
+void kfo_bilateral_guided(const kfo_image* out, const kfo_image* in, const kfo_image* guide, int guide_is_u8, float gs, float gr, float gc,
+                          int size);
+
 /* cu_depth_tools.cu:15-53, :86-119 */
 void kfo_disp2depth(const kfo_image* in, const kfo_image* out, float fu, float baseline, float min_disp);
 void kfo_filter_bad_kinect(const kfo_image* out, const kfo_image* in, int in_is_u16);

@@ -1042,3 +1042,21 @@ def test_gpu_depth_tools(roo):
     gid = roo.Image(vbo.w, vbo.h, "u8x4")
     roo.ColourVbo(gid, T.upload_image(roo, vbo.data), grgb, KT)
     assert np.array_equal(gid.MemcpyToHost(), want.data)
+
+
+@pytest.mark.parametrize("guide_kind,size", [("f32", 2), ("u8", 3)])
+def test_gpu_joint_bilateral_filter(roo, guide_kind, size):
+    """BilateralFilter(dOut, dIn, dImg, gs, gr, gc, size): hardware exp, so the same 2e-6 relative bar as the plain filter."""
+    rng = np.random.default_rng(11)
+    w, h = 97, 53
+    depth = (2.0 + 0.5 * rng.random((h, w))).astype(np.float32)
+    guide = rng.integers(0, 256, (h, w)).astype(np.uint8) if guide_kind == "u8" else rng.random((h, w)).astype(np.float32)
+    oi, og, oo = oracle.Image(w, h), oracle.Image(w, h, guide.dtype), oracle.Image(w, h)
+    oi.data[...] = depth
+    og.data[...] = guide
+    gc = 20.0 if guide_kind == "u8" else 0.1
+    oracle.bilateral_guided(oo, oi, og, 1.5, 0.1, gc, size)
+    go = roo.Image(w, h)
+    roo.BilateralFilterGuided(go, T.upload_image(roo, depth), T.upload_image(roo, guide), 1.5, 0.1, gc, size)
+    got = go.MemcpyToHost()
+    assert np.allclose(got, oo.data, rtol=BILATERAL_RTOL, atol=0) and np.isfinite(got).all()
