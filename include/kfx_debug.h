@@ -1,0 +1,21 @@
+/* kfx_debug.h -- measurement aids exported by libkfx.so; not part of the drop-in boundary (include/kfx.h). */
+#ifndef KFX_DEBUG_H
+#define KFX_DEBUG_H
+
+#include "kfx.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* In-place read-modify-write sweep of a BoundedVolume<SDF_t> (val += 1 on every cell, 16 B per lane), the memory
+ * ceiling SdfFuse is measured against (scripts/rmw_floor.py).  variant selects the thread
+ * mapping: 0 = linear grid-stride sweep of the contiguous span, 1 = the tiled fuse kernel's brick (64 x 8 x 16 voxels
+ * per workgroup, z-march), 2 / 5 = 128-voxel rows x 4 with 16 / 4 slices, 3 = whole z-columns, 4 = 64-slice bricks,
+ * 10-17 = generated shapes with and without nontemporal accesses (kangaroo_amd/csrc/debug.hip). */
+int kfx_debug_rmw(const kfx_volume* vol, int variant, kfx_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

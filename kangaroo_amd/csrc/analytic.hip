@@ -198,15 +198,7 @@ extern "C" int kfx_sdf_distance(const kfx_image* dist, const kfx_image* depth, c
     if ((((uintptr_t)dist->ptr | dist->pitch | (uintptr_t)depth->ptr | depth->pitch) & 3) || (((uintptr_t)vol->ptr | vol->pitch | vol->img_pitch) & 7))
         return set_error(KFX_E_ALIGN, "SdfDistance: alignment");
     DistParams p;
-    p.vol.ptr = (unsigned char*)vol->ptr;
-    p.vol.pitch = vol->pitch;
-    p.vol.img_pitch = vol->img_pitch;
-    p.vol.w = (int)vol->w; p.vol.h = (int)vol->h; p.vol.d = (int)vol->d;
-    p.vol.bmin = V3{vol->boxmin[0], vol->boxmin[1], vol->boxmin[2]};
-    p.vol.bmax = V3{vol->boxmax[0], vol->boxmax[1], vol->boxmax[2]};
-    p.size = V3{vol->boxmax[0] - vol->boxmin[0], vol->boxmax[1] - vol->boxmin[1], vol->boxmax[2] - vol->boxmin[2]};
-    p.dims1 = V3{(float)vol->w - 1.f, (float)vol->h - 1.f, (float)vol->d - 1.f};
-    p.hi2 = V3{(float)(vol->w - 2), (float)(vol->h - 2), (float)(vol->d - 2)};
+    set_geometry(p, vol);
     p.optr = (unsigned char*)dist->ptr; p.opitch = dist->pitch;
     p.dptr = (unsigned char*)depth->ptr; p.dpitch = depth->pitch;
     p.w = (int)depth->w; p.h = (int)depth->h;

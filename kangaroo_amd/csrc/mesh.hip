@@ -171,16 +171,8 @@ static int mesh_params(MeshParams& p, const kfx_volume* vol)
         return set_error(KFX_E_SHAPE, "SaveMesh: volume dimensions");
     if (vol->pitch < vol->w * 8 || vol->img_pitch < vol->pitch * (vol->h - 1) + vol->w * 8) return set_error(KFX_E_SHAPE, "SaveMesh: volume pitch");
     if (((uintptr_t)vol->ptr | vol->pitch | vol->img_pitch) & 7) return set_error(KFX_E_ALIGN, "SaveMesh: alignment");
-    p.vol.ptr = (unsigned char*)vol->ptr;
-    p.vol.pitch = vol->pitch;
-    p.vol.img_pitch = vol->img_pitch;
-    p.vol.w = (int)vol->w; p.vol.h = (int)vol->h; p.vol.d = (int)vol->d;
-    p.vol.bmin = V3{vol->boxmin[0], vol->boxmin[1], vol->boxmin[2]};
-    p.vol.bmax = V3{vol->boxmax[0], vol->boxmax[1], vol->boxmax[2]};
-    p.size = V3{vol->boxmax[0] - vol->boxmin[0], vol->boxmax[1] - vol->boxmin[1], vol->boxmax[2] - vol->boxmin[2]};
-    p.dims1 = V3{(float)vol->w - 1.f, (float)vol->h - 1.f, (float)vol->d - 1.f};
-    p.hi2 = V3{(float)(vol->w - 2), (float)(vol->h - 2), (float)(vol->d - 2)};
-    p.voxel = V3{p.size.x / (float)(vol->w - 1), p.size.y / (float)(vol->h - 1), p.size.z / (float)(vol->d - 1)};
+    set_geometry(p, vol);
+    set_voxel_size(p, vol);
     p.cx = (int)vol->w - 1; p.cy = (int)vol->h - 1; p.cz = (int)vol->d - 1;
     return 0;
 }
@@ -215,15 +207,7 @@ extern "C" int kfx_mc_emit(const kfx_volume* vol, const kfx_volume* colorvol, co
         if (colorvol->pitch < colorvol->w * 4 || colorvol->img_pitch < colorvol->pitch * (colorvol->h - 1) + colorvol->w * 4)
             return set_error(KFX_E_SHAPE, "SaveMesh: colour volume pitch");
         if (((uintptr_t)colorvol->ptr | colorvol->pitch | colorvol->img_pitch) & 3) return set_error(KFX_E_ALIGN, "SaveMesh: colour volume alignment");
-        cv.vol.ptr = (unsigned char*)colorvol->ptr;
-        cv.vol.pitch = colorvol->pitch;
-        cv.vol.img_pitch = colorvol->img_pitch;
-        cv.vol.w = (int)colorvol->w; cv.vol.h = (int)colorvol->h; cv.vol.d = (int)colorvol->d;
-        cv.vol.bmin = V3{colorvol->boxmin[0], colorvol->boxmin[1], colorvol->boxmin[2]};
-        cv.vol.bmax = V3{colorvol->boxmax[0], colorvol->boxmax[1], colorvol->boxmax[2]};
-        cv.size = V3{colorvol->boxmax[0] - colorvol->boxmin[0], colorvol->boxmax[1] - colorvol->boxmin[1], colorvol->boxmax[2] - colorvol->boxmin[2]};
-        cv.dims1 = V3{(float)colorvol->w - 1.f, (float)colorvol->h - 1.f, (float)colorvol->d - 1.f};
-        cv.hi2 = V3{(float)(colorvol->w - 2), (float)(colorvol->h - 2), (float)(colorvol->d - 2)};
+        set_geometry(cv, colorvol);
     }
     if (n_active > 0x7fffffffLL * 128) return set_error(KFX_E_RANGE, "SaveMesh: too many active cubes");
     hipLaunchKernelGGL(k_mc_emit, dim3((unsigned)((n_active + 127) / 128)), dim3(128), 0, (hipStream_t)stream, p, cv, has_color,

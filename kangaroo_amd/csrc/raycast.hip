@@ -257,19 +257,8 @@ static int raycast_launch(const kfx_image* depth, const kfx_image* norm, const k
         return set_error(KFX_E_SHAPE, "RaycastSdf: volume pitch");
 
     RayParams p;
-    p.vol.ptr = (unsigned char*)vol->ptr;
-    p.vol.pitch = vol->pitch;
-    p.vol.img_pitch = vol->img_pitch;
-    p.vol.w = (int)vol->w;
-    p.vol.h = (int)vol->h;
-    p.vol.d = (int)vol->d;
-    p.vol.bmin = V3{vol->boxmin[0], vol->boxmin[1], vol->boxmin[2]};
-    p.vol.bmax = V3{vol->boxmax[0], vol->boxmax[1], vol->boxmax[2]};
-    p.size = V3{vol->boxmax[0] - vol->boxmin[0], vol->boxmax[1] - vol->boxmin[1], vol->boxmax[2] - vol->boxmin[2]};
-    p.dims1 = V3{(float)vol->w - 1.f, (float)vol->h - 1.f, (float)vol->d - 1.f};
-    p.hi2 = V3{(float)(vol->w - 2), (float)(vol->h - 2), (float)(vol->d - 2)};
-    // VoxelSizeUnits = Size / make_float3(w-1,h-1,d-1) (size_t -> float), BoundedVolume.h:67-76
-    p.voxel = V3{p.size.x / (float)(vol->w - 1), p.size.y / (float)(vol->h - 1), p.size.z / (float)(vol->d - 1)};
+    set_geometry(p, vol);
+    set_voxel_size(p, vol);
     for (int i = 0; i < 12; ++i) p.T.m[i] = T_wc[i];
     p.K = Intr{K[0], K[1], K[2], K[3]};
     p.dptr = (unsigned char*)depth->ptr;
@@ -297,17 +286,7 @@ static int raycast_launch(const kfx_image* depth, const kfx_image* norm, const k
             colorvol->img_pitch < colorvol->pitch * (colorvol->h - 1) + colorvol->w * 4)
             return set_error(KFX_E_SHAPE, "RaycastSdf(colour): colour volume dimensions / pitch");
         if (((uintptr_t)colorvol->ptr | colorvol->pitch | colorvol->img_pitch) & 3) return set_error(KFX_E_ALIGN, "RaycastSdf(colour): alignment");
-        cv.vol.ptr = (unsigned char*)colorvol->ptr;
-        cv.vol.pitch = colorvol->pitch;
-        cv.vol.img_pitch = colorvol->img_pitch;
-        cv.vol.w = (int)colorvol->w;
-        cv.vol.h = (int)colorvol->h;
-        cv.vol.d = (int)colorvol->d;
-        cv.vol.bmin = V3{colorvol->boxmin[0], colorvol->boxmin[1], colorvol->boxmin[2]};
-        cv.vol.bmax = V3{colorvol->boxmax[0], colorvol->boxmax[1], colorvol->boxmax[2]};
-        cv.size = V3{colorvol->boxmax[0] - colorvol->boxmin[0], colorvol->boxmax[1] - colorvol->boxmin[1], colorvol->boxmax[2] - colorvol->boxmin[2]};
-        cv.dims1 = V3{(float)colorvol->w - 1.f, (float)colorvol->h - 1.f, (float)colorvol->d - 1.f};
-        cv.hi2 = V3{(float)(colorvol->w - 2), (float)(colorvol->h - 2), (float)(colorvol->d - 2)};
+        set_geometry(cv, colorvol);
         hipLaunchKernelGGL((k_raycast_sdf<CELL, true>), grid, dim3(256), 0, (hipStream_t)stream, p, cv);
     } else {
         hipLaunchKernelGGL((k_raycast_sdf<CELL, false>), grid, dim3(256), 0, (hipStream_t)stream, p, cv);

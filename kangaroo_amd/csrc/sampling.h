@@ -129,4 +129,27 @@ __device__ __forceinline__ V3 gradient(const GEOM& p, const V3 pos_w)
     return div_cw(deriv, p.voxel);
 }
 
+// Host side: fill the members the samplers read ({vol, size, dims1, hi2}) from a kfx_volume.  VoxelSizeUnits =
+// Size / (dims - 1) with the dims converted from size_t (BoundedVolume.h:67-76) goes into `voxel` where the block has one.
+template <typename GEOM>
+inline void set_geometry(GEOM& g, const kfx_volume* v)
+{
+    g.vol.ptr = (unsigned char*)v->ptr;
+    g.vol.pitch = v->pitch;
+    g.vol.img_pitch = v->img_pitch;
+    g.vol.w = (int)v->w;
+    g.vol.h = (int)v->h;
+    g.vol.d = (int)v->d;
+    g.vol.bmin = V3{v->boxmin[0], v->boxmin[1], v->boxmin[2]};
+    g.vol.bmax = V3{v->boxmax[0], v->boxmax[1], v->boxmax[2]};
+    g.size = V3{v->boxmax[0] - v->boxmin[0], v->boxmax[1] - v->boxmin[1], v->boxmax[2] - v->boxmin[2]};
+    g.dims1 = V3{(float)v->w - 1.f, (float)v->h - 1.f, (float)v->d - 1.f};
+    g.hi2 = V3{(float)(v->w - 2), (float)(v->h - 2), (float)(v->d - 2)};
+}
+template <typename GEOM>
+inline void set_voxel_size(GEOM& g, const kfx_volume* v)
+{
+    g.voxel = V3{g.size.x / (float)(v->w - 1), g.size.y / (float)(v->h - 1), g.size.z / (float)(v->d - 1)};
+}
+
 } // namespace kfx
