@@ -168,7 +168,6 @@ class SlabPipeline(FramePipeline):
         assert raycast in ("composite", "exact")
         self.halo = halo
         self.raycast_mode = raycast
-        self._state = None
         self.dist = dist
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
         self.full_boxmin = np.asarray(boxmin, np.float32)
@@ -190,7 +189,9 @@ class SlabPipeline(FramePipeline):
         hi = np.array([boxmax[0], boxmax[1], zhi], f)
         return self.ops.BoundedVolume(W, H, self.s1 - self.s0, lo, hi)
 
-    def fuse(self, T_wc):
+    def fuse(self, T_wc, T_cw=None):
+        """T_cw: world -> camera transform to use instead of the float32 inverse of T_wc (the tracking loop inverts
+        its pose in float64, main.cpp:345-356)."""
         # views may have a plane count that is not a multiple of 8: integrate all of it (full_extent)
         D = self.dims[2]
         zmin, zmax = float(self.full_boxmin[2]), float(self.full_boxmax[2])
@@ -200,7 +201,7 @@ class SlabPipeline(FramePipeline):
             target, first = self.vol.ZSlab(self.z0 - self.s0, self.z1 - self.s0), self.z0  # owned planes only
         # slab entry point: voxel positions by the FULL volume's expression, so every plane is integrated
         # bit-identically to the same plane of a single-GPU volume
-        self.ops.SdfFuse(target, self.filtered, self.normals, scenes.se3_inverse(T_wc), self.K, self.trunc,
+        self.ops.SdfFuse(target, self.filtered, self.normals, scenes.se3_inverse(T_wc) if T_cw is None else T_cw, self.K, self.trunc,
                          self.max_w, self.mincostheta, full_extent=True, slab=(D, first, zmin, zmax))
         if target is not self.vol:
             self.exchange_halos()
@@ -229,14 +230,28 @@ class SlabPipeline(FramePipeline):
         hit wins (one MIN + one SUM all-reduce; rays re-enter each slab with a fresh step, so depths can differ
         from the single-volume march in the last bits).  raycast = "exact": the march state travels with the
         ray from slab to slab (raycast_exact), bit-identical to RaycastSdf on the whole volume."""
-        if self.raycast_mode == "exact":
-            self.raycast_exact(T_wc)
-            return
-        super().raycast(T_wc)
-        if self.world > 1:
-            self.composite()
+        self.raycast_into(self.ray_d, self.ray_n, self.ray_i, self.K, T_wc)
 
-    def raycast_exact(self, T_wc):
+    def raycast_into(self, d, n, i, K, T_wc):
+        """The model rendered from T_wc with intrinsics K into the images d / n / i (any size: pyramid levels),
+        identical on every rank afterwards."""
+        if self.raycast_mode == "exact":
+            self.raycast_exact(T_wc, d, n, i, K)
+            return
+        self.ops.RaycastSdf(d, n, i, self.vol, T_wc, K, self.near, self.far, self.trunc, True)
+        if self.world > 1:
+            self.composite(d, n, i)
+
+    def _scratch(self, name, shape, dtype, like):
+        """Per-shape device scratch tensors (march state, composite key / payload), allocated once."""
+        import torch
+        cache = self.__dict__.setdefault("_scratch_cache", {})
+        key = (name, tuple(shape))
+        if key not in cache:
+            cache[key] = torch.empty(shape, dtype=dtype, device=like.tensor().device)
+        return cache[key]
+
+    def raycast_exact(self, T_wc, d=None, n=None, i=None, K=None):
         """Rounds of kfx_raycast_sdf_slab.  In a round exactly one rank advances a given ray (the owner of the
         trilinear base plane of its current sample), so the merge is one integer SUM all-reduce of the touched
         pixels' march planes (lambda, last_sdf, delta, status, touched); untouched pixels are identical on all
@@ -244,15 +259,16 @@ class SlabPipeline(FramePipeline):
         (planes 5-8, written by one rank per pixel) are merged once at the end."""
         import torch
         dist, o = self.dist, self.ops
+        d, n, i = (self.ray_d, self.ray_n, self.ray_i) if d is None else (d, n, i)
+        K = self.K if K is None else K
+        w, h = d.w, d.h
         D = self.dims[2]
         slab = (D, self.s0, float(self.full_boxmin[2]), float(self.full_boxmax[2]))
-        if self._state is None:
-            self._state = torch.empty((9, self.h, self.w), dtype=torch.float32, device=self.ray_d.tensor().device)
-        st = self._state
+        st = self._scratch("state", (9, h, w), torch.float32, d)
         march = st[0:5].view(torch.int32)   # contiguous planes 0..4
         rounds = 0
         while True:
-            o.RaycastSdfSlab(st, rounds == 0, self.vol, slab, self.z0, self.z1, self.w, self.h, T_wc, self.K,
+            o.RaycastSdfSlab(st, rounds == 0, self.vol, slab, self.z0, self.z1, w, h, T_wc, K,
                              self.near, self.far, self.trunc, True)
             rounds += 1
             if self.world > 1:
@@ -268,9 +284,9 @@ class SlabPipeline(FramePipeline):
             out = st[5:9].view(torch.int32)
             dist.all_reduce(out, op=dist.ReduceOp.SUM)
         self.rounds = rounds
-        o.RaycastStateToImages(self.ray_d, self.ray_n, self.ray_i, st)
+        o.RaycastStateToImages(d, n, i, st)
 
-    def composite(self):
+    def composite(self, d=None, n=None, i=None):
         """Nearest hit over all slabs.  key = depth bits (positive floats order like ints) in the
         high word, rank in the low byte; misses use +inf.  One MIN all-reduce picks the winner,
         one SUM all-reduce broadcasts its normal / shade (the depth travels in the key).  With the HIP
@@ -278,31 +294,84 @@ class SlabPipeline(FramePipeline):
         oracle-backed CPU stand-in of the tests) use the equivalent tensor expressions below."""
         import torch
         dist = self.dist
+        d, n, i = (self.ray_d, self.ray_n, self.ray_i) if d is None else (d, n, i)
+        w, h = d.w, d.h
         if hasattr(self.ops, "CompositePack"):
-            dev = self.ray_d.storage.device
-            if getattr(self, "_key", None) is None:
-                self._key = torch.empty(self.w * self.h, dtype=torch.int64, device=dev)
-                self._payload = torch.empty(self.w * self.h * 5, dtype=torch.float32, device=dev)
-            self.ops.CompositePack(self.ray_d, self.ray_n, self.ray_i, self._key, self.rank)
-            dist.all_reduce(self._key, op=dist.ReduceOp.MIN)
-            self.ops.CompositeSelect(self.ray_d, self.ray_n, self.ray_i, self._key, self._payload, self.rank)
-            dist.all_reduce(self._payload, op=dist.ReduceOp.SUM)
-            self.ops.CompositeUnpack(self.ray_d, self.ray_n, self.ray_i, self._key, self._payload)
+            key = self._scratch("key", (w * h,), torch.int64, d)
+            payload = self._scratch("payload", (w * h * 5,), torch.float32, d)
+            self.ops.CompositePack(d, n, i, key, self.rank)
+            dist.all_reduce(key, op=dist.ReduceOp.MIN)
+            self.ops.CompositeSelect(d, n, i, key, payload, self.rank)
+            dist.all_reduce(payload, op=dist.ReduceOp.SUM)
+            self.ops.CompositeUnpack(d, n, i, key, payload)
             return
-        d = self.ray_d.tensor()
-        n = self.ray_n.tensor()
-        i = self.ray_i.tensor()
-        hit = torch.isfinite(d)
-        bits = torch.where(hit, d, torch.full_like(d, float("inf"))).contiguous().view(torch.int32).to(torch.int64)
+        dt, nt, it = d.tensor(), n.tensor(), i.tensor()
+        hit = torch.isfinite(dt)
+        bits = torch.where(hit, dt, torch.full_like(dt, float("inf"))).contiguous().view(torch.int32).to(torch.int64)
         key = (bits << 8) | self.rank
         dist.all_reduce(key, op=dist.ReduceOp.MIN)
         mine = hit & ((key & 0xFF) == self.rank) & ((key >> 8) == bits)
-        payload = torch.zeros((self.h, self.w, 5), dtype=torch.float32, device=d.device)
-        payload[..., 0:4] = torch.where(mine.unsqueeze(-1), n, torch.zeros_like(n))
-        payload[..., 4] = torch.where(mine, i, torch.zeros_like(i))
+        payload = torch.zeros((h, w, 5), dtype=torch.float32, device=dt.device)
+        payload[..., 0:4] = torch.where(mine.unsqueeze(-1), nt, torch.zeros_like(nt))
+        payload[..., 4] = torch.where(mine, it, torch.zeros_like(it))
         dist.all_reduce(payload, op=dist.ReduceOp.SUM)
         win_bits = (key >> 8).to(torch.int32)
         any_hit = win_bits < 0x7F800000
-        d.copy_(torch.where(any_hit, win_bits.view(torch.float32), torch.full_like(d, float("nan"))))
-        n.copy_(payload[..., 0:4])
-        i.copy_(payload[..., 4])
+        dt.copy_(torch.where(any_hit, win_bits.view(torch.float32), torch.full_like(dt, float("nan"))))
+        nt.copy_(payload[..., 0:4])
+        it.copy_(payload[..., 4])
+
+
+class TrackingSlabPipeline(SlabPipeline):
+    """Tracked KinectFusion on Z-slabs: the loop of TrackingPipeline with the model spread over the ranks.  The
+    raycast of every pyramid level is merged across ranks (raycast_into), after which all ranks hold the same model
+    images; the ICP normal equations are image-space work of < 0.1 ms and are evaluated redundantly on every rank
+    (deterministic: every rank derives the same pose without a broadcast); SdfFuse then integrates each rank's slab.
+    With raycast="exact" the poses and the fused slabs equal the single-GPU TrackingPipeline bit for bit."""
+
+    LEVELS = TrackingPipeline.LEVELS
+
+    def __init__(self, ops, dist, dims, boxmin, boxmax, w, h, its=None, icp_c=0.1, max_rmse=0.10, **kw):
+        from . import tracking
+        super().__init__(ops, dist, dims, boxmin, boxmax, w, h, **kw)
+        self.tracking = tracking
+        self.its = tuple(tracking.DEFAULT_ITS if its is None else its)
+        self.icp_c, self.max_rmse = float(icp_c), float(max_rmse)
+        L, P = self.LEVELS, ops.Pyramid
+        self.kin_d, self.kin_v, self.kin_n = P(w, h, L, "f32"), P(w, h, L, "f32x4"), P(w, h, L, "f32x4")
+        self.pyr_d, self.pyr_i = P(w, h, L, "f32"), P(w, h, L, "f32")
+        self.pyr_n, self.pyr_v = P(w, h, L, "f32x4"), P(w, h, L, "f32x4")
+        self.K_levels = [scenes.intrinsics_level(self.K, l) for l in range(L)]
+        self.debug = ops.Image(w, h, "f32x4")
+        self.scratch = ops.Image(w * 232, h, "u8")
+        self.T_wl = np.eye(4)
+        self.frame = 0
+        self.rmse, self.tracking_good = 0.0, True
+
+    preprocess = TrackingPipeline.preprocess
+
+    def step(self, T_wl_init=None, raw_image=None):
+        o, tr = self.ops, self.tracking
+        self.preprocess(raw_image)
+        if self.frame == 0:
+            if T_wl_init is not None:
+                self.T_wl = np.vstack([np.asarray(T_wl_init, np.float64).reshape(3, 4), [0, 0, 0, 1]])
+            self._fuse_at(self.T_wl)
+        else:
+            T34 = self.T_wl[:3].astype(np.float32)
+            for l in range(self.LEVELS):
+                if self.its[l] > 0:
+                    self.raycast_into(self.pyr_d[l], self.pyr_n[l], self.pyr_i[l], self.K_levels[l], T34)
+                    o.DepthToVbo(self.pyr_v[l], self.pyr_d[l], self.K_levels[l])
+            T_lp, self.rmse, self.tracking_good = tr.refine_pose(o, self.kin_v, self.pyr_v, self.pyr_n, self.K_levels,
+                                                                 self.scratch, self.debug, self.its, self.icp_c, self.max_rmse)
+            if self.tracking_good:
+                self.T_wl = self.T_wl @ tr.se3_inv(T_lp)
+                self._fuse_at(self.T_wl)
+        self.frame += 1
+        return self.T_wl
+
+    def _fuse_at(self, T_wl):
+        # SlabPipeline.fuse integrates self.filtered / self.normals at T_wc; point them at pyramid level 0
+        self.filtered, self.normals = self.kin_d[0], self.kin_n[0]
+        self.fuse(T_wl[:3].astype(np.float32), T_cw=self.tracking.se3_inv(T_wl)[:3].astype(np.float32))
