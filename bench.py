@@ -185,6 +185,11 @@ def main():
     roo.set_math_mode(other)
     n_other = min(args.steps, 20)
     ev2 = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_other)]
+    for s in range(3):   # untimed: the first launches after the mode switch run on cold instruction caches
+        i = (args.warmup + s) % N_ORBIT
+        pipe.preprocess(frames[i])
+        pipe.fuse(poses[i])
+        pipe.raycast(poses[i])
     sync_all()
     t_other = time.perf_counter()
     for s in range(n_other):
