@@ -95,6 +95,50 @@ __global__ __launch_bounds__(TX * TY) void k_bilateral(const BilParams p)
     }
 }
 
+// Fast-numerics variant (kfx_set_math_mode(KFX_MATH_FAST)) for a compile-time radius: the exact kernel spends most of
+// its time in the correctly rounded division -(id2) / (2 gr^2) of every tap (49 per pixel at R = 3) and in a
+// data-dependent branch per tap.  Here the exponent argument is id2 * (-1 / (2 gr^2)) (one reciprocal per thread:
+// the argument moves by <= 1.5 ulp, far inside the accuracy of the hardware exp), validity is a select and the
+// (2R+1)^2 taps are fully unrolled.  Same tile, same tap order, same hardware exp.
+template <typename Ti, int R>
+__global__ __launch_bounds__(256) void k_bilateral_fast(const BilParams p)
+{
+    constexpr int TX = 16, TY = 16, D = 2 * R + 1, TW = TX + 2 * R, TH = TY + 2 * R;
+    __shared__ float tile[TH * TW];
+    __shared__ float sw[D * D];
+    const int tid = threadIdx.x;
+    const int bx = blockIdx.x * TX, by = blockIdx.y * TY;
+    for (int i = tid; i < TW * TH; i += 256) {
+        const int ty = i / TW, tx = i - ty * TW;
+        tile[i] = load_clamped<Ti>(p, bx + tx - R, by + ty - R);
+    }
+    if (tid < D * D) {
+        const int r = tid / D - R, c = tid % D - R;
+        sw[tid] = __expf(-((float)(r * r + c * c)) / (2 * p.gs * p.gs));
+    }
+    __syncthreads();
+    const int lx = tid % TX, ly = tid / TX;
+    const int x = bx + lx, y = by + ly;
+    if (x >= p.w || y >= p.h) return;
+    const float k = -1.0f / (2 * p.gr * p.gr);
+    const float pc = tile[(ly + R) * TW + lx + R];
+    const bool check = p.use_minval != 0;
+    float sum = 0.f, sumw = 0.f;
+#pragma unroll
+    for (int r = 0; r < D; ++r)
+#pragma unroll
+        for (int c = 0; c < D; ++c) {
+            const float q = tile[(ly + r) * TW + lx + c];
+            const bool ok = !check || q >= p.minval;
+            const float id = pc - q;
+            const float w = sw[r * D + c] * __expf(id * id * k);
+            sumw += ok ? w : 0.f;
+            sum += ok ? w * q : 0.f;
+        }
+    if (check && !(pc >= p.minval)) sum = sumw = 0.f; // the reference skips the window: 0 / 0 = NaN
+    reinterpret_cast<float*>(p.out + (size_t)y * p.out_pitch)[x] = sum / sumw;
+}
+
 // Window too large for the LDS tile: straight global gathers.
 template <typename Ti>
 __global__ __launch_bounds__(256) void k_bilateral_global(const BilParams p)
@@ -349,7 +393,12 @@ static int bilateral_launch(const kfx_image* out, const kfx_image* in, float gs,
     p.minval = minval;
     p.use_minval = use_minval;
     hipStream_t s = (hipStream_t)stream;
-    if (p.R <= BIL_MAX_R) {
+    if (math_mode() == KFX_MATH_FAST && p.R >= 1 && p.R <= 3) {
+        dim3 grid(ceil_div(p.w, 16), ceil_div(p.h, 16));
+        if (p.R == 3) hipLaunchKernelGGL((k_bilateral_fast<Ti, 3>), grid, dim3(256), 0, s, p);
+        else if (p.R == 2) hipLaunchKernelGGL((k_bilateral_fast<Ti, 2>), grid, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((k_bilateral_fast<Ti, 1>), grid, dim3(256), 0, s, p);
+    } else if (p.R <= BIL_MAX_R) {
         const int D = 2 * p.R + 1;
         // tile shape (config C3 sweep, scripts/config_sweep.py): KFX_BILATERAL_TILE = 0..5
         static const int shape = [] { const char* e = getenv("KFX_BILATERAL_TILE"); return e ? atoi(e) : 2; }();

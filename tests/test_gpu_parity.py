@@ -1060,3 +1060,34 @@ def test_gpu_joint_bilateral_filter(roo, guide_kind, size):
     roo.BilateralFilterGuided(go, T.upload_image(roo, depth), T.upload_image(roo, guide), 1.5, 0.1, gc, size)
     got = go.MemcpyToHost()
     assert np.allclose(got, oo.data, rtol=BILATERAL_RTOL, atol=0) and np.isfinite(got).all()
+
+
+@pytest.mark.parametrize("kind,minval,size", [("f32", 0.2, 3), ("f32", None, 2), ("u16", 200, 3), ("u8", None, 1)])
+def test_gpu_bilateral_fast_mode(roo, kind, minval, size):
+    """BilateralFilter under KFX_MATH_FAST (reciprocal-multiply exponent argument, unrolled taps): same NaN pattern
+    as the exact kernel and values within 1e-5 relative of the oracle (the weights are hardware exp either way)."""
+    rng = np.random.default_rng(21)
+    w, h = 161, 77
+    if kind == "f32":
+        img = scenes.render_depth("room", w, h, None, scenes.intrinsics(w, h)).astype(np.float32)
+        img += rng.normal(0, 0.01, img.shape).astype(np.float32)
+        img[rng.random(img.shape) < 0.05] = np.nan
+        img[::9, ::4] = 0.1
+    elif kind == "u16":
+        img = rng.integers(0, 4000, (h, w)).astype(np.uint16)
+    else:
+        img = rng.integers(0, 256, (h, w)).astype(np.uint8)
+    oi, oo = oracle.Image(w, h, img.dtype), oracle.Image(w, h)
+    oi.data[...] = img
+    gr = 0.1 if kind == "f32" else 40.0
+    oracle.bilateral(oo, oi, 1.5, gr, size, minval)
+    go = roo.Image(w, h)
+    prev = roo.set_math_mode("fast")
+    try:
+        roo.BilateralFilter(go, T.upload_image(roo, img), 1.5, gr, size, minval)
+    finally:
+        roo.set_math_mode(prev)
+    got = go.MemcpyToHost()
+    assert np.array_equal(np.isnan(got), np.isnan(oo.data))
+    ok = ~np.isnan(got)
+    assert np.allclose(got[ok], oo.data[ok], rtol=1e-5, atol=0)
