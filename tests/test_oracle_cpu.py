@@ -300,3 +300,14 @@ def test_oracle_colour_vbo_vs_reference_headers():
     kt = np.ascontiguousarray(KT, np.float32).reshape(-1)
     R.ref_colour_vbo(want.ref(), vbo.ref(), rgb.ref(), kt.ctypes.data_as(C.POINTER(C.c_float)))
     assert np.array_equal(got.data, want.data) and (got.data[..., 3] == 255).mean() > 0.3 and (got.data[..., 3] == 0).any()
+
+
+def test_oracle_is_clean_under_asan_and_ubsan():
+    """Every oracle entry point on small ragged inputs under AddressSanitizer + UBSan (oracle/sanitize_check.c):
+    the checker itself must not read out of bounds (GPU sanitizers are unavailable on the target pool)."""
+    import subprocess
+    out = subprocess.run(["make", "-C", os.path.join(T.ROOT, "oracle"), "asan"], capture_output=True, text=True, timeout=600)
+    if "unrecognized" in out.stderr or "cannot find -lasan" in out.stderr or "libasan" in out.stderr and out.returncode != 0:
+        pytest.skip("this toolchain has no AddressSanitizer runtime")
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "sanitize_check:" in out.stdout
