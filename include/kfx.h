@@ -188,6 +188,12 @@ int kfx_memcpy_2d(void* dst, size_t dpitch, const void* src, size_t spitch, size
                   size_t rows, int kind, kfx_stream stream);
 int kfx_stream_synchronize(kfx_stream stream);
 
+/* DepthToVbo<float>(vbo, depth, K, scale) followed by NormalsFromVbo(nrm, vbo) in one launch (no reference counterpart:
+ * both are launch-latency sized at VGA).  The neighbour vertices a normal needs are recomputed from `depth` with
+ * DepthToVbo's expression, so vbo and nrm hold exactly what the two separate entry points write. */
+int kfx_depth_to_vbo_normals_f32(const kfx_image* vbo, const kfx_image* nrm, const kfx_image* depth, const float K[4], float scale,
+                                 kfx_stream stream);
+
 /* BilateralFilter(dOut, dIn, dImg, gs, gr, gc, size) (cu_bilateral.cu:110-155): joint bilateral filter of a float image
  * with a float / unsigned char guide image (third weight exp(-(guide difference)^2 / 2 gc^2)); sumw == 0 keeps the input. */
 int kfx_bilateral_guided_f32(const kfx_image* out, const kfx_image* in, const kfx_image* guide, float gs, float gr, float gc,

@@ -248,6 +248,41 @@ __global__ __launch_bounds__(256) void k_normals_from_vbo(const NrmParams p)
     reinterpret_cast<float4*>(p.out + (size_t)v * p.out_pitch)[u] = N;
 }
 
+// DepthToVbo<float> and NormalsFromVbo in one launch (both are latency-sized at VGA: two 4-5 us launches become one).
+// A pixel's normal needs the vertices at (u+1, v) and (u, v+1); they are recomputed from the depth image with the
+// expression DepthToVbo uses, so both outputs carry exactly the bits the two separate operators write.
+struct VboNrmParams {
+    const unsigned char* in;
+    size_t in_pitch;
+    unsigned char *vbo, *nrm;
+    size_t vpitch, npitch;
+    int w, h;
+    Intr K;
+    float scale;
+};
+__device__ __forceinline__ float4 vertex_of(const VboNrmParams& p, int u, int v)
+{
+    const float kz = p.scale * reinterpret_cast<const float*>(p.in + (size_t)v * p.in_pitch)[u];
+    return make_float4(kz * ((float)u - p.K.u0) / p.K.fu, kz * ((float)v - p.K.v0) / p.K.fv, kz, 1.0f);
+}
+__global__ __launch_bounds__(256) void k_vbo_normals_f32(const VboNrmParams p)
+{
+    const int u = blockIdx.x * 64 + (threadIdx.x & 63), v = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (u >= p.w || v >= p.h) return;
+    const float4 Vc = vertex_of(p, u, v);
+    reinterpret_cast<float4*>(p.vbo + (size_t)v * p.vpitch)[u] = Vc;
+    float4 N = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (u + 1 < p.w && v + 1 < p.h) {
+        const float4 Vr = vertex_of(p, u + 1, v), Vu = vertex_of(p, u, v + 1);
+        const V3 a = v3(Vr.x - Vc.x, Vr.y - Vc.y, Vr.z - Vc.z);
+        const V3 b = v3(Vu.x - Vc.x, Vu.y - Vc.y, Vu.z - Vc.z);
+        const V3 axb = v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+        const float mag = length(axb);
+        N = make_float4(-axb.x / mag, -axb.y / mag, -axb.z / mag, 1.0f);
+    }
+    reinterpret_cast<float4*>(p.nrm + (size_t)v * p.npitch)[u] = N;
+}
+
 struct EwParams {
     const unsigned char* in;
     size_t in_pitch;
@@ -587,4 +622,22 @@ extern "C" int kfx_bilateral_guided_u8(const kfx_image* out, const kfx_image* in
                                        unsigned size, kfx_stream stream)
 {
     return guided_launch<unsigned char>(out, in, guide, gs, gr, gc, size, stream);
+}
+
+// DepthToVbo<float>(vbo, depth, K, scale) followed by NormalsFromVbo(nrm, vbo), one launch, identical outputs
+// (no reference counterpart: a launch-count optimisation for the frame pre-amble; vbo, nrm and depth of one size)
+extern "C" int kfx_depth_to_vbo_normals_f32(const kfx_image* vbo, const kfx_image* nrm, const kfx_image* depth, const float K[4], float scale,
+                                            kfx_stream stream)
+{
+    if (int e = check_image(vbo, 16, "DepthToVbo+Normals: vbo image")) return e;
+    if (int e = check_image(nrm, 16, "DepthToVbo+Normals: normal image")) return e;
+    if (int e = check_image(depth, 4, "DepthToVbo+Normals: depth image")) return e;
+    if (!K) return set_error(KFX_E_NULL, "DepthToVbo+Normals: null intrinsics");
+    if (vbo->w == 0 || vbo->h == 0) return 0;
+    if (nrm->w != vbo->w || nrm->h != vbo->h || depth->w < vbo->w || depth->h < vbo->h)
+        return set_error(KFX_E_SHAPE, "DepthToVbo+Normals: image sizes");
+    VboNrmParams p{(const unsigned char*)depth->ptr, depth->pitch, (unsigned char*)vbo->ptr, (unsigned char*)nrm->ptr, vbo->pitch, nrm->pitch,
+                   (int)vbo->w, (int)vbo->h, Intr{K[0], K[1], K[2], K[3]}, scale};
+    hipLaunchKernelGGL(k_vbo_normals_f32, dim3(ceil_div(p.w, 64), ceil_div(p.h, 4)), dim3(256), 0, (hipStream_t)stream, p);
+    return check_launch("kfx_depth_to_vbo_normals_f32");
 }

@@ -24,6 +24,16 @@ import numpy as np
 from . import scenes
 
 
+def vbo_normals(ops, vbo, normals, depth, K):
+    """DepthToVbo + NormalsFromVbo (main.cpp:213-214); one launch where the operator set offers the fused entry point
+    (identical outputs), else the two operators."""
+    if hasattr(ops, "DepthToVboNormals"):
+        ops.DepthToVboNormals(vbo, normals, depth, K)
+    else:
+        ops.DepthToVbo(vbo, depth, K)
+        ops.NormalsFromVbo(normals, vbo)
+
+
 class FramePipeline:
     def __init__(self, ops, dims, boxmin, boxmax, w, h, K=None, near=0.4, far=8.0, bilateral=None,
                  trunc_factor=scenes.TRUNC_DIST_FACTOR, max_w=scenes.MAX_W, mincostheta=scenes.MIN_COS_THETA,
@@ -61,8 +71,7 @@ class FramePipeline:
         o = self.ops
         src = self.raw if raw_image is None else raw_image
         o.BilateralFilter(self.filtered, src, self.bil["gs"], self.bil["gr"], self.bil["size"], self.bil["minval"])
-        o.DepthToVbo(self.vbo, self.filtered, self.K)
-        o.NormalsFromVbo(self.normals, self.vbo)
+        vbo_normals(o, self.vbo, self.normals, self.filtered, self.K)
 
     def fuse(self, T_wc):
         self.ops.SdfFuse(self.vol, self.filtered, self.normals, scenes.se3_inverse(T_wc), self.K, self.trunc,
@@ -112,8 +121,7 @@ class TrackingPipeline(FramePipeline):
         o.BilateralFilter(self.kin_d[0], src, self.bil["gs"], self.bil["gr"], self.bil["size"], self.bil["minval"])
         o.BoxReduceIgnoreInvalid(self.kin_d)
         for l in range(self.LEVELS):
-            o.DepthToVbo(self.kin_v[l], self.kin_d[l], self.K_levels[l])
-            o.NormalsFromVbo(self.kin_n[l], self.kin_v[l])
+            vbo_normals(o, self.kin_v[l], self.kin_n[l], self.kin_d[l], self.K_levels[l])
 
     def step(self, T_wl_init=None, raw_image=None):
         """One frame.  The first frame is fused at T_wl_init (identity if None); later frames are tracked

@@ -490,3 +490,9 @@ def BilateralFilterGuided(dOut, dIn, dImg, gs, gr, gc, size, stream=None):
     L = _lib.load()
     fn = L.kfx_bilateral_guided_u8 if dImg.kind == "u8" else L.kfx_bilateral_guided_f32
     _lib.check(fn(dOut.ref(), dIn.ref(), dImg.ref(), gs, gr, gc, size, _stream(stream)))
+
+
+def DepthToVboNormals(vbo, nrm, depth, K, scale=1.0, stream=None):
+    """DepthToVbo<float> + NormalsFromVbo in one launch (kfx_depth_to_vbo_normals_f32): identical outputs."""
+    k, _k = _fp(K, 4)
+    _lib.check(_lib.load().kfx_depth_to_vbo_normals_f32(vbo.ref(), nrm.ref(), depth.ref(), k, scale, _stream(stream)))

@@ -1091,3 +1091,17 @@ def test_gpu_bilateral_fast_mode(roo, kind, minval, size):
     assert np.array_equal(np.isnan(got), np.isnan(oo.data))
     ok = ~np.isnan(got)
     assert np.allclose(got[ok], oo.data[ok], rtol=1e-5, atol=0)
+
+
+@pytest.mark.parametrize("w,h", [(160, 120), (67, 45), (1, 1), (64, 1)])
+def test_gpu_fused_vbo_normals_equals_the_two_operators(roo, w, h):
+    rng = np.random.default_rng(5)
+    K = scenes.intrinsics(max(w, 8), max(h, 8))
+    depth = (2.0 + rng.random((h, w))).astype(np.float32)
+    depth[rng.random((h, w)) < 0.1] = np.nan
+    gd = T.upload_image(roo, depth)
+    v1, n1, v2, n2 = roo.Image(w, h, "f32x4"), roo.Image(w, h, "f32x4"), roo.Image(w, h, "f32x4"), roo.Image(w, h, "f32x4")
+    roo.DepthToVbo(v1, gd, K)
+    roo.NormalsFromVbo(n1, v1)
+    roo.DepthToVboNormals(v2, n2, gd, K)
+    assert T.nan_equal(v2.MemcpyToHost(), v1.MemcpyToHost()) and T.nan_equal(n2.MemcpyToHost(), n1.MemcpyToHost())
