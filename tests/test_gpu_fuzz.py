@@ -182,3 +182,87 @@ def test_gpu_fuzz_fast_mode_tolerance(roo, seed):
     d = (a[..., 0][both] - b[..., 0][both]).abs()
     assert float((d > 1e-4).float().mean()) < 2e-3, (seed, float(d.max()), int((d > 1e-4).sum()), int(both.sum()))
     assert float(d.median()) < 1e-6
+
+
+@pytest.mark.parametrize("seed", list(range(300, 308)))
+def test_gpu_fuzz_half_cells_and_slabs(roo, seed):
+    """fp16 cells (oracle's F16C arithmetic) on random geometry, and random Z-slab decompositions of an fp32 volume:
+    slab fuse through kfx_sdf_fuse_slab and the exact slab march must equal the monolithic volume / raycast bit for bit."""
+    import torch
+    rng, dims, w, h, K, bmin, bmax, poses, pitch, full = random_case(seed)
+    dims = tuple(max(d, 16) for d in dims)
+    tr = None
+    frames = []
+    for T_wc in poses:
+        u, v = np.meshgrid(np.arange(w, dtype=np.float32), np.arange(h, dtype=np.float32))
+        depth = (2.6 + 0.002 * (u - w / 2) - 0.003 * (v - h / 2) + 0.3 * np.exp(-((u - w / 2) ** 2 + (v - h / 2) ** 2) / (0.05 * w * w))).astype(np.float32)
+        depth[rng.random(depth.shape) < 0.02] = np.nan
+        f, vbo, nrm = T.preprocess_oracle(depth, K)
+        frames.append((f, nrm, scenes.se3_inverse(T_wc)))
+    # ---- half cells ----
+    ovh = oracle.VolumeH(dims[0], dims[1], dims[2], bmin, bmax)
+    oracle.sdf_reset(ovh, float("nan"))
+    gvh = roo.BoundedVolume(dims[0], dims[1], dims[2], bmin, bmax, kind="f16")
+    roo.SdfReset(gvh, float("nan"))
+    tr = float(2.0 * np.linalg.norm(gvh.VoxelSizeUnits()))
+    for f, nrm, T_cw in frames:
+        oracle.sdf_fuse(ovh, f, nrm, T_cw, K, tr, 1000.0, 0.1, full_extent=full)
+        roo.SdfFuse(gvh, T.upload_image(roo, f.data), T.upload_image(roo, nrm.data), T_cw, K, tr, 1000.0, 0.1, full_extent=full)
+    got = gvh.MemcpyToHost()
+    assert np.array_equal(got.view(np.uint16), ovh.data.view(np.uint16)), seed
+    od, on, oi = oracle.Image(w, h), oracle.Image(w, h, channels=4), oracle.Image(w, h)
+    oracle.raycast_sdf(od, on, oi, ovh, poses[0], K, 0.3, 9.0, tr, True)
+    rd, rn, ri = roo.Image(w, h), roo.Image(w, h, "f32x4"), roo.Image(w, h)
+    roo.RaycastSdf(rd, rn, ri, gvh, poses[0], K, 0.3, 9.0, tr, True)
+    assert T.nan_equal(rd.MemcpyToHost(), od.data) and T.nan_equal(rn.MemcpyToHost(), on.data) and T.nan_equal(ri.MemcpyToHost(), oi.data)
+    # ---- random slabs of an fp32 volume ----
+    D = dims[2]
+    mono = roo.BoundedVolume(dims[0], dims[1], D, bmin, bmax)
+    roo.SdfReset(mono, float("nan"))
+    cuts = sorted(set([0, D] + [int(c) for c in rng.integers(3, D - 3, int(rng.integers(1, 4)))]))
+    spans = [(a, b) for a, b in zip(cuts[:-1], cuts[1:]) if b - a >= 1]
+    ghost = int(rng.integers(1, 4))
+    stored = [(max(a - ghost, 0), min(b + ghost, D)) for a, b in spans]
+    f32 = np.float32
+    size_z = f32(bmax[2]) - f32(bmin[2])
+    slabs = []
+    for s0, s1 in stored:
+        lo = (bmin[0], bmin[1], float(f32(bmin[2]) + size_z * f32(s0) / f32(D - 1)))
+        hi = (bmax[0], bmax[1], float(f32(bmin[2]) + size_z * f32(s1 - 1) / f32(D - 1)))
+        vsl = roo.BoundedVolume(dims[0], dims[1], s1 - s0, lo, hi)
+        roo.SdfReset(vsl, float("nan"))
+        slabs.append(vsl)
+    for f, nrm, T_cw in frames:
+        gf, gn = T.upload_image(roo, f.data), T.upload_image(roo, nrm.data)
+        roo.SdfFuse(mono, gf, gn, T_cw, K, tr, 1000.0, 0.1, full_extent=True)
+        for vsl, (s0, s1) in zip(slabs, stored):
+            roo.SdfFuse(vsl, gf, gn, T_cw, K, tr, 1000.0, 0.1, full_extent=True, slab=(D, s0, float(bmin[2]), float(bmax[2])))
+    mt = mono.tensor().view(torch.int32)
+    for vsl, (s0, s1) in zip(slabs, stored):
+        assert torch.equal(vsl.tensor().view(torch.int32), mt[s0:s1]), (seed, s0, s1)
+    roo.RaycastSdf(rd, rn, ri, mono, poses[0], K, 0.3, 9.0, tr, True)
+    want = (rd.MemcpyToHost(), rn.MemcpyToHost(), ri.MemcpyToHost())
+    states = [torch.empty((9, h, w), dtype=torch.float32, device="cuda") for _ in spans]
+    rounds = 0
+    while True:
+        for r, vsl in enumerate(slabs):
+            roo.RaycastSdfSlab(states[r], rounds == 0, vsl, (D, stored[r][0], float(bmin[2]), float(bmax[2])), spans[r][0], spans[r][1], w, h,
+                               poses[0], K, 0.3, 9.0, tr, True)
+        rounds += 1
+        march = [st[0:5].view(torch.int32) for st in states]
+        total = torch.zeros_like(march[0])
+        for m in march:
+            total += torch.where((m[4] != 0).unsqueeze(0), m, torch.zeros_like(m))
+        assert bool(((total[4] == 0) | (total[4] == 0x3F800000)).all())
+        for m in march:
+            m.copy_(torch.where((total[4] != 0).unsqueeze(0), total, m))
+        if not bool(((states[0][3] == 0) | (states[0][3] == 3)).any()):
+            break
+        assert rounds <= len(spans) + 3, (seed, rounds)
+    out = torch.zeros((4, h, w), dtype=torch.int32, device="cuda")
+    for st in states:
+        out += st[5:9].view(torch.int32)
+    states[0][5:9].view(torch.int32).copy_(out)
+    gd, gn2, gi = roo.Image(w, h), roo.Image(w, h, "f32x4"), roo.Image(w, h)
+    roo.RaycastStateToImages(gd, gn2, gi, states[0])
+    assert T.nan_equal(gd.MemcpyToHost(), want[0]) and T.nan_equal(gn2.MemcpyToHost(), want[1]) and T.nan_equal(gi.MemcpyToHost(), want[2]), seed
