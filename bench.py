@@ -205,6 +205,23 @@ def main():
     other_bytes = float(np.mean([16.0 * n_updated[(args.warmup + s) % N_ORBIT] + 20.0 * w * h for s in range(n_other)]))
     roo.set_math_mode(args.math)
 
+    # measured device-to-device copy ceiling of this GPU, same run: a 1 GiB copy moves 2 GiB
+    copy_GBps = None
+    try:
+        src = torch.empty(1 << 28, dtype=torch.float32, device="cuda")
+        dst = torch.empty_like(src)
+        dst.copy_(src)
+        c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        c0.record()
+        for _ in range(5):
+            dst.copy_(src)
+        c1.record()
+        torch.cuda.synchronize()
+        copy_GBps = 5 * 2.0 * src.numel() * 4 / (c0.elapsed_time(c1) * 1e-3) / 1e9
+        del src, dst
+    except RuntimeError:
+        pass
+
     traffic = None  # HBM bytes per launch from the committed PMC passes of this same command (profiles/)
     try:
         with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fh:
@@ -254,6 +271,8 @@ def main():
                 "avg_launch_ms": round(fuse_avg_ms, 5),
                 "updated_fraction": round(float(np.mean([n_updated[i] for i in idx])) / local_voxels, 4),
                 "full_sweep_GBps": round(16.0 * local_voxels / (fuse_avg_ms * 1e-3) / 1e9, 1),
+                "measured_copy_GBps": None if copy_GBps is None else round(copy_GBps, 1),
+                "frac_of_measured_copy": None if copy_GBps is None else round(achieved / copy_GBps, 4),
                 "note": "rank-0 slab" if distributed else "whole volume",
             },
             "kernels_ms": {"sdf_fuse": round(fuse_avg_ms, 5), "raycast_sdf%s" % ("+composite" if distributed else ""): round(float(np.mean(ray_ms)), 5),
