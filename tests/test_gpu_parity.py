@@ -929,6 +929,35 @@ def test_gpu_c5_2048_cubed_half_volume_raycast(roo):
     assert (cosang[inner] > 0.97).mean() > 0.99
     del vol
     torch.cuda.empty_cache()
+    # the same 32 GiB cell array under SdfFuse: one frame of the room integrated into 2048^3 half cells (8.6 G voxels,
+    # offsets beyond 2^32 in every index expression), then ray-cast back: the model reproduces the measured depth
+    bmin, bmax, near, far = scenes.SCENES["room"]
+    vol = roo.BoundedVolume(N, N, N, bmin, bmax, kind="f16")
+    roo.SdfReset(vol, float("nan"))
+    tr = scenes.trunc_dist(bmin, bmax, (N, N, N))
+    graw = T.upload_image(roo, scenes.render_depth("room", w, h, None, K))
+    f, vbo, nrm = roo.Image(w, h), roo.Image(w, h, "f32x4"), roo.Image(w, h, "f32x4")
+    roo.BilateralFilter(f, graw, **scenes.BILATERAL)
+    roo.DepthToVbo(vbo, f, K)
+    roo.NormalsFromVbo(nrm, vbo)
+    Tid = scenes.identity_pose()
+    prev = roo.set_math_mode("fast")
+    try:
+        roo.SdfFuse(vol, f, nrm, Tid, K, tr, scenes.MAX_W, scenes.MIN_COS_THETA)
+    finally:
+        roo.set_math_mode(prev)
+    zw = int((3.8 - bmin[2]) / (bmax[2] - bmin[2]) * (N - 1))     # slices around the back wall (z = 3.8 m): 29 GiB into the array
+    last = vol.tensor()[zw - 6: zw + 2]
+    assert bool((~torch.isnan(last[..., 0].float())).any())
+    assert bool(torch.isnan(vol.tensor()[N - 4:][..., 0].float()).all())      # behind the wall: never observed
+    roo.RaycastSdf(rd, rn, ri, vol, Tid, K, near, far, tr, True)
+    d2, filt = rd.MemcpyToHost(), f.MemcpyToHost()
+    err = np.abs(d2 - filt)
+    ok = np.isfinite(err)
+    assert ok.sum() > 0.5 * w * h
+    assert np.median(err[ok]) < 2.0 * (bmax[0] - bmin[0]) / (N - 1) + 1e-3   # a voxel or two + half precision of the cells
+    del vol, last
+    torch.cuda.empty_cache()
 
 
 # ---------------------------------------------------------------------------------
