@@ -305,6 +305,13 @@ int kfx_composite_unpack(const kfx_image* depth, const kfx_image* norm, const kf
 int kfx_raycast_sdf_slab(float* state, int init, const kfx_volume* vol, const kfx_slab* slab, int own_lo, int own_hi,
                          int w, int h, const float T_wc[12], const float K[4], float near, float far,
                          float trunc_dist, int subpix, kfx_stream stream);
+/* fp16-cell (roo::SDF_h) variants of the slab entry points: config C5 spread over several GPUs */
+int kfx_sdf_fuse_slab_h(const kfx_volume* vol, const kfx_slab* slab, const kfx_image* depth, const kfx_image* norm,
+                        const float T_cw[12], const float K[4], float trunc_dist, float max_w, float mincostheta,
+                        unsigned flags, kfx_stream stream);
+int kfx_raycast_sdf_slab_h(float* state, int init, const kfx_volume* vol, const kfx_slab* slab, int own_lo, int own_hi,
+                           int w, int h, const float T_wc[12], const float K[4], float near, float far,
+                           float trunc_dist, int subpix, kfx_stream stream);
 int kfx_raycast_state_to_images(const kfx_image* depth, const kfx_image* norm, const kfx_image* img, const float* state,
                                 kfx_stream stream);
 

@@ -46,6 +46,7 @@ PI, PV, PF = C.POINTER(KfxImage), C.POINTER(KfxVolume), C.POINTER(C.c_float)
 SIGNATURES = {
     "kfx_sdf_fuse": (C.c_int, [PV, PI, PI, PF, PF, C.c_float, C.c_float, C.c_float, C.c_uint, C.c_void_p]),
     "kfx_sdf_fuse_slab": (C.c_int, [PV, C.POINTER(KfxSlab), PI, PI, PF, PF, C.c_float, C.c_float, C.c_float, C.c_uint, C.c_void_p]),
+    "kfx_sdf_fuse_slab_h": (C.c_int, [PV, C.POINTER(KfxSlab), PI, PI, PF, PF, C.c_float, C.c_float, C.c_float, C.c_uint, C.c_void_p]),
     "kfx_sdf_fuse_count": (C.c_int, [PV, PI, PI, PF, PF, C.c_float, C.c_float, C.c_uint, C.c_void_p, C.c_void_p]),
     "kfx_sdf_fuse_h": (C.c_int, [PV, PI, PI, PF, PF, C.c_float, C.c_float, C.c_float, C.c_uint, C.c_void_p]),
     "kfx_raycast_sdf_h": (C.c_int, [PI, PI, PI, PV, PF, PF, C.c_float, C.c_float, C.c_float, C.c_int, C.c_void_p]),
@@ -63,6 +64,8 @@ SIGNATURES = {
     "kfx_sdf_reset": (C.c_int, [PV, C.c_float, C.c_void_p]),
     "kfx_sdf_sphere": (C.c_int, [PV, PF, C.c_float, C.c_void_p]),
     "kfx_raycast_sdf_slab": (C.c_int, [C.c_void_p, C.c_int, PV, C.POINTER(KfxSlab), C.c_int, C.c_int, C.c_int, C.c_int, PF, PF,
+                                       C.c_float, C.c_float, C.c_float, C.c_int, C.c_void_p]),
+    "kfx_raycast_sdf_slab_h": (C.c_int, [C.c_void_p, C.c_int, PV, C.POINTER(KfxSlab), C.c_int, C.c_int, C.c_int, C.c_int, PF, PF,
                                        C.c_float, C.c_float, C.c_float, C.c_int, C.c_void_p]),
     "kfx_raycast_state_to_images": (C.c_int, [PI, PI, PI, C.c_void_p, C.c_void_p]),
     "kfx_sdf_fuse_color": (C.c_int, [PV, PV, PI, PI, PF, PF, PI, PF, PF, C.c_float, C.c_float, C.c_float, C.c_uint, C.c_void_p]),

@@ -882,6 +882,14 @@ extern "C" int kfx_sdf_fuse_slab(const kfx_volume* vol, const kfx_slab* slab, co
     return fuse_launch<CellF32>(vol, depth, norm, T_cw, K, trunc_dist, max_w, mincostheta, flags, stream, slab);
 }
 
+extern "C" int kfx_sdf_fuse_slab_h(const kfx_volume* vol, const kfx_slab* slab, const kfx_image* depth, const kfx_image* norm,
+                                   const float T_cw[12], const float K[4], float trunc_dist, float max_w,
+                                   float mincostheta, unsigned flags, kfx_stream stream)
+{
+    if (!slab) return set_error(KFX_E_NULL, "kfx_sdf_fuse_slab_h: null slab");
+    return fuse_launch<CellF16>(vol, depth, norm, T_cw, K, trunc_dist, max_w, mincostheta, flags, stream, slab);
+}
+
 extern "C" int kfx_sdf_fuse_h(const kfx_volume* vol, const kfx_image* depth, const kfx_image* norm,
                               const float T_cw[12], const float K[4], float trunc_dist, float max_w,
                               float mincostheta, unsigned flags, kfx_stream stream)

@@ -320,7 +320,8 @@ extern "C" int kfx_raycast_sdf_color(const kfx_image* depth, const kfx_image* no
 // Exact multi-GPU march: one round of a rank (see k_raycast_sdf_slab).  `vol` holds planes
 // [slab->z_offset, slab->z_offset + vol->d) of the full volume described by `slab`; the rank owns the
 // trilinear base cells [own_lo, own_hi).  `state` is KFX_RAY_STATE_PLANES dense planes of h*w floats; init != 0 starts the rays.
-extern "C" int kfx_raycast_sdf_slab(float* state, int init, const kfx_volume* vol, const kfx_slab* slab, int own_lo, int own_hi,
+template <typename CELL>
+static int raycast_slab_launch(float* state, int init, const kfx_volume* vol, const kfx_slab* slab, int own_lo, int own_hi,
                                     int w, int h, const float T_wc[12], const float K[4], float near, float far,
                                     float trunc_dist, int subpix, kfx_stream stream)
 {
@@ -328,7 +329,7 @@ extern "C" int kfx_raycast_sdf_slab(float* state, int init, const kfx_volume* vo
     if (w <= 0 || h <= 0) return 0;
     if (slab->full_d < 3 || slab->z_offset + vol->d > slab->full_d || vol->w < 3 || vol->h < 3)
         return set_error(KFX_E_SHAPE, "RaycastSdf(slab): slab outside the full volume");
-    if ((((uintptr_t)vol->ptr | vol->pitch | vol->img_pitch) & 7) || ((uintptr_t)state & 3)) return set_error(KFX_E_ALIGN, "RaycastSdf(slab): alignment");
+    if ((((uintptr_t)vol->ptr | vol->pitch | vol->img_pitch) & (CELL::BYTES - 1)) || ((uintptr_t)state & 3)) return set_error(KFX_E_ALIGN, "RaycastSdf(slab): alignment");
     RayParams p;
     // full-volume geometry, virtual base pointer (never dereferenced outside [avail_lo, avail_hi))
     p.vol.ptr = (unsigned char*)vol->ptr - (ptrdiff_t)slab->z_offset * (ptrdiff_t)vol->img_pitch;
@@ -357,8 +358,22 @@ extern "C" int kfx_raycast_sdf_slab(float* state, int init, const kfx_volume* vo
     p.wg_log2x = 1;
     SlabRay sl{state, own_lo, own_hi, (int)slab->z_offset, (int)(slab->z_offset + vol->d), init ? 1 : 0};
     dim3 grid(ceil_div(w, 64), ceil_div(h, 4));
-    hipLaunchKernelGGL(k_raycast_sdf_slab<RayF32>, grid, dim3(256), 0, (hipStream_t)stream, p, sl);
+    hipLaunchKernelGGL(k_raycast_sdf_slab<CELL>, grid, dim3(256), 0, (hipStream_t)stream, p, sl);
     return check_launch("kfx_raycast_sdf_slab");
+}
+
+extern "C" int kfx_raycast_sdf_slab(float* state, int init, const kfx_volume* vol, const kfx_slab* slab, int own_lo, int own_hi,
+                                    int w, int h, const float T_wc[12], const float K[4], float near, float far,
+                                    float trunc_dist, int subpix, kfx_stream stream)
+{
+    return raycast_slab_launch<RayF32>(state, init, vol, slab, own_lo, own_hi, w, h, T_wc, K, near, far, trunc_dist, subpix, stream);
+}
+
+extern "C" int kfx_raycast_sdf_slab_h(float* state, int init, const kfx_volume* vol, const kfx_slab* slab, int own_lo, int own_hi,
+                                      int w, int h, const float T_wc[12], const float K[4], float near, float far,
+                                      float trunc_dist, int subpix, kfx_stream stream)
+{
+    return raycast_slab_launch<RayF16>(state, init, vol, slab, own_lo, own_hi, w, h, T_wc, K, near, far, trunc_dist, subpix, stream);
 }
 
 extern "C" int kfx_raycast_state_to_images(const kfx_image* depth, const kfx_image* norm, const kfx_image* img, const float* state,

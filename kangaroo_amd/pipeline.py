@@ -167,7 +167,7 @@ class SlabPipeline(FramePipeline):
 
     GHOST = 2  # >= 1 for the trilinear z+1 corner and the gradient's z-1 / z+1 cells (Volume.h:240-289)
 
-    def __init__(self, ops, dist, dims, boxmin, boxmax, w, h, halo="exchange", raycast="composite", **kw):
+    def __init__(self, ops, dist, dims, boxmin, boxmax, w, h, halo="exchange", raycast="composite", kind="f32", **kw):
         """halo = "exchange": every rank integrates only the planes it owns and the ghost planes are
         refreshed from the two neighbours after each SdfFuse (point-to-point send/recv: one xGMI link
         per direction); halo = "recompute": every rank integrates its ghost planes itself (the update is
@@ -176,6 +176,7 @@ class SlabPipeline(FramePipeline):
         assert raycast in ("composite", "exact")
         self.halo = halo
         self.raycast_mode = raycast
+        self.kind = kind            # "f32": SDF_t cells; "f16": SDF_h cells (config C5: 2048^3 over 8 GPUs = 4 GiB per rank)
         self.dist = dist
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
         self.full_boxmin = np.asarray(boxmin, np.float32)
@@ -195,6 +196,8 @@ class SlabPipeline(FramePipeline):
         zhi = f(boxmin[2]) + size_z * f(self.s1 - 1) / f(D - 1)
         lo = np.array([boxmin[0], boxmin[1], zlo], f)
         hi = np.array([boxmax[0], boxmax[1], zhi], f)
+        if self.kind != "f32":
+            return self.ops.BoundedVolume(W, H, self.s1 - self.s0, lo, hi, kind=self.kind)
         return self.ops.BoundedVolume(W, H, self.s1 - self.s0, lo, hi)
 
     def fuse(self, T_wc, T_cw=None):

@@ -247,9 +247,9 @@ def SdfFuse(vol, depth, norm, T_cw, K, trunc_dist, maxw, mincostheta, full_exten
     t, _t = _fp(T_cw, 12)
     k, _k = _fp(K, 4)
     if slab is not None:
-        assert vol.kind == "f32"
         sl = _lib.KfxSlab(int(slab[0]), int(slab[1]), float(slab[2]), float(slab[3]))
-        _lib.check(_lib.load().kfx_sdf_fuse_slab(vol.ref(), C.byref(sl), depth.ref(), norm.ref(), t, k, trunc_dist, maxw,
+        fn = _lib.load().kfx_sdf_fuse_slab_h if vol.kind == "f16" else _lib.load().kfx_sdf_fuse_slab
+        _lib.check(fn(vol.ref(), C.byref(sl), depth.ref(), norm.ref(), t, k, trunc_dist, maxw,
                                                  mincostheta, 1 if full_extent else 0, _stream(stream)))
         return
     fn = _lib.load().kfx_sdf_fuse_h if vol.kind == "f16" else _lib.load().kfx_sdf_fuse
@@ -373,7 +373,8 @@ def RaycastSdfSlab(state, init, vol, slab, own_lo, own_hi, w, h, T_wc, K, near, 
     t, _t = _fp(T_wc, 12)
     k, _k = _fp(K, 4)
     sl = _lib.KfxSlab(int(slab[0]), int(slab[1]), float(slab[2]), float(slab[3]))
-    _lib.check(_lib.load().kfx_raycast_sdf_slab(C.c_void_p(state.data_ptr()), 1 if init else 0, vol.ref(), C.byref(sl), own_lo, own_hi,
+    fn = _lib.load().kfx_raycast_sdf_slab_h if vol.kind == "f16" else _lib.load().kfx_raycast_sdf_slab
+    _lib.check(fn(C.c_void_p(state.data_ptr()), 1 if init else 0, vol.ref(), C.byref(sl), own_lo, own_hi,
                                                 w, h, t, k, near, far, trunc_dist, 1 if subpix else 0, _stream(stream)))
 
 

@@ -215,9 +215,10 @@ def test_gpu_fuzz_half_cells_and_slabs(roo, seed):
     rd, rn, ri = roo.Image(w, h), roo.Image(w, h, "f32x4"), roo.Image(w, h)
     roo.RaycastSdf(rd, rn, ri, gvh, poses[0], K, 0.3, 9.0, tr, True)
     assert T.nan_equal(rd.MemcpyToHost(), od.data) and T.nan_equal(rn.MemcpyToHost(), on.data) and T.nan_equal(ri.MemcpyToHost(), oi.data)
-    # ---- random slabs of an fp32 volume ----
+    # ---- random slabs of an fp32 volume (even seeds) or of a half-cell volume (odd seeds) ----
     D = dims[2]
-    mono = roo.BoundedVolume(dims[0], dims[1], D, bmin, bmax)
+    kind = "f16" if seed % 2 else "f32"
+    mono = roo.BoundedVolume(dims[0], dims[1], D, bmin, bmax, kind=kind)
     roo.SdfReset(mono, float("nan"))
     cuts = sorted(set([0, D] + [int(c) for c in rng.integers(3, D - 3, int(rng.integers(1, 4)))]))
     spans = [(a, b) for a, b in zip(cuts[:-1], cuts[1:]) if b - a >= 1]
@@ -229,7 +230,7 @@ def test_gpu_fuzz_half_cells_and_slabs(roo, seed):
     for s0, s1 in stored:
         lo = (bmin[0], bmin[1], float(f32(bmin[2]) + size_z * f32(s0) / f32(D - 1)))
         hi = (bmax[0], bmax[1], float(f32(bmin[2]) + size_z * f32(s1 - 1) / f32(D - 1)))
-        vsl = roo.BoundedVolume(dims[0], dims[1], s1 - s0, lo, hi)
+        vsl = roo.BoundedVolume(dims[0], dims[1], s1 - s0, lo, hi, kind=kind)
         roo.SdfReset(vsl, float("nan"))
         slabs.append(vsl)
     for f, nrm, T_cw in frames:
@@ -237,9 +238,10 @@ def test_gpu_fuzz_half_cells_and_slabs(roo, seed):
         roo.SdfFuse(mono, gf, gn, T_cw, K, tr, 1000.0, 0.1, full_extent=True)
         for vsl, (s0, s1) in zip(slabs, stored):
             roo.SdfFuse(vsl, gf, gn, T_cw, K, tr, 1000.0, 0.1, full_extent=True, slab=(D, s0, float(bmin[2]), float(bmax[2])))
-    mt = mono.tensor().view(torch.int32)
+    bits = torch.int16 if kind == "f16" else torch.int32
+    mt = mono.tensor().view(bits)
     for vsl, (s0, s1) in zip(slabs, stored):
-        assert torch.equal(vsl.tensor().view(torch.int32), mt[s0:s1]), (seed, s0, s1)
+        assert torch.equal(vsl.tensor().view(bits), mt[s0:s1]), (seed, s0, s1)
     roo.RaycastSdf(rd, rn, ri, mono, poses[0], K, 0.3, 9.0, tr, True)
     want = (rd.MemcpyToHost(), rn.MemcpyToHost(), ri.MemcpyToHost())
     states = [torch.empty((9, h, w), dtype=torch.float32, device="cuda") for _ in spans]
