@@ -199,8 +199,14 @@ extern "C" int kfx_icp_point_plane(const kfx_image* Pl, const kfx_image* Pr, con
     hipLaunchKernelGGL(k_lss_final, dim3(1), dim3(256), 0, (hipStream_t)stream, p.sums, (int)nblocks);
     int st = check_launch("kfx_icp_point_plane");
     if (st) return st;
-    hipError_t e = hipMemcpyAsync(out, p.sums, sizeof(*out), hipMemcpyDeviceToHost, (hipStream_t)stream);
+    // read-back through a pinned staging word per calling thread: a device -> pageable copy is staged by the runtime
+    // and costs a second synchronisation
+    thread_local kfx_lss6* stage = nullptr;
+    if (!stage && hipHostMalloc((void**)&stage, sizeof(kfx_lss6), hipHostMallocDefault) != hipSuccess) stage = nullptr;
+    kfx_lss6* dst = stage ? stage : out;
+    hipError_t e = hipMemcpyAsync(dst, p.sums, sizeof(*out), hipMemcpyDeviceToHost, (hipStream_t)stream);
     if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
     if (e != hipSuccess) return set_error((int)e, hipGetErrorString(e));
+    if (dst != out) memcpy(out, dst, sizeof(*out));
     return 0;
 }
