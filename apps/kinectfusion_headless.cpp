@@ -14,7 +14,7 @@
 //   SdfFuse(work_vol, kin_d, kin_n, T_wl^-1, K, trunc_dist, max_w, mincostheta)            (:345-356)
 //
 // Host code only; all device work happens in libkfx behind the roo:: wrappers.
-// Usage: kinectfusion_headless [--res N] [--frames F] [--width W] [--height H] [--fast] [--track]
+// Usage: kinectfusion_headless [--res N] [--frames F] [--width W] [--height H] [--fast] [--track | --device-icp]
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -68,7 +68,7 @@ static Mat<float,3,4> OrbitPose(int i, int n)
 int main(int argc, char** argv)
 {
     int volres = 256, frames = 30, w = 640, h = 480;   // the application's defaults (main.cpp:90-91)
-    bool fast = false, track = false;
+    bool fast = false, track = false, device_icp = false;
     for (int i = 1; i < argc; ++i) {
         if (!strcmp(argv[i], "--res") && i + 1 < argc) volres = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--frames") && i + 1 < argc) frames = atoi(argv[++i]);
@@ -76,6 +76,7 @@ int main(int argc, char** argv)
         else if (!strcmp(argv[i], "--height") && i + 1 < argc) h = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--fast")) fast = true;
         else if (!strcmp(argv[i], "--track")) track = true;
+        else if (!strcmp(argv[i], "--device-icp")) track = device_icp = true;   // the refinement loop as one device-side chain
     }
     if (kfx_device_count() < 1) { fprintf(stderr, "no HIP device\n"); return 2; }
     kfx_set_math_mode(fast ? KFX_MATH_FAST : KFX_MATH_EXACT);
@@ -148,7 +149,29 @@ int main(int argc, char** argv)
             bool tracking_good = true;
             if (track && f > 0) {   // main.cpp:299-341
                 posesolve::SE3d T_lp;
-                for (int l = MaxLevels - 1; l >= 0; --l) {
+                if (device_icp) {   // kfx_icp_refine: all iterations and 6x6 solves on the GPU, one synchronisation
+                    kfx_icp_level lv[MaxLevels];
+                    for (int s = 0; s < MaxLevels; ++s) {
+                        const int l = MaxLevels - 1 - s;
+                        const ImageIntrinsics Kl = K[l];
+                        lv[s].Pl = *kin_v[l].abi(); lv[s].Pr = *ray_v[l].abi(); lv[s].Nr = *ray_n[l].abi();
+                        lv[s].K[0] = Kl.fu; lv[s].K[1] = Kl.fv; lv[s].K[2] = Kl.u0; lv[s].K[3] = Kl.v0;
+                        lv[s].iterations = its[l];
+                        lv[s].rotation_only = (l == MaxLevels - 1 && MaxLevels > 1) ? 1 : 0;
+                    }
+                    double T34[12];
+                    float r = 0;
+                    unsigned nobs = 0;
+                    int good = 1;
+                    GpuCheckStatus(kfx_icp_refine(lv, MaxLevels, icp_c, max_rmse, dScratch.abi(), dDebug.abi(), T34, &r, &nobs, &good, 0));
+                    for (int i = 0; i < 3; ++i) {
+                        for (int j = 0; j < 3; ++j) T_lp.R[i][j] = T34[i * 4 + j];
+                        T_lp.t[i] = T34[i * 4 + 3];
+                    }
+                    rmse = r;
+                    tracking_good = good != 0;
+                }
+                for (int l = MaxLevels - 1; l >= 0 && !device_icp; --l) {
                     const ImageIntrinsics Kl = K[l];
                     for (int i = 0; i < its[l]; ++i) {
                         Mat<float,3,4> KT_lp, T_pl = T_lp.inverse().matrix3x4<Mat<float,3,4> >();
@@ -201,7 +224,7 @@ int main(int argc, char** argv)
         }
     }
     printf("kinectfusion_headless: %d^3 volume, %dx%d, %d frames, %s math, %s poses: %.3f ms/frame (%.1f fps), last raycast hits %zu/%d\n",
-           volres, w, h, frames, fast ? "fast" : "exact", track ? "ICP-tracked" : "known", total_ms / frames, 1e3 * frames / total_ms, hits, w * h);
+           volres, w, h, frames, fast ? "fast" : "exact", device_icp ? "ICP-tracked (device loop)" : (track ? "ICP-tracked" : "known"), total_ms / frames, 1e3 * frames / total_ms, hits, w * h);
     if (track) printf("  tracking: worst position error %.2f mm over the orbit (step between poses up to %.1f mm), final rmse %.4f, %d frames lost\n",
                       1e3 * worst_pos_err, 1e3 * 0.0105, rmse, lost);
     if (track && (lost > 0 || worst_pos_err > 0.02)) return 1;

@@ -281,6 +281,21 @@ int kfx_icp_point_plane(const kfx_image* Pl, const kfx_image* Pr, const kfx_imag
                         const float T_rl[12], float c, const kfx_image* workspace, const kfx_image* debug,
                         kfx_lss6* out, kfx_stream stream);
 
+/* The whole coarse-to-fine refinement loop of the reference application (main.cpp:301-337) on the device: per level
+ * (given COARSEST FIRST) and iteration the ICP system is summed, solved in float64 by one GPU thread (weak prior,
+ * complete-pivoting LU, SE(3) exponential -- the algorithms of kangaroo_amd/tracking.py) and K*T_lp / T_lp^-1 are
+ * left in device memory for the next evaluation; the host synchronises once at the end instead of once per
+ * iteration.  `workspace`: >= (largest level's blocks * 116, rounded up to 256) + 512 bytes, 8-byte aligned.
+ * Results: T_lp (row-major 3x4, float64), rmse / obs of the last evaluation, tracking_good = rmse < max_rmse. */
+typedef struct kfx_icp_level {
+    kfx_image Pl, Pr, Nr;  /* live vertex map, model vertex map, model normals of this level */
+    float K[4];            /* the level's intrinsics fu, fv, u0, v0 */
+    int iterations;
+    int rotation_only;     /* the application solves the coarsest level for rotation only */
+} kfx_icp_level;
+int kfx_icp_refine(const kfx_icp_level* levels, int n_levels, float c, float max_rmse, const kfx_image* workspace,
+                   const kfx_image* debug, double T_lp[12], float* rmse, unsigned* obs, int* tracking_good, kfx_stream stream);
+
 /* ---- multi-GPU raycast composite (no reference counterpart) ------------------------
  * Per-pixel glue around the two collectives of kangaroo_amd/pipeline.py::SlabPipeline.composite:
  *   pack:   key[v*w+u] = (bits(depth or +inf) << 8) | rank                    then all_reduce(MIN, key)

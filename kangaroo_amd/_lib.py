@@ -29,6 +29,11 @@ class KfxLss6(C.Structure):
     _fields_ = [("JTy", C.c_float * 6), ("JTJ", C.c_float * 21), ("sqErr", C.c_float), ("obs", C.c_uint)]
 
 
+class KfxIcpLevel(C.Structure):
+    """kfx_icp_level (include/kfx.h): one pyramid level of kfx_icp_refine."""
+    _fields_ = [("Pl", KfxImage), ("Pr", KfxImage), ("Nr", KfxImage), ("K", C.c_float * 4), ("iterations", C.c_int), ("rotation_only", C.c_int)]
+
+
 class KfxSlab(C.Structure):
     """kfx_slab (include/kfx.h): Z-slab of a larger volume."""
     _fields_ = [("full_d", C.c_size_t), ("z_offset", C.c_size_t), ("full_zmin", C.c_float), ("full_zmax", C.c_float)]
@@ -84,6 +89,8 @@ SIGNATURES = {
     "kfx_sdf_distance": (C.c_int, [PI, PI, PV, PF, PF, C.c_float, C.c_void_p]),
     "kfx_mc_count": (C.c_int, [PV, C.c_void_p, C.c_void_p]),
     "kfx_mc_emit": (C.c_int, [PV, PV, C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "kfx_icp_refine": (C.c_int, [C.POINTER(KfxIcpLevel), C.c_int, C.c_float, C.c_float, PI, PI, C.POINTER(C.c_double), PF,
+                                 C.POINTER(C.c_uint), C.POINTER(C.c_int), C.c_void_p]),
     "kfx_icp_point_plane": (C.c_int, [PI, PI, PI, PF, PF, C.c_float, PI, PI, C.POINTER(KfxLss6), C.c_void_p]),
     "kfx_composite_pack": (C.c_int, [PI, PI, PI, C.c_void_p, C.c_int, C.c_void_p]),
     "kfx_composite_select": (C.c_int, [PI, PI, PI, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),

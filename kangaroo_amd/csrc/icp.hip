@@ -69,6 +69,7 @@ struct IcpParams {
     unsigned char* dbg; // may be null
     size_t dbg_pitch;
     Pose KT_lr, T_rl;
+    const float* dev_pose; // device-resident loop: KT_lr[12] then T_rl[12] live here instead (may be null)
     float c;
     float* sums;        // gridDim.x * gridDim.y systems of 29 words
 };
@@ -84,9 +85,14 @@ __global__ __launch_bounds__(256) void k_icp_point_plane(const IcpParams p)
     Lss sum;
     lss_zero(sum);
 
+    Pose KT_lr = p.KT_lr, T_rl = p.T_rl;
+    if (p.dev_pose) { // uniform loads: the pose was written by k_icp_solve of the previous iteration
+#pragma unroll
+        for (int i = 0; i < 12; ++i) { KT_lr.m[i] = p.dev_pose[i]; T_rl.m[i] = p.dev_pose[12 + i]; }
+    }
     const float4 Pr = row<float4>(p.Pr, v)[u];
     const float4 Nr = row<float4>(p.Nr, v)[u];
-    const V3 KPl = se3_mul(p.KT_lr, v3(Pr.x, Pr.y, Pr.z));
+    const V3 KPl = se3_mul(KT_lr, v3(Pr.x, Pr.y, Pr.z));
     const float plx = KPl.x / KPl.z, ply = KPl.y / KPl.z;
     float4 dbg;
     // Image::InBounds(pl, 3): border <= x && x < (w - border) with w converted to float (Image.h:288-291)
@@ -95,7 +101,7 @@ __global__ __launch_bounds__(256) void k_icp_point_plane(const IcpParams p)
         const int nx = (int)((double)plx + 0.5), ny = (int)((double)ply + 0.5);
         const float4 Pl = row<float4>(p.Pl, ny)[nx];
         if (isfinite(Pl.z)) {
-            const V3 _Pr = se3_mul(p.T_rl, v3(Pl.x, Pl.y, Pl.z));
+            const V3 _Pr = se3_mul(T_rl, v3(Pl.x, Pl.y, Pl.z));
             const V3 Dr = v3(_Pr.x - Pr.x, _Pr.y - Pr.y, _Pr.z - Pr.z);
             const V3 N = v3(Nr.x, Nr.y, Nr.z);
             const float y = dot(Dr, N);
@@ -153,6 +159,161 @@ __global__ __launch_bounds__(256) void k_lss_final(float* sums, const int nblock
     if (tid == 0) lss_store(sums, acc);
 }
 
+// ---------------------------------------------------------------------------------------
+// Device-resident refinement loop.  The reference application reads every summed system back, solves it with
+// Eigen on the host and uploads the new transforms (main.cpp:301-337): six launch + synchronise + read-back round
+// trips per frame.  Here the 6x6 step runs on the GPU as well -- one thread, float64, the same algorithm as
+// kangaroo_amd/tracking.py / apps/pose_solve.h (weak prior, rotation-only solve on the coarsest level, LU with
+// complete pivoting and Eigen's rank threshold, closed-form SE(3) exponential) -- and leaves K*T_lp / T_lp^-1 in
+// device memory for the next k_icp_point_plane.  The host enqueues all iterations back to back and synchronises once.
+// State (doubles): T_lp row-major 3x4 [0..11], rmse [12], obs [13], tracking flag [14]; floats: KT_lr[12], T_rl[12].
+// ---------------------------------------------------------------------------------------
+struct RefineState {
+    double T[12];
+    double rmse, obs, good;
+    float pose[24];
+};
+
+template <int N>
+__device__ void lu_solve_full_piv(const double* A, const double* b, double* x)
+{
+    double lu[N][N];
+    int rows[N], cols[N];
+    for (int i = 0; i < N; ++i) {
+        rows[i] = cols[i] = i;
+        for (int j = 0; j < N; ++j) lu[i][j] = A[i * N + j];
+    }
+    int nonzero = N;
+    double maxpivot = 0.0;
+    for (int k = 0; k < N; ++k) {
+        int pr = k, pc = k;
+        double biggest = 0.0;
+        for (int i = k; i < N; ++i)
+            for (int j = k; j < N; ++j)
+                if (fabs(lu[i][j]) > biggest) { biggest = fabs(lu[i][j]); pr = i; pc = j; }
+        if (biggest == 0.0) { nonzero = k; break; }
+        if (biggest > maxpivot) maxpivot = biggest;
+        if (pr != k) {
+            for (int j = 0; j < N; ++j) { const double t = lu[k][j]; lu[k][j] = lu[pr][j]; lu[pr][j] = t; }
+            const int t = rows[k]; rows[k] = rows[pr]; rows[pr] = t;
+        }
+        if (pc != k) {
+            for (int i = 0; i < N; ++i) { const double t = lu[i][k]; lu[i][k] = lu[i][pc]; lu[i][pc] = t; }
+            const int t = cols[k]; cols[k] = cols[pc]; cols[pc] = t;
+        }
+        for (int i = k + 1; i < N; ++i) {
+            lu[i][k] /= lu[k][k];
+            for (int j = k + 1; j < N; ++j) lu[i][j] -= lu[i][k] * lu[k][j];
+        }
+    }
+    const double thresh = 2.220446049250313e-16 * N * maxpivot;
+    int rank = 0;
+    for (int i = 0; i < nonzero; ++i) rank += fabs(lu[i][i]) > thresh ? 1 : 0;
+    for (int i = 0; i < N; ++i) x[i] = 0.0;
+    if (rank == 0) return;
+    double c[N], y[N];
+    for (int i = 0; i < N; ++i) {
+        c[i] = b[rows[i]];
+        for (int j = 0; j < i; ++j) c[i] -= lu[i][j] * c[j];
+        y[i] = 0.0;
+    }
+    for (int i = rank - 1; i >= 0; --i) {
+        double sum = c[i];
+        for (int j = i + 1; j < rank; ++j) sum -= lu[i][j] * y[j];
+        y[i] = sum / lu[i][i];
+    }
+    for (int i = 0; i < N; ++i) x[cols[i]] = y[i];
+}
+
+// T <- T * exp(x); rotation_only uses exp(omega) with zero translation
+__device__ void se3_right_multiply_exp(double T[12], const double x[6], bool rotation_only)
+{
+    const double* w = x + 3;
+    const double t2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2], t = sqrt(t2);
+    const double W[3][3] = {{0, -w[2], w[1]}, {w[2], 0, -w[0]}, {-w[1], w[0], 0}};
+    double W2[3][3];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) W2[i][j] = W[i][0] * W[0][j] + W[i][1] * W[1][j] + W[i][2] * W[2][j];
+    const bool small = t < 1e-10;
+    const double a = small ? 1.0 : sin(t) / t, b = small ? 0.5 : (1.0 - cos(t)) / t2, c = small ? 1.0 / 6.0 : (t - sin(t)) / (t2 * t);
+    double E[12];
+    for (int i = 0; i < 3; ++i) {
+        double p = 0.0;
+        for (int j = 0; j < 3; ++j) {
+            E[i * 4 + j] = (i == j ? 1.0 : 0.0) + a * W[i][j] + b * W2[i][j];
+            p += ((i == j ? 1.0 : 0.0) + b * W[i][j] + c * W2[i][j]) * x[j];
+        }
+        E[i * 4 + 3] = rotation_only ? 0.0 : p;
+    }
+    double R[12];
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j) R[i * 4 + j] = T[i * 4 + 0] * E[0 * 4 + j] + T[i * 4 + 1] * E[1 * 4 + j] + T[i * 4 + 2] * E[2 * 4 + j];
+        R[i * 4 + 3] = T[i * 4 + 0] * E[3] + T[i * 4 + 1] * E[7] + T[i * 4 + 2] * E[11] + T[i * 4 + 3];
+    }
+    for (int i = 0; i < 12; ++i) T[i] = R[i];
+}
+
+// writes KT_lr = K * T (3x4) and T_rl = T^-1 as floats
+__device__ void publish_pose(RefineState* st, const float K[4])
+{
+    const double* T = st->T;
+    for (int c = 0; c < 4; ++c) {
+        st->pose[0 * 4 + c] = (float)((double)K[0] * T[0 * 4 + c] + (double)K[2] * T[2 * 4 + c]);
+        st->pose[1 * 4 + c] = (float)((double)K[1] * T[1 * 4 + c] + (double)K[3] * T[2 * 4 + c]);
+        st->pose[2 * 4 + c] = (float)T[2 * 4 + c];
+    }
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j) st->pose[12 + i * 4 + j] = (float)T[j * 4 + i];
+        st->pose[12 + i * 4 + 3] = (float)(-(T[0 * 4 + i] * T[3] + T[1 * 4 + i] * T[7] + T[2 * 4 + i] * T[11]));
+    }
+}
+
+struct K4 { float k[4]; };
+
+__global__ void k_icp_refine_init(RefineState* st, const K4 K)
+{
+    for (int i = 0; i < 12; ++i) st->T[i] = (i % 5 == 0) ? 1.0 : 0.0;
+    st->rmse = 0.0; st->obs = 0.0; st->good = 1.0;
+    publish_pose(st, K.k);
+}
+
+// one Gauss-Newton step from the summed system in sums[0..28] (main.cpp:312-333); K_next: intrinsics of the level the
+// NEXT evaluation runs on
+__global__ void k_icp_solve(RefineState* st, const float* __restrict__ sums, const int rotation_only, const float max_rmse, const K4 K_next)
+{
+    double JTJ[36], JTy[6], x[6] = {0, 0, 0, 0, 0, 0};
+    int i = 6;
+    for (int r = 0; r < 6; ++r)
+        for (int c = 0; c <= r; ++c) {
+            const double e = (double)sums[i++];
+            JTJ[r * 6 + c] = e;
+            JTJ[c * 6 + r] = e;
+        }
+    for (int r = 0; r < 6; ++r) { JTy[r] = (double)sums[r]; JTJ[r * 7] += 0.1 / 0.2; } // weak pose prior: depthSigma / motionSigma
+    const float sq = sums[27];
+    const unsigned obs = __float_as_uint(sums[28]);
+    const float rmse = sqrtf(sq / (float)obs);
+    st->rmse = (double)rmse;
+    st->obs = (double)obs;
+    st->good = rmse < max_rmse ? 1.0 : 0.0;
+    if (rotation_only) {
+        double A3[9], b3[3];
+        for (int a = 0; a < 3; ++a) {
+            b3[a] = JTy[3 + a];
+            for (int b = 0; b < 3; ++b) A3[a * 3 + b] = JTJ[(3 + a) * 6 + 3 + b];
+        }
+        lu_solve_full_piv<3>(A3, b3, x + 3);
+        for (int a = 3; a < 6; ++a) x[a] = -x[a];
+        se3_right_multiply_exp(st->T, x, true);
+    } else {
+        lu_solve_full_piv<6>(JTJ, JTy, x);
+        bool finite = true;
+        for (int a = 0; a < 6; ++a) { x[a] = -x[a]; finite = finite && isfinite(x[a]); }
+        if (finite) se3_right_multiply_exp(st->T, x, false);
+    }
+    publish_pose(st, K_next.k);
+}
+
 static unsigned gcd_u(unsigned a, unsigned b) { return b == 0 ? a : gcd_u(b, a % b); }
 
 } // namespace kfx
@@ -192,6 +353,7 @@ extern "C" int kfx_icp_point_plane(const kfx_image* Pl, const kfx_image* Pr, con
     p.dbg_pitch = p.dbg ? debug->pitch : 0;
     for (int i = 0; i < 12; ++i) { p.KT_lr.m[i] = KT_lr[i]; p.T_rl.m[i] = T_rl[i]; }
     p.c = c;
+    p.dev_pose = nullptr;
     p.sums = (float*)workspace->ptr;
     const int n = (int)(bx * by);
     const size_t lds_bytes = n >= 128 ? (size_t)LSS_WORDS * (n / 2) * sizeof(float) : 0;
@@ -208,5 +370,84 @@ extern "C" int kfx_icp_point_plane(const kfx_image* Pl, const kfx_image* Pr, con
     if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
     if (e != hipSuccess) return set_error((int)e, hipGetErrorString(e));
     if (dst != out) memcpy(out, dst, sizeof(*out));
+    return 0;
+}
+
+// The coarse-to-fine loop of main.cpp:301-337 enqueued as one chain of kernels: for every level (coarsest first) and
+// iteration, k_icp_point_plane -> k_lss_final -> k_icp_solve, all on `stream`, one synchronisation at the end.
+// levels[l]: the three vertex / normal maps, the level's intrinsics and its iteration count, given COARSEST FIRST;
+// the first level with more than one level in total is solved for rotation only, as the application does.
+// workspace: >= max over levels of (blocks * 116) + 512 bytes; result: T_lp (row-major 3x4, float64), rmse, obs,
+// tracking_good (rmse < max_rmse at the last evaluation).
+extern "C" int kfx_icp_refine(const kfx_icp_level* levels, int n_levels, float c, float max_rmse, const kfx_image* workspace,
+                              const kfx_image* debug, double T_lp[12], float* rmse, unsigned* obs, int* tracking_good, kfx_stream stream)
+{
+    if (!levels || n_levels <= 0 || !workspace || !workspace->ptr || !T_lp) return set_error(KFX_E_NULL, "kfx_icp_refine: null argument");
+    size_t max_blocks = 0;
+    for (int l = 0; l < n_levels; ++l) {
+        const kfx_icp_level& L = levels[l];
+        if (!L.Pl.ptr || !L.Pr.ptr || !L.Nr.ptr) return set_error(KFX_E_NULL, "kfx_icp_refine: null image");
+        if (L.Pr.w < L.Pl.w || L.Pr.h < L.Pl.h || L.Nr.w < L.Pl.w || L.Nr.h < L.Pl.h) return set_error(KFX_E_SHAPE, "kfx_icp_refine: dPr / dNr smaller than dPl");
+        if (((uintptr_t)L.Pl.ptr | L.Pl.pitch | (uintptr_t)L.Pr.ptr | L.Pr.pitch | (uintptr_t)L.Nr.ptr | L.Nr.pitch) & 15)
+            return set_error(KFX_E_ALIGN, "kfx_icp_refine: float4 images must be 16-byte aligned");
+        if (L.Pl.w == 0 || L.Pl.h == 0) continue;
+        const unsigned bx = gcd_u((unsigned)L.Pl.w, 16), by = gcd_u((unsigned)L.Pl.h, 16);
+        const size_t nb = (L.Pl.w / bx) * (L.Pl.h / by);
+        if (nb > max_blocks) max_blocks = nb;
+    }
+    const size_t state_off = (max_blocks * sizeof(kfx_lss6) + 255) / 256 * 256;
+    if (state_off + sizeof(RefineState) > workspace->pitch * workspace->h || ((uintptr_t)workspace->ptr & 7))
+        return set_error(KFX_E_SHAPE, "kfx_icp_refine: workspace too small or misaligned");
+    hipStream_t s = (hipStream_t)stream;
+    float* sums = (float*)workspace->ptr;
+    RefineState* st = (RefineState*)((unsigned char*)workspace->ptr + state_off);
+    // flatten the schedule so that every solve knows the intrinsics of the evaluation that follows it
+    int first = -1;
+    for (int l = 0; l < n_levels; ++l)
+        if (levels[l].iterations > 0 && levels[l].Pl.w && levels[l].Pl.h) { first = l; break; }
+    K4 k0;
+    for (int i = 0; i < 4; ++i) k0.k[i] = first >= 0 ? levels[first].K[i] : 0.f;
+    hipLaunchKernelGGL(k_icp_refine_init, dim3(1), dim3(1), 0, s, st, k0);
+    for (int l = 0; l < n_levels; ++l) {
+        const kfx_icp_level& L = levels[l];
+        if (L.iterations <= 0 || L.Pl.w == 0 || L.Pl.h == 0) continue;
+        const unsigned bx = gcd_u((unsigned)L.Pl.w, 16), by = gcd_u((unsigned)L.Pl.h, 16);
+        const dim3 block(bx, by), grid((unsigned)(L.Pl.w / bx), (unsigned)(L.Pl.h / by));
+        const int nblocks = (int)(grid.x * grid.y), n = (int)(bx * by);
+        const size_t lds_bytes = n >= 128 ? (size_t)LSS_WORDS * (n / 2) * sizeof(float) : 0;
+        IcpParams p;
+        p.Pl = ImgView{(const unsigned char*)L.Pl.ptr, L.Pl.pitch, (int)L.Pl.w, (int)L.Pl.h};
+        p.Pr = ImgView{(const unsigned char*)L.Pr.ptr, L.Pr.pitch, (int)L.Pr.w, (int)L.Pr.h};
+        p.Nr = ImgView{(const unsigned char*)L.Nr.ptr, L.Nr.pitch, (int)L.Nr.w, (int)L.Nr.h};
+        const bool dbg = debug && debug->ptr && debug->w >= L.Pl.w && debug->h >= L.Pl.h && !(((uintptr_t)debug->ptr | debug->pitch) & 15);
+        p.dbg = dbg ? (unsigned char*)debug->ptr : nullptr;
+        p.dbg_pitch = dbg ? debug->pitch : 0;
+        p.c = c;
+        p.dev_pose = st->pose;
+        p.sums = sums;
+        // next evaluation's intrinsics: this level while iterations remain, else the next level that has any
+        int nxt = -1;
+        for (int m = l + 1; m < n_levels; ++m)
+            if (levels[m].iterations > 0 && levels[m].Pl.w && levels[m].Pl.h) { nxt = m; break; }
+        for (int it = 0; it < L.iterations; ++it) {
+            hipLaunchKernelGGL(k_icp_point_plane, grid, block, lds_bytes, s, p);
+            hipLaunchKernelGGL(k_lss_final, dim3(1), dim3(256), 0, s, sums, nblocks);
+            K4 kn;
+            const float* Kn = (it + 1 < L.iterations || nxt < 0) ? L.K : levels[nxt].K;
+            for (int i = 0; i < 4; ++i) kn.k[i] = Kn[i];
+            hipLaunchKernelGGL(k_icp_solve, dim3(1), dim3(1), 0, s, st, (const float*)sums, L.rotation_only ? 1 : 0, max_rmse, kn);
+        }
+    }
+    int e0 = check_launch("kfx_icp_refine");
+    if (e0) return e0;
+    thread_local double* stage = nullptr;
+    if (!stage && hipHostMalloc((void**)&stage, 15 * sizeof(double), hipHostMallocDefault) != hipSuccess) return set_error(KFX_E_RANGE, "kfx_icp_refine: pinned staging");
+    hipError_t e = hipMemcpyAsync(stage, st, 15 * sizeof(double), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) return set_error((int)e, hipGetErrorString(e));
+    for (int i = 0; i < 12; ++i) T_lp[i] = stage[i];
+    if (rmse) *rmse = (float)stage[12];
+    if (obs) *obs = (unsigned)stage[13];
+    if (tracking_good) *tracking_good = stage[14] != 0.0 ? 1 : 0;
     return 0;
 }

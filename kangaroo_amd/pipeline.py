@@ -96,10 +96,13 @@ class TrackingPipeline(FramePipeline):
 
     LEVELS = 4
 
-    def __init__(self, ops, dims, boxmin, boxmax, w, h, its=None, icp_c=0.1, max_rmse=0.10, **kw):
+    def __init__(self, ops, dims, boxmin, boxmax, w, h, its=None, icp_c=0.1, max_rmse=0.10, device_icp=False, **kw):
+        """device_icp: run the whole refinement loop on the GPU (ops.IcpRefine, one synchronisation per frame) instead
+        of one PoseRefinementProjectiveIcpPointPlane call + host solve per iteration."""
         from . import tracking
         super().__init__(ops, dims, boxmin, boxmax, w, h, **kw)
         self.tracking = tracking
+        self.device_icp = bool(device_icp) and hasattr(ops, "IcpRefine")
         self.its = tuple(tracking.DEFAULT_ITS if its is None else its)
         self.icp_c, self.max_rmse = float(icp_c), float(max_rmse)
         L = self.LEVELS
@@ -139,8 +142,12 @@ class TrackingPipeline(FramePipeline):
                     o.RaycastSdf(self.pyr_d[l], self.pyr_n[l], self.pyr_i[l], self.vol, T34, self.K_levels[l], self.near,
                                  self.far, self.trunc, True)
                     o.DepthToVbo(self.pyr_v[l], self.pyr_d[l], self.K_levels[l])
-            T_lp, self.rmse, self.tracking_good = tr.refine_pose(o, self.kin_v, self.pyr_v, self.pyr_n, self.K_levels,
-                                                                 self.scratch, self.debug, self.its, self.icp_c, self.max_rmse)
+            if self.device_icp:
+                T_lp, self.rmse, _, self.tracking_good = o.IcpRefine(self.kin_v, self.pyr_v, self.pyr_n, self.K_levels, self.its,
+                                                                     self.icp_c, self.max_rmse, self.scratch, self.debug)
+            else:
+                T_lp, self.rmse, self.tracking_good = tr.refine_pose(o, self.kin_v, self.pyr_v, self.pyr_n, self.K_levels,
+                                                                     self.scratch, self.debug, self.its, self.icp_c, self.max_rmse)
             if self.tracking_good:
                 self.T_wl = self.T_wl @ tr.se3_inv(T_lp)
                 self._fuse_at(self.T_wl)

@@ -497,3 +497,25 @@ def DepthToVboNormals(vbo, nrm, depth, K, scale=1.0, stream=None):
     """DepthToVbo<float> + NormalsFromVbo in one launch (kfx_depth_to_vbo_normals_f32): identical outputs."""
     k, _k = _fp(K, 4)
     _lib.check(_lib.load().kfx_depth_to_vbo_normals_f32(vbo.ref(), nrm.ref(), depth.ref(), k, scale, _stream(stream)))
+
+
+def IcpRefine(kin_v, ray_v, ray_n, K_levels, its, icp_c, max_rmse, dWorkspace, dDebug=None, stream=None):
+    """kfx_icp_refine: the coarse-to-fine loop of main.cpp:301-337 enqueued as one kernel chain with the 6x6 solves on
+    the device.  Per-level lists are indexed by pyramid level (0 = full resolution), as in the application; levels are
+    processed from the coarsest down, the coarsest one rotation-only.  Returns (T_lp 4x4 float64, rmse, obs, good)."""
+    n = len(K_levels)
+    order = list(range(n - 1, -1, -1))
+    arr = (_lib.KfxIcpLevel * n)()
+    for slot, l in enumerate(order):
+        arr[slot].Pl, arr[slot].Pr, arr[slot].Nr = kin_v[l].view(), ray_v[l].view(), ray_n[l].view()
+        for i in range(4):
+            arr[slot].K[i] = float(K_levels[l][i])
+        arr[slot].iterations = int(its[l])
+        arr[slot].rotation_only = 1 if (l == n - 1 and n > 1) else 0
+    T = (C.c_double * 12)()
+    rmse, obs, good = C.c_float(), C.c_uint(), C.c_int()
+    _lib.check(_lib.load().kfx_icp_refine(arr, n, icp_c, max_rmse, dWorkspace.ref(), dDebug.ref() if dDebug is not None else None, T,
+                                          C.byref(rmse), C.byref(obs), C.byref(good), _stream(stream)))
+    T4 = np.eye(4)
+    T4[:3, :] = np.array(list(T), np.float64).reshape(3, 4)
+    return T4, float(rmse.value), int(obs.value), bool(good.value)

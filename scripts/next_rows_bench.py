@@ -46,6 +46,17 @@ for i in range(12):
     t_frames.append((time.perf_counter() - t0) * 1e3)
     worst = max(worst, float(np.linalg.norm(T_est[:3, 3] - scenes.orbit_pose(i, 30)[:3, 3])))
 out["tracked_frame_ms"] = round(float(np.median(t_frames[2:])), 4)
+# the same loop with the refinement iterations chained on the device (kfx_icp_refine)
+pipe2 = TrackingPipeline(roo, (N, N, N), bmin, bmax, w, h, near=near, far=far, device_icp=True)
+t2 = []
+for i in range(12):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    pipe2.step(T_wl_init=scenes.orbit_pose(0, 30) if i == 0 else None, raw_image=dev[i])
+    torch.cuda.synchronize()
+    t2.append((time.perf_counter() - t0) * 1e3)
+out["tracked_frame_device_icp_ms"] = round(float(np.median(t2[2:])), 4)
+del pipe2
 out["tracked_fps"] = round(1e3 / out["tracked_frame_ms"], 1)
 out["tracking_worst_position_error_mm"] = round(worst * 1e3, 3)
 # one ICP evaluation at full resolution (kernel + block sum + 116-byte blocking readback)

@@ -1134,3 +1134,37 @@ def test_gpu_fused_vbo_normals_equals_the_two_operators(roo, w, h):
     roo.NormalsFromVbo(n1, v1)
     roo.DepthToVboNormals(v2, n2, gd, K)
     assert T.nan_equal(v2.MemcpyToHost(), v1.MemcpyToHost()) and T.nan_equal(n2.MemcpyToHost(), n1.MemcpyToHost())
+
+
+def test_gpu_device_resident_icp_loop(roo):
+    """kfx_icp_refine (solves on the device, one synchronisation) against the host loop on the same maps: the same pose to
+    float64 round-off of sin / cos (the float32 transforms handed to the kernel may differ in a last bit, so the bar is
+    1e-6 on the transform), and the tracked pipeline follows the orbit equally well."""
+    import test_tracking_cpu as TT
+    from kangaroo_amd import tracking
+    from kangaroo_amd.pipeline import TrackingPipeline
+    w, h = 160, 120
+    K = scenes.intrinsics(w, h)
+    T_wp, T_wl = scenes.orbit_pose(0, 60), scenes.orbit_pose(1, 60)
+    _, ray_v, ray_n, Ks = TT.pyramid_maps("room", w, h, T_wp, K)
+    _, kin_v, _, _ = TT.pyramid_maps("room", w, h, T_wl, K)
+    up = lambda imgs: [T.upload_image(roo, im.data) for im in imgs]
+    g_kin, g_rv, g_rn = up(kin_v), up(ray_v), up(ray_n)
+    ws, dbg = roo.Image(w * 232, h, "u8"), roo.Image(w, h, "f32x4")
+    for its in (tracking.DEFAULT_ITS, (4, 3, 3, 3), (2, 0, 0, 0)):
+        want_T, want_rmse, want_good = tracking.refine_pose(roo, g_kin, g_rv, g_rn, Ks, ws, dbg, its=its)
+        got_T, got_rmse, got_obs, got_good = roo.IcpRefine(g_kin, g_rv, g_rn, Ks, its, 0.1, 0.10, ws, dbg)
+        assert np.abs(got_T - want_T).max() < 1e-6, (its, np.abs(got_T - want_T).max())
+        assert abs(got_rmse - want_rmse) < 1e-6 and got_good == want_good and got_obs > 0
+    N, frames = 64, 6
+    bmin, bmax, near, far = scenes.SCENES["room"]
+    pipe = TrackingPipeline(roo, (N, N, N), bmin, bmax, 320, 240, near=near, far=far, device_icp=True)
+    assert pipe.device_icp
+    worst = 0.0
+    for i in range(frames):
+        T_true = scenes.orbit_pose(i, 30)
+        pipe.raw.MemcpyFromHost(scenes.render_depth("room", 320, 240, T_true, pipe.K))
+        T_est = pipe.step(T_wl_init=T_true if i == 0 else None)
+        assert pipe.tracking_good
+        worst = max(worst, float(np.linalg.norm(T_est[:3, 3] - T_true[:3, 3])))
+    assert worst < 0.2 * float(np.linalg.norm(scenes.orbit_pose(frames - 1, 30)[:3, 3] - scenes.orbit_pose(0, 30)[:3, 3]))
