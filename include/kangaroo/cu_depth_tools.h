@@ -1,12 +1,13 @@
 // cu_depth_tools.h -- roo::DepthToVbo<T> with the reference's signatures
 // (include/kangaroo/cu_depth_tools.h:19-27), instantiated for float and unsigned short depth
 // (src/cu_depth_tools.cu:216-217), and the header's small per-pixel tools Disp2Depth, FilterBadKinectData and
-// ColourVbo.  Not provided: TextureDepth (keyframe texturing of the GUI's view mode, SURVEY: out of scope).
+// ColourVbo and TextureDepth (ImageKeyframe is declared here too).
 #pragma once
 
 #include <kangaroo/Image.h>
 #include <kangaroo/ImageIntrinsics.h>
 #include <kangaroo/Mat.h>
+#include <kangaroo/MatUtils.h>
 #include <kangaroo/launch_utils.h>
 #include <kangaroo/platform.h>
 
@@ -49,6 +50,44 @@ template<typename T>
 inline void DepthToVbo( Image<float4> dVbo, const Image<T> dKinectDepth, float fu, float fv, float u0, float v0, float scale = 1.0f)
 {
     DepthToVbo<T>(dVbo, dKinectDepth, ImageIntrinsics(fu,fv,u0,v0), scale);
+}
+
+// roo::ImageKeyframe<T> (reference ImageKeyframe.h:10-14 over ImageTransformProject, ImageIntrinsics.h:202-212): a camera
+// {K, T_iw} with its image; 96 bytes, layout-identical to kfx_keyframe.
+struct ImageTransformProject
+{
+    float2 Project(const float3 P_w) const
+    {
+        const float3 P_i = T_iw * P_w;
+        return make_float2(K.u0 + K.fu * P_i.x / P_i.z, K.v0 + K.fv * P_i.y / P_i.z);
+    }
+    ImageIntrinsics K;
+    Mat<float,3,4> T_iw;
+};
+template<typename T, typename Target = TargetDevice, typename Management = DontManage>
+struct ImageKeyframe : public ImageTransformProject
+{
+    Image<T, TargetDevice> img;
+};
+static_assert(sizeof(ImageKeyframe<uchar3>) == sizeof(kfx_keyframe), "ImageKeyframe<uchar3> must match kfx_keyframe");
+
+// reference cu_depth_tools.h:33-38 (kernels cu_depth_tools.cu:123-207), instantiated as the reference does: <float4,uchar3>
+template<typename Tout, typename Tin>
+KANGAROO_EXPORT
+void TextureDepth(Image<Tout> img, const ImageKeyframe<Tin> kf, const Image<float> depth, const Image<float4> norm, const Mat<float,3,4> T_wd, ImageIntrinsics Kdepth);
+
+template<> inline void TextureDepth(Image<float4> img, const ImageKeyframe<uchar3> kf, const Image<float> depth, const Image<float4> norm, const Mat<float,3,4> T_wd, ImageIntrinsics Kdepth)
+{
+    GpuNoteStatus(kfx_texture_depth(img.abi(), reinterpret_cast<const kfx_keyframe*>(&kf), 1, depth.abi(), norm.abi(), nullptr, T_wd.m, &Kdepth.fu, 0));
+}
+
+template<typename Tout, typename Tin, unsigned N>   // the reference spells N as size_t; Mat's row count is unsigned
+KANGAROO_EXPORT
+void TextureDepth(Image<Tout> img, const Mat<ImageKeyframe<Tin>,N> kfs, const Image<float> depth, const Image<float4> norm, const Image<float> phong, const Mat<float,3,4> T_wd, ImageIntrinsics Kdepth);
+
+template<> inline void TextureDepth(Image<float4> img, const Mat<ImageKeyframe<uchar3>,10> kfs, const Image<float> depth, const Image<float4> norm, const Image<float> phong, const Mat<float,3,4> T_wd, ImageIntrinsics Kdepth)
+{
+    GpuNoteStatus(kfx_texture_depth(img.abi(), reinterpret_cast<const kfx_keyframe*>(kfs.m), 10, depth.abi(), norm.abi(), phong.abi(), T_wd.m, &Kdepth.fu, 0));
 }
 
 // reference cu_depth_tools.h:30 (kernel cu_depth_tools.cu:86-119)

@@ -210,6 +210,22 @@ int kfx_filter_bad_kinect_f32(const kfx_image* out, const kfx_image* in, kfx_str
 int kfx_filter_bad_kinect_u16(const kfx_image* out, const kfx_image* in, kfx_stream stream);
 int kfx_colour_vbo(const kfx_image* id, const kfx_image* vbo, const kfx_image* rgb, const float KT_cd[12], kfx_stream stream);
 
+/* roo::ImageKeyframe<uchar3> (ImageKeyframe.h:10-14 over ImageIntrinsics.h:202-212): {ImageIntrinsics K; Mat<float,3,4> T_iw;
+ * Image<uchar3> img}, 96 bytes, same field order. */
+typedef struct kfx_keyframe {
+    float K[4];
+    float T_iw[12];
+    kfx_image img;
+} kfx_keyframe;
+/* TextureDepth (cu_depth_tools.cu:123-207): colour every pixel of a rendered depth / normal image from RGB keyframes.
+ * phong == NULL, n_kf == 1: TextureDepth<float4,uchar3>(img, kf, depth, norm, T_wd, Kdepth) -- the keyframe's colour where the
+ *   point projects inside it and faces it (camera-frame normal z < -0.2), else black.
+ * phong != NULL, n_kf <= 10: TextureDepth<float4,uchar3,10>(img, kfs, depth, norm, phong, T_wd, Kdepth) -- keyframes blended by
+ *   the cosine between normal and viewing ray (> 0.1, in front of the keyframe), the Phong image where none applies; a keyframe
+ *   with img.ptr == NULL ends the list.  (The reference accumulates into an uninitialised float3; it is zero here.) */
+int kfx_texture_depth(const kfx_image* img, const kfx_keyframe* kfs, int n_kf, const kfx_image* depth, const kfx_image* norm,
+                      const kfx_image* phong, const float T_wd[12], const float Kdepth[4], kfx_stream stream);
+
 /* ---- the rest of cu_raycast.h / cu_sdffusion.h ---------------------------------------------------------
  * kfx_raycast_box:    RaycastBox(imgd, T_wc, K, bbox) (cu_raycast.cu:202-240) -- entry depth into the box, NaN on a miss.
  * kfx_raycast_sphere: RaycastSphere(imgd, img, T_wc, K, center, r) (:246-279) -- a sphere hit nearer than the depth already

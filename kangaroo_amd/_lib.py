@@ -34,6 +34,11 @@ class KfxIcpLevel(C.Structure):
     _fields_ = [("Pl", KfxImage), ("Pr", KfxImage), ("Nr", KfxImage), ("K", C.c_float * 4), ("iterations", C.c_int), ("rotation_only", C.c_int)]
 
 
+class KfxKeyframe(C.Structure):
+    """kfx_keyframe (include/kfx.h) = roo::ImageKeyframe<uchar3>."""
+    _fields_ = [("K", C.c_float * 4), ("T_iw", C.c_float * 12), ("img", KfxImage)]
+
+
 class KfxSlab(C.Structure):
     """kfx_slab (include/kfx.h): Z-slab of a larger volume."""
     _fields_ = [("full_d", C.c_size_t), ("z_offset", C.c_size_t), ("full_zmin", C.c_float), ("full_zmax", C.c_float)]
@@ -79,6 +84,7 @@ SIGNATURES = {
     "kfx_depth_to_vbo_normals_f32": (C.c_int, [PI, PI, PI, PF, C.c_float, C.c_void_p]),
     "kfx_bilateral_guided_f32": (C.c_int, [PI, PI, PI, C.c_float, C.c_float, C.c_float, C.c_uint, C.c_void_p]),
     "kfx_bilateral_guided_u8": (C.c_int, [PI, PI, PI, C.c_float, C.c_float, C.c_float, C.c_uint, C.c_void_p]),
+    "kfx_texture_depth": (C.c_int, [PI, C.POINTER(KfxKeyframe), C.c_int, PI, PI, PI, PF, PF, C.c_void_p]),
     "kfx_disp2depth": (C.c_int, [PI, PI, C.c_float, C.c_float, C.c_float, C.c_void_p]),
     "kfx_filter_bad_kinect_f32": (C.c_int, [PI, PI, C.c_void_p]),
     "kfx_filter_bad_kinect_u16": (C.c_int, [PI, PI, C.c_void_p]),

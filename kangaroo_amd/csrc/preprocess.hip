@@ -389,6 +389,86 @@ __global__ __launch_bounds__(256) void k_colour_vbo(const ColourVboParams p)
     *(reinterpret_cast<uchar4*>(p.out + (size_t)v * p.opitch) + u) = id;
 }
 
+// ---- TextureDepth (cu_depth_tools.cu:123-207): colour a rendered depth image from RGB keyframes ------------------
+struct KeyframeView {          // ImageKeyframe<uchar3>: {ImageIntrinsics K; Mat<float,3,4> T_iw; Image<uchar3> img}
+    Intr K;
+    Pose T_iw;
+    const unsigned char* img;  // null: slot unused (ends the list, as `kfs[k].img.ptr` does in the reference)
+    size_t pitch;
+    int w, h;
+};
+constexpr int TEX_MAX_KF = 10;
+struct TextureParams {
+    unsigned char* out;        // Image<float4>
+    size_t opitch;
+    const unsigned char *depth, *norm, *phong;   // Image<float>, Image<float4>, Image<float> (phong: multi-keyframe variant)
+    size_t dpitch, npitch, ppitch;
+    int w, h, nkf, single;
+    Pose T_wd;
+    Intr Kd;
+    KeyframeView kf[TEX_MAX_KF];
+};
+// Image<uchar3>::GetBilinear<float3> (see k_colour_vbo)
+__device__ __forceinline__ V3 rgb_bilinear(const KeyframeView& k, float pu, float pv)
+{
+    const float ix = floorf(pu), iy = floorf(pv);
+    const float fx = pu - ix, fy = pv - iy;
+    const Rgb3* bl = reinterpret_cast<const Rgb3*>(k.img + (size_t)iy * k.pitch) + (size_t)ix;
+    const Rgb3* tl = reinterpret_cast<const Rgb3*>(k.img + (size_t)(iy + 1) * k.pitch) + (size_t)ix;
+    const Rgb3 b0 = bl[0], b1 = bl[1], t0 = tl[0], t1 = tl[1];
+    const V3 lo = v3((float)b0.x + fx * (float)((int)b1.x - (int)b0.x), (float)b0.y + fx * (float)((int)b1.y - (int)b0.y),
+                     (float)b0.z + fx * (float)((int)b1.z - (int)b0.z));
+    const V3 hi = v3((float)t0.x + fx * (float)((int)t1.x - (int)t0.x), (float)t0.y + fx * (float)((int)t1.y - (int)t0.y),
+                     (float)t0.z + fx * (float)((int)t1.z - (int)t0.z));
+    return v3(lo.x + fy * (hi.x - lo.x), lo.y + fy * (hi.y - lo.y), lo.z + fy * (hi.z - lo.z));
+}
+__global__ __launch_bounds__(256) void k_texture_depth(const TextureParams p)
+{
+    const int u = blockIdx.x * 64 + (threadIdx.x & 63), v = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (u >= p.w || v >= p.h) return;
+    const float d = reinterpret_cast<const float*>(p.depth + (size_t)v * p.dpitch)[u];
+    const float4 N_d = reinterpret_cast<const float4*>(p.norm + (size_t)v * p.npitch)[u];
+    const V3 N_w = so3_mul(p.T_wd, v3(N_d.x, N_d.y, N_d.z));
+    const V3 P_d = v3(d * ((float)u - p.Kd.u0) / p.Kd.fu, d * ((float)v - p.Kd.v0) / p.Kd.fv, d);   // Unproject(u, v, z)
+    const V3 P_w = se3_mul(p.T_wd, P_d);
+    float4 out;
+    if (p.single) { // one keyframe: nearest-facing test on the camera-frame normal's z (cu_depth_tools.cu:123-149)
+        const KeyframeView& k = p.kf[0];
+        const V3 P_kf = se3_mul(k.T_iw, P_w);
+        const float pu = k.K.u0 + k.K.fu * P_kf.x / P_kf.z, pv = k.K.v0 + k.K.fv * P_kf.y / P_kf.z;
+        const V3 N_c = so3_mul(k.T_iw, N_w);
+        const float facing = N_c.x * 0.f + N_c.y * 0.f + N_c.z * 1.f;
+        if (2.0f <= pu && pu < ((float)k.w - 2.0f) && 2.0f <= pv && pv < ((float)k.h - 2.0f) && (double)facing < -0.2) { // the literal is a double
+            const V3 c = rgb_bilinear(k, pu, pv) * (1.0f / 255.0f);
+            out = make_float4(c.x, c.y, c.z, 1.f);
+        } else {
+            out = make_float4(0.f, 0.f, 0.f, 1.f);
+        }
+    } else {        // up to 10 keyframes blended by the cosine to the viewing ray (:164-197)
+        float w = 0.f;
+        V3 color = v3(0.f, 0.f, 0.f);   // the reference leaves `color` uninitialised before accumulating; zero here
+        for (int i = 0; i < p.nkf && p.kf[i].img; ++i) {
+            const KeyframeView& k = p.kf[i];
+            const V3 P_kf = se3_mul(k.T_iw, P_w);
+            const float pu = k.K.u0 + k.K.fu * P_kf.x / P_kf.z, pv = k.K.v0 + k.K.fv * P_kf.y / P_kf.z;
+            const V3 N_c = so3_mul(k.T_iw, N_w);
+            const float ndot = dot(N_c, P_kf) / -length(P_kf);
+            if (2.0f <= pu && pu < ((float)k.w - 2.0f) && 2.0f <= pv && pv < ((float)k.h - 2.0f) && (double)ndot > 0.1 && P_kf.z > 0.f) {
+                color = color + rgb_bilinear(k, pu, pv) * (ndot / 255.0f);
+                w += ndot;
+            }
+        }
+        if (w == 0.f) {
+            w = 1.f;
+            const float ph = reinterpret_cast<const float*>(p.phong + (size_t)v * p.ppitch)[u];
+            color = v3(ph, ph, ph);
+        }
+        const V3 c = div_s(color, w);
+        out = make_float4(c.x, c.y, c.z, 1.f);
+    }
+    reinterpret_cast<float4*>(p.out + (size_t)v * p.opitch)[u] = out;
+}
+
 } // namespace kfx
 
 using namespace kfx;
@@ -640,4 +720,44 @@ extern "C" int kfx_depth_to_vbo_normals_f32(const kfx_image* vbo, const kfx_imag
                    (int)vbo->w, (int)vbo->h, Intr{K[0], K[1], K[2], K[3]}, scale};
     hipLaunchKernelGGL(k_vbo_normals_f32, dim3(ceil_div(p.w, 64), ceil_div(p.h, 4)), dim3(256), 0, (hipStream_t)stream, p);
     return check_launch("kfx_depth_to_vbo_normals_f32");
+}
+
+// TextureDepth<float4,uchar3>(img, kf, depth, norm, T_wd, Kdepth) (single keyframe: n_kf = 1, phong = NULL) and
+// TextureDepth<float4,uchar3,10>(img, kfs, depth, norm, phong, T_wd, Kdepth) (cu_depth_tools.cu:123-207)
+extern "C" int kfx_texture_depth(const kfx_image* img, const kfx_keyframe* kfs, int n_kf, const kfx_image* depth, const kfx_image* norm,
+                                 const kfx_image* phong, const float T_wd[12], const float Kdepth[4], kfx_stream stream)
+{
+    if (int e = check_image(img, 16, "TextureDepth: output image")) return e;
+    if (int e = check_image(depth, 4, "TextureDepth: depth image")) return e;
+    if (int e = check_image(norm, 16, "TextureDepth: normal image")) return e;
+    if (!kfs || n_kf < 1 || n_kf > TEX_MAX_KF || !T_wd || !Kdepth) return set_error(KFX_E_NULL, "TextureDepth: keyframes / transforms");
+    const bool single = phong == nullptr;
+    if (!single) { if (int e = check_image(phong, 4, "TextureDepth: phong image")) return e; }
+    if (single && n_kf != 1) return set_error(KFX_E_RANGE, "TextureDepth: the single-keyframe form takes exactly one keyframe");
+    if (img->w == 0 || img->h == 0) return 0;
+    if (depth->w < img->w || depth->h < img->h || norm->w < img->w || norm->h < img->h || (!single && (phong->w < img->w || phong->h < img->h)))
+        return set_error(KFX_E_SHAPE, "TextureDepth: inputs smaller than the output");
+    TextureParams p;
+    p.out = (unsigned char*)img->ptr; p.opitch = img->pitch;
+    p.depth = (const unsigned char*)depth->ptr; p.dpitch = depth->pitch;
+    p.norm = (const unsigned char*)norm->ptr; p.npitch = norm->pitch;
+    p.phong = single ? nullptr : (const unsigned char*)phong->ptr; p.ppitch = single ? 0 : phong->pitch;
+    p.w = (int)img->w; p.h = (int)img->h; p.nkf = n_kf; p.single = single ? 1 : 0;
+    for (int i = 0; i < 12; ++i) p.T_wd.m[i] = T_wd[i];
+    p.Kd = Intr{Kdepth[0], Kdepth[1], Kdepth[2], Kdepth[3]};
+    for (int k = 0; k < TEX_MAX_KF; ++k) {
+        KeyframeView& kv = p.kf[k];
+        kv.img = nullptr; kv.pitch = 0; kv.w = kv.h = 0;
+        kv.K = Intr{1.f, 1.f, 0.f, 0.f};
+        for (int i = 0; i < 12; ++i) kv.T_iw.m[i] = 0.f;
+        if (k < n_kf && kfs[k].img.ptr) {
+            if (kfs[k].img.pitch < kfs[k].img.w * 3) return set_error(KFX_E_SHAPE, "TextureDepth: keyframe image pitch");
+            kv.img = (const unsigned char*)kfs[k].img.ptr; kv.pitch = kfs[k].img.pitch; kv.w = (int)kfs[k].img.w; kv.h = (int)kfs[k].img.h;
+            kv.K = Intr{kfs[k].K[0], kfs[k].K[1], kfs[k].K[2], kfs[k].K[3]};
+            for (int i = 0; i < 12; ++i) kv.T_iw.m[i] = kfs[k].T_iw[i];
+        }
+    }
+    if (single && !p.kf[0].img) return set_error(KFX_E_NULL, "TextureDepth: keyframe image is null");
+    hipLaunchKernelGGL(k_texture_depth, dim3(ceil_div(p.w, 64), ceil_div(p.h, 4)), dim3(256), 0, (hipStream_t)stream, p);
+    return check_launch("kfx_texture_depth");
 }

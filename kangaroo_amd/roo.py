@@ -519,3 +519,20 @@ def IcpRefine(kin_v, ray_v, ray_n, K_levels, its, icp_c, max_rmse, dWorkspace, d
     T4 = np.eye(4)
     T4[:3, :] = np.array(list(T), np.float64).reshape(3, 4)
     return T4, float(rmse.value), int(obs.value), bool(good.value)
+
+
+def TextureDepth(img, keyframes, depth, norm, T_wd, Kdepth, phong=None, stream=None):
+    """TextureDepth (cu_depth_tools.h:33-38).  keyframes: list of (Image("u8x3") or None, T_iw 3x4, K) -- one entry and
+    phong=None for the single-keyframe form, up to 10 entries and a Phong image for the blended form."""
+    n = len(keyframes)
+    arr = (_lib.KfxKeyframe * max(n, 1))()
+    for i, (kimg, T_iw, K) in enumerate(keyframes):
+        for j, v in enumerate(np.asarray(K, np.float32).reshape(-1)):
+            arr[i].K[j] = float(v)
+        for j, v in enumerate(np.asarray(T_iw, np.float32).reshape(-1)):
+            arr[i].T_iw[j] = float(v)
+        arr[i].img = kimg.view() if kimg is not None else _lib.KfxImage(0, None, 0, 0)
+    t, _t = _fp(T_wd, 12)
+    k, _k = _fp(Kdepth, 4)
+    _lib.check(_lib.load().kfx_texture_depth(img.ref(), arr, n, depth.ref(), norm.ref(), phong.ref() if phong is not None else None, t, k,
+                                             _stream(stream)))

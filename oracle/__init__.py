@@ -33,6 +33,10 @@ class KfoLss6(C.Structure):
     _fields_ = [("JTy", C.c_float * 6), ("JTJ", C.c_float * 21), ("sqErr", C.c_float), ("obs", C.c_uint)]
 
 
+class KfoKeyframe(C.Structure):
+    _fields_ = [("K", C.c_float * 4), ("T_iw", C.c_float * 12), ("img", KfoImage)]
+
+
 class KfoRaycastStats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("steps", C.c_uint64), ("hits", C.c_uint64)]
 
@@ -82,6 +86,8 @@ def lib():
         L.kfo_sdf_fuse_color.restype = C.c_uint64
         L.kfo_raycast_sdf_color.argtypes = [PI, PI, PI, PV, PV, PF, PF, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int]
         L.kfo_raycast_sdf_color.restype = None
+        L.kfo_texture_depth.argtypes = [PI, C.POINTER(KfoKeyframe), C.c_int, PI, PI, PI, PF, PF]
+        L.kfo_texture_depth.restype = None
         L.kfo_bilateral_guided.argtypes = [PI, PI, PI, C.c_int, C.c_float, C.c_float, C.c_float, C.c_int]
         L.kfo_bilateral_guided.restype = None
         L.kfo_disp2depth.argtypes = [PI, PI, C.c_float, C.c_float, C.c_float]
@@ -512,3 +518,19 @@ def colour_vbo(idimg, vbo, rgb, KT_cd):
 
 def bilateral_guided(out, inp, guide, gs, gr, gc, size):
     lib().kfo_bilateral_guided(out.ref(), inp.ref(), guide.ref(), 1 if guide.dtype == np.uint8 else 0, gs, gr, gc, size)
+
+
+def texture_depth(out, keyframes, depth, norm, T_wd, Kdepth, phong=None, fn=None):
+    """keyframes: list of (Image uint8 x3 or None, T_iw, K)."""
+    n = len(keyframes)
+    arr = (KfoKeyframe * max(n, 1))()
+    for i, (kimg, T_iw, K) in enumerate(keyframes):
+        for j, v in enumerate(np.asarray(K, np.float32).reshape(-1)):
+            arr[i].K[j] = float(v)
+        for j, v in enumerate(np.asarray(T_iw, np.float32).reshape(-1)):
+            arr[i].T_iw[j] = float(v)
+        arr[i].img = kimg.struct() if kimg is not None else KfoImage(0, None, 0, 0)
+    _, t = _fp(T_wd)
+    _, k = _fp(Kdepth)
+    f = lib().kfo_texture_depth if fn is None else fn
+    f(out.ref(), arr, n, depth.ref(), norm.ref(), phong.ref() if phong is not None else None, t, k)

@@ -1257,3 +1257,60 @@ void kfo_bilateral_guided(const kfo_image* out, const kfo_image* in, const kfo_i
             ((float*)img_row(out, (size_t)y))[x] = sumw == 0 ? p : sum / sumw;
         }
 }
+
+/* TextureDepth, cu_depth_tools.cu:123-207.  kf arrays: K[4], T_iw[12], image per keyframe; phong == NULL selects the
+ * single-keyframe kernel.  `color` starts at zero (uninitialised in the reference's multi-keyframe kernel). */
+static inline f3 rgb_bilinear(const kfo_image* img, float pu, float pv)
+{
+    const float jx = floorf(pu), jy = floorf(pv);
+    const float gx = pu - jx, gy = pv - jy;
+    const uc3* cbl = (const uc3*)img_row(img, (size_t)jy) + (size_t)jx;
+    const uc3* ctl = (const uc3*)img_row(img, (size_t)(jy + 1)) + (size_t)jx;
+    return lerp3(lerp_uc3(cbl[0], cbl[1], gx), lerp_uc3(ctl[0], ctl[1], gx), gy);
+}
+void kfo_texture_depth(const kfo_image* out, const kfo_keyframe* kfs, int n_kf, const kfo_image* depth, const kfo_image* norm,
+                       const kfo_image* phong, const float T[12], const float K[4])
+{
+    for (size_t v = 0; v < out->h; ++v)
+        for (size_t u = 0; u < out->w; ++u) {
+            const float d = ((const float*)img_row(depth, v))[u];
+            const f4 N_d = ((const f4*)img_row(norm, v))[u];
+            const f3 N_w = so3_mul(T, mk3(N_d.x, N_d.y, N_d.z));
+            const f3 P_d = mk3(d * ((float)(int)u - U0) / FU, d * ((float)(int)v - V0) / FV, d);
+            const f3 P_w = se3_mul(T, P_d);
+            f4 o = {0, 0, 0, 1};
+            if (!phong) {
+                const kfo_keyframe* k = &kfs[0];
+                const f3 P_kf = se3_mul(k->T_iw, P_w);
+                const float pu = k->K[2] + k->K[0] * P_kf.x / P_kf.z, pv = k->K[3] + k->K[1] * P_kf.y / P_kf.z;
+                const f3 N_c = so3_mul(k->T_iw, N_w);
+                const float facing = N_c.x * 0.f + N_c.y * 0.f + N_c.z * 1.f;
+                if (2.0f <= pu && pu < ((float)k->img.w - 2.0f) && 2.0f <= pv && pv < ((float)k->img.h - 2.0f) && (double)facing < -0.2) { /* double literal */
+                    const f3 c = scale3(rgb_bilinear(&k->img, pu, pv), 1.0f / 255.0f);
+                    o.x = c.x; o.y = c.y; o.z = c.z;
+                }
+            } else {
+                float w = 0;
+                f3 color = mk3(0, 0, 0);
+                for (int i = 0; i < n_kf && kfs[i].img.ptr; ++i) {
+                    const kfo_keyframe* k = &kfs[i];
+                    const f3 P_kf = se3_mul(k->T_iw, P_w);
+                    const float pu = k->K[2] + k->K[0] * P_kf.x / P_kf.z, pv = k->K[3] + k->K[1] * P_kf.y / P_kf.z;
+                    const f3 N_c = so3_mul(k->T_iw, N_w);
+                    const float ndot = dot3(N_c, P_kf) / -length3(P_kf);
+                    if (2.0f <= pu && pu < ((float)k->img.w - 2.0f) && 2.0f <= pv && pv < ((float)k->img.h - 2.0f) && (double)ndot > 0.1 && P_kf.z > 0) {
+                        color = add3(color, scale3(rgb_bilinear(&k->img, pu, pv), ndot / 255.0f));
+                        w += ndot;
+                    }
+                }
+                if (w == 0) {
+                    w = 1;
+                    const float ph = ((const float*)img_row(phong, v))[u];
+                    color = mk3(ph, ph, ph);
+                }
+                const f3 c = div3s(color, w);
+                o.x = c.x; o.y = c.y; o.z = c.z;
+            }
+            ((f4*)img_row(out, v))[u] = o;
+        }
+}

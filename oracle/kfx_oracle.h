@@ -100,6 +100,15 @@ void kfo_raycast_sdf_color(const kfo_image* depth, const kfo_image* norm, const 
                            const kfo_volume* cvol, const float T_wc[12], const float K[4], float near, float far, float trunc,
                            int subpix, int nthreads);
 
+/* ImageKeyframe<uchar3> and TextureDepth (cu_depth_tools.cu:123-207); phong == NULL: single-keyframe form */
+typedef struct kfo_keyframe {
+    float K[4];
+    float T_iw[12];
+    kfo_image img;
+} kfo_keyframe;
+void kfo_texture_depth(const kfo_image* out, const kfo_keyframe* kfs, int n_kf, const kfo_image* depth, const kfo_image* norm,
+                       const kfo_image* phong, const float T_wd[12], const float Kdepth[4]);
+
 /* cu_bilateral.cu:110-155 */
 void kfo_bilateral_guided(const kfo_image* out, const kfo_image* in, const kfo_image* guide, int guide_is_u8, float gs, float gr, float gc,
                           int size);

@@ -21,6 +21,7 @@
 #include <kangaroo/BoundedVolume.h>
 #include <kangaroo/Image.h>
 #include <kangaroo/ImageIntrinsics.h>
+#include <kangaroo/ImageKeyframe.h>
 #include <kangaroo/InvalidValue.h>
 #include <kangaroo/Mat.h>
 #include <kangaroo/MatUtils.h>
@@ -491,6 +492,67 @@ void ref_colour_vbo(const kfo_image* pid, const kfo_image* pvbo, const kfo_image
                 Id = make_uchar4(0, 0, 0, 0);
             }
             dId(u, v) = Id;
+        }
+}
+
+// TextureDepth, single-keyframe kernel body (cu_depth_tools.cu:131-148) and the per-keyframe terms of the blended kernel
+// (:178-191) with the reference's ImageKeyframe / ImageTransformProject / Unproject / mulSO3 / GetBilinear<float3>.
+// Blended form: color starts at zero here (uninitialised in the reference).
+void ref_texture_depth(const kfo_image* pout, const kfo_keyframe* kfs, int n_kf, const kfo_image* pdepth, const kfo_image* pnorm,
+                       const kfo_image* pphong, const float* t, const float* k)
+{
+    HImgF4 img = imf4(pout), norm = imf4(pnorm);
+    HImgF depth = imf(pdepth);
+    const Mat<float, 3, 4> T_wd = mkT(t);
+    const ImageIntrinsics Kdepth = mkK(k);
+    ImageKeyframe<uchar3> kf[10];
+    for (int i = 0; i < 10; ++i) {
+        kf[i].img.ptr = 0;
+        if (i < n_kf && kfs[i].img.ptr) {
+            kf[i].K = mkK(kfs[i].K);
+            kf[i].T_iw = mkT(kfs[i].T_iw);
+            kf[i].img.ptr = (uchar3*)kfs[i].img.ptr;
+            kf[i].img.pitch = kfs[i].img.pitch;
+            kf[i].img.w = kfs[i].img.w;
+            kf[i].img.h = kfs[i].img.h;
+        }
+    }
+    for (int v = 0; v < (int)img.h; ++v)
+        for (int u = 0; u < (int)img.w; ++u) {
+            const float d = depth(u, v);
+            const float4 N_d = norm(u, v);
+            const float3 N_w = mulSO3(T_wd, N_d);
+            const float3 P_d = Kdepth.Unproject(u, v, d);
+            const float3 P_w = T_wd * P_d;
+            if (!pphong) {
+                const float2 p_kf = kf[0].Project(P_w);
+                const float3 N_c = mulSO3(kf[0].T_iw, N_w);
+                if (kf[0].img.InBounds(p_kf, 2) && dot(N_c, make_float3(0, 0, 1)) < -0.2) {
+                    const float3 color = (1.0f / 255.0f) * kf[0].img.GetBilinear<float3>(p_kf);
+                    img(u, v) = make_float4(color, 1);
+                } else {
+                    img(u, v) = make_float4(0, 0, 0, 1);
+                }
+            } else {
+                HImgF phong = imf(pphong);
+                float w = 0;
+                float3 color = make_float3(0, 0, 0);
+                for (int i = 0; i < 10 && kf[i].img.ptr; ++i) {
+                    const float3 P_kf = kf[i].T_iw * P_w;
+                    const float2 p_kf = kf[i].K.Project(P_kf);
+                    const float3 N_c = mulSO3(kf[i].T_iw, N_w);
+                    const float ndot = dot(N_c, P_kf) / -length(P_kf);
+                    if (kf[i].img.InBounds(p_kf, 2) && ndot > 0.1 && P_kf.z > 0) {
+                        color += (ndot / 255.0f) * kf[i].img.GetBilinear<float3>(p_kf);
+                        w += ndot;
+                    }
+                }
+                if (w == 0) {
+                    w = 1;
+                    color = make_float3(phong(u, v));
+                }
+                img(u, v) = make_float4(color / w, 1);
+            }
         }
 }
 

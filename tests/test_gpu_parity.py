@@ -1168,3 +1168,22 @@ def test_gpu_device_resident_icp_loop(roo):
         assert pipe.tracking_good
         worst = max(worst, float(np.linalg.norm(T_est[:3, 3] - T_true[:3, 3])))
     assert worst < 0.2 * float(np.linalg.norm(scenes.orbit_pose(frames - 1, 30)[:3, 3] - scenes.orbit_pose(0, 30)[:3, 3]))
+
+
+def test_gpu_texture_depth(roo):
+    """TextureDepth, single-keyframe and blended forms, against the oracle (bit-identical)."""
+    from test_oracle_cpu import texture_inputs
+    K, T_wd, rd, rn, ri, kfs = texture_inputs()
+    w, h = rd.w, rd.h
+    gd, gn, gi = T.upload_image(roo, rd.data), T.upload_image(roo, rn.data), T.upload_image(roo, ri.data)
+    gk = []
+    for img, T_iw, Kk in kfs:
+        g = roo.Image(img.w, img.h, "u8x3")
+        g.MemcpyFromHost(img.data)
+        gk.append((g, T_iw, Kk))
+    for sel, phong in ((slice(0, 1), False), (slice(0, 3), True), (slice(1, 2), True)):
+        want = oracle.Image(w, h, channels=4)
+        oracle.texture_depth(want, kfs[sel], rd, rn, T_wd, K, ri if phong else None)
+        out = roo.Image(w, h, "f32x4")
+        roo.TextureDepth(out, gk[sel], gd, gn, T_wd, K, gi if phong else None)
+        assert T.nan_equal(out.MemcpyToHost(), want.data), T.mismatch_report(out.MemcpyToHost(), want.data)

@@ -311,3 +311,35 @@ def test_oracle_is_clean_under_asan_and_ubsan():
         pytest.skip("this toolchain has no AddressSanitizer runtime")
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert "sanitize_check:" in out.stdout
+
+
+def texture_inputs(w=96, h=72, seed=4):
+    """A rendered view (depth / normals / phong from the oracle's raycast of a fused room) and three RGB keyframes around it."""
+    rng = np.random.default_rng(seed)
+    K = scenes.intrinsics(w, h)
+    vol = T.make_volume(40, "room")
+    T.fuse_frames_oracle(vol, "room", w, h, 2)
+    T_wd = scenes.orbit_pose(1, 8)
+    bmin, bmax, near, far = scenes.SCENES["room"]
+    tr = scenes.trunc_dist(bmin, bmax, (40, 40, 40))
+    rd, rn, ri = oracle.Image(w, h), oracle.Image(w, h, channels=4), oracle.Image(w, h)
+    oracle.raycast_sdf(rd, rn, ri, vol, T_wd, K, near, far, tr, True)
+    kfs = []
+    for i, (cw, ch) in enumerate(((80, 60), (64, 64), (100, 40))):
+        img = oracle.Image(cw, ch, np.uint8, 3)
+        img.data[...] = rng.integers(0, 256, (ch, cw, 3), dtype=np.uint8)
+        kfs.append((img, scenes.se3_inverse(scenes.orbit_pose(i, 8, yaw_deg=12.0, trans=0.2)), scenes.intrinsics(cw, ch)))
+    return K, T_wd, rd, rn, ri, kfs
+
+
+@pytest.mark.skipif(not os.path.exists(REF_SO), reason="oracle/_ref not built (needs /root/reference)")
+def test_oracle_texture_depth_vs_reference_headers():
+    R = C.CDLL(REF_SO)
+    K, T_wd, rd, rn, ri, kfs = texture_inputs()
+    w, h = rd.w, rd.h
+    for keyframes, phong in ((kfs[:1], None), (kfs + [(None, np.zeros((3, 4)), np.ones(4))], ri), (kfs[1:2], ri)):
+        got, want = oracle.Image(w, h, channels=4), oracle.Image(w, h, channels=4)
+        oracle.texture_depth(got, keyframes, rd, rn, T_wd, K, phong)
+        oracle.texture_depth(want, keyframes, rd, rn, T_wd, K, phong, fn=R.ref_texture_depth)
+        assert T.nan_equal(got.data, want.data), T.mismatch_report(got.data, want.data)
+        assert (got.data[..., 3] == 1).all() and (got.data[..., :3] > 0).any()
