@@ -71,6 +71,31 @@ def test_argument_errors_are_reported_not_fatal():
     assert L.kfx_free(None) == 0
 
 
+def test_every_compute_entry_point_rejects_null_arguments():
+    """Every entry point that takes container pointers validates them before any HIP call: all-NULL arguments
+    return a negative KFX_E_* code (never a crash, never a launch) -- checked here without a GPU."""
+    L = _lib.load()
+    skip = {"kfx_version", "kfx_device_count", "kfx_last_error_string", "kfx_error_name", "kfx_free", "kfx_free_host",
+            "kfx_set_math_mode", "kfx_get_math_mode", "kfx_stream_synchronize", "kfx_alloc_host", "kfx_memcpy_2d"}
+    checked = 0
+    for name, (restype, argtypes) in sorted(_lib.SIGNATURES.items()):
+        if name in skip or restype is not C.c_int:
+            continue
+        args = []
+        for a in argtypes:
+            if a in (C.c_float, C.c_double):
+                args.append(a(0.5))
+            elif a in (C.c_int, C.c_uint, C.c_size_t, C.c_longlong, C.c_ushort, C.c_ulonglong):
+                args.append(a(0))
+            else:
+                args.append(None)       # pointers: NULL
+        rc = getattr(L, name)(*args)
+        assert rc < 0, "%s accepted NULL arguments (returned %d)" % (name, rc)
+        assert L.kfx_last_error_string()
+        checked += 1
+    assert checked >= 35
+
+
 def test_product_never_imports_the_oracle():
     """The product path must not route through oracle/ (tier rule 3)."""
     pkg = os.path.join(T.ROOT, "kangaroo_amd")
