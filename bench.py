@@ -179,6 +179,13 @@ def main():
     # sanity: the run produced a model and an image
     hits = int(torch.isfinite(pipe.ray_d.tensor()).sum())
     assert hits > 0, "raycast produced no hits"
+    ranks_agree = None
+    if distributed:   # after the composite every rank must hold the same images: compare a checksum of the depth bits
+        bits = torch.nan_to_num(pipe.ray_d.tensor(), nan=-1.0).contiguous().view(torch.int32).to(torch.int64)
+        chk = torch.stack([bits.sum(), -bits.sum()])
+        dist.all_reduce(chk, op=dist.ReduceOp.MAX)
+        ranks_agree = bool(int(chk[0].item()) == -int(chk[1].item()))
+        assert ranks_agree, "ranks hold different composite images"
 
     # the other numerics mode, same frames, SdfFuse only (reported beside the headline; not part of `value`)
     other = "exact" if args.math == "fast" else "fast"
@@ -253,6 +260,7 @@ def main():
                                 N, 8.0 * N ** 3 / 2 ** 30, w, h, scene, N_ORBIT),
                 "volume": [N, N, N], "image": [w, h], "scene": scene,
                 "backend": os.environ.get("KFX_BENCH_BACKEND", "nccl (RCCL)") if distributed else None,
+                "ranks_agree": ranks_agree,
                 "partition": ("z-slabs x%d, ghost planes %s, raycast %s" % (n_gpus, args.halo, "composite = all_reduce(MIN key) + all_reduce(SUM payload)" if args.raycast == "composite" else "exact = march state handed from slab to slab, one SUM all_reduce per round"))
                              if distributed else "single volume",
                 "math": {"fast": "fast (fp32 rcp/rsq + FMA: the reference's own -use_fast_math regime; TSDF within 1e-4 of the exact path, "
