@@ -248,8 +248,8 @@ int kfx_sdf_distance(const kfx_image* dist, const kfx_image* depth, const kfx_vo
  * kfx_sdf_fuse_color: SdfFuse(vol, colorVol, depth, norm, T_cw, K, img, T_iw, Kimg, ...) (cu_sdffusion.cu:70-138) --
  *   voxels whose projections fall inside both images get the SDF update of kfx_sdf_fuse and
  *   colour = (w*c + colour*w_old) / (w + w_old), c = bilinear RGB mean / 255.  Extents as the reference's launch:
- *   x, y truncated to multiples of 16, every z slice (KFX_FUSE_FULL_EXTENT lifts the truncation).  Always IEEE
- *   arithmetic (no fast variant).
+ *   x, y truncated to multiples of 16, every z slice (KFX_FUSE_FULL_EXTENT lifts the truncation).  Follows
+ *   kfx_set_math_mode like kfx_sdf_fuse.
  * kfx_raycast_sdf_color: RaycastSdf(depth, norm, img, vol, colorVol, ...) (cu_raycast.cu:119-196) -- as
  *   kfx_raycast_sdf, but img = trilinear sample of the colour volume at the hit instead of the Phong shade.
  * kfx_color_reset: SdfReset(BoundedVolume<float>) = Fill(0.5) including pitch padding (cu_sdffusion.cu:166-169). */

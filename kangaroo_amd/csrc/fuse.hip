@@ -622,8 +622,9 @@ __global__ __launch_bounds__(256) void k_sdf_sphere(VolView v, int X, int Y, int
 // Colour TSDF fusion: cu_sdffusion.cu:70-138.  Besides the SDF update the kernel keeps a
 // grey-level volume (BoundedVolume<float>) as the weighted running mean of the RGB image sampled at the
 // voxel's projection into the colour camera (T_iw, Kimg).  Reference launch: 16x16 threads over x/y, all of z
-// in a loop -- so x/y extents are (dim/16)*16 and every slice is visited.  IEEE arithmetic in the reference's
-// order in both numerics modes (the colour path has no fast variant).  A lane owns one voxel column segment:
+// in a loop -- so x/y extents are (dim/16)*16 and every slice is visited.  Exact mode: IEEE
+// arithmetic in the reference's order; fast mode: rcp / rsq / FMA as in the grey kernel, the colour mean with float
+// reciprocals (the channel sum is interpolated once: bilinear interpolation is linear).  A lane owns one voxel column segment:
 // 8-byte SDF cells and 4-byte colour cells are both contiguous across the wave.
 // ---------------------------------------------------------------------------------------
 struct ColorParams {
@@ -657,6 +658,21 @@ __device__ __forceinline__ float grey_bilinear(const ColorParams& q, float u, fl
     return (float)((double)grey / 255.0);
 }
 
+// fast numerics: the same bilinear RGB mean, scaled by the float constant 1 / (3 * 255)
+__device__ __forceinline__ float grey_bilinear_fast(const ColorParams& q, float u, float v)
+{
+    const float ix = floorf(u), iy = floorf(v);
+    const float fx = u - ix, fy = v - iy;
+    const U3* bl = reinterpret_cast<const U3*>(q.img.ptr + (size_t)iy * q.img.pitch) + (size_t)ix;
+    const U3* tl = reinterpret_cast<const U3*>(q.img.ptr + (size_t)(iy + 1) * q.img.pitch) + (size_t)ix;
+    const U3 b0 = bl[0], b1 = bl[1], t0 = tl[0], t1 = tl[1];
+    const float s00 = (float)((int)b0.x + (int)b0.y + (int)b0.z), s01 = (float)((int)b1.x + (int)b1.y + (int)b1.z);
+    const float s10 = (float)((int)t0.x + (int)t0.y + (int)t0.z), s11 = (float)((int)t1.x + (int)t1.y + (int)t1.z);
+    const float lo = lerp_f(s00, s01, fx), hi = lerp_f(s10, s11, fx);    // the channel sum is linear: interpolate it once
+    return lerp_f(lo, hi, fy) * (1.0f / 765.0f);
+}
+
+template <bool FAST>
 __global__ __launch_bounds__(256) void k_sdf_fuse_color(const FuseParams p, const ColorParams q)
 {
     __shared__ float s_pz[FUSE_ZC];
@@ -671,7 +687,7 @@ __global__ __launch_bounds__(256) void k_sdf_fuse_color(const FuseParams p, cons
 
     const float px = p.bmin.x + p.size.x * (float)x / p.w1;
     const float py = p.bmin.y + p.size.y * (float)y / p.h1;
-    CamXY<false> cam;
+    CamXY<FAST> cam;
     cam.init(p, px, py);
     // T_iw * P_w with the same hoisting: leading partial sums of the reference expression
     const float ix0 = q.Ti.m[0] * px + q.Ti.m[1] * py, iy0 = q.Ti.m[4] * px + q.Ti.m[5] * py, iz0 = q.Ti.m[8] * px + q.Ti.m[9] * py;
@@ -681,22 +697,35 @@ __global__ __launch_bounds__(256) void k_sdf_fuse_color(const FuseParams p, cons
     for (int z = zbeg; z < zend; ++z, cell += p.vimg_pitch, ccell += q.cimg_pitch) {
         const float pz = s_pz[z - zbeg];
         const V3 Pc = cam.at(p, pz);
-        float pu, pv, unused;
-        project<false>(p, Pc, pu, pv, unused);
+        float pu, pv, iz;
+        project<FAST>(p, Pc, pu, pv, iz);
         const V3 Pi = v3(ix0 + q.Ti.m[2] * pz + q.Ti.m[3], iy0 + q.Ti.m[6] * pz + q.Ti.m[7], iz0 + q.Ti.m[10] * pz + q.Ti.m[11]);
-        const float qu = q.Ki.u0 + q.Ki.fu * Pi.x / Pi.z, qv = q.Ki.v0 + q.Ki.fv * Pi.y / Pi.z;
+        float qu, qv;
+        if constexpr (FAST) {
+            const float izi = __builtin_amdgcn_rcpf(Pi.z);
+            qu = __builtin_fmaf(q.Ki.fu * Pi.x, izi, q.Ki.u0);
+            qv = __builtin_fmaf(q.Ki.fv * Pi.y, izi, q.Ki.v0);
+        } else {
+            qu = q.Ki.u0 + q.Ki.fu * Pi.x / Pi.z;
+            qv = q.Ki.v0 + q.Ki.fv * Pi.y / Pi.z;
+        }
         if (in_bounds(p, pu, pv) && 2.0f <= qu && qu < q.iwb && 2.0f <= qv && qv < q.ihb) {
             const float fix = floorf(pu), fiy = floorf(pv);
             const Corners c = fetch_global64(p, (int)fix, (int)fiy);
-            const Obs o = finish<false>(p, Pc, 0.f, pu - fix, pv - fiy, c);
+            const Obs o = finish<FAST>(p, Pc, iz, pu - fix, pv - fiy, c);
             if (o.ok) {
-                const float grey = grey_bilinear(q, qu, qv);
                 float2 cur = *reinterpret_cast<const float2*>(cell);
                 const float curw = cur.y;
-                accumulate<false, CellF32>(o, p.max_w, cur.x, cur.y);
+                accumulate<FAST, CellF32>(o, p.max_w, cur.x, cur.y);
                 *reinterpret_cast<float2*>(cell) = cur;
                 float* cc = reinterpret_cast<float*>(ccell);
-                *cc = (o.w * grey + *cc * curw) / (o.w + curw);
+                if constexpr (FAST) { // same formula with a float reciprocal for / 255 and one rcp for the mean
+                    const float grey = grey_bilinear_fast(q, qu, qv);
+                    *cc = __builtin_fmaf(o.w, grey, *cc * curw) * __builtin_amdgcn_rcpf(o.w + curw);
+                } else {
+                    const float grey = grey_bilinear(q, qu, qv);
+                    *cc = (o.w * grey + *cc * curw) / (o.w + curw);
+                }
             }
         }
     }
@@ -988,7 +1017,8 @@ extern "C" int kfx_sdf_fuse_color(const kfx_volume* vol, const kfx_volume* color
     q.iwb = (float)img->w - 2.0f;
     q.ihb = (float)img->h - 2.0f;
     dim3 grid(ceil_div(p.X, 64), ceil_div(p.Y, FUSE_ROWS), ceil_div(p.Z, FUSE_ZC));
-    hipLaunchKernelGGL(k_sdf_fuse_color, grid, dim3(256), 0, (hipStream_t)stream, p, q);
+    if (math_mode() == KFX_MATH_FAST) hipLaunchKernelGGL(k_sdf_fuse_color<true>, grid, dim3(256), 0, (hipStream_t)stream, p, q);
+    else hipLaunchKernelGGL(k_sdf_fuse_color<false>, grid, dim3(256), 0, (hipStream_t)stream, p, q);
     return check_launch("kfx_sdf_fuse_color");
 }
 

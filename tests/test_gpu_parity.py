@@ -1187,3 +1187,38 @@ def test_gpu_texture_depth(roo):
         out = roo.Image(w, h, "f32x4")
         roo.TextureDepth(out, gk[sel], gd, gn, T_wd, K, gi if phong else None)
         assert T.nan_equal(out.MemcpyToHost(), want.data), T.mismatch_report(out.MemcpyToHost(), want.data)
+
+
+def test_gpu_colour_fusion_fast_mode(roo):
+    """Colour fusion under KFX_MATH_FAST against the exact path: same classification up to a handful of voxels at
+    predicate boundaries, TSDF within 1e-4 and grey levels within 2e-3 (half a grey step of 1/255)."""
+    import torch
+    import test_color_cpu as TC
+    dims, w, h = (128, 128, 128), 320, 240
+    ovol, ocvol, K, Kimg, tr, near, far, inputs = TC.color_setup(0, w, h, w, h, dims=dims)
+    bmin, bmax = scenes.SCENES["room"][0], scenes.SCENES["room"][1]
+    res = {}
+    for mode in ("exact", "fast"):
+        prev = roo.set_math_mode(mode)
+        try:
+            vol = roo.BoundedVolume(*dims, bmin, bmax)
+            cvol = roo.BoundedVolume(*dims, bmin, bmax, kind="c32")
+            roo.SdfReset(vol, float("nan"))
+            roo.ColorReset(cvol)
+            for fr in inputs:
+                rgb = roo.Image(w, h, "u8x3")
+                rgb.MemcpyFromHost(fr["rgb"].data)
+                roo.SdfFuseColor(vol, cvol, T.upload_image(roo, fr["f"].data), T.upload_image(roo, fr["nrm"].data), fr["T_cw"], K, rgb,
+                                 fr["T_iw"], Kimg, tr, scenes.MAX_W, scenes.MIN_COS_THETA)
+            res[mode] = (vol.tensor().clone(), cvol.tensor().clone())
+        finally:
+            roo.set_math_mode(prev)
+    (a, ca), (b, cb) = res["exact"], res["fast"]
+    na, nb = torch.isnan(a[..., 0]), torch.isnan(b[..., 0])
+    assert int((na != nb).sum()) <= 20
+    both = ~na & ~nb
+    d = (a[..., 0][both] - b[..., 0][both]).abs()
+    assert float((d > 1e-4).float().mean()) < 1e-4 and float(d.median()) < 1e-6
+    dc = (ca[..., 0][both] - cb[..., 0][both]).abs()
+    assert float((dc > 2e-3).float().mean()) < 1e-4, float(dc.max())
+    assert float(dc.median()) < 1e-6
