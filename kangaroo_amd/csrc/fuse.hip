@@ -642,34 +642,104 @@ struct __attribute__((packed)) U3 { unsigned char x, y, z; };
 // (integer difference, converted to float, times t, plus the first value) and the float3 lerp of
 // cutil_math.h:375-378 across rows; then ConvertPixel<float,float3> (pixel_convert.h:159-165) and the
 // application's "/ 255.0", a double division rounded back to float (cu_sdffusion.cu:98).
-__device__ __forceinline__ float grey_bilinear(const ColorParams& q, float u, float v)
+// Texels arrive packed as r | g << 8 | b << 16 (from global memory or from the LDS tile: copies either way).
+// Fast numerics: the channel sum is interpolated once (bilinear interpolation is linear) and scaled by the
+// float constant 1 / (3 * 255).
+struct Rgb4 { unsigned b0, b1, t0, t1; };
+
+template <bool FAST>
+__device__ __forceinline__ float grey_bilinear(const Rgb4 t, float fx, float fy)
 {
-    const float ix = floorf(u), iy = floorf(v);
-    const float fx = u - ix, fy = v - iy;
-    const U3* bl = reinterpret_cast<const U3*>(q.img.ptr + (size_t)iy * q.img.pitch) + (size_t)ix;
-    const U3* tl = reinterpret_cast<const U3*>(q.img.ptr + (size_t)(iy + 1) * q.img.pitch) + (size_t)ix;
-    const U3 b0 = bl[0], b1 = bl[1], t0 = tl[0], t1 = tl[1];
-    const V3 lo = v3((float)b0.x + fx * (float)((int)b1.x - (int)b0.x), (float)b0.y + fx * (float)((int)b1.y - (int)b0.y),
-                     (float)b0.z + fx * (float)((int)b1.z - (int)b0.z));
-    const V3 hi = v3((float)t0.x + fx * (float)((int)t1.x - (int)t0.x), (float)t0.y + fx * (float)((int)t1.y - (int)t0.y),
-                     (float)t0.z + fx * (float)((int)t1.z - (int)t0.z));
-    const V3 c = v3(lo.x + fy * (hi.x - lo.x), lo.y + fy * (hi.y - lo.y), lo.z + fy * (hi.z - lo.z));
-    const float grey = (c.x + c.y + c.z) / 3.0f;
-    return (float)((double)grey / 255.0);
+    if constexpr (FAST) {
+        auto sum = [](unsigned u) { return (float)((u & 0xffu) + ((u >> 8) & 0xffu) + ((u >> 16) & 0xffu)); };
+        const float lo = lerp_f(sum(t.b0), sum(t.b1), fx), hi = lerp_f(sum(t.t0), sum(t.t1), fx);
+        return lerp_f(lo, hi, fy) * (1.0f / 765.0f);
+    } else {
+        auto ch = [](unsigned u, int k) { return (int)((u >> (8 * k)) & 0xffu); };
+        float c[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float lo = (float)ch(t.b0, k) + fx * (float)(ch(t.b1, k) - ch(t.b0, k));
+            const float hi = (float)ch(t.t0, k) + fx * (float)(ch(t.t1, k) - ch(t.t0, k));
+            c[k] = lo + fy * (hi - lo);
+        }
+        const float grey = (c[0] + c[1] + c[2]) / 3.0f;
+        return (float)((double)grey / 255.0);
+    }
 }
 
-// fast numerics: the same bilinear RGB mean, scaled by the float constant 1 / (3 * 255)
-__device__ __forceinline__ float grey_bilinear_fast(const ColorParams& q, float u, float v)
+__device__ __forceinline__ unsigned pack_rgb(const U3 c) { return (unsigned)c.x | ((unsigned)c.y << 8) | ((unsigned)c.z << 16); }
+
+__device__ __forceinline__ Rgb4 fetch_rgb_global(const ColorParams& q, int ix, int iy)
 {
-    const float ix = floorf(u), iy = floorf(v);
-    const float fx = u - ix, fy = v - iy;
     const U3* bl = reinterpret_cast<const U3*>(q.img.ptr + (size_t)iy * q.img.pitch) + (size_t)ix;
     const U3* tl = reinterpret_cast<const U3*>(q.img.ptr + (size_t)(iy + 1) * q.img.pitch) + (size_t)ix;
-    const U3 b0 = bl[0], b1 = bl[1], t0 = tl[0], t1 = tl[1];
-    const float s00 = (float)((int)b0.x + (int)b0.y + (int)b0.z), s01 = (float)((int)b1.x + (int)b1.y + (int)b1.z);
-    const float s10 = (float)((int)t0.x + (int)t0.y + (int)t0.z), s11 = (float)((int)t1.x + (int)t1.y + (int)t1.z);
-    const float lo = lerp_f(s00, s01, fx), hi = lerp_f(s10, s11, fx);    // the channel sum is linear: interpolate it once
-    return lerp_f(lo, hi, fy) * (1.0f / 765.0f);
+    return Rgb4{pack_rgb(bl[0]), pack_rgb(bl[1]), pack_rgb(tl[0]), pack_rgb(tl[1])};
+}
+
+// T_iw * P_w with the x/y terms hoisted: leading partial sums of the reference expression (MatUtils.h:117-125)
+struct ColCam {
+    float ax, ay, az;
+    __device__ __forceinline__ void init(const ColorParams& q, float px, float py)
+    {
+        ax = q.Ti.m[0] * px + q.Ti.m[1] * py;
+        ay = q.Ti.m[4] * px + q.Ti.m[5] * py;
+        az = q.Ti.m[8] * px + q.Ti.m[9] * py;
+    }
+    __device__ __forceinline__ V3 at(const ColorParams& q, float pz) const
+    {
+        return v3(ax + q.Ti.m[2] * pz + q.Ti.m[3], ay + q.Ti.m[6] * pz + q.Ti.m[7], az + q.Ti.m[10] * pz + q.Ti.m[11]);
+    }
+};
+
+template <bool FAST>
+__device__ __forceinline__ void project_color(const ColorParams& q, const V3 Pi, float& qu, float& qv)
+{
+    if constexpr (FAST) {
+        const float izi = __builtin_amdgcn_rcpf(Pi.z);
+        qu = __builtin_fmaf(q.Ki.fu * Pi.x, izi, q.Ki.u0);
+        qv = __builtin_fmaf(q.Ki.fv * Pi.y, izi, q.Ki.v0);
+    } else {
+        qu = q.Ki.u0 + q.Ki.fu * Pi.x / Pi.z;
+        qv = q.Ki.v0 + q.Ki.fv * Pi.y / Pi.z;
+    }
+}
+
+__device__ __forceinline__ bool in_bounds_color(const ColorParams& q, float qu, float qv)
+{
+    return 2.0f <= qu && qu < q.iwb && 2.0f <= qv && qv < q.ihb;
+}
+
+// One voxel through global memory: both bounds tests, the observation and the grey level (cu_sdffusion.cu:84-99)
+template <bool FAST>
+__device__ __forceinline__ Obs observe_color_global(const FuseParams& p, const ColorParams& q, const V3 Pc, const V3 Pi, float& grey)
+{
+    Obs o;
+    o.ok = false;
+    o.val = 0.f;
+    o.w = 0.f;
+    grey = 0.f;
+    float pu, pv, iz, qu, qv;
+    project<FAST>(p, Pc, pu, pv, iz);
+    project_color<FAST>(q, Pi, qu, qv);
+    if (in_bounds(p, pu, pv) && in_bounds_color(q, qu, qv)) {
+        const float fix = floorf(pu), fiy = floorf(pv);
+        o = finish<FAST>(p, Pc, iz, pu - fix, pv - fiy, fetch_global64(p, (int)fix, (int)fiy));
+        if (o.ok) {
+            const float gix = floorf(qu), giy = floorf(qv);
+            grey = grey_bilinear<FAST>(fetch_rgb_global(q, (int)gix, (int)giy), qu - gix, qv - giy);
+        }
+    }
+    return o;
+}
+
+// colour running mean with the weight pair of the SDF update (cu_sdffusion.cu:100-104): `w` is the new sample's
+// weight, `curw` the stored weight before the update
+template <bool FAST>
+__device__ __forceinline__ float color_mean(float w, float grey, float cc, float curw)
+{
+    if constexpr (FAST) return __builtin_fmaf(w, grey, cc * curw) * __builtin_amdgcn_rcpf(w + curw);
+    else return (w * grey + cc * curw) / (w + curw);
 }
 
 template <bool FAST>
@@ -689,44 +759,212 @@ __global__ __launch_bounds__(256) void k_sdf_fuse_color(const FuseParams p, cons
     const float py = p.bmin.y + p.size.y * (float)y / p.h1;
     CamXY<FAST> cam;
     cam.init(p, px, py);
-    // T_iw * P_w with the same hoisting: leading partial sums of the reference expression
-    const float ix0 = q.Ti.m[0] * px + q.Ti.m[1] * py, iy0 = q.Ti.m[4] * px + q.Ti.m[5] * py, iz0 = q.Ti.m[8] * px + q.Ti.m[9] * py;
+    ColCam ccam;
+    ccam.init(q, px, py);
 
     unsigned char* cell = p.vptr + (size_t)zbeg * p.vimg_pitch + (size_t)y * p.vpitch + (size_t)x * 8;
     unsigned char* ccell = q.cptr + (size_t)zbeg * q.cimg_pitch + (size_t)y * q.cpitch + (size_t)x * 4;
     for (int z = zbeg; z < zend; ++z, cell += p.vimg_pitch, ccell += q.cimg_pitch) {
         const float pz = s_pz[z - zbeg];
-        const V3 Pc = cam.at(p, pz);
-        float pu, pv, iz;
-        project<FAST>(p, Pc, pu, pv, iz);
-        const V3 Pi = v3(ix0 + q.Ti.m[2] * pz + q.Ti.m[3], iy0 + q.Ti.m[6] * pz + q.Ti.m[7], iz0 + q.Ti.m[10] * pz + q.Ti.m[11]);
-        float qu, qv;
-        if constexpr (FAST) {
-            const float izi = __builtin_amdgcn_rcpf(Pi.z);
-            qu = __builtin_fmaf(q.Ki.fu * Pi.x, izi, q.Ki.u0);
-            qv = __builtin_fmaf(q.Ki.fv * Pi.y, izi, q.Ki.v0);
-        } else {
-            qu = q.Ki.u0 + q.Ki.fu * Pi.x / Pi.z;
-            qv = q.Ki.v0 + q.Ki.fv * Pi.y / Pi.z;
+        float grey;
+        const Obs o = observe_color_global<FAST>(p, q, cam.at(p, pz), ccam.at(q, pz), grey);
+        if (o.ok) {
+            float2 cur = *reinterpret_cast<const float2*>(cell);
+            const float curw = cur.y;
+            accumulate<FAST, CellF32>(o, p.max_w, cur.x, cur.y);
+            *reinterpret_cast<float2*>(cell) = cur;
+            float* cc = reinterpret_cast<float*>(ccell);
+            *cc = color_mean<FAST>(o.w, grey, *cc, curw);
         }
-        if (in_bounds(p, pu, pv) && 2.0f <= qu && qu < q.iwb && 2.0f <= qv && qv < q.ihb) {
-            const float fix = floorf(pu), fiy = floorf(pv);
-            const Corners c = fetch_global64(p, (int)fix, (int)fiy);
-            const Obs o = finish<FAST>(p, Pc, iz, pu - fix, pv - fiy, c);
-            if (o.ok) {
-                float2 cur = *reinterpret_cast<const float2*>(cell);
-                const float curw = cur.y;
-                accumulate<FAST, CellF32>(o, p.max_w, cur.x, cur.y);
-                *reinterpret_cast<float2*>(cell) = cur;
-                float* cc = reinterpret_cast<float*>(ccell);
-                if constexpr (FAST) { // same formula with a float reciprocal for / 255 and one rcp for the mean
-                    const float grey = grey_bilinear_fast(q, qu, qv);
-                    *cc = __builtin_fmaf(o.w, grey, *cc * curw) * __builtin_amdgcn_rcpf(o.w + curw);
-                } else {
-                    const float grey = grey_bilinear(q, qu, qv);
-                    *cc = (o.w * grey + *cc * curw) / (o.w + curw);
-                }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// LDS-tiled colour fusion: the brick / rectangle scheme of k_sdf_fuse_tiled with a second rectangle, the
+// brick's footprint in the RGB image, staged beside the depth / normal tile as packed r | g << 8 | b << 16
+// texels.  A lane owns two x-adjacent voxels (16-byte SDF and 8-byte colour accesses).  Bricks whose
+// rectangles do not fit, or that straddle either camera plane, take the global-gather path per voxel;
+// texel values are copies, so results equal k_sdf_fuse_color's in either numerics mode.
+// ---------------------------------------------------------------------------------------
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+template <bool FAST>
+__global__ __launch_bounds__(256) void k_sdf_fuse_color_tiled(const FuseParams p, const ColorParams q, const int cap_px, const int cap_cpx)
+{
+    extern __shared__ __attribute__((aligned(16))) float4 s_tile[];
+    unsigned* const s_rgb = reinterpret_cast<unsigned*>(s_tile + cap_px);
+    __shared__ float s_pz[FUSE_ZC];
+    __shared__ float s_box[4][9];
+    __shared__ float s_dmax[4];
+    __shared__ int s_bad[4];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int x0 = (blockIdx.x * 32 + (lane & 31)) * 2;
+    const int y = blockIdx.y * TB_Y + wv * 2 + (lane >> 5);
+    const int zbeg = blockIdx.z * FUSE_ZC;
+    const int zend = min(zbeg + FUSE_ZC, p.Z);
+    const bool live = x0 < p.X && y < p.Y;
+    if (tid < FUSE_ZC) s_pz[tid] = p.bmin.z + p.size.z * (float)(zbeg + tid + p.zoff) / p.d1;
+    __syncthreads();
+
+    const float py = p.bmin.y + p.size.y * (float)y / p.h1;
+    CamXY<FAST> cam[2];
+    ColCam ccam[2];
+#pragma unroll
+    for (int v = 0; v < 2; ++v) {
+        const float px = p.bmin.x + p.size.x * (float)(x0 + v) / p.w1;
+        cam[v].init(p, px, py);
+        ccam[v].init(q, px, py);
+    }
+
+    // ---- pixel rectangles of the brick in both images: projections of its first and last slice ----
+    const float inf = __builtin_inff();
+    float lo[5] = {inf, inf, inf, inf, inf};      // umin, vmin, qumin, qvmin, zmin
+    float hi[4] = {-inf, -inf, -inf, -inf};       // umax, vmax, qumax, qvmax
+    bool bad = false;
+    if (live) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const float pz = s_pz[e ? (zend - 1 - zbeg) : 0];
+#pragma unroll
+            for (int v = 0; v < 2; ++v) {
+                const V3 Pc = cam[v].at(p, pz), Pi = ccam[v].at(q, pz);
+                float pu, pv, iz, qu, qv;
+                project<FAST>(p, Pc, pu, pv, iz);
+                project_color<FAST>(q, Pi, qu, qv);
+                bad = bad || !(Pc.z > 0.f) || !(Pi.z > 0.f) || !(fabsf(pu) < 1e9f) || !(fabsf(pv) < 1e9f) || !(fabsf(qu) < 1e9f) || !(fabsf(qv) < 1e9f);
+                lo[0] = fminf(lo[0], pu); hi[0] = fmaxf(hi[0], pu);
+                lo[1] = fminf(lo[1], pv); hi[1] = fmaxf(hi[1], pv);
+                lo[2] = fminf(lo[2], qu); hi[2] = fmaxf(hi[2], qu);
+                lo[3] = fminf(lo[3], qv); hi[3] = fmaxf(hi[3], qv);
+                lo[4] = fminf(lo[4], Pc.z);
             }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { // wave64 butterfly
+#pragma unroll
+        for (int k = 0; k < 5; ++k) lo[k] = fminf(lo[k], __shfl_xor(lo[k], off, 64));
+#pragma unroll
+        for (int k = 0; k < 4; ++k) hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], off, 64));
+    }
+    const bool wave_bad = __ballot(bad) != 0ull;
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 5; ++k) s_box[wv][k] = lo[k];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s_box[wv][5 + k] = hi[k];
+        s_bad[wv] = wave_bad ? 1 : 0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 5; ++k) lo[k] = fminf(fminf(s_box[0][k], s_box[1][k]), fminf(s_box[2][k], s_box[3][k]));
+#pragma unroll
+    for (int k = 0; k < 4; ++k) hi[k] = fmaxf(fmaxf(s_box[0][5 + k], s_box[1][5 + k]), fmaxf(s_box[2][5 + k], s_box[3][5 + k]));
+    const bool any_bad = (s_bad[0] | s_bad[1] | s_bad[2] | s_bad[3]) != 0;
+    const float zmin = lo[4];
+
+    bool use_tile = false;
+    int tx0 = 0, ty0 = 0, tw = 0, th = 0, cx0 = 0, cy0 = 0, cw = 0, chh = 0;
+    if (!any_bad) {
+        // an update needs both samples inside their image's border band: a rectangle that misses it means no voxel
+        // of the brick can change (workgroup-uniform exit)
+        if (hi[0] < 2.0f || !(lo[0] < p.dwb) || hi[1] < 2.0f || !(lo[1] < p.dhb)) return;
+        if (hi[2] < 2.0f || !(lo[2] < q.iwb) || hi[3] < 2.0f || !(lo[3] < q.ihb)) return;
+        const float fx0 = fmaxf(floorf(lo[0]) - 1.f, 0.f), fx1 = fminf(floorf(hi[0]) + 2.f, (float)(p.depth.w - 1));
+        const float fy0 = fmaxf(floorf(lo[1]) - 1.f, 0.f), fy1 = fminf(floorf(hi[1]) + 2.f, (float)(p.depth.h - 1));
+        tx0 = (int)fx0; ty0 = (int)fy0;
+        tw = (int)fx1 - tx0 + 1; th = (int)fy1 - ty0 + 1;
+        const float gx0 = fmaxf(floorf(lo[2]) - 1.f, 0.f), gx1 = fminf(floorf(hi[2]) + 2.f, (float)(q.img.w - 1));
+        const float gy0 = fmaxf(floorf(lo[3]) - 1.f, 0.f), gy1 = fminf(floorf(hi[3]) + 2.f, (float)(q.img.h - 1));
+        cx0 = (int)gx0; cy0 = (int)gy0;
+        cw = (int)gx1 - cx0 + 1; chh = (int)gy1 - cy0 + 1;
+        use_tile = tw > 1 && th > 1 && tw * th <= cap_px && cw > 1 && chh > 1 && cw * chh <= cap_cpx;
+    }
+    float dmax = -inf;
+    if (use_tile) { // cooperative, row-coalesced staging of both rectangles
+        for (int r = wv; r < th; r += 4) {
+            const float* drow = row<float>(p.depth, (size_t)(ty0 + r)) + tx0;
+            const float4* nrow = row<float4>(p.norm, (size_t)(ty0 + r)) + tx0;
+            for (int c = lane; c < tw; c += 64) {
+                const float4 n = nrow[c];
+                const float d = drow[c];
+                s_tile[r * tw + c] = make_float4(n.x, n.y, n.z, d);
+                dmax = fmaxf(dmax, d);
+            }
+        }
+        for (int r = wv; r < chh; r += 4) {
+            const U3* irow = reinterpret_cast<const U3*>(q.img.ptr + (size_t)(cy0 + r) * q.img.pitch) + cx0;
+            for (int c = lane; c < cw; c += 64) s_rgb[r * cw + c] = pack_rgb(irow[c]);
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) dmax = fmaxf(dmax, __shfl_xor(dmax, off, 64));
+        if (lane == 0) s_dmax[wv] = dmax;
+    }
+    __syncthreads();
+    // occlusion culling of the whole brick: see k_sdf_fuse_tiled
+    if (use_tile && p.mincos > 0.f && p.trunc > 0.f) {
+        dmax = fmaxf(fmaxf(s_dmax[0], s_dmax[1]), fmaxf(s_dmax[2], s_dmax[3]));
+        const float bound = -(p.trunc / p.mincos) * 1.001f;
+        if (dmax + fabsf(dmax) * 1e-5f - zmin < bound) return;
+    }
+    if (!live) return;
+
+    unsigned char* cell = p.vptr + (size_t)zbeg * p.vimg_pitch + (size_t)y * p.vpitch + (size_t)x0 * 8;
+    unsigned char* ccell = q.cptr + (size_t)zbeg * q.cimg_pitch + (size_t)y * q.cpitch + (size_t)x0 * 4;
+    const int cxmax = tw - 2, cymax = th - 2, gxmax = cw - 2, gymax = chh - 2;
+    for (int z = zbeg; z < zend; ++z, cell += p.vimg_pitch, ccell += q.cimg_pitch) {
+        const float pz = s_pz[z - zbeg];
+        Obs o[2];
+        float grey[2];
+        bool stray = !use_tile;
+        if (use_tile) { // branch-free: indices clamped into the staged rectangles, results gate the update only
+#pragma unroll
+            for (int v = 0; v < 2; ++v) {
+                const V3 Pc = cam[v].at(p, pz), Pi = ccam[v].at(q, pz);
+                float pu, pv, iz, qu, qv;
+                project<FAST>(p, Pc, pu, pv, iz);
+                project_color<FAST>(q, Pi, qu, qv);
+                const bool inb = in_bounds(p, pu, pv) && in_bounds_color(q, qu, qv);
+                const float fix = floorf(pu), fiy = floorf(pv), gix = floorf(qu), giy = floorf(qv);
+                const int rx = (int)fix - tx0, ry = (int)fiy - ty0, gx = (int)gix - cx0, gy = (int)giy - cy0;
+                const bool inside = (unsigned)rx <= (unsigned)cxmax && (unsigned)ry <= (unsigned)cymax &&
+                                    (unsigned)gx <= (unsigned)gxmax && (unsigned)gy <= (unsigned)gymax;
+                const float4* t = s_tile + (min(max(ry, 0), cymax) * tw + min(max(rx, 0), cxmax));
+                Corners c;
+                c.c00 = t[0]; c.c01 = t[1]; c.c10 = t[tw]; c.c11 = t[tw + 1];
+                o[v] = finish<FAST>(p, Pc, iz, pu - fix, pv - fiy, c);
+                o[v].ok = ((int)o[v].ok & (int)inb & (int)inside) != 0;
+                const unsigned* g = s_rgb + (min(max(gy, 0), gymax) * cw + min(max(gx, 0), gxmax));
+                const Rgb4 texels{g[0], g[1], g[cw], g[cw + 1]};
+                if constexpr (FAST) {
+                    grey[v] = grey_bilinear<true>(texels, qu - gix, qv - giy);
+                } else { // IEEE path: a float and a double division per sample -- worth a divergent skip
+                    grey[v] = 0.f;
+                    if (o[v].ok) grey[v] = grey_bilinear<false>(texels, qu - gix, qv - giy);
+                }
+                stray |= ((int)inb & (int)!inside) != 0;
+            }
+        }
+        if (__builtin_expect(__ballot(stray) != 0ull, 0)) {
+#pragma unroll
+            for (int v = 0; v < 2; ++v) o[v] = observe_color_global<FAST>(p, q, cam[v].at(p, pz), ccam[v].at(q, pz), grey[v]);
+        }
+        if (o[0].ok || o[1].ok) {
+            float4 c = CellF32::ld2(cell);
+            const v2f k = __builtin_nontemporal_load(reinterpret_cast<const v2f*>(ccell));
+            float k0 = k.x, k1 = k.y;
+            if (o[0].ok) {
+                k0 = color_mean<FAST>(o[0].w, grey[0], k0, c.y);
+                accumulate<FAST, CellF32>(o[0], p.max_w, c.x, c.y);
+            }
+            if (o[1].ok) {
+                k1 = color_mean<FAST>(o[1].w, grey[1], k1, c.w);
+                accumulate<FAST, CellF32>(o[1], p.max_w, c.z, c.w);
+            }
+            CellF32::st2(cell, c);
+            v2f kk;
+            kk.x = k0; kk.y = k1;
+            __builtin_nontemporal_store(kk, reinterpret_cast<v2f*>(ccell));
         }
     }
 }
@@ -818,6 +1056,22 @@ static int fuse_params(FuseParams& p, bool* small_images, const kfx_volume* vol,
     return 0;
 }
 
+// LDS tile capacity (texels) for the bricks of local planes [z0, z1): grows with the pixels-per-voxel ratio
+// r = f * voxel / Z of camera (T, K), evaluated at the centre of the range (see fuse_launch).
+static int tile_cap(const FuseParams& p, const Pose& T, const Intr& K, int z0, int z1)
+{
+    const float cx = p.bmin.x + 0.5f * p.size.x, cy = p.bmin.y + 0.5f * p.size.y;
+    const float cz = p.bmin.z + p.size.z * (0.5f * (float)(z0 + z1 - 1) + (float)p.zoff) / p.d1;
+    const float Zc = T.m[8] * cx + T.m[9] * cy + T.m[10] * cz + T.m[11];
+    if (!(Zc > 0.f)) return 1536;
+    const float voxel = fmaxf(p.size.x / p.w1, p.size.y / p.h1);
+    const float r = fmaxf(fabsf(K.fu), fabsf(K.fv)) * voxel / Zc;
+    if (!(r > 1.3f)) return 1536;
+    const float want = 1536.f * (r / 1.05f) * (r / 1.05f);
+    const int c = want >= 3072.f ? 3072 : ((int)want + 511) / 512 * 512;
+    return c < 1536 ? 1536 : c;
+}
+
 template <typename CELL>
 static int fuse_launch(const kfx_volume* vol, const kfx_image* depth, const kfx_image* norm, const float T_cw[12],
                        const float K[4], float trunc_dist, float max_w, float mincostheta, unsigned flags, kfx_stream stream,
@@ -845,19 +1099,7 @@ static int fuse_launch(const kfx_volume* vol, const kfx_image* depth, const kfx_
         // 3 workgroups per CU) -- measured at 512^3, 1280x960, 2-4 m: 0.80 ms (1536) / 0.62 ms (3072), while at
         // r < 1.2 the larger tile only costs occupancy (0.39 -> 0.51 ms).  r is evaluated at the centre of each
         // 64-slice range and ranges with equal capacity share a launch.
-        auto cap_for = [&](int z0, int z1) -> int {
-            if (cap_env) return cap_env;
-            const float cx = p.bmin.x + 0.5f * p.size.x, cy = p.bmin.y + 0.5f * p.size.y;
-            const float cz = p.bmin.z + p.size.z * (0.5f * (float)(z0 + z1 - 1) + (float)p.zoff) / p.d1;
-            const float Zc = p.T.m[8] * cx + p.T.m[9] * cy + p.T.m[10] * cz + p.T.m[11];
-            if (!(Zc > 0.f)) return 1536;
-            const float voxel = fmaxf(p.size.x / p.w1, p.size.y / p.h1);
-            const float r = fmaxf(fabsf(p.K.fu), fabsf(p.K.fv)) * voxel / Zc;
-            if (!(r > 1.3f)) return 1536;
-            const float want = 1536.f * (r / 1.05f) * (r / 1.05f);
-            const int c = want >= 3072.f ? 3072 : ((int)want + 511) / 512 * 512;
-            return c < 1536 ? 1536 : c;
-        };
+        auto cap_for = [&](int z0, int z1) -> int { return cap_env ? cap_env : tile_cap(p, p.T, p.K, z0, z1); };
         const int zstep = 64;
         int z0 = 0;
         while (z0 < p.Z) {
@@ -1016,9 +1258,43 @@ extern "C" int kfx_sdf_fuse_color(const kfx_volume* vol, const kfx_volume* color
     q.img = ImgView{(const unsigned char*)img->ptr, img->pitch, (int)img->w, (int)img->h};
     q.iwb = (float)img->w - 2.0f;
     q.ihb = (float)img->h - 2.0f;
-    dim3 grid(ceil_div(p.X, 64), ceil_div(p.Y, FUSE_ROWS), ceil_div(p.Z, FUSE_ZC));
-    if (math_mode() == KFX_MATH_FAST) hipLaunchKernelGGL(k_sdf_fuse_color<true>, grid, dim3(256), 0, (hipStream_t)stream, p, q);
-    else hipLaunchKernelGGL(k_sdf_fuse_color<false>, grid, dim3(256), 0, (hipStream_t)stream, p, q);
+    const bool fast = math_mode() == KFX_MATH_FAST;
+    hipStream_t s = (hipStream_t)stream;
+    static const int tiled = [] { const char* e = getenv("KFX_FUSE_TILED"); return e ? atoi(e) : 1; }();
+    // two voxels per lane: even extent, 16-byte aligned SDF rows, 8-byte aligned colour rows
+    const bool vec2 = (p.X % 2 == 0) && ((((uintptr_t)vol->ptr | vol->pitch | vol->img_pitch) & 15) == 0) &&
+                      ((((uintptr_t)colorvol->ptr | colorvol->pitch | colorvol->img_pitch) & 7) == 0);
+    if (tiled && vec2) {
+        // per z-range LDS capacities as in fuse_launch: the depth / normal tile (16 B texels) by the depth camera's
+        // pixels-per-voxel ratio, the RGB tile (4 B texels, a third more room) by the colour camera's
+        auto rgb_cap = [&](int a, int b) { const int c = tile_cap(p, q.Ti, q.Ki, a, b) * 4 / 3; return c > 3584 ? 3584 : c; }; // 48 + 14 KiB + statics < 64 KiB
+        const int zstep = 64;
+        int z0 = 0;
+        while (z0 < p.Z) {
+            int z1 = z0 + zstep < p.Z ? z0 + zstep : p.Z;
+            const int cap_px = tile_cap(p, p.T, p.K, z0, z1), cap_cpx = rgb_cap(z0, z1);
+            while (z1 < p.Z) {
+                const int z2 = z1 + zstep < p.Z ? z1 + zstep : p.Z;
+                if (tile_cap(p, p.T, p.K, z1, z2) != cap_px || rgb_cap(z1, z2) != cap_cpx) break;
+                z1 = z2;
+            }
+            FuseParams pp = p;
+            ColorParams qq = q;
+            pp.vptr = p.vptr + (size_t)z0 * p.vimg_pitch;
+            qq.cptr = q.cptr + (size_t)z0 * q.cimg_pitch;
+            pp.zoff = z0;
+            pp.Z = z1 - z0;
+            dim3 grid(ceil_div(pp.X, TB_X), ceil_div(pp.Y, TB_Y), ceil_div(pp.Z, FUSE_ZC));
+            const size_t lds = (size_t)cap_px * sizeof(float4) + (size_t)cap_cpx * sizeof(unsigned);
+            if (fast) hipLaunchKernelGGL(k_sdf_fuse_color_tiled<true>, grid, dim3(256), lds, s, pp, qq, cap_px, cap_cpx);
+            else hipLaunchKernelGGL(k_sdf_fuse_color_tiled<false>, grid, dim3(256), lds, s, pp, qq, cap_px, cap_cpx);
+            z0 = z1;
+        }
+    } else {
+        dim3 grid(ceil_div(p.X, 64), ceil_div(p.Y, FUSE_ROWS), ceil_div(p.Z, FUSE_ZC));
+        if (fast) hipLaunchKernelGGL(k_sdf_fuse_color<true>, grid, dim3(256), 0, s, p, q);
+        else hipLaunchKernelGGL(k_sdf_fuse_color<false>, grid, dim3(256), 0, s, p, q);
+    }
     return check_launch("kfx_sdf_fuse_color");
 }
 

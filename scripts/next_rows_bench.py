@@ -87,6 +87,10 @@ out["color_fuse_updated_voxels"] = updated
 # 16 B SDF read+write + 8 B colour read+write per updated voxel, one pass over depth + normals + rgb
 alg = 24 * updated + (4 + 16 + 3) * w * h
 out["color_fuse_GBps"] = round(alg / (out["color_fuse_ms"] * 1e-3) / 1e9, 1)
+roo.set_math_mode("fast")
+out["color_fuse_fast_ms"] = round(timed(fuse_c), 4)
+out["color_fuse_fast_GBps"] = round(alg / (out["color_fuse_fast_ms"] * 1e-3) / 1e9, 1)
+roo.set_math_mode("exact")
 rd, rn, ri = roo.Image(w, h), roo.Image(w, h, "f32x4"), roo.Image(w, h)
 T_wc = scenes.orbit_pose(0, 30)
 out["color_raycast_ms"] = round(timed(lambda: roo.RaycastSdfColor(rd, rn, ri, vol, cvol, T_wc, K, near, far, tr, True)), 4)
