@@ -15,6 +15,11 @@ extern "C" {
  * 10-17 = generated shapes with and without nontemporal accesses (kangaroo_amd/csrc/debug.hip). */
 int kfx_debug_rmw(const kfx_volume* vol, int variant, kfx_stream stream);
 
+/* Exhaustive check of the kernels' division-by-a-uniform-divisor shortcut (kfx_device.h: div_uniform) against the
+ * hardware IEEE division: all 2^32 numerator bit patterns for divisor b.  d_out[0] += mismatching patterns,
+ * d_out[1] += patterns tested (those inside the shortcut's operand range); both device-side 64-bit counters. */
+int kfx_debug_div_uniform_check(float b, unsigned long long* d_out, kfx_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -92,6 +92,8 @@ __global__ __launch_bounds__(256) void k_raycast_plane(const PixParams p)
 struct DistParams {
     VolView vol;
     V3 size, dims1, hi2;
+    V3 inv_size;
+    int fastdiv, off32;
     unsigned char *optr, *dptr;
     size_t opitch, dpitch;
     int w, h;

@@ -92,9 +92,35 @@ __global__ __launch_bounds__(256) void k_rmw_gen(unsigned char* vptr, size_t pit
     }
 }
 
+// exhaustive check of div_uniform against the hardware division: every numerator bit pattern for one divisor
+__global__ __launch_bounds__(256) void k_div_uniform_check(float b, float inv, unsigned long long* __restrict__ out)
+{
+    unsigned long long bad = 0, tested = 0;
+    const unsigned stride = gridDim.x * blockDim.x;
+    unsigned bits = blockIdx.x * blockDim.x + threadIdx.x;
+    for (unsigned it = 0; it < (1u << 16); ++it, bits += stride) { // grid = 2^16 threads: 2^16 iterations cover 2^32 patterns
+        const float a = __uint_as_float(bits);
+        if (!div_uniform_safe(a)) continue;
+        const float want = a / b;
+        const float got = div_uniform(a, b, inv);
+        tested += 1;
+        bad += (__float_as_uint(want) != __float_as_uint(got)) ? 1 : 0;
+    }
+    atomicAdd(out, bad);
+    atomicAdd(out + 1, tested);
+}
+
 } // namespace kfx
 
 using namespace kfx;
+
+extern "C" int kfx_debug_div_uniform_check(float b, unsigned long long* d_out, kfx_stream stream)
+{
+    if (!d_out) return set_error(KFX_E_NULL, "kfx_debug_div_uniform_check");
+    if (!div_uniform_safe_host(b)) return set_error(KFX_E_RANGE, "kfx_debug_div_uniform_check: divisor outside [2^-40, 2^40]");
+    hipLaunchKernelGGL(k_div_uniform_check, dim3(256), dim3(256), 0, (hipStream_t)stream, b, 1.0f / b, d_out);
+    return check_launch("kfx_debug_div_uniform_check");
+}
 
 extern "C" int kfx_debug_rmw(const kfx_volume* vol, int variant, kfx_stream stream)
 {

@@ -32,6 +32,8 @@ __constant__ signed char c_tris[256][15];
 struct MeshParams {
     VolView vol;
     V3 size, dims1, hi2, voxel;  // members trilinear<>() / gradient<>() expect
+    V3 inv_size;
+    int fastdiv, off32;
     int cx, cy, cz;              // cubes per axis = dims - 1
 };
 

@@ -23,6 +23,8 @@ struct RayParams {
     V3 dims1;         // (w-1.f, h-1.f, d-1.f)           Volume.h:226
     V3 hi2;           // ((float)(w-2), (float)(h-2), (float)(d-2))   Volume.h:229-231
     V3 voxel;         // VoxelSizeUnits()                BoundedVolume.h:67-76
+    V3 inv_size;      // 1 / size, for div_uniform
+    int fastdiv, off32;
     Pose T;           // T_wc
     Intr K;
     unsigned char *dptr, *nptr, *iptr;
@@ -344,6 +346,7 @@ static int raycast_slab_launch(float* state, int init, const kfx_volume* vol, co
     p.dims1 = V3{(float)vol->w - 1.f, (float)vol->h - 1.f, (float)slab->full_d - 1.f};
     p.hi2 = V3{(float)(vol->w - 2), (float)(vol->h - 2), (float)(slab->full_d - 2)};
     p.voxel = V3{p.size.x / (float)(vol->w - 1), p.size.y / (float)(vol->h - 1), p.size.z / (float)(slab->full_d - 1)};
+    set_shortcuts(p);
     for (int i = 0; i < 12; ++i) p.T.m[i] = T_wc[i];
     p.K = Intr{K[0], K[1], K[2], K[3]};
     p.dptr = p.nptr = p.iptr = nullptr;

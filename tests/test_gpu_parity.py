@@ -1222,3 +1222,31 @@ def test_gpu_colour_fusion_fast_mode(roo):
     dc = (ca[..., 0][both] - cb[..., 0][both]).abs()
     assert float((dc > 2e-3).float().mean()) < 1e-4, float(dc.max())
     assert float(dc.median()) < 1e-6
+
+
+# ---------------------------------------------------------------------------------
+# arithmetic shortcuts that must not change a bit
+# ---------------------------------------------------------------------------------
+def test_gpu_division_by_uniform_divisor_is_the_ieee_quotient(roo):
+    """kfx_device.h div_uniform (q0 = a * (1/b); r = fma(-b, q0, a); q = fma(r, 1/b, q0)) against the hardware's IEEE
+    division, exhaustively: all 2^32 numerator patterns (those inside the shortcut's operand range, ~31 % of them) for
+    divisors with awkward significands (all ones, one ulp above a power of two), the benchmark's box sizes, negative
+    and random values across the allowed exponent range."""
+    import ctypes as C
+    import torch
+    from kangaroo_amd import _lib
+    L = _lib.load()
+    L.kfx_debug_div_uniform_check.restype = C.c_int
+    L.kfx_debug_div_uniform_check.argtypes = [C.c_float, C.c_void_p, C.c_void_p]
+    rng = np.random.default_rng(7)
+    special = np.array([0x3fffffff, 0x3f800001, 0x3f7fffff, 0x40000000, 0x3faaaaab, 0x3f800000, 0x3fb504f3, 0x3fc00001], np.uint32).view(np.float32)
+    divisors = [2.0, 1.8, 3.0, 0.1, 7.3, -2.5, 1e-9, 3e9, float(np.float32(2.0) / np.float32(511.0))] + [float(x) for x in special]
+    mant = rng.integers(0, 1 << 23, 24, dtype=np.uint32)
+    expo = rng.integers(127 - 39, 127 + 39, 24, dtype=np.uint32)
+    divisors += [float(x) for x in ((expo << 23) | mant).view(np.float32)]
+    out = torch.zeros(2, dtype=torch.int64, device="cuda")
+    for b in divisors:
+        out.zero_()
+        assert L.kfx_debug_div_uniform_check(C.c_float(b), C.c_void_p(out.data_ptr()), None) == 0
+        bad, tested = (int(v) for v in out.cpu())
+        assert tested > 1_300_000_000 and bad == 0, (b, bad, tested)
