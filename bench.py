@@ -190,7 +190,7 @@ def main():
     # the other numerics mode, same frames, SdfFuse only (reported beside the headline; not part of `value`)
     other = "exact" if args.math == "fast" else "fast"
     roo.set_math_mode(other)
-    n_other = min(args.steps, 20)
+    n_other = min(args.steps, N_ORBIT)   # one full orbit: launch times depend on the pose
     ev2 = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_other)]
     for s in range(3):   # untimed: the first launches after the mode switch run on cold instruction caches
         i = (args.warmup + s) % N_ORBIT
