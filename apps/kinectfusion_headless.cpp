@@ -14,7 +14,7 @@
 //   SdfFuse(work_vol, kin_d, kin_n, T_wl^-1, K, trunc_dist, max_w, mincostheta)            (:345-356)
 //
 // Host code only; all device work happens in libkfx behind the roo:: wrappers.
-// Usage: kinectfusion_headless [--res N] [--frames F] [--width W] [--height H] [--fast] [--track | --device-icp]
+// Usage: kinectfusion_headless [--res N] [--frames F] [--width W] [--height H] [--fast] [--track | --device-icp] [--one-raycast]
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -68,7 +68,7 @@ static Mat<float,3,4> OrbitPose(int i, int n)
 int main(int argc, char** argv)
 {
     int volres = 256, frames = 30, w = 640, h = 480;   // the application's defaults (main.cpp:90-91)
-    bool fast = false, track = false, device_icp = false;
+    bool fast = false, track = false, device_icp = false, one_raycast = false;
     for (int i = 1; i < argc; ++i) {
         if (!strcmp(argv[i], "--res") && i + 1 < argc) volres = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--frames") && i + 1 < argc) frames = atoi(argv[++i]);
@@ -76,6 +76,7 @@ int main(int argc, char** argv)
         else if (!strcmp(argv[i], "--height") && i + 1 < argc) h = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--fast")) fast = true;
         else if (!strcmp(argv[i], "--track")) track = true;
+        else if (!strcmp(argv[i], "--one-raycast")) one_raycast = true;   // all pyramid levels rendered by one launch
         else if (!strcmp(argv[i], "--device-icp")) track = device_icp = true;   // the refinement loop as one device-side chain
     }
     if (kfx_device_count() < 1) { fprintf(stderr, "no HIP device\n"); return 2; }
@@ -139,11 +140,23 @@ int main(int argc, char** argv)
         const BoundingBox roi(T_wl, w, h, K, knear, kfar);
         BoundedVolume<SDF_t> work_vol = vol.SubBoundingVolume(roi);
         if (work_vol.IsValid()) {
-            for (int l = 0; l < MaxLevels; ++l) {
-                if (its[l] > 0) {
-                    const ImageIntrinsics Kl = K[l];
-                    RaycastSdf(ray_d[l], ray_n[l], ray_i[l], work_vol, T_wl, Kl, knear, kfar, trunc_dist, true);
-                    DepthToVbo<float>(ray_v[l], ray_d[l], Kl);
+            if (one_raycast) {   // the same images from one launch: the levels' marches overlap (kfx_raycast_sdf_levels)
+                Image<float> rd[MaxLevels], ri[MaxLevels];
+                Image<float4> rn[MaxLevels];
+                ImageIntrinsics Kl[MaxLevels];
+                unsigned n = 0;
+                for (int l = 0; l < MaxLevels; ++l)
+                    if (its[l] > 0) { rd[n] = ray_d[l]; rn[n] = ray_n[l]; ri[n] = ray_i[l]; Kl[n] = K[l]; ++n; }
+                RaycastSdfLevels(rd, rn, ri, n, work_vol, T_wl, Kl, knear, kfar, trunc_dist, true);
+                for (int l = 0; l < MaxLevels; ++l)
+                    if (its[l] > 0) DepthToVbo<float>(ray_v[l], ray_d[l], K[l]);
+            } else {
+                for (int l = 0; l < MaxLevels; ++l) {
+                    if (its[l] > 0) {
+                        const ImageIntrinsics Kl = K[l];
+                        RaycastSdf(ray_d[l], ray_n[l], ray_i[l], work_vol, T_wl, Kl, knear, kfar, trunc_dist, true);
+                        DepthToVbo<float>(ray_v[l], ray_d[l], Kl);
+                    }
                 }
             }
             bool tracking_good = true;

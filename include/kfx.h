@@ -120,6 +120,19 @@ int kfx_raycast_sdf(const kfx_image* depth, const kfx_image* norm, const kfx_ima
                     const kfx_volume* vol, const float T_wc[12], const float K[4], float near,
                     float far, float trunc_dist, int subpix, kfx_stream stream);
 
+/* The per-level RaycastSdf calls of the tracking loop (applications/kinectfusion/main.cpp:280-288: one call per
+ * pyramid level with ICP iterations, same model, same pose, intrinsics K[l]) as ONE launch.  depth / norm / img are
+ * arrays of n_levels image pointers, K holds n_levels x 4 floats {fu, fv, u0, v0}; n_levels <= 8.  Every image is
+ * bit-identical to what its own kfx_raycast_sdf call writes; the levels' marches overlap instead of running one
+ * after the other (a coarse level takes as long as the full-resolution one: DESIGN.md 5.2).  No counterpart in the
+ * reference API -- an addition next to it; the roo:: wrapper is RaycastSdfLevels (include/kangaroo/cu_raycast.h). */
+int kfx_raycast_sdf_levels(int n_levels, const kfx_image* const* depth, const kfx_image* const* norm, const kfx_image* const* img,
+                           const kfx_volume* vol, const float T_wc[12], const float* K, float near, float far,
+                           float trunc_dist, int subpix, kfx_stream stream);
+int kfx_raycast_sdf_levels_h(int n_levels, const kfx_image* const* depth, const kfx_image* const* norm, const kfx_image* const* img,
+                             const kfx_volume* vol, const float T_wc[12], const float* K, float near, float far,
+                             float trunc_dist, int subpix, kfx_stream stream);
+
 /* roo::BilateralFilter<float,float>(Image<float>, Image<float>, gs, gr, size[, minval])
  * reference: include/kangaroo/cu_bilateral.h:9-19, src/cu_bilateral.cu:13-53 (use_minval=0),
  * :59-104 (use_minval=1) */

@@ -50,15 +50,21 @@ __device__ __forceinline__ float phong(const V3 p_c, const V3 n_c)
     return ambient + diffuse * ldotn + specular * spec;
 }
 
-template <typename CELL, bool COLOR>
-__global__ __launch_bounds__(256) void k_raycast_sdf(const RayParams p, const ColorGeom cv)
+// pixel of thread `tid` of workgroup (bx, by): wave -> (1 << tile_log2w) x (64 >> tile_log2w) pixel tile,
+// workgroup -> 2 x 2 such tiles (wg_log2x = 1)
+__device__ __forceinline__ void ray_pixel_of(const RayParams& p, int bx, int by, int tid, int& u, int& v)
 {
-    // wave -> (1 << tile_log2w) x (64 >> tile_log2w) pixel tile; workgroup -> 2 x 2 such tiles
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int lane = tid & 63, wv = tid >> 6;
     const int tw = 1 << p.tile_log2w, th = 64 >> p.tile_log2w;
     const int wgx = 1 << p.wg_log2x, wgy = 4 >> p.wg_log2x; // waves per workgroup along x / y
-    const int u = (blockIdx.x * wgx + (wv & (wgx - 1))) * tw + (lane & (tw - 1));
-    const int v = (blockIdx.y * wgy + (wv >> p.wg_log2x)) * th + (lane >> p.tile_log2w);
+    u = (bx * wgx + (wv & (wgx - 1))) * tw + (lane & (tw - 1));
+    v = (by * wgy + (wv >> p.wg_log2x)) * th + (lane >> p.tile_log2w);
+}
+
+// one ray: KernRaycastSdf (cu_raycast.cu:34-113) for pixel (u, v)
+template <typename CELL, bool COLOR>
+__device__ __forceinline__ void raycast_pixel(const RayParams& p, const ColorGeom& cv, const int u, const int v)
+{
     if (u >= p.w || v >= p.h) return;
 
     const V3 c_w = v3(p.T.m[3], p.T.m[7], p.T.m[11]);                              // SE3Translation
@@ -113,6 +119,53 @@ __global__ __launch_bounds__(256) void k_raycast_sdf(const RayParams p, const Co
         *pi = 0.f;
         *pn = make_float4(0.f, 0.f, 0.f, 0.f);
     }
+}
+
+template <typename CELL, bool COLOR>
+__global__ __launch_bounds__(256) void k_raycast_sdf(const RayParams p, const ColorGeom cv)
+{
+    int u, v;
+    ray_pixel_of(p, blockIdx.x, blockIdx.y, threadIdx.x, u, v);
+    raycast_pixel<CELL, COLOR>(p, cv, u, v);
+}
+
+// ---------------------------------------------------------------------------------------
+// Several renderings of the same model in one launch.  The tracking loop raycasts the model at every pyramid level
+// that has ICP iterations (main.cpp:280-288: 640x480, 160x120, 80x60), and a coarse level takes as long as the
+// full-resolution one: the march is a chain of ~150 dependent misses whatever the number of rays (DESIGN.md 5.2;
+// measured 0.168 / 0.147 / 0.167 ms for levels 0 / 2 / 3).  One grid over the workgroups of all levels lets the
+// chains overlap: 0.465 -> 0.274 ms (S_room), 0.452 -> 0.255 ms (S_full), scripts/raycast_levels.py.  Each pixel runs raycast_pixel unchanged, so every image is
+// bit-identical to its own kfx_raycast_sdf call.
+// ---------------------------------------------------------------------------------------
+constexpr int RAY_MAX_LEVELS = 8;
+struct RayLevel {
+    unsigned char *dptr, *nptr, *iptr;
+    size_t dpitch, npitch, ipitch;
+    int w, h;
+    Intr K;
+    int first_block, blocks_x; // this level's workgroups are [first_block, next level's first_block), row-major
+};
+struct RayLevels {
+    RayLevel lv[RAY_MAX_LEVELS];
+    int n;
+};
+
+template <typename CELL>
+__global__ __launch_bounds__(256) void k_raycast_sdf_levels(const RayParams base, const RayLevels L)
+{
+    int l = 0;
+    for (int k = 1; k < L.n; ++k)
+        if ((int)blockIdx.x >= L.lv[k].first_block) l = k; // uniform
+    const RayLevel& lv = L.lv[l];
+    RayParams p = base;
+    p.dptr = lv.dptr; p.nptr = lv.nptr; p.iptr = lv.iptr;
+    p.dpitch = lv.dpitch; p.npitch = lv.npitch; p.ipitch = lv.ipitch;
+    p.w = lv.w; p.h = lv.h;
+    p.K = lv.K;
+    const int b = (int)blockIdx.x - lv.first_block;
+    int u, v;
+    ray_pixel_of(p, b % lv.blocks_x, b / lv.blocks_x, threadIdx.x, u, v);
+    raycast_pixel<CELL, false>(p, ColorGeom{}, u, v);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -237,14 +290,14 @@ __global__ __launch_bounds__(256) void k_raycast_state_to_images(const RayParams
 
 using namespace kfx;
 
+// argument checks of one output image set + volume, and the kernel parameters they give
 template <typename CELL>
-static int raycast_launch(const kfx_image* depth, const kfx_image* norm, const kfx_image* img,
-                          const kfx_volume* vol, const float T_wc[12], const float K[4], float near,
-                          float far, float trunc_dist, int subpix, kfx_stream stream, const kfx_volume* colorvol = nullptr)
+static int ray_params(RayParams& p, const kfx_image* depth, const kfx_image* norm, const kfx_image* img,
+                      const kfx_volume* vol, const float T_wc[12], const float K[4], float near,
+                      float far, float trunc_dist, int subpix)
 {
     if (!depth || !norm || !img || !vol || !T_wc || !K || !depth->ptr || !norm->ptr || !img->ptr || !vol->ptr)
         return set_error(KFX_E_NULL, "RaycastSdf: null argument");
-    if (img->w == 0 || img->h == 0) return 0;
     if (depth->w < img->w || depth->h < img->h || norm->w < img->w || norm->h < img->h)
         return set_error(KFX_E_SHAPE, "RaycastSdf: output images smaller than img");
     if (depth->pitch < img->w * 4 || img->pitch < img->w * 4 || norm->pitch < img->w * 16)
@@ -257,8 +310,6 @@ static int raycast_launch(const kfx_image* depth, const kfx_image* norm, const k
         return set_error(KFX_E_SHAPE, "RaycastSdf: volume dimensions");
     if (vol->pitch < vol->w * CELL::BYTES || vol->img_pitch < vol->pitch * (vol->h - 1) + vol->w * CELL::BYTES)
         return set_error(KFX_E_SHAPE, "RaycastSdf: volume pitch");
-
-    RayParams p;
     set_geometry(p, vol);
     set_voxel_size(p, vol);
     for (int i = 0; i < 12; ++i) p.T.m[i] = T_wc[i];
@@ -275,6 +326,48 @@ static int raycast_launch(const kfx_image* depth, const kfx_image* norm, const k
     p.far = far;
     p.trunc = trunc_dist;
     p.subpix = subpix ? 1 : 0;
+    p.tile_log2w = 5; // 32 x 2 pixel wave tiles, 2 x 2 of them per workgroup
+    p.wg_log2x = 1;
+    return 0;
+}
+
+template <typename CELL>
+static int raycast_levels_launch(int n_levels, const kfx_image* const* depth, const kfx_image* const* norm, const kfx_image* const* img,
+                                 const kfx_volume* vol, const float T_wc[12], const float* K, float near, float far,
+                                 float trunc_dist, int subpix, kfx_stream stream)
+{
+    if (n_levels < 0 || n_levels > RAY_MAX_LEVELS) return set_error(KFX_E_RANGE, "RaycastSdf(levels): number of levels");
+    if (!depth || !norm || !img || !K) return set_error(KFX_E_NULL, "RaycastSdf(levels): null argument");
+    RayParams base{};
+    RayLevels L{};
+    int blocks = 0;
+    for (int l = 0; l < n_levels; ++l) { // (coarse levels first was tried: no faster)
+        RayParams p;
+        if (int e = ray_params<CELL>(p, depth[l], norm[l], img[l], vol, T_wc, K + 4 * l, near, far, trunc_dist, subpix)) return e;
+        if (p.w == 0 || p.h == 0) continue; // an empty level launches nothing, as kfx_raycast_sdf
+        RayLevel& lv = L.lv[L.n++];
+        lv.dptr = p.dptr; lv.nptr = p.nptr; lv.iptr = p.iptr;
+        lv.dpitch = p.dpitch; lv.npitch = p.npitch; lv.ipitch = p.ipitch;
+        lv.w = p.w; lv.h = p.h;
+        lv.K = p.K;
+        lv.first_block = blocks;
+        lv.blocks_x = ceil_div(p.w, 64);
+        blocks += lv.blocks_x * ceil_div(p.h, 4);
+        base = p;
+    }
+    if (L.n == 0) return 0;
+    hipLaunchKernelGGL(k_raycast_sdf_levels<CELL>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, base, L);
+    return check_launch("kfx_raycast_sdf_levels");
+}
+
+template <typename CELL>
+static int raycast_launch(const kfx_image* depth, const kfx_image* norm, const kfx_image* img,
+                          const kfx_volume* vol, const float T_wc[12], const float K[4], float near,
+                          float far, float trunc_dist, int subpix, kfx_stream stream, const kfx_volume* colorvol = nullptr)
+{
+    RayParams p;
+    if (int e = ray_params<CELL>(p, depth, norm, img, vol, T_wc, K, near, far, trunc_dist, subpix)) return e;
+    if (p.w == 0 || p.h == 0) return 0;
 
     static const int tile_env = [] { const char* e = getenv("KFX_RAYCAST_TILE"); const int v = e ? atoi(e) : 5; return v < 0 ? 0 : (v > 6 ? 6 : v); }();
     static const int wg_env = [] { const char* e = getenv("KFX_RAYCAST_WG"); const int v = e ? atoi(e) : 1; return v < 0 ? 0 : (v > 2 ? 2 : v); }();
@@ -311,6 +404,20 @@ extern "C" int kfx_raycast_sdf_h(const kfx_image* depth, const kfx_image* norm, 
 }
 
 // RaycastSdf(depth, norm, img, vol, colorVol, T_wc, K, near, far, trunc_dist, subpix) (cu_raycast.cu:119-196)
+extern "C" int kfx_raycast_sdf_levels(int n_levels, const kfx_image* const* depth, const kfx_image* const* norm, const kfx_image* const* img,
+                                      const kfx_volume* vol, const float T_wc[12], const float* K, float near, float far,
+                                      float trunc_dist, int subpix, kfx_stream stream)
+{
+    return raycast_levels_launch<RayF32>(n_levels, depth, norm, img, vol, T_wc, K, near, far, trunc_dist, subpix, stream);
+}
+
+extern "C" int kfx_raycast_sdf_levels_h(int n_levels, const kfx_image* const* depth, const kfx_image* const* norm, const kfx_image* const* img,
+                                        const kfx_volume* vol, const float T_wc[12], const float* K, float near, float far,
+                                        float trunc_dist, int subpix, kfx_stream stream)
+{
+    return raycast_levels_launch<RayF16>(n_levels, depth, norm, img, vol, T_wc, K, near, far, trunc_dist, subpix, stream);
+}
+
 extern "C" int kfx_raycast_sdf_color(const kfx_image* depth, const kfx_image* norm, const kfx_image* img, const kfx_volume* vol,
                                      const kfx_volume* colorvol, const float T_wc[12], const float K[4], float near, float far,
                                      float trunc_dist, int subpix, kfx_stream stream)

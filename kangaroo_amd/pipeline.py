@@ -96,13 +96,15 @@ class TrackingPipeline(FramePipeline):
 
     LEVELS = 4
 
-    def __init__(self, ops, dims, boxmin, boxmax, w, h, its=None, icp_c=0.1, max_rmse=0.10, device_icp=False, **kw):
+    def __init__(self, ops, dims, boxmin, boxmax, w, h, its=None, icp_c=0.1, max_rmse=0.10, device_icp=False, one_raycast=None, **kw):
         """device_icp: run the whole refinement loop on the GPU (ops.IcpRefine, one synchronisation per frame) instead
-        of one PoseRefinementProjectiveIcpPointPlane call + host solve per iteration."""
+        of one PoseRefinementProjectiveIcpPointPlane call + host solve per iteration.  one_raycast: render all pyramid
+        levels with one launch (ops.RaycastSdfLevels; default: when the operator set has it)."""
         from . import tracking
         super().__init__(ops, dims, boxmin, boxmax, w, h, **kw)
         self.tracking = tracking
         self.device_icp = bool(device_icp) and hasattr(ops, "IcpRefine")
+        self.one_raycast = hasattr(ops, "RaycastSdfLevels") if one_raycast is None else (bool(one_raycast) and hasattr(ops, "RaycastSdfLevels"))
         self.its = tuple(tracking.DEFAULT_ITS if its is None else its)
         self.icp_c, self.max_rmse = float(icp_c), float(max_rmse)
         L = self.LEVELS
@@ -137,11 +139,15 @@ class TrackingPipeline(FramePipeline):
             self._fuse_at(self.T_wl)
         else:
             T34 = self.T_wl[:3].astype(np.float32)
-            for l in range(self.LEVELS):
-                if self.its[l] > 0:
+            lv = [l for l in range(self.LEVELS) if self.its[l] > 0]
+            if self.one_raycast:   # the per-level RaycastSdf calls as one launch: same images, overlapping marches
+                o.RaycastSdfLevels([(self.pyr_d[l], self.pyr_n[l], self.pyr_i[l]) for l in lv], self.vol, T34,
+                                   [self.K_levels[l] for l in lv], self.near, self.far, self.trunc, True)
+            for l in lv:
+                if not self.one_raycast:
                     o.RaycastSdf(self.pyr_d[l], self.pyr_n[l], self.pyr_i[l], self.vol, T34, self.K_levels[l], self.near,
                                  self.far, self.trunc, True)
-                    o.DepthToVbo(self.pyr_v[l], self.pyr_d[l], self.K_levels[l])
+                o.DepthToVbo(self.pyr_v[l], self.pyr_d[l], self.K_levels[l])
             if self.device_icp:
                 T_lp, self.rmse, _, self.tracking_good = o.IcpRefine(self.kin_v, self.pyr_v, self.pyr_n, self.K_levels, self.its,
                                                                      self.icp_c, self.max_rmse, self.scratch, self.debug)

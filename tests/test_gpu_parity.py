@@ -1250,3 +1250,51 @@ def test_gpu_division_by_uniform_divisor_is_the_ieee_quotient(roo):
         assert L.kfx_debug_div_uniform_check(C.c_float(b), C.c_void_p(out.data_ptr()), None) == 0
         bad, tested = (int(v) for v in out.cpu())
         assert tested > 1_300_000_000 and bad == 0, (b, bad, tested)
+
+
+def test_gpu_raycast_levels_equal_per_level_calls(roo):
+    """kfx_raycast_sdf_levels (all pyramid levels of the tracking loop in one launch) writes, per level, exactly what
+    kfx_raycast_sdf writes: fp32 and fp16 cells, odd level sizes, an empty level list, and the tracked pipeline
+    follows the same trajectory with either."""
+    import torch
+    from kangaroo_amd.pipeline import TrackingPipeline
+    N, w, h, scene = 96, 200, 148, "room"
+    bmin, bmax, near, far = scenes.SCENES[scene]
+    K = scenes.intrinsics(w, h)
+    tr = scenes.trunc_dist(bmin, bmax, (N, N, N))
+    for kind in ("f32", "f16"):
+        vol = roo.BoundedVolume(N, N, N, bmin, bmax, kind=kind)
+        roo.SdfReset(vol, float("nan"))
+        f, vbo, nrm = roo.Image(w, h), roo.Image(w, h, "f32x4"), roo.Image(w, h, "f32x4")
+        for i in range(2):
+            T_wc = scenes.orbit_pose(i, 30)
+            roo.BilateralFilter(f, T.upload_image(roo, scenes.render_depth(scene, w, h, T_wc, K)), **scenes.BILATERAL)
+            roo.DepthToVbo(vbo, f, K)
+            roo.NormalsFromVbo(nrm, vbo)
+            roo.SdfFuse(vol, f, nrm, scenes.se3_inverse(T_wc), K, tr, scenes.MAX_W, scenes.MIN_COS_THETA)
+        levels = (0, 1, 3)
+        sizes = {l: (max(w >> l, 1), max(h >> l, 1)) for l in levels}
+        Ks = [scenes.intrinsics_level(K, l) for l in levels]
+        mk = lambda: [(roo.Image(*sizes[l]), roo.Image(*sizes[l], "f32x4"), roo.Image(*sizes[l])) for l in levels]
+        a, b = mk(), mk()
+        T_wc = scenes.orbit_pose(1, 30)
+        for (d, n, i), Kl in zip(a, Ks):
+            roo.RaycastSdf(d, n, i, vol, T_wc, Kl, near, far, tr, True)
+        roo.RaycastSdfLevels(b, vol, T_wc, Ks, near, far, tr, True)
+        for x, y in zip(a, b):
+            for p_, q_ in zip(x, y):
+                assert T.nan_equal(p_.MemcpyToHost(), q_.MemcpyToHost())
+        assert np.isfinite(a[0][0].MemcpyToHost()).mean() > 0.2
+        roo.RaycastSdfLevels([], vol, T_wc, [], near, far, tr, True)   # nothing to do, no error
+    poses = []
+    for one in (False, True):
+        pipe = TrackingPipeline(roo, (N, N, N), bmin, bmax, 320, 240, near=near, far=far, one_raycast=one)
+        assert pipe.one_raycast == one
+        tr_ = []
+        for i in range(4):
+            T_true = scenes.orbit_pose(i, 30)
+            pipe.raw.MemcpyFromHost(scenes.render_depth(scene, 320, 240, T_true, pipe.K))
+            tr_.append(pipe.step(T_wl_init=T_true if i == 0 else None).copy())
+        poses.append(np.stack(tr_))
+        torch.cuda.synchronize()
+    assert np.array_equal(poses[0], poses[1])
