@@ -14,7 +14,7 @@
 //   SdfFuse(work_vol, kin_d, kin_n, T_wl^-1, K, trunc_dist, max_w, mincostheta)            (:345-356)
 //
 // Host code only; all device work happens in libkfx behind the roo:: wrappers.
-// Usage: kinectfusion_headless [--res N] [--frames F] [--width W] [--height H] [--fast] [--track | --device-icp] [--one-raycast]
+// Usage: kinectfusion_headless [--res N] [--frames F] [--width W] [--height H] [--fast] [--track | --device-icp] [--fused-launches]
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -76,7 +76,7 @@ int main(int argc, char** argv)
         else if (!strcmp(argv[i], "--height") && i + 1 < argc) h = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--fast")) fast = true;
         else if (!strcmp(argv[i], "--track")) track = true;
-        else if (!strcmp(argv[i], "--one-raycast")) one_raycast = true;   // all pyramid levels rendered by one launch
+        else if (!strcmp(argv[i], "--one-raycast") || !strcmp(argv[i], "--fused-launches")) one_raycast = true;   // additions beside the reference API: all pyramid levels rendered by one launch, vbo + normals in one launch
         else if (!strcmp(argv[i], "--device-icp")) track = device_icp = true;   // the refinement loop as one device-side chain
     }
     if (kfx_device_count() < 1) { fprintf(stderr, "no HIP device\n"); return 2; }
@@ -130,8 +130,12 @@ int main(int argc, char** argv)
         BilateralFilter<float,float>(kin_d[0], dKinectMeters, bigs, bigr, biwin, 0.2f);
         BoxReduceIgnoreInvalid<float,MaxLevels,float>(kin_d);
         for (int l = 0; l < MaxLevels; ++l) {
-            DepthToVbo<float>(kin_v[l], kin_d[l], K[l]);
-            NormalsFromVbo(kin_n[l], kin_v[l]);
+            if (one_raycast) {   // --fused-launches: both maps from one launch, same images
+                DepthToVboNormals(kin_v[l], kin_n[l], kin_d[l], K[l]);
+            } else {
+                DepthToVbo<float>(kin_v[l], kin_d[l], K[l]);
+                NormalsFromVbo(kin_n[l], kin_v[l]);
+            }
         }
         if (f == 0) {
             SdfReset(vol, std::numeric_limits<float>::quiet_NaN());

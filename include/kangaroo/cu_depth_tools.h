@@ -52,6 +52,13 @@ inline void DepthToVbo( Image<float4> dVbo, const Image<T> dKinectDepth, float f
     DepthToVbo<T>(dVbo, dKinectDepth, ImageIntrinsics(fu,fv,u0,v0), scale);
 }
 
+// Addition next to the reference API: DepthToVbo<float> followed by NormalsFromVbo in one launch; dVbo and dN hold exactly
+// what the two separate calls write (kfx_depth_to_vbo_normals_f32).
+inline void DepthToVboNormals( Image<float4> dVbo, Image<float4> dN, const Image<float> dKinectDepth, ImageIntrinsics K, float scale = 1.0f)
+{
+    GpuNoteStatus(kfx_depth_to_vbo_normals_f32(dVbo.abi(), dN.abi(), dKinectDepth.abi(), &K.fu, scale, 0));
+}
+
 // roo::ImageKeyframe<T> (reference ImageKeyframe.h:10-14 over ImageTransformProject, ImageIntrinsics.h:202-212): a camera
 // {K, T_iw} with its image; 96 bytes, layout-identical to kfx_keyframe.
 struct ImageTransformProject

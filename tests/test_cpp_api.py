@@ -98,7 +98,7 @@ def test_cpp_api_on_device():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("extra", [[], ["--fast"], ["--track"], ["--device-icp"], ["--track", "--one-raycast"]])
+@pytest.mark.parametrize("extra", [[], ["--fast"], ["--track"], ["--device-icp"], ["--track", "--fused-launches"]])
 def test_headless_kinectfusion_app(extra):
     _build()
     out = subprocess.run([os.path.join(APPS, "kinectfusion_headless"), "--res", "128", "--frames", "8"] + extra,
