@@ -555,25 +555,29 @@ __global__ __launch_bounds__(256) void k_sdf_fuse_tiled(const FuseParams p, cons
 
 // Diagnostics: how many voxels the fuse kernels would update (same predicate, no volume access).
 template <bool FAST>
-__global__ __launch_bounds__(256) void k_sdf_fuse_count(const FuseParams p, unsigned long long* __restrict__ count)
+__global__ __launch_bounds__(256) void k_sdf_fuse_count(const FuseParams p, const int bx, const int by, const int bz,
+                                                        unsigned long long* __restrict__ count)
 {
-    __shared__ float s_pz[FUSE_ZC];
+    // a workgroup walks bricks of 64 x FUSE_ROWS x FUSE_ZC voxels with a grid stride and adds its total once: a single
+    // counter takes ~10 ns per atomic, so one atomic per wave-brick (131 k at 512^3) made this kernel 1.6 ms
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int x = blockIdx.x * 64 + lane;
-    const int y = blockIdx.y * FUSE_ROWS + wv;
-    const bool live = x < p.X && y < p.Y;
-    const int zbeg = blockIdx.z * FUSE_ZC;
-    const int zend = min(zbeg + FUSE_ZC, p.Z);
-    if (threadIdx.x < FUSE_ZC) s_pz[threadIdx.x] = p.bmin.z + p.size.z * (float)(zbeg + (int)threadIdx.x + p.zoff) / p.d1;
-    __syncthreads();
-    CamXY<FAST> cam;
-    cam.init(p, p.bmin.x + p.size.x * (float)x / p.w1, p.bmin.y + p.size.y * (float)y / p.h1);
     unsigned n = 0;
-    if (live)
-        for (int z = zbeg; z < zend; ++z) n += observe<FAST, false>(p, cam.at(p, s_pz[z - zbeg])).ok ? 1u : 0u;
+    for (int b = blockIdx.x; b < bx * by * bz; b += gridDim.x) {
+        const int x = (b % bx) * 64 + lane;
+        const int y = ((b / bx) % by) * FUSE_ROWS + wv;
+        const int zbeg = (b / (bx * by)) * FUSE_ZC;
+        const int zend = min(zbeg + FUSE_ZC, p.Z);
+        if (x >= p.X || y >= p.Y) continue;
+        CamXY<FAST> cam;
+        cam.init(p, p.bmin.x + p.size.x * (float)x / p.w1, p.bmin.y + p.size.y * (float)y / p.h1);
+        for (int z = zbeg; z < zend; ++z) {
+            const float pz = p.bmin.z + p.size.z * (float)(z + p.zoff) / p.d1;
+            n += observe<FAST, false>(p, cam.at(p, pz)).ok ? 1u : 0u;
+        }
+    }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) n += __shfl_xor(n, off, 64); // wave64 butterfly sum
-    if (lane == 0 && n) atomicAdd(count, (unsigned long long)n);        // one atomic per wave
+    if (lane == 0 && n) atomicAdd(count, (unsigned long long)n);
 }
 
 // SdfReset: contiguous fill of (trunc, 0) over [ptr, RowPtr(h-1,d-1)+w) (Volume.h:343-356).
@@ -1177,9 +1181,12 @@ extern "C" int kfx_sdf_fuse_count(const kfx_volume* vol, const kfx_image* depth,
     bool small_images = false;
     if (int e = fuse_params(p, &small_images, vol, depth, norm, T_cw, K, trunc_dist, 0.f, mincostheta, flags)) return e;
     if (p.X == 0 || p.Y == 0 || p.Z == 0) return 0;
-    dim3 grid(ceil_div(p.X, 64), ceil_div(p.Y, FUSE_ROWS), ceil_div(p.Z, FUSE_ZC));
-    if (math_mode() == KFX_MATH_FAST) hipLaunchKernelGGL(k_sdf_fuse_count<true>, grid, dim3(256), 0, (hipStream_t)stream, p, d_count);
-    else hipLaunchKernelGGL(k_sdf_fuse_count<false>, grid, dim3(256), 0, (hipStream_t)stream, p, d_count);
+    const int bx = ceil_div(p.X, 64), by = ceil_div(p.Y, FUSE_ROWS), bz = ceil_div(p.Z, FUSE_ZC);
+    const long long total = (long long)bx * by * bz;
+    if (total > 0x7fffffffLL) return set_error(KFX_E_RANGE, "kfx_sdf_fuse_count: volume too large");
+    dim3 grid((unsigned)(total < 4096 ? total : 4096));
+    if (math_mode() == KFX_MATH_FAST) hipLaunchKernelGGL(k_sdf_fuse_count<true>, grid, dim3(256), 0, (hipStream_t)stream, p, bx, by, bz, d_count);
+    else hipLaunchKernelGGL(k_sdf_fuse_count<false>, grid, dim3(256), 0, (hipStream_t)stream, p, bx, by, bz, d_count);
     return check_launch("kfx_sdf_fuse_count");
 }
 
