@@ -1298,3 +1298,16 @@ def test_gpu_raycast_levels_equal_per_level_calls(roo):
         poses.append(np.stack(tr_))
         torch.cuda.synchronize()
     assert np.array_equal(poses[0], poses[1])
+
+
+def test_gpu_sampler_general_paths_vs_oracle():
+    """The raycast / mesh samplers without their two shortcuts (KFX_SAMPLER_SHORTCUTS=0: hardware division instead of
+    div_uniform, 64-bit addresses instead of base + 32-bit offset) -- the paths that volumes above 4 GiB take -- rerun the
+    oracle-parity tests of raycast, colour raycast, slab march and marching cubes in a child process."""
+    import subprocess
+    import sys
+    env = dict(os.environ, KFX_SAMPLER_SHORTCUTS="0")
+    sel = "fuse_raycast_vs_oracle or colour_fusion_and_raycast or exact_slab_raycast or marching_cubes or half_cells_fuse_raycast"
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-x", "-q", "-k", sel],
+                         env=env, capture_output=True, text=True, timeout=1200, cwd=T.ROOT)
+    assert out.returncode == 0 and " passed" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
