@@ -2,7 +2,7 @@
 
 The reference copies the volume to the host, marches the (w-1)(h-1)(d-1) cubes one by one and hands the lists to
 Assimp's PLY exporter.  Here: kfx_mc_count (triangles per cube, in the reference's emission order) -> exclusive
-prefix sum and compaction of the active cubes (torch.cumsum / torch.nonzero on the device) -> kfx_mc_emit (one
+compaction of the active cubes and prefix sum over them (torch.nonzero / torch.cumsum on the device) -> kfx_mc_emit (one
 thread per active cube: vertices, normals, grey colours into their slots).  The
 arrays equal the host algorithm's element for element (tests compare with the oracle); only the finished arrays
 cross PCIe.
@@ -32,12 +32,13 @@ def ExtractMesh(vol, colorVol=None, stream=None):
     dev = vol.storage.device
     counts = torch.empty(cx * cy * cz, dtype=torch.uint8, device=dev)
     _lib.check(L.kfx_mc_count(vol.ref(), C.c_void_p(counts.data_ptr()), _stream(stream)))
-    incl = torch.cumsum(counts, 0, dtype=torch.int64)
+    active = torch.nonzero(counts).reshape(-1)                        # cubes with triangles, ascending = emission order
+    ca = counts[active].to(torch.int64)                               # the scan only needs them: empty cubes add nothing
+    incl = torch.cumsum(ca, 0)
     ntri = int(incl[-1].item()) if incl.numel() else 0
     if ntri >= 2 ** 32 // 3:
         raise ValueError("mesh too large for 32-bit vertex offsets")
-    active = torch.nonzero(counts).reshape(-1)                        # cubes with triangles, ascending = emission order
-    tri_offset = (incl[active] - counts[active]).to(torch.int32)     # exclusive prefix sum at those cubes
+    tri_offset = (incl - ca).to(torch.int32)                          # exclusive prefix sum at those cubes
     verts = torch.empty((3 * ntri, 3), dtype=torch.float32, device=dev)
     norms = torch.empty((3 * ntri, 3), dtype=torch.float32, device=dev)
     has_color = colorVol is not None and min(colorVol.w, colorVol.h, colorVol.d) >= 8
