@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void k_icp_point_plane(const IcpParams p)
     lss_zero(sum);
 
     Pose KT_lr = p.KT_lr, T_rl = p.T_rl;
-    if (p.dev_pose) { // uniform loads: the pose was written by k_icp_solve of the previous iteration
+    if (p.dev_pose) { // uniform loads: the pose was written by k_lss_final_solve of the previous iteration
 #pragma unroll
         for (int i = 0; i < 12; ++i) { KT_lr.m[i] = p.dev_pose[i]; T_rl.m[i] = p.dev_pose[12 + i]; }
     }
@@ -279,7 +279,7 @@ __global__ void k_icp_refine_init(RefineState* st, const K4 K)
 
 // one Gauss-Newton step from the summed system in sums[0..28] (main.cpp:312-333); K_next: intrinsics of the level the
 // NEXT evaluation runs on
-__global__ void k_icp_solve(RefineState* st, const float* __restrict__ sums, const int rotation_only, const float max_rmse, const K4 K_next)
+__device__ void icp_solve_step(RefineState* st, const float* sums, const int rotation_only, const float max_rmse, const float K_next[4])
 {
     double JTJ[36], JTy[6], x[6] = {0, 0, 0, 0, 0, 0};
     int i = 6;
@@ -311,7 +311,33 @@ __global__ void k_icp_solve(RefineState* st, const float* __restrict__ sums, con
         for (int a = 0; a < 6; ++a) { x[a] = -x[a]; finite = finite && isfinite(x[a]); }
         if (finite) se3_right_multiply_exp(st->T, x, false);
     }
-    publish_pose(st, K_next.k);
+    publish_pose(st, K_next);
+}
+
+
+// k_lss_final followed by the 6x6 step (icp_solve_step) as one launch (the device-resident loop is a chain of ~5 us kernels: every launch
+// saved is time saved).  Thread 0 holds the summed system after the tree; it stores it (so sums[0..28] is what
+// k_lss_final leaves) and runs the same solve on it.
+__global__ __launch_bounds__(256) void k_lss_final_solve(float* sums, const int nblocks, RefineState* st, const int rotation_only,
+                                                         const float max_rmse, const K4 K_next)
+{
+    __shared__ float lds[LSS_WORDS * 128];
+    __shared__ float s_sum[LSS_WORDS];
+    const int tid = threadIdx.x;
+    Lss acc;
+    lss_zero(acc);
+    for (int b = tid; b < nblocks; b += 256) {
+        const float* s = sums + (size_t)b * LSS_WORDS;
+#pragma unroll
+        for (int k = 0; k < 28; ++k) acc.f[k] += s[k];
+        acc.obs += __float_as_uint(s[28]);
+    }
+    lss_tree(acc, tid, 256, lds);
+    if (tid == 0) {
+        lss_store(sums, acc);
+        lss_store(s_sum, acc);
+        icp_solve_step(st, s_sum, rotation_only, max_rmse, K_next.k);
+    }
 }
 
 static unsigned gcd_u(unsigned a, unsigned b) { return b == 0 ? a : gcd_u(b, a % b); }
@@ -374,7 +400,7 @@ extern "C" int kfx_icp_point_plane(const kfx_image* Pl, const kfx_image* Pr, con
 }
 
 // The coarse-to-fine loop of main.cpp:301-337 enqueued as one chain of kernels: for every level (coarsest first) and
-// iteration, k_icp_point_plane -> k_lss_final -> k_icp_solve, all on `stream`, one synchronisation at the end.
+// iteration, k_icp_point_plane -> k_lss_final_solve (block sum + 6x6 step), all on `stream`, one synchronisation at the end.
 // levels[l]: the three vertex / normal maps, the level's intrinsics and its iteration count, given COARSEST FIRST;
 // the first level with more than one level in total is solved for rotation only, as the application does.
 // workspace: >= max over levels of (blocks * 116) + 512 bytes; result: T_lp (row-major 3x4, float64), rmse, obs,
@@ -431,11 +457,10 @@ extern "C" int kfx_icp_refine(const kfx_icp_level* levels, int n_levels, float c
             if (levels[m].iterations > 0 && levels[m].Pl.w && levels[m].Pl.h) { nxt = m; break; }
         for (int it = 0; it < L.iterations; ++it) {
             hipLaunchKernelGGL(k_icp_point_plane, grid, block, lds_bytes, s, p);
-            hipLaunchKernelGGL(k_lss_final, dim3(1), dim3(256), 0, s, sums, nblocks);
             K4 kn;
             const float* Kn = (it + 1 < L.iterations || nxt < 0) ? L.K : levels[nxt].K;
             for (int i = 0; i < 4; ++i) kn.k[i] = Kn[i];
-            hipLaunchKernelGGL(k_icp_solve, dim3(1), dim3(1), 0, s, st, (const float*)sums, L.rotation_only ? 1 : 0, max_rmse, kn);
+            hipLaunchKernelGGL(k_lss_final_solve, dim3(1), dim3(256), 0, s, sums, nblocks, st, L.rotation_only ? 1 : 0, max_rmse, kn);
         }
     }
     int e0 = check_launch("kfx_icp_refine");
