@@ -1094,9 +1094,10 @@ static int fuse_launch(const kfx_volume* vol, const kfx_image* depth, const kfx_
     static const int tiled = [] { const char* e = getenv("KFX_FUSE_TILED"); return e ? atoi(e) : 1; }();
     static const int cap_env = [] { const char* e = getenv("KFX_FUSE_CAP"); const int v = e ? atoi(e) : 0; return v <= 0 ? 0 : (v < 64 ? 64 : (v > 8192 ? 8192 : v)); }();
     if (tiled && vec2 && small_images) {
-        // slices per iteration: 2 in fast mode (memory-bound: more reads in flight), 1 in exact mode (VALU-bound)
+        // slices per iteration: 2 in fast mode (memory-bound: more reads in flight), 4 where the large LDS tile leaves
+        // only 3 workgroups per CU (1280x960 at 512^3: 0.568 -> 0.538 ms; at 6 workgroups per CU 4 is slower), 1 in exact
+        // mode (VALU-bound)
         static const int zu_env = [] { const char* e = getenv("KFX_FUSE_ZU"); return e ? atoi(e) : 0; }();
-        const int zu = zu_env ? zu_env : (fast ? 2 : 1);
         // LDS tile capacity per z-range.  A brick's pixel rectangle grows with the pixels-per-voxel ratio
         // r = f * voxel / Z: 1536 texels (24 KiB, 6 workgroups per CU) hold it up to r ~ 1.3; beyond that more
         // bricks would fall back to global gathers, so the capacity grows with r^2 up to 3072 texels (48 KiB,
@@ -1120,7 +1121,9 @@ static int fuse_launch(const kfx_volume* vol, const kfx_image* depth, const kfx_
             q.Z = z1 - z0;
             dim3 grid(ceil_div(q.X, TB_X), ceil_div(q.Y, TB_Y), ceil_div(q.Z, FUSE_ZC));
             const size_t lds = (size_t)cap_px * sizeof(float4);
-            if (fast && zu == 2) hipLaunchKernelGGL((k_sdf_fuse_tiled<true, 2, CELL>), grid, dim3(256), lds, s, q, cap_px);
+            const int zu = zu_env ? zu_env : (fast ? (cap_px > 2560 ? 4 : 2) : 1);
+            if (fast && zu == 4) hipLaunchKernelGGL((k_sdf_fuse_tiled<true, 4, CELL>), grid, dim3(256), lds, s, q, cap_px);
+            else if (fast && zu == 2) hipLaunchKernelGGL((k_sdf_fuse_tiled<true, 2, CELL>), grid, dim3(256), lds, s, q, cap_px);
             else if (fast) hipLaunchKernelGGL((k_sdf_fuse_tiled<true, 1, CELL>), grid, dim3(256), lds, s, q, cap_px);
             else if (zu == 2) hipLaunchKernelGGL((k_sdf_fuse_tiled<false, 2, CELL>), grid, dim3(256), lds, s, q, cap_px);
             else hipLaunchKernelGGL((k_sdf_fuse_tiled<false, 1, CELL>), grid, dim3(256), lds, s, q, cap_px);
