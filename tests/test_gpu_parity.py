@@ -1311,3 +1311,51 @@ def test_gpu_sampler_general_paths_vs_oracle():
     out = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-x", "-q", "-k", sel],
                          env=env, capture_output=True, text=True, timeout=1200, cwd=T.ROOT)
     assert out.returncode == 0 and " passed" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
+
+
+_COLOUR_FULL_SIZE = r"""
+import sys, hashlib, numpy as np, torch
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+from kangaroo_amd import roo, scenes
+N, w, h = 512, 640, 480
+bmin, bmax, near, far = scenes.SCENES["room"]
+K = scenes.intrinsics(w, h)
+tr = scenes.trunc_dist(bmin, bmax, (N, N, N))
+roo.set_math_mode(sys.argv[2])
+vol, cvol = roo.BoundedVolume(N, N, N, bmin, bmax), roo.BoundedVolume(N, N, N, bmin, bmax, kind="c32")
+roo.SdfReset(vol, float("nan")); roo.ColorReset(cvol)
+f, vbo, nrm, rgb = roo.Image(w, h), roo.Image(w, h, "f32x4"), roo.Image(w, h, "f32x4"), roo.Image(w, h, "u8x3")
+rgb.MemcpyFromHost(np.random.default_rng(5).integers(0, 256, (h, w, 3), dtype=np.uint8))
+for i in range(3):
+    T_wc = scenes.orbit_pose(3 * i, 30)
+    raw = roo.Image(w, h).MemcpyFromHost(scenes.render_depth("room", w, h, T_wc, K))
+    roo.BilateralFilter(f, raw, **scenes.BILATERAL); roo.DepthToVbo(vbo, f, K); roo.NormalsFromVbo(nrm, vbo)
+    T_cw = scenes.se3_inverse(T_wc)
+    T_iw = T_cw.copy(); T_iw[0, 3] += 0.02   # colour camera 2 cm beside the depth camera
+    roo.SdfFuseColor(vol, cvol, f, nrm, T_cw, K, rgb, T_iw, K, tr, scenes.MAX_W, scenes.MIN_COS_THETA)
+torch.cuda.synchronize()
+hv = hashlib.sha256(vol.storage.cpu().numpy().tobytes()).hexdigest()
+hc = hashlib.sha256(cvol.storage.cpu().numpy().tobytes()).hexdigest()
+touched = int((cvol.tensor() != 0.5).sum())
+print("DIGEST", hv, hc, touched)
+"""
+
+
+@pytest.mark.parametrize("math", ["exact", "fast"])
+def test_gpu_colour_fusion_full_size_tiled_equals_untiled(math, tmp_path):
+    """BASELINE size (512^3, 640x480), three frames with a displaced colour camera: the LDS-tiled colour fusion and the
+    global-gather kernel (KFX_FUSE_TILED=0) must leave byte-identical SDF and colour volumes (both read the same texels:
+    the tile is a copy), in either numerics mode."""
+    import subprocess
+    import sys
+    script = tmp_path / "colour_full.py"
+    script.write_text(_COLOUR_FULL_SIZE)
+    digests = []
+    for tiled in ("1", "0"):
+        out = subprocess.run([sys.executable, str(script), T.ROOT, math], env=dict(os.environ, KFX_FUSE_TILED=tiled),
+                             capture_output=True, text=True, timeout=900)
+        line = [l for l in out.stdout.splitlines() if l.startswith("DIGEST")]
+        assert out.returncode == 0 and line, out.stdout[-2000:] + out.stderr[-2000:]
+        digests.append(line[0].split()[1:])
+    assert digests[0] == digests[1], digests
+    assert int(digests[0][2]) > 10_000_000
