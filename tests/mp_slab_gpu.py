@@ -1,0 +1,91 @@
+"""Two (or more) ranks of the Z-slab pipeline on ONE GPU, real HIP operators, collectives over gloo (RCCL needs one GPU per
+rank; the data path, the composite kernels and the march hand-over are the same code).  Launched by
+tests/test_gpu_multi_rank.py through torch.distributed.run; every rank checks its result against the single-volume pipeline
+it runs itself and prints MP_OK.
+
+    python -m torch.distributed.run --nproc-per-node 2 tests/mp_slab_gpu.py <halo> <raycast> [tracking]
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from kangaroo_amd import roo, scenes  # noqa: E402
+from kangaroo_amd.pipeline import FramePipeline, SlabPipeline, TrackingPipeline, TrackingSlabPipeline  # noqa: E402
+import kfx_testlib as T  # noqa: E402
+
+halo, raycast = sys.argv[1], sys.argv[2]
+tracking = len(sys.argv) > 3 and sys.argv[3] == "tracking"
+torch.cuda.set_device(0)
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+N, W, H, FRAMES, scene = 96, 160, 120, 3, "room"
+bmin, bmax, near, far = scenes.SCENES[scene]
+
+
+def same(a, b):
+    return T.nan_equal(a, b)
+
+
+if not tracking:
+    pipe = SlabPipeline(roo, dist, (N, N, N), bmin, bmax, W, H, halo=halo, raycast=raycast, near=near, far=far)
+    ref = FramePipeline(roo, (N, N, N), bmin, bmax, W, H, near=near, far=far)
+    for i in range(FRAMES):
+        T_wc = scenes.orbit_pose(i, 8)
+        depth = scenes.render_depth(scene, W, H, T_wc, pipe.K)
+        pipe.raw.MemcpyFromHost(depth)
+        pipe.step(T_wc)
+        ref.raw.MemcpyFromHost(depth)
+        ref.preprocess()
+        roo.SdfFuse(ref.vol, ref.filtered, ref.normals, scenes.se3_inverse(T_wc), ref.K, ref.trunc, ref.max_w, ref.mincostheta, full_extent=True)
+        ref.raycast(T_wc)
+    torch.cuda.synchronize()
+    # (1) every stored plane (owned + ghost) equals the same plane of the single volume, bit for bit
+    full = ref.vol.MemcpyToHost()
+    mine = pipe.vol.MemcpyToHost()
+    assert same(mine, full[pipe.s0:pipe.s1]), "rank %d: slab planes differ from the single volume" % rank
+    d, n, im = pipe.ray_d.MemcpyToHost(), pipe.ray_n.MemcpyToHost(), pipe.ray_i.MemcpyToHost()
+    rd, rn, ri = ref.ray_d.MemcpyToHost(), ref.ray_n.MemcpyToHost(), ref.ray_i.MemcpyToHost()
+    if raycast == "exact":   # (2a) the handed-over march reproduces RaycastSdf exactly
+        assert same(d, rd) and same(n, rn) and same(im, ri), "rank %d: exact slab march differs from RaycastSdf" % rank
+        assert 1 <= pipe.rounds <= world + 3
+    else:                    # (2b) nearest-hit composite: same hits up to the slab-entry resampling
+        hit, rhit = np.isfinite(d), np.isfinite(rd)
+        assert (hit != rhit).mean() < 0.01, (hit != rhit).mean()
+        both = hit & rhit
+        voxel = (bmax[0] - bmin[0]) / (N - 1)
+        err = np.abs(d[both] - rd[both])   # the march restarts at each slab entry: a fraction of a voxel (as tests/test_multi_rank_cpu.py)
+        assert both.mean() > 0.3 and np.median(err) < 0.02 * voxel and np.quantile(err, 0.99) < 0.5 * voxel, (np.median(err) / voxel, np.quantile(err, 0.99) / voxel)
+        assert (np.abs(n[both] - rn[both]).max(axis=1) < 0.05).mean() > 0.98
+        assert (n[hit][:, 3] == 1).all() and (n[~hit] == 0).all() and (im[~hit] == 0).all()
+    # (3) all ranks hold the same images
+    chk = torch.tensor(np.nan_to_num(d, nan=-1.0).view(np.int32).astype(np.int64).sum()).reshape(1)
+    both = torch.cat([chk, -chk])
+    dist.all_reduce(both, op=dist.ReduceOp.MAX)
+    assert int(both[0]) == -int(both[1]), "ranks hold different images"
+else:
+    pipe = TrackingSlabPipeline(roo, dist, (N, N, N), bmin, bmax, 320, 240, halo=halo, raycast=raycast, near=near, far=far)
+    ref = TrackingPipeline(roo, (N, N, N), bmin, bmax, 320, 240, near=near, far=far)
+    for i in range(4):
+        T_true = scenes.orbit_pose(i, 30)
+        depth = scenes.render_depth(scene, 320, 240, T_true, pipe.K)
+        pipe.raw.MemcpyFromHost(depth)
+        ref.raw.MemcpyFromHost(depth)
+        Ta = pipe.step(T_wl_init=T_true if i == 0 else None)
+        Tb = ref.step(T_wl_init=T_true if i == 0 else None)
+        if raycast == "exact":
+            assert np.array_equal(Ta, Tb), "rank %d frame %d: tracked pose differs from the single-GPU loop" % (rank, i)
+        else:
+            assert np.abs(Ta - Tb).max() < 2e-3, np.abs(Ta - Tb).max()
+        assert pipe.tracking_good
+    torch.cuda.synchronize()
+    if raycast == "exact":
+        assert same(pipe.vol.MemcpyToHost(), ref.vol.MemcpyToHost()[pipe.s0:pipe.s1])
+dist.barrier()
+print("MP_OK rank %d of %d (%s, %s%s)" % (rank, world, halo, raycast, ", tracking" if tracking else ""), flush=True)
+dist.destroy_process_group()
