@@ -266,6 +266,42 @@ class SlabPipeline(FramePipeline):
         if self.world > 1:
             self.composite(d, n, i)
 
+    def raycast_levels_into(self, outputs, K_levels, T_wc):
+        """Several renderings of the model from one pose (the tracking loop's pyramid levels): outputs = [(d, n, i), ...].
+        Composite mode renders them with one launch where the operator set has RaycastSdfLevels and merges them with ONE
+        pair of all-reduces (keys and payloads of all levels side by side) instead of a pair per level; the images equal
+        those of per-level raycast_into calls.  Exact mode hands the march over level by level."""
+        if self.raycast_mode == "exact":
+            for (d, n, i), K in zip(outputs, K_levels):
+                self.raycast_exact(T_wc, d, n, i, K)
+            return
+        if hasattr(self.ops, "RaycastSdfLevels") and len(outputs) > 1:
+            self.ops.RaycastSdfLevels(outputs, self.vol, T_wc, K_levels, self.near, self.far, self.trunc, True)
+        else:
+            for (d, n, i), K in zip(outputs, K_levels):
+                self.ops.RaycastSdf(d, n, i, self.vol, T_wc, K, self.near, self.far, self.trunc, True)
+        if self.world == 1:
+            return
+        if not hasattr(self.ops, "CompositePack"):
+            for d, n, i in outputs:
+                self.composite(d, n, i)
+            return
+        import torch
+        sizes = [d.w * d.h for d, _, _ in outputs]
+        total = sum(sizes)
+        key = self._scratch("keys", (total,), torch.int64, outputs[0][0])
+        payload = self._scratch("payloads", (total * 5,), torch.float32, outputs[0][0])
+        offs = np.concatenate([[0], np.cumsum(sizes)]).astype(int)
+        parts = [(key[offs[k]:offs[k + 1]], payload[5 * offs[k]:5 * offs[k + 1]]) for k in range(len(outputs))]
+        for (d, n, i), (kk, _) in zip(outputs, parts):
+            self.ops.CompositePack(d, n, i, kk, self.rank)
+        self.dist.all_reduce(key, op=self.dist.ReduceOp.MIN)
+        for (d, n, i), (kk, pp) in zip(outputs, parts):
+            self.ops.CompositeSelect(d, n, i, kk, pp, self.rank)
+        self.dist.all_reduce(payload, op=self.dist.ReduceOp.SUM)
+        for (d, n, i), (kk, pp) in zip(outputs, parts):
+            self.ops.CompositeUnpack(d, n, i, kk, pp)
+
     def _scratch(self, name, shape, dtype, like):
         """Per-shape device scratch tensors (march state, composite key / payload), allocated once."""
         import torch
@@ -383,10 +419,10 @@ class TrackingSlabPipeline(SlabPipeline):
             self._fuse_at(self.T_wl)
         else:
             T34 = self.T_wl[:3].astype(np.float32)
-            for l in range(self.LEVELS):
-                if self.its[l] > 0:
-                    self.raycast_into(self.pyr_d[l], self.pyr_n[l], self.pyr_i[l], self.K_levels[l], T34)
-                    o.DepthToVbo(self.pyr_v[l], self.pyr_d[l], self.K_levels[l])
+            lv = [l for l in range(self.LEVELS) if self.its[l] > 0]
+            self.raycast_levels_into([(self.pyr_d[l], self.pyr_n[l], self.pyr_i[l]) for l in lv], [self.K_levels[l] for l in lv], T34)
+            for l in lv:
+                o.DepthToVbo(self.pyr_v[l], self.pyr_d[l], self.K_levels[l])
             T_lp, self.rmse, self.tracking_good = tr.refine_pose(o, self.kin_v, self.pyr_v, self.pyr_n, self.K_levels,
                                                                  self.scratch, self.debug, self.its, self.icp_c, self.max_rmse)
             if self.tracking_good:

@@ -63,6 +63,19 @@ if not tracking:
         assert both.mean() > 0.3 and np.median(err) < 0.02 * voxel and np.quantile(err, 0.99) < 0.5 * voxel, (np.median(err) / voxel, np.quantile(err, 0.99) / voxel)
         assert (np.abs(n[both] - rn[both]).max(axis=1) < 0.05).mean() > 0.98
         assert (n[hit][:, 3] == 1).all() and (n[~hit] == 0).all() and (im[~hit] == 0).all()
+    # (2c) several levels rendered and merged at once (one launch, one pair of all-reduces) = level by level
+    lv = (0, 1, 2)
+    Ks = [scenes.intrinsics_level(pipe.K, l) for l in lv]
+    mk = lambda: [(roo.Image(W >> l, H >> l), roo.Image(W >> l, H >> l, "f32x4"), roo.Image(W >> l, H >> l)) for l in lv]
+    a, b = mk(), mk()
+    T_last = scenes.orbit_pose(FRAMES - 1, 8)
+    for (dd, nn, ii), Kl in zip(a, Ks):
+        pipe.raycast_into(dd, nn, ii, Kl, T_last)
+    pipe.raycast_levels_into(b, Ks, T_last)
+    for x, y in zip(a, b):
+        for p_, q_ in zip(x, y):
+            assert same(p_.MemcpyToHost(), q_.MemcpyToHost()), "rank %d: merged levels differ from level-by-level" % rank
+    assert same(a[0][0].MemcpyToHost(), d)
     # (3) all ranks hold the same images
     chk = torch.tensor(np.nan_to_num(d, nan=-1.0).view(np.int32).astype(np.int64).sum()).reshape(1)
     both = torch.cat([chk, -chk])
