@@ -29,3 +29,20 @@ def test_gpu_slab_pipeline_ranks_sharing_one_gpu(world, halo, raycast, mode):
            "--master-port", str(_free_port()), os.path.join(T.ROOT, "tests", "mp_slab_gpu.py"), halo, raycast] + ([mode] if mode else [])
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=T.ROOT)
     assert out.returncode == 0 and out.stdout.count("MP_OK") == world, out.stdout[-3000:] + out.stderr[-3000:]
+
+
+@pytest.mark.parametrize("raycast", ["composite", "exact"])
+def test_gpu_bench_two_ranks_smoke(raycast):
+    """bench.py as the driver launches it for N > 1 (torch.distributed.run, one rank per process), with the transport
+    switched to gloo because both ranks share the box's single GPU: one JSON line, whole-job value, ranks agree."""
+    import json
+    env = dict(os.environ, KFX_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(T.ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
+           "--res", "128", "--raycast", raycast, "--no-cpu-baseline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=T.ROOT, env=env)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert out.returncode == 0 and len(lines) == 1, out.stdout[-2000:] + out.stderr[-3000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["value"] > 0 and d["scaling"] == "strong"
+    assert d["config"]["ranks_agree"] is True and d["roofline"]["bound"] == "hbm" and "cpu_baseline" not in d
