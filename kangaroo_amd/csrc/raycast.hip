@@ -34,6 +34,7 @@ struct RayParams {
     int subpix;
     int tile_log2w;   // log2 of the wave's pixel-tile width (3: 8x8, 4: 16x4, 5: 32x2)
     int wg_log2x;     // log2 of the number of wave tiles side by side in a workgroup (0: 1x4, 1: 2x2, 2: 4x1)
+    int sparse_lanes; // 0, or the number of lanes per wave that carry rays (small images; KFX_RAYCAST_LANES = 8 / 16 / 32 forces it, -1 disables it)
 };
 
 // PhongShade (cu_raycast.cu:14-28)
@@ -125,7 +126,14 @@ template <typename CELL, bool COLOR>
 __global__ __launch_bounds__(256) void k_raycast_sdf(const RayParams p, const ColorGeom cv)
 {
     int u, v;
-    ray_pixel_of(p, blockIdx.x, blockIdx.y, threadIdx.x, u, v);
+    if (p.sparse_lanes) { // only the first sparse_lanes lanes of a wave carry rays (a strip of one pixel row): small images
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        if (lane >= p.sparse_lanes) return;
+        u = (blockIdx.x * 2 + (wv & 1)) * p.sparse_lanes + lane;
+        v = blockIdx.y * 2 + (wv >> 1);
+    } else {
+        ray_pixel_of(p, blockIdx.x, blockIdx.y, threadIdx.x, u, v);
+    }
     raycast_pixel<CELL, COLOR>(p, cv, u, v);
 }
 
@@ -144,6 +152,7 @@ struct RayLevel {
     int w, h;
     Intr K;
     int first_block, blocks_x; // this level's workgroups are [first_block, next level's first_block), row-major
+    int sparse;                // 0, or rays per wave (a strip of one pixel row, the other lanes idle); workgroup = 2 x 2 strips
 };
 struct RayLevels {
     RayLevel lv[RAY_MAX_LEVELS];
@@ -164,7 +173,16 @@ __global__ __launch_bounds__(256) void k_raycast_sdf_levels(const RayParams base
     p.K = lv.K;
     const int b = (int)blockIdx.x - lv.first_block;
     int u, v;
-    ray_pixel_of(p, b % lv.blocks_x, b / lv.blocks_x, threadIdx.x, u, v);
+    if (lv.sparse) {
+        // coarse levels: neighbouring rays are many voxels apart, so every lane of a load fetches its own line and a
+        // wave-step waits for the slowest of 64 misses; with `sparse` rays per wave it waits for the slowest of those
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        if (lane >= lv.sparse) return;
+        u = ((b % lv.blocks_x) * 2 + (wv & 1)) * lv.sparse + lane;
+        v = (b / lv.blocks_x) * 2 + (wv >> 1);
+    } else {
+        ray_pixel_of(p, b % lv.blocks_x, b / lv.blocks_x, threadIdx.x, u, v);
+    }
     raycast_pixel<CELL, false>(p, ColorGeom{}, u, v);
 }
 
@@ -328,6 +346,7 @@ static int ray_params(RayParams& p, const kfx_image* depth, const kfx_image* nor
     p.subpix = subpix ? 1 : 0;
     p.tile_log2w = 5; // 32 x 2 pixel wave tiles, 2 x 2 of them per workgroup
     p.wg_log2x = 1;
+    p.sparse_lanes = 0;
     return 0;
 }
 
@@ -351,8 +370,10 @@ static int raycast_levels_launch(int n_levels, const kfx_image* const* depth, co
         lv.w = p.w; lv.h = p.h;
         lv.K = p.K;
         lv.first_block = blocks;
-        lv.blocks_x = ceil_div(p.w, 64);
-        blocks += lv.blocks_x * ceil_div(p.h, 4);
+        static const int sparse_env = [] { const char* e = getenv("KFX_RAYCAST_SPARSE"); const int v = e ? atoi(e) : 16; return (v == 8 || v == 16 || v == 32) ? v : 0; }();
+        lv.sparse = (long long)p.w * p.h <= 160 * 120 ? sparse_env : 0; // coarse levels only: at full resolution dense waves are faster
+        lv.blocks_x = lv.sparse ? ceil_div(p.w, 2 * lv.sparse) : ceil_div(p.w, 64);
+        blocks += lv.blocks_x * (lv.sparse ? ceil_div(p.h, 2) : ceil_div(p.h, 4));
         base = p;
     }
     if (L.n == 0) return 0;
@@ -374,6 +395,13 @@ static int raycast_launch(const kfx_image* depth, const kfx_image* norm, const k
     p.tile_log2w = tile_env;
     p.wg_log2x = wg_env;
     dim3 grid(ceil_div(p.w, (1 << p.wg_log2x) << p.tile_log2w), ceil_div(p.h, (4 >> p.wg_log2x) * (64 >> p.tile_log2w)));
+    static const int lanes_env = [] { const char* e = getenv("KFX_RAYCAST_LANES"); const int v = e ? atoi(e) : 0; return (v == 8 || v == 16 || v == 32) ? v : (v < 0 ? -1 : 0); }();
+    // small images (pyramid levels): rays of a wave are many voxels apart, 16 rays per wave wait for fewer misses per step
+    const int lanes = lanes_env ? lanes_env : ((long long)p.w * p.h <= 160 * 120 ? 16 : 0);
+    if (lanes && lanes_env >= 0) {
+        p.sparse_lanes = lanes;
+        grid = dim3(ceil_div(p.w, 2 * lanes), ceil_div(p.h, 2));
+    }
     ColorGeom cv{};
     if (colorvol) {
         if (!colorvol->ptr) return set_error(KFX_E_NULL, "RaycastSdf(colour): null colour volume");
