@@ -146,14 +146,12 @@ int main(int argc, char** argv)
         if (work_vol.IsValid()) {
             if (one_raycast) {   // the same images from one launch: the levels' marches overlap (kfx_raycast_sdf_levels)
                 Image<float> rd[MaxLevels], ri[MaxLevels];
-                Image<float4> rn[MaxLevels];
+                Image<float4> rn[MaxLevels], rv[MaxLevels];
                 ImageIntrinsics Kl[MaxLevels];
                 unsigned n = 0;
                 for (int l = 0; l < MaxLevels; ++l)
-                    if (its[l] > 0) { rd[n] = ray_d[l]; rn[n] = ray_n[l]; ri[n] = ray_i[l]; Kl[n] = K[l]; ++n; }
-                RaycastSdfLevels(rd, rn, ri, n, work_vol, T_wl, Kl, knear, kfar, trunc_dist, true);
-                for (int l = 0; l < MaxLevels; ++l)
-                    if (its[l] > 0) DepthToVbo<float>(ray_v[l], ray_d[l], K[l]);
+                    if (its[l] > 0) { rd[n] = ray_d[l]; rn[n] = ray_n[l]; ri[n] = ray_i[l]; rv[n] = ray_v[l]; Kl[n] = K[l]; ++n; }
+                RaycastSdfLevels(rd, rn, ri, n, work_vol, T_wl, Kl, knear, kfar, trunc_dist, true, rv);   // rv[l] = DepthToVbo(rd[l], K[l])
             } else {
                 for (int l = 0; l < MaxLevels; ++l) {
                     if (its[l] > 0) {

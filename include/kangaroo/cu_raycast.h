@@ -24,16 +24,17 @@ void RaycastSdf(Image<float> depth, Image<float4> norm, Image<float> img, const 
 // (applications/kinectfusion/main.cpp:280-288) as one launch -- same images, bit for bit, but the levels' marches
 // overlap (kfx_raycast_sdf_levels).  depth / norm / img / K are arrays of n entries.
 KANGAROO_EXPORT inline
-void RaycastSdfLevels(const Image<float>* depth, const Image<float4>* norm, const Image<float>* img, unsigned n, const BoundedVolume<SDF_t> vol, const Mat<float,3,4> T_wc, const ImageIntrinsics* K, float near, float far, float trunc_dist, bool subpix = true)
+void RaycastSdfLevels(const Image<float>* depth, const Image<float4>* norm, const Image<float>* img, unsigned n, const BoundedVolume<SDF_t> vol, const Mat<float,3,4> T_wc, const ImageIntrinsics* K, float near, float far, float trunc_dist, bool subpix = true, const Image<float4>* vbo = 0)
 {
-    const kfx_image *d[8], *nn[8], *im[8];
+    const kfx_image *d[8], *nn[8], *im[8], *vb[8];
     float k[32];
     if (n > 8) GpuCheckStatus(KFX_E_RANGE);
     for (unsigned l = 0; l < n && l < 8; ++l) {
         d[l] = depth[l].abi(); nn[l] = norm[l].abi(); im[l] = img[l].abi();
+        vb[l] = vbo ? vbo[l].abi() : 0;   // vbo[l] receives DepthToVbo(vbo[l], depth[l], K[l]) from the same launch
         k[4 * l] = K[l].fu; k[4 * l + 1] = K[l].fv; k[4 * l + 2] = K[l].u0; k[4 * l + 3] = K[l].v0;
     }
-    GpuCheckStatus(kfx_raycast_sdf_levels((int)n, d, nn, im, vol.abi(), T_wc.m, k, near, far, trunc_dist, subpix ? 1 : 0, 0));
+    GpuCheckStatus(kfx_raycast_sdf_levels((int)n, d, nn, im, vbo ? vb : 0, vol.abi(), T_wc.m, k, near, far, trunc_dist, subpix ? 1 : 0, 0));
 }
 
 // colour overload (reference cu_raycast.h:16-17, kernel cu_raycast.cu:119-196): img = colour volume sampled at the hit

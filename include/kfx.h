@@ -125,12 +125,14 @@ int kfx_raycast_sdf(const kfx_image* depth, const kfx_image* norm, const kfx_ima
  * arrays of n_levels image pointers, K holds n_levels x 4 floats {fu, fv, u0, v0}; n_levels <= 8.  Every image is
  * bit-identical to what its own kfx_raycast_sdf call writes; the levels' marches overlap instead of running one
  * after the other (a coarse level takes as long as the full-resolution one: DESIGN.md 5.2).  No counterpart in the
- * reference API -- an addition next to it; the roo:: wrapper is RaycastSdfLevels (include/kangaroo/cu_raycast.h). */
+ * reference API -- an addition next to it; the roo:: wrapper is RaycastSdfLevels (include/kangaroo/cu_raycast.h).
+ * vbo: NULL, or n_levels pointers (each may be NULL) to Image<float4> vertex maps that receive DepthToVbo<float>(vbo[l],
+ * depth[l], K[l]) -- the call that follows each RaycastSdf in the application (main.cpp:286) -- from the same launch. */
 int kfx_raycast_sdf_levels(int n_levels, const kfx_image* const* depth, const kfx_image* const* norm, const kfx_image* const* img,
-                           const kfx_volume* vol, const float T_wc[12], const float* K, float near, float far,
+                           const kfx_image* const* vbo, const kfx_volume* vol, const float T_wc[12], const float* K, float near, float far,
                            float trunc_dist, int subpix, kfx_stream stream);
 int kfx_raycast_sdf_levels_h(int n_levels, const kfx_image* const* depth, const kfx_image* const* norm, const kfx_image* const* img,
-                             const kfx_volume* vol, const float T_wc[12], const float* K, float near, float far,
+                             const kfx_image* const* vbo, const kfx_volume* vol, const float T_wc[12], const float* K, float near, float far,
                              float trunc_dist, int subpix, kfx_stream stream);
 
 /* roo::BilateralFilter<float,float>(Image<float>, Image<float>, gs, gr, size[, minval])

@@ -64,9 +64,9 @@ __device__ __forceinline__ void ray_pixel_of(const RayParams& p, int bx, int by,
 
 // one ray: KernRaycastSdf (cu_raycast.cu:34-113) for pixel (u, v)
 template <typename CELL, bool COLOR>
-__device__ __forceinline__ void raycast_pixel(const RayParams& p, const ColorGeom& cv, const int u, const int v)
+__device__ __forceinline__ float raycast_pixel(const RayParams& p, const ColorGeom& cv, const int u, const int v)
 {
-    if (u >= p.w || v >= p.h) return;
+    if (u >= p.w || v >= p.h) return 0.f;
 
     const V3 c_w = v3(p.T.m[3], p.T.m[7], p.T.m[11]);                              // SE3Translation
     const V3 ray_c = v3(((float)u - p.K.u0) / p.K.fu, ((float)v - p.K.v0) / p.K.fv, 1.0f); // Unproject
@@ -120,6 +120,7 @@ __device__ __forceinline__ void raycast_pixel(const RayParams& p, const ColorGeo
         *pi = 0.f;
         *pn = make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    return depth > 0 ? depth : __builtin_nanf(""); // the value written to the depth image
 }
 
 template <typename CELL, bool COLOR>
@@ -151,6 +152,8 @@ struct RayLevel {
     size_t dpitch, npitch, ipitch;
     int w, h;
     Intr K;
+    unsigned char* vptr;       // optional vertex map of the rendering: DepthToVbo(depth, K) (cu_depth_tools.cu:59-70), or null
+    size_t vpitch;
     int first_block, blocks_x; // this level's workgroups are [first_block, next level's first_block), row-major
     int sparse;                // 0, or rays per wave (a strip of one pixel row, the other lanes idle); workgroup = 2 x 2 strips
 };
@@ -183,7 +186,10 @@ __global__ __launch_bounds__(256) void k_raycast_sdf_levels(const RayParams base
     } else {
         ray_pixel_of(p, b % lv.blocks_x, b / lv.blocks_x, threadIdx.x, u, v);
     }
-    raycast_pixel<CELL, false>(p, ColorGeom{}, u, v);
+    const float kz = raycast_pixel<CELL, false>(p, ColorGeom{}, u, v);
+    if (lv.vptr && u < p.w && v < p.h) // the application's DepthToVbo(ray_v[l], ray_d[l], K[l]) (main.cpp:286), same expression
+        reinterpret_cast<float4*>(lv.vptr + (size_t)v * lv.vpitch)[u] =
+            make_float4(kz * ((float)u - p.K.u0) / p.K.fu, kz * ((float)v - p.K.v0) / p.K.fv, kz, 1.0f);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -352,7 +358,7 @@ static int ray_params(RayParams& p, const kfx_image* depth, const kfx_image* nor
 
 template <typename CELL>
 static int raycast_levels_launch(int n_levels, const kfx_image* const* depth, const kfx_image* const* norm, const kfx_image* const* img,
-                                 const kfx_volume* vol, const float T_wc[12], const float* K, float near, float far,
+                                 const kfx_image* const* vbo, const kfx_volume* vol, const float T_wc[12], const float* K, float near, float far,
                                  float trunc_dist, int subpix, kfx_stream stream)
 {
     if (n_levels < 0 || n_levels > RAY_MAX_LEVELS) return set_error(KFX_E_RANGE, "RaycastSdf(levels): number of levels");
@@ -369,6 +375,16 @@ static int raycast_levels_launch(int n_levels, const kfx_image* const* depth, co
         lv.dpitch = p.dpitch; lv.npitch = p.npitch; lv.ipitch = p.ipitch;
         lv.w = p.w; lv.h = p.h;
         lv.K = p.K;
+        lv.vptr = nullptr;
+        lv.vpitch = 0;
+        if (vbo && vbo[l]) {
+            const kfx_image* vb = vbo[l];
+            if (!vb->ptr) return set_error(KFX_E_NULL, "RaycastSdf(levels): null vertex map");
+            if (vb->w < (size_t)p.w || vb->h < (size_t)p.h || vb->pitch < (size_t)p.w * 16) return set_error(KFX_E_SHAPE, "RaycastSdf(levels): vertex map smaller than img");
+            if (((uintptr_t)vb->ptr | vb->pitch) & 15) return set_error(KFX_E_ALIGN, "RaycastSdf(levels): vertex map alignment");
+            lv.vptr = (unsigned char*)vb->ptr;
+            lv.vpitch = vb->pitch;
+        }
         lv.first_block = blocks;
         static const int sparse_env = [] { const char* e = getenv("KFX_RAYCAST_SPARSE"); const int v = e ? atoi(e) : 16; return (v == 8 || v == 16 || v == 32) ? v : 0; }();
         lv.sparse = (long long)p.w * p.h <= 160 * 120 ? sparse_env : 0; // coarse levels only: at full resolution dense waves are faster
@@ -433,17 +449,17 @@ extern "C" int kfx_raycast_sdf_h(const kfx_image* depth, const kfx_image* norm, 
 
 // RaycastSdf(depth, norm, img, vol, colorVol, T_wc, K, near, far, trunc_dist, subpix) (cu_raycast.cu:119-196)
 extern "C" int kfx_raycast_sdf_levels(int n_levels, const kfx_image* const* depth, const kfx_image* const* norm, const kfx_image* const* img,
-                                      const kfx_volume* vol, const float T_wc[12], const float* K, float near, float far,
+                                      const kfx_image* const* vbo, const kfx_volume* vol, const float T_wc[12], const float* K, float near, float far,
                                       float trunc_dist, int subpix, kfx_stream stream)
 {
-    return raycast_levels_launch<RayF32>(n_levels, depth, norm, img, vol, T_wc, K, near, far, trunc_dist, subpix, stream);
+    return raycast_levels_launch<RayF32>(n_levels, depth, norm, img, vbo, vol, T_wc, K, near, far, trunc_dist, subpix, stream);
 }
 
 extern "C" int kfx_raycast_sdf_levels_h(int n_levels, const kfx_image* const* depth, const kfx_image* const* norm, const kfx_image* const* img,
-                                        const kfx_volume* vol, const float T_wc[12], const float* K, float near, float far,
-                                        float trunc_dist, int subpix, kfx_stream stream)
+                                      const kfx_image* const* vbo, const kfx_volume* vol, const float T_wc[12], const float* K, float near, float far,
+                                      float trunc_dist, int subpix, kfx_stream stream)
 {
-    return raycast_levels_launch<RayF16>(n_levels, depth, norm, img, vol, T_wc, K, near, far, trunc_dist, subpix, stream);
+    return raycast_levels_launch<RayF16>(n_levels, depth, norm, img, vbo, vol, T_wc, K, near, far, trunc_dist, subpix, stream);
 }
 
 extern "C" int kfx_raycast_sdf_color(const kfx_image* depth, const kfx_image* norm, const kfx_image* img, const kfx_volume* vol,

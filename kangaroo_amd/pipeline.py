@@ -140,14 +140,14 @@ class TrackingPipeline(FramePipeline):
         else:
             T34 = self.T_wl[:3].astype(np.float32)
             lv = [l for l in range(self.LEVELS) if self.its[l] > 0]
-            if self.one_raycast:   # the per-level RaycastSdf calls as one launch: same images, overlapping marches
-                o.RaycastSdfLevels([(self.pyr_d[l], self.pyr_n[l], self.pyr_i[l]) for l in lv], self.vol, T34,
+            if self.one_raycast:   # the per-level RaycastSdf + DepthToVbo calls as one launch: same images, overlapping marches
+                o.RaycastSdfLevels([(self.pyr_d[l], self.pyr_n[l], self.pyr_i[l], self.pyr_v[l]) for l in lv], self.vol, T34,
                                    [self.K_levels[l] for l in lv], self.near, self.far, self.trunc, True)
-            for l in lv:
-                if not self.one_raycast:
+            else:
+                for l in lv:
                     o.RaycastSdf(self.pyr_d[l], self.pyr_n[l], self.pyr_i[l], self.vol, T34, self.K_levels[l], self.near,
                                  self.far, self.trunc, True)
-                o.DepthToVbo(self.pyr_v[l], self.pyr_d[l], self.K_levels[l])
+                    o.DepthToVbo(self.pyr_v[l], self.pyr_d[l], self.K_levels[l])
             if self.device_icp:
                 T_lp, self.rmse, _, self.tracking_good = o.IcpRefine(self.kin_v, self.pyr_v, self.pyr_n, self.K_levels, self.its,
                                                                      self.icp_c, self.max_rmse, self.scratch, self.debug)

@@ -1284,6 +1284,16 @@ def test_gpu_raycast_levels_equal_per_level_calls(roo):
         for x, y in zip(a, b):
             for p_, q_ in zip(x, y):
                 assert T.nan_equal(p_.MemcpyToHost(), q_.MemcpyToHost())
+        # optional fourth output: the vertex map DepthToVbo(depth, K) of each rendering, from the same launch (one level without)
+        c = [t + ((roo.Image(*sizes[l], "f32x4"),) if l != 1 else (None,)) for t, l in zip(mk(), levels)]
+        roo.RaycastSdfLevels(c, vol, T_wc, Ks, near, far, tr, True)
+        for x, y, Kl in zip(a, c, Ks):
+            for p_, q_ in zip(x, y[:3]):
+                assert T.nan_equal(p_.MemcpyToHost(), q_.MemcpyToHost())
+            if y[3] is not None:
+                want = roo.Image(x[0].w, x[0].h, "f32x4")
+                roo.DepthToVbo(want, x[0], Kl)
+                assert T.nan_equal(want.MemcpyToHost(), y[3].MemcpyToHost())
         assert np.isfinite(a[0][0].MemcpyToHost()).mean() > 0.2
         roo.RaycastSdfLevels([], vol, T_wc, [], near, far, tr, True)   # nothing to do, no error
     poses = []
