@@ -27,13 +27,14 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 N_ORBIT = 30
+PMC_TRAFFIC_FILE = "profiles/r01_pmc_traffic.json"
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=60)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=600)
+    ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--scene", default="full", choices=["room", "full"],
                     help="full (default) = S_full of SURVEY 8(d), the roofline scene: a wall behind the volume, ~98 %% of the "
                          "voxels are updated every frame (the heaviest SdfFuse traffic); room = S_room, a furnished room "
@@ -54,11 +55,26 @@ def parse():
     return ap.parse_args()
 
 
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(args, scene, n_frames):
     """The oracle (kind "port") timed on this host's cores: full frames of the same workload
-    (same volume size, image size, scene, poses), all cores via OpenMP over z-slices / rows."""
+    (same volume size, image size, scene, poses).  Two figures: all cores (OpenMP
+    over z-slices / rows) = `value`, and one full frame on a single thread.  The library is
+    rebuilt -O3 -march=native for this host (oracle/_native, same -ffp-contract=off arithmetic);
+    if that build fails the portable -O2 build of the parity tests is timed instead."""
     import oracle
     from kangaroo_amd import scenes
+    build = oracle.use_native_build()
     N, w, h = args.res, args.width, args.height
     bmin, bmax, near, far = scenes.SCENES[scene]
     K = scenes.intrinsics(w, h)
@@ -68,33 +84,63 @@ def cpu_baseline(args, scene, n_frames):
     oracle.sdf_reset(vol, float("nan"))
     f, vbo, nrm = oracle.Image(w, h), oracle.Image(w, h, channels=4), oracle.Image(w, h, channels=4)
     rd, rn, ri = oracle.Image(w, h), oracle.Image(w, h, channels=4), oracle.Image(w, h)
-    times = []
-    budget_s = 12.0   # bounded sample: at least 2 timed frames, then as many as fit ~12 s of CPU work (at most n_frames)
-    for i in range(n_frames + 1):  # first frame untimed (page faults of the 1 GiB volume)
-        if len(times) >= 2 and sum(times) + times[-1] > budget_s:
-            break
+
+    def frame(i, nt):
         T_wc = scenes.orbit_pose(i, N_ORBIT)
         raw = oracle.Image.from_numpy(scenes.render_depth(scene, w, h, T_wc, K))
         t0 = time.perf_counter()
-        oracle.bilateral(f, raw, nthreads=threads, **scenes.BILATERAL)
+        oracle.bilateral(f, raw, nthreads=nt, **scenes.BILATERAL)
         oracle.depth_to_vbo(vbo, f, K)
         oracle.normals_from_vbo(nrm, vbo)
-        oracle.sdf_fuse(vol, f, nrm, scenes.se3_inverse(T_wc), K, tr, scenes.MAX_W, scenes.MIN_COS_THETA, nthreads=threads)
-        oracle.raycast_sdf(rd, rn, ri, vol, T_wc, K, near, far, tr, True, nthreads=threads)
-        dt = time.perf_counter() - t0
+        oracle.sdf_fuse(vol, f, nrm, scenes.se3_inverse(T_wc), K, tr, scenes.MAX_W, scenes.MIN_COS_THETA, nthreads=nt)
+        oracle.raycast_sdf(rd, rn, ri, vol, T_wc, K, near, far, tr, True, nthreads=nt)
+        return time.perf_counter() - t0
+
+    times = []
+    budget_s = 8.0   # bounded sample: at least 2 timed frames, then as many as fit ~8 s of CPU work (at most n_frames)
+    for i in range(n_frames + 1):  # first frame untimed (page faults of the volume)
+        if len(times) >= 2 and sum(times) + times[-1] > budget_s:
+            break
+        dt = frame(i, threads)
         if i > 0:
             times.append(dt)
     fps = len(times) / sum(times)
+    single_s = frame(len(times) + 1, 1) if threads > 1 else times[-1]   # one full frame on one thread
     return {"value": round(fps, 4), "unit": "frames/s", "cores": threads, "kind": "port",
+            "single_thread": {"value": round(1.0 / single_s, 4), "unit": "frames/s", "cores": 1, "sample": "1 full frame = %.1f s" % single_s},
+            "cpu_model": cpu_model(), "build": build,
             "sample": "%d full frames = %.1f s (%d^3 volume, %dx%d, scene %s, orbit poses) of the C restatement oracle/kfx_oracle.c, "
-                      "OpenMP over z-slices/rows on %d threads; 1 untimed warm frame" % (len(times), sum(times), N, w, h, scene, threads)}
+                      "OpenMP over z-slices/rows on %d threads; 1 untimed warm frame; then 1 full frame on 1 thread"
+                      % (len(times), sum(times), N, w, h, scene, threads)}
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes (one per GPU, RCCL) through
+    torch.distributed.run as a CHILD of this process -- which has not imported torch or touched a GPU --, relay the
+    ranks' output and exit with the child's code.  Never exec: a process that has initialised the GPU must not be replaced."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.run(cmd, env=env)
+    sys.exit(proc.returncode)
 
 
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        spawn_ranks(args)   # does not return
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
     import torch
     import torch.distributed as dist
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
@@ -108,6 +154,9 @@ def main():
         # RCCL needs one GPU per rank; KFX_BENCH_BACKEND=gloo lets several ranks share a GPU to smoke-test the
         # distributed code path on a 1-GPU box (never used for reported numbers)
         backend = os.environ.get("KFX_BENCH_BACKEND", "nccl")
+        if backend == "nccl" and ndev < world:
+            sys.exit("bench.py: --gpus %d needs %d GPUs, this node shows %d (KFX_BENCH_BACKEND=gloo lets ranks share a GPU "
+                     "for smoke tests only)" % (world, world, ndev))
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
         else:
@@ -232,14 +281,21 @@ def main():
     except RuntimeError:
         pass
 
-    traffic = None  # HBM bytes per launch from the committed PMC passes of this same command (profiles/)
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fh:
-            traffic = json.load(fh).get("%s_%s" % (scene, args.math), {}).get("traffic_bytes")
-    except (OSError, ValueError):
-        pass
-    if distributed or (N, w, h) != (512, 640, 480):
-        traffic = None
+    # HBM bytes per launch from PMC passes.  PMC collection needs its own rocprofv3 runs (FETCH_SIZE and WRITE_SIZE do
+    # not fit one pass and must not be combined with the timed run), so the figure comes from the committed summary of
+    # those passes over this same command (scripts/gpu_profile.sh -> profiles/<tag>/summary.txt -> PMC_TRAFFIC_FILE);
+    # `traffic_source` names the file and the commit it was collected at: it is NOT measured in this run.
+    traffic, traffic_source = None, None
+    if not distributed and (N, w, h) == (512, 640, 480):
+        try:
+            with open(os.path.join(ROOT, PMC_TRAFFIC_FILE)) as fh:
+                tj = json.load(fh)
+            traffic = tj.get("%s_%s" % (scene, args.math), {}).get("traffic_bytes")
+            if traffic is not None:
+                traffic_source = "%s (separate rocprofv3 --pmc passes of this command, kernels of commit %s; not measured in this run)" % (
+                    PMC_TRAFFIC_FILE, tj.get("_commit", "?"))
+        except (OSError, ValueError):
+            pass
 
     if rank == 0:
         fps = args.steps / elapsed
@@ -278,6 +334,7 @@ def main():
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": traffic,
+                "traffic_source": traffic_source,
                 "algorithmic_bytes_per_launch": round(bytes_avg),
                 "avg_launch_ms": round(fuse_avg_ms, 5),
                 "updated_fraction": round(float(np.mean([n_updated[i] for i in idx])) / local_voxels, 4),

@@ -41,7 +41,27 @@ class KfoRaycastStats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("steps", C.c_uint64), ("hits", C.c_uint64)]
 
 
+_SO_OVERRIDE = None
+
+
+def use_native_build():
+    """Switch this module to a -O3 -march=native build of the same source (oracle/_native/, built on the spot for the
+    host it runs on; same -ffp-contract=off arithmetic).  Used by bench.py's cpu_baseline leg only -- the parity tests
+    keep the portable build.  Returns a description of the build in use."""
+    global _SO_OVERRIDE, _LIB
+    so = os.path.join(_HERE, "_native", "libkfx_oracle_native.so")
+    try:
+        subprocess.check_call(["make", "-C", _HERE, "native"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        C.CDLL(so)
+    except (subprocess.CalledProcessError, OSError):
+        return "gcc -O2 -march=x86-64-v3 -ffp-contract=off -fopenmp (portable parity build; native rebuild failed)"
+    _SO_OVERRIDE, _LIB = so, None
+    return "gcc -O3 -march=native -ffp-contract=off -fopenmp"
+
+
 def build(force=False):
+    if _SO_OVERRIDE:
+        return _SO_OVERRIDE
     so = os.path.join(_HERE, "libkfx_oracle.so")
     src = os.path.join(_HERE, "kfx_oracle.c")
     if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):

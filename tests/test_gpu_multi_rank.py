@@ -46,3 +46,30 @@ def test_gpu_bench_two_ranks_smoke(raycast):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 4 and d["value"] > 0 and d["scaling"] == "strong"
     assert d["config"]["ranks_agree"] is True and d["roofline"]["bound"] == "hbm" and "cpu_baseline" not in d
+
+
+def test_gpu_bench_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it: bench.py starts the two ranks itself (child processes of
+    a parent that never touches the GPU) and the line says n_gpus = 2.  gloo, because the box has a single GPU."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["KFX_BENCH_BACKEND"] = "gloo"
+    cmd = [sys.executable, os.path.join(T.ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--res", "128", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=T.ROOT, env=env)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert out.returncode == 0 and len(lines) == 1, out.stdout[-2000:] + out.stderr[-3000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["ranks_agree"] is True
+
+
+def test_gpu_bench_refuses_more_ranks_than_gpus():
+    """With the RCCL backend every rank needs its own GPU: on this 1-GPU box `--gpus 2` must fail loudly, not report
+    a 1-GPU number."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "KFX_BENCH_BACKEND")}
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("needs a box with fewer than 2 GPUs")
+    cmd = [sys.executable, os.path.join(T.ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--res", "64", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=T.ROOT, env=env)
+    assert out.returncode != 0 and not [l for l in out.stdout.splitlines() if l.startswith("{")], out.stdout[-2000:]
+    assert "needs 2 GPUs" in out.stderr + out.stdout
