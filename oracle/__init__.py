@@ -143,6 +143,8 @@ def lib():
         L.kfo_gradient.restype = None
         L.kfo_sdf_accumulate.argtypes = [C.c_float] * 5 + [PF]
         L.kfo_sdf_accumulate.restype = None
+        L.kfo_phong_shade.argtypes = [PF, PF]
+        L.kfo_phong_shade.restype = C.c_float
         L.kfo_intrinsics_level.argtypes = [PF, PF, C.c_int]
         L.kfo_intrinsics_level.restype = None
         L.kfo_voxel_position.argtypes = [PV, C.c_int, C.c_int, C.c_int, PF]
@@ -418,6 +420,11 @@ def sdf_accumulate(val, w, old_val, old_w, max_w):
     o = (C.c_float * 2)()
     lib().kfo_sdf_accumulate(val, w, old_val, old_w, max_w, o)
     return np.array(list(o), np.float32)
+
+
+def phong_shade(p_c, n_c):
+    p, n = _fp(p_c), _fp(n_c)
+    return np.float32(lib().kfo_phong_shade(p[1], n[1]))
 
 
 def intrinsics_level(K, level):

@@ -739,6 +739,12 @@ void kfo_gradient(const kfo_volume* vol, const float pos_w[3], float out[3])
     const f3 g = units_backward_diff(vol, mk3(pos_w[0], pos_w[1], pos_w[2]), NULL, 0);
     out[0] = g.x; out[1] = g.y; out[2] = g.z;
 }
+float kfo_phong_shade(const float p_c[3], const float n_c[3]) /* PhongShade, cu_raycast.cu:14-28 */
+{
+    const f3 p = {p_c[0], p_c[1], p_c[2]}, n = {n_c[0], n_c[1], n_c[2]};
+    return phong_shade(p, n);
+}
+
 void kfo_sdf_accumulate(float val, float w, float old_val, float old_w, float max_w, float out[2])
 {
     /* Sdf.h:25-32 then :22-24 */

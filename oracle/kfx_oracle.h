@@ -196,6 +196,7 @@ void kfo_se3_inverse(float out[12], const float T[12]);
 float kfo_trilinear(const kfo_volume* vol, const float pos_w[3]);
 void kfo_gradient(const kfo_volume* vol, const float pos_w[3], float out[3]);
 void kfo_sdf_accumulate(float val, float w, float old_val, float old_w, float max_w, float out[2]);
+float kfo_phong_shade(const float p_c[3], const float n_c[3]); /* PhongShade, cu_raycast.cu:14-28 */
 void kfo_intrinsics_level(float out[4], const float K[4], int level);
 void kfo_voxel_position(const kfo_volume* vol, int x, int y, int z, float out[3]);
 

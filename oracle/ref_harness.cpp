@@ -36,6 +36,14 @@
 
 #include "kfx_oracle.h"
 
+// PhongShade (src/cu_raycast.cu:14-28) is a plain __host__ __device__ inline function without thread builtins, but it
+// lives in the .cu.  oracle/Makefile extracts exactly those lines from the read-only reference tree into a temporary
+// file at build time (REF_PHONG_INC, deleted after the compile; nothing is copied into the repo) and it is compiled
+// here, inside the reference's namespace, as the reference wrote it.
+namespace roo {
+#include REF_PHONG_INC
+}
+
 using namespace roo;
 
 typedef Image<float, TargetHost, DontManage> HImgF;
@@ -58,6 +66,40 @@ static Mat<float, 3, 4> mkT(const float* t)
 }
 static ImageIntrinsics mkK(const float* k) { return ImageIntrinsics(k[0], k[1], k[2], k[3]); }
 
+// KernBilateralFilter, both forms (cu_bilateral.cu:13-41 and :59-92), on the reference's Image::InBounds and
+// GetWithClampedRange.  The reference's __expf is a device intrinsic; expf here (the oracle uses the same libm call, the
+// GPU kernels are held to 2e-6 relative).  Arithmetic types as in the kernel: `p - q` in Ti's promoted type, then float.
+template <typename Ti>
+static void bilateral_t(const kfo_image* pout, const kfo_image* pin, float gs, float gr, int size, Ti minval, int use_minval)
+{
+    HImgF dOut = imf(pout);
+    Image<Ti, TargetHost, DontManage> dIn((Ti*)pin->ptr, pin->w, pin->h, pin->pitch);
+    for (unsigned y = 0; y < dOut.h; ++y)
+        for (unsigned x = 0; x < dOut.w; ++x) {
+            if (!dOut.InBounds(x, y)) continue;
+            const Ti p = dIn(x, y);
+            float sum = 0;
+            float sumw = 0;
+            if (!use_minval || p >= minval) {
+                for (int r = -size; r <= size; ++r) {
+                    for (int c = -size; c <= size; ++c) {
+                        const Ti q = dIn.GetWithClampedRange(x + c, y + r);
+                        if (!use_minval || q >= minval) {
+                            const float sd2 = r * r + c * c;
+                            const float id = p - q;
+                            const float id2 = id * id;
+                            const float sw = expf(-(sd2) / (2 * gs * gs));
+                            const float iw = expf(-(id2) / (2 * gr * gr));
+                            const float w = sw * iw;
+                            sumw += w;
+                            sum += w * q;
+                        }
+                    }
+                }
+            }
+            dOut(x, y) = (float)(sum / sumw);
+        }
+}
 extern "C" {
 
 // layouts the C-ABI mirrors
@@ -134,8 +176,8 @@ void ref_backward_diff(const kfo_volume* pv, const float pos[3], float out[3])
     out[0] = g.x; out[1] = g.y; out[2] = g.z;
 }
 
-// Ray march with the reference's samplers.  Outputs depth (0 = miss) and the
-// camera-frame normal; shading (PhongShade lives in the .cu) is not covered.
+// Ray march with the reference's samplers.  Outputs depth (NaN = miss) and the
+// camera-frame normal; ref_raycast_shade adds the PhongShade image.
 void ref_raycast_geom(const kfo_image* pdepth, const kfo_image* pnorm, const kfo_volume* pv, const float* t,
                       const float* k, float near, float far, float trunc_dist, int subpix)
 {
@@ -200,29 +242,113 @@ void ref_depth_to_vbo(const kfo_image* pvbo, const kfo_image* pd, const float* k
         }
 }
 
-// Bilateral weights use expf here (the reference's __expf is a device intrinsic).
-void ref_bilateral_f32(const kfo_image* pout, const kfo_image* pin, float gs, float gr, int size,
-                       float minval, int use_minval)
+void ref_bilateral_f32(const kfo_image* pout, const kfo_image* pin, float gs, float gr, int size, float minval, int use_minval)
 {
-    HImgF out = imf(pout);
-    HImgF in = imf(pin);
+    bilateral_t<float>(pout, pin, gs, gr, size, minval, use_minval);
+}
+void ref_bilateral_u16(const kfo_image* pout, const kfo_image* pin, float gs, float gr, int size, unsigned short minval)
+{
+    bilateral_t<unsigned short>(pout, pin, gs, gr, size, minval, 1);
+}
+void ref_bilateral_u8(const kfo_image* pout, const kfo_image* pin, float gs, float gr, int size)
+{
+    bilateral_t<unsigned char>(pout, pin, gs, gr, size, 0, 0);
+}
+
+// KernNormalsFromVbo (cu_normals.cu:12-38) on the reference's float4 operator-, make_float3, length, make_float4
+void ref_normals_from_vbo(const kfo_image* pn, const kfo_image* pv)
+{
+    HImgF4 dN = imf4(pn), dV = imf4(pv);
+    for (int v = 0; v < (int)dN.h; ++v)
+        for (int u = 0; u < (int)dN.w; ++u) {
+            if (u + 1 < (int)dN.w && v + 1 < (int)dN.h) {
+                const float4 Vc = dV(u, v);
+                const float4 Vr = dV(u + 1, v);
+                const float4 Vu = dV(u, v + 1);
+                const float4 a = Vr - Vc;
+                const float4 b = Vu - Vc;
+                const float3 axb = make_float3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+                const float magaxb = length(axb);
+                dN(u, v) = make_float4(-axb.x / magaxb, -axb.y / magaxb, -axb.z / magaxb, 1);
+            } else {
+                dN(u, v) = make_float4(0, 0, 0, 0);
+            }
+        }
+}
+
+// The reference's PhongShade, compiled from its own lines (see the top of this file)
+float ref_phong_shade(const float p_c[3], const float n_c[3])
+{
+    return PhongShade(make_float3(p_c[0], p_c[1], p_c[2]), make_float3(n_c[0], n_c[1], n_c[2]));
+}
+
+// The shade image of KernRaycastSdf (cu_raycast.cu:90-101) from the depth / normal images ref_raycast_geom produced:
+// p_c = depth * K.Unproject(u, v), img = PhongShade(p_c, n_c) on hits, 0 on misses.
+void ref_raycast_shade(const kfo_image* pimg, const kfo_image* pdepth, const kfo_image* pnorm, const float* k)
+{
+    HImgF img = imf(pimg), imgdepth = imf(pdepth);
+    HImgF4 norm = imf4(pnorm);
+    const ImageIntrinsics K = mkK(k);
+    for (int v = 0; v < (int)img.h; ++v)
+        for (int u = 0; u < (int)img.w; ++u) {
+            const float depth = imgdepth(u, v);
+            if (depth > 0) {
+                const float3 ray_c = K.Unproject(u, v);
+                const float3 p_c = depth * ray_c;
+                img(u, v) = PhongShade(p_c, make_float3(norm(u, v)));
+            } else {
+                img(u, v) = 0;
+            }
+        }
+}
+
+// KernSdfSphere (cu_sdffusion.cu:175-187) over the (dim/8)*8 extents of its launch (:189-195)
+void ref_sdf_sphere(const kfo_volume* pv, const float center[3], float r)
+{
+    HVol vol = mkvol(pv);
+    const float3 c = make_float3(center[0], center[1], center[2]);
+    const int X = (int)(vol.w / 8) * 8, Y = (int)(vol.h / 8) * 8, Z = (int)(vol.d / 8) * 8;
+    for (int z = 0; z < Z; ++z)
+        for (int y = 0; y < Y; ++y)
+            for (int x = 0; x < X; ++x) {
+                const float3 pos = vol.VoxelPositionInUnits(x, y, z);
+                const float dist = length(pos - c);
+                const float sdf = dist - r;
+                vol(x, y, z) = SDF_t(sdf);
+            }
+}
+
+// KernElementwiseScaleBias<float,float,float> (cu_operations.cu:39-49) on the reference's InBounds and ConvertPixel
+void ref_elementwise_scale_bias_f32(const kfo_image* pb, const kfo_image* pa, float s, float offset)
+{
+    HImgF b = imf(pb), a = imf(pa);
+    for (int y = 0; y < (int)b.h; ++y)
+        for (int x = 0; x < (int)b.w; ++x)
+            if (b.InBounds(x, y)) {
+                const float v1 = ConvertPixel<float, float>(a(x, y));
+                b(x, y) = ConvertPixel<float, float>(s * v1 + offset);
+            }
+}
+
+// KernBoxHalfIgnoreInvalid<float,float,float> (cu_resample.cu:89-110) on the reference's InvalidValue<float>
+void ref_box_half_ignore_invalid_f32(const kfo_image* pout, const kfo_image* pin)
+{
+    HImgF out = imf(pout), in = imf(pin);
     for (unsigned y = 0; y < out.h; ++y)
         for (unsigned x = 0; x < out.w; ++x) {
-            if (!out.InBounds((int)x, (int)y)) continue;
-            const float p = in(x, y);
-            float sum = 0, sumw = 0;
-            if (!use_minval || p >= minval)
-                for (int r = -size; r <= size; ++r)
-                    for (int c = -size; c <= size; ++c) {
-                        const float q = in.GetWithClampedRange(x + c, y + r);
-                        if (use_minval && !(q >= minval)) continue;
-                        const float sd2 = r * r + c * c;
-                        const float id = p - q;
-                        const float w = expf(-(sd2) / (2 * gs * gs)) * expf(-(id * id) / (2 * gr * gr));
-                        sumw += w;
-                        sum += w * q;
-                    }
-            out(x, y) = sum / sumw;
+            const float* tl = &in(2 * x, 2 * y);
+            const float* bl = &in(2 * x, 2 * y + 1);
+            const float v1 = *tl;
+            const float v2 = *(tl + 1);
+            const float v3 = *bl;
+            const float v4 = *(bl + 1);
+            int n = 0;
+            float sum = 0;
+            if (InvalidValue<float>::IsValid(v1)) { sum += v1; n++; }
+            if (InvalidValue<float>::IsValid(v2)) { sum += v2; n++; }
+            if (InvalidValue<float>::IsValid(v3)) { sum += v3; n++; }
+            if (InvalidValue<float>::IsValid(v4)) { sum += v4; n++; }
+            out(x, y) = n > 0 ? (float)(sum / n) : InvalidValue<float>::Value();
         }
 }
 

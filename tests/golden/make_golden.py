@@ -5,11 +5,15 @@ where /root/reference exists:
     make -C oracle all ref && python tests/golden/make_golden.py
 
 Producers (recorded per array in each .npz under the key `producers`):
-  * "ref"    -- the reference's own header code compiled in place (oracle/_ref/libkfx_refhdr.so,
-                see oracle/ref_harness.cpp): voxel positions, SE3/pinhole maths, bilinear/trilinear
-                sampling, gradient stencil, SDF_t running average, ROI helpers.
-  * "oracle" -- the plain-C restatement (oracle/kfx_oracle.c), for the pieces that only exist
-                inside the reference's .cu kernels (bilateral weights, NormalsFromVbo, PhongShade).
+  * "ref"    -- the reference's own code compiled in place (oracle/_ref/libkfx_refhdr.so, see
+                oracle/ref_harness.cpp): voxel positions, SE3/pinhole maths, bilinear/trilinear
+                sampling, gradient stencil, SDF_t running average, ROI helpers; the bilateral and
+                NormalsFromVbo loops on the reference's GetWithClampedRange / float4 operators;
+                PhongShade compiled from the reference's own lines; SdfSphere on the reference's
+                VoxelPositionInUnits / length / SDF_t(float).
+  * "input"  -- synthetic inputs (kangaroo_amd/scenes.py).
+Every producer="ref" array is also asserted equal to the plain-C restatement (oracle/kfx_oracle.c)
+while the fixture is written, so a fixture can only be generated when oracle and reference agree.
 The fixtures are data only: inputs and expected outputs.  No reference source text is stored.
 """
 import ctypes as C
@@ -64,10 +68,16 @@ def chain_fixture(R, name, scene, N, w, h, n_frames, dims=None, subpix=True, hol
         f = oracle.Image(w, h)
         vbo = oracle.Image(w, h, channels=4)
         nrm = oracle.Image(w, h, channels=4)
-        oracle.bilateral(f, d, 1.5, 0.1, 3, 0.2)
+        R.ref_bilateral_f32(f.ref(), d.ref(), C.c_float(1.5), C.c_float(0.1), 3, C.c_float(0.2), 1)
         _, k = fp(K)
         R.ref_depth_to_vbo(vbo.ref(), f.ref(), k, C.c_float(1.0))
-        oracle.normals_from_vbo(nrm, vbo)
+        R.ref_normals_from_vbo(nrm.ref(), vbo.ref())
+        of, ov, on_ = oracle.Image(w, h), oracle.Image(w, h, channels=4), oracle.Image(w, h, channels=4)
+        oracle.bilateral(of, d, 1.5, 0.1, 3, 0.2)
+        oracle.depth_to_vbo(ov, of, K)
+        oracle.normals_from_vbo(on_, ov)
+        assert all(np.array_equal(a.data, b.data, equal_nan=True) for a, b in ((f, of), (vbo, ov), (nrm, on_))), \
+            "oracle preprocess disagrees with the reference-header preprocess"
         T_cw = scenes.se3_inverse(T_wc)
         _, t = fp(T_cw)
         work = vol
@@ -88,13 +98,13 @@ def chain_fixture(R, name, scene, N, w, h, n_frames, dims=None, subpix=True, hol
         n = R.ref_sdf_fuse(work.ref(), f.ref(), nrm.ref(), t, k, C.c_float(tr), C.c_float(scenes.MAX_W),
                            C.c_float(scenes.MIN_COS_THETA), 0)
         out["raw_%d" % i] = raw; prod["raw_%d" % i] = "input"
-        out["filtered_%d" % i] = f.data.copy(); prod["filtered_%d" % i] = "oracle"
+        out["filtered_%d" % i] = f.data.copy(); prod["filtered_%d" % i] = "ref"
         out["vbo_%d" % i] = vbo.data.copy(); prod["vbo_%d" % i] = "ref"
-        out["normals_%d" % i] = nrm.data.copy(); prod["normals_%d" % i] = "oracle"
+        out["normals_%d" % i] = nrm.data.copy(); prod["normals_%d" % i] = "ref"
         poses.append(T_wc)
         n_upd.append(int(n))
     out["volume"] = vol.data.copy(); prod["volume"] = "ref"
-    # raycast from the last pose: geometry by the reference headers, shading by the oracle
+    # raycast from the last pose: geometry by the reference headers, shading by the reference's PhongShade
     T_wc = poses[-1]
     rd, rn = oracle.Image(w, h), oracle.Image(w, h, channels=4)
     _, t = fp(T_wc)
@@ -103,11 +113,13 @@ def chain_fixture(R, name, scene, N, w, h, n_frames, dims=None, subpix=True, hol
                        1 if subpix else 0)
     od, on, oi = oracle.Image(w, h), oracle.Image(w, h, channels=4), oracle.Image(w, h)
     st = oracle.raycast_sdf(od, on, oi, vol, T_wc, K, near, far, tr, subpix)
-    assert np.array_equal(od.data, rd.data, equal_nan=True) and np.array_equal(on.data, rn.data), \
+    ri = oracle.Image(w, h)
+    R.ref_raycast_shade(ri.ref(), rd.ref(), rn.ref(), k)
+    assert np.array_equal(od.data, rd.data, equal_nan=True) and np.array_equal(on.data, rn.data) and np.array_equal(oi.data, ri.data), \
         "oracle raycast disagrees with the reference-header raycast"
     out["ray_depth"] = rd.data.copy(); prod["ray_depth"] = "ref"
     out["ray_norm"] = rn.data.copy(); prod["ray_norm"] = "ref"
-    out["ray_img"] = oi.data.copy(); prod["ray_img"] = "oracle"
+    out["ray_img"] = ri.data.copy(); prod["ray_img"] = "ref"
     out["poses"] = np.stack(poses); prod["poses"] = "input"
     meta = dict(scene=scene, dims=list(dims), w=w, h=h, n_frames=n_frames, K=K.tolist(), boxmin=list(bmin),
                 boxmax=list(bmax), near=near, far=far, trunc=tr, max_w=scenes.MAX_W, mincostheta=scenes.MIN_COS_THETA,
@@ -125,8 +137,13 @@ def sphere_fixture(R, name, N, w, h, trunc):
     K = scenes.intrinsics(w, h)
     vol = oracle.Volume(N, N, N, (-1, -1, -1), (1, 1, 1))
     oracle.sdf_reset(vol, float("nan"))
-    # SdfSphere via reference VoxelPositionInUnits + oracle length/sub (the kernel body is .cu-only)
-    oracle.sdf_sphere(vol, (0.05, -0.1, 0.0), 0.7)
+    # SdfSphere: the kernel body on the reference's VoxelPositionInUnits / length / SDF_t(float)
+    _, cc = fp((0.05, -0.1, 0.0))
+    R.ref_sdf_sphere(vol.ref(), cc, C.c_float(0.7))
+    ovol = oracle.Volume(N, N, N, (-1, -1, -1), (1, 1, 1))
+    oracle.sdf_reset(ovol, float("nan"))
+    oracle.sdf_sphere(ovol, (0.05, -0.1, 0.0), 0.7)
+    assert np.array_equal(ovol.data, vol.data, equal_nan=True), "oracle SdfSphere disagrees with the reference-header SdfSphere"
     pos = (C.c_float * 3)()
     for (x, y, z) in ((0, 0, 0), (N - 1, N - 1, N - 1), (5, 17, 9), (N // 2, 3, N - 2)):
         R.ref_voxel_position(vol.ref(), x, y, z, pos)
@@ -142,13 +159,15 @@ def sphere_fixture(R, name, N, w, h, trunc):
     R.ref_raycast_geom(rd.ref(), rn.ref(), vol.ref(), t, k, C.c_float(0.1), C.c_float(10.0), C.c_float(trunc), 1)
     od, on, oi = oracle.Image(w, h), oracle.Image(w, h, channels=4), oracle.Image(w, h)
     st = oracle.raycast_sdf(od, on, oi, vol, T_wc, K, 0.1, 10.0, trunc, True)
-    assert np.array_equal(od.data, rd.data, equal_nan=True) and np.array_equal(on.data, rn.data)
+    ri = oracle.Image(w, h)
+    R.ref_raycast_shade(ri.ref(), rd.ref(), rn.ref(), k)
+    assert np.array_equal(od.data, rd.data, equal_nan=True) and np.array_equal(on.data, rn.data) and np.array_equal(oi.data, ri.data)
     meta = dict(dims=[N, N, N], w=w, h=h, K=K.tolist(), boxmin=[-1, -1, -1], boxmax=[1, 1, 1], near=0.1, far=10.0,
                 trunc=trunc, center=[0.05, -0.1, 0.0], r=0.7, raycast_stats={k_: int(v) for k_, v in st.items()})
-    prod = dict(volume="oracle(+ref voxel positions spot-checked)", ray_depth="ref", ray_norm="ref", ray_img="oracle")
+    prod = dict(volume="ref", ray_depth="ref", ray_norm="ref", ray_img="ref")
     path = os.path.join(HERE, name + ".npz")
     np.savez_compressed(path, volume=vol.data.copy(), T_wc=T_wc, ray_depth=rd.data.copy(), ray_norm=rn.data.copy(),
-                        ray_img=oi.data.copy(), meta=np.array(json.dumps(meta)), producers=np.array(json.dumps(prod)))
+                        ray_img=ri.data.copy(), meta=np.array(json.dumps(meta)), producers=np.array(json.dumps(prod)))
     print("%-28s %8.1f KiB  hits=%d" % (name + ".npz", os.path.getsize(path) / 1024, st["hits"]))
 
 
@@ -257,6 +276,17 @@ def next_rows_fixture(R, name):
         assert R.ref_save_pxm(fn.encode(), small.ref(), 8) == 0
         out.update(pxm_volume=small.data.copy(), pxm_boxmin=small.boxmin, pxm_boxmax=small.boxmax,
                    pxm_bytes=np.frombuffer(open(fn, "rb").read(), np.uint8).copy())
+    # ---- frame pre-amble (row f-1): mm -> m scale-bias and the NaN-aware 2x2 reduction, reference header arithmetic ----
+    rng = np.random.default_rng(11)
+    pw, ph = 70, 50
+    mm = rng.uniform(300, 6000, (ph, pw)).astype(np.float32)
+    mm[3:6, 9:20] = np.nan
+    mm[20:22, 30:32] = np.nan          # one fully invalid 2x2 cell
+    mm[41, 7] = np.inf
+    src, metres, half = oracle.Image.from_numpy(mm), oracle.Image(pw, ph), oracle.Image(pw // 2, ph // 2)
+    R.ref_elementwise_scale_bias_f32(metres.ref(), src.ref(), C.c_float(1.0 / 1000.0), C.c_float(0.0))
+    R.ref_box_half_ignore_invalid_f32(half.ref(), metres.ref())
+    out.update(pre_mm=mm, pre_metres=metres.data.copy(), pre_half=half.data.copy())
     path = os.path.join(HERE, name + ".npz")
     np.savez_compressed(path, **out)
     print("%-28s %8.1f KiB" % (name + ".npz", os.path.getsize(path) / 1024))

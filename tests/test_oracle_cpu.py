@@ -343,3 +343,138 @@ def test_oracle_texture_depth_vs_reference_headers():
         oracle.texture_depth(want, keyframes, rd, rn, T_wd, K, phong, fn=R.ref_texture_depth)
         assert T.nan_equal(got.data, want.data), T.mismatch_report(got.data, want.data)
         assert (got.data[..., 3] == 1).all() and (got.data[..., :3] > 0).any()
+
+
+def _ref_lib():
+    R = C.CDLL(REF_SO)
+    R.ref_phong_shade.restype = C.c_float
+    return R
+
+
+def _pf(a):
+    a = np.ascontiguousarray(a, np.float32).reshape(-1)
+    return a, a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+@pytest.mark.skipif(not os.path.exists(REF_SO), reason="oracle/_ref not built (needs /root/reference)")
+def test_oracle_bilateral_vs_reference_headers():
+    """BilateralFilter, all four instantiations the path uses (cu_bilateral.cu:52-53,103-104): the restatement against
+    the kernel's loop run on the reference's Image::InBounds / GetWithClampedRange -- same libm expf, so bit-equal."""
+    R = _ref_lib()
+    rng = np.random.default_rng(21)
+    w, h = 75, 53
+    K = scenes.intrinsics(w, h)
+    raw = scenes.render_depth("room", w, h, scenes.orbit_pose(2, 8), K, noise_sigma=0.003, seed=5)
+    raw[7:15, 20:31] = np.nan          # holes
+    raw[30:33, :] = 0.1                # below minval
+    raw[0, 0] = np.nan                 # invalid corner: clamped taps
+    for gs, gr, size in ((1.5, 0.1, 3), (2.0, 0.05, 1), (0.8, 0.3, 4)):
+        for minval in (0.2, None):
+            src = oracle.Image.from_numpy(raw if minval is not None else np.nan_to_num(raw, nan=1.0), pitch_bytes=w * 4 + 32)
+            got, want = oracle.Image(w, h), oracle.Image(w, h)
+            oracle.bilateral(got, src, gs, gr, size, minval)
+            R.ref_bilateral_f32(want.ref(), src.ref(), C.c_float(gs), C.c_float(gr), size, C.c_float(minval or 0.0), int(minval is not None))
+            assert T.nan_equal(got.data, want.data), (gs, gr, size, minval, T.mismatch_report(got.data, want.data))
+            if minval is not None:
+                assert np.isnan(got.data).any() and np.isfinite(got.data).any()
+    mm = rng.integers(0, 4000, (h, w)).astype(np.uint16)
+    mm[10:14] = 100
+    src = oracle.Image.from_numpy(mm)
+    got, want = oracle.Image(w, h), oracle.Image(w, h)
+    oracle.bilateral(got, src, 1.5, 80.0, 3, 200)
+    R.ref_bilateral_u16(want.ref(), src.ref(), C.c_float(1.5), C.c_float(80.0), 3, C.c_ushort(200))
+    assert T.nan_equal(got.data, want.data) and np.isnan(got.data).any()
+    g8 = rng.integers(0, 256, (h, w)).astype(np.uint8)
+    src = oracle.Image.from_numpy(g8)
+    oracle.bilateral(got, src, 1.5, 20.0, 2)
+    R.ref_bilateral_u8(want.ref(), src.ref(), C.c_float(1.5), C.c_float(20.0), 2)
+    assert T.nan_equal(got.data, want.data) and np.isfinite(got.data).all()
+
+
+@pytest.mark.skipif(not os.path.exists(REF_SO), reason="oracle/_ref not built (needs /root/reference)")
+def test_oracle_normals_from_vbo_vs_reference_headers():
+    """NormalsFromVbo (cu_normals.cu:12-38) on the reference's float4 operator-, length, make_float4: NaN vertices,
+    zero-area triangles (0/0) and the zeroed last row / column included."""
+    R = _ref_lib()
+    w, h = 67, 45
+    K = scenes.intrinsics(w, h)
+    raw = scenes.render_depth("room", w, h, scenes.orbit_pose(3, 8), K, noise_sigma=0.002, seed=9)
+    raw[5:9, 11:19] = np.nan
+    vbo = oracle.Image(w, h, channels=4, pitch_bytes=w * 16 + 48)
+    oracle.depth_to_vbo(vbo, oracle.Image.from_numpy(raw), K)
+    vbo.data[20, 30] = vbo.data[20, 31] = vbo.data[21, 30]        # degenerate: a = b = 0
+    got, want = oracle.Image(w, h, channels=4), oracle.Image(w, h, channels=4)
+    oracle.normals_from_vbo(got, vbo)
+    R.ref_normals_from_vbo(want.ref(), vbo.ref())
+    assert T.nan_equal(got.data, want.data), T.mismatch_report(got.data, want.data)
+    assert (got.data[-1] == 0).all() and (got.data[:, -1] == 0).all() and np.isnan(got.data[20, 30, :3]).all()
+    inner = got.data[:-1, :-1]
+    ok = np.isfinite(inner[..., 0])
+    assert ok.sum() > 0.8 * w * h and (inner[..., 3] == 1).all()
+
+
+@pytest.mark.skipif(not os.path.exists(REF_SO), reason="oracle/_ref not built (needs /root/reference)")
+def test_oracle_phong_shade_vs_reference_source():
+    """PhongShade compiled from the reference's own lines (cu_raycast.cu:14-28, extracted by oracle/Makefile at build
+    time): the oracle's shade image equals it on every hit of a raycast, and misses are 0."""
+    R = _ref_lib()
+    w, h = 96, 72
+    K = scenes.intrinsics(w, h)
+    vol = T.make_volume(40, "room")
+    T.fuse_frames_oracle(vol, "room", w, h, 2)
+    bmin, bmax, near, far = scenes.SCENES["room"]
+    tr = scenes.trunc_dist(bmin, bmax, (40, 40, 40))
+    for T_wc in (scenes.orbit_pose(1, 8), scenes.orbit_pose(5, 8, yaw_deg=15.0, trans=0.15)):
+        rd, rn, ri = oracle.Image(w, h), oracle.Image(w, h, channels=4), oracle.Image(w, h)
+        st = oracle.raycast_sdf(rd, rn, ri, vol, T_wc, K, near, far, tr, True)
+        want = oracle.Image(w, h)
+        want.data[...] = 7.0
+        _, k = _pf(K)
+        R.ref_raycast_shade(want.ref(), rd.ref(), rn.ref(), k)
+        assert T.nan_equal(ri.data, want.data), T.mismatch_report(ri.data, want.data)
+        assert st["hits"] > 1000 and (ri.data[np.isnan(rd.data)] == 0).all() and (ri.data[np.isfinite(rd.data)] > 0.0).all()
+    # and the function itself on arbitrary (not unit, back-facing) vectors
+    rng = np.random.default_rng(2)
+    for _ in range(200):
+        p, n = rng.normal(0, 1, 3).astype(np.float32), rng.normal(0, 1, 3).astype(np.float32)
+        _, pp = _pf(p)
+        _, nn = _pf(n)
+        assert np.float32(R.ref_phong_shade(pp, nn)) == np.float32(oracle.phong_shade(p, n))
+
+
+@pytest.mark.skipif(not os.path.exists(REF_SO), reason="oracle/_ref not built (needs /root/reference)")
+def test_oracle_sdf_sphere_and_preamble_vs_reference_headers():
+    """SdfSphere (cu_sdffusion.cu:175-195), ElementwiseScaleBias<float,float,float> (cu_operations.cu:39-57) and
+    BoxHalfIgnoreInvalid<float,float,float> (cu_resample.cu:89-120) against the kernels' bodies run on the reference's
+    VoxelPositionInUnits / length / SDF_t(float), ConvertPixel and InvalidValue<float>."""
+    R = _ref_lib()
+    for dims, pitch in (((32, 32, 32), None), ((20, 17, 13), 20 * 8 + 24)):
+        a = oracle.Volume(*dims, (-1, -0.5, 0.25), (1, 1.5, 2.0), pitch_bytes=pitch)
+        b = oracle.Volume(*dims, (-1, -0.5, 0.25), (1, 1.5, 2.0), pitch_bytes=pitch)
+        for v in (a, b):
+            oracle.sdf_reset(v, float("nan"))
+        c, cp = _pf((0.05, 0.3, 1.1))
+        oracle.sdf_sphere(a, c, 0.6)
+        R.ref_sdf_sphere(b.ref(), cp, C.c_float(0.6))
+        assert T.nan_equal(a.data, b.data) and (a.data[..., 1][np.isfinite(a.data[..., 0])] == 1).all()
+        assert np.isnan(a.data[..., 0]).any() == (dims != (32, 32, 32))   # (dim/8)*8 extents
+    rng = np.random.default_rng(8)
+    w, h = 70, 50
+    mm = rng.uniform(0, 6000, (h, w)).astype(np.float32)
+    mm[3:6, 9:20] = np.nan
+    src = oracle.Image.from_numpy(mm, pitch_bytes=w * 4 + 16)
+    got, want = oracle.Image(w, h), oracle.Image(w, h)
+    oracle.elementwise_scale_bias(got, src, 1.0 / 1000.0, 0.0)
+    R.ref_elementwise_scale_bias_f32(want.ref(), src.ref(), C.c_float(1.0 / 1000.0), C.c_float(0.0))
+    assert T.nan_equal(got.data, want.data)
+    oracle.elementwise_scale_bias(got, src, 0.5, -1.25)
+    R.ref_elementwise_scale_bias_f32(want.ref(), src.ref(), C.c_float(0.5), C.c_float(-1.25))
+    assert T.nan_equal(got.data, want.data)
+    m = got.data.copy()
+    m[10:12, 10:12] = np.nan       # a fully invalid 2x2 cell -> NaN out
+    m[20, 21] = np.inf             # non-finite counts as invalid
+    src = oracle.Image.from_numpy(m)
+    g2, w2 = oracle.Image(w // 2, h // 2), oracle.Image(w // 2, h // 2)
+    oracle.box_half_ignore_invalid(g2, src)
+    R.ref_box_half_ignore_invalid_f32(w2.ref(), src.ref())
+    assert T.nan_equal(g2.data, w2.data) and np.isnan(g2.data[5, 5]) and np.isfinite(g2.data).sum() > 0.9 * g2.data.size
