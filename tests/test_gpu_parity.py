@@ -330,25 +330,29 @@ def _fast_vs_oracle(roo, scene, N, w, h, frames):
         roo.set_math_mode(prev)
     exp = ovol.data
     nan_g, nan_e = np.isnan(got[..., 0]), np.isnan(exp[..., 0])
-    flips = int((nan_g != nan_e).sum())
+    flips = int((nan_g != nan_e).sum())                       # observed on one side only
     both = ~nan_g & ~nan_e
-    dv = np.abs(got[..., 0][both] - exp[..., 0][both])
     dw = np.abs(got[..., 1][both] - exp[..., 1][both]) / np.maximum(np.abs(exp[..., 1][both]), 1e-12)
-    outliers = int((dv > FAST_TSDF_TOL).sum())
-    return dict(n=N ** 3, flips=flips, outliers=outliers, linf=float(dv[dv <= FAST_TSDF_TOL].max()),
-                w_rel=float(np.median(dw)), w_rel_p999=float(np.quantile(dw, 0.999)))
+    same = dw <= 1e-3                                         # same set of frames updated the voxel on both sides
+    dv = np.abs(got[..., 0][both] - exp[..., 0][both])
+    return dict(n=N ** 3, flips=flips, history_flips=int((~same).sum()), linf=float(dv[same].max()),   # TRUE max, nothing filtered
+                n_above_tol=int((dv[same] > FAST_TSDF_TOL).sum()), top5=np.sort(dv[same])[-5:].tolist(),
+                linf_all_common=float(dv.max()), trunc=float(tr), w_rel=float(np.median(dw[same])))
 
 
 @pytest.mark.parametrize("scene,N,w,h,frames", [("room", 64, 160, 120, 4), ("full", 64, 160, 120, 2),
                                                 ("room", 128, 640, 480, 3)])
 def test_gpu_fast_mode_within_tolerance(roo, scene, N, w, h, frames):
-    """KFX_MATH_FAST (rcp/rsq/FMA) vs the exact oracle: TSDF values within 1e-4 on identically
-    classified voxels; the number of differently classified voxels (update flips at predicate
-    boundaries, bilinear-cell flips at depth edges) is counted and must stay negligible."""
+    """KFX_MATH_FAST SdfFuse (rcp/rsq/FMA) on the oracle's filtered images vs the exact oracle: TSDF values within 1e-4 on
+    EVERY identically classified voxel (the true maximum; no exception list); the voxels classified differently (observed
+    on one side only, or updated by a different set of frames: predicate / bilinear-cell boundaries) are counted, must stay
+    negligible, and can differ by at most the clamp range.  The whole chain from raw depth at the benchmarked sizes is
+    tests/test_gpu_chain.py."""
     r = _fast_vs_oracle(roo, scene, N, w, h, frames)
     budget = max(3, int(FAST_FLIP_FRACTION * r["n"] * frames))
-    assert r["flips"] <= budget and r["outliers"] <= budget, r
-    assert r["linf"] <= FAST_TSDF_TOL and r["w_rel_p999"] < 1e-4, r
+    assert r["flips"] + r["history_flips"] <= budget, r
+    assert r["linf"] < FAST_TSDF_TOL and r["n_above_tol"] == 0, r
+    assert r["linf_all_common"] <= 2 * r["trunc"] * (1 + 1e-6), r
 
 
 def test_gpu_fast_mode_unaligned_and_default_restored(roo):
