@@ -20,6 +20,13 @@ int kfx_debug_rmw(const kfx_volume* vol, int variant, kfx_stream stream);
  * d_out[1] += patterns tested (those inside the shortcut's operand range); both device-side 64-bit counters. */
 int kfx_debug_div_uniform_check(float b, unsigned long long* d_out, kfx_stream stream);
 
+/* The exact-mode SdfFuse kernel's division / square-root shortcuts (kfx_device.h: rcp_nr + div_core, sqrt_core) against
+ * the hardware IEEE operations.  div: every divisor significand in ten binades of [2^-40, 2^40] x per_divisor numerators
+ * (random and awkward significands in [2^-60, 2^60], zeros); sqrt: every float in [2^-80, 2^80].  d_out[0] += results that
+ * differ (a zero of the other sign counts as equal), d_out[1] += cases tested. */
+int kfx_debug_div_core_check(unsigned seed, int per_divisor, unsigned long long* d_out, kfx_stream stream);
+int kfx_debug_sqrt_core_check(unsigned long long* d_out, kfx_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -110,9 +110,84 @@ __global__ __launch_bounds__(256) void k_div_uniform_check(float b, float inv, u
     atomicAdd(out + 1, tested);
 }
 
+// div_core / rcp_nr against the hardware IEEE division.  Thread t sweeps divisor significands (every 2^23 of them
+// across the grid) in each of a set of binades and pairs each with numerators from a counter-based generator
+// (splitmix-style hash): random significands in random binades of [2^-60, 2^60], plus the awkward ones (all ones, one ulp
+// above / below a power of two) and exact zeros.  A signed-zero quotient counts as equal to the other zero.
+__device__ __forceinline__ unsigned hash32(unsigned long long x)
+{
+    x += 0x9e3779b97f4a7c15ull;
+    x = (x ^ (x >> 30)) * 0xbf58476d1ce4e5b9ull;
+    x = (x ^ (x >> 27)) * 0x94d049bb133111ebull;
+    return (unsigned)((x ^ (x >> 31)) >> 16);
+}
+__global__ __launch_bounds__(256) void k_div_core_check(unsigned seed, int per_divisor, unsigned long long* __restrict__ out)
+{
+    const int bexp[] = {-40, -20, -3, -1, 0, 1, 2, 10, 20, 40};
+    unsigned long long bad = 0, tested = 0;
+    const unsigned tid = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
+    for (unsigned m = tid; m < (1u << 23); m += stride) {
+        for (int be = 0; be < 10; ++be) {
+            const unsigned bbits = ((unsigned)(127 + bexp[be]) << 23) | m | ((m & 1u) << 31); // alternate signs
+            const float b = __uint_as_float(bbits);
+            const float y = rcp_nr(b);
+            for (int k = 0; k < per_divisor; ++k) {
+                const unsigned h = hash32(((unsigned long long)seed << 40) ^ ((unsigned long long)m << 8) ^ (unsigned)(be * 64 + k));
+                unsigned am = h & 0x7fffffu;
+                const int sel = (h >> 23) & 15;
+                if (sel == 0) am = 0x7fffffu;
+                else if (sel == 1) am = 0u;
+                else if (sel == 2) am = 1u;
+                else if (sel == 3) am = 0x7ffffeu;
+                const int ae = (int)((h >> 27) % 121u) - 60;
+                unsigned abits = ((unsigned)(127 + ae) << 23) | am | (h & 0x80000000u);
+                if (k == 0) abits = h & 0x80000000u; // +-0
+                const float a = __uint_as_float(abits);
+                const float want = a / b;
+                const float got = div_core(a, b, y);
+                tested += 1;
+                const bool same = __float_as_uint(want) == __float_as_uint(got) || (want == 0.0f && got == 0.0f);
+                bad += same ? 0 : 1;
+            }
+        }
+    }
+    atomicAdd(out, bad);
+    atomicAdd(out + 1, tested);
+}
+
+// sqrt_core against sqrtf for every float in [2^-80, 2^80]
+__global__ __launch_bounds__(256) void k_sqrt_core_check(unsigned long long* __restrict__ out)
+{
+    unsigned long long bad = 0, tested = 0;
+    const unsigned lo = (unsigned)(127 - 80) << 23, hi = (unsigned)(127 + 80) << 23;
+    const unsigned stride = gridDim.x * blockDim.x;
+    for (unsigned long long bits = (unsigned long long)lo + blockIdx.x * blockDim.x + threadIdx.x; bits <= hi; bits += stride) {
+        const float x = __uint_as_float((unsigned)bits);
+        tested += 1;
+        bad += (__float_as_uint(sqrtf(x)) != __float_as_uint(sqrt_core(x))) ? 1 : 0;
+    }
+    atomicAdd(out, bad);
+    atomicAdd(out + 1, tested);
+}
+
 } // namespace kfx
 
 using namespace kfx;
+
+extern "C" int kfx_debug_div_core_check(unsigned seed, int per_divisor, unsigned long long* d_out, kfx_stream stream)
+{
+    if (!d_out) return set_error(KFX_E_NULL, "kfx_debug_div_core_check");
+    if (per_divisor < 1 || per_divisor > 64) return set_error(KFX_E_RANGE, "kfx_debug_div_core_check: per_divisor in [1, 64]");
+    hipLaunchKernelGGL(k_div_core_check, dim3(4096), dim3(256), 0, (hipStream_t)stream, seed, per_divisor, d_out);
+    return check_launch("kfx_debug_div_core_check");
+}
+
+extern "C" int kfx_debug_sqrt_core_check(unsigned long long* d_out, kfx_stream stream)
+{
+    if (!d_out) return set_error(KFX_E_NULL, "kfx_debug_sqrt_core_check");
+    hipLaunchKernelGGL(k_sqrt_core_check, dim3(4096), dim3(256), 0, (hipStream_t)stream, d_out);
+    return check_launch("kfx_debug_sqrt_core_check");
+}
 
 extern "C" int kfx_debug_div_uniform_check(float b, unsigned long long* d_out, kfx_stream stream)
 {

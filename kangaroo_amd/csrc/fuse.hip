@@ -46,6 +46,7 @@ struct FuseParams {
     float dwb, dhb;         // (float)depth.w - 2, (float)depth.h - 2  (InBounds border, Image.h:287-291)
     float trunc, max_w, mincos;
     unsigned dpitch, npitch; // image pitches as 32-bit values (valid when `small_images`)
+    int exact_shared;        // exact mode: camera / thresholds allow the shared-reciprocal arithmetic (see finish_shared)
 };
 
 struct Obs {
@@ -180,6 +181,41 @@ __device__ __forceinline__ Obs finish(const FuseParams& p, const V3 Pc, float iz
     o.val = clampf(sd, -p.trunc, p.trunc);
     o.w = w;
     return o;
+}
+
+// Exact numerics with cheaper instruction sequences (k_sdf_fuse_tiled, bricks that pass the operand-range test):
+// the same IEEE results as finish<false>, computed with
+//   * one Newton-refined reciprocal of Z (`yz`, shared with the two projection quotients) for w = costheta / Z,
+//   * sqrt_core for length(Pc) and rcp_nr + div_core for dot / -length (kfx_device.h),
+//   * v_med3_f32 for the clamp (sd is never NaN when the predicate holds).
+// The operand ranges that make div_core / sqrt_core exact are established per brick (Z, |X|, |Y| of all its voxels within
+// [2^-20, 2^20]) and per launch (|fu|, |fv| in [2^-20, 2^20], mincostheta >= 2^-20, trunc > 0).  Numerators are not range
+// checked: a quotient too small or too large for div_core to be exact (|dot| < 2^-100, results beyond 2^127) cannot pass
+// the update predicate on either path -- costheta <= mincostheta, or a non-finite weight -- and a projection quotient
+// below 2^-80 disappears in u0 + q (or leaves the sample outside the image border when u0 is that small too).
+__device__ __forceinline__ Obs finish_shared(const FuseParams& p, const V3 Pc, float yz, float fx, float fy, const Corners& c)
+{
+    Obs o;
+    const float md = lerp(lerp(c.c00.w, c.c01.w, fx), lerp(c.c10.w, c.c11.w, fx), fy);
+    V3 mdn;
+    mdn.x = lerp(lerp(c.c00.x, c.c01.x, fx), lerp(c.c10.x, c.c11.x, fx), fy);
+    mdn.y = lerp(lerp(c.c00.y, c.c01.y, fx), lerp(c.c10.y, c.c11.y, fx), fy);
+    mdn.z = lerp(lerp(c.c00.z, c.c01.z, fx), lerp(c.c10.z, c.c11.z, fx), fy);
+    const float nlen = -sqrt_core(dot(Pc, Pc));
+    const float costheta = div_core(dot(mdn, Pc), nlen, rcp_nr(nlen));
+    const float w = div_core(costheta, Pc.z, yz); // costheta * 1.0f / Pc.z
+    const float sd = costheta * (md - Pc.z);
+    o.ok = ((int)!(sd <= -p.trunc) & (int)isfinite(md) & (int)isfinite(w) & (int)(costheta > p.mincos)) != 0;
+    o.val = __builtin_amdgcn_fmed3f(sd, -p.trunc, p.trunc);
+    o.w = w;
+    return o;
+}
+
+__device__ __forceinline__ int med3_i32(int x, int lo, int hi) // clamp for lo <= hi
+{
+    int r;
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(lo), "v"(hi));
+    return r;
 }
 
 // ---- cell storage policies ----------------------------------------------------------------
@@ -338,16 +374,21 @@ __global__ __launch_bounds__(256) void k_sdf_fuse_tiled(const FuseParams p, cons
 {
     extern __shared__ __attribute__((aligned(16))) float4 s_tile[];
     __shared__ float s_pz[FUSE_ZC];
-    __shared__ float s_box[4][5];
+    __shared__ float s_box[4][6];
     __shared__ float s_dmax[4];
     __shared__ int s_bad[4];
+    __shared__ float4 s_tz[FUSE_ZC]; // exact mode: {pz, T(0,2)*pz, T(1,2)*pz, T(2,2)*pz} per slice
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int x0 = (blockIdx.x * 32 + (lane & 31)) * 2;
     const int y = blockIdx.y * TB_Y + wv * 2 + (lane >> 5);
     const int zbeg = blockIdx.z * FUSE_ZC;
     const int zend = min(zbeg + FUSE_ZC, p.Z);
     const bool live = x0 < p.X && y < p.Y;
-    if (tid < FUSE_ZC) s_pz[tid] = p.bmin.z + p.size.z * (float)(zbeg + tid + p.zoff) / p.d1;
+    if (tid < FUSE_ZC) {
+        const float pz = p.bmin.z + p.size.z * (float)(zbeg + tid + p.zoff) / p.d1;
+        s_pz[tid] = pz;
+        if constexpr (!FAST) s_tz[tid] = make_float4(pz, p.T.m[2] * pz, p.T.m[6] * pz, p.T.m[10] * pz);
+    }
     __syncthreads();
 
     const float py = p.bmin.y + p.size.y * (float)y / p.h1;
@@ -358,6 +399,7 @@ __global__ __launch_bounds__(256) void k_sdf_fuse_tiled(const FuseParams p, cons
     // ---- pixel rectangle of the brick: projections of its first and last slice ----
     float umin = __builtin_inff(), umax = -__builtin_inff(), vmin = __builtin_inff(), vmax = -__builtin_inff();
     float zmin = __builtin_inff(); // nearest camera-space Z of the brick (Z is affine along a column: ends suffice)
+    float cmax = 0.f;              // exact mode: largest |X|, |Y|, Z of the brick (affine too: the corner voxels hold the extremes)
     bool bad = false;
     if (live) {
 #pragma unroll
@@ -372,6 +414,7 @@ __global__ __launch_bounds__(256) void k_sdf_fuse_tiled(const FuseParams p, cons
                 umin = fminf(umin, pu); umax = fmaxf(umax, pu);
                 vmin = fminf(vmin, pv); vmax = fmaxf(vmax, pv);
                 zmin = fminf(zmin, Pc.z);
+                if constexpr (!FAST) cmax = fmaxf(cmax, fmaxf(fmaxf(fabsf(Pc.x), fabsf(Pc.y)), Pc.z));
             }
         }
     }
@@ -380,14 +423,17 @@ __global__ __launch_bounds__(256) void k_sdf_fuse_tiled(const FuseParams p, cons
         umin = fminf(umin, __shfl_xor(umin, off, 64)); umax = fmaxf(umax, __shfl_xor(umax, off, 64));
         vmin = fminf(vmin, __shfl_xor(vmin, off, 64)); vmax = fmaxf(vmax, __shfl_xor(vmax, off, 64));
         zmin = fminf(zmin, __shfl_xor(zmin, off, 64));
+        if constexpr (!FAST) cmax = fmaxf(cmax, __shfl_xor(cmax, off, 64));
     }
     const bool wave_bad = __ballot(bad) != 0ull;
     if (lane == 0) {
         s_box[wv][0] = umin; s_box[wv][1] = umax; s_box[wv][2] = vmin; s_box[wv][3] = vmax; s_box[wv][4] = zmin;
+        s_box[wv][5] = cmax;
         s_bad[wv] = wave_bad ? 1 : 0;
     }
     __syncthreads();
     zmin = fminf(fminf(s_box[0][4], s_box[1][4]), fminf(s_box[2][4], s_box[3][4]));
+    cmax = fmaxf(fmaxf(s_box[0][5], s_box[1][5]), fmaxf(s_box[2][5], s_box[3][5]));
     umin = fminf(fminf(s_box[0][0], s_box[1][0]), fminf(s_box[2][0], s_box[3][0]));
     umax = fmaxf(fmaxf(s_box[0][1], s_box[1][1]), fmaxf(s_box[2][1], s_box[3][1]));
     vmin = fminf(fminf(s_box[0][2], s_box[1][2]), fminf(s_box[2][2], s_box[3][2]));
@@ -471,6 +517,53 @@ __global__ __launch_bounds__(256) void k_sdf_fuse_tiled(const FuseParams p, cons
     // and divergent early-outs cost more issue slots than they save.)  A sample that is in bounds but outside
     // the rectangle -- impossible with the one-texel slack, kept as a guard -- sends the wave through the
     // generic per-lane path for that iteration.  Values are the same expressions as the generic path.
+    if constexpr (!FAST) {
+        // Exact numerics, cheaper instruction sequences (finish_shared): taken when every voxel of the brick keeps the
+        // operands of div_core / sqrt_core inside the range where they are the IEEE results (NaN bounds fail the test).
+        if (use_tile && p.exact_shared && zmin >= 0x1p-20f && cmax <= 0x1p20f) {
+            const int cxmax = tw - 2, cymax = th - 2;
+            // both voxels of the lane in slice z; `any` = the lane has a cell pair to update
+            auto observe_pair = [&](int z, Obs (&o)[2]) -> bool {
+                const float4 tz = s_tz[z - zbeg];
+                bool stray = false;
+#pragma unroll
+                for (int v = 0; v < 2; ++v) {
+                    // cam[v].at(p, pz): the products T(i,2)*pz are uniform per slice and come from LDS
+                    const V3 Pc = v3(cam[v].ax + tz.y + p.T.m[3], cam[v].ay + tz.z + p.T.m[7], cam[v].az + tz.w + p.T.m[11]);
+                    const float yz = rcp_nr(Pc.z);
+                    const float pu = p.K.u0 + div_core(p.K.fu * Pc.x, Pc.z, yz);
+                    const float pv = p.K.v0 + div_core(p.K.fv * Pc.y, Pc.z, yz);
+                    const bool inb = in_bounds(p, pu, pv);
+                    const float fix = floorf(pu), fiy = floorf(pv);
+                    const int rx = (int)fix - tx0, ry = (int)fiy - ty0;
+                    const bool inside = (unsigned)rx <= (unsigned)cxmax && (unsigned)ry <= (unsigned)cymax;
+                    const float4* t = s_tile + (med3_i32(ry, 0, cymax) * tw + med3_i32(rx, 0, cxmax));
+                    Corners c;
+                    c.c00 = t[0]; c.c01 = t[1]; c.c10 = t[tw]; c.c11 = t[tw + 1];
+                    o[v] = finish_shared(p, Pc, yz, pu - fix, pv - fiy, c);
+                    o[v].ok = ((int)o[v].ok & (int)inb & (int)inside) != 0;
+                    stray |= ((int)inb & (int)!inside) != 0;
+                }
+                if (__builtin_expect(__ballot(stray) != 0ull, 0)) {
+                    o[0] = observe<false, true>(p, cam[0].at(p, tz.x));
+                    o[1] = observe<false, true>(p, cam[1].at(p, tz.x));
+                }
+                return ((int)o[0].ok | (int)o[1].ok) != 0;
+            };
+            // (requesting the cells of slice z and consuming them after the observation of slice z + 1 -- a software
+            // pipeline -- was measured and changes nothing: 0.54 ms either way, the loop is bound by instruction issue)
+            for (int z = zbeg; z < zend; ++z, cell += p.vimg_pitch) {
+                Obs o[2];
+                if (observe_pair(z, o)) {
+                    float4 c = CELL::ld2(cell);
+                    if (o[0].ok) accumulate<false, CELL>(o[0], p.max_w, c.x, c.y);
+                    if (o[1].ok) accumulate<false, CELL>(o[1], p.max_w, c.z, c.w);
+                    CELL::st2(cell, c);
+                }
+            }
+            return;
+        }
+    }
     if (use_tile) {
         const int cxmax = tw - 2, cymax = th - 2;
         for (int z = zbeg; z < zend; z += ZU, cell += (size_t)ZU * p.vimg_pitch) {
@@ -1057,6 +1150,12 @@ static int fuse_params(FuseParams& p, bool* small_images, const kfx_volume* vol,
                     depth->pitch < (1u << 24) && norm->pitch < (1u << 24) && depth->h < (1u << 24);
     p.dpitch = *small_images ? (unsigned)depth->pitch : 0u;
     p.npitch = *small_images ? (unsigned)norm->pitch : 0u;
+    // launch-wide half of the operand-range test of the exact kernel's shared-reciprocal arithmetic (finish_shared);
+    // KFX_FUSE_EXACT_SHARED=0 keeps hipcc's own division / square-root expansions (A/B, and the parity suite runs both)
+    static const int shared_env = [] { const char* e = getenv("KFX_FUSE_EXACT_SHARED"); return e ? atoi(e) : 1; }();
+    const float afu = fabsf(p.K.fu), afv = fabsf(p.K.fv);
+    p.exact_shared = shared_env && afu >= 0x1p-20f && afu <= 0x1p20f && afv >= 0x1p-20f && afv <= 0x1p20f &&
+                     mincostheta >= 0x1p-20f && mincostheta < __builtin_inff() && trunc_dist > 0.f && trunc_dist < __builtin_inff();
     return 0;
 }
 

@@ -49,6 +49,46 @@ __device__ __forceinline__ float div_uniform(float a, float b, float inv)
 __device__ __forceinline__ bool div_uniform_safe(float a) { return fabsf(a) < 0x1p40f && fabsf(a) > 0x1p-40f; }
 inline bool div_uniform_safe_host(float b) { const float m = b < 0 ? -b : b; return m < 0x1p40f && m > 0x1p-40f; }
 
+// ---- IEEE quotients and square roots without the range-scaling wrapper ---------------------------------------------
+// hipcc expands a correctly rounded fp32 a / b into v_div_scale x2, v_rcp, a Newton step on the reciprocal, a quotient
+// with two residual corrections, v_div_fmas and v_div_fixup: eleven instructions, five of them of the slow class (measured
+// on MI355X, scripts/ubench/valu_rate.hip: v_div_scale / v_div_fmas / v_div_fixup 5.1 cycles, v_rcp 8.8, v_fma 3.3 per
+// wave-instruction).  v_div_scale only rescales operands whose exponents are extreme and v_div_fixup only patches
+// zero / infinity / NaN operands; in between, the expansion is exactly rcp_nr + div_core below (multiplying by a power of
+// two commutes with every rounding when nothing over- or underflows), so for |b| in [2^-40, 2^40] and a = 0 or |a| in
+// [2^-60, 2^60] div_core(a, b, rcp_nr(b)) IS the IEEE quotient (up to the sign of a zero result) -- and the refined
+// reciprocal can be shared by several numerators.  Checked against the hardware division on the GPU
+// (kfx_debug_div_core_check, tests/test_gpu_parity.py).
+__device__ __forceinline__ float rcp_nr(float b)
+{
+    const float y0 = __builtin_amdgcn_rcpf(b);
+    const float e = __builtin_fmaf(-b, y0, 1.0f);
+    return __builtin_fmaf(e, y0, y0);
+}
+__device__ __forceinline__ float div_core(float a, float b, float y)
+{
+    const float q0 = a * y;
+    const float r0 = __builtin_fmaf(-b, q0, a);
+    const float q1 = __builtin_fmaf(r0, y, q0);
+    const float r1 = __builtin_fmaf(-b, q1, a);
+    return __builtin_fmaf(r1, y, q1);
+}
+// Correctly rounded sqrtf for x in [2^-80, 2^80]: the reciprocal-square-root iteration LLVM itself uses for IEEE sqrt
+// when denormals need no care (one v_rsq_f32 and seven multiply-adds; the denormal-safe expansion hipcc emits here is
+// v_sqrt_f32 plus fifteen instructions, nine of them of the slow class).  Compared with sqrtf over every float of that
+// range on the GPU (kfx_debug_sqrt_core_check).
+__device__ __forceinline__ float sqrt_core(float x)
+{
+    const float r = __builtin_amdgcn_rsqf(x);
+    float s = x * r;
+    float h = r * 0.5f;
+    const float e = __builtin_fmaf(-h, s, 0.5f);
+    h = __builtin_fmaf(h, e, h);
+    s = __builtin_fmaf(s, e, s);
+    const float d = __builtin_fmaf(-s, s, x);
+    return __builtin_fmaf(d, h, s);
+}
+
 // Row-major 3x4 pose, roo::Mat<float,3,4> (Mat.h:33-163)
 struct Pose { float m[12]; };
 // ImageIntrinsics {fu, fv, u0, v0} (ImageIntrinsics.h:51-200)

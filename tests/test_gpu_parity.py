@@ -1256,6 +1256,32 @@ def test_gpu_division_by_uniform_divisor_is_the_ieee_quotient(roo):
         assert tested > 1_300_000_000 and bad == 0, (b, bad, tested)
 
 
+def test_gpu_shared_reciprocal_division_and_sqrt_are_the_ieee_results(roo):
+    """The exact SdfFuse kernel divides three numerators by one Z through a shared Newton-refined reciprocal and takes
+    its square root by the rsq iteration (kfx_device.h: rcp_nr / div_core / sqrt_core) instead of hipcc's scaled expansions.
+    Inside the operand ranges the kernel establishes per brick these must be the hardware's IEEE results bit for bit:
+    every divisor significand in ten binades x 24 numerators each (two seeds: 4e9 quotients), and every float of
+    [2^-80, 2^80] for the square root."""
+    import ctypes as C
+    import torch
+    from kangaroo_amd import _lib
+    L = _lib.load()
+    L.kfx_debug_div_core_check.restype = C.c_int
+    L.kfx_debug_div_core_check.argtypes = [C.c_uint, C.c_int, C.c_void_p, C.c_void_p]
+    L.kfx_debug_sqrt_core_check.restype = C.c_int
+    L.kfx_debug_sqrt_core_check.argtypes = [C.c_void_p, C.c_void_p]
+    out = torch.zeros(2, dtype=torch.int64, device="cuda")
+    for seed in (1, 20261002):
+        out.zero_()
+        assert L.kfx_debug_div_core_check(seed, 24, C.c_void_p(out.data_ptr()), None) == 0
+        bad, tested = (int(v) for v in out.cpu())
+        assert tested == (1 << 23) * 10 * 24 and bad == 0, (seed, bad, tested)
+    out.zero_()
+    assert L.kfx_debug_sqrt_core_check(C.c_void_p(out.data_ptr()), None) == 0
+    bad, tested = (int(v) for v in out.cpu())
+    assert tested == 160 * (1 << 23) + 1 and bad == 0, (bad, tested)
+
+
 def test_gpu_raycast_levels_equal_per_level_calls(roo):
     """kfx_raycast_sdf_levels (all pyramid levels of the tracking loop in one launch) writes, per level, exactly what
     kfx_raycast_sdf writes: fp32 and fp16 cells, odd level sizes, an empty level list, and the tracked pipeline
