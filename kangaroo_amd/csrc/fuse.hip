@@ -369,22 +369,31 @@ __global__ __launch_bounds__(256) void k_sdf_fuse(const FuseParams p)
 // rectangle can never be read from LDS).  Texel values are copies, so results are identical
 // to the generic kernel in either numerics mode.
 // ---------------------------------------------------------------------------------------
-template <bool FAST, int ZU, typename CELL>
+// Brick geometry (template): LX lanes side by side in x (2 voxels each), 64 / LX rows per wave, WY waves stacked in y,
+// the remaining 4 / WY waves split the ZC slices between them.  <32, 4, 16>: 64 x 8 x 16 voxels, the default; <16, 2, 16>:
+// 32 x 8 x 16 voxels (a wave = 32 voxels x 4 rows, two waves per half of the slices) for ranges where a voxel covers more
+// than ~1.3 pixels -- the rectangle narrows with the brick (its width is about r (BX + 0.56 BZ), its height r (BY + 0.42 BZ)
+// texels for r pixels per voxel), so it keeps fitting a tile that leaves 3-6 workgroups on a CU where the wide brick would
+// need 48 KiB or fall back to global gathers.
+template <bool FAST, int ZU, typename CELL, int LX = 32, int WY = 4, int ZC = FUSE_ZC>
 __global__ __launch_bounds__(256) void k_sdf_fuse_tiled(const FuseParams p, const int cap_px)
 {
+    constexpr int RW = 64 / LX, WZ = 4 / WY, ZW = ZC / WZ, BY = RW * WY;
+    static_assert(LX * RW == 64 && WY * WZ == 4 && ZW * WZ == ZC && ZW % ZU == 0, "brick geometry");
     extern __shared__ __attribute__((aligned(16))) float4 s_tile[];
-    __shared__ float s_pz[FUSE_ZC];
+    __shared__ float s_pz[ZC];
     __shared__ float s_box[4][6];
     __shared__ float s_dmax[4];
     __shared__ int s_bad[4];
-    __shared__ float4 s_tz[FUSE_ZC]; // exact mode: {pz, T(0,2)*pz, T(1,2)*pz, T(2,2)*pz} per slice
+    __shared__ float4 s_tz[ZC]; // exact mode: {pz, T(0,2)*pz, T(1,2)*pz, T(2,2)*pz} per slice
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int x0 = (blockIdx.x * 32 + (lane & 31)) * 2;
-    const int y = blockIdx.y * TB_Y + wv * 2 + (lane >> 5);
-    const int zbeg = blockIdx.z * FUSE_ZC;
-    const int zend = min(zbeg + FUSE_ZC, p.Z);
+    const int x0 = (blockIdx.x * LX + (lane & (LX - 1))) * 2;
+    const int y = blockIdx.y * BY + (wv % WY) * RW + lane / LX;
+    const int zbeg = blockIdx.z * ZC;
+    const int zend = min(zbeg + ZC, p.Z);
+    const int wz0 = zbeg + (wv / WY) * ZW, wz1 = min(wz0 + ZW, zend); // this wave's slices
     const bool live = x0 < p.X && y < p.Y;
-    if (tid < FUSE_ZC) {
+    if (tid < ZC) {
         const float pz = p.bmin.z + p.size.z * (float)(zbeg + tid + p.zoff) / p.d1;
         s_pz[tid] = pz;
         if constexpr (!FAST) s_tz[tid] = make_float4(pz, p.T.m[2] * pz, p.T.m[6] * pz, p.T.m[10] * pz);
@@ -509,7 +518,7 @@ __global__ __launch_bounds__(256) void k_sdf_fuse_tiled(const FuseParams p, cons
 
     // ZU slices per iteration: their volume cells are requested together, so a wave keeps ZU
     // 16-byte reads per lane in flight
-    unsigned char* cell = p.vptr + (size_t)zbeg * p.vimg_pitch + (size_t)y * p.vpitch + (size_t)x0 * CELL::BYTES;
+    unsigned char* cell = p.vptr + (size_t)wz0 * p.vimg_pitch + (size_t)y * p.vpitch + (size_t)x0 * CELL::BYTES;
 
     // Tiled bricks run branch-free: tile indices are clamped into the staged rectangle (always a valid LDS
     // address), every lane evaluates the observation, and the bounds / predicate results only gate the
@@ -552,7 +561,7 @@ __global__ __launch_bounds__(256) void k_sdf_fuse_tiled(const FuseParams p, cons
             };
             // (requesting the cells of slice z and consuming them after the observation of slice z + 1 -- a software
             // pipeline -- was measured and changes nothing: 0.54 ms either way, the loop is bound by instruction issue)
-            for (int z = zbeg; z < zend; ++z, cell += p.vimg_pitch) {
+            for (int z = wz0; z < wz1; ++z, cell += p.vimg_pitch) {
                 Obs o[2];
                 if (observe_pair(z, o)) {
                     float4 c = CELL::ld2(cell);
@@ -566,14 +575,14 @@ __global__ __launch_bounds__(256) void k_sdf_fuse_tiled(const FuseParams p, cons
     }
     if (use_tile) {
         const int cxmax = tw - 2, cymax = th - 2;
-        for (int z = zbeg; z < zend; z += ZU, cell += (size_t)ZU * p.vimg_pitch) {
+        for (int z = wz0; z < wz1; z += ZU, cell += (size_t)ZU * p.vimg_pitch) {
             Obs o[ZU][2];
             bool any[ZU];
             bool stray = false;
 #pragma unroll
             for (int k = 0; k < ZU; ++k) {
                 any[k] = false;
-                if (z + k < zend) { // uniform
+                if (z + k < wz1) { // uniform
                     const float pz = s_pz[z + k - zbeg];
 #pragma unroll
                     for (int v = 0; v < 2; ++v) {
@@ -598,7 +607,7 @@ __global__ __launch_bounds__(256) void k_sdf_fuse_tiled(const FuseParams p, cons
             if (__builtin_expect(__ballot(stray) != 0ull, 0)) {
 #pragma unroll
                 for (int k = 0; k < ZU; ++k)
-                    if (z + k < zend) {
+                    if (z + k < wz1) {
                         const float pz = s_pz[z + k - zbeg];
                         o[k][0] = observe<FAST, true>(p, cam[0].at(p, pz));
                         o[k][1] = observe<FAST, true>(p, cam[1].at(p, pz));
@@ -619,13 +628,13 @@ __global__ __launch_bounds__(256) void k_sdf_fuse_tiled(const FuseParams p, cons
         }
         return;
     }
-    for (int z = zbeg; z < zend; z += ZU, cell += (size_t)ZU * p.vimg_pitch) {
+    for (int z = wz0; z < wz1; z += ZU, cell += (size_t)ZU * p.vimg_pitch) {
         Obs o[ZU][2];
         bool any[ZU];
 #pragma unroll
         for (int k = 0; k < ZU; ++k) {
             any[k] = false;
-            if (z + k < zend) {
+            if (z + k < wz1) {
                 const float pz = s_pz[z + k - zbeg];
                 o[k][0] = observe_tile(0, pz);
                 o[k][1] = observe_tile(1, pz);
@@ -1159,20 +1168,49 @@ static int fuse_params(FuseParams& p, bool* small_images, const kfx_volume* vol,
     return 0;
 }
 
-// LDS tile capacity (texels) for the bricks of local planes [z0, z1): grows with the pixels-per-voxel ratio
-// r = f * voxel / Z of camera (T, K), evaluated at the centre of the range (see fuse_launch).
-static int tile_cap(const FuseParams& p, const Pose& T, const Intr& K, int z0, int z1)
+// Pixels per voxel, r = f * voxel / Z of camera (T, K), at the centre of local planes [z0, z1) (0 when that point is
+// behind the camera)
+static float px_per_voxel(const FuseParams& p, const Pose& T, const Intr& K, int z0, int z1)
 {
     const float cx = p.bmin.x + 0.5f * p.size.x, cy = p.bmin.y + 0.5f * p.size.y;
     const float cz = p.bmin.z + p.size.z * (0.5f * (float)(z0 + z1 - 1) + (float)p.zoff) / p.d1;
     const float Zc = T.m[8] * cx + T.m[9] * cy + T.m[10] * cz + T.m[11];
-    if (!(Zc > 0.f)) return 1536;
+    if (!(Zc > 0.f)) return 0.f;
     const float voxel = fmaxf(p.size.x / p.w1, p.size.y / p.h1);
-    const float r = fmaxf(fabsf(K.fu), fabsf(K.fv)) * voxel / Zc;
+    return fmaxf(fabsf(K.fu), fabsf(K.fv)) * voxel / Zc;
+}
+
+// LDS tile capacity (texels) of the 64 x 8 x 16 brick for the bricks of local planes [z0, z1): grows with r (see fuse_launch)
+static int tile_cap(const FuseParams& p, const Pose& T, const Intr& K, int z0, int z1)
+{
+    const float r = px_per_voxel(p, T, K, z0, z1);
     if (!(r > 1.3f)) return 1536;
     const float want = 1536.f * (r / 1.05f) * (r / 1.05f);
     const int c = want >= 3072.f ? 3072 : ((int)want + 511) / 512 * 512;
     return c < 1536 ? 1536 : c;
+}
+
+// Brick geometry and tile capacity for local planes [z0, z1).  Up to r = 1.3 pixels per voxel: the 64 x 8 x 16 brick with
+// 1536 texels (24 KiB, 6 workgroups per CU).  Beyond: the 32 x 8 x 16 brick, whose rectangle -- about r (32 + 0.56 * 16) + 5
+// by r (8 + 0.42 * 16) + 5 texels for a brick at the edge of a 60 x 45 degree field of view -- is given the smallest of the
+// capacities that leave 8 / 6 / 5 / 4 / 3 workgroups on a CU (160 KiB LDS, ~1 KiB of statics per workgroup).  Measured at
+// 512^3, 1280x960, 2-4 m (r = 2.2 ... 1.1; scripts/c3_brick_ab.py, fast / exact): 64 x 8 x 16 everywhere 0.591 / 0.799 ms,
+// 32 x 8 x 16 everywhere 0.537 / 0.732 ms, 32 x 8 x 8 0.586 / 0.749 ms (its staging and rectangle prologue are amortised
+// over half the slices); at 640x480 (r <= 1.05) the narrow brick costs 0-3 %.
+struct TilePlan { int small_brick, cap; };
+static TilePlan tile_plan(const FuseParams& p, const Pose& T, const Intr& K, int z0, int z1, int brick_env)
+{
+    const float r = px_per_voxel(p, T, K, z0, z1);
+    const int small_brick = brick_env < 0 ? (r > 1.3f ? 1 : 0) : (brick_env != 0);
+    if (!small_brick) return TilePlan{0, tile_cap(p, T, K, z0, z1)};
+    // three quarters of the worst-case rectangle: most bricks are nearer the optical axis than the image corner, and a
+    // brick that does not fit still works (it gathers from global memory); measured at 1280x960 with one capacity for the
+    // whole volume: 1984 texels 0.525 ms, 2496 0.543 ms, 3328 0.577 ms, per-range worst case 0.538 ms (fast mode)
+    const float want = 0.75f * (r * 41.f + 5.f) * (r * 14.7f + 5.f);
+    const int caps[] = {1216, 1600, 1984, 2496, 3328};
+    for (int c : caps)
+        if (want <= (float)c) return TilePlan{small_brick, c};
+    return TilePlan{small_brick, 3328};
 }
 
 template <typename CELL>
@@ -1189,9 +1227,9 @@ static int fuse_launch(const kfx_volume* vol, const kfx_image* depth, const kfx_
     const bool fast = math_mode() == KFX_MATH_FAST;
     hipStream_t s = (hipStream_t)stream;
     // tuning / A-B knobs (read once): KFX_FUSE_TILED=0 forces the global-gather kernel,
-    // KFX_FUSE_CAP sets the LDS tile capacity in texels (16 B each)
+    // KFX_FUSE_CAP sets the LDS tile capacity in texels (16 B each, at most 3968)
     static const int tiled = [] { const char* e = getenv("KFX_FUSE_TILED"); return e ? atoi(e) : 1; }();
-    static const int cap_env = [] { const char* e = getenv("KFX_FUSE_CAP"); const int v = e ? atoi(e) : 0; return v <= 0 ? 0 : (v < 64 ? 64 : (v > 8192 ? 8192 : v)); }();
+    static const int cap_env = [] { const char* e = getenv("KFX_FUSE_CAP"); const int v = e ? atoi(e) : 0; return v <= 0 ? 0 : (v < 64 ? 64 : (v > 3968 ? 3968 : v)); }();  // <= 62 KiB: dynamic + static LDS stay below the 64 KiB launch limit
     if (tiled && vec2 && small_images) {
         // slices per iteration: 2 in fast mode (memory-bound: more reads in flight), 4 where the large LDS tile leaves
         // only 3 workgroups per CU (1280x960 at 512^3: 0.568 -> 0.538 ms; at 6 workgroups per CU 4 is slower), 1 in exact
@@ -1203,29 +1241,48 @@ static int fuse_launch(const kfx_volume* vol, const kfx_image* depth, const kfx_
         // 3 workgroups per CU) -- measured at 512^3, 1280x960, 2-4 m: 0.80 ms (1536) / 0.62 ms (3072), while at
         // r < 1.2 the larger tile only costs occupancy (0.39 -> 0.51 ms).  r is evaluated at the centre of each
         // 64-slice range and ranges with equal capacity share a launch.
-        auto cap_for = [&](int z0, int z1) -> int { return cap_env ? cap_env : tile_cap(p, p.T, p.K, z0, z1); };
+        // Beyond r = 1.3 the brick narrows to 32 x 8 x 16 voxels instead (tile_plan; KFX_FUSE_BRICK=0 / 1 forces the wide /
+        // narrow brick): its rectangle fits 25-52 KiB up to r ~ 2.2, where the wide brick needs the full 48 KiB from
+        // r ~ 1.5 on and above r ~ 1.9 does not fit at all (those bricks gathered from global memory).
+        static const int brick_env = [] { const char* e = getenv("KFX_FUSE_BRICK"); return e ? atoi(e) : -1; }();
+        auto plan_for = [&](int z0, int z1) -> TilePlan {
+            TilePlan t = tile_plan(p, p.T, p.K, z0, z1, brick_env);
+            if (cap_env) t.cap = cap_env;
+            return t;
+        };
         const int zstep = 64;
         int z0 = 0;
         while (z0 < p.Z) {
             int z1 = z0 + zstep < p.Z ? z0 + zstep : p.Z;
-            const int cap_px = cap_for(z0, z1);
-            while (z1 < p.Z) { // extend over following ranges that want the same capacity
+            const TilePlan plan = plan_for(z0, z1);
+            const int cap_px = plan.cap;
+            while (z1 < p.Z) { // extend over following ranges that want the same brick and capacity
                 const int z2 = z1 + zstep < p.Z ? z1 + zstep : p.Z;
-                if (cap_for(z1, z2) != cap_px) break;
+                const TilePlan nxt = plan_for(z1, z2);
+                if (nxt.cap != cap_px || nxt.small_brick != plan.small_brick) break;
                 z1 = z2;
             }
             FuseParams q = p;
             q.vptr = p.vptr + (size_t)z0 * p.vimg_pitch;
             q.zoff = p.zoff + z0;
             q.Z = z1 - z0;
-            dim3 grid(ceil_div(q.X, TB_X), ceil_div(q.Y, TB_Y), ceil_div(q.Z, FUSE_ZC));
             const size_t lds = (size_t)cap_px * sizeof(float4);
-            const int zu = zu_env ? zu_env : (fast ? (cap_px > 2560 ? 4 : 2) : 1);
-            if (fast && zu == 4) hipLaunchKernelGGL((k_sdf_fuse_tiled<true, 4, CELL>), grid, dim3(256), lds, s, q, cap_px);
-            else if (fast && zu == 2) hipLaunchKernelGGL((k_sdf_fuse_tiled<true, 2, CELL>), grid, dim3(256), lds, s, q, cap_px);
-            else if (fast) hipLaunchKernelGGL((k_sdf_fuse_tiled<true, 1, CELL>), grid, dim3(256), lds, s, q, cap_px);
-            else if (zu == 2) hipLaunchKernelGGL((k_sdf_fuse_tiled<false, 2, CELL>), grid, dim3(256), lds, s, q, cap_px);
-            else hipLaunchKernelGGL((k_sdf_fuse_tiled<false, 1, CELL>), grid, dim3(256), lds, s, q, cap_px);
+            if (plan.small_brick) {
+                dim3 grid(ceil_div(q.X, 32), ceil_div(q.Y, 8), ceil_div(q.Z, 16));
+                const int zu = zu_env ? zu_env : (fast ? (cap_px > 2560 ? 4 : 2) : 1);
+                if (fast && zu == 4) hipLaunchKernelGGL((k_sdf_fuse_tiled<true, 4, CELL, 16, 2, 16>), grid, dim3(256), lds, s, q, cap_px);
+                else if (fast && zu == 2) hipLaunchKernelGGL((k_sdf_fuse_tiled<true, 2, CELL, 16, 2, 16>), grid, dim3(256), lds, s, q, cap_px);
+                else if (fast) hipLaunchKernelGGL((k_sdf_fuse_tiled<true, 1, CELL, 16, 2, 16>), grid, dim3(256), lds, s, q, cap_px);
+                else hipLaunchKernelGGL((k_sdf_fuse_tiled<false, 1, CELL, 16, 2, 16>), grid, dim3(256), lds, s, q, cap_px);
+            } else {
+                dim3 grid(ceil_div(q.X, TB_X), ceil_div(q.Y, TB_Y), ceil_div(q.Z, FUSE_ZC));
+                const int zu = zu_env ? zu_env : (fast ? (cap_px > 2560 ? 4 : 2) : 1);
+                if (fast && zu == 4) hipLaunchKernelGGL((k_sdf_fuse_tiled<true, 4, CELL>), grid, dim3(256), lds, s, q, cap_px);
+                else if (fast && zu == 2) hipLaunchKernelGGL((k_sdf_fuse_tiled<true, 2, CELL>), grid, dim3(256), lds, s, q, cap_px);
+                else if (fast) hipLaunchKernelGGL((k_sdf_fuse_tiled<true, 1, CELL>), grid, dim3(256), lds, s, q, cap_px);
+                else if (zu == 2) hipLaunchKernelGGL((k_sdf_fuse_tiled<false, 2, CELL>), grid, dim3(256), lds, s, q, cap_px);
+                else hipLaunchKernelGGL((k_sdf_fuse_tiled<false, 1, CELL>), grid, dim3(256), lds, s, q, cap_px);
+            }
             z0 = z1;
         }
     } else if (vec2) {
