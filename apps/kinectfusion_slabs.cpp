@@ -1,0 +1,224 @@
+// kinectfusion_slabs.cpp -- the headless KinectFusion frame loop (kinectfusion_headless.cpp, known poses) with the TSDF volume
+// partitioned into Z-slabs over several ranks, in C++ only: roo::SlabVolume (include/kangaroo/SlabVolume.h) over the C ABI of
+// include/kfx_slab.h.  Every rank preprocesses the depth frame (replicated: < 0.03 ms), integrates its own planes, refreshes
+// its ghost planes (RCCL send / recv with the two neighbours, or redundant integration), and the model is rendered by all
+// ranks together (nearest-hit composite, or the exact march hand-over).
+//
+//   --transport rccl     one PROCESS per GPU; rank / world from RANK, WORLD_SIZE, LOCAL_RANK (torchrun --no-python, or
+//                        scripts/launch_ranks.sh), ncclUniqueId through --rendezvous FILE
+//   --transport threads  --ranks R host threads of this process share one GPU (emulation: exercises the same slab code on
+//                        a 1-GPU box; not a performance mode)
+//
+// Rank 0 prints the frame time and checksums of the final raycast images and of the whole volume (sum of the owned cells'
+// bit patterns over all ranks): with --raycast exact they equal the checksums of a --ranks 1 run bit for bit.
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include <kangaroo/kangaroo.h>
+#include <kangaroo/SlabVolume.h>
+
+using namespace roo;
+
+struct Options {
+    int volres = 256, frames = 10, w = 640, h = 480, ranks = 1;
+    bool fast = false, rccl = false;
+    SlabVolume::HaloMode halo = SlabVolume::HaloExchange;
+    SlabVolume::RaycastMode raycast = SlabVolume::Composite;
+    std::string rendezvous = "/tmp/kfx_slabs.id";
+};
+
+// analytic depth of the synthetic room: same scene as kinectfusion_headless.cpp / kangaroo_amd/scenes.py
+static void RenderRoom(std::vector<float>& out, int w, int h, const Mat<float,3,4>& T_wc, const ImageIntrinsics& K)
+{
+    out.resize((size_t)w * h);
+    const float3 c = SE3Translation(T_wc);
+    for (int v = 0; v < h; ++v)
+        for (int u = 0; u < w; ++u) {
+            const float3 r = mulSO3(T_wc, K.Unproject((float)u, (float)v));
+            float best = INFINITY;
+            const float3 lo = make_float3(-0.9f, -0.9f, -10.f), hi = make_float3(0.9f, 0.9f, 3.8f);
+            const float3 a = div_cw(sub(lo, c), r), b = div_cw(sub(hi, c), r);
+            const float texit = fminf(fminf(fmaxf(a.x, b.x), fmaxf(a.y, b.y)), fmaxf(a.z, b.z));
+            if (texit > 0) best = texit;
+            const float3 oc = sub(make_float3(0, 0, 3.0f), c);
+            const float ldotc = dot(r, oc), lsq = dot(r, r), csq = dot(oc, oc);
+            const float disc = ldotc * ldotc - lsq * (csq - 0.25f);
+            if (disc >= 0) {
+                const float ts = (ldotc - sqrtf(disc)) / lsq;
+                if (ts > 0 && ts < best) best = ts;
+            }
+            out[(size_t)v * w + u] = std::isfinite(best) ? best : NAN;
+        }
+}
+
+static Mat<float,3,4> OrbitPose(int i, int n)
+{
+    const float ph = 2.0f * (float)M_PI * i / n;
+    const float yaw = 5.0f * (float)M_PI / 180.0f * sinf(ph);
+    const float c = cosf(yaw), s = sinf(yaw);
+    Mat<float,3,4> T = SE3Identity();
+    T(0,0) = c; T(0,2) = s; T(2,0) = -s; T(2,2) = c;
+    T(0,3) = 0.05f * sinf(ph);
+    T(1,3) = 0.025f * (1.0f - cosf(ph)) - 0.025f;
+    return T;
+}
+
+static unsigned BitSum(const void* p, size_t bytes)
+{
+    const unsigned* u = static_cast<const unsigned*>(p);
+    unsigned s = 0;
+    for (size_t i = 0; i < bytes / 4; ++i) s += u[i] * 2654435761u + (unsigned)i;   // position-dependent: a permutation changes it
+    return s;
+}
+
+struct Result { double ms_per_frame = 0; unsigned chk_d = 0, chk_n = 0, chk_i = 0, chk_vol = 0; size_t hits = 0; int rounds = 0; int status = 0; };
+
+// the frame loop of one rank
+static void RunRank(const Options& o, kfx_comm* comm, const std::vector<std::vector<float> >& depth_mm, const std::vector<Mat<float,3,4> >& poses,
+                    Result* res)
+{
+    const int w = o.w, h = o.h;
+    const double depth_focal = w * 570.342 / 640.0;
+    const ImageIntrinsics K(depth_focal, depth_focal, w / 2.0 - 0.5, h / 2.0 - 0.5);
+    const float knear = 0.4f, kfar = 4.0f, bigs = 1.5f, bigr = 0.1f;
+    const int biwin = 3;
+    const float max_w = 1000.0f, mincostheta = 0.1f;
+    const BoundingBox bb(make_float3(-1, -1, 2), make_float3(1, 1, 4));
+
+    Image<float, TargetDevice, Manage> dMeters(w, h), dFiltered(w, h), ray_d(w, h), ray_i(w, h);
+    Image<float4, TargetDevice, Manage> dVbo(w, h), dNormals(w, h), ray_n(w, h);
+    SlabVolume slab(o.volres, o.volres, o.volres, bb, comm, o.halo, o.raycast);
+    // the whole volume's voxel size (the local view has the same spacing in x / y; z spacing is the full volume's)
+    const float3 vs = make_float3(2.0f / (o.volres - 1), 2.0f / (o.volres - 1), 2.0f / (o.volres - 1));
+    const float trunc_dist = 2.0f * length(vs);
+    SdfReset(slab.local, std::numeric_limits<float>::quiet_NaN());
+
+    double total_ms = 0;
+    for (int f = 0; f < o.frames; ++f) {
+        const Mat<float,3,4> T_wl = poses[f];
+        dMeters.MemcpyFromHost(const_cast<float*>(depth_mm[f].data()));
+        comm->barrier(comm);
+        const auto t0 = std::chrono::steady_clock::now();
+        ElementwiseScaleBias<float,float,float>(dMeters, dMeters, 1.0f / 1000.0f);
+        BilateralFilter<float,float>(dFiltered, dMeters, bigs, bigr, biwin, 0.2f);
+        DepthToVbo<float>(dVbo, dFiltered, K);
+        NormalsFromVbo(dNormals, dVbo);
+        slab.Fuse(dFiltered, dNormals, SE3inv(T_wl), K, trunc_dist, max_w, mincostheta);
+        slab.Raycast(ray_d, ray_n, ray_i, T_wl, K, knear, kfar, trunc_dist, true);
+        kfx_stream_synchronize(0);
+        comm->barrier(comm);
+        total_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+    res->ms_per_frame = total_ms / o.frames;
+    res->rounds = slab.last_rounds;
+
+    // checksums: images (identical on every rank after the merge) and the owned planes of the volume, summed over the ranks
+    std::vector<float> hd((size_t)w * h), hi((size_t)w * h);
+    std::vector<float4> hn((size_t)w * h);
+    ray_d.MemcpyToHost(hd.data());
+    ray_n.MemcpyToHost(hn.data());
+    ray_i.MemcpyToHost(hi.data());
+    for (float d : hd) res->hits += std::isfinite(d) ? 1 : 0;
+    for (float& d : hd) if (!std::isfinite(d)) d = -1.0f;   // NaN payload bits are not part of the contract
+    res->chk_d = BitSum(hd.data(), hd.size() * 4);
+    res->chk_n = BitSum(hn.data(), hn.size() * 16);
+    res->chk_i = BitSum(hi.data(), hi.size() * 4);
+    const kfx_slab_layout& L = slab.layout;
+    const size_t plane = slab.local.img_pitch, own = L.z1 - L.z0;
+    std::vector<unsigned char> hv(plane * own);
+    GpuCheckStatus(kfx_memcpy_2d(hv.data(), plane, (unsigned char*)slab.local.ptr + (L.z0 - L.s0) * plane, plane, plane, own, 2, 0));
+    unsigned vs_sum = 0;
+    for (size_t z = 0; z < own; ++z)
+        for (size_t y = 0; y < slab.local.h; ++y) {
+            const unsigned* row = reinterpret_cast<const unsigned*>(hv.data() + z * plane + y * slab.local.pitch);
+            for (size_t x = 0; x < 2 * slab.local.w; ++x) {
+                unsigned bits = row[x];
+                if ((bits & 0x7fffffffu) > 0x7f800000u) bits = 0x7fc00000u;   // any NaN
+                vs_sum += bits * 2654435761u + (unsigned)((L.z0 + z) * 7919u + y * 104729u + x);
+            }
+        }
+    void* dsum = nullptr;
+    size_t pitch;
+    GpuCheckStatus(kfx_alloc_pitched(&dsum, &pitch, 64, 1));
+    int hsum[2] = {(int)vs_sum, 0};
+    GpuCheckStatus(kfx_memcpy_2d(dsum, 64, hsum, 8, 8, 1, 1, 0));
+    GpuCheckStatus(comm->all_reduce(comm, dsum, 2, KFX_COMM_SUM_I32, 0));
+    GpuCheckStatus(kfx_memcpy_2d(hsum, 8, dsum, 64, 8, 1, 2, 0));
+    kfx_free(dsum);
+    res->chk_vol = (unsigned)hsum[0];
+}
+
+int main(int argc, char** argv)
+{
+    Options o;
+    for (int i = 1; i < argc; ++i) {
+        if (!strcmp(argv[i], "--res") && i + 1 < argc) o.volres = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--frames") && i + 1 < argc) o.frames = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--width") && i + 1 < argc) o.w = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--height") && i + 1 < argc) o.h = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--ranks") && i + 1 < argc) o.ranks = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--fast")) o.fast = true;
+        else if (!strcmp(argv[i], "--transport") && i + 1 < argc) o.rccl = !strcmp(argv[++i], "rccl");
+        else if (!strcmp(argv[i], "--halo") && i + 1 < argc) o.halo = !strcmp(argv[++i], "recompute") ? SlabVolume::HaloRecompute : SlabVolume::HaloExchange;
+        else if (!strcmp(argv[i], "--raycast") && i + 1 < argc) o.raycast = !strcmp(argv[++i], "exact") ? SlabVolume::Exact : SlabVolume::Composite;
+        else if (!strcmp(argv[i], "--rendezvous") && i + 1 < argc) o.rendezvous = argv[++i];
+        else { fprintf(stderr, "unknown argument %s\n", argv[i]); return 2; }
+    }
+    const int ndev = kfx_device_count();
+    if (ndev < 1) { fprintf(stderr, "no HIP device\n"); return 2; }
+    kfx_set_math_mode(o.fast ? KFX_MATH_FAST : KFX_MATH_EXACT);
+
+    const double depth_focal = o.w * 570.342 / 640.0;
+    const ImageIntrinsics K(depth_focal, depth_focal, o.w / 2.0 - 0.5, o.h / 2.0 - 0.5);
+    std::vector<std::vector<float> > depth_mm(o.frames);
+    std::vector<Mat<float,3,4> > poses(o.frames);
+    for (int f = 0; f < o.frames; ++f) {
+        poses[f] = OrbitPose(f, 30);
+        RenderRoom(depth_mm[f], o.w, o.h, poses[f], K);
+        for (float& d : depth_mm[f]) d *= 1000.0f;
+    }
+
+    Result r0;
+    int world = o.ranks, rank = 0;
+    if (o.rccl) {
+        const char* er = getenv("RANK"); const char* ew = getenv("WORLD_SIZE"); const char* el = getenv("LOCAL_RANK");
+        rank = er ? atoi(er) : 0;
+        world = ew ? atoi(ew) : 1;
+        const int local = el ? atoi(el) : rank;
+        if (world > ndev) { fprintf(stderr, "kinectfusion_slabs: %d ranks need %d GPUs, this node shows %d\n", world, world, ndev); return 2; }
+        GpuCheckStatus(kfx_set_device(local % ndev));
+        kfx_comm comm;
+        const int st = kfx_comm_create_rccl(&comm, rank, world, o.rendezvous.c_str(), 120);
+        if (st != 0) { fprintf(stderr, "kfx_comm_create_rccl failed: %d\n", st); return 3; }
+        RunRank(o, &comm, depth_mm, poses, &r0);
+        comm.destroy(&comm);
+    } else {
+        std::vector<kfx_comm> comms(world);
+        GpuCheckStatus(kfx_comm_create_threads(comms.data(), world));
+        std::vector<Result> results(world);
+        std::vector<std::thread> threads;
+        for (int r = 1; r < world; ++r) threads.emplace_back(RunRank, std::cref(o), &comms[r], std::cref(depth_mm), std::cref(poses), &results[r]);
+        RunRank(o, &comms[0], depth_mm, poses, &results[0]);
+        for (auto& t : threads) t.join();
+        r0 = results[0];
+        for (int r = 1; r < world; ++r)   // after the merge every rank must hold the same images
+            if (results[r].chk_d != r0.chk_d || results[r].chk_n != r0.chk_n || results[r].chk_i != r0.chk_i) r0.status = 4;
+        comms[0].destroy(&comms[0]);
+    }
+    if (rank == 0) {
+        printf("kinectfusion_slabs: %d^3 volume in %d slab(s) [%s], %dx%d, %d frames, %s math, halo %s, raycast %s%s: %.3f ms/frame (%.1f fps)\n",
+               o.volres, world, o.rccl ? "RCCL, one process per GPU" : "threads sharing one GPU", o.w, o.h, o.frames, o.fast ? "fast" : "exact",
+               o.halo == SlabVolume::HaloExchange ? "exchange" : "recompute", o.raycast == SlabVolume::Exact ? "exact" : "composite",
+               o.raycast == SlabVolume::Exact ? (" (" + std::to_string(r0.rounds) + " rounds)").c_str() : "", r0.ms_per_frame, 1e3 / r0.ms_per_frame);
+        printf("checksums depth=%08x norm=%08x img=%08x volume=%08x hits=%zu ranks_agree=%d\n", r0.chk_d, r0.chk_n, r0.chk_i, r0.chk_vol, r0.hits,
+               r0.status == 0 ? 1 : 0);
+    }
+    if (r0.status) return r0.status;
+    return r0.hits > (size_t)(o.w * o.h) / 4 ? 0 : 1;
+}

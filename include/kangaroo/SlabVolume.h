@@ -1,0 +1,105 @@
+// SlabVolume.h -- a BoundedVolume<SDF_t> spread over the ranks of a node in Z-slabs, for C++ hosts (one rank per GPU, or
+// one rank per host thread with the in-process transport).  Addition beside the reference API (the reference is
+// single-GPU): thin wrappers over include/kfx_slab.h in the style of the roo:: operators -- same container types, same
+// error convention.  Include it explicitly; <kangaroo/kangaroo.h> stays the reference's surface.
+//
+//   kfx_comm comm;  kfx_comm_create_rccl(&comm, rank, world, "/tmp/kfx.id", 60);        // or kfx_comm_create_threads
+//   roo::SlabVolume slab(512, 512, 512, bbox, &comm);                                    // allocates this rank's planes
+//   roo::SdfReset(slab.local, NaN);
+//   per frame:  slab.Fuse(depth, normals, T_cw, K, trunc, max_w, mincostheta);           // + halo exchange
+//               slab.Raycast(d, n, i, T_wc, K, near, far, trunc);                        // identical images on every rank
+#pragma once
+
+#include <kfx_slab.h>
+
+#include <kangaroo/BoundedVolume.h>
+#include <kangaroo/Image.h>
+#include <kangaroo/ImageIntrinsics.h>
+#include <kangaroo/Mat.h>
+#include <kangaroo/Sdf.h>
+#include <kangaroo/cu_raycast.h>
+#include <kangaroo/launch_utils.h>
+
+namespace roo
+{
+
+class SlabVolume
+{
+public:
+    enum HaloMode { HaloExchange, HaloRecompute };   // ghost planes: from the neighbours (RCCL send / recv) or integrated redundantly
+    enum RaycastMode { Composite, Exact };           // nearest hit of per-slab marches, or the march state handed from slab to slab
+
+    kfx_slab_layout layout;
+    BoundedVolume<SDF_t, TargetDevice, Manage> local; // planes [layout.s0, layout.s1) of the whole volume
+    BoundingBox full_bbox;
+    kfx_comm* comm;
+    HaloMode halo;
+    RaycastMode raycast;
+    int last_rounds;
+
+    SlabVolume(size_t w, size_t h, size_t d, const BoundingBox& bbox, kfx_comm* comm_, HaloMode halo_ = HaloExchange,
+               RaycastMode raycast_ = Composite, int ghost = 2)
+        : layout(MakeLayout(d, bbox, comm_, ghost)),
+          local(w, h, layout.s1 - layout.s0, BoundingBox(make_float3(bbox.Min().x, bbox.Min().y, layout.local_zmin),
+                                                           make_float3(bbox.Max().x, bbox.Max().y, layout.local_zmax))),
+          full_bbox(bbox), comm(comm_), halo(halo_), raycast(raycast_), last_rounds(0), key_(0), payload_(0), state_(0), scratch_(0), cap_(0)
+    {
+    }
+    ~SlabVolume()
+    {
+        kfx_free(key_); kfx_free(payload_); kfx_free(state_); kfx_free(scratch_);
+    }
+    SlabVolume(const SlabVolume&) = delete;
+    SlabVolume& operator=(const SlabVolume&) = delete;
+
+    // SdfFuse of this rank's planes, evaluated with the whole volume's voxel positions and over the whole volume's
+    // extents (bit-identical to the same planes of a single-GPU volume), then the ghost planes are brought up to date
+    void Fuse(Image<float> depth, Image<float4> norm, Mat<float,3,4> T_cw, ImageIntrinsics K, float trunc_dist, float maxw, float mincostheta)
+    {
+        const bool own_only = halo == HaloExchange && layout.world > 1;
+        const size_t first = own_only ? layout.z0 : layout.s0, count = own_only ? layout.z1 - layout.z0 : layout.s1 - layout.s0;
+        kfx_volume v = *local.abi();
+        v.ptr = (unsigned char*)v.ptr + (first - layout.s0) * v.img_pitch;
+        v.d = count;
+        const kfx_slab s = {layout.full_d, first, layout.full_zmin, layout.full_zmax};
+        GpuCheckStatus(kfx_sdf_fuse_slab(&v, &s, depth.abi(), norm.abi(), T_cw.m, &K.fu, trunc_dist, maxw, mincostheta, KFX_FUSE_SLAB_EXTENT, 0));
+        if (own_only) GpuCheckStatus(kfx_slab_exchange_halos(local.abi(), &layout, comm, 0));
+    }
+
+    // RaycastSdf of the whole model; every rank returns with the same images
+    void Raycast(Image<float> depth, Image<float4> norm, Image<float> img, Mat<float,3,4> T_wc, ImageIntrinsics K, float near, float far,
+                 float trunc_dist, bool subpix = true)
+    {
+        Reserve(depth.w * depth.h);
+        if (raycast == Exact) {
+            GpuCheckStatus(kfx_slab_raycast_exact(depth.abi(), norm.abi(), img.abi(), (float*)state_, scratch_, local.abi(), &layout, T_wc.m,
+                                                  &K.fu, near, far, trunc_dist, subpix ? 1 : 0, comm, 0, &last_rounds));
+        } else {
+            RaycastSdf(depth, norm, img, local, T_wc, K, near, far, trunc_dist, subpix);
+            GpuCheckStatus(kfx_slab_composite(depth.abi(), norm.abi(), img.abi(), (long long*)key_, (float*)payload_, comm, 0));
+        }
+    }
+
+private:
+    static kfx_slab_layout MakeLayout(size_t d, const BoundingBox& bbox, kfx_comm* c, int ghost)
+    {
+        kfx_slab_layout L;
+        GpuCheckStatus(kfx_slab_layout_init(&L, d, bbox.Min().z, bbox.Max().z, c->rank, c->world, ghost));
+        return L;
+    }
+    void* key_; void* payload_; void* state_; void* scratch_;
+    size_t cap_;
+    void Reserve(size_t n)
+    {
+        if (n <= cap_) return;
+        kfx_free(key_); kfx_free(payload_); kfx_free(state_); kfx_free(scratch_);
+        size_t pitch;
+        GpuCheckStatus(kfx_alloc_pitched(&key_, &pitch, n * sizeof(long long), 1));
+        GpuCheckStatus(kfx_alloc_pitched(&payload_, &pitch, 5 * n * sizeof(float), 1));
+        GpuCheckStatus(kfx_alloc_pitched(&state_, &pitch, KFX_RAY_STATE_PLANES * n * sizeof(float), 1));
+        GpuCheckStatus(kfx_alloc_pitched(&scratch_, &pitch, kfx_slab_exact_scratch_bytes(n, 1), 1));
+        cap_ = n;
+    }
+};
+
+}

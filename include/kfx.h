@@ -79,6 +79,10 @@ typedef void* kfx_stream; /* hipStream_t */
 #define KFX_FUSE_FULL_EXTENT 1u /* also integrate the trailing dim%8 voxels the reference's
                                    integer-division grid skips (cu_sdffusion.cu:57-59) */
 
+#define KFX_FUSE_SLAB_EXTENT 2u /* kfx_sdf_fuse_slab*: integrate exactly the voxels the reference integrates on the WHOLE
+                                   volume -- x / y extents (dim/8)*8, and the local planes below (full_d/8)*8 -- whatever
+                                   the slab's own plane count is */
+
 /* ---- the hot path ------------------------------------------------------------ */
 
 /* roo::SdfFuse(BoundedVolume<SDF_t>, Image<float>, Image<float4>, Mat<float,3,4> T_cw,
@@ -378,6 +382,7 @@ const char* kfx_last_error_string(void); /* thread-local, never NULL */
 const char* kfx_error_name(int code);    /* hipGetErrorString for >0, KFX_E_* names for <0 */
 int kfx_version(void);                   /* major*100 + minor */
 int kfx_device_count(void);
+int kfx_set_device(int device);          /* hipSetDevice for the calling thread (one rank per GPU: include/kfx_slab.h) */
 
 #ifdef __cplusplus
 }

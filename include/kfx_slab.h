@@ -1,0 +1,94 @@
+/*
+ * kfx_slab.h -- the multi-GPU half of the C ABI: a BoundedVolume<SDF_t> partitioned into Z-slabs, one rank per GPU
+ * (BASELINE.json north_star: "Z-slab-partitioned across the 8 GPUs of one node with RCCL halo exchange over
+ * xGMI for rays that cross slabs").  The reference is single-GPU: there is no roo:: counterpart, so these entry points are
+ * additions beside the drop-in boundary of kfx.h, callable from C / C++ hosts without Python.
+ *
+ * Rank r of `world` stores planes [s0, s1) = [z0 - ghost, z1 + ghost) clipped to the volume, of which it OWNS [z0, z1)
+ * (ghost >= 1: the trilinear z+1 corner and the gradient stencil's z-1 / z+1 cells, Volume.h:240-289).  The local storage
+ * is an ordinary BoundedVolume whose box is VoxelPositionInUnits of its first / last stored plane -- the view
+ * BoundedVolume::SubBoundingVolume produces (BoundedVolume.h:156-164).
+ *
+ *   per frame and rank:  kfx_sdf_fuse_slab (kfx.h) on the owned planes            -- no communication, bit-identical
+ *                        kfx_slab_exchange_halos                                  -- ghost planes from the two neighbours
+ *                        kfx_raycast_sdf on the local view + kfx_slab_composite   -- nearest hit of all slabs (2 all-reduces)
+ *                     or kfx_slab_raycast_exact                                   -- march state handed from slab to slab,
+ *                                                                                    bit-identical to the single-volume march
+ *
+ * Collectives go through a kfx_comm, a small table of transport functions.  Two transports ship:
+ *   kfx_comm_create_rccl     (libkfx_rccl.so, links librccl): one PROCESS per GPU, RCCL all-reduce / grouped send-recv over
+ *                            xGMI.  Rendezvous of the ncclUniqueId through a file.
+ *   kfx_comm_create_threads  (libkfx.so): the ranks are host THREADS of one process sharing one device -- the emulation
+ *                            used to exercise the slab logic where only one GPU exists (tests, apps --transport threads).
+ * All buffers are device pointers; operations are enqueued on `stream` (the threads transport uses the null stream).
+ */
+#ifndef KFX_SLAB_H
+#define KFX_SLAB_H
+
+#include "kfx.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- transport ---------------------------------------------------------------------------------------------- */
+#define KFX_COMM_MIN_I64 0 /* count x int64, minimum   (composite keys) */
+#define KFX_COMM_SUM_F32 1 /* count x float, sum       (composite payload: one rank contributes per pixel, so exact) */
+#define KFX_COMM_SUM_I32 2 /* count x int32, sum       (march state bits: one rank contributes per pixel) */
+
+typedef struct kfx_comm {
+    int rank, world;
+    void* impl;
+    /* in-place all-reduce of a dense device buffer */
+    int (*all_reduce)(struct kfx_comm* c, void* buf, size_t count, int op, kfx_stream stream);
+    /* neighbour exchange along the rank order: send_lo / recv_lo talk to rank - 1, send_hi / recv_hi to rank + 1; a byte
+     * count of 0 (or a missing neighbour) skips that direction.  One batched group of point-to-point operations. */
+    int (*exchange)(struct kfx_comm* c, const void* send_lo, void* recv_lo, size_t bytes_lo, const void* send_hi, void* recv_hi,
+                    size_t bytes_hi, kfx_stream stream);
+    int (*barrier)(struct kfx_comm* c);
+    void (*destroy)(struct kfx_comm* c);
+} kfx_comm;
+
+/* In-process transport: fills comms[0 .. world) for `world` host threads of this process that share the current device;
+ * every collective must be called by all of them (each with its own comms[r]).  Destroy through comms[0] after the threads
+ * have joined. */
+int kfx_comm_create_threads(kfx_comm* comms, int world);
+
+/* RCCL transport (libkfx_rccl.so).  rank 0 writes the ncclUniqueId to `rendezvous_file` (created atomically), the other
+ * ranks wait for it (at most timeout_s seconds); the caller has selected its device (hipSetDevice) beforehand.  Returns 0,
+ * KFX_E_*, or 1000 + ncclResult_t. */
+int kfx_comm_create_rccl(kfx_comm* comm, int rank, int world, const char* rendezvous_file, int timeout_s);
+
+/* ---- slab layout --------------------------------------------------------------------------------------------- */
+typedef struct kfx_slab_layout {
+    size_t full_d;             /* planes of the whole volume */
+    float  full_zmin, full_zmax;
+    int    rank, world, ghost;
+    size_t z0, z1;             /* owned planes [z0, z1): contiguous, sizes differ by at most one plane between ranks */
+    size_t s0, s1;             /* stored planes [s0, s1) = owned +- ghost, clipped */
+    float  local_zmin, local_zmax; /* z of planes s0 and s1 - 1 by VoxelPositionInUnits of the whole volume: the local box */
+} kfx_slab_layout;
+int kfx_slab_layout_init(kfx_slab_layout* L, size_t full_d, float full_zmin, float full_zmax, int rank, int world, int ghost);
+
+/* Refresh the ghost planes of `local` (planes [s0, s1) of the layout, fp32 SDF_t or fp16 cells: any cell size, whole
+ * img_pitch-sized planes travel) from the neighbours' owned planes.  Requires every rank to own at least `ghost` planes. */
+int kfx_slab_exchange_halos(const kfx_volume* local, const kfx_slab_layout* L, kfx_comm* comm, kfx_stream stream);
+
+/* Nearest-hit composite of per-slab raycasts: on entry depth / norm / img hold this rank's RaycastSdf of its local view,
+ * on return every rank holds the merged images.  key: w*h int64, payload: 5*w*h float, dense device scratch of the caller. */
+int kfx_slab_composite(const kfx_image* depth, const kfx_image* norm, const kfx_image* img, long long* key, float* payload,
+                       kfx_comm* comm, kfx_stream stream);
+
+/* The exact march: rounds of kfx_raycast_sdf_slab, one SUM all-reduce of the touched pixels' march state per round and one
+ * of the normals / shade at the end; every rank returns with the images of kfx_raycast_sdf on the whole volume, bit for
+ * bit.  state: KFX_RAY_STATE_PLANES * w*h floats; scratch: kfx_slab_exact_scratch_bytes(w, h) bytes (device).  *rounds_out
+ * (optional) receives the number of rounds (<= world + 2).  Synchronises the stream once per round (termination test). */
+size_t kfx_slab_exact_scratch_bytes(size_t w, size_t h);
+int kfx_slab_raycast_exact(const kfx_image* depth, const kfx_image* norm, const kfx_image* img, float* state, void* scratch,
+                           const kfx_volume* local, const kfx_slab_layout* L, const float T_wc[12], const float K[4],
+                           float near, float far, float trunc_dist, int subpix, kfx_comm* comm, kfx_stream stream, int* rounds_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KFX_SLAB_H */

@@ -115,6 +115,7 @@ SIGNATURES = {
     "kfx_get_math_mode": (C.c_int, []),
     "kfx_version": (C.c_int, []),
     "kfx_device_count": (C.c_int, []),
+    "kfx_set_device": (C.c_int, [C.c_int]),
 }
 
 _lib = None

@@ -75,6 +75,17 @@ extern "C" int kfx_device_count(void)
     return n;
 }
 
+// one process (or host thread) per GPU: select the device the calling thread's allocations and launches go to
+extern "C" int kfx_set_device(int device)
+{
+    const hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return set_error((int)e, "kfx_set_device");
+    }
+    return 0;
+}
+
 // Rows are padded to 256 B so that every row (and every z-slice, img_pitch = pitch*h)
 // starts on a boundary that keeps 16-byte-per-lane wave accesses (1 KiB per instruction)
 // and 128-B cache lines aligned.  hipMalloc itself returns >= 256-B aligned blocks.

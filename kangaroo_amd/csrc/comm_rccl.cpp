@@ -1,0 +1,134 @@
+// comm_rccl.cpp -- the RCCL transport behind kfx_comm (include/kfx_slab.h): one process per GPU, all-reduce and grouped
+// neighbour send / recv over xGMI.  Built into libkfx_rccl.so so that libkfx.so itself does not depend on librccl.
+// The ncclUniqueId travels through a file: rank 0 creates it atomically (write + rename), the others wait for it.
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <thread>
+
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+#include <unistd.h>
+
+#include "../../include/kfx_slab.h"
+
+namespace {
+
+struct RcclImpl {
+    ncclComm_t comm = nullptr;
+    void* token = nullptr; // 4-byte device word for the barrier
+};
+
+int nccl_status(ncclResult_t r) { return r == ncclSuccess ? 0 : 1000 + (int)r; }
+
+int rccl_all_reduce(kfx_comm* c, void* buf, size_t count, int op, kfx_stream stream)
+{
+    RcclImpl* im = static_cast<RcclImpl*>(c->impl);
+    if (count == 0) return 0;
+    if (!buf) return KFX_E_NULL;
+    ncclDataType_t dt;
+    ncclRedOp_t ro;
+    switch (op) {
+    case KFX_COMM_MIN_I64: dt = ncclInt64; ro = ncclMin; break;
+    case KFX_COMM_SUM_F32: dt = ncclFloat32; ro = ncclSum; break;
+    case KFX_COMM_SUM_I32: dt = ncclInt32; ro = ncclSum; break;
+    default: return KFX_E_RANGE;
+    }
+    return nccl_status(ncclAllReduce(buf, buf, count, dt, ro, im->comm, (hipStream_t)stream));
+}
+
+int rccl_exchange(kfx_comm* c, const void* send_lo, void* recv_lo, size_t bytes_lo, const void* send_hi, void* recv_hi, size_t bytes_hi,
+                  kfx_stream stream)
+{
+    RcclImpl* im = static_cast<RcclImpl*>(c->impl);
+    hipStream_t s = (hipStream_t)stream;
+    const bool lo = c->rank > 0 && bytes_lo, hi = c->rank + 1 < c->world && bytes_hi;
+    if (!lo && !hi) return 0;
+    ncclResult_t r = ncclGroupStart();
+    if (r == ncclSuccess && lo) r = ncclSend(send_lo, bytes_lo, ncclInt8, c->rank - 1, im->comm, s);
+    if (r == ncclSuccess && lo) r = ncclRecv(recv_lo, bytes_lo, ncclInt8, c->rank - 1, im->comm, s);
+    if (r == ncclSuccess && hi) r = ncclSend(send_hi, bytes_hi, ncclInt8, c->rank + 1, im->comm, s);
+    if (r == ncclSuccess && hi) r = ncclRecv(recv_hi, bytes_hi, ncclInt8, c->rank + 1, im->comm, s);
+    const ncclResult_t e = ncclGroupEnd();
+    return nccl_status(r != ncclSuccess ? r : e);
+}
+
+int rccl_barrier(kfx_comm* c)
+{
+    RcclImpl* im = static_cast<RcclImpl*>(c->impl);
+    const ncclResult_t r = ncclAllReduce(im->token, im->token, 1, ncclInt32, ncclSum, im->comm, nullptr);
+    if (r != ncclSuccess) return nccl_status(r);
+    return hipStreamSynchronize(nullptr) == hipSuccess ? 0 : 1;
+}
+
+void rccl_destroy(kfx_comm* c)
+{
+    if (!c || !c->impl) return;
+    RcclImpl* im = static_cast<RcclImpl*>(c->impl);
+    if (im->comm) ncclCommDestroy(im->comm);
+    if (im->token) (void)hipFree(im->token);
+    delete im;
+    c->impl = nullptr;
+}
+
+} // namespace
+
+extern "C" int kfx_comm_create_rccl(kfx_comm* comm, int rank, int world, const char* rendezvous_file, int timeout_s)
+{
+    if (!comm || (world > 1 && !rendezvous_file)) return KFX_E_NULL;
+    if (world < 1 || rank < 0 || rank >= world) return KFX_E_RANGE;
+    ncclUniqueId id;
+    memset(&id, 0, sizeof(id));
+    if (rank == 0) {
+        const ncclResult_t r = ncclGetUniqueId(&id);
+        if (r != ncclSuccess) return nccl_status(r);
+        if (world > 1) {
+            const std::string tmp = std::string(rendezvous_file) + ".tmp";
+            FILE* f = fopen(tmp.c_str(), "wb");
+            if (!f) return KFX_E_RANGE;
+            const size_t n = fwrite(&id, 1, sizeof(id), f);
+            fclose(f);
+            if (n != sizeof(id) || rename(tmp.c_str(), rendezvous_file) != 0) return KFX_E_RANGE;
+        }
+    } else {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (;;) {
+            FILE* f = fopen(rendezvous_file, "rb");
+            if (f) {
+                const size_t n = fread(&id, 1, sizeof(id), f);
+                fclose(f);
+                if (n == sizeof(id)) break;
+            }
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(timeout_s > 0 ? timeout_s : 60)) return KFX_E_RANGE;
+            std::this_thread::sleep_for(std::chrono::milliseconds(20));
+        }
+    }
+    RcclImpl* im = new (std::nothrow) RcclImpl;
+    if (!im) return KFX_E_RANGE;
+    const ncclResult_t r = ncclCommInitRank(&im->comm, world, id, rank);
+    if (r != ncclSuccess) {
+        delete im;
+        return nccl_status(r);
+    }
+    if (hipMalloc(&im->token, 4) != hipSuccess || hipMemset(im->token, 0, 4) != hipSuccess) {
+        ncclCommDestroy(im->comm);
+        delete im;
+        return KFX_E_NODEVICE;
+    }
+    comm->rank = rank;
+    comm->world = world;
+    comm->impl = im;
+    comm->all_reduce = rccl_all_reduce;
+    comm->exchange = rccl_exchange;
+    comm->barrier = rccl_barrier;
+    comm->destroy = rccl_destroy;
+    if (rank == 0 && world > 1) { // every rank has joined once ncclCommInitRank returns: the file has served its purpose
+        rccl_barrier(comm);
+        unlink(rendezvous_file);
+    } else if (world > 1) {
+        rccl_barrier(comm);
+    }
+    return 0;
+}

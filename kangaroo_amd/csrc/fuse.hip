@@ -1129,6 +1129,12 @@ static int fuse_params(FuseParams& p, bool* small_images, const kfx_volume* vol,
     p.X = full ? (int)vol->w : (int)(vol->w / 8) * 8;
     p.Y = full ? (int)vol->h : (int)(vol->h / 8) * 8;
     p.Z = full ? (int)vol->d : (int)(vol->d / 8) * 8;
+    if (!full && (flags & KFX_FUSE_SLAB_EXTENT) && slab) {
+        // the reference's extents on the WHOLE volume (quirk Q1): x / y as above, z = the local planes below (full_d / 8) * 8
+        const size_t zlim = (slab->full_d / 8) * 8;
+        const size_t z_end = slab->z_offset + vol->d < zlim ? slab->z_offset + vol->d : zlim;
+        p.Z = z_end > slab->z_offset ? (int)(z_end - slab->z_offset) : 0;
+    }
     p.w1 = (float)(vol->w - 1);
     p.h1 = (float)(vol->h - 1);
     p.d1 = (float)(vol->d - 1);

@@ -1,0 +1,283 @@
+// slab.hip -- Z-slab partition of the TSDF volume across ranks (include/kfx_slab.h): layout, halo exchange, nearest-hit
+// composite, exact march hand-over, and the in-process "threads" transport.  The collectives themselves belong to the
+// transport behind kfx_comm (RCCL: comm_rccl.cpp); this file only orders kernels and collectives on the caller's stream.
+// No reference counterpart (the reference is single-GPU); the host-side protocol is the one of
+// kangaroo_amd/pipeline.py::SlabPipeline, so that C / C++ applications can use slabs without Python.
+#include <condition_variable>
+#include <mutex>
+#include <new>
+
+#include "kfx_device.h"
+#include "../../include/kfx_slab.h"
+
+namespace kfx {
+
+// ---- exact march: merging the per-rank states between rounds -------------------------------------------------------
+// state planes (kfx.h, KFX_RAY_STATE_PLANES): 0 lambda, 1 last_sdf, 2 delta, 3 status, 4 touched, 5-7 normal, 8 shade.
+// In a round exactly one rank touches a pixel, so SUM over ranks of (touched ? bits : 0) is that rank's state.
+__global__ __launch_bounds__(256) void k_state_contrib(const int* __restrict__ state, int* __restrict__ contrib, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const bool touched = state[4 * n + i] != 0;
+#pragma unroll
+    for (int p = 0; p < 5; ++p) contrib[p * n + i] = touched ? state[p * n + i] : 0;
+}
+
+// after the all-reduce: adopt the touching rank's state; *flag |= 1 while any ray is still marching (status 0) or a hit
+// awaits its normal (status 3)
+__global__ __launch_bounds__(256) void k_state_merge(int* __restrict__ state, const int* __restrict__ contrib, size_t n, int merge,
+                                                     int* __restrict__ flag)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    bool open = false;
+    if (i < n) {
+        if (merge && contrib[4 * n + i] != 0) {
+#pragma unroll
+            for (int p = 0; p < 5; ++p) state[p * n + i] = contrib[p * n + i];
+        }
+        const float status = __int_as_float(state[3 * n + i]);
+        open = status == 0.0f || status == 3.0f;
+    }
+    if (__ballot(open) != 0ull && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+}
+
+// ---- threads transport: reduction over the ranks' buffers by one kernel -------------------------------------------
+constexpr int MAX_THREAD_RANKS = 16;
+struct PtrList { void* p[MAX_THREAD_RANKS]; };
+
+template <typename T, int OP>
+__global__ __launch_bounds__(256) void k_group_reduce(PtrList bufs, int world, size_t count)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= count) return;
+    T acc = reinterpret_cast<const T*>(bufs.p[0])[i];
+    for (int r = 1; r < world; ++r) {
+        const T v = reinterpret_cast<const T*>(bufs.p[r])[i];
+        if constexpr (OP == 0) acc = v < acc ? v : acc;
+        else acc = acc + v;   // rank order: every rank ends up with the same bits
+    }
+    for (int r = 0; r < world; ++r) reinterpret_cast<T*>(bufs.p[r])[i] = acc;
+}
+
+struct ThreadGroup {
+    int world = 0;
+    std::mutex m;
+    std::condition_variable cv;
+    int arrived = 0;
+    unsigned long generation = 0;
+    void* buf[MAX_THREAD_RANKS];
+    const void* send_lo[MAX_THREAD_RANKS];
+    const void* send_hi[MAX_THREAD_RANKS];
+    size_t bytes_lo[MAX_THREAD_RANKS], bytes_hi[MAX_THREAD_RANKS];
+    int status = 0;
+
+    void wait_all()
+    {
+        std::unique_lock<std::mutex> lk(m);
+        const unsigned long g = generation;
+        if (++arrived == world) {
+            arrived = 0;
+            ++generation;
+            cv.notify_all();
+        } else {
+            cv.wait(lk, [&] { return generation != g; });
+        }
+    }
+};
+
+static int hip_status(hipError_t e, const char* what)
+{
+    if (e == hipSuccess) return 0;
+    (void)hipGetLastError();
+    return set_error((int)e, what);
+}
+
+static int threads_all_reduce(kfx_comm* c, void* buf, size_t count, int op, kfx_stream stream)
+{
+    ThreadGroup* g = static_cast<ThreadGroup*>(c->impl);
+    if (!buf && count) return set_error(KFX_E_NULL, "kfx_comm(threads) all_reduce: null buffer");
+    if (int e = hip_status(hipStreamSynchronize((hipStream_t)stream), "kfx_comm(threads) all_reduce")) return e; // this rank's producers are done
+    g->buf[c->rank] = buf;
+    g->wait_all();
+    if (c->rank == 0) {
+        int st = 0;
+        if (count) {
+            PtrList pl;
+            for (int r = 0; r < g->world; ++r) pl.p[r] = g->buf[r];
+            const dim3 grid((unsigned)((count + 255) / 256));
+            hipStream_t s = (hipStream_t)stream;
+            if (op == KFX_COMM_MIN_I64) hipLaunchKernelGGL((k_group_reduce<long long, 0>), grid, dim3(256), 0, s, pl, g->world, count);
+            else if (op == KFX_COMM_SUM_F32) hipLaunchKernelGGL((k_group_reduce<float, 1>), grid, dim3(256), 0, s, pl, g->world, count);
+            else if (op == KFX_COMM_SUM_I32) hipLaunchKernelGGL((k_group_reduce<int, 1>), grid, dim3(256), 0, s, pl, g->world, count);
+            else st = set_error(KFX_E_RANGE, "kfx_comm all_reduce: unknown op");
+            if (!st) st = check_launch("kfx_comm(threads) all_reduce");
+            if (!st) st = hip_status(hipStreamSynchronize(s), "kfx_comm(threads) all_reduce");
+        }
+        g->status = st;
+    }
+    g->wait_all();
+    return g->status;
+}
+
+static int threads_exchange(kfx_comm* c, const void* send_lo, void* recv_lo, size_t bytes_lo, const void* send_hi, void* recv_hi,
+                            size_t bytes_hi, kfx_stream stream)
+{
+    ThreadGroup* g = static_cast<ThreadGroup*>(c->impl);
+    const int r = c->rank;
+    if (int e = hip_status(hipStreamSynchronize((hipStream_t)stream), "kfx_comm(threads) exchange")) return e;
+    g->send_lo[r] = send_lo; g->bytes_lo[r] = bytes_lo;
+    g->send_hi[r] = send_hi; g->bytes_hi[r] = bytes_hi;
+    g->wait_all();
+    int st = 0;
+    hipStream_t s = (hipStream_t)stream;
+    if (r > 0 && bytes_lo) { // what rank - 1 sends upwards
+        if (g->bytes_hi[r - 1] != bytes_lo) st = set_error(KFX_E_SHAPE, "kfx_comm exchange: neighbours disagree on the byte count");
+        else st = hip_status(hipMemcpyAsync(recv_lo, g->send_hi[r - 1], bytes_lo, hipMemcpyDeviceToDevice, s), "kfx_comm(threads) exchange");
+    }
+    if (!st && r + 1 < g->world && bytes_hi) { // what rank + 1 sends downwards
+        if (g->bytes_lo[r + 1] != bytes_hi) st = set_error(KFX_E_SHAPE, "kfx_comm exchange: neighbours disagree on the byte count");
+        else st = hip_status(hipMemcpyAsync(recv_hi, g->send_lo[r + 1], bytes_hi, hipMemcpyDeviceToDevice, s), "kfx_comm(threads) exchange");
+    }
+    if (!st) st = hip_status(hipStreamSynchronize(s), "kfx_comm(threads) exchange");
+    g->wait_all(); // nobody reuses a send buffer before its reader is done
+    return st;
+}
+
+static int threads_barrier(kfx_comm* c)
+{
+    static_cast<ThreadGroup*>(c->impl)->wait_all();
+    return 0;
+}
+
+static void threads_destroy(kfx_comm* c)
+{
+    if (c && c->impl && c->rank == 0) delete static_cast<ThreadGroup*>(c->impl);
+    if (c) c->impl = nullptr;
+}
+
+} // namespace kfx
+
+using namespace kfx;
+
+extern "C" int kfx_comm_create_threads(kfx_comm* comms, int world)
+{
+    if (!comms) return set_error(KFX_E_NULL, "kfx_comm_create_threads: null comms");
+    if (world < 1 || world > MAX_THREAD_RANKS) return set_error(KFX_E_RANGE, "kfx_comm_create_threads: world in [1, 16]");
+    ThreadGroup* g = new (std::nothrow) ThreadGroup;
+    if (!g) return set_error(KFX_E_RANGE, "kfx_comm_create_threads: out of memory");
+    g->world = world;
+    for (int r = 0; r < world; ++r) {
+        comms[r].rank = r;
+        comms[r].world = world;
+        comms[r].impl = g;
+        comms[r].all_reduce = threads_all_reduce;
+        comms[r].exchange = threads_exchange;
+        comms[r].barrier = threads_barrier;
+        comms[r].destroy = threads_destroy;
+    }
+    return 0;
+}
+
+extern "C" int kfx_slab_layout_init(kfx_slab_layout* L, size_t full_d, float full_zmin, float full_zmax, int rank, int world, int ghost)
+{
+    if (!L) return set_error(KFX_E_NULL, "kfx_slab_layout_init: null layout");
+    if (full_d < 2 || world < 1 || rank < 0 || rank >= world || ghost < 1 || (size_t)world > full_d)
+        return set_error(KFX_E_RANGE, "kfx_slab_layout_init: need full_d >= 2, 0 <= rank < world <= full_d, ghost >= 1");
+    const size_t base = full_d / (size_t)world, rem = full_d % (size_t)world;
+    if (world > 1 && base < (size_t)ghost) return set_error(KFX_E_RANGE, "kfx_slab_layout_init: every rank must own at least `ghost` planes");
+    L->full_d = full_d;
+    L->full_zmin = full_zmin;
+    L->full_zmax = full_zmax;
+    L->rank = rank;
+    L->world = world;
+    L->ghost = ghost;
+    const size_t r = (size_t)rank;
+    L->z0 = r * base + (r < rem ? r : rem);
+    L->z1 = L->z0 + base + (r < rem ? 1 : 0);
+    L->s0 = L->z0 >= (size_t)ghost ? L->z0 - (size_t)ghost : 0;
+    L->s1 = L->z1 + (size_t)ghost <= full_d ? L->z1 + (size_t)ghost : full_d;
+    // BoundedVolume::VoxelPositionInUnits (BoundedVolume.h:115-125): min + size * i / (float)(d - 1)
+    const float size_z = full_zmax - full_zmin;
+    L->local_zmin = full_zmin + size_z * (float)L->s0 / (float)(full_d - 1);
+    L->local_zmax = full_zmin + size_z * (float)(L->s1 - 1) / (float)(full_d - 1);
+    return 0;
+}
+
+extern "C" int kfx_slab_exchange_halos(const kfx_volume* local, const kfx_slab_layout* L, kfx_comm* comm, kfx_stream stream)
+{
+    if (!local || !local->ptr || !L || !comm) return set_error(KFX_E_NULL, "kfx_slab_exchange_halos: null argument");
+    if (local->d != L->s1 - L->s0 || comm->rank != L->rank || comm->world != L->world)
+        return set_error(KFX_E_SHAPE, "kfx_slab_exchange_halos: volume / communicator do not match the layout");
+    if (L->world == 1) return 0;
+    unsigned char* base = static_cast<unsigned char*>(local->ptr);
+    const size_t plane = local->img_pitch;
+    const size_t lo_ghost = L->z0 - L->s0, hi_ghost = L->s1 - L->z1;   // planes [s0, z0) come from rank - 1, [z1, s1) from rank + 1
+    const size_t own0 = L->z0 - L->s0, own1 = L->z1 - L->s0;           // local indices of the owned range
+    // the lower neighbour's upper ghost is `ghost` planes unless it is clipped by the volume's end -- it never is for
+    // rank - 1 < world - 1; symmetric for the upper neighbour: both directions carry lo_ghost / hi_ghost planes
+    const void* send_lo = L->rank > 0 ? base + own0 * plane : nullptr;                 // my first owned planes -> rank - 1's upper ghost
+    void* recv_lo = L->rank > 0 ? base : nullptr;
+    const void* send_hi = L->rank + 1 < L->world ? base + (own1 - hi_ghost) * plane : nullptr; // my last owned planes -> rank + 1's lower ghost
+    void* recv_hi = L->rank + 1 < L->world ? base + own1 * plane : nullptr;
+    return comm->exchange(comm, send_lo, recv_lo, L->rank > 0 ? lo_ghost * plane : 0, send_hi, recv_hi,
+                          L->rank + 1 < L->world ? hi_ghost * plane : 0, stream);
+}
+
+extern "C" int kfx_slab_composite(const kfx_image* depth, const kfx_image* norm, const kfx_image* img, long long* key, float* payload,
+                                  kfx_comm* comm, kfx_stream stream)
+{
+    if (!comm || !depth) return set_error(KFX_E_NULL, "kfx_slab_composite: null argument");
+    if (comm->world == 1) return 0;
+    const size_t n = depth->w * depth->h;
+    if (int e = kfx_composite_pack(depth, norm, img, key, comm->rank, stream)) return e;
+    if (int e = comm->all_reduce(comm, key, n, KFX_COMM_MIN_I64, stream)) return e;
+    if (int e = kfx_composite_select(depth, norm, img, key, payload, comm->rank, stream)) return e;
+    if (int e = comm->all_reduce(comm, payload, 5 * n, KFX_COMM_SUM_F32, stream)) return e;
+    return kfx_composite_unpack(depth, norm, img, key, payload, stream);
+}
+
+extern "C" size_t kfx_slab_exact_scratch_bytes(size_t w, size_t h) { return (5 * w * h + 64) * sizeof(int); }
+
+extern "C" int kfx_slab_raycast_exact(const kfx_image* depth, const kfx_image* norm, const kfx_image* img, float* state, void* scratch,
+                                      const kfx_volume* local, const kfx_slab_layout* L, const float T_wc[12], const float K[4],
+                                      float near, float far, float trunc_dist, int subpix, kfx_comm* comm, kfx_stream stream,
+                                      int* rounds_out)
+{
+    if (!depth || !norm || !img || !state || !scratch || !local || !L || !comm) return set_error(KFX_E_NULL, "kfx_slab_raycast_exact: null argument");
+    if (local->d != L->s1 - L->s0 || comm->rank != L->rank || comm->world != L->world)
+        return set_error(KFX_E_SHAPE, "kfx_slab_raycast_exact: volume / communicator do not match the layout");
+    const int w = (int)depth->w, h = (int)depth->h;
+    const size_t n = (size_t)w * h;
+    if (n == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    int* contrib = static_cast<int*>(scratch);
+    int* flag = contrib + 5 * n;
+    int* istate = reinterpret_cast<int*>(state);
+    const kfx_slab slab = {L->full_d, L->s0, L->full_zmin, L->full_zmax};
+    const dim3 grid((unsigned)((n + 255) / 256));
+    int rounds = 0;
+    for (;;) {
+        if (int e = kfx_raycast_sdf_slab(state, rounds == 0, local, &slab, (int)L->z0, (int)L->z1, w, h, T_wc, K, near, far,
+                                         trunc_dist, subpix, stream))
+            return e;
+        ++rounds;
+        if (comm->world > 1) {
+            hipLaunchKernelGGL(k_state_contrib, grid, dim3(256), 0, s, istate, contrib, n);
+            if (int e = check_launch("kfx_slab_raycast_exact")) return e;
+            if (int e = comm->all_reduce(comm, contrib, 5 * n, KFX_COMM_SUM_I32, stream)) return e;
+        }
+        if (int e = hip_status(hipMemsetAsync(flag, 0, sizeof(int), s), "kfx_slab_raycast_exact")) return e;
+        hipLaunchKernelGGL(k_state_merge, grid, dim3(256), 0, s, istate, contrib, n, comm->world > 1 ? 1 : 0, flag);
+        if (int e = check_launch("kfx_slab_raycast_exact")) return e;
+        int open = 0;
+        if (int e = hip_status(hipMemcpyAsync(&open, flag, sizeof(int), hipMemcpyDeviceToHost, s), "kfx_slab_raycast_exact")) return e;
+        if (int e = hip_status(hipStreamSynchronize(s), "kfx_slab_raycast_exact")) return e;
+        if (!open) break; // the merged state is identical on every rank, so all ranks leave together
+        if (rounds > L->world + 3) return set_error(KFX_E_RANGE, "kfx_slab_raycast_exact: march did not terminate");
+    }
+    if (comm->world > 1) // normals (planes 5-7) and shade (8): written by one rank per pixel
+        if (int e = comm->all_reduce(comm, istate + 5 * n, 4 * n, KFX_COMM_SUM_I32, stream)) return e;
+    if (rounds_out) *rounds_out = rounds;
+    return kfx_raycast_state_to_images(depth, norm, img, state, stream);
+}

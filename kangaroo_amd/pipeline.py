@@ -195,6 +195,8 @@ class SlabPipeline(FramePipeline):
         self.full_boxmin = np.asarray(boxmin, np.float32)
         self.full_boxmax = np.asarray(boxmax, np.float32)
         d = int(dims[2])
+        # exchange_halos takes the ghost planes from the immediate neighbours: every rank must own at least GHOST planes
+        assert self.world == 1 or d // self.world >= self.GHOST, "slabs thinner than the ghost width (%d planes / %d ranks)" % (d, self.world)
         self.z0, self.z1 = slab_range(d, self.rank, self.world)
         self.s0, self.s1 = max(self.z0 - self.GHOST, 0), min(self.z1 + self.GHOST, d)
         kw["contiguous_images"] = True  # collectives operate on dense tensors
@@ -216,7 +218,8 @@ class SlabPipeline(FramePipeline):
     def fuse(self, T_wc, T_cw=None):
         """T_cw: world -> camera transform to use instead of the float32 inverse of T_wc (the tracking loop inverts
         its pose in float64, main.cpp:345-356)."""
-        # views may have a plane count that is not a multiple of 8: integrate all of it (full_extent)
+        # a slab's plane count is usually not a multiple of 8: full_extent="slab" integrates exactly the voxels roo::SdfFuse
+        # integrates on the whole volume (x / y extents (dim/8)*8, planes below (D/8)*8), whatever the partition
         D = self.dims[2]
         zmin, zmax = float(self.full_boxmin[2]), float(self.full_boxmax[2])
         if self.halo == "recompute" or self.world == 1:
@@ -226,7 +229,7 @@ class SlabPipeline(FramePipeline):
         # slab entry point: voxel positions by the FULL volume's expression, so every plane is integrated
         # bit-identically to the same plane of a single-GPU volume
         self.ops.SdfFuse(target, self.filtered, self.normals, scenes.se3_inverse(T_wc) if T_cw is None else T_cw, self.K, self.trunc,
-                         self.max_w, self.mincostheta, full_extent=True, slab=(D, first, zmin, zmax))
+                         self.max_w, self.mincostheta, full_extent="slab", slab=(D, first, zmin, zmax))
         if target is not self.vol:
             self.exchange_halos()
 

@@ -249,8 +249,9 @@ def SdfFuse(vol, depth, norm, T_cw, K, trunc_dist, maxw, mincostheta, full_exten
     if slab is not None:
         sl = _lib.KfxSlab(int(slab[0]), int(slab[1]), float(slab[2]), float(slab[3]))
         fn = _lib.load().kfx_sdf_fuse_slab_h if vol.kind == "f16" else _lib.load().kfx_sdf_fuse_slab
+        # full_extent="slab": the reference's extents on the whole volume (KFX_FUSE_SLAB_EXTENT)
         _lib.check(fn(vol.ref(), C.byref(sl), depth.ref(), norm.ref(), t, k, trunc_dist, maxw,
-                                                 mincostheta, 1 if full_extent else 0, _stream(stream)))
+                                                 mincostheta, 2 if full_extent == "slab" else (1 if full_extent else 0), _stream(stream)))
         return
     fn = _lib.load().kfx_sdf_fuse_h if vol.kind == "f16" else _lib.load().kfx_sdf_fuse
     _lib.check(fn(vol.ref(), depth.ref(), norm.ref(), t, k, trunc_dist, maxw, mincostheta,

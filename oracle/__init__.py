@@ -320,7 +320,7 @@ def sdf_fuse(vol, depth, norm, T_cw, K, trunc, max_w, mincostheta, full_extent=F
     if slab is not None:
         sl = KfoSlab(int(slab[0]), int(slab[1]), float(slab[2]), float(slab[3]))
         return int(lib().kfo_sdf_fuse_slab(vol.ref(), C.byref(sl), depth.ref(), norm.ref(), t, k, trunc, max_w, mincostheta,
-                                           1 if full_extent else 0, nthreads))
+                                           2 if full_extent == "slab" else (1 if full_extent else 0), nthreads))
     fn = lib().kfo_sdf_fuse_h if _is_half(vol) else lib().kfo_sdf_fuse
     return int(fn(vol.ref(), depth.ref(), norm.ref(), t, k, trunc, max_w, mincostheta, 1 if full_extent else 0, nthreads))
 

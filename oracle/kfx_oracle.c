@@ -363,9 +363,17 @@ static uint64_t sdf_fuse_any(const kfo_volume* vol, const kfo_image* depth, cons
                              float mincostheta, int full_extent, int nthreads, int half, const kfo_slab* slab)
 {
     /* gridDim = (w/8, h/8, d/8), blockDim = (8,8,8): integer division, no tail (quirk Q1) */
-    const int X = full_extent ? (int)vol->w : (int)(vol->w / 8) * 8;
-    const int Y = full_extent ? (int)vol->h : (int)(vol->h / 8) * 8;
-    const int Z = full_extent ? (int)vol->d : (int)(vol->d / 8) * 8;
+    /* full_extent: 0 = the reference's (dim/8)*8 extents of `vol` (quirk Q1), 1 = every voxel, 2 (slabs) = the reference's
+     * extents on the WHOLE volume: x / y (dim/8)*8, z = the local planes below (full_d/8)*8 */
+    const int full = full_extent == 1;
+    const int X = full ? (int)vol->w : (int)(vol->w / 8) * 8;
+    const int Y = full ? (int)vol->h : (int)(vol->h / 8) * 8;
+    int Z = full ? (int)vol->d : (int)(vol->d / 8) * 8;
+    if (full_extent == 2 && slab) {
+        const size_t zlim = (slab->full_d / 8) * 8;
+        const size_t z_end = slab->z_offset + vol->d < zlim ? slab->z_offset + vol->d : zlim;
+        Z = z_end > slab->z_offset ? (int)(z_end - slab->z_offset) : 0;
+    }
     uint64_t updated = 0;
     const int nt = pick_threads(nthreads);
     (void)nt;

@@ -42,7 +42,7 @@ if not tracking:
         pipe.step(T_wc)
         ref.raw.MemcpyFromHost(depth)
         ref.preprocess()
-        roo.SdfFuse(ref.vol, ref.filtered, ref.normals, scenes.se3_inverse(T_wc), ref.K, ref.trunc, ref.max_w, ref.mincostheta, full_extent=True)
+        roo.SdfFuse(ref.vol, ref.filtered, ref.normals, scenes.se3_inverse(T_wc), ref.K, ref.trunc, ref.max_w, ref.mincostheta)
         ref.raycast(T_wc)
     torch.cuda.synchronize()
     # (1) every stored plane (owned + ghost) equals the same plane of the single volume, bit for bit

@@ -32,6 +32,58 @@ def test_library_exports_every_declared_symbol():
     assert set(names) <= exported
 
 
+def test_debug_and_slab_headers_are_exported_too():
+    """include/kfx_debug.h (measurement aids) and include/kfx_slab.h (multi-GPU slab partition) declare symbols of
+    libkfx.so, except the RCCL transport, which lives in libkfx_rccl.so so that libkfx.so does not depend on librccl."""
+    def decl(path):
+        src = re.sub(r"/\*.*?\*/", "", open(os.path.join(T.ROOT, "include", path)).read(), flags=re.S)
+        return set(re.findall(r"\b(kfx_[a-z0-9_]+)\s*\(", src))
+
+    def exported(lib):
+        out = subprocess.check_output(["nm", "-D", "--defined-only", lib]).decode()
+        return set(re.findall(r" T (kfx_[a-z0-9_]+)", out))
+    main = exported(_lib.LIB_PATH)
+    rccl_lib = os.path.join(os.path.dirname(_lib.LIB_PATH), "libkfx_rccl.so")
+    assert os.path.exists(rccl_lib), "libkfx_rccl.so not built"
+    rccl = exported(rccl_lib)
+    dbg, slab = decl("kfx_debug.h"), decl("kfx_slab.h")
+    assert len(dbg) >= 4 and dbg <= main
+    assert "kfx_comm_create_rccl" in slab and len(slab) >= 7
+    assert slab - {"kfx_comm_create_rccl"} <= main and "kfx_comm_create_rccl" in rccl
+    needed = subprocess.check_output(["readelf", "-d", _lib.LIB_PATH]).decode()
+    assert "rccl" not in needed
+    assert "librccl" in subprocess.check_output(["readelf", "-d", rccl_lib]).decode()
+
+
+def test_slab_layout_and_argument_checks():
+    """kfx_slab_layout_init: contiguous owned ranges that tile the volume, ghost planes clipped at the ends, the local box
+    from VoxelPositionInUnits of the whole volume; bad arguments are rejected (host-only code, no GPU needed)."""
+    L = _lib.load()
+
+    class Layout(C.Structure):
+        _fields_ = [("full_d", C.c_size_t), ("full_zmin", C.c_float), ("full_zmax", C.c_float), ("rank", C.c_int), ("world", C.c_int),
+                    ("ghost", C.c_int), ("z0", C.c_size_t), ("z1", C.c_size_t), ("s0", C.c_size_t), ("s1", C.c_size_t),
+                    ("local_zmin", C.c_float), ("local_zmax", C.c_float)]
+    L.kfx_slab_layout_init.argtypes = [C.POINTER(Layout), C.c_size_t, C.c_float, C.c_float, C.c_int, C.c_int, C.c_int]
+    from kangaroo_amd.pipeline import slab_range
+    f = np.float32
+    for d, world, ghost in ((512, 8, 2), (100, 3, 2), (64, 5, 1), (17, 4, 3)):
+        prev = 0
+        for r in range(world):
+            lay = Layout()
+            assert L.kfx_slab_layout_init(C.byref(lay), d, 2.0, 4.0, r, world, ghost) == 0
+            assert (lay.z0, lay.z1) == slab_range(d, r, world) and lay.z0 == prev
+            prev = lay.z1
+            assert lay.s0 == max(lay.z0 - ghost, 0) and lay.s1 == min(lay.z1 + ghost, d)
+            assert f(lay.local_zmin) == f(2.0) + (f(4.0) - f(2.0)) * f(lay.s0) / f(d - 1)
+            assert f(lay.local_zmax) == f(2.0) + (f(4.0) - f(2.0)) * f(lay.s1 - 1) / f(d - 1)
+        assert prev == d
+    lay = Layout()
+    assert L.kfx_slab_layout_init(C.byref(lay), 16, 0.0, 1.0, 0, 8, 3) == -4      # slabs thinner than the ghost width
+    assert L.kfx_slab_layout_init(C.byref(lay), 16, 0.0, 1.0, 8, 8, 1) == -4 and L.kfx_slab_layout_init(None, 16, 0.0, 1.0, 0, 1, 1) == -1
+    assert L.kfx_slab_exchange_halos(None, None, None, None) == -1 and L.kfx_slab_composite(None, None, None, None, None, None, None) == -1
+
+
 def test_library_contains_gfx950_code_object():
     blob = open(_lib.LIB_PATH, "rb").read()
     assert b"gfx950" in blob and b"k_sdf_fuse" in blob and b"k_raycast_sdf" in blob
@@ -76,7 +128,7 @@ def test_every_compute_entry_point_rejects_null_arguments():
     return a negative KFX_E_* code (never a crash, never a launch) -- checked here without a GPU."""
     L = _lib.load()
     skip = {"kfx_version", "kfx_device_count", "kfx_last_error_string", "kfx_error_name", "kfx_free", "kfx_free_host",
-            "kfx_set_math_mode", "kfx_get_math_mode", "kfx_stream_synchronize", "kfx_alloc_host", "kfx_memcpy_2d"}
+            "kfx_set_math_mode", "kfx_get_math_mode", "kfx_stream_synchronize", "kfx_alloc_host", "kfx_memcpy_2d", "kfx_set_device"}
     checked = 0
     for name, (restype, argtypes) in sorted(_lib.SIGNATURES.items()):
         if name in skip or restype is not C.c_int:

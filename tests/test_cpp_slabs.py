@@ -1,0 +1,70 @@
+"""The Z-slab partition driven from C++ only (apps/kinectfusion_slabs.cpp -> include/kangaroo/SlabVolume.h -> include/kfx_slab.h):
+no Python in the product path.  The GPU box has one GPU, so the multi-rank runs use the in-process transport (ranks = host
+threads sharing the device): same slab code, same kernels, collectives by the thread group instead of RCCL.  The RCCL
+transport itself runs with a single rank (RCCL refuses two ranks on one device); with more GPUs scripts/launch_ranks.sh
+starts one process per GPU."""
+import os
+import re
+import subprocess
+
+import pytest
+
+import kfx_testlib as T
+
+APP = os.path.join(T.ROOT, "apps", "kinectfusion_slabs")
+pytestmark = pytest.mark.gpu
+
+
+def run(*args, env=None):
+    out = subprocess.run([APP] + [str(a) for a in args], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    m = re.search(r"checksums depth=(\w+) norm=(\w+) img=(\w+) volume=(\w+) hits=(\d+) ranks_agree=(\d)", out.stdout)
+    assert m, out.stdout
+    ms = float(re.search(r"([\d.]+) ms/frame", out.stdout).group(1))
+    return dict(depth=m.group(1), norm=m.group(2), img=m.group(3), volume=m.group(4), hits=int(m.group(5)), agree=int(m.group(6)), ms=ms,
+                text=out.stdout)
+
+
+COMMON = ("--res", 128, "--frames", 4, "--width", 320, "--height", 240)
+
+
+def test_cpp_slabs_exact_march_equals_single_volume():
+    """4 and 3 slabs, ghost planes exchanged or recomputed, march state handed over: volume and all three images are
+    bit-identical to the one-slab run (which is the single-volume pipeline)."""
+    ref = run(*COMMON, "--ranks", 1, "--raycast", "exact")
+    assert ref["hits"] > 320 * 240 // 3 and ref["agree"] == 1
+    for ranks, halo in ((4, "exchange"), (3, "recompute"), (8, "exchange")):
+        got = run(*COMMON, "--ranks", ranks, "--raycast", "exact", "--halo", halo)
+        assert got["agree"] == 1
+        for k in ("depth", "norm", "img", "volume", "hits"):
+            assert got[k] == ref[k], (ranks, halo, k, got["text"], ref["text"])
+        assert re.search(r"\((\d+) rounds\)", got["text"]) and 1 < int(re.search(r"\((\d+) rounds\)", got["text"]).group(1)) <= ranks + 3
+
+
+def test_cpp_slabs_composite_and_fast_mode():
+    """Nearest-hit composite: the volume is still bit-identical, every rank ends with the same images and the hit count
+    stays within 1 % of the single-volume march (rays restart at slab entries).  Also in fast numerics."""
+    for fast in ((), ("--fast",)):
+        ref = run(*COMMON, *fast, "--ranks", 1, "--raycast", "composite")
+        got = run(*COMMON, *fast, "--ranks", 4, "--raycast", "composite", "--halo", "exchange")
+        assert got["agree"] == 1 and got["volume"] == ref["volume"]
+        assert abs(got["hits"] - ref["hits"]) <= 0.01 * ref["hits"]
+
+
+def test_cpp_slabs_rccl_transport_single_rank(tmp_path):
+    """The RCCL transport (libkfx_rccl.so: ncclCommInitRank, all-reduce, grouped send / recv) on the one GPU of the box: a
+    one-rank communicator, through the same code path N ranks take; results equal the thread transport's."""
+    ref = run(*COMMON, "--ranks", 1, "--raycast", "exact")
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    for mode in ("exact", "composite"):
+        got = run(*COMMON, "--transport", "rccl", "--raycast", mode, "--rendezvous", str(tmp_path / "id"), env=env)
+        assert "RCCL" in got["text"] and got["volume"] == ref["volume"] and got["depth"] == ref["depth"] and got["norm"] == ref["norm"]
+
+
+def test_cpp_slabs_refuse_more_rccl_ranks_than_gpus(tmp_path):
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("needs a box with fewer than 2 GPUs")
+    env = dict(os.environ, RANK="0", WORLD_SIZE="2", LOCAL_RANK="0")
+    out = subprocess.run([APP, "--transport", "rccl", "--rendezvous", str(tmp_path / "id")], capture_output=True, text=True, timeout=120, env=env)
+    assert out.returncode == 2 and "need 2 GPUs" in out.stderr

@@ -56,6 +56,36 @@ def test_slab_range_partitions_every_plane_once():
             assert max(sizes) - min(sizes) <= 1
 
 
+def test_slab_extent_reproduces_the_reference_extents_of_the_whole_volume():
+    """Dimensions that are not multiples of 8: roo::SdfFuse skips the trailing dim % 8 voxels per axis (quirk Q1).  Slabs
+    integrated with full_extent="slab" leave exactly those voxels untouched, whatever the partition."""
+    import oracle
+    dims, w, h = (20, 17, 29), 80, 60
+    bmin, bmax = scenes.SCENES["full"][:2]
+    K = scenes.intrinsics(w, h)
+    f, vbo, nrm = T.preprocess_oracle(scenes.render_depth("full", w, h, None, K), K)
+    tr = scenes.trunc_dist(bmin, bmax, dims)
+    whole = oracle.Volume(*dims, bmin, bmax)
+    oracle.sdf_reset(whole, float("nan"))
+    n_ref = oracle.sdf_fuse(whole, f, nrm, scenes.identity_pose(), K, tr, 1000.0, 0.1)
+    assert n_ref == 16 * 16 * 24
+    for world in (2, 3, 5):
+        parts = oracle.Volume(*dims, bmin, bmax)
+        oracle.sdf_reset(parts, float("nan"))
+        n = 0
+        for r in range(world):
+            z0, z1 = slab_range(dims[2], r, world)
+            sub = oracle.KfoVolume()
+            sub.pitch, sub.img_pitch, sub.w, sub.h, sub.d = parts.pitch, parts.img_pitch, dims[0], dims[1], z1 - z0
+            sub.ptr = parts.raw.ctypes.data + z0 * parts.img_pitch
+            for k in range(3):
+                sub.boxmin[k], sub.boxmax[k] = bmin[k], bmax[k]
+            view = oracle.SubVolume(parts, sub)
+            n += oracle.sdf_fuse(view, f, nrm, scenes.identity_pose(), K, tr, 1000.0, 0.1, full_extent="slab",
+                                 slab=(dims[2], z0, bmin[2], bmax[2]))
+        assert n == n_ref and T.nan_equal(parts.data, whole.data)
+
+
 @pytest.mark.parametrize("world,halo", [(2, "exchange"), (2, "recompute"), (3, "exchange")])
 def test_slab_pipeline_matches_single_volume(tmp_path, world, halo):
     import oracle_ops as ops
@@ -67,9 +97,8 @@ def test_slab_pipeline_matches_single_volume(tmp_path, world, halo):
         T_wc = scenes.orbit_pose(i, 8)
         ref.raw.MemcpyFromHost(scenes.render_depth("room", W, H, T_wc, ref.K))
         ref.preprocess()
-        # the monolithic reference integrates every plane too (the slabs use full_extent)
-        ops.SdfFuse(ref.vol, ref.filtered, ref.normals, scenes.se3_inverse(T_wc), ref.K, ref.trunc, ref.max_w,
-                    ref.mincostheta, full_extent=True)
+        # the monolithic reference with roo::SdfFuse's own extents: the slabs integrate exactly those voxels (full_extent="slab")
+        ops.SdfFuse(ref.vol, ref.filtered, ref.normals, scenes.se3_inverse(T_wc), ref.K, ref.trunc, ref.max_w, ref.mincostheta)
         ref.raycast(T_wc)
     full = ref.vol.data
     ranks = [np.load(os.path.join(str(tmp_path), "rank%d.npz" % r)) for r in range(world)]
@@ -115,8 +144,7 @@ def test_exact_slab_raycast_is_bit_identical_to_single_volume(tmp_path, world):
         T_wc = scenes.orbit_pose(i, 8)
         ref.raw.MemcpyFromHost(scenes.render_depth("room", W, H, T_wc, ref.K))
         ref.preprocess()
-        ops.SdfFuse(ref.vol, ref.filtered, ref.normals, scenes.se3_inverse(T_wc), ref.K, ref.trunc, ref.max_w,
-                    ref.mincostheta, full_extent=True)
+        ops.SdfFuse(ref.vol, ref.filtered, ref.normals, scenes.se3_inverse(T_wc), ref.K, ref.trunc, ref.max_w, ref.mincostheta)
         ref.raycast(T_wc)
     assert np.isfinite(ref.ray_d.data).mean() > 0.3
     for r in range(world):
