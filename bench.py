@@ -50,6 +50,8 @@ def parse():
     ap.add_argument("--halo", default="recompute", choices=["recompute", "exchange"],
                     help="N > 1: how ghost planes are kept current -- recomputed by each rank (no traffic) or "
                          "exchanged with the neighbours over RCCL point-to-point after each SdfFuse")
+    ap.add_argument("--overlap", action="store_true",
+                    help="N > 1, composite raycast: merge frame k's images on a second stream under frame k+1's preprocess + SdfFuse")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=30, help="upper bound on the timed CPU-baseline frames (the sample also stops after ~12 s)")
     return ap.parse_args()
@@ -172,7 +174,8 @@ def main():
     bmin, bmax, near, far = scenes.SCENES[scene]
     K = scenes.intrinsics(w, h)
     if distributed:
-        pipe = SlabPipeline(roo, dist, (N, N, N), bmin, bmax, w, h, halo=args.halo, raycast=args.raycast, K=K, near=near, far=far)
+        pipe = SlabPipeline(roo, dist, (N, N, N), bmin, bmax, w, h, halo=args.halo, raycast=args.raycast, K=K, near=near, far=far,
+                            overlap=args.overlap)
     else:
         pipe = FramePipeline(roo, (N, N, N), bmin, bmax, w, h, K=K, near=near, far=far)
 
@@ -186,6 +189,8 @@ def main():
 
     def sync_all():
         if distributed:
+            pipe.wait_composite()
+            torch.cuda.synchronize()
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -264,6 +269,37 @@ def main():
     other_bytes = float(np.mean([16.0 * n_updated[(args.warmup + s) % N_ORBIT] + 20.0 * w * h for s in range(n_other)]))
     roo.set_math_mode(args.math)
 
+    # N > 1: the same frames with the other ghost-plane policy (RCCL neighbour exchange vs redundant integration: same bits)
+    # and with the composite merge overlapped / not overlapped with the next frame -- reported beside the headline so that
+    # one multi-GPU run of the default command measures all of them (not part of `value`)
+    variants = None
+    if distributed:
+        def timed_fps(n):
+            for s in range(3):
+                i = (args.warmup + s) % N_ORBIT
+                pipe.step(poses[i], frames[i])
+            sync_all()
+            t_v = time.perf_counter()
+            for s in range(n):
+                i = (args.warmup + s) % N_ORBIT
+                pipe.step(poses[i], frames[i])
+            sync_all()
+            tt = torch.tensor([time.perf_counter() - t_v], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            return round(n / float(tt.item()), 1)
+        n_var = min(args.steps, 2 * N_ORBIT)
+        variants = {"steps": n_var, "as_configured_fps": timed_fps(n_var)}
+        base_halo, base_overlap = pipe.halo, pipe.overlap
+        pipe.halo = "exchange" if base_halo == "recompute" else "recompute"
+        variants["halo_%s_fps" % pipe.halo] = timed_fps(n_var)
+        pipe.halo = base_halo
+        if args.raycast == "composite":
+            pipe.wait_composite()
+            pipe.overlap = not base_overlap
+            variants["overlap_%s_fps" % ("on" if pipe.overlap else "off")] = timed_fps(n_var)
+            pipe.wait_composite()
+            pipe.overlap = base_overlap
+
     # measured device-to-device copy ceiling of this GPU, same run: a 1 GiB copy moves 2 GiB
     copy_GBps = None
     try:
@@ -320,7 +356,7 @@ def main():
                 "volume": [N, N, N], "image": [w, h], "scene": scene,
                 "backend": os.environ.get("KFX_BENCH_BACKEND", "nccl (RCCL)") if distributed else None,
                 "ranks_agree": ranks_agree,
-                "partition": ("z-slabs x%d, ghost planes %s, raycast %s" % (n_gpus, args.halo, "composite = all_reduce(MIN key) + all_reduce(SUM payload)" if args.raycast == "composite" else "exact = march state handed from slab to slab, one SUM all_reduce per round"))
+                "partition": ("z-slabs x%d, ghost planes %s%s, raycast %s" % (n_gpus, args.halo, ", merge overlapped with the next frame" if args.overlap else "", "composite = all_reduce(MIN key) + all_reduce(SUM payload)" if args.raycast == "composite" else "exact = march state handed from slab to slab, one SUM all_reduce per round"))
                              if distributed else "single volume",
                 "math": {"fast": "fast (fp32 rcp/rsq + FMA: the reference's own -use_fast_math regime; TSDF within 1e-4 of the exact path, "
                                  "tests/test_gpu_parity.py::test_gpu_fast_mode_within_tolerance)",
@@ -351,6 +387,8 @@ def main():
                                       "frac": round(other_bytes / (other_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                       "frames_per_sec": round(other_fps, 1),
                                       "note": "same frames, whole step (preprocess + fuse + raycast), %d steps" % n_other}
+        if variants is not None:
+            out["multi_gpu_variants"] = variants
         if not args.no_cpu_baseline and n_gpus == 1:
             try:
                 out["cpu_baseline"] = cpu_baseline(args, scene, args.cpu_frames)

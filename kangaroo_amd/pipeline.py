@@ -180,13 +180,18 @@ class SlabPipeline(FramePipeline):
 
     GHOST = 2  # >= 1 for the trilinear z+1 corner and the gradient's z-1 / z+1 cells (Volume.h:240-289)
 
-    def __init__(self, ops, dist, dims, boxmin, boxmax, w, h, halo="exchange", raycast="composite", kind="f32", **kw):
+    def __init__(self, ops, dist, dims, boxmin, boxmax, w, h, halo="exchange", raycast="composite", kind="f32", overlap=False, **kw):
         """halo = "exchange": every rank integrates only the planes it owns and the ghost planes are
         refreshed from the two neighbours after each SdfFuse (point-to-point send/recv: one xGMI link
         per direction); halo = "recompute": every rank integrates its ghost planes itself (the update is
         deterministic per voxel, so no traffic is needed) -- the cross-check of the exchange path."""
         assert halo in ("exchange", "recompute")
         assert raycast in ("composite", "exact")
+        # overlap (composite mode, known-pose streams): the merge of frame k's per-slab images -- two latency-bound
+        # all-reduces and three small kernels -- runs on a second stream while the main stream already preprocesses and
+        # integrates frame k + 1; the merged images are complete after wait_composite().
+        self.overlap = bool(overlap)
+        self._side = self._merged = None
         self.halo = halo
         self.raycast_mode = raycast
         self.kind = kind            # "f32": SDF_t cells; "f16": SDF_h cells (config C5: 2048^3 over 8 GPUs = 4 GiB per rank)
@@ -265,9 +270,29 @@ class SlabPipeline(FramePipeline):
         if self.raycast_mode == "exact":
             self.raycast_exact(T_wc, d, n, i, K)
             return
+        self.wait_composite()   # the previous frame's merge still reads these images
         self.ops.RaycastSdf(d, n, i, self.vol, T_wc, K, self.near, self.far, self.trunc, True)
         if self.world > 1:
-            self.composite(d, n, i)
+            if self.overlap and hasattr(self.ops, "CompositePack"):
+                import torch
+                if self._side is None:
+                    self._side = torch.cuda.Stream()
+                marched = torch.cuda.Event()
+                marched.record()
+                with torch.cuda.stream(self._side):
+                    self._side.wait_event(marched)
+                    self.composite(d, n, i)
+                    self._merged = torch.cuda.Event()
+                    self._merged.record(self._side)
+            else:
+                self.composite(d, n, i)
+
+    def wait_composite(self):
+        """Make the current stream wait for an overlapped merge (no-op otherwise)."""
+        if self._merged is not None:
+            import torch
+            torch.cuda.current_stream().wait_event(self._merged)
+            self._merged = None
 
     def raycast_levels_into(self, outputs, K_levels, T_wc):
         """Several renderings of the model from one pose (the tracking loop's pyramid levels): outputs = [(d, n, i), ...].

@@ -60,6 +60,23 @@ def test_gpu_bench_spawns_its_own_ranks():
     assert out.returncode == 0 and len(lines) == 1, out.stdout[-2000:] + out.stderr[-3000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["ranks_agree"] is True
+    v = d["multi_gpu_variants"]   # the other ghost-plane policy and the overlapped merge, timed in the same run
+    assert v["as_configured_fps"] > 0 and v["halo_exchange_fps"] > 0 and v["overlap_on_fps"] > 0
+
+
+def test_gpu_bench_overlapped_merge_two_ranks():
+    """--overlap: frame k's composite runs on a second stream under frame k+1's SdfFuse; ranks still agree on the images."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["KFX_BENCH_BACKEND"] = "gloo"
+    cmd = [sys.executable, os.path.join(T.ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--res", "128", "--no-cpu-baseline",
+           "--overlap", "--halo", "exchange"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=T.ROOT, env=env)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert out.returncode == 0 and len(lines) == 1, out.stdout[-2000:] + out.stderr[-3000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["ranks_agree"] is True and "overlapped" in d["config"]["partition"]
+    assert d["multi_gpu_variants"]["halo_recompute_fps"] > 0 and d["multi_gpu_variants"]["overlap_off_fps"] > 0
 
 
 def test_gpu_bench_refuses_more_ranks_than_gpus():
