@@ -52,6 +52,10 @@ def parse():
                          "exchanged with the neighbours over RCCL point-to-point after each SdfFuse")
     ap.add_argument("--overlap", action="store_true",
                     help="N > 1, composite raycast: merge frame k's images on a second stream under frame k+1's preprocess + SdfFuse")
+    ap.add_argument("--summary", action="store_true",
+                    help="fast math, 1 GPU: time the headline with the brick summary (kfx_sdf_summary: SdfFuse keeps value ranges per "
+                         "8^3 cells, RaycastSdf steps through uniformly free space without reading the volume).  Off by default: "
+                         "the tracking costs SdfFuse ~5 %; the default run reports the variant beside the headline instead")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=30, help="upper bound on the timed CPU-baseline frames (the sample also stops after ~12 s)")
     return ap.parse_args()
@@ -177,7 +181,11 @@ def main():
         pipe = SlabPipeline(roo, dist, (N, N, N), bmin, bmax, w, h, halo=args.halo, raycast=args.raycast, K=K, near=near, far=far,
                             overlap=args.overlap)
     else:
-        pipe = FramePipeline(roo, (N, N, N), bmin, bmax, w, h, K=K, near=near, far=far)
+        # fast numerics: SdfFuse keeps a brick summary of the volume as a by-product and RaycastSdf takes its steps through
+        # uniformly free / never-observed regions from it (same volume bits; depth within the fast-mode tolerance of the plain
+        # march, tests/test_gpu_summary.py).  Exact numerics gain nothing from it (averaged +trunc values are not bit-uniform).
+        use_summary = args.math == "fast" and args.summary
+        pipe = FramePipeline(roo, (N, N, N), bmin, bmax, w, h, K=K, near=near, far=far, track=use_summary)
 
     # synthetic depth stream, uploaded once: the timed region starts with inputs resident in HBM
     poses = [scenes.orbit_pose(i, N_ORBIT) for i in range(N_ORBIT)]
@@ -247,6 +255,9 @@ def main():
     # the other numerics mode, same frames, SdfFuse only (reported beside the headline; not part of `value`)
     other = "exact" if args.math == "fast" else "fast"
     roo.set_math_mode(other)
+    if getattr(pipe, "track", False):   # the other mode is timed on the plain kernels; the summary no longer describes the volume
+        pipe.track = False
+        pipe.summary.invalidate()
     n_other = min(args.steps, N_ORBIT)   # one full orbit: launch times depend on the pose
     ev2 = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_other)]
     for s in range(3):   # untimed: the first launches after the mode switch run on cold instruction caches
@@ -299,6 +310,37 @@ def main():
             variants["overlap_%s_fps" % ("on" if pipe.overlap else "off")] = timed_fps(n_var)
             pipe.wait_composite()
             pipe.overlap = base_overlap
+
+    # 1 GPU, fast numerics: the same frames with the brick summary switched on (tracked SdfFuse + RaycastSdf that steps through
+    # uniform regions without reading the volume), reported beside the headline (not part of `value`)
+    summary_variant = None
+    if not distributed and args.math == "fast" and not use_summary and hasattr(roo, "SdfSummary"):
+        pipe.track = True
+        pipe.reset()                      # SdfReset of volume and summary together
+        n_sv = min(args.steps, 2 * N_ORBIT)
+        for s in range(min(args.warmup, N_ORBIT) + 5):
+            i = s % N_ORBIT
+            pipe.step(poses[i], frames[i])
+        ev3 = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(n_sv)]
+        sync_all()
+        t_sv = time.perf_counter()
+        for s in range(n_sv):
+            i = (args.warmup + s) % N_ORBIT
+            pipe.preprocess(frames[i])
+            ev3[s][0].record()
+            pipe.fuse(poses[i])
+            ev3[s][1].record()
+            ev3[s][2].record()
+            pipe.raycast(poses[i])
+            ev3[s][3].record()
+        sync_all()
+        dt_sv = time.perf_counter() - t_sv
+        summary_variant = {"frames_per_sec": round(n_sv / dt_sv, 1), "steps": n_sv,
+                           "sdf_fuse_tracked_ms": round(float(np.mean([e[0].elapsed_time(e[1]) for e in ev3])), 5),
+                           "raycast_sdf_tracked_ms": round(float(np.mean([e[2].elapsed_time(e[3]) for e in ev3])), 5),
+                           "note": "kfx_sdf_fuse_tracked + kfx_raycast_sdf_tracked on a freshly reset volume, same frames (bench.py --summary makes it the headline)"}
+        pipe.track = False
+        pipe.summary.invalidate()
 
     # measured device-to-device copy ceiling of this GPU, same run: a 1 GiB copy moves 2 GiB
     copy_GBps = None
@@ -356,6 +398,8 @@ def main():
                 "volume": [N, N, N], "image": [w, h], "scene": scene,
                 "backend": os.environ.get("KFX_BENCH_BACKEND", "nccl (RCCL)") if distributed else None,
                 "ranks_agree": ranks_agree,
+                "raycast": ("brick summary: steps through uniform regions taken without reading the volume (kfx_raycast_sdf_tracked)"
+                            if (not distributed and use_summary) else "plain march (kfx_raycast_sdf)"),
                 "partition": ("z-slabs x%d, ghost planes %s%s, raycast %s" % (n_gpus, args.halo, ", merge overlapped with the next frame" if args.overlap else "", "composite = all_reduce(MIN key) + all_reduce(SUM payload)" if args.raycast == "composite" else "exact = march state handed from slab to slab, one SUM all_reduce per round"))
                              if distributed else "single volume",
                 "math": {"fast": "fast (fp32 rcp/rsq + FMA: the reference's own -use_fast_math regime; TSDF within 1e-4 of the exact path, "
@@ -389,6 +433,8 @@ def main():
                                       "note": "same frames, whole step (preprocess + fuse + raycast), %d steps" % n_other}
         if variants is not None:
             out["multi_gpu_variants"] = variants
+        if summary_variant is not None:
+            out["brick_summary_variant"] = summary_variant
         if not args.no_cpu_baseline and n_gpus == 1:
             try:
                 out["cpu_baseline"] = cpu_baseline(args, scene, args.cpu_frames)

@@ -365,6 +365,30 @@ int kfx_raycast_sdf_slab_h(float* state, int init, const kfx_volume* vol, const 
 int kfx_raycast_state_to_images(const kfx_image* depth, const kfx_image* norm, const kfx_image* img, const float* state,
                                 kfx_stream stream);
 
+/* ---- brick summary: RaycastSdf without touching uniformly free or never-observed space (addition) ---------------
+ * The reference's march (cu_raycast.cu:58-81) reads eight cells at every step, ~100 dependent HBM misses per ray, most
+ * of them in space the TSDF knows to be empty.  A kfx_sdf_summary keeps, per 8 x 8 x 8 cells, the range of the stored
+ * values; the tracked SdfFuse maintains it as a by-product (one workgroup owns a summary brick: wave shuffles + LDS, no
+ * atomics) and the tracked RaycastSdf takes its steps from it wherever a brick and its +1 neighbours hold one value:
+ *   exact numerics: only where the cells are bit-identical (or all NaN) -- the images equal kfx_raycast_sdf bit for bit;
+ *   fast numerics:  also where they agree to a relative 1e-5 (observed free space: the running average of +trunc drifts
+ *                   by a few ulp per frame) -- depth within the fast-mode tolerance of the exact march.
+ * The summary describes the volume it was created for; views of that volume (SubBoundingVolume) may be passed to the
+ * tracked calls.  Anything else that writes the volume (copies, kfx_sdf_sphere, untracked kfx_sdf_fuse) must be followed
+ * by kfx_sdf_summary_invalidate.  A tracked SdfFuse whose view does not start on multiples of 8 cells, or that takes the
+ * untiled kernel, invalidates the summary itself (correct, no skipping until the next reset). */
+typedef struct kfx_sdf_summary kfx_sdf_summary;
+int kfx_sdf_summary_create(kfx_sdf_summary** out, const kfx_volume* vol);
+int kfx_sdf_summary_destroy(kfx_sdf_summary* s);
+int kfx_sdf_summary_invalidate(kfx_sdf_summary* s, kfx_stream stream);
+int kfx_sdf_reset_tracked(const kfx_volume* vol, kfx_sdf_summary* s, float trunc_dist, kfx_stream stream);
+int kfx_sdf_fuse_tracked(const kfx_volume* vol, kfx_sdf_summary* s, const kfx_image* depth, const kfx_image* norm,
+                         const float T_cw[12], const float K[4], float trunc_dist, float max_w, float mincostheta,
+                         unsigned flags, kfx_stream stream);
+int kfx_raycast_sdf_tracked(const kfx_image* depth, const kfx_image* norm, const kfx_image* img, const kfx_volume* vol,
+                            kfx_sdf_summary* s, const float T_wc[12], const float K[4], float near, float far,
+                            float trunc_dist, int subpix, kfx_stream stream);
+
 /* ---- numerics mode --------------------------------------------------------------- */
 /* KFX_MATH_EXACT (default): IEEE fp32, no FMA contraction, correctly rounded div/sqrt, reference
  * operation order -- bit-identical to the CPU oracle.  KFX_MATH_FAST: hardware rcp/rsq (1 ulp),

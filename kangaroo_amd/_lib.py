@@ -116,6 +116,12 @@ SIGNATURES = {
     "kfx_version": (C.c_int, []),
     "kfx_device_count": (C.c_int, []),
     "kfx_set_device": (C.c_int, [C.c_int]),
+    "kfx_sdf_summary_create": (C.c_int, [C.POINTER(C.c_void_p), PV]),
+    "kfx_sdf_summary_destroy": (C.c_int, [C.c_void_p]),
+    "kfx_sdf_summary_invalidate": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "kfx_sdf_reset_tracked": (C.c_int, [PV, C.c_void_p, C.c_float, C.c_void_p]),
+    "kfx_sdf_fuse_tracked": (C.c_int, [PV, C.c_void_p, PI, PI, PF, PF, C.c_float, C.c_float, C.c_float, C.c_uint, C.c_void_p]),
+    "kfx_raycast_sdf_tracked": (C.c_int, [PI, PI, PI, PV, C.c_void_p, PF, PF, C.c_float, C.c_float, C.c_float, C.c_int, C.c_void_p]),
 }
 
 _lib = None

@@ -47,6 +47,13 @@ struct FuseParams {
     float trunc, max_w, mincos;
     unsigned dpitch, npitch; // image pitches as 32-bit values (valid when `small_images`)
     int exact_shared;        // exact mode: camera / thresholds allow the shared-reciprocal arithmetic (see finish_shared)
+    // brick summary maintained by the TRACK kernels (kfx_sdf_summary, summary.hip): one float4 {lo, hi, state, -} per
+    // 8 x 8 x 8 cells of the PARENT volume; (sum_bx0, sum_by0, sum_bz0) = brick index of this view's first cell
+    float4* sum_R;
+    int sum_nbx, sum_nby;
+    int sum_bx0, sum_by0, sum_bz0;
+    int sum_w, sum_h, sum_d; // parent volume dimensions in cells
+    int zoff_local;          // first plane of this launch within the view (fuse_launch splits the view into z-ranges)
 };
 
 struct Obs {
@@ -375,11 +382,21 @@ __global__ __launch_bounds__(256) void k_sdf_fuse(const FuseParams p)
 // than ~1.3 pixels -- the rectangle narrows with the brick (its width is about r (BX + 0.56 BZ), its height r (BY + 0.42 BZ)
 // texels for r pixels per voxel), so it keeps fitting a tile that leaves 3-6 workgroups on a CU where the wide brick would
 // need 48 KiB or fall back to global gathers.
-template <bool FAST, int ZU, typename CELL, int LX = 32, int WY = 4, int ZC = FUSE_ZC>
+// TRACK: besides the update, the kernel keeps the brick summary of the volume current (include/kfx.h, kfx_sdf_summary):
+// per 8 x 8 x 8 cells the range of the values written this frame and their number, folded into the stored range by the one
+// workgroup that owns the summary brick (64 x 8 x 16 and 32 x 8 x 16 voxel bricks are unions of whole summary bricks, so
+// no atomics: wave64 shuffles reduce a wave's lanes, LDS the workgroup's waves).  RaycastSdf uses it to step through
+// uniformly free or never-observed space without touching the volume (raycast.hip).
+template <bool FAST, int ZU, typename CELL, int LX = 32, int WY = 4, int ZC = FUSE_ZC, bool TRACK = false>
 __global__ __launch_bounds__(256) void k_sdf_fuse_tiled(const FuseParams p, const int cap_px)
 {
     constexpr int RW = 64 / LX, WZ = 4 / WY, ZW = ZC / WZ, BY = RW * WY;
     static_assert(LX * RW == 64 && WY * WZ == 4 && ZW * WZ == ZC && ZW % ZU == 0, "brick geometry");
+    constexpr int NG = ZW / 8, NXB = LX / 4, NZB = ZC / 8; // summary bricks: z-groups per wave, per workgroup along x and z
+    static_assert(!TRACK || (BY == 8 && ZW % 8 == 0 && NG <= 2), "summary bricks are 8 x 8 x 8");
+    __shared__ float s_part[TRACK ? 4 * 2 * 8 * 3 : 1];
+    float t_mn0 = __builtin_inff(), t_mx0 = -__builtin_inff(), t_mn1 = __builtin_inff(), t_mx1 = -__builtin_inff();
+    int t_cnt0 = 0, t_cnt1 = 0;
     extern __shared__ __attribute__((aligned(16))) float4 s_tile[];
     __shared__ float s_pz[ZC];
     __shared__ float s_box[4][6];
@@ -489,169 +506,232 @@ __global__ __launch_bounds__(256) void k_sdf_fuse_tiled(const FuseParams p, cons
         const float bound = -(p.trunc / p.mincos) * 1.001f;
         if (dmax + fabsf(dmax) * 1e-5f - zmin < bound) return; // also when every texel is NaN (dmax = -inf)
     }
-    if (!live) return;
-
-    // one voxel's observation, corners from the LDS tile when the cell lies inside it
-    auto observe_tile = [&](int v, float pz) -> Obs {
-        Obs o;
-        o.ok = false;
-        o.val = 0.f;
-        o.w = 0.f;
-        const V3 Pc = cam[v].at(p, pz);
-        float pu, pv, iz;
-        project<FAST>(p, Pc, pu, pv, iz);
-        if (in_bounds(p, pu, pv)) {
-            const float fix = floorf(pu), fiy = floorf(pv);
-            const int ix = (int)fix, iy = (int)fiy;
-            const unsigned rx = (unsigned)(ix - tx0), ry = (unsigned)(iy - ty0);
-            Corners c;
-            if (use_tile && rx < (unsigned)(tw - 1) && ry < (unsigned)(th - 1)) {
-                const float4* t = s_tile + (ry * (unsigned)tw + rx);
-                c.c00 = t[0]; c.c01 = t[1]; c.c10 = t[tw]; c.c11 = t[tw + 1];
-            } else {
-                c = fetch_global32(p, ix, iy);
-            }
-            o = finish<FAST>(p, Pc, iz, pu - fix, pv - fiy, c);
+    // values written this frame, per 8-slice group of this wave (TRACK)
+    auto note = [&](int z, const float4& c, bool ok0, bool ok1) {
+        if constexpr (TRACK) {
+            const float lo = fminf(ok0 ? c.x : __builtin_inff(), ok1 ? c.z : __builtin_inff());
+            const float hi = fmaxf(ok0 ? c.x : -__builtin_inff(), ok1 ? c.z : -__builtin_inff());
+            const int n = (int)ok0 + (int)ok1;
+            if (NG == 1 || z - wz0 < 8) { t_mn0 = fminf(t_mn0, lo); t_mx0 = fmaxf(t_mx0, hi); t_cnt0 += n; }
+            else { t_mn1 = fminf(t_mn1, lo); t_mx1 = fmaxf(t_mx1, hi); t_cnt1 += n; }
         }
-        return o;
     };
+    auto march = [&]() {
+        if (!live) return;
 
-    // ZU slices per iteration: their volume cells are requested together, so a wave keeps ZU
-    // 16-byte reads per lane in flight
-    unsigned char* cell = p.vptr + (size_t)wz0 * p.vimg_pitch + (size_t)y * p.vpitch + (size_t)x0 * CELL::BYTES;
-
-    // Tiled bricks run branch-free: tile indices are clamped into the staged rectangle (always a valid LDS
-    // address), every lane evaluates the observation, and the bounds / predicate results only gate the
-    // update.  (Fast mode is co-limited by VALU issue and HBM -- about 75 VALU ops per voxel against 16 B --
-    // and divergent early-outs cost more issue slots than they save.)  A sample that is in bounds but outside
-    // the rectangle -- impossible with the one-texel slack, kept as a guard -- sends the wave through the
-    // generic per-lane path for that iteration.  Values are the same expressions as the generic path.
-    if constexpr (!FAST) {
-        // Exact numerics, cheaper instruction sequences (finish_shared): taken when every voxel of the brick keeps the
-        // operands of div_core / sqrt_core inside the range where they are the IEEE results (NaN bounds fail the test).
-        if (use_tile && p.exact_shared && zmin >= 0x1p-20f && cmax <= 0x1p20f) {
-            const int cxmax = tw - 2, cymax = th - 2;
-            // both voxels of the lane in slice z; `any` = the lane has a cell pair to update
-            auto observe_pair = [&](int z, Obs (&o)[2]) -> bool {
-                const float4 tz = s_tz[z - zbeg];
-                bool stray = false;
-#pragma unroll
-                for (int v = 0; v < 2; ++v) {
-                    // cam[v].at(p, pz): the products T(i,2)*pz are uniform per slice and come from LDS
-                    const V3 Pc = v3(cam[v].ax + tz.y + p.T.m[3], cam[v].ay + tz.z + p.T.m[7], cam[v].az + tz.w + p.T.m[11]);
-                    const float yz = rcp_nr(Pc.z);
-                    const float pu = p.K.u0 + div_core(p.K.fu * Pc.x, Pc.z, yz);
-                    const float pv = p.K.v0 + div_core(p.K.fv * Pc.y, Pc.z, yz);
-                    const bool inb = in_bounds(p, pu, pv);
-                    const float fix = floorf(pu), fiy = floorf(pv);
-                    const int rx = (int)fix - tx0, ry = (int)fiy - ty0;
-                    const bool inside = (unsigned)rx <= (unsigned)cxmax && (unsigned)ry <= (unsigned)cymax;
-                    const float4* t = s_tile + (med3_i32(ry, 0, cymax) * tw + med3_i32(rx, 0, cxmax));
-                    Corners c;
+        // one voxel's observation, corners from the LDS tile when the cell lies inside it
+        auto observe_tile = [&](int v, float pz) -> Obs {
+            Obs o;
+            o.ok = false;
+            o.val = 0.f;
+            o.w = 0.f;
+            const V3 Pc = cam[v].at(p, pz);
+            float pu, pv, iz;
+            project<FAST>(p, Pc, pu, pv, iz);
+            if (in_bounds(p, pu, pv)) {
+                const float fix = floorf(pu), fiy = floorf(pv);
+                const int ix = (int)fix, iy = (int)fiy;
+                const unsigned rx = (unsigned)(ix - tx0), ry = (unsigned)(iy - ty0);
+                Corners c;
+                if (use_tile && rx < (unsigned)(tw - 1) && ry < (unsigned)(th - 1)) {
+                    const float4* t = s_tile + (ry * (unsigned)tw + rx);
                     c.c00 = t[0]; c.c01 = t[1]; c.c10 = t[tw]; c.c11 = t[tw + 1];
-                    o[v] = finish_shared(p, Pc, yz, pu - fix, pv - fiy, c);
-                    o[v].ok = ((int)o[v].ok & (int)inb & (int)inside) != 0;
-                    stray |= ((int)inb & (int)!inside) != 0;
+                } else {
+                    c = fetch_global32(p, ix, iy);
                 }
-                if (__builtin_expect(__ballot(stray) != 0ull, 0)) {
-                    o[0] = observe<false, true>(p, cam[0].at(p, tz.x));
-                    o[1] = observe<false, true>(p, cam[1].at(p, tz.x));
-                }
-                return ((int)o[0].ok | (int)o[1].ok) != 0;
-            };
-            // (requesting the cells of slice z and consuming them after the observation of slice z + 1 -- a software
-            // pipeline -- was measured and changes nothing: 0.54 ms either way, the loop is bound by instruction issue)
-            for (int z = wz0; z < wz1; ++z, cell += p.vimg_pitch) {
-                Obs o[2];
-                if (observe_pair(z, o)) {
-                    float4 c = CELL::ld2(cell);
-                    if (o[0].ok) accumulate<false, CELL>(o[0], p.max_w, c.x, c.y);
-                    if (o[1].ok) accumulate<false, CELL>(o[1], p.max_w, c.z, c.w);
-                    CELL::st2(cell, c);
-                }
+                o = finish<FAST>(p, Pc, iz, pu - fix, pv - fiy, c);
             }
-            return;
-        }
-    }
-    if (use_tile) {
-        const int cxmax = tw - 2, cymax = th - 2;
-        for (int z = wz0; z < wz1; z += ZU, cell += (size_t)ZU * p.vimg_pitch) {
-            Obs o[ZU][2];
-            bool any[ZU];
-            bool stray = false;
-#pragma unroll
-            for (int k = 0; k < ZU; ++k) {
-                any[k] = false;
-                if (z + k < wz1) { // uniform
-                    const float pz = s_pz[z + k - zbeg];
-#pragma unroll
+            return o;
+        };
+
+        // ZU slices per iteration: their volume cells are requested together, so a wave keeps ZU
+        // 16-byte reads per lane in flight
+        unsigned char* cell = p.vptr + (size_t)wz0 * p.vimg_pitch + (size_t)y * p.vpitch + (size_t)x0 * CELL::BYTES;
+
+        // Tiled bricks run branch-free: tile indices are clamped into the staged rectangle (always a valid LDS
+        // address), every lane evaluates the observation, and the bounds / predicate results only gate the
+        // update.  (Fast mode is co-limited by VALU issue and HBM -- about 75 VALU ops per voxel against 16 B --
+        // and divergent early-outs cost more issue slots than they save.)  A sample that is in bounds but outside
+        // the rectangle -- impossible with the one-texel slack, kept as a guard -- sends the wave through the
+        // generic per-lane path for that iteration.  Values are the same expressions as the generic path.
+        if constexpr (!FAST) {
+            // Exact numerics, cheaper instruction sequences (finish_shared): taken when every voxel of the brick keeps the
+            // operands of div_core / sqrt_core inside the range where they are the IEEE results (NaN bounds fail the test).
+            if (use_tile && p.exact_shared && zmin >= 0x1p-20f && cmax <= 0x1p20f) {
+                const int cxmax = tw - 2, cymax = th - 2;
+                // both voxels of the lane in slice z; `any` = the lane has a cell pair to update
+                auto observe_pair = [&](int z, Obs (&o)[2]) -> bool {
+                    const float4 tz = s_tz[z - zbeg];
+                    bool stray = false;
+    #pragma unroll
                     for (int v = 0; v < 2; ++v) {
-                        const V3 Pc = cam[v].at(p, pz);
-                        float pu, pv, iz;
-                        project<FAST>(p, Pc, pu, pv, iz);
+                        // cam[v].at(p, pz): the products T(i,2)*pz are uniform per slice and come from LDS
+                        const V3 Pc = v3(cam[v].ax + tz.y + p.T.m[3], cam[v].ay + tz.z + p.T.m[7], cam[v].az + tz.w + p.T.m[11]);
+                        const float yz = rcp_nr(Pc.z);
+                        const float pu = p.K.u0 + div_core(p.K.fu * Pc.x, Pc.z, yz);
+                        const float pv = p.K.v0 + div_core(p.K.fv * Pc.y, Pc.z, yz);
                         const bool inb = in_bounds(p, pu, pv);
                         const float fix = floorf(pu), fiy = floorf(pv);
                         const int rx = (int)fix - tx0, ry = (int)fiy - ty0;
                         const bool inside = (unsigned)rx <= (unsigned)cxmax && (unsigned)ry <= (unsigned)cymax;
-                        const int cx = min(max(rx, 0), cxmax), cy = min(max(ry, 0), cymax);
-                        const float4* t = s_tile + (cy * tw + cx);
+                        const float4* t = s_tile + (med3_i32(ry, 0, cymax) * tw + med3_i32(rx, 0, cxmax));
                         Corners c;
                         c.c00 = t[0]; c.c01 = t[1]; c.c10 = t[tw]; c.c11 = t[tw + 1];
-                        o[k][v] = finish<FAST>(p, Pc, iz, pu - fix, pv - fiy, c);
-                        o[k][v].ok = ((int)o[k][v].ok & (int)inb & (int)inside) != 0;
+                        o[v] = finish_shared(p, Pc, yz, pu - fix, pv - fiy, c);
+                        o[v].ok = ((int)o[v].ok & (int)inb & (int)inside) != 0;
                         stray |= ((int)inb & (int)!inside) != 0;
                     }
-                    any[k] = ((int)o[k][0].ok | (int)o[k][1].ok) != 0;
+                    if (__builtin_expect(__ballot(stray) != 0ull, 0)) {
+                        o[0] = observe<false, true>(p, cam[0].at(p, tz.x));
+                        o[1] = observe<false, true>(p, cam[1].at(p, tz.x));
+                    }
+                    return ((int)o[0].ok | (int)o[1].ok) != 0;
+                };
+                // (requesting the cells of slice z and consuming them after the observation of slice z + 1 -- a software
+                // pipeline -- was measured and changes nothing: 0.54 ms either way, the loop is bound by instruction issue)
+                for (int z = wz0; z < wz1; ++z, cell += p.vimg_pitch) {
+                    Obs o[2];
+                    if (observe_pair(z, o)) {
+                        float4 c = CELL::ld2(cell);
+                        if (o[0].ok) accumulate<false, CELL>(o[0], p.max_w, c.x, c.y);
+                        if (o[1].ok) accumulate<false, CELL>(o[1], p.max_w, c.z, c.w);
+                        CELL::st2(cell, c);
+                        note(z, c, o[0].ok, o[1].ok);
+                    }
                 }
+                return;
             }
-            if (__builtin_expect(__ballot(stray) != 0ull, 0)) {
-#pragma unroll
-                for (int k = 0; k < ZU; ++k)
-                    if (z + k < wz1) {
+        }
+        if (use_tile) {
+            const int cxmax = tw - 2, cymax = th - 2;
+            for (int z = wz0; z < wz1; z += ZU, cell += (size_t)ZU * p.vimg_pitch) {
+                Obs o[ZU][2];
+                bool any[ZU];
+                bool stray = false;
+    #pragma unroll
+                for (int k = 0; k < ZU; ++k) {
+                    any[k] = false;
+                    if (z + k < wz1) { // uniform
                         const float pz = s_pz[z + k - zbeg];
-                        o[k][0] = observe<FAST, true>(p, cam[0].at(p, pz));
-                        o[k][1] = observe<FAST, true>(p, cam[1].at(p, pz));
-                        any[k] = o[k][0].ok || o[k][1].ok;
+    #pragma unroll
+                        for (int v = 0; v < 2; ++v) {
+                            const V3 Pc = cam[v].at(p, pz);
+                            float pu, pv, iz;
+                            project<FAST>(p, Pc, pu, pv, iz);
+                            const bool inb = in_bounds(p, pu, pv);
+                            const float fix = floorf(pu), fiy = floorf(pv);
+                            const int rx = (int)fix - tx0, ry = (int)fiy - ty0;
+                            const bool inside = (unsigned)rx <= (unsigned)cxmax && (unsigned)ry <= (unsigned)cymax;
+                            const int cx = min(max(rx, 0), cxmax), cy = min(max(ry, 0), cymax);
+                            const float4* t = s_tile + (cy * tw + cx);
+                            Corners c;
+                            c.c00 = t[0]; c.c01 = t[1]; c.c10 = t[tw]; c.c11 = t[tw + 1];
+                            o[k][v] = finish<FAST>(p, Pc, iz, pu - fix, pv - fiy, c);
+                            o[k][v].ok = ((int)o[k][v].ok & (int)inb & (int)inside) != 0;
+                            stray |= ((int)inb & (int)!inside) != 0;
+                        }
+                        any[k] = ((int)o[k][0].ok | (int)o[k][1].ok) != 0;
+                    }
+                }
+                if (__builtin_expect(__ballot(stray) != 0ull, 0)) {
+    #pragma unroll
+                    for (int k = 0; k < ZU; ++k)
+                        if (z + k < wz1) {
+                            const float pz = s_pz[z + k - zbeg];
+                            o[k][0] = observe<FAST, true>(p, cam[0].at(p, pz));
+                            o[k][1] = observe<FAST, true>(p, cam[1].at(p, pz));
+                            any[k] = o[k][0].ok || o[k][1].ok;
+                        }
+                }
+                float4 c[ZU];
+    #pragma unroll
+                for (int k = 0; k < ZU; ++k)
+                    if (any[k]) c[k] = CELL::ld2(cell + (size_t)k * p.vimg_pitch);
+    #pragma unroll
+                for (int k = 0; k < ZU; ++k)
+                    if (any[k]) {
+                        if (o[k][0].ok) accumulate<FAST, CELL>(o[k][0], p.max_w, c[k].x, c[k].y);
+                        if (o[k][1].ok) accumulate<FAST, CELL>(o[k][1], p.max_w, c[k].z, c[k].w);
+                        CELL::st2(cell + (size_t)k * p.vimg_pitch, c[k]);
+                        note(z + k, c[k], o[k][0].ok, o[k][1].ok);
                     }
             }
+            return;
+        }
+        for (int z = wz0; z < wz1; z += ZU, cell += (size_t)ZU * p.vimg_pitch) {
+            Obs o[ZU][2];
+            bool any[ZU];
+    #pragma unroll
+            for (int k = 0; k < ZU; ++k) {
+                any[k] = false;
+                if (z + k < wz1) {
+                    const float pz = s_pz[z + k - zbeg];
+                    o[k][0] = observe_tile(0, pz);
+                    o[k][1] = observe_tile(1, pz);
+                    any[k] = o[k][0].ok || o[k][1].ok;
+                }
+            }
             float4 c[ZU];
-#pragma unroll
+    #pragma unroll
             for (int k = 0; k < ZU; ++k)
                 if (any[k]) c[k] = CELL::ld2(cell + (size_t)k * p.vimg_pitch);
-#pragma unroll
+    #pragma unroll
             for (int k = 0; k < ZU; ++k)
                 if (any[k]) {
                     if (o[k][0].ok) accumulate<FAST, CELL>(o[k][0], p.max_w, c[k].x, c[k].y);
                     if (o[k][1].ok) accumulate<FAST, CELL>(o[k][1], p.max_w, c[k].z, c[k].w);
                     CELL::st2(cell + (size_t)k * p.vimg_pitch, c[k]);
+                    note(z + k, c[k], o[k][0].ok, o[k][1].ok);
                 }
         }
-        return;
-    }
-    for (int z = wz0; z < wz1; z += ZU, cell += (size_t)ZU * p.vimg_pitch) {
-        Obs o[ZU][2];
-        bool any[ZU];
+    };
+    march();
+
+    if constexpr (TRACK) {
+        // ---- summary epilogue: every thread of the workgroup arrives here (the early exits above are workgroup-uniform
+        // and leave the summary as it is: nothing was written) ----
 #pragma unroll
-        for (int k = 0; k < ZU; ++k) {
-            any[k] = false;
-            if (z + k < wz1) {
-                const float pz = s_pz[z + k - zbeg];
-                o[k][0] = observe_tile(0, pz);
-                o[k][1] = observe_tile(1, pz);
-                any[k] = o[k][0].ok || o[k][1].ok;
+        for (int g = 0; g < NG; ++g) {
+            float mn = g ? t_mn1 : t_mn0, mx = g ? t_mx1 : t_mx0;
+            int cnt = g ? t_cnt1 : t_cnt0;
+            // lanes of one summary brick: 4 neighbours in x (8 cells) and all rows of the wave
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                if (off == 4) off = LX; // skip the lane bits that select the x-brick
+                mn = fminf(mn, __shfl_xor(mn, off, 64));
+                mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+                cnt += __shfl_xor(cnt, off, 64);
+            }
+            if ((lane & 3) == 0 && lane < LX) {
+                float* q = s_part + ((wv * 2 + g) * 8 + (lane >> 2)) * 3;
+                q[0] = mn; q[1] = mx; q[2] = __int_as_float(cnt);
             }
         }
-        float4 c[ZU];
+        __syncthreads();
+        if (tid < NXB * NZB) {
+            const int xb = tid % NXB, zb = tid / NXB;
+            float mn = __builtin_inff(), mx = -__builtin_inff();
+            int cnt = 0;
 #pragma unroll
-        for (int k = 0; k < ZU; ++k)
-            if (any[k]) c[k] = CELL::ld2(cell + (size_t)k * p.vimg_pitch);
-#pragma unroll
-        for (int k = 0; k < ZU; ++k)
-            if (any[k]) {
-                if (o[k][0].ok) accumulate<FAST, CELL>(o[k][0], p.max_w, c[k].x, c[k].y);
-                if (o[k][1].ok) accumulate<FAST, CELL>(o[k][1], p.max_w, c[k].z, c[k].w);
-                CELL::st2(cell + (size_t)k * p.vimg_pitch, c[k]);
+            for (int w4 = 0; w4 < 4; ++w4) { // the waves whose slices include summary z-brick zb
+                const int g = zb - (w4 / WY) * NG;
+                if (g >= 0 && g < NG) {
+                    const float* q = s_part + ((w4 * 2 + g) * 8 + xb) * 3;
+                    mn = fminf(mn, q[0]); mx = fmaxf(mx, q[1]); cnt += __float_as_int(q[2]);
+                }
             }
+            const int bx = p.sum_bx0 + blockIdx.x * NXB + xb, by = p.sum_by0 + blockIdx.y, bz = p.sum_bz0 + (zbeg + p.zoff_local) / 8 + zb;
+            if (cnt > 0 && bx * 8 < p.sum_w && by * 8 < p.sum_h && bz * 8 < p.sum_d) {
+                const int total = min(8, p.sum_w - bx * 8) * min(8, p.sum_h - by * 8) * min(8, p.sum_d - bz * 8);
+                float4* r = p.sum_R + ((size_t)bz * p.sum_nby + by) * p.sum_nbx + bx;
+                float4 old = *r;
+                const int st = __float_as_int(old.z); // 0: every cell has a value in [lo, hi]; 1: every cell NaN; 2: mixed / unknown
+                if (cnt == total) old = make_float4(mn, mx, __int_as_float(0), 0.f);
+                else if (st == 1) old = make_float4(mn, mx, __int_as_float(2), 0.f);
+                else old = make_float4(fminf(old.x, mn), fmaxf(old.y, mx), old.z, 0.f);
+                *r = old;
+            }
+        }
     }
 }
 
@@ -1165,6 +1245,8 @@ static int fuse_params(FuseParams& p, bool* small_images, const kfx_volume* vol,
                     depth->pitch < (1u << 24) && norm->pitch < (1u << 24) && depth->h < (1u << 24);
     p.dpitch = *small_images ? (unsigned)depth->pitch : 0u;
     p.npitch = *small_images ? (unsigned)norm->pitch : 0u;
+    p.sum_R = nullptr;
+    p.sum_nbx = p.sum_nby = p.sum_bx0 = p.sum_by0 = p.sum_bz0 = p.sum_w = p.sum_h = p.sum_d = p.zoff_local = 0;
     // launch-wide half of the operand-range test of the exact kernel's shared-reciprocal arithmetic (finish_shared);
     // KFX_FUSE_EXACT_SHARED=0 keeps hipcc's own division / square-root expansions (A/B, and the parity suite runs both)
     static const int shared_env = [] { const char* e = getenv("KFX_FUSE_EXACT_SHARED"); return e ? atoi(e) : 1; }();
@@ -1222,11 +1304,23 @@ static TilePlan tile_plan(const FuseParams& p, const Pose& T, const Intr& K, int
 template <typename CELL>
 static int fuse_launch(const kfx_volume* vol, const kfx_image* depth, const kfx_image* norm, const float T_cw[12],
                        const float K[4], float trunc_dist, float max_w, float mincostheta, unsigned flags, kfx_stream stream,
-                       const kfx_slab* slab = nullptr)
+                       const kfx_slab* slab = nullptr, kfx_sdf_summary* summary = nullptr)
 {
     FuseParams p;
     bool small_images = false;
     if (int e = fuse_params(p, &small_images, vol, depth, norm, T_cw, K, trunc_dist, max_w, mincostheta, flags, CELL::BYTES, slab)) return e;
+    p.sum_R = nullptr;
+    p.zoff_local = 0;
+    bool track = false;
+    if (summary) {
+        int ox, oy, oz;
+        if (int e = summary_view_offset(summary, vol, &ox, &oy, &oz)) return e;
+        track = (ox % 8 == 0) && (oy % 8 == 0) && (oz % 8 == 0);
+        p.sum_R = summary->R;
+        p.sum_nbx = summary->nbx; p.sum_nby = summary->nby;
+        p.sum_bx0 = ox / 8; p.sum_by0 = oy / 8; p.sum_bz0 = oz / 8;
+        p.sum_w = summary->w; p.sum_h = summary->h; p.sum_d = summary->d;
+    }
     if (p.X == 0 || p.Y == 0 || p.Z == 0) return 0; // reference launches an empty grid
     // two cells per lane need an even extent and a pointer / pitches aligned to the cell pair
     const bool vec2 = (p.X % 2 == 0) && ((((uintptr_t)vol->ptr | vol->pitch | vol->img_pitch) & (2 * CELL::BYTES - 1)) == 0);
@@ -1236,6 +1330,12 @@ static int fuse_launch(const kfx_volume* vol, const kfx_image* depth, const kfx_
     // KFX_FUSE_CAP sets the LDS tile capacity in texels (16 B each, at most 3968)
     static const int tiled = [] { const char* e = getenv("KFX_FUSE_TILED"); return e ? atoi(e) : 1; }();
     static const int cap_env = [] { const char* e = getenv("KFX_FUSE_CAP"); const int v = e ? atoi(e) : 0; return v <= 0 ? 0 : (v < 64 ? 64 : (v > 3968 ? 3968 : v)); }();  // <= 62 KiB: dynamic + static LDS stay below the 64 KiB launch limit
+    if (summary && !(track && tiled && vec2 && small_images && CELL::BYTES == 8)) {
+        // this launch cannot keep the summary current (unaligned view, untiled kernel): nothing is known afterwards
+        if (int e = kfx_sdf_summary_invalidate(summary, stream)) return e;
+        track = false;
+    }
+    if (summary) summary->dirty = 1;
     if (tiled && vec2 && small_images) {
         // slices per iteration: 2 in fast mode (memory-bound: more reads in flight), 4 where the large LDS tile leaves
         // only 3 workgroups per CU (1280x960 at 512^3: 0.568 -> 0.538 ms; at 6 workgroups per CU 4 is slower), 1 in exact
@@ -1271,8 +1371,20 @@ static int fuse_launch(const kfx_volume* vol, const kfx_image* depth, const kfx_
             FuseParams q = p;
             q.vptr = p.vptr + (size_t)z0 * p.vimg_pitch;
             q.zoff = p.zoff + z0;
+            q.zoff_local = z0;
             q.Z = z1 - z0;
             const size_t lds = (size_t)cap_px * sizeof(float4);
+            if constexpr (CELL::BYTES == 8) {
+                if (track) { // the same kernels with the summary epilogue (ZU = 2 fast, 1 exact)
+                    const dim3 gw(ceil_div(q.X, TB_X), ceil_div(q.Y, TB_Y), ceil_div(q.Z, FUSE_ZC)), gn(ceil_div(q.X, 32), ceil_div(q.Y, 8), ceil_div(q.Z, 16));
+                    if (plan.small_brick && fast) hipLaunchKernelGGL((k_sdf_fuse_tiled<true, 2, CELL, 16, 2, 16, true>), gn, dim3(256), lds, s, q, cap_px);
+                    else if (plan.small_brick) hipLaunchKernelGGL((k_sdf_fuse_tiled<false, 1, CELL, 16, 2, 16, true>), gn, dim3(256), lds, s, q, cap_px);
+                    else if (fast) hipLaunchKernelGGL((k_sdf_fuse_tiled<true, 2, CELL, 32, 4, FUSE_ZC, true>), gw, dim3(256), lds, s, q, cap_px);
+                    else hipLaunchKernelGGL((k_sdf_fuse_tiled<false, 1, CELL, 32, 4, FUSE_ZC, true>), gw, dim3(256), lds, s, q, cap_px);
+                    z0 = z1;
+                    continue;
+                }
+            }
             if (plan.small_brick) {
                 dim3 grid(ceil_div(q.X, 32), ceil_div(q.Y, 8), ceil_div(q.Z, 16));
                 const int zu = zu_env ? zu_env : (fast ? (cap_px > 2560 ? 4 : 2) : 1);
@@ -1312,6 +1424,14 @@ extern "C" int kfx_sdf_fuse(const kfx_volume* vol, const kfx_image* depth, const
                             float mincostheta, unsigned flags, kfx_stream stream)
 {
     return fuse_launch<CellF32>(vol, depth, norm, T_cw, K, trunc_dist, max_w, mincostheta, flags, stream);
+}
+
+extern "C" int kfx_sdf_fuse_tracked(const kfx_volume* vol, kfx_sdf_summary* summary, const kfx_image* depth, const kfx_image* norm,
+                                    const float T_cw[12], const float K[4], float trunc_dist, float max_w, float mincostheta,
+                                    unsigned flags, kfx_stream stream)
+{
+    if (!summary) return set_error(KFX_E_NULL, "kfx_sdf_fuse_tracked: null summary");
+    return fuse_launch<CellF32>(vol, depth, norm, T_cw, K, trunc_dist, max_w, mincostheta, flags, stream, nullptr, summary);
 }
 
 extern "C" int kfx_sdf_fuse_slab(const kfx_volume* vol, const kfx_slab* slab, const kfx_image* depth, const kfx_image* norm,

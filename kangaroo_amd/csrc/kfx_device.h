@@ -140,6 +140,44 @@ __host__ __device__ inline int ceil_div(int a, int b) { return (a + b - 1) / b; 
 
 } // namespace kfx
 
+// ---- brick summary of a TSDF volume (kfx_sdf_summary, include/kfx.h; summary.hip) -----------------------------------
+// R: one float4 {lo, hi, state, -} per 8 x 8 x 8 cells, kept current by the TRACK fuse kernels (state 0: every cell holds
+// a value in [lo, hi]; 1: every cell is NaN; 2: mixed / unknown).  D: what the ray-march reads, one float per brick, built
+// from R over the brick and its +1 neighbours (a trilinear sample based in the brick reads those cells): v > 0 = every
+// such cell equals v (exact numerics) or lies within `tol` of v (fast numerics); NaN = every cell is NaN; -2 = sample.
+// A ray crosses a brick in two or three steps, so D alone would only trade one dependent load per step for one per brick;
+// two coarser levels (32^3 and 128^3 cells) let it cross wide uniform regions with a handful of loads in total.
+struct kfx_sdf_summary {
+    float4* R;
+    float* D;                    // level 1 (8^3 cells), then level 2 (32^3) behind it
+    float *D2, *D3;              // (D3 unused: level 3 is derived in LDS by the ray-march)
+    int* useful2;                // device counters of the table build: [2] = level-2 entries a ray can cross without sampling
+    int nbx, nby, nbz;
+    int n2x, n2y, n2z, n3x, n3y, n3z;
+    int w, h, d;                 // parent volume (cells)
+    const unsigned char* base;   // parent volume storage
+    size_t pitch, img_pitch;
+    int dirty;                   // R changed since D was built
+    float built_tol;             // tolerance D was built with
+};
+namespace kfx {
+// Levels 2 and 3 summarise 4 x 4 x 4 entries of the level below: v > 0 / NaN as above when all of them agree, -1 = look
+// one level down (level 3) / some bricks below are uniform (level 2), -2 = nothing below is uniform.
+struct SummaryView {
+    const float *D, *D2, *D3;
+    int nbx, nby, n2x, n2y, n3x, n3y;
+    int n2, n3, n2z; // entries of levels 2 and 3
+    float tol;       // the tolerance level 2 was built with (level 3 is derived with the same)
+    const int* useful; // device: number of level-2 entries a ray can cross without sampling
+    int force;      // 0: decide by the counter, 1: always use the summary, -1: never (KFX_RAYCAST_SUMMARY)
+    int ox, oy, oz; // cell offset of the view inside the parent volume
+};
+// cell offset of a view of the summary's parent volume (same pitches, pointer inside the parent): 0 on success
+int summary_view_offset(const kfx_sdf_summary* s, const kfx_volume* view, int* ox, int* oy, int* oz);
+// (re)build D if R changed or the tolerance differs
+int summary_prepare(kfx_sdf_summary* s, float tol, hipStream_t stream);
+} // namespace kfx
+
 // ---- host-side launch helpers (capi.hip) --------------------------------------
 namespace kfx {
 int set_error(int code, const char* what);

@@ -62,9 +62,14 @@ __device__ __forceinline__ void ray_pixel_of(const RayParams& p, int bx, int by,
     v = (by * wgy + (wv >> p.wg_log2x)) * th + (lane >> p.tile_log2w);
 }
 
-// one ray: KernRaycastSdf (cu_raycast.cu:34-113) for pixel (u, v)
-template <typename CELL, bool COLOR>
-__device__ __forceinline__ float raycast_pixel(const RayParams& p, const ColorGeom& cv, const int u, const int v)
+// one ray: KernRaycastSdf (cu_raycast.cu:34-113) for pixel (u, v).
+// SKIP: a sample whose base cell lies in a brick the summary calls uniform (kfx_device.h, SummaryView: the brick and its
+// +1 neighbours hold one value, or only NaN) takes that value without reading the volume -- the blend of eight equal
+// cells is that cell (a + t (a - a) = a), so with the exact-numerics summary the march is the reference's, addition for
+// addition.  The brick's entry is kept in registers while consecutive samples stay in the brick.
+template <typename CELL, bool COLOR, bool SKIP = false>
+__device__ __forceinline__ float raycast_pixel(const RayParams& p, const ColorGeom& cv, const int u, const int v, const SummaryView sv = SummaryView{},
+                                               const float* lds_D3 = nullptr, const float* lds_D2 = nullptr, const bool use_summary = false)
 {
     if (u >= p.w || v >= p.h) return 0.f;
 
@@ -86,8 +91,71 @@ __device__ __forceinline__ float raycast_pixel(const RayParams& p, const ColorGe
         float last_sdf = __builtin_nanf("");
         const float min_delta = p.voxel.x;
         float delta = 0.f;
+        int cur_b2 = -1, cur_b3 = -1;       // summary entries of the current position (registers), per level
+        float cur_s2 = -1.f, cur_s3 = -1.f;
+        V3 pfA = v3(0.f, 0.f, 0.f), pfB = pfA; // SKIP: base-cell coordinate along the ray, pf(lambda) = pfA + pfB * lambda
+        if constexpr (SKIP) {
+            pfA = v3((c_w.x - p.vol.bmin.x) / p.size.x * p.dims1.x, (c_w.y - p.vol.bmin.y) / p.size.y * p.dims1.y, (c_w.z - p.vol.bmin.z) / p.size.z * p.dims1.z);
+            pfB = v3(ray_w.x / p.size.x * p.dims1.x, ray_w.y / p.size.y * p.dims1.y, ray_w.z / p.size.z * p.dims1.z);
+        }
+        bool wave_skips = SKIP && use_summary;   // this wave still consults the summary (equal in all marching lanes)
+        int n_iter = 0, n_sampled = 0;           // iterations so far (equal in all marching lanes), and those this lane sampled in
         while (lambda < min_tmax) {
-            const float sdf = trilinear<CELL>(p, c_w + ray_w * lambda);
+            float sdf;
+            if constexpr (SKIP) {
+                // A wave with rays along a border between observed and unobserved space (the frustum's sides) samples at nearly
+                // every step and would pay for both paths in every iteration: if some lane sampled in 4 of the first 8
+                // iterations, the wave gives up on the summary and marches plainly
+                if (wave_skips && n_iter == 8 && __ballot(n_sampled >= 4) != 0ull) wave_skips = false;
+                n_iter += 1;
+            }
+            if (SKIP && wave_skips) {
+                // A position whose base cell lies in a uniform (or never-observed) 32^3 / 128^3-cell region needs no memory
+                // beyond the LDS copy of the summary, and neither do the following steps up to the region's far side: the
+                // base-cell coordinate is affine in lambda (pf = A + B lambda), so the exit parameter of the region is three
+                // divisions away and the steps before it are bare additions -- the reference's own lambda += delta, one per
+                // step, so the exact march stays the reference's march.  (Re-deriving the cell at every skipped step costs as
+                // many instructions as a sample, and this kernel runs about one wave per SIMD, where an instruction issues
+                // every ~12 cycles: measured, per-step skipping gains nothing in S_room and bursts of it lose.)
+                const CellPos c = cell_of(p, c_w + ray_w * lambda);
+                const int gx = c.ix + sv.ox, gy = c.iy + sv.oy, gz = c.iz + sv.oz;
+                const int b3 = ((gz >> 7) * sv.n3y + (gy >> 7)) * sv.n3x + (gx >> 7);
+                if (b3 != cur_b3) { cur_s3 = lds_D3[b3]; cur_b3 = b3; }
+                float s = cur_s3;
+                int shift = 7;
+                if (s == -1.0f) {
+                    const int b2 = ((gz >> 5) * sv.n2y + (gy >> 5)) * sv.n2x + (gx >> 5);
+                    if (b2 != cur_b2) { cur_s2 = lds_D2[b2]; cur_b2 = b2; }
+                    s = cur_s2;
+                    shift = 5;
+                }
+                if (s > 0.f || s != s) {
+                    // the reference's step for sdf = s (s > 0: no crossing possible; NaN: step by trunc, cu_raycast.cu:77-80)
+                    delta = s > 0 ? fmaxf(s, min_delta) : p.trunc;
+                    last_sdf = s;
+                    // base cells [lo, lo + L) of the region in this view's coordinates; exit = first lambda with pf outside
+                    const float L = (float)(1 << shift);
+                    const float lox = (float)(((gx >> shift) << shift) - sv.ox), loy = (float)(((gy >> shift) << shift) - sv.oy),
+                                loz = (float)(((gz >> shift) << shift) - sv.oz);
+                    const float ex = (pfB.x > 0.f ? lox + L - pfA.x : lox - pfA.x) / pfB.x;   // +-inf / NaN when the ray is parallel
+                    const float ey = (pfB.y > 0.f ? loy + L - pfA.y : loy - pfA.y) / pfB.y;
+                    const float ez = (pfB.z > 0.f ? loz + L - pfA.z : loz - pfA.z) / pfB.z;
+                    float lam_exit = min_tmax;
+                    if (pfB.x != 0.f) lam_exit = fminf(lam_exit, ex);
+                    if (pfB.y != 0.f) lam_exit = fminf(lam_exit, ey);
+                    if (pfB.z != 0.f) lam_exit = fminf(lam_exit, ez);
+                    // steps that certainly stay inside: one fewer than fit (pfA / pfB are rounded: a step is ~3 cells, the
+                    // rounding error ~1e-4 cell); the step at the current position is always taken
+                    int k = (int)fminf(floorf((lam_exit - lambda) / delta) - 1.0f, 4096.f);
+                    lambda += delta;
+                    for (; k > 0; --k) lambda += delta;
+                    continue;
+                }
+                n_sampled += 1;
+                sdf = trilinear_at<CELL>(p, c);
+            } else {
+                sdf = trilinear<CELL>(p, c_w + ray_w * lambda);
+            }
             if (sdf <= 0) {
                 if (last_sdf > 0) {
                     if (p.subpix) lambda = lambda + delta * sdf / (last_sdf - sdf);
@@ -123,9 +191,60 @@ __device__ __forceinline__ float raycast_pixel(const RayParams& p, const ColorGe
     return depth > 0 ? depth : __builtin_nanf(""); // the value written to the depth image
 }
 
-template <typename CELL, bool COLOR>
-__global__ __launch_bounds__(256) void k_raycast_sdf(const RayParams p, const ColorGeom cv)
+template <typename CELL, bool COLOR, bool SKIP = false>
+__global__ __launch_bounds__(256) void k_raycast_sdf(const RayParams p, const ColorGeom cv, const SummaryView sv = SummaryView{})
 {
+    // SKIP: the two coarse summary levels are staged in LDS (level 3 always: at most a few hundred entries; level 2 when
+    // it fits `sv.lds2` entries), so that in wide uniform or hopeless regions a step costs no global access at all -- a
+    // dependent global load per step, even an L2 hit, is what the march is made of (measured: lookups in global memory
+    // made the march slower than sampling)
+    // The kernel lasts as long as its slowest wave, and a wave whose rays run along a border between observed and
+    // unobserved space (the frustum's sides) samples at every step whatever the summary says: the summary is used when at
+    // least three quarters of its 32^3-cell entries can be crossed without sampling (decided on the device from a counter the
+    // summary build leaves behind: no host synchronisation), otherwise the plain march runs (measured: S_full 0.162 ->
+    // 0.045 ms; S_room, where half the entries are mixed, 0.170 -> 0.225 ms if it were used).
+    extern __shared__ float s_sum[];   // SKIP: level 2 (n2 entries), then level 3 (n3), then one counter
+    const float *lds_D3 = nullptr, *lds_D2 = nullptr;
+    bool use_summary = false;
+    if constexpr (SKIP) {
+        // worth it?  (workgroup-uniform scalar load of the count the table build published)
+        use_summary = sv.force > 0 || (sv.force == 0 && (long long)*sv.useful * 10 >= (long long)sv.n2 * 9);
+    }
+    if (SKIP && use_summary) {
+        // every workgroup stages level 2 in LDS (16-byte loads, all in flight together) and derives level 3 (4 x 4 x 4
+        // level-2 entries each) from it: a few hundred LDS operations instead of another launch per frame
+        float* l2 = s_sum;
+        float* l3 = s_sum + ((sv.n2 + 3) & ~3);
+        const int n4 = sv.n2 >> 2;
+        const float4* src4 = reinterpret_cast<const float4*>(sv.D2);
+        for (int i = threadIdx.x; i < n4; i += 256) reinterpret_cast<float4*>(l2)[i] = src4[i];
+        for (int i = (n4 << 2) + threadIdx.x; i < sv.n2; i += 256) l2[i] = sv.D2[i];
+        __syncthreads();
+        for (int i = threadIdx.x; i < sv.n3; i += 256) {
+            const int bx = i % sv.n3x, by = (i / sv.n3x) % sv.n3y, bz = i / (sv.n3x * sv.n3y);
+            float lo = __builtin_inff(), hi = -__builtin_inff();
+            bool all_nan = true, all_val = true, any_useful = false;
+            for (int dz = 0; dz < 4; ++dz)
+                for (int dy = 0; dy < 4; ++dy)
+                    for (int dx = 0; dx < 4; ++dx) {
+                        const int x = bx * 4 + dx, y = by * 4 + dy, z = bz * 4 + dz;
+                        if (x >= sv.n2x || y >= sv.n2y || z >= sv.n2z) continue;
+                        const float v2 = l2[(z * sv.n2y + y) * sv.n2x + x];
+                        const bool isn = v2 != v2, isv = v2 > 0.f;
+                        all_nan = all_nan && isn;
+                        all_val = all_val && isv;
+                        any_useful = any_useful || isn || isv;
+                        if (isv) { lo = fminf(lo, v2); hi = fmaxf(hi, v2); }
+                    }
+            float out = any_useful ? -1.0f : -2.0f;
+            if (all_nan) out = __builtin_nanf("");
+            else if (all_val && hi - lo <= sv.tol * hi) out = sv.tol > 0.f ? 0.5f * (lo + hi) : lo;
+            l3[i] = out;
+        }
+        __syncthreads();
+        lds_D3 = l3;
+        lds_D2 = l2;
+    }
     int u, v;
     if (p.sparse_lanes) { // only the first sparse_lanes lanes of a wave carry rays (a strip of one pixel row): small images
         const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -135,7 +254,7 @@ __global__ __launch_bounds__(256) void k_raycast_sdf(const RayParams p, const Co
     } else {
         ray_pixel_of(p, blockIdx.x, blockIdx.y, threadIdx.x, u, v);
     }
-    raycast_pixel<CELL, COLOR>(p, cv, u, v);
+    raycast_pixel<CELL, COLOR, SKIP>(p, cv, u, v, sv, lds_D3, lds_D2, use_summary);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -400,7 +519,8 @@ static int raycast_levels_launch(int n_levels, const kfx_image* const* depth, co
 template <typename CELL>
 static int raycast_launch(const kfx_image* depth, const kfx_image* norm, const kfx_image* img,
                           const kfx_volume* vol, const float T_wc[12], const float K[4], float near,
-                          float far, float trunc_dist, int subpix, kfx_stream stream, const kfx_volume* colorvol = nullptr)
+                          float far, float trunc_dist, int subpix, kfx_stream stream, const kfx_volume* colorvol = nullptr,
+                          kfx_sdf_summary* summary = nullptr)
 {
     RayParams p;
     if (int e = ray_params<CELL>(p, depth, norm, img, vol, T_wc, K, near, far, trunc_dist, subpix)) return e;
@@ -426,9 +546,33 @@ static int raycast_launch(const kfx_image* depth, const kfx_image* norm, const k
             return set_error(KFX_E_SHAPE, "RaycastSdf(colour): colour volume dimensions / pitch");
         if (((uintptr_t)colorvol->ptr | colorvol->pitch | colorvol->img_pitch) & 3) return set_error(KFX_E_ALIGN, "RaycastSdf(colour): alignment");
         set_geometry(cv, colorvol);
-        hipLaunchKernelGGL((k_raycast_sdf<CELL, true>), grid, dim3(256), 0, (hipStream_t)stream, p, cv);
+        hipLaunchKernelGGL((k_raycast_sdf<CELL, true>), grid, dim3(256), 0, (hipStream_t)stream, p, cv, SummaryView{});
+    } else if (summary) {
+        // fast numerics: bricks whose values agree to 1e-5 count as uniform (observed free space: the running average of
+        // +trunc drifts by a few ulp per frame); exact numerics: bit-identical cells only
+        SummaryView sv;
+        if (int e = summary_view_offset(summary, vol, &sv.ox, &sv.oy, &sv.oz)) return e;
+        if (int e = summary_prepare(summary, math_mode() == KFX_MATH_FAST ? 1e-5f : 0.f, (hipStream_t)stream)) return e;
+        sv.D = summary->D; sv.D2 = summary->D2; sv.D3 = summary->D3;
+        sv.nbx = summary->nbx; sv.nby = summary->nby;
+        sv.n2x = summary->n2x; sv.n2y = summary->n2y;
+        sv.n3x = summary->n3x; sv.n3y = summary->n3y;
+        sv.n3 = summary->n3x * summary->n3y * summary->n3z;
+        sv.n2 = summary->n2x * summary->n2y * summary->n2z;
+        sv.n2z = summary->n2z;
+        sv.tol = math_mode() == KFX_MATH_FAST ? 1e-5f : 0.f;
+        sv.useful = summary->useful2 + 2;
+        static const int force_env = [] { const char* e = getenv("KFX_RAYCAST_SUMMARY"); return e ? atoi(e) : 0; }(); // 1: always, -1: never, 0: by the counter
+        sv.force = force_env;
+        const size_t lds_bytes = (size_t)(((sv.n2 + 3) & ~3) + sv.n3 + 4) * sizeof(float);
+        if (lds_bytes > 60 * 1024) { // level 2 does not fit LDS (volumes beyond ~768^3): the plain march
+            hipLaunchKernelGGL((k_raycast_sdf<CELL, false>), grid, dim3(256), 0, (hipStream_t)stream, p, cv, SummaryView{});
+            return check_launch("kfx_raycast_sdf");
+        }
+        if constexpr (CELL::BYTES == 8) hipLaunchKernelGGL((k_raycast_sdf<CELL, false, true>), grid, dim3(256), lds_bytes, (hipStream_t)stream, p, cv, sv);
+        else return set_error(KFX_E_RANGE, "kfx_raycast_sdf_tracked: fp32 cells only");
     } else {
-        hipLaunchKernelGGL((k_raycast_sdf<CELL, false>), grid, dim3(256), 0, (hipStream_t)stream, p, cv);
+        hipLaunchKernelGGL((k_raycast_sdf<CELL, false>), grid, dim3(256), 0, (hipStream_t)stream, p, cv, SummaryView{});
     }
     return check_launch("kfx_raycast_sdf");
 }
@@ -438,6 +582,14 @@ extern "C" int kfx_raycast_sdf(const kfx_image* depth, const kfx_image* norm, co
                                float far, float trunc_dist, int subpix, kfx_stream stream)
 {
     return raycast_launch<RayF32>(depth, norm, img, vol, T_wc, K, near, far, trunc_dist, subpix, stream);
+}
+
+extern "C" int kfx_raycast_sdf_tracked(const kfx_image* depth, const kfx_image* norm, const kfx_image* img, const kfx_volume* vol,
+                                       kfx_sdf_summary* summary, const float T_wc[12], const float K[4], float near, float far,
+                                       float trunc_dist, int subpix, kfx_stream stream)
+{
+    if (!summary) return set_error(KFX_E_NULL, "kfx_raycast_sdf_tracked: null summary");
+    return raycast_launch<RayF32>(depth, norm, img, vol, T_wc, K, near, far, trunc_dist, subpix, stream, nullptr, summary);
 }
 
 extern "C" int kfx_raycast_sdf_h(const kfx_image* depth, const kfx_image* norm, const kfx_image* img,

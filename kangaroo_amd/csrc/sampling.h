@@ -130,15 +130,27 @@ __device__ __forceinline__ V3 box_fraction(const GEOM& p, const V3 pos_w)
     return div_cw(d, p.size);
 }
 
-template <typename CELL, typename GEOM>
-__device__ __forceinline__ float trilinear(const GEOM& p, const V3 pos_w)
+// base cell (clamped to [0, dim - 2], Volume.h:229-234) and unclamped fractions of a trilinear sample
+struct CellPos { int ix, iy, iz; float fx, fy, fz; };
+template <typename GEOM>
+__device__ __forceinline__ CellPos cell_of(const GEOM& p, const V3 pos_w)
 {
     const V3 pos_v = box_fraction(p, pos_w);
     const V3 pf = v3(pos_v.x * p.dims1.x, pos_v.y * p.dims1.y, pos_v.z * p.dims1.z);
-    const int ix = (int)fmaxf(fminf(p.hi2.x, floorf(pf.x)), 0.f);
-    const int iy = (int)fmaxf(fminf(p.hi2.y, floorf(pf.y)), 0.f);
-    const int iz = (int)fmaxf(fminf(p.hi2.z, floorf(pf.z)), 0.f);
-    const float fx = pf.x - (float)ix, fy = pf.y - (float)iy, fz = pf.z - (float)iz;
+    CellPos c;
+    c.ix = (int)fmaxf(fminf(p.hi2.x, floorf(pf.x)), 0.f);
+    c.iy = (int)fmaxf(fminf(p.hi2.y, floorf(pf.y)), 0.f);
+    c.iz = (int)fmaxf(fminf(p.hi2.z, floorf(pf.z)), 0.f);
+    c.fx = pf.x - (float)c.ix; c.fy = pf.y - (float)c.iy; c.fz = pf.z - (float)c.iz;
+    return c;
+}
+
+// the eight cells of the sample and their blend (Volume.h:236-250)
+template <typename CELL, typename GEOM>
+__device__ __forceinline__ float trilinear_at(const GEOM& p, const CellPos& c)
+{
+    const int ix = c.ix, iy = c.iy, iz = c.iz;
+    const float fx = c.fx, fy = c.fy, fz = c.fz;
     float2 c00, c10, c01, c11;
     if (p.off32) { // launch-uniform
         const unsigned pitch = (unsigned)p.vol.pitch, img = (unsigned)p.vol.img_pitch;
@@ -150,6 +162,12 @@ __device__ __forceinline__ float trilinear(const GEOM& p, const V3 pos_w)
     }
     return lerp(lerp(lerp(c00.x, c00.y, fx), lerp(c10.x, c10.y, fx), fy),
                 lerp(lerp(c01.x, c01.y, fx), lerp(c11.x, c11.y, fx), fy), fz);
+}
+
+template <typename CELL, typename GEOM>
+__device__ __forceinline__ float trilinear(const GEOM& p, const V3 pos_w)
+{
+    return trilinear_at<CELL>(p, cell_of(p, pos_w));
 }
 
 // BoundedVolume::GetUnitsBackwardDiffDxDyDz -> Volume::GetFractionalBackwardDiffDxDyDz.

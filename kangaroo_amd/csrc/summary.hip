@@ -1,0 +1,207 @@
+// summary.hip -- the brick summary of a TSDF volume (kfx_sdf_summary, include/kfx.h): creation, the conservative state
+// changes for writers that do not track (invalidate), SdfReset with tracking, and the dilation R -> D the ray-march reads.
+// The summary is maintained by k_sdf_fuse_tiled<..., TRACK> (fuse.hip) and consumed by k_raycast_sdf<..., SKIP>
+// (raycast.hip).  No reference counterpart: the reference's march samples the volume at every step (cu_raycast.cu:58-81).
+#include <algorithm>
+#include <new>
+
+#include "kfx_device.h"
+#include "../../include/kfx_debug.h"
+
+namespace kfx {
+
+__global__ __launch_bounds__(256) void k_summary_fill(float4* __restrict__ R, size_t n, float lo, float hi, int state)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) R[i] = make_float4(lo, hi, __int_as_float(state), 0.f);
+}
+
+// One launch builds both tables: a wave per level-2 entry, one lane per level-1 brick of its 4 x 4 x 4 group.
+//   level 1: D[b] from R over b + {0, 1}^3 (clamped to the grid) -- a trilinear sample based in brick b reads those cells;
+//   level 2: uniform when every brick of the group is uniform (v > 0) and they agree within tol (the mid value is then
+//            within tol of every cell they cover), NaN when every brick is all-NaN, -1 when only some are (nothing the march
+//            uses: it samples), -2 when none is.
+// Level 3 (128^3 cells) is derived from level 2 by the ray-march itself, in LDS (raycast.hip).
+__global__ __launch_bounds__(256) void k_summary_build(const float4* __restrict__ R, float* __restrict__ D, float* __restrict__ D2,
+                                                        int nbx, int nby, int nbz, int n2x, int n2y, int n2, float tol, int* __restrict__ counters)
+{
+    __shared__ int s_useful[4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int useful = 0; // (per wave, lane 0)
+    for (int g = blockIdx.x * 4 + wv; g < n2; g += gridDim.x * 4) { // one wave per level-2 entry
+        const int bx = (g % n2x) * 4 + (lane & 3), by = ((g / n2x) % n2y) * 4 + ((lane >> 2) & 3), bz = (g / (n2x * n2y)) * 4 + (lane >> 4);
+        const bool exists = bx < nbx && by < nby && bz < nbz;
+        float v = -2.0f; // sample
+        if (exists) {
+            float lo = __builtin_inff(), hi = -__builtin_inff();
+            bool all_nan = true, all_val = true;
+#pragma unroll
+            for (int dz = 0; dz < 2; ++dz)
+#pragma unroll
+                for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < 2; ++dx) {
+                        const int x = min(bx + dx, nbx - 1), y = min(by + dy, nby - 1), z = min(bz + dz, nbz - 1);
+                        const float4 r = R[((size_t)z * nby + y) * nbx + x];
+                        const int st = __float_as_int(r.z);
+                        all_nan = all_nan && st == 1;
+                        all_val = all_val && st == 0;
+                        lo = fminf(lo, r.x);
+                        hi = fmaxf(hi, r.y);
+                    }
+            if (all_nan) v = __builtin_nanf("");
+            else if (all_val && lo > 0.f && hi < __builtin_inff() && hi - lo <= tol * hi) v = tol > 0.f ? 0.5f * (lo + hi) : lo;
+            D[((size_t)bz * nby + by) * nbx + bx] = v;
+        }
+        // the group's verdict: wave64 ballots and a min / max butterfly
+        const bool isn = v != v, isv = v > 0.f;
+        const unsigned long long m_exists = __ballot(exists), m_nan = __ballot(exists && isn), m_val = __ballot(exists && isv);
+        float lo = (exists && isv) ? v : __builtin_inff(), hi = (exists && isv) ? v : -__builtin_inff();
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            lo = fminf(lo, __shfl_xor(lo, off, 64));
+            hi = fmaxf(hi, __shfl_xor(hi, off, 64));
+        }
+        if (lane == 0) {
+            float out = (m_nan | m_val) ? -1.0f : -2.0f;
+            if (m_nan == m_exists) out = __builtin_nanf("");
+            else if (m_val == m_exists && hi - lo <= tol * hi) out = tol > 0.f ? 0.5f * (lo + hi) : lo;
+            D2[g] = out;
+            useful += (out > 0.f || out != out) ? 1 : 0;
+        }
+    }
+    // counters: [0] running count of entries a ray can cross without sampling, [1] workgroups done, [2] the published count
+    // of the finished build.  One pair of atomics per workgroup (a few hundred in all: 4096 of them on one address cost
+    // 0.1 ms); the last workgroup publishes and re-arms the other two, so no memset launch is needed per frame.
+    if (lane == 0) s_useful[wv] = useful;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(&counters[0], s_useful[0] + s_useful[1] + s_useful[2] + s_useful[3]);
+        __threadfence();
+        if (atomicAdd(&counters[1], 1) == (int)gridDim.x - 1) {
+            counters[2] = atomicExch(&counters[0], 0);
+            counters[1] = 0;
+        }
+    }
+}
+
+int summary_view_offset(const kfx_sdf_summary* s, const kfx_volume* view, int* ox, int* oy, int* oz)
+{
+    if (!s || !view || !view->ptr) return set_error(KFX_E_NULL, "summary: null argument");
+    if (view->pitch != s->pitch || view->img_pitch != s->img_pitch) return set_error(KFX_E_SHAPE, "summary: the volume is not a view of the summary's volume (pitches)");
+    const unsigned char* q = static_cast<const unsigned char*>(view->ptr);
+    if (q < s->base) return set_error(KFX_E_SHAPE, "summary: the volume is not a view of the summary's volume");
+    const size_t off = (size_t)(q - s->base);
+    const size_t z = off / s->img_pitch, rem = off % s->img_pitch, y = rem / s->pitch, xb = rem % s->pitch;
+    if (xb % 8 || z + view->d > (size_t)s->d || y + view->h > (size_t)s->h || xb / 8 + view->w > (size_t)s->w)
+        return set_error(KFX_E_SHAPE, "summary: the volume is not a view of the summary's volume (extent)");
+    *ox = (int)(xb / 8); *oy = (int)y; *oz = (int)z;
+    return 0;
+}
+
+int summary_prepare(kfx_sdf_summary* s, float tol, hipStream_t stream)
+{
+    if (!s->dirty && s->built_tol == tol) return 0;
+    const int n2 = s->n2x * s->n2y * s->n2z;
+    hipLaunchKernelGGL(k_summary_build, dim3(std::min(ceil_div(n2, 4), 256)), dim3(256), 0, stream, s->R, s->D, s->D2, s->nbx, s->nby, s->nbz,
+                       s->n2x, s->n2y, n2, tol, s->useful2);
+    if (int e = check_launch("kfx_sdf_summary (build)")) return e;
+    s->dirty = 0;
+    s->built_tol = tol;
+    return 0;
+}
+
+} // namespace kfx
+
+using namespace kfx;
+
+extern "C" int kfx_sdf_summary_create(kfx_sdf_summary** out, const kfx_volume* vol)
+{
+    if (!out || !vol || !vol->ptr) return set_error(KFX_E_NULL, "kfx_sdf_summary_create: null argument");
+    if (vol->w < 2 || vol->h < 2 || vol->d < 2 || vol->w > 65535 || vol->h > 65535 || vol->d > 65535) return set_error(KFX_E_SHAPE, "kfx_sdf_summary_create: volume dimensions");
+    kfx_sdf_summary* s = new (std::nothrow) kfx_sdf_summary;
+    if (!s) return set_error(KFX_E_RANGE, "kfx_sdf_summary_create: out of memory");
+    s->nbx = ceil_div((int)vol->w, 8); s->nby = ceil_div((int)vol->h, 8); s->nbz = ceil_div((int)vol->d, 8);
+    s->w = (int)vol->w; s->h = (int)vol->h; s->d = (int)vol->d;
+    s->base = static_cast<const unsigned char*>(vol->ptr);
+    s->pitch = vol->pitch; s->img_pitch = vol->img_pitch;
+    s->dirty = 1; s->built_tol = -1.f;
+    const size_t n = (size_t)s->nbx * s->nby * s->nbz;
+    s->n2x = ceil_div(s->nbx, 4); s->n2y = ceil_div(s->nby, 4); s->n2z = ceil_div(s->nbz, 4);
+    s->n3x = ceil_div(s->n2x, 4); s->n3y = ceil_div(s->n2y, 4); s->n3z = ceil_div(s->n2z, 4);
+    const size_t n2 = (size_t)s->n2x * s->n2y * s->n2z, n3 = (size_t)s->n3x * s->n3y * s->n3z;
+    s->R = nullptr; s->D = nullptr;
+    if (hipMalloc((void**)&s->R, n * sizeof(float4)) != hipSuccess || hipMalloc((void**)&s->D, (((n + 3) & ~(size_t)3) + n2 + n3 + 8) * sizeof(float)) != hipSuccess) {
+        (void)hipGetLastError();
+        if (s->R) (void)hipFree(s->R);
+        delete s;
+        return set_error(KFX_E_NODEVICE, "kfx_sdf_summary_create: hipMalloc");
+    }
+    s->D2 = s->D + ((n + 3) & ~(size_t)3);   // 16-byte aligned: the ray-march stages it with float4 loads
+    s->D3 = s->D2 + n2;
+    s->useful2 = reinterpret_cast<int*>(s->D3 + n3);
+    if (hipMemset(s->useful2, 0, 4 * sizeof(int)) != hipSuccess) return set_error(KFX_E_RANGE, "kfx_sdf_summary_create: memset");
+    *out = s;
+    return kfx_sdf_summary_invalidate(s, nullptr); // nothing is known about the volume's contents yet
+}
+
+extern "C" int kfx_sdf_summary_destroy(kfx_sdf_summary* s)
+{
+    if (!s) return 0;
+    (void)hipFree(s->R);
+    (void)hipFree(s->D);
+    delete s;
+    return 0;
+}
+
+// After the volume was written by anything that does not track (memcpy, LoadPXM, SdfSphere, an untracked SdfFuse):
+// every brick becomes "unknown", so the march samples everywhere until tracked updates re-establish ranges.
+extern "C" int kfx_sdf_summary_invalidate(kfx_sdf_summary* s, kfx_stream stream)
+{
+    if (!s) return set_error(KFX_E_NULL, "kfx_sdf_summary_invalidate: null summary");
+    const size_t n = (size_t)s->nbx * s->nby * s->nbz;
+    hipLaunchKernelGGL(k_summary_fill, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, s->R, n, -__builtin_inff(), __builtin_inff(), 2);
+    s->dirty = 1;
+    return check_launch("kfx_sdf_summary_invalidate");
+}
+
+// SdfReset(vol, trunc_dist) of the WHOLE volume with the summary set to match: every cell = trunc_dist (NaN: never observed)
+extern "C" int kfx_sdf_reset_tracked(const kfx_volume* vol, kfx_sdf_summary* s, float trunc_dist, kfx_stream stream)
+{
+    if (!s) return set_error(KFX_E_NULL, "kfx_sdf_reset_tracked: null summary");
+    int ox, oy, oz;
+    if (int e = summary_view_offset(s, vol, &ox, &oy, &oz)) return e;
+    if (ox || oy || oz || (int)vol->w != s->w || (int)vol->h != s->h || (int)vol->d != s->d)
+        return set_error(KFX_E_SHAPE, "kfx_sdf_reset_tracked: resets the whole volume only (use kfx_sdf_reset + kfx_sdf_summary_invalidate for views)");
+    if (int e = kfx_sdf_reset(vol, trunc_dist, stream)) return e;
+    const size_t n = (size_t)s->nbx * s->nby * s->nbz;
+    const bool nan = trunc_dist != trunc_dist;
+    hipLaunchKernelGGL(k_summary_fill, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, s->R, n,
+                       nan ? __builtin_inff() : trunc_dist, nan ? -__builtin_inff() : trunc_dist, nan ? 1 : 0);
+    s->dirty = 1;
+    return check_launch("kfx_sdf_reset_tracked");
+}
+
+// test / diagnostics aid (include/kfx_debug.h): copies of R (float4 per brick) and of D built with `tol` into caller buffers
+extern "C" int kfx_debug_summary_export(kfx_sdf_summary* s, float tol, void* R_out, void* D_out, int dims_out[9], kfx_stream stream)
+{
+    if (!s || !dims_out) return set_error(KFX_E_NULL, "kfx_debug_summary_export: null argument");
+    dims_out[0] = s->nbx; dims_out[1] = s->nby; dims_out[2] = s->nbz;
+    dims_out[3] = s->n2x; dims_out[4] = s->n2y; dims_out[5] = s->n2z;
+    dims_out[6] = dims_out[7] = dims_out[8] = 0; // level 3 exists only inside the ray-march; here: the build's counters
+    const size_t n = (size_t)s->nbx * s->nby * s->nbz;
+    const size_t n_all = n + (size_t)s->n2x * s->n2y * s->n2z;
+    hipStream_t st = (hipStream_t)stream;
+    if (R_out && hipMemcpyAsync(R_out, s->R, n * sizeof(float4), hipMemcpyDeviceToDevice, st) != hipSuccess) return set_error(KFX_E_RANGE, "kfx_debug_summary_export: copy");
+    if (D_out) {
+        if (int e = summary_prepare(s, tol, st)) return e;
+        if (hipMemcpyAsync(D_out, s->D, n * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess ||
+            hipMemcpyAsync(static_cast<float*>(D_out) + n, s->D2, (n_all - n) * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
+            return set_error(KFX_E_RANGE, "kfx_debug_summary_export: copy");
+        int c[3] = {0, 0, 0};
+        if (hipStreamSynchronize(st) != hipSuccess || hipMemcpy(c, s->useful2, sizeof(c), hipMemcpyDeviceToHost) != hipSuccess)
+            return set_error(KFX_E_RANGE, "kfx_debug_summary_export: copy");
+        dims_out[6] = c[0]; dims_out[7] = c[1]; dims_out[8] = c[2]; // running count, workgroups done, published count
+    }
+    return 0;
+}

@@ -37,8 +37,13 @@ def vbo_normals(ops, vbo, normals, depth, K):
 class FramePipeline:
     def __init__(self, ops, dims, boxmin, boxmax, w, h, K=None, near=0.4, far=8.0, bilateral=None,
                  trunc_factor=scenes.TRUNC_DIST_FACTOR, max_w=scenes.MAX_W, mincostheta=scenes.MIN_COS_THETA,
-                 contiguous_images=False):
+                 contiguous_images=False, track=False):
+        """track: keep a brick summary of the volume (ops.SdfSummary) current in SdfFuse and let RaycastSdf step through
+        uniformly free / never-observed bricks without reading the volume (same volume bits; images bit-identical in
+        exact numerics, within the fast-mode tolerance in fast numerics)."""
         self.ops = ops
+        self.track = bool(track) and hasattr(ops, "SdfSummary")
+        self.summary = None
         self.dims = tuple(int(d) for d in dims)
         self.w, self.h = int(w), int(h)
         self.K = scenes.intrinsics(w, h) if K is None else np.asarray(K, np.float32)
@@ -65,7 +70,12 @@ class FramePipeline:
 
     def reset(self):
         """SdfReset(vol, NaN): 'never observed' = (NaN, 0) (main.cpp:229)."""
-        self.ops.SdfReset(self.vol, float("nan"))
+        if self.track:
+            if self.summary is None:
+                self.summary = self.ops.SdfSummary(self.vol)
+            self.ops.SdfReset(self.vol, float("nan"), summary=self.summary)
+        else:
+            self.ops.SdfReset(self.vol, float("nan"))
 
     def preprocess(self, raw_image=None):
         o = self.ops
@@ -74,12 +84,14 @@ class FramePipeline:
         vbo_normals(o, self.vbo, self.normals, self.filtered, self.K)
 
     def fuse(self, T_wc):
+        kw = {"summary": self.summary} if self.track else {}
         self.ops.SdfFuse(self.vol, self.filtered, self.normals, scenes.se3_inverse(T_wc), self.K, self.trunc,
-                         self.max_w, self.mincostheta)
+                         self.max_w, self.mincostheta, **kw)
 
     def raycast(self, T_wc):
+        kw = {"summary": self.summary} if self.track else {}
         self.ops.RaycastSdf(self.ray_d, self.ray_n, self.ray_i, self.vol, T_wc, self.K, self.near, self.far,
-                            self.trunc, True)
+                            self.trunc, True, **kw)
 
     def step(self, T_wc, raw_image=None):
         """One frame: preprocess the new depth image, integrate it, render the model."""

@@ -240,12 +240,41 @@ def get_math_mode():
 
 # ---- operators ------------------------------------------------------------------
 
-def SdfFuse(vol, depth, norm, T_cw, K, trunc_dist, maxw, mincostheta, full_extent=False, stream=None, slab=None):
+class SdfSummary:
+    """kfx_sdf_summary of a BoundedVolume (fp32 cells): per 8 x 8 x 8 cells the range of the stored values, kept current by
+    SdfFuse(..., summary=) / SdfReset(..., summary=) and used by RaycastSdf(..., summary=) to step through uniformly free
+    or never-observed space without reading the volume.  Views of the volume may be passed to those calls; after any
+    other write to the volume call invalidate()."""
+
+    def __init__(self, vol):
+        assert vol.kind == "f32"
+        self.vol = vol
+        self.handle = C.c_void_p()
+        _lib.check(_lib.load().kfx_sdf_summary_create(C.byref(self.handle), vol.ref()))
+
+    def invalidate(self, stream=None):
+        _lib.check(_lib.load().kfx_sdf_summary_invalidate(self.handle, _stream(stream)))
+
+    def __del__(self):
+        try:
+            if self.handle is not None and self.handle.value:
+                _lib.load().kfx_sdf_summary_destroy(self.handle)
+                self.handle = None
+        except Exception:   # interpreter shutdown: the process is going away with its device memory
+            pass
+
+
+def SdfFuse(vol, depth, norm, T_cw, K, trunc_dist, maxw, mincostheta, full_extent=False, stream=None, slab=None, summary=None):
     """roo::SdfFuse (cu_sdffusion.h:13-14).  slab = (full_d, z_offset, full_zmin, full_zmax) integrates `vol`
     as planes [z_offset, z_offset + d) of a larger volume (kfx_sdf_fuse_slab), bit-identically to the same
-    planes of the monolithic volume."""
+    planes of the monolithic volume.  summary: keep this SdfSummary current (kfx_sdf_fuse_tracked, same volume bits)."""
     t, _t = _fp(T_cw, 12)
     k, _k = _fp(K, 4)
+    if summary is not None:
+        assert slab is None and vol.kind == "f32"
+        _lib.check(_lib.load().kfx_sdf_fuse_tracked(vol.ref(), summary.handle, depth.ref(), norm.ref(), t, k, trunc_dist, maxw, mincostheta,
+                                                    1 if full_extent else 0, _stream(stream)))
+        return
     if slab is not None:
         sl = _lib.KfxSlab(int(slab[0]), int(slab[1]), float(slab[2]), float(slab[3]))
         fn = _lib.load().kfx_sdf_fuse_slab_h if vol.kind == "f16" else _lib.load().kfx_sdf_fuse_slab
@@ -268,10 +297,15 @@ def SdfFuseCount(vol, depth, norm, T_cw, K, trunc_dist, mincostheta, full_extent
     return int(cnt.item())
 
 
-def RaycastSdf(depth, norm, img, vol, T_wc, K, near, far, trunc_dist, subpix=True, stream=None):
-    """roo::RaycastSdf (cu_raycast.h:13-14)."""
+def RaycastSdf(depth, norm, img, vol, T_wc, K, near, far, trunc_dist, subpix=True, stream=None, summary=None):
+    """roo::RaycastSdf (cu_raycast.h:13-14).  summary: take the steps through uniform bricks from this SdfSummary
+    (kfx_raycast_sdf_tracked: bit-identical images in exact numerics, within the fast-mode tolerance in fast numerics)."""
     t, _t = _fp(T_wc, 12)
     k, _k = _fp(K, 4)
+    if summary is not None:
+        _lib.check(_lib.load().kfx_raycast_sdf_tracked(depth.ref(), norm.ref(), img.ref(), vol.ref(), summary.handle, t, k, near, far,
+                                                       trunc_dist, 1 if subpix else 0, _stream(stream)))
+        return
     fn = _lib.load().kfx_raycast_sdf_h if vol.kind == "f16" else _lib.load().kfx_raycast_sdf
     _lib.check(fn(depth.ref(), norm.ref(), img.ref(), vol.ref(), t, k, near, far, trunc_dist, 1 if subpix else 0,
                   _stream(stream)))
@@ -325,8 +359,11 @@ def NormalsFromVbo(dN, dV, stream=None):
     _lib.check(_lib.load().kfx_normals_from_vbo(dN.ref(), dV.ref(), _stream(stream)))
 
 
-def SdfReset(vol, trunc_dist, stream=None):
-    """roo::SdfReset(BoundedVolume<SDF_t>, float) (cu_sdffusion.h:20)."""
+def SdfReset(vol, trunc_dist, stream=None, summary=None):
+    """roo::SdfReset(BoundedVolume<SDF_t>, float) (cu_sdffusion.h:20).  summary: the whole volume's SdfSummary, set to match."""
+    if summary is not None:
+        _lib.check(_lib.load().kfx_sdf_reset_tracked(vol.ref(), summary.handle, trunc_dist, _stream(stream)))
+        return
     fn = _lib.load().kfx_sdf_reset_h if vol.kind == "f16" else _lib.load().kfx_sdf_reset
     _lib.check(fn(vol.ref(), trunc_dist, _stream(stream)))
 
