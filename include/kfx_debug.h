@@ -31,8 +31,7 @@ int kfx_debug_sqrt_core_check(unsigned long long* d_out, kfx_stream stream);
  * (state 0: every cell has a value in [lo, hi], 1: every cell NaN, 2: mixed / unknown), D_out the ray-march's table built
  * with relative tolerance `tol`, level 1 (8^3 cells) followed by levels 2 (32^3) and 3 (128^3) (v > 0: uniform value, NaN:
  * all NaN, -2: sample, -1 on levels 2 / 3: look one level down); either may be NULL.  dims_out = entries along x, y, z of
- * levels 1 and 2, then (with D_out) the table build's three counters {running, workgroups done, published number of level-2 entries a
- * ray can cross without sampling}.  Device buffers: R_out n1 float4, D_out (n1 + n2) floats. */
+ * levels 1 and 2, then (with D_out) {number of partial counts, 0, number of level-2 entries a ray can cross without sampling}.  Device buffers: R_out n1 float4, D_out (n1 + n2) floats. */
 int kfx_debug_summary_export(kfx_sdf_summary* s, float tol, void* R_out, void* D_out, int dims_out[9], kfx_stream stream);
 
 #ifdef __cplusplus

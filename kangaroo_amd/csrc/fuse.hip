@@ -185,7 +185,10 @@ __device__ __forceinline__ Obs finish(const FuseParams& p, const V3 Pc, float iz
     const float sd = costheta * (md - Pc.z);
     // unconditional: val / w are only read when ok is set, and selects are cheaper than divergent branches
     o.ok = ((int)!(sd <= -p.trunc) & (int)isfinite(md) & (int)isfinite(w) & (int)(costheta > p.mincos)) != 0;
-    o.val = clampf(sd, -p.trunc, p.trunc);
+    // fast numerics: one v_med3_f32 (sd is never NaN when the predicate holds; for a negative trunc_dist the median would
+    // differ from the clamp, a case only the exact path reproduces)
+    if constexpr (FAST) o.val = __builtin_amdgcn_fmed3f(sd, -p.trunc, p.trunc);
+    else o.val = clampf(sd, -p.trunc, p.trunc);
     o.w = w;
     return o;
 }
@@ -507,13 +510,17 @@ __global__ __launch_bounds__(256) void k_sdf_fuse_tiled(const FuseParams p, cons
         if (dmax + fabsf(dmax) * 1e-5f - zmin < bound) return; // also when every texel is NaN (dmax = -inf)
     }
     // values written this frame, per 8-slice group of this wave (TRACK)
+    // Called for a cell pair that was loaded, updated (one or both cells) and stored.  Both cells enter the range: a cell
+    // that was not updated keeps a value that belongs to the brick anyway (NaN is ignored by min3 / max3), so the range
+    // stays conservative and two instructions suffice; only the count is per updated cell.
     auto note = [&](int z, const float4& c, bool ok0, bool ok1) {
         if constexpr (TRACK) {
-            const float lo = fminf(ok0 ? c.x : __builtin_inff(), ok1 ? c.z : __builtin_inff());
-            const float hi = fmaxf(ok0 ? c.x : -__builtin_inff(), ok1 ? c.z : -__builtin_inff());
             const int n = (int)ok0 + (int)ok1;
-            if (NG == 1 || z - wz0 < 8) { t_mn0 = fminf(t_mn0, lo); t_mx0 = fmaxf(t_mx0, hi); t_cnt0 += n; }
-            else { t_mn1 = fminf(t_mn1, lo); t_mx1 = fmaxf(t_mx1, hi); t_cnt1 += n; }
+            if (NG == 1 || z - wz0 < 8) {
+                t_mn0 = __builtin_fminf(__builtin_fminf(t_mn0, c.x), c.z); t_mx0 = __builtin_fmaxf(__builtin_fmaxf(t_mx0, c.x), c.z); t_cnt0 += n;
+            } else {
+                t_mn1 = __builtin_fminf(__builtin_fminf(t_mn1, c.x), c.z); t_mx1 = __builtin_fmaxf(__builtin_fmaxf(t_mx1, c.x), c.z); t_cnt1 += n;
+            }
         }
     };
     auto march = [&]() {
@@ -622,8 +629,7 @@ __global__ __launch_bounds__(256) void k_sdf_fuse_tiled(const FuseParams p, cons
                             const float fix = floorf(pu), fiy = floorf(pv);
                             const int rx = (int)fix - tx0, ry = (int)fiy - ty0;
                             const bool inside = (unsigned)rx <= (unsigned)cxmax && (unsigned)ry <= (unsigned)cymax;
-                            const int cx = min(max(rx, 0), cxmax), cy = min(max(ry, 0), cymax);
-                            const float4* t = s_tile + (cy * tw + cx);
+                            const float4* t = s_tile + (med3_i32(ry, 0, cymax) * tw + med3_i32(rx, 0, cxmax)); // clamps: one v_med3_i32 each
                             Corners c;
                             c.c00 = t[0]; c.c01 = t[1]; c.c10 = t[tw]; c.c11 = t[tw + 1];
                             o[k][v] = finish<FAST>(p, Pc, iz, pu - fix, pv - fiy, c);
@@ -1480,7 +1486,7 @@ extern "C" int kfx_sdf_reset(const kfx_volume* vol, float trunc_dist, kfx_stream
     if (int e = check_volume(vol)) return e;
     const size_t span_bytes = (vol->d - 1) * vol->img_pitch + (vol->h - 1) * vol->pitch + vol->w * 8;
     const size_t n = span_bytes / 8;
-    const int blocks = (int)std::min<size_t>((n / 2 + 255) / 256 + 1, 256 * 16);
+    const int blocks = (int)std::min<size_t>((n / 2 + 255) / 256 + 1, 256 * 32);
     hipStream_t s = (hipStream_t)stream;
     if (((uintptr_t)vol->ptr & 15) == 0)
         hipLaunchKernelGGL(k_fill_sdf, dim3(blocks), dim3(256), 0, s, (float2*)vol->ptr, n, trunc_dist, 0.0f);

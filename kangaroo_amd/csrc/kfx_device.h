@@ -151,7 +151,8 @@ struct kfx_sdf_summary {
     float4* R;
     float* D;                    // level 1 (8^3 cells), then level 2 (32^3) behind it
     float *D2, *D3;              // (D3 unused: level 3 is derived in LDS by the ray-march)
-    int* useful2;                // device counters of the table build: [2] = level-2 entries a ray can cross without sampling
+    int* useful2;                // device: per-workgroup counts of level-2 entries a ray can cross without sampling (n_partials of them)
+    int n_partials;
     int nbx, nby, nbz;
     int n2x, n2y, n2z, n3x, n3y, n3z;
     int w, h, d;                 // parent volume (cells)
@@ -168,7 +169,8 @@ struct SummaryView {
     int nbx, nby, n2x, n2y, n3x, n3y;
     int n2, n3, n2z; // entries of levels 2 and 3
     float tol;       // the tolerance level 2 was built with (level 3 is derived with the same)
-    const int* useful; // device: number of level-2 entries a ray can cross without sampling
+    const int* useful; // device: n_partials partial counts of level-2 entries a ray can cross without sampling
+    int n_partials;
     int force;      // 0: decide by the counter, 1: always use the summary, -1: never (KFX_RAYCAST_SUMMARY)
     int ox, oy, oz; // cell offset of the view inside the parent volume
 };

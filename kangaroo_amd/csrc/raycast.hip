@@ -207,8 +207,17 @@ __global__ __launch_bounds__(256) void k_raycast_sdf(const RayParams p, const Co
     const float *lds_D3 = nullptr, *lds_D2 = nullptr;
     bool use_summary = false;
     if constexpr (SKIP) {
-        // worth it?  (workgroup-uniform scalar load of the count the table build published)
-        use_summary = sv.force > 0 || (sv.force == 0 && (long long)*sv.useful * 10 >= (long long)sv.n2 * 9);
+        // worth it?  add up the table build's per-workgroup counts (at most 1024 of them: four loads per thread)
+        int useful = 0;
+        for (int i = threadIdx.x; i < sv.n_partials; i += 256) useful += sv.useful[i];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) useful += __shfl_xor(useful, off, 64);
+        int* cnt = reinterpret_cast<int*>(s_sum);
+        if ((threadIdx.x & 63) == 0) cnt[threadIdx.x >> 6] = useful;
+        __syncthreads();
+        useful = cnt[0] + cnt[1] + cnt[2] + cnt[3];
+        __syncthreads(); // (s_sum is reused for the tables)
+        use_summary = sv.force > 0 || (sv.force == 0 && (long long)useful * 10 >= (long long)sv.n2 * 9); // workgroup-uniform
     }
     if (SKIP && use_summary) {
         // every workgroup stages level 2 in LDS (16-byte loads, all in flight together) and derives level 3 (4 x 4 x 4
@@ -561,7 +570,8 @@ static int raycast_launch(const kfx_image* depth, const kfx_image* norm, const k
         sv.n2 = summary->n2x * summary->n2y * summary->n2z;
         sv.n2z = summary->n2z;
         sv.tol = math_mode() == KFX_MATH_FAST ? 1e-5f : 0.f;
-        sv.useful = summary->useful2 + 2;
+        sv.useful = summary->useful2;
+        sv.n_partials = summary->n_partials;
         static const int force_env = [] { const char* e = getenv("KFX_RAYCAST_SUMMARY"); return e ? atoi(e) : 0; }(); // 1: always, -1: never, 0: by the counter
         sv.force = force_env;
         const size_t lds_bytes = (size_t)(((sv.n2 + 3) & ~3) + sv.n3 + 4) * sizeof(float);

@@ -23,7 +23,7 @@ __global__ __launch_bounds__(256) void k_summary_fill(float4* __restrict__ R, si
 //            uses: it samples), -2 when none is.
 // Level 3 (128^3 cells) is derived from level 2 by the ray-march itself, in LDS (raycast.hip).
 __global__ __launch_bounds__(256) void k_summary_build(const float4* __restrict__ R, float* __restrict__ D, float* __restrict__ D2,
-                                                        int nbx, int nby, int nbz, int n2x, int n2y, int n2, float tol, int* __restrict__ counters)
+                                                        int nbx, int nby, int nbz, int n2x, int n2y, int n2, float tol, int* __restrict__ partials)
 {
     __shared__ int s_useful[4];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -70,19 +70,11 @@ __global__ __launch_bounds__(256) void k_summary_build(const float4* __restrict_
             useful += (out > 0.f || out != out) ? 1 : 0;
         }
     }
-    // counters: [0] running count of entries a ray can cross without sampling, [1] workgroups done, [2] the published count
-    // of the finished build.  One pair of atomics per workgroup (a few hundred in all: 4096 of them on one address cost
-    // 0.1 ms); the last workgroup publishes and re-arms the other two, so no memset launch is needed per frame.
+    // the workgroup's number of entries a ray can cross without sampling; the ray-march adds the partials up itself (a
+    // single counter would take an atomic per workgroup on one address: 4096 of them cost 0.1 ms, 1024 still 10 us)
     if (lane == 0) s_useful[wv] = useful;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        atomicAdd(&counters[0], s_useful[0] + s_useful[1] + s_useful[2] + s_useful[3]);
-        __threadfence();
-        if (atomicAdd(&counters[1], 1) == (int)gridDim.x - 1) {
-            counters[2] = atomicExch(&counters[0], 0);
-            counters[1] = 0;
-        }
-    }
+    if (threadIdx.x == 0) partials[blockIdx.x] = s_useful[0] + s_useful[1] + s_useful[2] + s_useful[3];
 }
 
 int summary_view_offset(const kfx_sdf_summary* s, const kfx_volume* view, int* ox, int* oy, int* oz)
@@ -103,7 +95,8 @@ int summary_prepare(kfx_sdf_summary* s, float tol, hipStream_t stream)
 {
     if (!s->dirty && s->built_tol == tol) return 0;
     const int n2 = s->n2x * s->n2y * s->n2z;
-    hipLaunchKernelGGL(k_summary_build, dim3(std::min(ceil_div(n2, 4), 256)), dim3(256), 0, stream, s->R, s->D, s->D2, s->nbx, s->nby, s->nbz,
+    s->n_partials = std::min(ceil_div(n2, 4), 1024);
+    hipLaunchKernelGGL(k_summary_build, dim3(s->n_partials), dim3(256), 0, stream, s->R, s->D, s->D2, s->nbx, s->nby, s->nbz,
                        s->n2x, s->n2y, n2, tol, s->useful2);
     if (int e = check_launch("kfx_sdf_summary (build)")) return e;
     s->dirty = 0;
@@ -131,7 +124,7 @@ extern "C" int kfx_sdf_summary_create(kfx_sdf_summary** out, const kfx_volume* v
     s->n3x = ceil_div(s->n2x, 4); s->n3y = ceil_div(s->n2y, 4); s->n3z = ceil_div(s->n2z, 4);
     const size_t n2 = (size_t)s->n2x * s->n2y * s->n2z, n3 = (size_t)s->n3x * s->n3y * s->n3z;
     s->R = nullptr; s->D = nullptr;
-    if (hipMalloc((void**)&s->R, n * sizeof(float4)) != hipSuccess || hipMalloc((void**)&s->D, (((n + 3) & ~(size_t)3) + n2 + n3 + 8) * sizeof(float)) != hipSuccess) {
+    if (hipMalloc((void**)&s->R, n * sizeof(float4)) != hipSuccess || hipMalloc((void**)&s->D, (((n + 3) & ~(size_t)3) + n2 + n3 + 1024 + 8) * sizeof(float)) != hipSuccess) {
         (void)hipGetLastError();
         if (s->R) (void)hipFree(s->R);
         delete s;
@@ -140,7 +133,7 @@ extern "C" int kfx_sdf_summary_create(kfx_sdf_summary** out, const kfx_volume* v
     s->D2 = s->D + ((n + 3) & ~(size_t)3);   // 16-byte aligned: the ray-march stages it with float4 loads
     s->D3 = s->D2 + n2;
     s->useful2 = reinterpret_cast<int*>(s->D3 + n3);
-    if (hipMemset(s->useful2, 0, 4 * sizeof(int)) != hipSuccess) return set_error(KFX_E_RANGE, "kfx_sdf_summary_create: memset");
+    s->n_partials = 0;
     *out = s;
     return kfx_sdf_summary_invalidate(s, nullptr); // nothing is known about the volume's contents yet
 }
@@ -198,10 +191,12 @@ extern "C" int kfx_debug_summary_export(kfx_sdf_summary* s, float tol, void* R_o
         if (hipMemcpyAsync(D_out, s->D, n * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess ||
             hipMemcpyAsync(static_cast<float*>(D_out) + n, s->D2, (n_all - n) * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
             return set_error(KFX_E_RANGE, "kfx_debug_summary_export: copy");
-        int c[3] = {0, 0, 0};
-        if (hipStreamSynchronize(st) != hipSuccess || hipMemcpy(c, s->useful2, sizeof(c), hipMemcpyDeviceToHost) != hipSuccess)
+        int c[1024];
+        if (hipStreamSynchronize(st) != hipSuccess || hipMemcpy(c, s->useful2, s->n_partials * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess)
             return set_error(KFX_E_RANGE, "kfx_debug_summary_export: copy");
-        dims_out[6] = c[0]; dims_out[7] = c[1]; dims_out[8] = c[2]; // running count, workgroups done, published count
+        int total = 0;
+        for (int i = 0; i < s->n_partials; ++i) total += c[i];
+        dims_out[6] = s->n_partials; dims_out[7] = 0; dims_out[8] = total; // partial counts, -, their sum
     }
     return 0;
 }
