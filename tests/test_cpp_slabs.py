@@ -68,3 +68,14 @@ def test_cpp_slabs_refuse_more_rccl_ranks_than_gpus(tmp_path):
     env = dict(os.environ, RANK="0", WORLD_SIZE="2", LOCAL_RANK="0")
     out = subprocess.run([APP, "--transport", "rccl", "--rendezvous", str(tmp_path / "id")], capture_output=True, text=True, timeout=120, env=env)
     assert out.returncode == 2 and "need 2 GPUs" in out.stderr
+
+
+def test_cpp_slabs_c4_1024_cubed_in_eight_slabs():
+    """BASELINE config C4's volume (1024^3, 8 GiB, 640x480) cut into eight slabs the way eight GPUs would hold it -- here as
+    eight rank threads on the one GPU: halo exchange + exact march give the volume and images of the one-slab run."""
+    common = ("--res", 1024, "--frames", 2, "--width", 640, "--height", 480, "--raycast", "exact")
+    ref = run(*common, "--ranks", 1)
+    got = run(*common, "--ranks", 8, "--halo", "exchange")
+    assert got["agree"] == 1 and ref["hits"] > 640 * 480 // 3
+    for k in ("depth", "norm", "img", "volume", "hits"):
+        assert got[k] == ref[k], (k, got["text"], ref["text"])
