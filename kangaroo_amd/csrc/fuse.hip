@@ -730,12 +730,15 @@ __global__ __launch_bounds__(256) void k_sdf_fuse_tiled(const FuseParams p, cons
             if (cnt > 0 && bx * 8 < p.sum_w && by * 8 < p.sum_h && bz * 8 < p.sum_d) {
                 const int total = min(8, p.sum_w - bx * 8) * min(8, p.sum_h - by * 8) * min(8, p.sum_d - bz * 8);
                 float4* r = p.sum_R + ((size_t)bz * p.sum_nby + by) * p.sum_nbx + bx;
-                float4 old = *r;
-                const int st = __float_as_int(old.z); // 0: every cell has a value in [lo, hi]; 1: every cell NaN; 2: mixed / unknown
-                if (cnt == total) old = make_float4(mn, mx, __int_as_float(0), 0.f);
-                else if (st == 1) old = make_float4(mn, mx, __int_as_float(2), 0.f);
-                else old = make_float4(fminf(old.x, mn), fmaxf(old.y, mx), old.z, 0.f);
-                *r = old;
+                // state 0: every cell has a value in [lo, hi]; 1: every cell NaN; 2: mixed / unknown
+                if (cnt == total) { // every cell rewritten: the frame's range, no need to know the old one
+                    *r = make_float4(mn, mx, __int_as_float(0), 0.f);
+                } else {
+                    float4 old = *r;
+                    if (__float_as_int(old.z) == 1) old = make_float4(mn, mx, __int_as_float(2), 0.f);
+                    else old = make_float4(fminf(old.x, mn), fmaxf(old.y, mx), old.z, 0.f);
+                    *r = old;
+                }
             }
         }
     }
