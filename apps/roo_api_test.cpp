@@ -7,6 +7,7 @@
 #include <vector>
 
 #include <kangaroo/kangaroo.h>
+#include <kangaroo/SdfSummary.h>
 #include <kangaroo/extra/SavePPM.h>
 
 using namespace roo;
@@ -258,6 +259,46 @@ int main()
         for (size_t i = 0; i < hi.size(); ++i)
             if (std::isfinite(hdc[i])) { ++chit; if (std::fabs(hi[i] - 0.2f) > 1e-5f || std::fabs(hdc[i] - 3.0f) > 0.05f) ++cbad; }
         CHECK(chit > w * h / 8 && cbad == 0);
+    }
+
+    // ---- brick summary (roo::SdfSummary): tracked SdfFuse / RaycastSdf give the volume and images of the plain calls ----
+    {
+        const int M = 64, sw = 160, sh = 120;
+        const ImageIntrinsics Ks(142.5855, 142.5855, sw / 2.0 - 0.5, sh / 2.0 - 0.5);
+        const BoundingBox box(make_float3(-1, -1, 2), make_float3(1, 1, 4));
+        BoundedVolume<SDF_t, TargetDevice, Manage> va(M, M, M, box), vb(M, M, M, box);
+        Image<float, TargetDevice, Manage> sd(sw, sh), da(sw, sh), db(sw, sh), ia(sw, sh), ib(sw, sh);
+        Image<float4, TargetDevice, Manage> sv(sw, sh), sn(sw, sh), na(sw, sh), nb(sw, sh);
+        std::vector<float> wall((size_t)sw * sh, 3.5f);
+        for (int v = 30; v < 90; ++v)
+            for (int u = 40; u < 120; ++u) wall[(size_t)v * sw + u] = 2.8f;   // a box in front of the wall
+        sd.MemcpyFromHost(wall.data());
+        DepthToVbo<float>(sv, sd, Ks);
+        NormalsFromVbo(sn, sv);
+        const Mat<float,3,4> I = SE3Identity();
+        const float tr = 2.0f * length(va.VoxelSizeUnits());
+        SdfSummary summary(vb);
+        SdfReset(va, NAN);
+        SdfReset(vb, NAN, summary);
+        for (int f = 0; f < 2; ++f) {
+            SdfFuse(va, sd, sn, I, Ks, tr, 1000.0f, 0.1f);
+            SdfFuse(vb, summary, sd, sn, I, Ks, tr, 1000.0f, 0.1f);
+        }
+        RaycastSdf(da, na, ia, va, I, Ks, 0.4f, 8.0f, tr, true);
+        RaycastSdf(db, nb, ib, vb, summary, I, Ks, 0.4f, 8.0f, tr, true);
+        Volume<SDF_t, TargetHost, Manage> ha(M, M, M), hb(M, M, M);
+        CHECK(kfx_memcpy_2d(ha.ptr, ha.pitch, va.ptr, va.pitch, M * sizeof(SDF_t), (size_t)M * M, 2, 0) == 0);
+        CHECK(kfx_memcpy_2d(hb.ptr, hb.pitch, vb.ptr, vb.pitch, M * sizeof(SDF_t), (size_t)M * M, 2, 0) == 0);
+        CHECK(memcmp(ha.ptr, hb.ptr, ha.pitch * M * M) == 0);
+        std::vector<float> hda((size_t)sw * sh), hdb((size_t)sw * sh);
+        da.MemcpyToHost(hda.data());
+        db.MemcpyToHost(hdb.data());
+        int shits = 0;
+        for (size_t i = 0; i < hda.size(); ++i) {
+            if (std::isfinite(hda[i])) ++shits;
+            CHECK((std::isnan(hda[i]) && std::isnan(hdb[i])) || hda[i] == hdb[i]);
+        }
+        CHECK(shits > sw * sh / 4);
     }
 
     printf("roo_api_test: %s (%d ray hits checked)\n", g_fail ? "FAILED" : "all checks passed", nhit);

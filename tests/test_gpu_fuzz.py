@@ -46,6 +46,10 @@ def test_gpu_fuzz_fuse_count_raycast(roo, seed):
     oracle.sdf_reset(ovol, float("nan"))
     vol = roo.BoundedVolume(dims[0], dims[1], dims[2], bmin, bmax, pitch=pitch)
     roo.SdfReset(vol, float("nan"))
+    # a second copy maintained through the tracked entry points (brick summary): same bits, same images
+    volt = roo.BoundedVolume(dims[0], dims[1], dims[2], bmin, bmax, pitch=pitch)
+    summ = roo.SdfSummary(volt)
+    roo.SdfReset(volt, float("nan"), summary=summ)
     tr = float(rng.uniform(1.0, 3.0) * np.linalg.norm(ovol.voxel_size()))
     max_w = float(rng.choice([2.0, 100.0, 1000.0]))
     for T_wc in poses:
@@ -62,6 +66,8 @@ def test_gpu_fuzz_fuse_count_raycast(roo, seed):
         roo.SdfFuse(vol, gf, gn, T_cw, K, tr, max_w, 0.1, full_extent=full)
         got = vol.MemcpyToHost()
         assert T.nan_equal(got, ovol.data), (seed, T.mismatch_report(got, ovol.data))
+        roo.SdfFuse(volt, gf, gn, T_cw, K, tr, max_w, 0.1, full_extent=full, summary=summ)
+        assert T.nan_equal(volt.MemcpyToHost(), ovol.data), (seed, "tracked")
     for T_wc in poses[:2]:
         od, on, oi = oracle.Image(w, h), oracle.Image(w, h, channels=4), oracle.Image(w, h)
         near = float(rng.uniform(0.05, 0.6))
@@ -70,6 +76,10 @@ def test_gpu_fuzz_fuse_count_raycast(roo, seed):
         roo.RaycastSdf(rd, rn, ri, vol, T_wc, K, near, 9.0, tr, bool(seed % 2))
         assert T.nan_equal(rd.MemcpyToHost(), od.data), (seed, T.mismatch_report(rd.MemcpyToHost(), od.data))
         assert T.nan_equal(rn.MemcpyToHost(), on.data) and T.nan_equal(ri.MemcpyToHost(), oi.data), seed
+        td, tn, ti = roo.Image(w, h), roo.Image(w, h, "f32x4"), roo.Image(w, h)
+        roo.RaycastSdf(td, tn, ti, volt, T_wc, K, near, 9.0, tr, bool(seed % 2), summary=summ)
+        assert T.nan_equal(td.MemcpyToHost(), od.data), (seed, "tracked", T.mismatch_report(td.MemcpyToHost(), od.data))
+        assert T.nan_equal(tn.MemcpyToHost(), on.data) and T.nan_equal(ti.MemcpyToHost(), oi.data), (seed, "tracked")
 
 
 @pytest.mark.parametrize("seed", list(range(100, 110)))
