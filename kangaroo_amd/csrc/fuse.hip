@@ -54,6 +54,7 @@ struct FuseParams {
     int sum_bx0, sum_by0, sum_bz0;
     int sum_w, sum_h, sum_d; // parent volume dimensions in cells
     int zoff_local;          // first plane of this launch within the view (fuse_launch splits the view into z-ranges)
+    int xcd_swizzle;         // tiled kernels: n > 0 rotates the x-brick of a workgroup by (z-brick >> (n - 1)) (see k_sdf_fuse_tiled)
 };
 
 struct Obs {
@@ -407,7 +408,14 @@ __global__ __launch_bounds__(256) void k_sdf_fuse_tiled(const FuseParams p, cons
     __shared__ int s_bad[4];
     __shared__ float4 s_tz[ZC]; // exact mode: {pz, T(0,2)*pz, T(1,2)*pz, T(2,2)*pz} per slice
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int x0 = (blockIdx.x * LX + (lane & (LX - 1))) * 2;
+    // Workgroups go to the 8 XCDs round-robin by linear id, and the grid is 8 bricks wide at 512 voxels: blockIdx.x alone
+    // would pin an x-slab of the volume to an XCD, and a scene that leaves the outer slabs half empty (the walls of
+    // S_room) leaves two XCDs idle while six finish.  Rotating the x-brick by the z-brick gives every XCD every x-slab;
+    // an XCD still works on one x-slab at a time (all y-bricks of a layer), so the image columns its bricks stage stay
+    // in its L2 (rotating by the y-brick as well made S_full 12 % slower: every XCD then cycles through the whole image).
+    // Measured, interleaved on one box (scripts/ab_xcd_swizzle.sh): S_room fast 0.438 -> 0.410 ms, S_full unchanged.
+    const int bxi = p.xcd_swizzle ? (int)((blockIdx.x + (blockIdx.z >> (p.xcd_swizzle - 1))) % gridDim.x) : (int)blockIdx.x;
+    const int x0 = (bxi * LX + (lane & (LX - 1))) * 2;
     const int y = blockIdx.y * BY + (wv % WY) * RW + lane / LX;
     const int zbeg = blockIdx.z * ZC;
     const int zend = min(zbeg + ZC, p.Z);
@@ -726,7 +734,7 @@ __global__ __launch_bounds__(256) void k_sdf_fuse_tiled(const FuseParams p, cons
                     mn = fminf(mn, q[0]); mx = fmaxf(mx, q[1]); cnt += __float_as_int(q[2]);
                 }
             }
-            const int bx = p.sum_bx0 + blockIdx.x * NXB + xb, by = p.sum_by0 + blockIdx.y, bz = p.sum_bz0 + (zbeg + p.zoff_local) / 8 + zb;
+            const int bx = p.sum_bx0 + bxi * NXB + xb, by = p.sum_by0 + blockIdx.y, bz = p.sum_bz0 + (zbeg + p.zoff_local) / 8 + zb;
             if (cnt > 0 && bx * 8 < p.sum_w && by * 8 < p.sum_h && bz * 8 < p.sum_d) {
                 const int total = min(8, p.sum_w - bx * 8) * min(8, p.sum_h - by * 8) * min(8, p.sum_d - bz * 8);
                 float4* r = p.sum_R + ((size_t)bz * p.sum_nby + by) * p.sum_nbx + bx;
@@ -1256,6 +1264,8 @@ static int fuse_params(FuseParams& p, bool* small_images, const kfx_volume* vol,
     p.npitch = *small_images ? (unsigned)norm->pitch : 0u;
     p.sum_R = nullptr;
     p.sum_nbx = p.sum_nby = p.sum_bx0 = p.sum_by0 = p.sum_bz0 = p.sum_w = p.sum_h = p.sum_d = p.zoff_local = 0;
+    static const int swizzle_env = [] { const char* e = getenv("KFX_FUSE_XCD_SWIZZLE"); const int v = e ? atoi(e) : 1; return v < 0 ? 0 : (v > 8 ? 8 : v); }();
+    p.xcd_swizzle = swizzle_env;
     // launch-wide half of the operand-range test of the exact kernel's shared-reciprocal arithmetic (finish_shared);
     // KFX_FUSE_EXACT_SHARED=0 keeps hipcc's own division / square-root expansions (A/B, and the parity suite runs both)
     static const int shared_env = [] { const char* e = getenv("KFX_FUSE_EXACT_SHARED"); return e ? atoi(e) : 1; }();
