@@ -397,17 +397,22 @@ __global__ __launch_bounds__(256) void k_sdf_fuse_tiled(const FuseParams p, cons
     constexpr int RW = 64 / LX, WZ = 4 / WY, ZW = ZC / WZ, BY = RW * WY;
     static_assert(LX * RW == 64 && WY * WZ == 4 && ZW * WZ == ZC && ZW % ZU == 0, "brick geometry");
     constexpr int NG = ZW / 8, NXB = LX / 4, NZB = ZC / 8; // summary bricks: z-groups per wave, per workgroup along x and z
-    static_assert(!TRACK || (BY == 8 && ZW % 8 == 0 && NG <= 2), "summary bricks are 8 x 8 x 8");
+    static_assert(!TRACK || (BY == 8 && ZW % 8 == 0 && NG <= 2 && 8 % ZU == 0), "summary bricks are 8 x 8 x 8");
     __shared__ float s_part[TRACK ? 4 * 2 * 8 * 3 : 1];
-    float t_mn0 = __builtin_inff(), t_mx0 = -__builtin_inff(), t_mn1 = __builtin_inff(), t_mx1 = -__builtin_inff();
-    int t_cnt0 = 0, t_cnt1 = 0;
+    // TRACK results per 8-slice group of the wave (NG of them): range of the cell values it stored, the lanes that updated
+    // both of their cells in every slice, slices seen.  Lanes outside the extents keep these defaults.
+    float r_mn[2] = {__builtin_inff(), __builtin_inff()}, r_mx[2] = {-__builtin_inff(), -__builtin_inff()};
+    unsigned long long r_all[2] = {0ull, 0ull};
+    int r_nz[2] = {0, 0};
     extern __shared__ __attribute__((aligned(16))) float4 s_tile[];
     __shared__ float s_pz[ZC];
     __shared__ float s_box[4][6];
     __shared__ float s_dmax[4];
     __shared__ int s_bad[4];
     __shared__ float4 s_tz[ZC]; // exact mode: {pz, T(0,2)*pz, T(1,2)*pz, T(2,2)*pz} per slice
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    // (the wave index through readfirstlane: the compiler cannot tell that tid >> 6 is wave-uniform, and without it the slice
+    // loop's bounds, the loop branch and everything derived from them are computed per lane)
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     // Workgroups go to the 8 XCDs round-robin by linear id, and the grid is 8 bricks wide at 512 voxels: blockIdx.x alone
     // would pin an x-slab of the volume to an XCD, and a scene that leaves the outer slabs half empty (the walls of
     // S_room) leaves two XCDs idle while six finish.  Rotating the x-brick by the z-brick gives every XCD every x-slab;
@@ -517,22 +522,43 @@ __global__ __launch_bounds__(256) void k_sdf_fuse_tiled(const FuseParams p, cons
         const float bound = -(p.trunc / p.mincos) * 1.001f;
         if (dmax + fabsf(dmax) * 1e-5f - zmin < bound) return; // also when every texel is NaN (dmax = -inf)
     }
-    // values written this frame, per 8-slice group of this wave (TRACK)
-    // Called for a cell pair that was loaded, updated (one or both cells) and stored.  Both cells enter the range: a cell
-    // that was not updated keeps a value that belongs to the brick anyway (NaN is ignored by min3 / max3), so the range
-    // stays conservative and two instructions suffice; only the count is per updated cell.
-    auto note = [&](int z, const float4& c, bool ok0, bool ok1) {
-        if constexpr (TRACK) {
-            const int n = (int)ok0 + (int)ok1;
-            if (NG == 1 || z - wz0 < 8) {
-                t_mn0 = __builtin_fminf(__builtin_fminf(t_mn0, c.x), c.z); t_mx0 = __builtin_fmaxf(__builtin_fmaxf(t_mx0, c.x), c.z); t_cnt0 += n;
-            } else {
-                t_mn1 = __builtin_fminf(__builtin_fminf(t_mn1, c.x), c.z); t_mx1 = __builtin_fmaxf(__builtin_fmaxf(t_mx1, c.x), c.z); t_cnt1 += n;
-            }
-        }
-    };
     auto march = [&]() {
         if (!live) return;
+
+        // TRACK bookkeeping of the group the wave is in.  The lane mask lives in scalar registers and the per-pair cost is one
+        // v_min3, one v_max3 and three scalar instructions (the fast kernel is co-limited by vector issue).
+        // note_pair: every cell pair of every slice, in wave-uniform control flow (`ok` = the cell is updated).  note_vals: a
+        // pair that was loaded, updated (one or both cells) and stored -- both cells enter the range: a cell that was not
+        // updated keeps a value that belongs to the brick anyway (NaN is ignored by min3 / max3), so the range stays
+        // conservative.  next_group: the wave moves from its first 8 slices to its second.  flush: before leaving.
+        float t_mn = __builtin_inff(), t_mx = -__builtin_inff();
+        unsigned long long t_all = ~0ull;
+        int t_nz = 0, t_g = 0;
+        auto note_pair = [&](bool ok0, bool ok1) {
+            if constexpr (TRACK) {
+                t_all &= __ballot(ok0) & __ballot(ok1);
+                t_nz += 1;
+            }
+        };
+        auto note_vals = [&](const float4& c) {
+            if constexpr (TRACK) {
+                t_mn = __builtin_fminf(__builtin_fminf(t_mn, c.x), c.z);
+                t_mx = __builtin_fmaxf(__builtin_fmaxf(t_mx, c.x), c.z);
+            }
+        };
+        auto flush = [&]() {
+            if constexpr (TRACK) {
+                r_mn[t_g] = t_mn; r_mx[t_g] = t_mx; r_all[t_g] = t_all; r_nz[t_g] = t_nz;
+            }
+        };
+        auto next_group = [&](int z) {
+            if constexpr (TRACK && NG == 2) {
+                if (z - wz0 == 8) { // uniform
+                    flush();
+                    t_mn = __builtin_inff(); t_mx = -__builtin_inff(); t_all = ~0ull; t_nz = 0; t_g = 1;
+                }
+            }
+        };
 
         // one voxel's observation, corners from the LDS tile when the cell lies inside it
         auto observe_tile = [&](int v, float pz) -> Obs {
@@ -605,21 +631,26 @@ __global__ __launch_bounds__(256) void k_sdf_fuse_tiled(const FuseParams p, cons
                 // (requesting the cells of slice z and consuming them after the observation of slice z + 1 -- a software
                 // pipeline -- was measured and changes nothing: 0.54 ms either way, the loop is bound by instruction issue)
                 for (int z = wz0; z < wz1; ++z, cell += p.vimg_pitch) {
+                    next_group(z);
                     Obs o[2];
-                    if (observe_pair(z, o)) {
+                    const bool any = observe_pair(z, o);
+                    note_pair(o[0].ok, o[1].ok);
+                    if (any) {
                         float4 c = CELL::ld2(cell);
                         if (o[0].ok) accumulate<false, CELL>(o[0], p.max_w, c.x, c.y);
                         if (o[1].ok) accumulate<false, CELL>(o[1], p.max_w, c.z, c.w);
                         CELL::st2(cell, c);
-                        note(z, c, o[0].ok, o[1].ok);
+                        note_vals(c);
                     }
                 }
+                flush();
                 return;
             }
         }
         if (use_tile) {
             const int cxmax = tw - 2, cymax = th - 2;
             for (int z = wz0; z < wz1; z += ZU, cell += (size_t)ZU * p.vimg_pitch) {
+                next_group(z);
                 Obs o[ZU][2];
                 bool any[ZU];
                 bool stray = false;
@@ -657,6 +688,9 @@ __global__ __launch_bounds__(256) void k_sdf_fuse_tiled(const FuseParams p, cons
                             any[k] = o[k][0].ok || o[k][1].ok;
                         }
                 }
+    #pragma unroll
+                for (int k = 0; k < ZU; ++k)
+                    if (z + k < wz1) note_pair(o[k][0].ok, o[k][1].ok); // uniform
                 float4 c[ZU];
     #pragma unroll
                 for (int k = 0; k < ZU; ++k)
@@ -667,12 +701,14 @@ __global__ __launch_bounds__(256) void k_sdf_fuse_tiled(const FuseParams p, cons
                         if (o[k][0].ok) accumulate<FAST, CELL>(o[k][0], p.max_w, c[k].x, c[k].y);
                         if (o[k][1].ok) accumulate<FAST, CELL>(o[k][1], p.max_w, c[k].z, c[k].w);
                         CELL::st2(cell + (size_t)k * p.vimg_pitch, c[k]);
-                        note(z + k, c[k], o[k][0].ok, o[k][1].ok);
+                        note_vals(c[k]);
                     }
             }
+            flush();
             return;
         }
         for (int z = wz0; z < wz1; z += ZU, cell += (size_t)ZU * p.vimg_pitch) {
+            next_group(z);
             Obs o[ZU][2];
             bool any[ZU];
     #pragma unroll
@@ -683,6 +719,7 @@ __global__ __launch_bounds__(256) void k_sdf_fuse_tiled(const FuseParams p, cons
                     o[k][0] = observe_tile(0, pz);
                     o[k][1] = observe_tile(1, pz);
                     any[k] = o[k][0].ok || o[k][1].ok;
+                    note_pair(o[k][0].ok, o[k][1].ok);
                 }
             }
             float4 c[ZU];
@@ -695,51 +732,56 @@ __global__ __launch_bounds__(256) void k_sdf_fuse_tiled(const FuseParams p, cons
                     if (o[k][0].ok) accumulate<FAST, CELL>(o[k][0], p.max_w, c[k].x, c[k].y);
                     if (o[k][1].ok) accumulate<FAST, CELL>(o[k][1], p.max_w, c[k].z, c[k].w);
                     CELL::st2(cell + (size_t)k * p.vimg_pitch, c[k]);
-                    note(z + k, c[k], o[k][0].ok, o[k][1].ok);
+                    note_vals(c[k]);
                 }
         }
+        flush();
     };
     march();
 
     if constexpr (TRACK) {
         // ---- summary epilogue: every thread of the workgroup arrives here (the early exits above are workgroup-uniform
         // and leave the summary as it is: nothing was written) ----
+        const auto fmin2 = [](float a, float b) { return fminf(a, b); };
+        const auto fmax2 = [](float a, float b) { return fmaxf(a, b); };
+        // lanes of this lane's summary brick within the wave: 4 neighbours in x (8 cells), every row
+        const unsigned long long brick = (LX == 32 ? 0x0000000F0000000Full : 0x000F000F000F000Full) << (lane & (LX - 1) & ~3);
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
-            float mn = g ? t_mn1 : t_mn0, mx = g ? t_mx1 : t_mx0;
-            int cnt = g ? t_cnt1 : t_cnt0;
-            // lanes of one summary brick: 4 neighbours in x (8 cells) and all rows of the wave
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                if (off == 4) off = LX; // skip the lane bits that select the x-brick
-                mn = fminf(mn, __shfl_xor(mn, off, 64));
-                mx = fmaxf(mx, __shfl_xor(mx, off, 64));
-                cnt += __shfl_xor(cnt, off, 64);
-            }
+            float mn = r_mn[g], mx = r_mx[g];
+            // reduce over the brick's lanes: DPP within the 4 x-neighbours, row / half swaps across the rows
+            mn = wave_xor_combine<1>(mn, fmin2); mx = wave_xor_combine<1>(mx, fmax2);
+            mn = wave_xor_combine<2>(mn, fmin2); mx = wave_xor_combine<2>(mx, fmax2);
+            if constexpr (LX == 16) { mn = wave_xor_combine<16>(mn, fmin2); mx = wave_xor_combine<16>(mx, fmax2); }
+            mn = wave_xor_combine<32>(mn, fmin2); mx = wave_xor_combine<32>(mx, fmax2);
             if ((lane & 3) == 0 && lane < LX) {
+                // every cell of the brick's part in this wave was updated: all 8 slices seen, every lane updated both cells in each
+                const int full = (r_nz[g] == 8 && (r_all[g] & brick) == brick) ? 1 : 0;
                 float* q = s_part + ((wv * 2 + g) * 8 + (lane >> 2)) * 3;
-                q[0] = mn; q[1] = mx; q[2] = __int_as_float(cnt);
+                q[0] = mn; q[1] = mx; q[2] = __int_as_float(full);
             }
         }
         __syncthreads();
         if (tid < NXB * NZB) {
             const int xb = tid % NXB, zb = tid / NXB;
             float mn = __builtin_inff(), mx = -__builtin_inff();
-            int cnt = 0;
+            int full = 1;
 #pragma unroll
             for (int w4 = 0; w4 < 4; ++w4) { // the waves whose slices include summary z-brick zb
                 const int g = zb - (w4 / WY) * NG;
                 if (g >= 0 && g < NG) {
                     const float* q = s_part + ((w4 * 2 + g) * 8 + xb) * 3;
-                    mn = fminf(mn, q[0]); mx = fmaxf(mx, q[1]); cnt += __float_as_int(q[2]);
+                    mn = fminf(mn, q[0]); mx = fmaxf(mx, q[1]); full &= __float_as_int(q[2]);
                 }
             }
+            const bool some = mx > -__builtin_inff(); // an updated cell holds a number, and it entered the range
             const int bx = p.sum_bx0 + bxi * NXB + xb, by = p.sum_by0 + blockIdx.y, bz = p.sum_bz0 + (zbeg + p.zoff_local) / 8 + zb;
-            if (cnt > 0 && bx * 8 < p.sum_w && by * 8 < p.sum_h && bz * 8 < p.sum_d) {
-                const int total = min(8, p.sum_w - bx * 8) * min(8, p.sum_h - by * 8) * min(8, p.sum_d - bz * 8);
+            if (some && bx * 8 < p.sum_w && by * 8 < p.sum_h && bz * 8 < p.sum_d) {
                 float4* r = p.sum_R + ((size_t)bz * p.sum_nby + by) * p.sum_nbx + bx;
                 // state 0: every cell has a value in [lo, hi]; 1: every cell NaN; 2: mixed / unknown
-                if (cnt == total) { // every cell rewritten: the frame's range, no need to know the old one
+                // `full`: all 8 x 8 x 8 cells were updated (a brick cut by the volume's or the launch's extents never is: it
+                // takes the merge below, which is always valid)
+                if (full) { // every cell rewritten: the frame's range, no need to know the old one
                     *r = make_float4(mn, mx, __int_as_float(0), 0.f);
                 } else {
                     float4 old = *r;

@@ -89,6 +89,28 @@ __device__ __forceinline__ float sqrt_core(float x)
     return __builtin_fmaf(d, h, s);
 }
 
+// op(x[lane], x[lane ^ OFF]) for OFF in {1, 2, 16, 32} without the LDS crossbar of __shfl_xor (ds_bpermute): DPP quad
+// permutes within 4 lanes; v_permlane16_swap / v_permlane32_swap (gfx950) exchange odd and even rows / the two halves of a
+// wave -- called with both operands equal they return (even-side value, odd-side value) in every lane, which is all a
+// commutative op needs.
+template <int OFF, typename F>
+__device__ __forceinline__ float wave_xor_combine(float x, F op)
+{
+    static_assert(OFF == 1 || OFF == 2 || OFF == 16 || OFF == 32, "lane distance");
+    const unsigned u = __float_as_uint(x);
+    if constexpr (OFF == 1 || OFF == 2) {
+        const int o = __builtin_amdgcn_update_dpp(0, (int)u, OFF == 1 ? 0xB1 : 0x4E, 0xF, 0xF, true); // quad_perm [1,0,3,2] / [2,3,0,1]
+        return op(x, __uint_as_float((unsigned)o));
+    } else if constexpr (OFF == 16) {
+        const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+        return op(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    } else {
+        const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+        return op(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    }
+}
+
+
 // Row-major 3x4 pose, roo::Mat<float,3,4> (Mat.h:33-163)
 struct Pose { float m[12]; };
 // ImageIntrinsics {fu, fv, u0, v0} (ImageIntrinsics.h:51-200)

@@ -7,7 +7,7 @@ from kangaroo_amd import roo, scenes
 from kangaroo_amd.pipeline import FramePipeline
 
 N, w, h = 512, 640, 480
-scene = sys.argv[1] if len(sys.argv) > 1 else "full"
+scene = "full"
 bmin, bmax, near, far = scenes.SCENES[scene]
 roo.set_math_mode("fast")
 K = scenes.intrinsics(w, h)
@@ -19,6 +19,11 @@ for T in poses:
     im.MemcpyFromHost(scenes.render_depth(scene, w, h, T, K))
     frames.append(im)
 torch.cuda.synchronize()
+if "--count" in sys.argv:   # what bench.py does before its warm-up: 30 diagnostic launches
+    for i in range(30):
+        pipe.preprocess(frames[i])
+        roo.SdfFuseCount(pipe.vol, pipe.filtered, pipe.normals, scenes.se3_inverse(poses[i]), K, pipe.trunc, pipe.mincostheta)
+    torch.cuda.synchronize()
 
 def run(n, label):
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(n)]
@@ -40,7 +45,5 @@ def run(n, label):
     for k in range(0, n, B):
         print("  steps %4d-%4d  (t = %4.0f ms)  fuse %.4f  raycast %.4f" % (k, k + B - 1, 1e3 * el * k / n, f[k:k + B].mean(), r[k:k + B].mean()))
 
-run(1800, "cold start")
-time.sleep(2.0)
-run(900, "after 2 s idle")
-run(900, "back to back")
+run(900, "cold start")
+run(450, "back to back")
