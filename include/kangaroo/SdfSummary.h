@@ -56,4 +56,21 @@ inline void RaycastSdf(Image<float> depth, Image<float4> norm, Image<float> img,
                                            subpix ? 1 : 0, 0));
 }
 
+// RaycastSdfLevels (cu_raycast.h: several renderings of the model in one launch) with the summary consulted in every march
+inline void RaycastSdfLevels(const Image<float>* depth, const Image<float4>* norm, const Image<float>* img, unsigned n,
+                             const BoundedVolume<SDF_t> vol, SdfSummary& summary, const Mat<float,3,4> T_wc, const ImageIntrinsics* K,
+                             float near, float far, float trunc_dist, bool subpix = true, const Image<float4>* vbo = 0)
+{
+    const kfx_image *d[8], *nn[8], *im[8], *vb[8];
+    float k[32];
+    if (n > 8) GpuCheckStatus(KFX_E_RANGE);
+    for (unsigned l = 0; l < n && l < 8; ++l) {
+        d[l] = depth[l].abi(); nn[l] = norm[l].abi(); im[l] = img[l].abi();
+        vb[l] = vbo ? vbo[l].abi() : 0;
+        k[4 * l] = K[l].fu; k[4 * l + 1] = K[l].fv; k[4 * l + 2] = K[l].u0; k[4 * l + 3] = K[l].v0;
+    }
+    GpuCheckStatus(kfx_raycast_sdf_levels_tracked((int)n, d, nn, im, vbo ? vb : 0, vol.abi(), summary.get(), T_wc.m, k, near, far, trunc_dist,
+                                                  subpix ? 1 : 0, 0));
+}
+
 }

@@ -388,6 +388,10 @@ int kfx_sdf_fuse_tracked(const kfx_volume* vol, kfx_sdf_summary* s, const kfx_im
 int kfx_raycast_sdf_tracked(const kfx_image* depth, const kfx_image* norm, const kfx_image* img, const kfx_volume* vol,
                             kfx_sdf_summary* s, const float T_wc[12], const float K[4], float near, float far,
                             float trunc_dist, int subpix, kfx_stream stream);
+/* kfx_raycast_sdf_levels (several renderings of the model in one launch) with the summary consulted in every march */
+int kfx_raycast_sdf_levels_tracked(int n_levels, const kfx_image* const* depth, const kfx_image* const* norm, const kfx_image* const* img,
+                                   const kfx_image* const* vbo, const kfx_volume* vol, kfx_sdf_summary* s, const float T_wc[12],
+                                   const float* K, float near, float far, float trunc_dist, int subpix, kfx_stream stream);
 
 /* ---- numerics mode --------------------------------------------------------------- */
 /* KFX_MATH_EXACT (default): IEEE fp32, no FMA contraction, correctly rounded div/sqrt, reference

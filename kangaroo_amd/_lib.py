@@ -122,6 +122,7 @@ SIGNATURES = {
     "kfx_sdf_reset_tracked": (C.c_int, [PV, C.c_void_p, C.c_float, C.c_void_p]),
     "kfx_sdf_fuse_tracked": (C.c_int, [PV, C.c_void_p, PI, PI, PF, PF, C.c_float, C.c_float, C.c_float, C.c_uint, C.c_void_p]),
     "kfx_raycast_sdf_tracked": (C.c_int, [PI, PI, PI, PV, C.c_void_p, PF, PF, C.c_float, C.c_float, C.c_float, C.c_int, C.c_void_p]),
+    "kfx_raycast_sdf_levels_tracked": (C.c_int, [C.c_int, C.POINTER(PI), C.POINTER(PI), C.POINTER(PI), C.POINTER(PI), PV, C.c_void_p, PF, PF, C.c_float, C.c_float, C.c_float, C.c_int, C.c_void_p]),
 }
 
 _lib = None

@@ -191,6 +191,58 @@ __device__ __forceinline__ float raycast_pixel(const RayParams& p, const ColorGe
     return depth > 0 ? depth : __builtin_nanf(""); // the value written to the depth image
 }
 
+// SKIP kernels, workgroup prologue: decide whether the summary is worth consulting and, if so, stage its coarse levels in
+// LDS (`s_sum`: level 2, n2 entries; then level 3, n3 entries).  Returns the (workgroup-uniform) decision.
+__device__ __forceinline__ bool summary_stage(const SummaryView& sv, float* s_sum, const float*& lds_D3, const float*& lds_D2)
+{
+    // worth it?  add up the table build's per-workgroup counts (at most 1024 of them: four loads per thread)
+    int useful = 0;
+    for (int i = threadIdx.x; i < sv.n_partials; i += 256) useful += sv.useful[i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) useful += __shfl_xor(useful, off, 64);
+    int* cnt = reinterpret_cast<int*>(s_sum);
+    if ((threadIdx.x & 63) == 0) cnt[threadIdx.x >> 6] = useful;
+    __syncthreads();
+    useful = cnt[0] + cnt[1] + cnt[2] + cnt[3];
+    __syncthreads(); // (s_sum is reused for the tables)
+    const bool use_summary = sv.force > 0 || (sv.force == 0 && (long long)useful * 10 >= (long long)sv.n2 * 9); // workgroup-uniform
+    if (!use_summary) return false;
+    // every workgroup stages level 2 in LDS (16-byte loads, all in flight together) and derives level 3 (4 x 4 x 4
+    // level-2 entries each) from it: a few hundred LDS operations instead of another launch per frame
+    float* l2 = s_sum;
+    float* l3 = s_sum + ((sv.n2 + 3) & ~3);
+    const int n4 = sv.n2 >> 2;
+    const float4* src4 = reinterpret_cast<const float4*>(sv.D2);
+    for (int i = threadIdx.x; i < n4; i += 256) reinterpret_cast<float4*>(l2)[i] = src4[i];
+    for (int i = (n4 << 2) + threadIdx.x; i < sv.n2; i += 256) l2[i] = sv.D2[i];
+    __syncthreads();
+    for (int i = threadIdx.x; i < sv.n3; i += 256) {
+        const int bx = i % sv.n3x, by = (i / sv.n3x) % sv.n3y, bz = i / (sv.n3x * sv.n3y);
+        float lo = __builtin_inff(), hi = -__builtin_inff();
+        bool all_nan = true, all_val = true, any_useful = false;
+        for (int dz = 0; dz < 4; ++dz)
+            for (int dy = 0; dy < 4; ++dy)
+                for (int dx = 0; dx < 4; ++dx) {
+                    const int x = bx * 4 + dx, y = by * 4 + dy, z = bz * 4 + dz;
+                    if (x >= sv.n2x || y >= sv.n2y || z >= sv.n2z) continue;
+                    const float v2 = l2[(z * sv.n2y + y) * sv.n2x + x];
+                    const bool isn = v2 != v2, isv = v2 > 0.f;
+                    all_nan = all_nan && isn;
+                    all_val = all_val && isv;
+                    any_useful = any_useful || isn || isv;
+                    if (isv) { lo = fminf(lo, v2); hi = fmaxf(hi, v2); }
+                }
+        float out = any_useful ? -1.0f : -2.0f;
+        if (all_nan) out = __builtin_nanf("");
+        else if (all_val && hi - lo <= sv.tol * hi) out = sv.tol > 0.f ? 0.5f * (lo + hi) : lo;
+        l3[i] = out;
+    }
+    __syncthreads();
+    lds_D3 = l3;
+    lds_D2 = l2;
+    return true;
+}
+
 template <typename CELL, bool COLOR, bool SKIP = false>
 __global__ __launch_bounds__(256) void k_raycast_sdf(const RayParams p, const ColorGeom cv, const SummaryView sv = SummaryView{})
 {
@@ -206,54 +258,7 @@ __global__ __launch_bounds__(256) void k_raycast_sdf(const RayParams p, const Co
     extern __shared__ float s_sum[];   // SKIP: level 2 (n2 entries), then level 3 (n3), then one counter
     const float *lds_D3 = nullptr, *lds_D2 = nullptr;
     bool use_summary = false;
-    if constexpr (SKIP) {
-        // worth it?  add up the table build's per-workgroup counts (at most 1024 of them: four loads per thread)
-        int useful = 0;
-        for (int i = threadIdx.x; i < sv.n_partials; i += 256) useful += sv.useful[i];
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) useful += __shfl_xor(useful, off, 64);
-        int* cnt = reinterpret_cast<int*>(s_sum);
-        if ((threadIdx.x & 63) == 0) cnt[threadIdx.x >> 6] = useful;
-        __syncthreads();
-        useful = cnt[0] + cnt[1] + cnt[2] + cnt[3];
-        __syncthreads(); // (s_sum is reused for the tables)
-        use_summary = sv.force > 0 || (sv.force == 0 && (long long)useful * 10 >= (long long)sv.n2 * 9); // workgroup-uniform
-    }
-    if (SKIP && use_summary) {
-        // every workgroup stages level 2 in LDS (16-byte loads, all in flight together) and derives level 3 (4 x 4 x 4
-        // level-2 entries each) from it: a few hundred LDS operations instead of another launch per frame
-        float* l2 = s_sum;
-        float* l3 = s_sum + ((sv.n2 + 3) & ~3);
-        const int n4 = sv.n2 >> 2;
-        const float4* src4 = reinterpret_cast<const float4*>(sv.D2);
-        for (int i = threadIdx.x; i < n4; i += 256) reinterpret_cast<float4*>(l2)[i] = src4[i];
-        for (int i = (n4 << 2) + threadIdx.x; i < sv.n2; i += 256) l2[i] = sv.D2[i];
-        __syncthreads();
-        for (int i = threadIdx.x; i < sv.n3; i += 256) {
-            const int bx = i % sv.n3x, by = (i / sv.n3x) % sv.n3y, bz = i / (sv.n3x * sv.n3y);
-            float lo = __builtin_inff(), hi = -__builtin_inff();
-            bool all_nan = true, all_val = true, any_useful = false;
-            for (int dz = 0; dz < 4; ++dz)
-                for (int dy = 0; dy < 4; ++dy)
-                    for (int dx = 0; dx < 4; ++dx) {
-                        const int x = bx * 4 + dx, y = by * 4 + dy, z = bz * 4 + dz;
-                        if (x >= sv.n2x || y >= sv.n2y || z >= sv.n2z) continue;
-                        const float v2 = l2[(z * sv.n2y + y) * sv.n2x + x];
-                        const bool isn = v2 != v2, isv = v2 > 0.f;
-                        all_nan = all_nan && isn;
-                        all_val = all_val && isv;
-                        any_useful = any_useful || isn || isv;
-                        if (isv) { lo = fminf(lo, v2); hi = fmaxf(hi, v2); }
-                    }
-            float out = any_useful ? -1.0f : -2.0f;
-            if (all_nan) out = __builtin_nanf("");
-            else if (all_val && hi - lo <= sv.tol * hi) out = sv.tol > 0.f ? 0.5f * (lo + hi) : lo;
-            l3[i] = out;
-        }
-        __syncthreads();
-        lds_D3 = l3;
-        lds_D2 = l2;
-    }
+    if constexpr (SKIP) use_summary = summary_stage(sv, s_sum, lds_D3, lds_D2);
     int u, v;
     if (p.sparse_lanes) { // only the first sparse_lanes lanes of a wave carry rays (a strip of one pixel row): small images
         const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -290,9 +295,13 @@ struct RayLevels {
     int n;
 };
 
-template <typename CELL>
-__global__ __launch_bounds__(256) void k_raycast_sdf_levels(const RayParams base, const RayLevels L)
+template <typename CELL, bool SKIP = false>
+__global__ __launch_bounds__(256) void k_raycast_sdf_levels(const RayParams base, const RayLevels L, const SummaryView sv = SummaryView{})
 {
+    extern __shared__ float s_sum[];
+    const float *lds_D3 = nullptr, *lds_D2 = nullptr;
+    bool use_summary = false;
+    if constexpr (SKIP) use_summary = summary_stage(sv, s_sum, lds_D3, lds_D2); // before any lane leaves (barriers inside)
     int l = 0;
     for (int k = 1; k < L.n; ++k)
         if ((int)blockIdx.x >= L.lv[k].first_block) l = k; // uniform
@@ -314,7 +323,7 @@ __global__ __launch_bounds__(256) void k_raycast_sdf_levels(const RayParams base
     } else {
         ray_pixel_of(p, b % lv.blocks_x, b / lv.blocks_x, threadIdx.x, u, v);
     }
-    const float kz = raycast_pixel<CELL, false>(p, ColorGeom{}, u, v);
+    const float kz = raycast_pixel<CELL, false, SKIP>(p, ColorGeom{}, u, v, sv, lds_D3, lds_D2, use_summary);
     if (lv.vptr && u < p.w && v < p.h) // the application's DepthToVbo(ray_v[l], ray_d[l], K[l]) (main.cpp:286), same expression
         reinterpret_cast<float4*>(lv.vptr + (size_t)v * lv.vpitch)[u] =
             make_float4(kz * ((float)u - p.K.u0) / p.K.fu, kz * ((float)v - p.K.v0) / p.K.fv, kz, 1.0f);
@@ -484,10 +493,34 @@ static int ray_params(RayParams& p, const kfx_image* depth, const kfx_image* nor
     return 0;
 }
 
+// The march's view of a summary for a launch on `vol` (the summary's volume or an aligned view of it): brings the tables up
+// to date on `stream` and reports the LDS bytes a SKIP kernel needs.
+// fast numerics: bricks whose values agree to 1e-5 count as uniform (observed free space: the running average of
+// +trunc drifts by a few ulp per frame); exact numerics: bit-identical cells only
+static int summary_view(SummaryView& sv, size_t* lds_bytes, kfx_sdf_summary* summary, const kfx_volume* vol, kfx_stream stream)
+{
+    if (int e = summary_view_offset(summary, vol, &sv.ox, &sv.oy, &sv.oz)) return e;
+    if (int e = summary_prepare(summary, math_mode() == KFX_MATH_FAST ? 1e-5f : 0.f, (hipStream_t)stream)) return e;
+    sv.D = summary->D; sv.D2 = summary->D2; sv.D3 = summary->D3;
+    sv.nbx = summary->nbx; sv.nby = summary->nby;
+    sv.n2x = summary->n2x; sv.n2y = summary->n2y;
+    sv.n3x = summary->n3x; sv.n3y = summary->n3y;
+    sv.n3 = summary->n3x * summary->n3y * summary->n3z;
+    sv.n2 = summary->n2x * summary->n2y * summary->n2z;
+    sv.n2z = summary->n2z;
+    sv.tol = math_mode() == KFX_MATH_FAST ? 1e-5f : 0.f;
+    sv.useful = summary->useful2;
+    sv.n_partials = summary->n_partials;
+    static const int force_env = [] { const char* e = getenv("KFX_RAYCAST_SUMMARY"); return e ? atoi(e) : 0; }(); // 1: always, -1: never, 0: by the counter
+    sv.force = force_env;
+    *lds_bytes = (size_t)(((sv.n2 + 3) & ~3) + sv.n3 + 4) * sizeof(float);
+    return 0;
+}
+
 template <typename CELL>
 static int raycast_levels_launch(int n_levels, const kfx_image* const* depth, const kfx_image* const* norm, const kfx_image* const* img,
                                  const kfx_image* const* vbo, const kfx_volume* vol, const float T_wc[12], const float* K, float near, float far,
-                                 float trunc_dist, int subpix, kfx_stream stream)
+                                 float trunc_dist, int subpix, kfx_stream stream, kfx_sdf_summary* summary = nullptr)
 {
     if (n_levels < 0 || n_levels > RAY_MAX_LEVELS) return set_error(KFX_E_RANGE, "RaycastSdf(levels): number of levels");
     if (!depth || !norm || !img || !K) return set_error(KFX_E_NULL, "RaycastSdf(levels): null argument");
@@ -521,7 +554,20 @@ static int raycast_levels_launch(int n_levels, const kfx_image* const* depth, co
         base = p;
     }
     if (L.n == 0) return 0;
-    hipLaunchKernelGGL(k_raycast_sdf_levels<CELL>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, base, L);
+    if (summary) {
+        if constexpr (CELL::BYTES == 8) {
+            SummaryView sv;
+            size_t lds_bytes = 0;
+            if (int e = summary_view(sv, &lds_bytes, summary, vol, stream)) return e;
+            if (lds_bytes <= 60 * 1024) {
+                hipLaunchKernelGGL((k_raycast_sdf_levels<CELL, true>), dim3(blocks), dim3(256), lds_bytes, (hipStream_t)stream, base, L, sv);
+                return check_launch("kfx_raycast_sdf_levels_tracked");
+            }
+        } else {
+            return set_error(KFX_E_RANGE, "kfx_raycast_sdf_levels_tracked: fp32 cells only");
+        }
+    }
+    hipLaunchKernelGGL((k_raycast_sdf_levels<CELL, false>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, base, L, SummaryView{});
     return check_launch("kfx_raycast_sdf_levels");
 }
 
@@ -557,24 +603,9 @@ static int raycast_launch(const kfx_image* depth, const kfx_image* norm, const k
         set_geometry(cv, colorvol);
         hipLaunchKernelGGL((k_raycast_sdf<CELL, true>), grid, dim3(256), 0, (hipStream_t)stream, p, cv, SummaryView{});
     } else if (summary) {
-        // fast numerics: bricks whose values agree to 1e-5 count as uniform (observed free space: the running average of
-        // +trunc drifts by a few ulp per frame); exact numerics: bit-identical cells only
         SummaryView sv;
-        if (int e = summary_view_offset(summary, vol, &sv.ox, &sv.oy, &sv.oz)) return e;
-        if (int e = summary_prepare(summary, math_mode() == KFX_MATH_FAST ? 1e-5f : 0.f, (hipStream_t)stream)) return e;
-        sv.D = summary->D; sv.D2 = summary->D2; sv.D3 = summary->D3;
-        sv.nbx = summary->nbx; sv.nby = summary->nby;
-        sv.n2x = summary->n2x; sv.n2y = summary->n2y;
-        sv.n3x = summary->n3x; sv.n3y = summary->n3y;
-        sv.n3 = summary->n3x * summary->n3y * summary->n3z;
-        sv.n2 = summary->n2x * summary->n2y * summary->n2z;
-        sv.n2z = summary->n2z;
-        sv.tol = math_mode() == KFX_MATH_FAST ? 1e-5f : 0.f;
-        sv.useful = summary->useful2;
-        sv.n_partials = summary->n_partials;
-        static const int force_env = [] { const char* e = getenv("KFX_RAYCAST_SUMMARY"); return e ? atoi(e) : 0; }(); // 1: always, -1: never, 0: by the counter
-        sv.force = force_env;
-        const size_t lds_bytes = (size_t)(((sv.n2 + 3) & ~3) + sv.n3 + 4) * sizeof(float);
+        size_t lds_bytes = 0;
+        if (int e = summary_view(sv, &lds_bytes, summary, vol, stream)) return e;
         if (lds_bytes > 60 * 1024) { // level 2 does not fit LDS (volumes beyond ~768^3): the plain march
             hipLaunchKernelGGL((k_raycast_sdf<CELL, false>), grid, dim3(256), 0, (hipStream_t)stream, p, cv, SummaryView{});
             return check_launch("kfx_raycast_sdf");
@@ -615,6 +646,14 @@ extern "C" int kfx_raycast_sdf_levels(int n_levels, const kfx_image* const* dept
                                       float trunc_dist, int subpix, kfx_stream stream)
 {
     return raycast_levels_launch<RayF32>(n_levels, depth, norm, img, vbo, vol, T_wc, K, near, far, trunc_dist, subpix, stream);
+}
+
+extern "C" int kfx_raycast_sdf_levels_tracked(int n_levels, const kfx_image* const* depth, const kfx_image* const* norm, const kfx_image* const* img,
+                                              const kfx_image* const* vbo, const kfx_volume* vol, kfx_sdf_summary* summary, const float T_wc[12],
+                                              const float* K, float near, float far, float trunc_dist, int subpix, kfx_stream stream)
+{
+    if (!summary) return set_error(KFX_E_NULL, "kfx_raycast_sdf_levels_tracked: null summary");
+    return raycast_levels_launch<RayF32>(n_levels, depth, norm, img, vbo, vol, T_wc, K, near, far, trunc_dist, subpix, stream, summary);
 }
 
 extern "C" int kfx_raycast_sdf_levels_h(int n_levels, const kfx_image* const* depth, const kfx_image* const* norm, const kfx_image* const* img,

@@ -152,13 +152,14 @@ class TrackingPipeline(FramePipeline):
         else:
             T34 = self.T_wl[:3].astype(np.float32)
             lv = [l for l in range(self.LEVELS) if self.its[l] > 0]
+            kw = {"summary": self.summary} if self.track else {}
             if self.one_raycast:   # the per-level RaycastSdf + DepthToVbo calls as one launch: same images, overlapping marches
                 o.RaycastSdfLevels([(self.pyr_d[l], self.pyr_n[l], self.pyr_i[l], self.pyr_v[l]) for l in lv], self.vol, T34,
-                                   [self.K_levels[l] for l in lv], self.near, self.far, self.trunc, True)
+                                   [self.K_levels[l] for l in lv], self.near, self.far, self.trunc, True, **kw)
             else:
                 for l in lv:
                     o.RaycastSdf(self.pyr_d[l], self.pyr_n[l], self.pyr_i[l], self.vol, T34, self.K_levels[l], self.near,
-                                 self.far, self.trunc, True)
+                                 self.far, self.trunc, True, **kw)
                     o.DepthToVbo(self.pyr_v[l], self.pyr_d[l], self.K_levels[l])
             if self.device_icp:
                 T_lp, self.rmse, _, self.tracking_good = o.IcpRefine(self.kin_v, self.pyr_v, self.pyr_n, self.K_levels, self.its,
@@ -174,7 +175,8 @@ class TrackingPipeline(FramePipeline):
 
     def _fuse_at(self, T_wl):
         T_cw = self.tracking.se3_inv(T_wl)[:3].astype(np.float32)
-        self.ops.SdfFuse(self.vol, self.kin_d[0], self.kin_n[0], T_cw, self.K, self.trunc, self.max_w, self.mincostheta)
+        kw = {"summary": self.summary} if self.track else {}
+        self.ops.SdfFuse(self.vol, self.kin_d[0], self.kin_n[0], T_cw, self.K, self.trunc, self.max_w, self.mincostheta, **kw)
 
 
 def slab_range(d, rank, world):

@@ -311,10 +311,11 @@ def RaycastSdf(depth, norm, img, vol, T_wc, K, near, far, trunc_dist, subpix=Tru
                   _stream(stream)))
 
 
-def RaycastSdfLevels(outputs, vol, T_wc, K_levels, near, far, trunc_dist, subpix=True, stream=None):
+def RaycastSdfLevels(outputs, vol, T_wc, K_levels, near, far, trunc_dist, subpix=True, stream=None, summary=None):
     """kfx_raycast_sdf_levels: the tracking loop's per-level RaycastSdf calls (main.cpp:280-288) as one launch.
     outputs = [(depth, norm, img[, vbo]), ...] per level, K_levels the matching intrinsics; images identical to per-level
-    calls.  A fourth image per level receives DepthToVbo(depth, K) from the same launch (main.cpp:286)."""
+    calls.  A fourth image per level receives DepthToVbo(depth, K) from the same launch (main.cpp:286).
+    summary: an SdfSummary of the volume (kfx_raycast_sdf_levels_tracked), as in RaycastSdf."""
     n = len(outputs)
     assert n == len(K_levels)
     views = [[o[k].view() for o in outputs] for k in range(3)]   # KfxImage structs, kept alive over the call
@@ -323,6 +324,10 @@ def RaycastSdfLevels(outputs, vol, T_wc, K_levels, near, far, trunc_dist, subpix
     vptrs = (_lib.PI * n)(*[C.pointer(v) if v is not None else None for v in vviews]) if any(v is not None for v in vviews) else None
     t, _t = _fp(T_wc, 12)
     k, _k = _fp(np.concatenate([np.asarray(K, np.float32).reshape(4) for K in K_levels]) if n else np.zeros(0, np.float32), 4 * n)
+    if summary is not None:
+        _lib.check(_lib.load().kfx_raycast_sdf_levels_tracked(n, ptrs[0], ptrs[1], ptrs[2], vptrs, vol.ref(), summary.handle, t, k, near, far,
+                                                              trunc_dist, 1 if subpix else 0, _stream(stream)))
+        return
     fn = _lib.load().kfx_raycast_sdf_levels_h if vol.kind == "f16" else _lib.load().kfx_raycast_sdf_levels
     _lib.check(fn(n, ptrs[0], ptrs[1], ptrs[2], vptrs, vol.ref(), t, k, near, far, trunc_dist, 1 if subpix else 0, _stream(stream)))
 

@@ -120,6 +120,51 @@ def test_gpu_tracked_fuse_and_raycast(roo, scene, N, w, h, dims, math):
         roo.set_math_mode(prev)
 
 
+@pytest.mark.parametrize("scene", ["room", "full"])
+def test_gpu_tracked_raycast_of_pyramid_levels_in_one_launch(roo, scene):
+    """kfx_raycast_sdf_levels_tracked: the tracking loop's three renderings (640x480-like pyramid levels 0, 2, 3) from one
+    launch with the summary consulted.  Every image -- and the vertex map of each level -- must equal the per-level tracked
+    call, which in exact numerics equals the plain march bit for bit."""
+    N, w, h = 128, 320, 240
+    bmin, bmax, near, far = scenes.SCENES[scene]
+    K = scenes.intrinsics(w, h)
+    tr = scenes.trunc_dist(bmin, bmax, (N, N, N))
+    prev = roo.set_math_mode("exact")
+    try:
+        vol = roo.BoundedVolume(N, N, N, bmin, bmax)
+        summ = roo.SdfSummary(vol)
+        roo.SdfReset(vol, float("nan"), summary=summ)
+        f, vbo, nrm = roo.Image(w, h), roo.Image(w, h, "f32x4"), roo.Image(w, h, "f32x4")
+        for i in range(2):
+            T_wc = scenes.orbit_pose(i, 30)
+            roo.BilateralFilter(f, T.upload_image(roo, scenes.render_depth(scene, w, h, T_wc, K)), **scenes.BILATERAL)
+            roo.DepthToVbo(vbo, f, K)
+            roo.NormalsFromVbo(nrm, vbo)
+            roo.SdfFuse(vol, f, nrm, scenes.se3_inverse(T_wc), K, tr, scenes.MAX_W, scenes.MIN_COS_THETA, summary=summ)
+        levels = [0, 2, 3]
+        Ks = [scenes.intrinsics_level(K, l) for l in levels]
+        def images(l):
+            return [roo.Image(w >> l, h >> l), roo.Image(w >> l, h >> l, "f32x4"), roo.Image(w >> l, h >> l), roo.Image(w >> l, h >> l, "f32x4")]
+        one = [images(l) for l in levels]
+        roo.RaycastSdfLevels([tuple(o) for o in one], vol, T_wc, Ks, near, far, tr, True, summary=summ)
+        for math in ("exact", "fast"):          # the summary's tolerance follows the numerics mode: compare like with like
+            roo.set_math_mode(math)
+            roo.RaycastSdfLevels([tuple(o) for o in one], vol, T_wc, Ks, near, far, tr, True, summary=summ)
+            for o, l, Kl in zip(one, levels, Ks):
+                ref = images(l)
+                roo.RaycastSdf(ref[0], ref[1], ref[2], vol, T_wc, Kl, near, far, tr, True, summary=summ)
+                roo.DepthToVbo(ref[3], ref[0], Kl)
+                for a, b in zip(o, ref):
+                    assert T.nan_equal(a.MemcpyToHost(), b.MemcpyToHost()), (math, l)
+                if math == "exact":
+                    plain = images(l)
+                    roo.RaycastSdf(plain[0], plain[1], plain[2], vol, T_wc, Kl, near, far, tr, True)
+                    assert T.nan_equal(o[0].MemcpyToHost(), plain[0].MemcpyToHost()) and T.nan_equal(o[1].MemcpyToHost(), plain[1].MemcpyToHost())
+                assert np.isfinite(o[0].MemcpyToHost()).sum() > 0.02 * (w >> l) * (h >> l)
+    finally:
+        roo.set_math_mode(prev)
+
+
 def test_gpu_summary_views_and_untracked_writers(roo):
     """8-aligned views keep tracking, unaligned views and untracked writers drop to 'unknown' (correct, nothing skipped);
     SdfSphere + invalidate; all raycasts equal the untracked kernel bit for bit (exact numerics)."""
