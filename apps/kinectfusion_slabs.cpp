@@ -27,7 +27,7 @@ using namespace roo;
 
 struct Options {
     int volres = 256, frames = 10, w = 640, h = 480, ranks = 1;
-    bool fast = false, rccl = false;
+    bool fast = false, rccl = false, broadcast_inputs = false;
     SlabVolume::HaloMode halo = SlabVolume::HaloExchange;
     SlabVolume::RaycastMode raycast = SlabVolume::Composite;
     std::string rendezvous = "/tmp/kfx_slabs.id";
@@ -105,10 +105,13 @@ static void RunRank(const Options& o, kfx_comm* comm, const std::vector<std::vec
         dMeters.MemcpyFromHost(const_cast<float*>(depth_mm[f].data()));
         comm->barrier(comm);
         const auto t0 = std::chrono::steady_clock::now();
-        ElementwiseScaleBias<float,float,float>(dMeters, dMeters, 1.0f / 1000.0f);
-        BilateralFilter<float,float>(dFiltered, dMeters, bigs, bigr, biwin, 0.2f);
-        DepthToVbo<float>(dVbo, dFiltered, K);
-        NormalsFromVbo(dNormals, dVbo);
+        if (!o.broadcast_inputs || comm->rank == 0) {   // --inputs broadcast: rank 0 preprocesses, the maps travel to the others
+            ElementwiseScaleBias<float,float,float>(dMeters, dMeters, 1.0f / 1000.0f);
+            BilateralFilter<float,float>(dFiltered, dMeters, bigs, bigr, biwin, 0.2f);
+            DepthToVbo<float>(dVbo, dFiltered, K);
+            NormalsFromVbo(dNormals, dVbo);
+        }
+        if (o.broadcast_inputs) slab.BroadcastInputs(dFiltered, dNormals, 0);
         slab.Fuse(dFiltered, dNormals, SE3inv(T_wl), K, trunc_dist, max_w, mincostheta);
         slab.Raycast(ray_d, ray_n, ray_i, T_wl, K, knear, kfar, trunc_dist, true);
         kfx_stream_synchronize(0);
@@ -167,6 +170,7 @@ int main(int argc, char** argv)
         else if (!strcmp(argv[i], "--transport") && i + 1 < argc) o.rccl = !strcmp(argv[++i], "rccl");
         else if (!strcmp(argv[i], "--halo") && i + 1 < argc) o.halo = !strcmp(argv[++i], "recompute") ? SlabVolume::HaloRecompute : SlabVolume::HaloExchange;
         else if (!strcmp(argv[i], "--raycast") && i + 1 < argc) o.raycast = !strcmp(argv[++i], "exact") ? SlabVolume::Exact : SlabVolume::Composite;
+        else if (!strcmp(argv[i], "--inputs") && i + 1 < argc) o.broadcast_inputs = !strcmp(argv[++i], "broadcast");
         else if (!strcmp(argv[i], "--rendezvous") && i + 1 < argc) o.rendezvous = argv[++i];
         else { fprintf(stderr, "unknown argument %s\n", argv[i]); return 2; }
     }

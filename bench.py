@@ -50,6 +50,8 @@ def parse():
     ap.add_argument("--halo", default="recompute", choices=["recompute", "exchange"],
                     help="N > 1: how ghost planes are kept current -- recomputed by each rank (no traffic) or "
                          "exchanged with the neighbours over RCCL point-to-point after each SdfFuse")
+    ap.add_argument("--inputs", default="replicate", choices=["replicate", "broadcast"],
+                    help="N > 1: every rank preprocesses the frame itself, or rank 0 does and broadcasts the filtered depth + normal map")
     ap.add_argument("--overlap", action="store_true",
                     help="N > 1, composite raycast: merge frame k's images on a second stream under frame k+1's preprocess + SdfFuse")
     ap.add_argument("--summary", action="store_true",
@@ -179,7 +181,7 @@ def main():
     K = scenes.intrinsics(w, h)
     if distributed:
         pipe = SlabPipeline(roo, dist, (N, N, N), bmin, bmax, w, h, halo=args.halo, raycast=args.raycast, K=K, near=near, far=far,
-                            overlap=args.overlap)
+                            overlap=args.overlap, inputs=args.inputs)
     else:
         # fast numerics: SdfFuse keeps a brick summary of the volume as a by-product and RaycastSdf takes its steps through
         # uniformly free / never-observed regions from it (same volume bits; depth within the fast-mode tolerance of the plain
@@ -300,7 +302,7 @@ def main():
             return round(n / float(tt.item()), 1)
         n_var = min(args.steps, 2 * N_ORBIT)
         variants = {"steps": n_var}
-        base_halo, base_overlap = pipe.halo, pipe.overlap
+        base_halo, base_overlap, base_inputs = pipe.halo, pipe.overlap, pipe.inputs
         try:   # reported extras must never cost the headline line (errors in collectives are symmetric across ranks)
             variants["as_configured_fps"] = timed_fps(n_var)
             pipe.halo = "exchange" if base_halo == "recompute" else "recompute"
@@ -311,9 +313,12 @@ def main():
                 pipe.overlap = not base_overlap
                 variants["overlap_%s_fps" % ("on" if pipe.overlap else "off")] = timed_fps(n_var)
                 pipe.wait_composite()
+            pipe.overlap = base_overlap
+            pipe.inputs = "broadcast" if base_inputs == "replicate" else "replicate"
+            variants["inputs_%s_fps" % pipe.inputs] = timed_fps(n_var)
         except Exception as e:   # noqa: BLE001
             variants["error"] = repr(e)[:300]
-        pipe.halo, pipe.overlap = base_halo, base_overlap
+        pipe.halo, pipe.overlap, pipe.inputs = base_halo, base_overlap, base_inputs
 
     # 1 GPU, fast numerics: the same frames with the brick summary switched on (tracked SdfFuse + RaycastSdf that steps through
     # uniform regions without reading the volume), reported beside the headline (not part of `value`)
@@ -408,7 +413,7 @@ def main():
                 "ranks_agree": ranks_agree,
                 "raycast": ("brick summary: steps through uniform regions taken without reading the volume (kfx_raycast_sdf_tracked)"
                             if (not distributed and use_summary) else "plain march (kfx_raycast_sdf)"),
-                "partition": ("z-slabs x%d, ghost planes %s%s, raycast %s" % (n_gpus, args.halo, ", merge overlapped with the next frame" if args.overlap else "", "composite = all_reduce(MIN key) + all_reduce(SUM payload)" if args.raycast == "composite" else "exact = march state handed from slab to slab, one SUM all_reduce per round"))
+                "partition": ("z-slabs x%d, inputs %s, ghost planes %s%s, raycast %s" % (n_gpus, "preprocessed by every rank" if args.inputs == "replicate" else "preprocessed by rank 0 and broadcast", args.halo, ", merge overlapped with the next frame" if args.overlap else "", "composite = all_reduce(MIN key) + all_reduce(SUM payload)" if args.raycast == "composite" else "exact = march state handed from slab to slab, one SUM all_reduce per round"))
                              if distributed else "single volume",
                 "math": {"fast": "fast (fp32 rcp/rsq + FMA: the reference's own -use_fast_math regime; TSDF within 1e-4 of the exact path, "
                                  "tests/test_gpu_parity.py::test_gpu_fast_mode_within_tolerance)",

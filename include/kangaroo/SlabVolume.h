@@ -66,6 +66,14 @@ public:
         if (own_only) GpuCheckStatus(kfx_slab_exchange_halos(local.abi(), &layout, comm, 0));
     }
 
+    // Input distribution (the alternative to every rank preprocessing the frame itself): rank `root` holds the filtered depth
+    // and the normal map, afterwards every rank does
+    void BroadcastInputs(Image<float> depth, Image<float4> norm, int root = 0)
+    {
+        Reserve(depth.w * depth.h);
+        GpuCheckStatus(kfx_slab_broadcast_inputs(depth.abi(), norm.abi(), payload_, root, comm, 0));   // payload_: 20 B per pixel
+    }
+
     // RaycastSdf of the whole model; every rank returns with the same images
     void Raycast(Image<float> depth, Image<float4> norm, Image<float> img, Mat<float,3,4> T_wc, ImageIntrinsics K, float near, float far,
                  float trunc_dist, bool subpix = true)

@@ -47,6 +47,9 @@ typedef struct kfx_comm {
                     size_t bytes_hi, kfx_stream stream);
     int (*barrier)(struct kfx_comm* c);
     void (*destroy)(struct kfx_comm* c);
+    /* `bytes` of a dense device buffer from rank `root` to every rank (the filtered depth / normal maps of a frame when only
+     * one rank runs the preprocessing, SURVEY.md 8(e) "input distribution") */
+    int (*broadcast)(struct kfx_comm* c, void* buf, size_t bytes, int root, kfx_stream stream);
 } kfx_comm;
 
 /* In-process transport: fills comms[0 .. world) for `world` host threads of this process that share the current device;
@@ -69,6 +72,11 @@ typedef struct kfx_slab_layout {
     float  local_zmin, local_zmax; /* z of planes s0 and s1 - 1 by VoxelPositionInUnits of the whole volume: the local box */
 } kfx_slab_layout;
 int kfx_slab_layout_init(kfx_slab_layout* L, size_t full_d, float full_zmin, float full_zmax, int rank, int world, int ghost);
+
+/* Input distribution, the alternative to every rank running the (cheap) preprocessing itself: rank `root` holds the frame's
+ * filtered depth and normal maps, afterwards every rank does.  Rows travel without their padding when the images are
+ * pitched (staged through `scratch`, (4 + 16) * w * h bytes of device memory; may be null for dense images). */
+int kfx_slab_broadcast_inputs(const kfx_image* depth, const kfx_image* norm, void* scratch, int root, kfx_comm* comm, kfx_stream stream);
 
 /* Refresh the ghost planes of `local` (planes [s0, s1) of the layout, fp32 SDF_t or fp16 cells: any cell size, whole
  * img_pitch-sized planes travel) from the neighbours' owned planes.  Requires every rank to own at least `ghost` planes. */

@@ -55,6 +55,15 @@ int rccl_exchange(kfx_comm* c, const void* send_lo, void* recv_lo, size_t bytes_
     return nccl_status(r != ncclSuccess ? r : e);
 }
 
+int rccl_broadcast(kfx_comm* c, void* buf, size_t bytes, int root, kfx_stream stream)
+{
+    RcclImpl* im = static_cast<RcclImpl*>(c->impl);
+    if (bytes == 0) return 0;
+    if (!buf) return KFX_E_NULL;
+    if (root < 0 || root >= c->world) return KFX_E_RANGE;
+    return nccl_status(ncclBroadcast(buf, buf, bytes, ncclInt8, root, im->comm, (hipStream_t)stream));
+}
+
 int rccl_barrier(kfx_comm* c)
 {
     RcclImpl* im = static_cast<RcclImpl*>(c->impl);
@@ -124,6 +133,7 @@ extern "C" int kfx_comm_create_rccl(kfx_comm* comm, int rank, int world, const c
     comm->exchange = rccl_exchange;
     comm->barrier = rccl_barrier;
     comm->destroy = rccl_destroy;
+    comm->broadcast = rccl_broadcast;
     if (rank == 0 && world > 1) { // every rank has joined once ncclCommInitRank returns: the file has served its purpose
         rccl_barrier(comm);
         unlink(rendezvous_file);

@@ -144,6 +144,23 @@ static int threads_exchange(kfx_comm* c, const void* send_lo, void* recv_lo, siz
     return st;
 }
 
+static int threads_broadcast(kfx_comm* c, void* buf, size_t bytes, int root, kfx_stream stream)
+{
+    ThreadGroup* g = static_cast<ThreadGroup*>(c->impl);
+    if (root < 0 || root >= g->world) return set_error(KFX_E_RANGE, "kfx_comm broadcast: root");
+    if (!buf && bytes) return set_error(KFX_E_NULL, "kfx_comm(threads) broadcast: null buffer");
+    if (int e = hip_status(hipStreamSynchronize((hipStream_t)stream), "kfx_comm(threads) broadcast")) return e; // the root's producers are done
+    g->buf[c->rank] = buf;
+    g->wait_all();
+    int st = 0;
+    if (c->rank != root && bytes) {
+        st = hip_status(hipMemcpyAsync(buf, g->buf[root], bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream), "kfx_comm(threads) broadcast");
+        if (!st) st = hip_status(hipStreamSynchronize((hipStream_t)stream), "kfx_comm(threads) broadcast");
+    }
+    g->wait_all(); // the root keeps its buffer untouched until every reader is done
+    return st;
+}
+
 static int threads_barrier(kfx_comm* c)
 {
     static_cast<ThreadGroup*>(c->impl)->wait_all();
@@ -175,6 +192,7 @@ extern "C" int kfx_comm_create_threads(kfx_comm* comms, int world)
         comms[r].exchange = threads_exchange;
         comms[r].barrier = threads_barrier;
         comms[r].destroy = threads_destroy;
+        comms[r].broadcast = threads_broadcast;
     }
     return 0;
 }
@@ -201,6 +219,36 @@ extern "C" int kfx_slab_layout_init(kfx_slab_layout* L, size_t full_d, float ful
     const float size_z = full_zmax - full_zmin;
     L->local_zmin = full_zmin + size_z * (float)L->s0 / (float)(full_d - 1);
     L->local_zmax = full_zmin + size_z * (float)(L->s1 - 1) / (float)(full_d - 1);
+    return 0;
+}
+
+extern "C" int kfx_slab_broadcast_inputs(const kfx_image* depth, const kfx_image* norm, void* scratch, int root, kfx_comm* comm, kfx_stream stream)
+{
+    if (!depth || !norm || !comm || !depth->ptr || !norm->ptr) return set_error(KFX_E_NULL, "kfx_slab_broadcast_inputs: null argument");
+    if (norm->w != depth->w || norm->h != depth->h) return set_error(KFX_E_SHAPE, "kfx_slab_broadcast_inputs: depth and normals differ in size");
+    if (depth->pitch < depth->w * 4 || norm->pitch < norm->w * 16) return set_error(KFX_E_SHAPE, "kfx_slab_broadcast_inputs: image pitch");
+    if (comm->world == 1) return 0;
+    if (!comm->broadcast) return set_error(KFX_E_NULL, "kfx_slab_broadcast_inputs: the transport has no broadcast");
+    const size_t w = depth->w, h = depth->h;
+    if (w == 0 || h == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    const bool dense = depth->pitch == w * 4 && norm->pitch == w * 16;
+    if (dense) {
+        if (int e = comm->broadcast(comm, depth->ptr, w * h * 4, root, stream)) return e;
+        return comm->broadcast(comm, norm->ptr, w * h * 16, root, stream);
+    }
+    if (!scratch) return set_error(KFX_E_NULL, "kfx_slab_broadcast_inputs: pitched images need the scratch buffer");
+    unsigned char* sd = static_cast<unsigned char*>(scratch);
+    unsigned char* sn = sd + w * h * 4;
+    if (comm->rank == root) {
+        if (int e = hip_status(hipMemcpy2DAsync(sd, w * 4, depth->ptr, depth->pitch, w * 4, h, hipMemcpyDeviceToDevice, s), "kfx_slab_broadcast_inputs")) return e;
+        if (int e = hip_status(hipMemcpy2DAsync(sn, w * 16, norm->ptr, norm->pitch, w * 16, h, hipMemcpyDeviceToDevice, s), "kfx_slab_broadcast_inputs")) return e;
+    }
+    if (int e = comm->broadcast(comm, sd, w * h * 20, root, stream)) return e;
+    if (comm->rank != root) {
+        if (int e = hip_status(hipMemcpy2DAsync(depth->ptr, depth->pitch, sd, w * 4, w * 4, h, hipMemcpyDeviceToDevice, s), "kfx_slab_broadcast_inputs")) return e;
+        if (int e = hip_status(hipMemcpy2DAsync(norm->ptr, norm->pitch, sn, w * 16, w * 16, h, hipMemcpyDeviceToDevice, s), "kfx_slab_broadcast_inputs")) return e;
+    }
     return 0;
 }
 

@@ -194,13 +194,18 @@ class SlabPipeline(FramePipeline):
 
     GHOST = 2  # >= 1 for the trilinear z+1 corner and the gradient's z-1 / z+1 cells (Volume.h:240-289)
 
-    def __init__(self, ops, dist, dims, boxmin, boxmax, w, h, halo="exchange", raycast="composite", kind="f32", overlap=False, **kw):
+    def __init__(self, ops, dist, dims, boxmin, boxmax, w, h, halo="exchange", raycast="composite", kind="f32", overlap=False,
+                 inputs="replicate", **kw):
         """halo = "exchange": every rank integrates only the planes it owns and the ghost planes are
         refreshed from the two neighbours after each SdfFuse (point-to-point send/recv: one xGMI link
         per direction); halo = "recompute": every rank integrates its ghost planes itself (the update is
         deterministic per voxel, so no traffic is needed) -- the cross-check of the exchange path."""
         assert halo in ("exchange", "recompute")
         assert raycast in ("composite", "exact")
+        # inputs (SURVEY.md 8(e) "input distribution"): "replicate" = every rank filters the frame and derives the normal map
+        # itself (no traffic); "broadcast" = rank 0 does, and its filtered depth + normal map (20 B per pixel) are broadcast
+        assert inputs in ("replicate", "broadcast")
+        self.inputs = inputs
         # overlap (composite mode, known-pose streams): the merge of frame k's per-slab images -- two latency-bound
         # all-reduces and three small kernels -- runs on a second stream while the main stream already preprocesses and
         # integrates frame k + 1; the merged images are complete after wait_composite().
@@ -233,6 +238,15 @@ class SlabPipeline(FramePipeline):
         if self.kind != "f32":
             return self.ops.BoundedVolume(W, H, self.s1 - self.s0, lo, hi, kind=self.kind)
         return self.ops.BoundedVolume(W, H, self.s1 - self.s0, lo, hi)
+
+    def preprocess(self, raw_image=None):
+        if self.inputs == "broadcast" and self.world > 1:
+            if self.rank == 0:
+                super().preprocess(raw_image)
+            self.dist.broadcast(self.filtered.tensor(), src=0)
+            self.dist.broadcast(self.normals.tensor(), src=0)
+        else:
+            super().preprocess(raw_image)
 
     def fuse(self, T_wc, T_cw=None):
         """T_cw: world -> camera transform to use instead of the float32 inverse of T_wc (the tracking loop inverts

@@ -41,6 +41,16 @@ def test_cpp_slabs_exact_march_equals_single_volume():
         assert re.search(r"\((\d+) rounds\)", got["text"]) and 1 < int(re.search(r"\((\d+) rounds\)", got["text"]).group(1)) <= ranks + 3
 
 
+def test_cpp_slabs_inputs_broadcast_from_rank_zero():
+    """--inputs broadcast: only rank 0 filters the frame and derives the normal map; kfx_slab_broadcast_inputs (pitched
+    images: staged densely) hands both to the other ranks.  Same bits everywhere as with every rank preprocessing."""
+    ref = run(*COMMON, "--ranks", 4, "--raycast", "exact", "--halo", "exchange")
+    got = run(*COMMON, "--ranks", 4, "--raycast", "exact", "--halo", "exchange", "--inputs", "broadcast")
+    assert got["agree"] == 1
+    for k in ("depth", "norm", "img", "volume", "hits"):
+        assert got[k] == ref[k], (k, got["text"], ref["text"])
+
+
 def test_cpp_slabs_composite_and_fast_mode():
     """Nearest-hit composite: the volume is still bit-identical, every rank ends with the same images and the hit count
     stays within 1 % of the single-volume march (rays restart at slab entries).  Also in fast numerics."""

@@ -28,17 +28,20 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out_dir, halo, raycast="composite"):
+def _worker(rank, world, port, out_dir, halo, raycast="composite", inputs="replicate"):
     import oracle_ops as ops
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     bmin, bmax, near, far = scenes.SCENES["room"]
-    pipe = SlabPipeline(ops, dist, (N, N, N), bmin, bmax, W, H, halo=halo, raycast=raycast, near=near, far=far)
+    pipe = SlabPipeline(ops, dist, (N, N, N), bmin, bmax, W, H, halo=halo, raycast=raycast, near=near, far=far, inputs=inputs)
     K = pipe.K
     for i in range(FRAMES):
         T_wc = scenes.orbit_pose(i, 8)
-        pipe.raw.MemcpyFromHost(scenes.render_depth("room", W, H, T_wc, K))
+        raw = scenes.render_depth("room", W, H, T_wc, K)
+        if inputs == "broadcast" and rank != 0:   # only rank 0 sees the sensor: the others must get the maps from it
+            raw = np.full_like(raw, np.nan)
+        pipe.raw.MemcpyFromHost(raw)
         pipe.step(T_wc)
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), rounds=getattr(pipe, "rounds", 0), vol=pipe.vol.data, s0=pipe.s0, s1=pipe.s1, z0=pipe.z0, z1=pipe.z1,
              depth=pipe.ray_d.data, norm=pipe.ray_n.data, img=pipe.ray_i.data)
@@ -86,10 +89,11 @@ def test_slab_extent_reproduces_the_reference_extents_of_the_whole_volume():
         assert n == n_ref and T.nan_equal(parts.data, whole.data)
 
 
-@pytest.mark.parametrize("world,halo", [(2, "exchange"), (2, "recompute"), (3, "exchange")])
-def test_slab_pipeline_matches_single_volume(tmp_path, world, halo):
+@pytest.mark.parametrize("world,halo,inputs", [(2, "exchange", "replicate"), (2, "recompute", "replicate"), (3, "exchange", "replicate"),
+                                              (2, "exchange", "broadcast")])
+def test_slab_pipeline_matches_single_volume(tmp_path, world, halo, inputs):
     import oracle_ops as ops
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), halo), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), halo, "composite", inputs), nprocs=world, join=True)
     # single-process reference: the same frames through the monolithic pipeline
     bmin, bmax, near, far = scenes.SCENES["room"]
     ref = FramePipeline(ops, (N, N, N), bmin, bmax, W, H, near=near, far=far)
