@@ -392,8 +392,14 @@ __global__ __launch_bounds__(256) void k_sdf_fuse(const FuseParams p)
 // no atomics: wave64 shuffles reduce a wave's lanes, LDS the workgroup's waves).  RaycastSdf uses it to step through
 // uniformly free or never-observed space without touching the volume (raycast.hip).
 template <bool FAST, int ZU, typename CELL, int LX = 32, int WY = 4, int ZC = FUSE_ZC, bool TRACK = false>
-__global__ __launch_bounds__(256) void k_sdf_fuse_tiled(const FuseParams p, const int cap_px)
+__global__ __launch_bounds__(256) void k_sdf_fuse_tiled(const FuseParams p_arg, const int cap_px)
 {
+    // the uniforms of the per-voxel arithmetic live in vector registers (in_vgpr, kfx_device.h): an SGPR operand makes a
+    // 3.3-cycle instruction a 5-cycle one, and the loop is bound by instruction issue
+    FuseParams p = p_arg;
+    p.T.m[2] = in_vgpr(p.T.m[2]); p.T.m[6] = in_vgpr(p.T.m[6]); p.T.m[10] = in_vgpr(p.T.m[10]);
+    if constexpr (!FAST) { p.T.m[3] = in_vgpr(p.T.m[3]); p.T.m[7] = in_vgpr(p.T.m[7]); p.T.m[11] = in_vgpr(p.T.m[11]); }
+    p.K.fu = in_vgpr(p.K.fu); p.K.fv = in_vgpr(p.K.fv); p.K.u0 = in_vgpr(p.K.u0); p.K.v0 = in_vgpr(p.K.v0);
     constexpr int RW = 64 / LX, WZ = 4 / WY, ZW = ZC / WZ, BY = RW * WY;
     static_assert(LX * RW == 64 && WY * WZ == 4 && ZW * WZ == ZC && ZW % ZU == 0, "brick geometry");
     constexpr int NG = ZW / 8, NXB = LX / 4, NZB = ZC / 8; // summary bricks: z-groups per wave, per workgroup along x and z
@@ -599,7 +605,7 @@ __global__ __launch_bounds__(256) void k_sdf_fuse_tiled(const FuseParams p, cons
             // Exact numerics, cheaper instruction sequences (finish_shared): taken when every voxel of the brick keeps the
             // operands of div_core / sqrt_core inside the range where they are the IEEE results (NaN bounds fail the test).
             if (use_tile && p.exact_shared && zmin >= 0x1p-20f && cmax <= 0x1p20f) {
-                const int cxmax = tw - 2, cymax = th - 2;
+                const int cxmax = in_vgpr(tw - 2), cymax = in_vgpr(th - 2), tx0v = in_vgpr(tx0), ty0v = in_vgpr(ty0);
                 // both voxels of the lane in slice z; `any` = the lane has a cell pair to update
                 auto observe_pair = [&](int z, Obs (&o)[2]) -> bool {
                     const float4 tz = s_tz[z - zbeg];
@@ -613,7 +619,7 @@ __global__ __launch_bounds__(256) void k_sdf_fuse_tiled(const FuseParams p, cons
                         const float pv = p.K.v0 + div_core(p.K.fv * Pc.y, Pc.z, yz);
                         const bool inb = in_bounds(p, pu, pv);
                         const float fix = floorf(pu), fiy = floorf(pv);
-                        const int rx = (int)fix - tx0, ry = (int)fiy - ty0;
+                        const int rx = (int)fix - tx0v, ry = (int)fiy - ty0v;
                         const bool inside = (unsigned)rx <= (unsigned)cxmax && (unsigned)ry <= (unsigned)cymax;
                         const float4* t = s_tile + (med3_i32(ry, 0, cymax) * tw + med3_i32(rx, 0, cxmax));
                         Corners c;
@@ -648,7 +654,7 @@ __global__ __launch_bounds__(256) void k_sdf_fuse_tiled(const FuseParams p, cons
             }
         }
         if (use_tile) {
-            const int cxmax = tw - 2, cymax = th - 2;
+            const int cxmax = in_vgpr(tw - 2), cymax = in_vgpr(th - 2), tx0v = in_vgpr(tx0), ty0v = in_vgpr(ty0);
             for (int z = wz0; z < wz1; z += ZU, cell += (size_t)ZU * p.vimg_pitch) {
                 next_group(z);
                 Obs o[ZU][2];
@@ -666,7 +672,7 @@ __global__ __launch_bounds__(256) void k_sdf_fuse_tiled(const FuseParams p, cons
                             project<FAST>(p, Pc, pu, pv, iz);
                             const bool inb = in_bounds(p, pu, pv);
                             const float fix = floorf(pu), fiy = floorf(pv);
-                            const int rx = (int)fix - tx0, ry = (int)fiy - ty0;
+                            const int rx = (int)fix - tx0v, ry = (int)fiy - ty0v;
                             const bool inside = (unsigned)rx <= (unsigned)cxmax && (unsigned)ry <= (unsigned)cymax;
                             const float4* t = s_tile + (med3_i32(ry, 0, cymax) * tw + med3_i32(rx, 0, cxmax)); // clamps: one v_med3_i32 each
                             Corners c;

@@ -89,6 +89,17 @@ __device__ __forceinline__ float sqrt_core(float x)
     return __builtin_fmaf(d, h, s);
 }
 
+// A wave-uniform value the compiler would keep in a scalar register, moved to a vector register for good.  On gfx950 any
+// VALU instruction with an SGPR source issues at the 5-cycle rate of the "slow" class instead of 3.3 cycles (measured:
+// v_fma / v_mul / v_add / v_fmac with one SGPR operand 5.1 cycles per wave-instruction against 3.3-3.4 all-VGPR,
+// scripts/ubench/valu_rate.hip), so the operands of an issue-bound inner loop belong in VGPRs even when they are uniform.
+template <typename T>
+__device__ __forceinline__ T in_vgpr(T x)
+{
+    asm volatile("" : "+v"(x));
+    return x;
+}
+
 // op(x[lane], x[lane ^ OFF]) for OFF in {1, 2, 16, 32} without the LDS crossbar of __shfl_xor (ds_bpermute): DPP quad
 // permutes within 4 lanes; v_permlane16_swap / v_permlane32_swap (gfx950) exchange odd and even rows / the two halves of a
 // wave -- called with both operands equal they return (even-side value, odd-side value) in every lane, which is all a

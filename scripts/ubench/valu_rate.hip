@@ -80,6 +80,14 @@ KERNEL_SCALAR(k_mad24, "v_mad_u32_u24 %0, %1, %2, %0")
 KERNEL_SCALAR(k_cmpclass, "v_cmp_class_f32 vcc, %0, %1")
 KERNEL_SCALAR(k_fma_neg, "v_fma_f32 %0, -%1, %2, %0")
 KERNEL_SCALAR(k_fma_sgpr, "v_fma_f32 %0, s20, %2, %0")
+KERNEL_SCALAR(k_mul_sgpr_e32, "v_mul_f32_e32 %0, s20, %0")
+KERNEL_SCALAR(k_add_sgpr_e32, "v_add_f32_e32 %0, s20, %0")
+KERNEL_SCALAR(k_fmac_sgpr_e32, "v_fmac_f32_e32 %0, s20, %1")
+KERNEL_SCALAR(k_fma_sgpr_add, "v_fma_f32 %0, %1, %0, s20")
+KERNEL_SCALAR(k_cmp_sgpr_src, "v_cmp_lt_f32 vcc, s20, %0")
+KERNEL_SCALAR(k_cmp_e64_sgpr_dst, "v_cmp_lt_f32 s[22:23], %1, %0")
+KERNEL_SCALAR(k_med3_sgpr, "v_med3_f32 %0, %0, s20, s20")
+KERNEL_SCALAR(k_max_sgpr, "v_max_f32_e32 %0, s20, %0")
 KERNEL_SCALAR(k_mul_lit, "v_mul_f32 %0, 0x3f8ccccd, %0")
 KERNEL_SCALAR(k_salu_mix, "v_fma_f32 %0, %1, %2, %0\n\ts_and_b64 s[20:21], s[20:21], exec")
 KERNEL_PACKED(k_pk_fma, "v_pk_fma_f32 %0, %1, %2, %0")
@@ -109,7 +117,9 @@ int main(int argc, char** argv)
         {"v_cndmask_b32", k_cndmask}, {"v_cndmask sgpr mask", k_cnd_sgpr}, {"v_cndmask_e32 vcc", k_cnd_vcc_init},
         {"v_cmp+v_cndmask vcc", k_cmp_cnd}, {"v_cmp+v_cndmask sgpr", k_cmp_sgpr_cnd}, {"v_min_f32", k_min}, {"v_max_f32", k_max},
         {"v_sub_f32", k_sub}, {"v_and_b32", k_and}, {"v_add_u32", k_addu}, {"v_lshl_add_u32", k_lshladd}, {"v_mad_u32_u24", k_mad24},
-        {"v_cmp_class_f32", k_cmpclass}, {"v_fma_f32 neg", k_fma_neg}, {"v_fma_f32 sgpr", k_fma_sgpr}, {"v_mul_f32 literal", k_mul_lit},
+        {"v_cmp_class_f32", k_cmpclass}, {"v_fma_f32 neg", k_fma_neg}, {"v_fma_f32 sgpr", k_fma_sgpr}, {"v_cmp_lt vcc, sgpr src", k_cmp_sgpr_src}, {"v_cmp_lt sgpr dst", k_cmp_e64_sgpr_dst},
+        {"v_med3 sgpr srcs", k_med3_sgpr}, {"v_max_f32 sgpr src", k_max_sgpr}, {"v_mul_f32_e32 sgpr", k_mul_sgpr_e32}, {"v_add_f32_e32 sgpr", k_add_sgpr_e32},
+        {"v_fmac_f32_e32 sgpr", k_fmac_sgpr_e32}, {"v_fma_f32 sgpr addend", k_fma_sgpr_add}, {"v_mul_f32 literal", k_mul_lit},
         {"v_fma + s_and_b64", k_salu_mix}, {"v_cmp_lt_f32", k_cmp}, {"v_mul_u32_u24", k_mul_u24}, {"v_mul_lo_u32", k_mul_lo},
     };
     hipEvent_t e0, e1;
