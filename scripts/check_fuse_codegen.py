@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""Codegen guard for fuse.hip (CPU only: hipcc cross-compiles gfx950).
+
+The voxel loops of k_sdf_fuse_tiled must not wait for vector memory inside an observation block.  hipcc's register
+allocation has produced builds whose loop head reuses the VGPRs of the previous iteration's volume store for the slice
+constants read from LDS; the hazard is resolved with `s_waitcnt vmcnt(0)` at the top of every iteration, which drains the
+store (and exposes its full latency) before any arithmetic starts: the bit-exact kernel went from 0.438 to 0.486 ms with
+an identical instruction sequence otherwise (round 2, found by diffing the two builds).  This script compiles fuse.hip to
+assembly with the Makefile's flags and fails if any block with >= 8 ds_read_b128 (an observation of a voxel pair) contains
+a vmcnt wait.  Usage: python scripts/check_fuse_codegen.py [path/to/fuse.s]"""
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "kangaroo_amd", "csrc")
+FLAGS = ["-std=c++17", "-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-fast-math",
+         "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-slp-vectorize"]
+
+
+def compile_to_asm(out):
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    subprocess.run([hipcc] + FLAGS + ["-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-S", "--cuda-device-only", "-o", out,
+                                      os.path.join(CSRC, "fuse.hip")], check=True, stderr=subprocess.DEVNULL)
+
+
+def hot_block_waits(asm_path):
+    """[(kernel, block label, instruction index, text)] of vmcnt waits inside observation blocks of k_sdf_fuse_tiled."""
+    src = open(asm_path).read().split("\n")
+    found, kernels = [], 0
+    i = 0
+    while i < len(src):
+        m = re.match(r"^(_ZN3kfx16k_sdf_fuse_tiled\w+):", src[i])
+        if not m:
+            i += 1
+            continue
+        kernels += 1
+        name, label, block = m.group(1), "entry", []
+        i += 1
+
+        def flush():
+            if sum(1 for t in block if t.startswith("ds_read_b128")) >= 8:
+                for k, t in enumerate(block):
+                    if t.startswith("s_waitcnt") and "vmcnt" in t:
+                        found.append((name, label, k, t))
+        while i < len(src) and not src[i].startswith(".Lfunc_end"):
+            mm = re.match(r"^(\.LBB\d+_\d+):", src[i])
+            if mm:
+                flush()
+                label, block = mm.group(1), []
+            elif src[i].startswith("\t") and not src[i].startswith("\t.") and not src[i].startswith("\t;"):
+                block.append(src[i].strip())
+            i += 1
+        flush()
+    return kernels, found
+
+
+def main():
+    if len(sys.argv) > 1:
+        path = sys.argv[1]
+        kernels, found = hot_block_waits(path)
+    else:
+        with tempfile.TemporaryDirectory() as d:
+            path = os.path.join(d, "fuse.s")
+            compile_to_asm(path)
+            kernels, found = hot_block_waits(path)
+    print("%d k_sdf_fuse_tiled instantiations, %d vector-memory waits inside observation blocks" % (kernels, len(found)))
+    for f in found:
+        print("  %s %s [%d] %s" % f)
+    return 1 if (found or kernels == 0) else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
