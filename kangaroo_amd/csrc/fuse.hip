@@ -673,18 +673,31 @@ __global__ __launch_bounds__(256) void k_sdf_fuse_tiled(const FuseParams p_arg, 
                 };
                 // (requesting the cells of slice z and consuming them after the observation of slice z + 1 -- a software
                 // pipeline -- was measured and changes nothing: 0.54 ms either way, the loop is bound by instruction issue)
-                for (int z = wz0; z < wz1; ++z, cell += p.vimg_pitch) {
+                // ZU slices per iteration: their cells are requested together and consumed after all ZU observations
+                for (int z = wz0; z < wz1; z += ZU, cell += (size_t)ZU * p.vimg_pitch) {
                     next_group(z);
-                    Obs o[2];
-                    const bool any = observe_pair(z, o);
-                    note_pair(o[0].ok, o[1].ok);
-                    if (any) {
-                        float4 c = CELL::ld2(cell);
-                        if (o[0].ok) accumulate<false, CELL>(o[0], p.max_w, c.x, c.y);
-                        if (o[1].ok) accumulate<false, CELL>(o[1], p.max_w, c.z, c.w);
-                        CELL::st2(cell, c);
-                        note_vals(c);
+                    Obs o[ZU][2];
+                    bool any[ZU];
+    #pragma unroll
+                    for (int k = 0; k < ZU; ++k) {
+                        any[k] = false;
+                        if (z + k < wz1) { // uniform
+                            any[k] = observe_pair(z + k, o[k]);
+                            note_pair(o[k][0].ok, o[k][1].ok);
+                        }
                     }
+                    float4 c[ZU];
+    #pragma unroll
+                    for (int k = 0; k < ZU; ++k)
+                        if (any[k]) c[k] = CELL::ld2(cell + (size_t)k * p.vimg_pitch);
+    #pragma unroll
+                    for (int k = 0; k < ZU; ++k)
+                        if (any[k]) {
+                            if (o[k][0].ok) accumulate<false, CELL>(o[k][0], p.max_w, c[k].x, c[k].y);
+                            if (o[k][1].ok) accumulate<false, CELL>(o[k][1], p.max_w, c[k].z, c[k].w);
+                            CELL::st2(cell + (size_t)k * p.vimg_pitch, c[k]);
+                            note_vals(c[k]);
+                        }
                 }
                 flush();
                 return;
