@@ -17,7 +17,7 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "kangaroo_amd", "csrc")
 FLAGS = ["-std=c++17", "-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-fast-math",
-         "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-slp-vectorize"]
+         "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-slp-vectorize", "-mllvm", "-amdgpu-sched-strategy=max-ilp"]
 
 
 def compile_to_asm(out):
