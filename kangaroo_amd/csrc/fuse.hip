@@ -1386,9 +1386,17 @@ static float px_per_voxel(const FuseParams& p, const Pose& T, const Intr& K, int
 }
 
 // LDS tile capacity (texels) of the 64 x 8 x 16 brick for the bricks of local planes [z0, z1): grows with r (see fuse_launch)
-static int tile_cap(const FuseParams& p, const Pose& T, const Intr& K, int z0, int z1)
+static int tile_cap(const FuseParams& p, const Pose& T, const Intr& K, int z0, int z1, bool small_ok = false)
 {
     const float r = px_per_voxel(p, T, K, z0, z1);
+    // far ranges (small_ok: the fast kernel): the rectangle, about (73 r + 5) x (14.7 r + 5) texels at the image corner, fits
+    // 1216 texels (19 KiB: 8 workgroups per CU instead of 6, and the fast kernel's 64 VGPRs allow 8 waves per SIMD) --
+    // 512^3, 640x480, frame loop: S_full (r <= 0.54) fast 0.351 -> 0.333 ms, S_room (r = 1.05 ... 0.58: planes beyond
+    // 2.6 m) 0.286 -> 0.283 ms; with 1216 texels everywhere S_room loses (0.291 ms: the near bricks gather from global
+    // memory).  The bit-exact kernel holds 78 VGPRs = 6 waves per SIMD whatever the tile and only pays for the extra launch
+    // boundary (S_room 0.391 -> 0.405 ms), so it keeps 1536.
+    static const float r_small = [] { const char* e = getenv("KFX_FUSE_R_SMALL"); return e ? (float)atof(e) : 0.85f; }();
+    if (small_ok && !(r > r_small)) return 1216;
     if (!(r > 1.3f)) return 1536;
     const float want = 1536.f * (r / 1.05f) * (r / 1.05f);
     const int c = want >= 3072.f ? 3072 : ((int)want + 511) / 512 * 512;
@@ -1403,11 +1411,11 @@ static int tile_cap(const FuseParams& p, const Pose& T, const Intr& K, int z0, i
 // 32 x 8 x 16 everywhere 0.537 / 0.732 ms, 32 x 8 x 8 0.586 / 0.749 ms (its staging and rectangle prologue are amortised
 // over half the slices); at 640x480 (r <= 1.05) the narrow brick costs 0-3 %.
 struct TilePlan { int small_brick, cap; };
-static TilePlan tile_plan(const FuseParams& p, const Pose& T, const Intr& K, int z0, int z1, int brick_env)
+static TilePlan tile_plan(const FuseParams& p, const Pose& T, const Intr& K, int z0, int z1, int brick_env, bool fast)
 {
     const float r = px_per_voxel(p, T, K, z0, z1);
     const int small_brick = brick_env < 0 ? (r > 1.3f ? 1 : 0) : (brick_env != 0);
-    if (!small_brick) return TilePlan{0, tile_cap(p, T, K, z0, z1)};
+    if (!small_brick) return TilePlan{0, tile_cap(p, T, K, z0, z1, fast)};
     // three quarters of the worst-case rectangle: most bricks are nearer the optical axis than the image corner, and a
     // brick that does not fit still works (it gathers from global memory); measured at 1280x960 with one capacity for the
     // whole volume: 1984 texels 0.525 ms, 2496 0.543 ms, 3328 0.577 ms, per-range worst case 0.538 ms (fast mode)
@@ -1469,7 +1477,7 @@ static int fuse_launch(const kfx_volume* vol, const kfx_image* depth, const kfx_
         // r ~ 1.5 on and above r ~ 1.9 does not fit at all (those bricks gathered from global memory).
         static const int brick_env = [] { const char* e = getenv("KFX_FUSE_BRICK"); return e ? atoi(e) : -1; }();
         auto plan_for = [&](int z0, int z1) -> TilePlan {
-            TilePlan t = tile_plan(p, p.T, p.K, z0, z1, brick_env);
+            TilePlan t = tile_plan(p, p.T, p.K, z0, z1, brick_env, fast);
             if (cap_env) t.cap = cap_env;
             return t;
         };
