@@ -334,9 +334,10 @@ int kfx_icp_refine(const kfx_icp_level* levels, int n_levels, float c, float max
 /* ---- multi-GPU raycast composite (no reference counterpart) ------------------------
  * Per-pixel glue around the two collectives of kangaroo_amd/pipeline.py::SlabPipeline.composite:
  *   pack:   key[v*w+u] = (bits(depth or +inf) << 8) | rank                    then all_reduce(MIN, key)
- *   select: payload[(v*w+u)*5 ..] = this rank won ? {n.x,n.y,n.z,n.w, shade} : 0   then all_reduce(SUM, payload)
- *   unpack: depth = key's depth (NaN if no rank hit), norm / img = payload
- * key (w*h int64) and payload (w*h*5 float) are dense device buffers owned by the caller. */
+ *   select: payload[(v*w+u)*4 ..] = this rank won ? {n.x,n.y,n.z, shade} : 0   then all_reduce(SUM, payload)
+ *   unpack: depth = key's depth (NaN if no rank hit), norm = (payload xyz, hit ? 1 : 0), img = payload w
+ * key (w*h int64) and payload (w*h*KFX_COMPOSITE_PAYLOAD float, 16-byte aligned) are dense device buffers owned by the caller. */
+#define KFX_COMPOSITE_PAYLOAD 4
 int kfx_composite_pack(const kfx_image* depth, const kfx_image* norm, const kfx_image* img, long long* key, int rank, kfx_stream stream);
 int kfx_composite_select(const kfx_image* depth, const kfx_image* norm, const kfx_image* img, const long long* key,
                          float* payload, int rank, kfx_stream stream);

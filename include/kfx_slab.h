@@ -83,7 +83,7 @@ int kfx_slab_broadcast_inputs(const kfx_image* depth, const kfx_image* norm, voi
 int kfx_slab_exchange_halos(const kfx_volume* local, const kfx_slab_layout* L, kfx_comm* comm, kfx_stream stream);
 
 /* Nearest-hit composite of per-slab raycasts: on entry depth / norm / img hold this rank's RaycastSdf of its local view,
- * on return every rank holds the merged images.  key: w*h int64, payload: 5*w*h float, dense device scratch of the caller. */
+ * on return every rank holds the merged images.  key: w*h int64, payload: KFX_COMPOSITE_PAYLOAD*w*h float, dense device scratch of the caller. */
 int kfx_slab_composite(const kfx_image* depth, const kfx_image* norm, const kfx_image* img, long long* key, float* payload,
                        kfx_comm* comm, kfx_stream stream);
 

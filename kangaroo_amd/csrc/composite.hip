@@ -4,7 +4,7 @@
 // that a frame costs three small launches instead of a dozen elementwise tensor ops.
 //   key     = (depth bits << 8) | rank     positive floats order like their bit patterns; misses = +inf
 //   all_reduce(MIN, key)                   -> winner rank and its depth, per pixel
-//   payload = winner ? {n.x, n.y, n.z, n.w, shade} : 0      all_reduce(SUM, payload)
+//   payload = winner ? {n.x, n.y, n.z, shade} : 0           all_reduce(SUM, payload)   (n.w = hit ? 1 : 0 comes out of the key)
 // No reference counterpart (the reference is single-GPU).
 #include "kfx_device.h"
 
@@ -14,7 +14,7 @@ struct CompParams {
     unsigned char *dptr, *nptr, *iptr;
     size_t dpitch, npitch, ipitch;
     long long* key;   // w*h, dense
-    float* payload;   // w*h*5, dense
+    float* payload;   // w*h*4, dense (KFX_COMPOSITE_PAYLOAD floats per pixel)
     int w, h, rank;
 };
 
@@ -42,8 +42,7 @@ __global__ __launch_bounds__(256) void k_composite_select(const CompParams p)
         n = reinterpret_cast<const float4*>(p.nptr + (size_t)v * p.npitch)[u];
         s = reinterpret_cast<const float*>(p.iptr + (size_t)v * p.ipitch)[u];
     }
-    float* o = p.payload + i * 5;
-    o[0] = n.x; o[1] = n.y; o[2] = n.z; o[3] = n.w; o[4] = s;
+    reinterpret_cast<float4*>(p.payload)[i] = make_float4(n.x, n.y, n.z, s); // n.w of a hit is 1 (Q8): it travels as the key's hit bit
 }
 
 // after the SUM all-reduce of `payload`: write the composite images (depth comes back out of the key)
@@ -54,10 +53,10 @@ __global__ __launch_bounds__(256) void k_composite_unpack(const CompParams p)
     const size_t i = (size_t)v * p.w + u;
     const unsigned bits = (unsigned)(p.key[i] >> 8);
     const bool hit = bits < 0x7f800000u;
-    const float* o = p.payload + i * 5;
+    const float4 o = reinterpret_cast<const float4*>(p.payload)[i];
     reinterpret_cast<float*>(p.dptr + (size_t)v * p.dpitch)[u] = hit ? __uint_as_float(bits) : __builtin_nanf("");
-    reinterpret_cast<float4*>(p.nptr + (size_t)v * p.npitch)[u] = make_float4(o[0], o[1], o[2], o[3]);
-    reinterpret_cast<float*>(p.iptr + (size_t)v * p.ipitch)[u] = o[4];
+    reinterpret_cast<float4*>(p.nptr + (size_t)v * p.npitch)[u] = make_float4(o.x, o.y, o.z, hit ? 1.0f : 0.0f);
+    reinterpret_cast<float*>(p.iptr + (size_t)v * p.ipitch)[u] = o.w;
 }
 
 } // namespace kfx
@@ -71,7 +70,7 @@ static int comp_params(CompParams& p, const kfx_image* depth, const kfx_image* n
     if (norm->w < depth->w || norm->h < depth->h || img->w < depth->w || img->h < depth->h) return set_error(KFX_E_SHAPE, "composite: image sizes");
     if (rank < 0 || rank > 255) return set_error(KFX_E_RANGE, "composite: rank must fit 8 bits");
     if ((((uintptr_t)norm->ptr | norm->pitch) & 15) || (((uintptr_t)depth->ptr | depth->pitch | (uintptr_t)img->ptr | img->pitch) & 3) ||
-        ((uintptr_t)key & 7) || ((uintptr_t)payload & 3))
+        ((uintptr_t)key & 7) || ((uintptr_t)payload & 15))
         return set_error(KFX_E_ALIGN, "composite: alignment");
     p = CompParams{(unsigned char*)depth->ptr, (unsigned char*)norm->ptr, (unsigned char*)img->ptr, depth->pitch, norm->pitch, img->pitch,
                    key, payload, (int)depth->w, (int)depth->h, rank};

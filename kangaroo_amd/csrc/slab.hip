@@ -281,7 +281,7 @@ extern "C" int kfx_slab_composite(const kfx_image* depth, const kfx_image* norm,
     if (int e = kfx_composite_pack(depth, norm, img, key, comm->rank, stream)) return e;
     if (int e = comm->all_reduce(comm, key, n, KFX_COMM_MIN_I64, stream)) return e;
     if (int e = kfx_composite_select(depth, norm, img, key, payload, comm->rank, stream)) return e;
-    if (int e = comm->all_reduce(comm, payload, 5 * n, KFX_COMM_SUM_F32, stream)) return e;
+    if (int e = comm->all_reduce(comm, payload, KFX_COMPOSITE_PAYLOAD * n, KFX_COMM_SUM_F32, stream)) return e;
     return kfx_composite_unpack(depth, norm, img, key, payload, stream);
 }
 

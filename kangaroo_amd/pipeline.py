@@ -346,9 +346,9 @@ class SlabPipeline(FramePipeline):
         sizes = [d.w * d.h for d, _, _ in outputs]
         total = sum(sizes)
         key = self._scratch("keys", (total,), torch.int64, outputs[0][0])
-        payload = self._scratch("payloads", (total * 5,), torch.float32, outputs[0][0])
+        payload = self._scratch("payloads", (total * 4,), torch.float32, outputs[0][0])
         offs = np.concatenate([[0], np.cumsum(sizes)]).astype(int)
-        parts = [(key[offs[k]:offs[k + 1]], payload[5 * offs[k]:5 * offs[k + 1]]) for k in range(len(outputs))]
+        parts = [(key[offs[k]:offs[k + 1]], payload[4 * offs[k]:4 * offs[k + 1]]) for k in range(len(outputs))]
         for (d, n, i), (kk, _) in zip(outputs, parts):
             self.ops.CompositePack(d, n, i, kk, self.rank)
         self.dist.all_reduce(key, op=self.dist.ReduceOp.MIN)
@@ -405,7 +405,7 @@ class SlabPipeline(FramePipeline):
     def composite(self, d=None, n=None, i=None):
         """Nearest hit over all slabs.  key = depth bits (positive floats order like ints) in the
         high word, rank in the low byte; misses use +inf.  One MIN all-reduce picks the winner,
-        one SUM all-reduce broadcasts its normal / shade (the depth travels in the key).  With the HIP
+        one SUM all-reduce broadcasts its normal / shade (four floats per pixel; the depth and the hit flag travel in the key).  With the HIP
         operator set the per-pixel glue is three fused kernels; operator sets without them (the
         oracle-backed CPU stand-in of the tests) use the equivalent tensor expressions below."""
         import torch
@@ -414,7 +414,7 @@ class SlabPipeline(FramePipeline):
         w, h = d.w, d.h
         if hasattr(self.ops, "CompositePack"):
             key = self._scratch("key", (w * h,), torch.int64, d)
-            payload = self._scratch("payload", (w * h * 5,), torch.float32, d)
+            payload = self._scratch("payload", (w * h * 4,), torch.float32, d)
             self.ops.CompositePack(d, n, i, key, self.rank)
             dist.all_reduce(key, op=dist.ReduceOp.MIN)
             self.ops.CompositeSelect(d, n, i, key, payload, self.rank)
@@ -427,15 +427,16 @@ class SlabPipeline(FramePipeline):
         key = (bits << 8) | self.rank
         dist.all_reduce(key, op=dist.ReduceOp.MIN)
         mine = hit & ((key & 0xFF) == self.rank) & ((key >> 8) == bits)
-        payload = torch.zeros((h, w, 5), dtype=torch.float32, device=dt.device)
-        payload[..., 0:4] = torch.where(mine.unsqueeze(-1), nt, torch.zeros_like(nt))
-        payload[..., 4] = torch.where(mine, it, torch.zeros_like(it))
+        payload = torch.zeros((h, w, 4), dtype=torch.float32, device=dt.device)   # {n.x, n.y, n.z, shade}; n.w = hit ? 1 : 0 comes out of the key
+        payload[..., 0:3] = torch.where(mine.unsqueeze(-1), nt[..., 0:3], torch.zeros_like(nt[..., 0:3]))
+        payload[..., 3] = torch.where(mine, it, torch.zeros_like(it))
         dist.all_reduce(payload, op=dist.ReduceOp.SUM)
         win_bits = (key >> 8).to(torch.int32)
         any_hit = win_bits < 0x7F800000
         dt.copy_(torch.where(any_hit, win_bits.view(torch.float32), torch.full_like(dt, float("nan"))))
-        nt.copy_(payload[..., 0:4])
-        it.copy_(payload[..., 4])
+        nt[..., 0:3].copy_(payload[..., 0:3])
+        nt[..., 3].copy_(any_hit.to(torch.float32))
+        it.copy_(payload[..., 3])
 
 
 class TrackingSlabPipeline(SlabPipeline):

@@ -615,23 +615,23 @@ def test_gpu_composite_kernels_match_tensor_expressions(roo):
         keys.append((bits << 8) | r)
         bits_l.append((hit, bits))
     key_ref = torch.minimum(keys[0], keys[1])
-    pay_ref = torch.zeros((h, w, 5), device=key_ref.device)
+    pay_ref = torch.zeros((h, w, 4), device=key_ref.device)   # {n.x, n.y, n.z, shade}: KFX_COMPOSITE_PAYLOAD floats per pixel
     for r, (rd, rn, ri) in enumerate(ranks):
         hit, bits = bits_l[r]
         mine = hit & ((key_ref & 0xFF) == r) & ((key_ref >> 8) == bits)
-        pay_ref[..., 0:4] += torch.where(mine.unsqueeze(-1), rn.tensor(), torch.zeros_like(rn.tensor()))
-        pay_ref[..., 4] += torch.where(mine, ri.tensor(), torch.zeros_like(ri.tensor()))
+        pay_ref[..., 0:3] += torch.where(mine.unsqueeze(-1), rn.tensor()[..., 0:3], torch.zeros_like(rn.tensor()[..., 0:3]))
+        pay_ref[..., 3] += torch.where(mine, ri.tensor(), torch.zeros_like(ri.tensor()))
     # fused kernels
     kbuf = [torch.empty(w * h, dtype=torch.int64, device="cuda") for _ in ranks]
     for r, (rd, rn, ri) in enumerate(ranks):
         roo.CompositePack(rd, rn, ri, kbuf[r], r)
     key = torch.minimum(kbuf[0], kbuf[1])
     assert torch.equal(key.view(h, w), key_ref)
-    pbuf = [torch.empty(w * h * 5, dtype=torch.float32, device="cuda") for _ in ranks]
+    pbuf = [torch.empty(w * h * 4, dtype=torch.float32, device="cuda") for _ in ranks]
     for r, (rd, rn, ri) in enumerate(ranks):
         roo.CompositeSelect(rd, rn, ri, key, pbuf[r], r)
     pay = pbuf[0] + pbuf[1]
-    assert torch.equal(pay.view(h, w, 5), pay_ref)
+    assert torch.equal(pay.view(h, w, 4), pay_ref)
     rd, rn, ri = ranks[0]
     roo.CompositeUnpack(rd, rn, ri, key, pay)
     d = rd.MemcpyToHost()
