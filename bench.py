@@ -58,6 +58,9 @@ def parse():
                     help="fast math, 1 GPU: time the headline with the brick summary (kfx_sdf_summary: SdfFuse keeps value ranges per "
                          "8^3 cells, RaycastSdf steps through uniformly free space without reading the volume).  Off by default: "
                          "the tracking costs SdfFuse ~5 %; the default run reports the variant beside the headline instead")
+    ap.add_argument("--prime", type=int, default=150,
+                    help="untimed frames of the same stream run before the W warm-up steps, so that the timed steps see a volume in "
+                         "steady state and settled clocks whatever W is (0 = start from the freshly reset volume)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=30, help="upper bound on the timed CPU-baseline frames (the sample also stops after ~12 s)")
     return ap.parse_args()
@@ -211,10 +214,15 @@ def main():
         pipe.preprocess(frames[i])
         n_updated.append(roo.SdfFuseCount(pipe.vol, pipe.filtered, pipe.normals, scenes.se3_inverse(poses[i]), K,
                                           pipe.trunc, pipe.mincostheta, full_extent=distributed))
+    for i in range(max(args.prime, 0)):   # the stream so far: whole orbits before the W warm-up steps
+        pipe.step(poses[i % N_ORBIT], frames[i % N_ORBIT])
     for i in range(args.warmup):
         pipe.step(poses[i % N_ORBIT], frames[i % N_ORBIT])
 
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
+    import gc
+    gc.collect()
+    gc.disable()   # a generation-2 collection inside the timed region stalls the launching thread for tens of ms (seen at --steps 200)
     sync_all()
     t0 = time.perf_counter()
     for s in range(args.steps):
@@ -229,6 +237,7 @@ def main():
         ev[s][3].record()
     sync_all()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     if distributed:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -262,7 +271,7 @@ def main():
         pipe.summary.invalidate()
     n_other = min(args.steps, 2 * N_ORBIT)   # whole orbits: launch times depend on the pose
     ev2 = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_other)]
-    for s in range(12):   # untimed: the first launches after the mode switch run on cold instruction caches / a settling clock
+    for s in range(2 * N_ORBIT):   # untimed: the first launches after the mode switch run on cold instruction caches / a settling clock
         i = (args.warmup + s) % N_ORBIT
         pipe.preprocess(frames[i])
         pipe.fuse(poses[i])
@@ -328,7 +337,7 @@ def main():
             pipe.track = True
             pipe.reset()                      # SdfReset of volume and summary together
             n_sv = min(args.steps, 2 * N_ORBIT)
-            for s in range(min(args.warmup, N_ORBIT) + 5):
+            for s in range(2 * N_ORBIT):   # untimed: the summary of a freshly reset volume settles within the first orbit
                 i = s % N_ORBIT
                 pipe.step(poses[i], frames[i])
             ev3 = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(n_sv)]
@@ -406,8 +415,8 @@ def main():
             "config": {
                 "workload": "BASELINE configs[1]: %d^3 TSDF (SDF_t f32 val+weight, %.2f GiB), %dx%d synthetic depth "
                             "resident in HBM, scene S_%s, %d-pose orbit with known poses; per frame: BilateralFilter(7x7) "
-                            "-> DepthToVbo -> NormalsFromVbo -> SdfFuse -> RaycastSdf" % (
-                                N, 8.0 * N ** 3 / 2 ** 30, w, h, scene, N_ORBIT),
+                            "-> DepthToVbo -> NormalsFromVbo -> SdfFuse -> RaycastSdf; %d untimed frames of the stream precede the warm-up steps" % (
+                                N, 8.0 * N ** 3 / 2 ** 30, w, h, scene, N_ORBIT, max(args.prime, 0)),
                 "volume": [N, N, N], "image": [w, h], "scene": scene,
                 "backend": os.environ.get("KFX_BENCH_BACKEND", "nccl (RCCL)") if distributed else None,
                 "ranks_agree": ranks_agree,
@@ -443,7 +452,7 @@ def main():
                                       "achieved_GBps": round(other_bytes / (other_ms * 1e-3) / 1e9, 1),
                                       "frac": round(other_bytes / (other_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                       "frames_per_sec": round(other_fps, 1),
-                                      "note": "same frames, whole step (preprocess + fuse + raycast), %d steps after 12 untimed ones" % n_other}
+                                      "note": "same frames, whole step (preprocess + fuse + raycast), %d steps after %d untimed ones" % (n_other, 2 * N_ORBIT)}
         if variants is not None:
             out["multi_gpu_variants"] = variants
         if summary_variant is not None:
