@@ -392,24 +392,24 @@ __global__ __launch_bounds__(256) void k_sdf_fuse(const FuseParams p)
 // no atomics: wave64 shuffles reduce a wave's lanes, LDS the workgroup's waves).  RaycastSdf uses it to step through
 // uniformly free or never-observed space without touching the volume (raycast.hip).
 template <bool FAST, int ZU, typename CELL, int LX = 32, int WY = 4, int ZC = FUSE_ZC, bool TRACK = false>
-__global__ __launch_bounds__(256) void k_sdf_fuse_tiled(const FuseParams p_arg, const int cap_px)
+__global__ __launch_bounds__(256, (FAST && TRACK && ZU == 2) ? 8 : 1) void k_sdf_fuse_tiled(const FuseParams p_arg, const int cap_px)
 {
     // the uniforms of the per-voxel arithmetic live in vector registers (in_vgpr, kfx_device.h): an SGPR operand makes a
     // 3.3-cycle instruction a 5-cycle one, and the loop is bound by instruction issue
     FuseParams p = p_arg;
-    p.T.m[2] = in_vgpr(p.T.m[2]); p.T.m[6] = in_vgpr(p.T.m[6]); p.T.m[10] = in_vgpr(p.T.m[10]);
-    if constexpr (!FAST) { p.T.m[3] = in_vgpr(p.T.m[3]); p.T.m[7] = in_vgpr(p.T.m[7]); p.T.m[11] = in_vgpr(p.T.m[11]); }
-    p.K.fu = in_vgpr(p.K.fu); p.K.fv = in_vgpr(p.K.fv); p.K.u0 = in_vgpr(p.K.u0); p.K.v0 = in_vgpr(p.K.v0);
+    // (not in the fast TRACK instantiation: its bookkeeping registers on top of the parked uniforms would cost the eighth wave
+    // per SIMD -- 72 VGPRs -- which is worth more than the issue slots)
+    constexpr bool PARK = !(FAST && TRACK);
+    if constexpr (PARK) {
+        p.T.m[2] = in_vgpr(p.T.m[2]); p.T.m[6] = in_vgpr(p.T.m[6]); p.T.m[10] = in_vgpr(p.T.m[10]);
+        if constexpr (!FAST) { p.T.m[3] = in_vgpr(p.T.m[3]); p.T.m[7] = in_vgpr(p.T.m[7]); p.T.m[11] = in_vgpr(p.T.m[11]); }
+        p.K.fu = in_vgpr(p.K.fu); p.K.fv = in_vgpr(p.K.fv); p.K.u0 = in_vgpr(p.K.u0); p.K.v0 = in_vgpr(p.K.v0);
+    }
     constexpr int RW = 64 / LX, WZ = 4 / WY, ZW = ZC / WZ, BY = RW * WY;
     static_assert(LX * RW == 64 && WY * WZ == 4 && ZW * WZ == ZC && ZW % ZU == 0, "brick geometry");
     constexpr int NG = ZW / 8, NXB = LX / 4, NZB = ZC / 8; // summary bricks: z-groups per wave, per workgroup along x and z
     static_assert(!TRACK || (BY == 8 && ZW % 8 == 0 && NG <= 2 && 8 % ZU == 0), "summary bricks are 8 x 8 x 8");
     __shared__ float s_part[TRACK ? 4 * 2 * 8 * 3 : 1];
-    // TRACK results per 8-slice group of the wave (NG of them): range of the cell values it stored, the lanes that updated
-    // both of their cells in every slice, slices seen.  Lanes outside the extents keep these defaults.
-    float r_mn[2] = {__builtin_inff(), __builtin_inff()}, r_mx[2] = {-__builtin_inff(), -__builtin_inff()};
-    unsigned long long r_all[2] = {0ull, 0ull};
-    int r_nz[2] = {0, 0};
     extern __shared__ __attribute__((aligned(16))) float4 s_tile[];
     __shared__ float s_pz[ZC];
     __shared__ float s_box[4][6];
@@ -566,21 +566,27 @@ __global__ __launch_bounds__(256) void k_sdf_fuse_tiled(const FuseParams p_arg, 
         if (dmax + fabsf(dmax) * 1e-5f - zmin < bound) return; // also when every texel is NaN (dmax = -inf)
     }
     auto march = [&]() {
-        if (!live) return;
+        // TRACK kernels keep every lane in the march (`live` only gates the updates): the per-group reductions below run in
+        // wave-uniform control flow with all lanes present, and the lane mask stays in scalar registers throughout
+        if constexpr (!TRACK) {
+            if (!live) return;
+        }
 
-        // TRACK bookkeeping of the group the wave is in.  The lane mask lives in scalar registers and the per-pair cost is one
-        // v_min3, one v_max3 and three scalar instructions (the fast kernel is co-limited by vector issue).
+        // TRACK bookkeeping of the 8-slice group the wave is in: range of the cell values it stored (one v_min3 and one
+        // v_max3 per cell pair) and the lanes that updated both of their cells in every slice so far (three scalar
+        // instructions per pair) -- the fast kernel is co-limited by vector issue.
         // note_pair: every cell pair of every slice, in wave-uniform control flow (`ok` = the cell is updated).  note_vals: a
         // pair that was loaded, updated (one or both cells) and stored -- both cells enter the range: a cell that was not
         // updated keeps a value that belongs to the brick anyway (NaN is ignored by min3 / max3), so the range stays
-        // conservative.  next_group: the wave moves from its first 8 slices to its second.  flush: before leaving.
+        // conservative.  emit_group: the group is complete -- reduce over the lanes of each summary brick (4 neighbours in x
+        // = 8 cells, every row of the wave; DPP within the 4, row / half swaps across the rows: no LDS crossbar) and leave
+        // {lo, hi, every cell rewritten} per brick in s_part for the workgroup's epilogue.
         float t_mn = __builtin_inff(), t_mx = -__builtin_inff();
         unsigned long long t_all = ~0ull;
-        int t_nz = 0, t_g = 0;
+        int t_g = 0;
         auto note_pair = [&](bool ok0, bool ok1) {
             if constexpr (TRACK) {
                 t_all &= __ballot(ok0) & __ballot(ok1);
-                t_nz += 1;
             }
         };
         auto note_vals = [&](const float4& c) {
@@ -589,19 +595,38 @@ __global__ __launch_bounds__(256) void k_sdf_fuse_tiled(const FuseParams p_arg, 
                 t_mx = __builtin_fmaxf(__builtin_fmaxf(t_mx, c.x), c.z);
             }
         };
-        auto flush = [&]() {
+        auto emit_group = [&](int g, float mn, float mx, unsigned long long all) {
             if constexpr (TRACK) {
-                r_mn[t_g] = t_mn; r_mx[t_g] = t_mx; r_all[t_g] = t_all; r_nz[t_g] = t_nz;
+                const auto fmin2 = [](float a, float b) { return fminf(a, b); };
+                const auto fmax2 = [](float a, float b) { return fmaxf(a, b); };
+                mn = wave_xor_combine<1>(mn, fmin2); mx = wave_xor_combine<1>(mx, fmax2);
+                mn = wave_xor_combine<2>(mn, fmin2); mx = wave_xor_combine<2>(mx, fmax2);
+                if constexpr (LX == 16) { mn = wave_xor_combine<16>(mn, fmin2); mx = wave_xor_combine<16>(mx, fmax2); }
+                mn = wave_xor_combine<32>(mn, fmin2); mx = wave_xor_combine<32>(mx, fmax2);
+                if ((lane & 3) == 0 && lane < LX) {
+                    // lanes of this lane's summary brick within the wave; the group's 8 slices must lie inside the launch
+                    const unsigned long long brick = (LX == 32 ? 0x0000000F0000000Full : 0x000F000F000F000Full) << (lane & (LX - 1) & ~3);
+                    const int full = (wz1 - wz0 >= 8 * (g + 1) && (all & brick) == brick) ? 1 : 0;
+                    float* q = s_part + ((wv * 2 + g) * 8 + (lane >> 2)) * 3;
+                    q[0] = mn; q[1] = mx; q[2] = __int_as_float(full);
+                }
+            }
+        };
+        auto flush = [&]() {   // before leaving: the current group, and an empty second group if the wave never reached it
+            if constexpr (TRACK) {
+                emit_group(t_g, t_mn, t_mx, t_all);
+                if (NG == 2 && t_g == 0) emit_group(1, __builtin_inff(), -__builtin_inff(), 0ull);
             }
         };
         auto next_group = [&](int z) {
             if constexpr (TRACK && NG == 2) {
                 if (z - wz0 == 8) { // uniform
-                    flush();
-                    t_mn = __builtin_inff(); t_mx = -__builtin_inff(); t_all = ~0ull; t_nz = 0; t_g = 1;
+                    emit_group(0, t_mn, t_mx, t_all);
+                    t_mn = __builtin_inff(); t_mx = -__builtin_inff(); t_all = ~0ull; t_g = 1;
                 }
             }
         };
+        const bool upd = !TRACK || live;   // TRACK: a lane outside the extents observes like the others and updates nothing
 
         // one voxel's observation, corners from the LDS tile when the cell lies inside it
         auto observe_tile = [&](int v, float pz) -> Obs {
@@ -654,7 +679,7 @@ __global__ __launch_bounds__(256) void k_sdf_fuse_tiled(const FuseParams p_arg, 
                         const float yz = rcp_nr(Pc.z);
                         const float pu = p.K.u0 + div_core(p.K.fu * Pc.x, Pc.z, yz);
                         const float pv = p.K.v0 + div_core(p.K.fv * Pc.y, Pc.z, yz);
-                        const bool inb = in_bounds(p, pu, pv);
+                        const bool inb = upd && in_bounds(p, pu, pv);
                         const float fix = floorf(pu), fiy = floorf(pv);
                         const int rx = (int)fix - tx0v, ry = (int)fiy - ty0v;
                         const bool inside = (unsigned)rx <= (unsigned)cxmax && (unsigned)ry <= (unsigned)cymax;
@@ -668,6 +693,7 @@ __global__ __launch_bounds__(256) void k_sdf_fuse_tiled(const FuseParams p_arg, 
                     if (__builtin_expect(__ballot(stray) != 0ull, 0)) {
                         o[0] = observe<false, true>(p, cam[0].at(p, tz.x));
                         o[1] = observe<false, true>(p, cam[1].at(p, tz.x));
+                        o[0].ok = o[0].ok && upd; o[1].ok = o[1].ok && upd;
                     }
                     return ((int)o[0].ok | (int)o[1].ok) != 0;
                 };
@@ -704,7 +730,8 @@ __global__ __launch_bounds__(256) void k_sdf_fuse_tiled(const FuseParams p_arg, 
             }
         }
         if (use_tile) {
-            const int cxmax = in_vgpr(tw - 2), cymax = in_vgpr(th - 2), tx0v = in_vgpr(tx0), ty0v = in_vgpr(ty0);
+            const int cxmax = PARK ? in_vgpr(tw - 2) : tw - 2, cymax = PARK ? in_vgpr(th - 2) : th - 2, tx0v = PARK ? in_vgpr(tx0) : tx0,
+                      ty0v = PARK ? in_vgpr(ty0) : ty0;
             for (int z = wz0; z < wz1; z += ZU, cell += (size_t)ZU * p.vimg_pitch) {
                 next_group(z);
                 Obs o[ZU][2];
@@ -720,7 +747,7 @@ __global__ __launch_bounds__(256) void k_sdf_fuse_tiled(const FuseParams p_arg, 
                             const V3 Pc = cam[v].at(p, pz);
                             float pu, pv, iz;
                             project<FAST>(p, Pc, pu, pv, iz);
-                            const bool inb = in_bounds(p, pu, pv);
+                            const bool inb = upd && in_bounds(p, pu, pv);
                             const float fix = floorf(pu), fiy = floorf(pv);
                             const int rx = (int)fix - tx0v, ry = (int)fiy - ty0v;
                             const bool inside = (unsigned)rx <= (unsigned)cxmax && (unsigned)ry <= (unsigned)cymax;
@@ -741,6 +768,7 @@ __global__ __launch_bounds__(256) void k_sdf_fuse_tiled(const FuseParams p_arg, 
                             const float pz = s_pz[z + k - zbeg];
                             o[k][0] = observe<FAST, true>(p, cam[0].at(p, pz));
                             o[k][1] = observe<FAST, true>(p, cam[1].at(p, pz));
+                            o[k][0].ok = o[k][0].ok && upd; o[k][1].ok = o[k][1].ok && upd;
                             any[k] = o[k][0].ok || o[k][1].ok;
                         }
                 }
@@ -774,6 +802,7 @@ __global__ __launch_bounds__(256) void k_sdf_fuse_tiled(const FuseParams p_arg, 
                     const float pz = s_pz[z + k - zbeg];
                     o[k][0] = observe_tile(0, pz);
                     o[k][1] = observe_tile(1, pz);
+                    o[k][0].ok = o[k][0].ok && upd; o[k][1].ok = o[k][1].ok && upd;
                     any[k] = o[k][0].ok || o[k][1].ok;
                     note_pair(o[k][0].ok, o[k][1].ok);
                 }
@@ -798,25 +827,6 @@ __global__ __launch_bounds__(256) void k_sdf_fuse_tiled(const FuseParams p_arg, 
     if constexpr (TRACK) {
         // ---- summary epilogue: every thread of the workgroup arrives here (the early exits above are workgroup-uniform
         // and leave the summary as it is: nothing was written) ----
-        const auto fmin2 = [](float a, float b) { return fminf(a, b); };
-        const auto fmax2 = [](float a, float b) { return fmaxf(a, b); };
-        // lanes of this lane's summary brick within the wave: 4 neighbours in x (8 cells), every row
-        const unsigned long long brick = (LX == 32 ? 0x0000000F0000000Full : 0x000F000F000F000Full) << (lane & (LX - 1) & ~3);
-#pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            float mn = r_mn[g], mx = r_mx[g];
-            // reduce over the brick's lanes: DPP within the 4 x-neighbours, row / half swaps across the rows
-            mn = wave_xor_combine<1>(mn, fmin2); mx = wave_xor_combine<1>(mx, fmax2);
-            mn = wave_xor_combine<2>(mn, fmin2); mx = wave_xor_combine<2>(mx, fmax2);
-            if constexpr (LX == 16) { mn = wave_xor_combine<16>(mn, fmin2); mx = wave_xor_combine<16>(mx, fmax2); }
-            mn = wave_xor_combine<32>(mn, fmin2); mx = wave_xor_combine<32>(mx, fmax2);
-            if ((lane & 3) == 0 && lane < LX) {
-                // every cell of the brick's part in this wave was updated: all 8 slices seen, every lane updated both cells in each
-                const int full = (r_nz[g] == 8 && (r_all[g] & brick) == brick) ? 1 : 0;
-                float* q = s_part + ((wv * 2 + g) * 8 + (lane >> 2)) * 3;
-                q[0] = mn; q[1] = mx; q[2] = __int_as_float(full);
-            }
-        }
         __syncthreads();
         if (tid < NXB * NZB) {
             const int xb = tid % NXB, zb = tid / NXB;
