@@ -57,19 +57,42 @@ def hot_block_waits(asm_path):
     return kernels, found
 
 
+def register_budget(asm_path):
+    """[(kernel, NumVgprs, ScratchSize)] of the fast two-slice instantiations (k_sdf_fuse_tiled<true, 2, ...>): they must
+    fit the 64 VGPRs of 8 waves per SIMD (the 1216-texel tile leaves LDS for 8 workgroups per CU) without spilling."""
+    out, cur = [], None
+    vg = None
+    for line in open(asm_path):
+        m = re.match(r"^(_ZN3kfx16k_sdf_fuse_tiledILb1ELi2\w+):", line)
+        if m:
+            cur, vg = m.group(1), None
+        elif cur and line.startswith("; NumVgprs:"):
+            vg = int(line.split(":")[1])
+        elif cur and line.startswith("; ScratchSize:"):
+            out.append((cur, vg, int(line.split(":")[1])))
+            cur = None
+    return out
+
+
 def main():
     if len(sys.argv) > 1:
         path = sys.argv[1]
         kernels, found = hot_block_waits(path)
+        budget = register_budget(path)
     else:
         with tempfile.TemporaryDirectory() as d:
             path = os.path.join(d, "fuse.s")
             compile_to_asm(path)
             kernels, found = hot_block_waits(path)
+            budget = register_budget(path)
     print("%d k_sdf_fuse_tiled instantiations, %d vector-memory waits inside observation blocks" % (kernels, len(found)))
     for f in found:
         print("  %s %s [%d] %s" % f)
-    return 1 if (found or kernels == 0) else 0
+    over = [b for b in budget if b[1] is None or b[1] > 64 or b[2] != 0]
+    print("%d fast two-slice instantiations, %d over the 64-VGPR / no-scratch budget" % (len(budget), len(over)))
+    for b in over:
+        print("  %s NumVgprs %s ScratchSize %s" % b)
+    return 1 if (found or kernels == 0 or over or not budget) else 0
 
 
 if __name__ == "__main__":
