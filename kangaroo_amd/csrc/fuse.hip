@@ -393,8 +393,9 @@ __global__ __launch_bounds__(256) void k_sdf_fuse(const FuseParams p)
 // uniformly free or never-observed space without touching the volume (raycast.hip).
 template <bool FAST, int ZU, typename CELL, int LX = 32, int WY = 4, int ZC = FUSE_ZC, bool TRACK = false>
 // (fast, ZU = 2: registers for 8 waves per SIMD -- what the 1216-texel tile makes room for; without the bound hipcc's
-// allocation moves between 64 and 78 VGPRs on unrelated edits)
-__global__ __launch_bounds__(256, (FAST && ZU == 2) ? 8 : 1) void k_sdf_fuse_tiled(const FuseParams p_arg, const int cap_px)
+// allocation moves between 64 and 78 VGPRs on unrelated edits; bit-exact: the 80 registers of 6 waves, one wave less costs
+// 6 % -- measured when an edit took it from 78 to 81)
+__global__ __launch_bounds__(256, (FAST && ZU == 2) ? 8 : ((!FAST && !TRACK) ? 6 : 1)) void k_sdf_fuse_tiled(const FuseParams p_arg, const int cap_px)
 {
     // the uniforms of the per-voxel arithmetic live in vector registers (in_vgpr, kfx_device.h): an SGPR operand makes a
     // 3.3-cycle instruction a 5-cycle one, and the loop is bound by instruction issue

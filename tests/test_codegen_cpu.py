@@ -15,4 +15,4 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 def test_fuse_voxel_loops_do_not_wait_for_vector_memory():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "check_fuse_codegen.py")], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout + out.stderr
-    assert "0 vector-memory waits" in out.stdout and ", 0 over the 64-VGPR" in out.stdout
+    assert "0 vector-memory waits" in out.stdout and ", 0 over the VGPR" in out.stdout
