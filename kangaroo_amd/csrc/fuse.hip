@@ -24,6 +24,8 @@
 
 #include <hip/hip_fp16.h>
 
+#include <type_traits>
+
 #include "kfx_device.h"
 
 namespace kfx {
@@ -504,6 +506,14 @@ __global__ __launch_bounds__(256, (FAST && ZU == 2) ? 8 : ((!FAST && !TRACK) ? 6
         tw = (int)fx1 - tx0 + 1; th = (int)fy1 - ty0 + 1;
         use_tile = tw > 1 && th > 1 && tw * th <= cap_px;
     }
+    // Interior bricks: the rectangle of projections lies inside the band 2 <= pu < w - 2, 2 <= pv < h - 2 by a margin far
+    // above the rounding of a projection (a voxel of an inner slice projects between the projections of its column's two
+    // ends), so every sample passes InBounds and falls inside the staged rectangle with its one-texel slack: the voxel loop
+    // of such a brick needs neither the four bounds compares, nor the two rectangle compares, nor the two index clamps --
+    // eight slow-class instructions and as many scalar ones per voxel (fast: 139 + 40 -> 123 + 19 vector + scalar
+    // instructions per voxel pair, exact: 240 + 35 -> 219 + 15).  Measured: fast 0.3310 -> 0.3293 ms, exact 0.4425 -> 0.436 ms
+    // at 512^3 -- far less than the instruction count: by now neither loop is bound by issue alone.
+    const bool interior = __builtin_amdgcn_readfirstlane((int)(use_tile && umin >= 2.01f && umax < p.dwb - 0.01f && vmin >= 2.01f && vmax < p.dhb - 0.01f)) != 0;
     float dmax = -__builtin_inff(); // farthest finite depth in the rectangle (fmaxf skips NaN texels)
     if (use_tile) {
         // Cooperative staging, flat over the rectangle's texels (consecutive threads = consecutive texels of a row), four
@@ -672,7 +682,8 @@ __global__ __launch_bounds__(256, (FAST && ZU == 2) ? 8 : ((!FAST && !TRACK) ? 6
             if (use_tile && p.exact_shared && zmin >= 0x1p-20f && cmax <= 0x1p20f) {
                 const int cxmax = in_vgpr(tw - 2), cymax = in_vgpr(th - 2), tx0v = in_vgpr(tx0), ty0v = in_vgpr(ty0);
                 // both voxels of the lane in slice z; `any` = the lane has a cell pair to update
-                auto observe_pair = [&](int z, Obs (&o)[2]) -> bool {
+                auto observe_pair = [&](auto interior_c, int z, Obs (&o)[2]) -> bool {
+                    constexpr bool INTERIOR = decltype(interior_c)::value;
                     const float4 tz = s_tz[z - zbeg];
                     bool stray = false;
     #pragma unroll
@@ -682,27 +693,37 @@ __global__ __launch_bounds__(256, (FAST && ZU == 2) ? 8 : ((!FAST && !TRACK) ? 6
                         const float yz = rcp_nr(Pc.z);
                         const float pu = p.K.u0 + div_core(p.K.fu * Pc.x, Pc.z, yz);
                         const float pv = p.K.v0 + div_core(p.K.fv * Pc.y, Pc.z, yz);
-                        const bool inb = upd && in_bounds(p, pu, pv);
                         const float fix = floorf(pu), fiy = floorf(pv);
                         const int rx = (int)fix - tx0v, ry = (int)fiy - ty0v;
-                        const bool inside = (unsigned)rx <= (unsigned)cxmax && (unsigned)ry <= (unsigned)cymax;
-                        const float4* t = s_tile + (med3_i32(ry, 0, cymax) * tw + med3_i32(rx, 0, cxmax));
-                        Corners c;
-                        c.c00 = t[0]; c.c01 = t[1]; c.c10 = t[tw]; c.c11 = t[tw + 1];
-                        o[v] = finish_shared(p, Pc, yz, pu - fix, pv - fiy, c);
-                        o[v].ok = ((int)o[v].ok & (int)inb & (int)inside) != 0;
-                        stray |= ((int)inb & (int)!inside) != 0;
+                        if constexpr (INTERIOR && !TRACK) { // every lane samples inside the image band and the rectangle
+                            const float4* t = s_tile + (ry * tw + rx);
+                            Corners c;
+                            c.c00 = t[0]; c.c01 = t[1]; c.c10 = t[tw]; c.c11 = t[tw + 1];
+                            o[v] = finish_shared(p, Pc, yz, pu - fix, pv - fiy, c);
+                        } else {
+                            const bool inb = INTERIOR ? upd : (upd && in_bounds(p, pu, pv));
+                            const bool inside = INTERIOR || ((unsigned)rx <= (unsigned)cxmax && (unsigned)ry <= (unsigned)cymax);
+                            const float4* t = s_tile + (med3_i32(ry, 0, cymax) * tw + med3_i32(rx, 0, cxmax));
+                            Corners c;
+                            c.c00 = t[0]; c.c01 = t[1]; c.c10 = t[tw]; c.c11 = t[tw + 1];
+                            o[v] = finish_shared(p, Pc, yz, pu - fix, pv - fiy, c);
+                            o[v].ok = ((int)o[v].ok & (int)inb & (int)inside) != 0;
+                            stray |= ((int)inb & (int)!inside) != 0;
+                        }
                     }
-                    if (__builtin_expect(__ballot(stray) != 0ull, 0)) {
-                        o[0] = observe<false, true>(p, cam[0].at(p, tz.x));
-                        o[1] = observe<false, true>(p, cam[1].at(p, tz.x));
-                        o[0].ok = o[0].ok && upd; o[1].ok = o[1].ok && upd;
+                    if constexpr (!INTERIOR) {
+                        if (__builtin_expect(__ballot(stray) != 0ull, 0)) {
+                            o[0] = observe<false, true>(p, cam[0].at(p, tz.x));
+                            o[1] = observe<false, true>(p, cam[1].at(p, tz.x));
+                            o[0].ok = o[0].ok && upd; o[1].ok = o[1].ok && upd;
+                        }
                     }
                     return ((int)o[0].ok | (int)o[1].ok) != 0;
                 };
                 // (requesting the cells of slice z and consuming them after the observation of slice z + 1 -- a software
                 // pipeline -- was measured and changes nothing: 0.54 ms either way, the loop is bound by instruction issue)
                 // ZU slices per iteration: their cells are requested together and consumed after all ZU observations
+                auto shared_loop = [&](auto interior_c) {
                 for (int z = wz0; z < wz1; z += ZU, cell += (size_t)ZU * p.vimg_pitch) {
                     next_group(z);
                     Obs o[ZU][2];
@@ -711,7 +732,7 @@ __global__ __launch_bounds__(256, (FAST && ZU == 2) ? 8 : ((!FAST && !TRACK) ? 6
                     for (int k = 0; k < ZU; ++k) {
                         any[k] = false;
                         if (z + k < wz1) { // uniform
-                            any[k] = observe_pair(z + k, o[k]);
+                            any[k] = observe_pair(interior_c, z + k, o[k]);
                             note_pair(o[k][0].ok, o[k][1].ok);
                         }
                     }
@@ -728,6 +749,9 @@ __global__ __launch_bounds__(256, (FAST && ZU == 2) ? 8 : ((!FAST && !TRACK) ? 6
                             note_vals(c[k]);
                         }
                 }
+                };
+                if (interior) shared_loop(std::true_type{});
+                else shared_loop(std::false_type{});
                 flush();
                 return;
             }
@@ -735,6 +759,8 @@ __global__ __launch_bounds__(256, (FAST && ZU == 2) ? 8 : ((!FAST && !TRACK) ? 6
         if (use_tile) {
             const int cxmax = PARK ? in_vgpr(tw - 2) : tw - 2, cymax = PARK ? in_vgpr(th - 2) : th - 2, tx0v = PARK ? in_vgpr(tx0) : tx0,
                       ty0v = PARK ? in_vgpr(ty0) : ty0;
+            auto tiled_loop = [&](auto interior_c) {
+            constexpr bool INTERIOR = decltype(interior_c)::value;
             for (int z = wz0; z < wz1; z += ZU, cell += (size_t)ZU * p.vimg_pitch) {
                 next_group(z);
                 Obs o[ZU][2];
@@ -750,20 +776,28 @@ __global__ __launch_bounds__(256, (FAST && ZU == 2) ? 8 : ((!FAST && !TRACK) ? 6
                             const V3 Pc = cam[v].at(p, pz);
                             float pu, pv, iz;
                             project<FAST>(p, Pc, pu, pv, iz);
-                            const bool inb = upd && in_bounds(p, pu, pv);
                             const float fix = floorf(pu), fiy = floorf(pv);
                             const int rx = (int)fix - tx0v, ry = (int)fiy - ty0v;
-                            const bool inside = (unsigned)rx <= (unsigned)cxmax && (unsigned)ry <= (unsigned)cymax;
-                            const float4* t = s_tile + (med3_i32(ry, 0, cymax) * tw + med3_i32(rx, 0, cxmax)); // clamps: one v_med3_i32 each
-                            Corners c;
-                            c.c00 = t[0]; c.c01 = t[1]; c.c10 = t[tw]; c.c11 = t[tw + 1];
-                            o[k][v] = finish<FAST>(p, Pc, iz, pu - fix, pv - fiy, c);
-                            o[k][v].ok = ((int)o[k][v].ok & (int)inb & (int)inside) != 0;
-                            stray |= ((int)inb & (int)!inside) != 0;
+                            if constexpr (INTERIOR && !TRACK) { // every lane samples inside the image band and the rectangle
+                                const float4* t = s_tile + (ry * tw + rx);
+                                Corners c;
+                                c.c00 = t[0]; c.c01 = t[1]; c.c10 = t[tw]; c.c11 = t[tw + 1];
+                                o[k][v] = finish<FAST>(p, Pc, iz, pu - fix, pv - fiy, c);
+                            } else {
+                                const bool inb = INTERIOR ? upd : (upd && in_bounds(p, pu, pv));
+                                const bool inside = INTERIOR || ((unsigned)rx <= (unsigned)cxmax && (unsigned)ry <= (unsigned)cymax);
+                                const float4* t = s_tile + (med3_i32(ry, 0, cymax) * tw + med3_i32(rx, 0, cxmax)); // clamps: one v_med3_i32 each
+                                Corners c;
+                                c.c00 = t[0]; c.c01 = t[1]; c.c10 = t[tw]; c.c11 = t[tw + 1];
+                                o[k][v] = finish<FAST>(p, Pc, iz, pu - fix, pv - fiy, c);
+                                o[k][v].ok = ((int)o[k][v].ok & (int)inb & (int)inside) != 0;
+                                stray |= ((int)inb & (int)!inside) != 0;
+                            }
                         }
                         any[k] = ((int)o[k][0].ok | (int)o[k][1].ok) != 0;
                     }
                 }
+                if constexpr (!INTERIOR) {
                 if (__builtin_expect(__ballot(stray) != 0ull, 0)) {
     #pragma unroll
                     for (int k = 0; k < ZU; ++k)
@@ -774,6 +808,7 @@ __global__ __launch_bounds__(256, (FAST && ZU == 2) ? 8 : ((!FAST && !TRACK) ? 6
                             o[k][0].ok = o[k][0].ok && upd; o[k][1].ok = o[k][1].ok && upd;
                             any[k] = o[k][0].ok || o[k][1].ok;
                         }
+                }
                 }
     #pragma unroll
                 for (int k = 0; k < ZU; ++k)
@@ -791,6 +826,9 @@ __global__ __launch_bounds__(256, (FAST && ZU == 2) ? 8 : ((!FAST && !TRACK) ? 6
                         note_vals(c[k]);
                     }
             }
+            };
+            if (interior) tiled_loop(std::true_type{});
+            else tiled_loop(std::false_type{});
             flush();
             return;
         }

@@ -6,8 +6,8 @@ allocation has produced builds whose loop head reuses the VGPRs of the previous 
 constants read from LDS; the hazard is resolved with `s_waitcnt vmcnt(0)` at the top of every iteration, which drains the
 store (and exposes its full latency) before any arithmetic starts: the bit-exact kernel went from 0.438 to 0.486 ms with
 an identical instruction sequence otherwise (round 2, found by diffing the two builds).  This script compiles fuse.hip to
-assembly with the Makefile's flags and fails if any block with >= 8 ds_read_b128 (an observation of a voxel pair) contains
-a vmcnt wait.  Usage: python scripts/check_fuse_codegen.py [path/to/fuse.s]"""
+assembly with the Makefile's flags and fails if any block with >= 8 ds_read_b128 (an observation of a voxel pair) waits
+for vector memory before it has issued a load of its own (i.e. for the previous iteration's traffic).  Usage: python scripts/check_fuse_codegen.py [path/to/fuse.s]"""
 import os
 import re
 import subprocess
@@ -42,8 +42,11 @@ def hot_block_waits(asm_path):
 
         def flush():
             if sum(1 for t in block if t.startswith("ds_read_b128")) >= 8:
+                loaded = False   # a wait that follows a load of the same block waits for that load: fine
                 for k, t in enumerate(block):
-                    if t.startswith("s_waitcnt") and "vmcnt" in t:
+                    if t.startswith("global_load") or t.startswith("buffer_load"):
+                        loaded = True
+                    if t.startswith("s_waitcnt") and "vmcnt" in t and not loaded:
                         found.append((name, label, k, t))
         while i < len(src) and not src[i].startswith(".Lfunc_end"):
             mm = re.match(r"^(\.LBB\d+_\d+):", src[i])
