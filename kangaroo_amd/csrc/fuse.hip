@@ -389,18 +389,18 @@ __global__ __launch_bounds__(256) void k_sdf_fuse(const FuseParams p)
 // texels for r pixels per voxel), so it keeps fitting a tile that leaves 3-6 workgroups on a CU where the wide brick would
 // need 48 KiB or fall back to global gathers.
 // TRACK: besides the update, the kernel keeps the brick summary of the volume current (include/kfx.h, kfx_sdf_summary):
-// per 8 x 8 x 8 cells the range of the values written this frame and their number, folded into the stored range by the one
-// workgroup that owns the summary brick (64 x 8 x 16 and 32 x 8 x 16 voxel bricks are unions of whole summary bricks, so
-// no atomics: wave64 shuffles reduce a wave's lanes, LDS the workgroup's waves).  RaycastSdf uses it to step through
-// uniformly free or never-observed space without touching the volume (raycast.hip).
+// per 8 x 8 x 8 cells the range of the values written this frame and whether every cell was rewritten, folded into the
+// stored range by the one workgroup that owns the summary brick (64 x 8 x 16 and 32 x 8 x 16 voxel bricks are unions of
+// whole summary bricks, so no atomics: DPP / permlane swaps reduce a wave's lanes, LDS the workgroup's waves).  RaycastSdf
+// uses it to step through uniformly free or never-observed space without touching the volume (raycast.hip).
+// Register budget (launch bounds): fast, ZU = 2: the 64 VGPRs of 8 waves per SIMD -- what the 1216-texel tile makes room
+// for; without the bound hipcc's allocation moves between 64 and 78 on unrelated edits.  Bit-exact, untracked: the 80 of 6
+// waves; one wave less costs 6 % (measured when an edit took it from 78 to 81).  scripts/check_fuse_codegen.py checks both.
 template <bool FAST, int ZU, typename CELL, int LX = 32, int WY = 4, int ZC = FUSE_ZC, bool TRACK = false>
-// (fast, ZU = 2: registers for 8 waves per SIMD -- what the 1216-texel tile makes room for; without the bound hipcc's
-// allocation moves between 64 and 78 VGPRs on unrelated edits; bit-exact: the 80 registers of 6 waves, one wave less costs
-// 6 % -- measured when an edit took it from 78 to 81)
 __global__ __launch_bounds__(256, (FAST && ZU == 2) ? 8 : ((!FAST && !TRACK) ? 6 : 1)) void k_sdf_fuse_tiled(const FuseParams p_arg, const int cap_px)
 {
     // the uniforms of the per-voxel arithmetic live in vector registers (in_vgpr, kfx_device.h): an SGPR operand makes a
-    // 3.3-cycle instruction a 5-cycle one, and the loop is bound by instruction issue
+    // 3.3-cycle instruction a 5-cycle one
     FuseParams p = p_arg;
     // (not in the fast TRACK instantiation: its bookkeeping registers on top of the parked uniforms would cost the eighth wave
     // per SIMD -- 72 VGPRs -- which is worth more than the issue slots)
