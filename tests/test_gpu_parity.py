@@ -1353,6 +1353,23 @@ def test_gpu_sampler_general_paths_vs_oracle():
     assert out.returncode == 0 and " passed" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
 
 
+@pytest.mark.parametrize("knob", ["KFX_FUSE_XCD_SWIZZLE=0", "KFX_FUSE_XCD_SWIZZLE=3", "KFX_FUSE_R_SMALL=0", "KFX_FUSE_R_SMALL=9",
+                                  "KFX_FUSE_BRICK=0", "KFX_FUSE_BRICK=1", "KFX_FUSE_ZU=4", "KFX_FUSE_ZU=1", "KFX_FUSE_CAP=256",
+                                  "KFX_FUSE_EXACT_SHARED=0"])
+def test_gpu_fuse_scheduling_knobs_do_not_change_a_bit(knob):
+    """The A/B knobs of SdfFuse (workgroup order, tile capacity, brick shape, slices per iteration, division
+    sequences) select launch geometry and instruction sequences, never values: the oracle-parity tests of SdfFuse -- exact
+    numerics bit for bit, fast numerics within its tolerance, tracked kernels included -- rerun in a child process per knob."""
+    import subprocess
+    import sys
+    k, v = knob.split("=")
+    here = os.path.dirname(os.path.abspath(__file__))
+    sel = "fuse_raycast_vs_oracle or fast_mode_within_tolerance or tracked_fuse_and_raycast"
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), os.path.join(here, "test_gpu_summary.py"), "-m", "gpu", "-x", "-q",
+                          "-k", sel], env=dict(os.environ, **{k: v}), capture_output=True, text=True, timeout=1200, cwd=T.ROOT)
+    assert out.returncode == 0 and " passed" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
+
+
 _COLOUR_FULL_SIZE = r"""
 import sys, hashlib, numpy as np, torch
 sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
