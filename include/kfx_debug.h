@@ -26,6 +26,9 @@ int kfx_debug_div_uniform_check(float b, unsigned long long* d_out, kfx_stream s
  * differ (a zero of the other sign counts as equal), d_out[1] += cases tested. */
 int kfx_debug_div_core_check(unsigned seed, int per_divisor, unsigned long long* d_out, kfx_stream stream);
 int kfx_debug_sqrt_core_check(unsigned long long* d_out, kfx_stream stream);
+/* wave_xor_combine (DPP / permlane swaps, kfx_device.h) against __shfl_xor for lane distances 1, 2, 16, 32, min and max:
+ * d_out[0] += mismatches, d_out[1] += comparisons */
+int kfx_debug_wave_xor_check(unsigned seed, unsigned long long* d_out, kfx_stream stream);
 
 /* Copies of a kfx_sdf_summary's per-brick state for tests: R_out receives {lo, hi, state bits, 0} per 8 x 8 x 8 brick
  * (state 0: every cell has a value in [lo, hi], 1: every cell NaN, 2: mixed / unknown), D_out the ray-march's table built

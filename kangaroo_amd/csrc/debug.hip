@@ -170,9 +170,42 @@ __global__ __launch_bounds__(256) void k_sqrt_core_check(unsigned long long* __r
     atomicAdd(out + 1, tested);
 }
 
+// wave_xor_combine (DPP quad permutes, v_permlane16_swap / v_permlane32_swap) against __shfl_xor for the four lane
+// distances, min and max, on pseudo-random lane values: out[0] += mismatching lanes, out[1] += lanes tested
+__global__ __launch_bounds__(256) void k_wave_xor_check(unsigned seed, unsigned long long* __restrict__ out)
+{
+    unsigned s = seed ^ (blockIdx.x * 256u + threadIdx.x) * 2654435761u;
+    unsigned long long bad = 0, tested = 0;
+    const auto fmin2 = [](float a, float b) { return fminf(a, b); };
+    const auto fmax2 = [](float a, float b) { return fmaxf(a, b); };
+    for (int it = 0; it < 64; ++it) {
+        s = s * 1664525u + 1013904223u;
+        const float x = (float)(int)(s >> 8) * (1.0f / 8388608.0f) - 1.0f;
+        const float r[8] = {wave_xor_combine<1>(x, fmin2), wave_xor_combine<2>(x, fmin2), wave_xor_combine<16>(x, fmin2), wave_xor_combine<32>(x, fmin2),
+                            wave_xor_combine<1>(x, fmax2), wave_xor_combine<2>(x, fmax2), wave_xor_combine<16>(x, fmax2), wave_xor_combine<32>(x, fmax2)};
+        const int off[4] = {1, 2, 16, 32};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float o = __shfl_xor(x, off[k], 64);
+            bad += (__float_as_uint(r[k]) != __float_as_uint(fminf(x, o))) ? 1 : 0;
+            bad += (__float_as_uint(r[4 + k]) != __float_as_uint(fmaxf(x, o))) ? 1 : 0;
+            tested += 2;
+        }
+    }
+    atomicAdd(out, bad);
+    atomicAdd(out + 1, tested);
+}
+
 } // namespace kfx
 
 using namespace kfx;
+
+extern "C" int kfx_debug_wave_xor_check(unsigned seed, unsigned long long* d_out, kfx_stream stream)
+{
+    if (!d_out) return set_error(KFX_E_NULL, "kfx_debug_wave_xor_check");
+    hipLaunchKernelGGL(k_wave_xor_check, dim3(64), dim3(256), 0, (hipStream_t)stream, seed, d_out);
+    return check_launch("kfx_debug_wave_xor_check");
+}
 
 extern "C" int kfx_debug_div_core_check(unsigned seed, int per_divisor, unsigned long long* d_out, kfx_stream stream)
 {

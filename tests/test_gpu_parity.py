@@ -1282,6 +1282,22 @@ def test_gpu_shared_reciprocal_division_and_sqrt_are_the_ieee_results(roo):
     assert tested == 160 * (1 << 23) + 1 and bad == 0, (bad, tested)
 
 
+def test_gpu_wave_reductions_without_the_lds_crossbar_equal_shuffles():
+    """wave_xor_combine (kfx_device.h: DPP quad permutes, v_permlane16_swap, v_permlane32_swap) -- the lane reductions of the
+    tracked SdfFuse kernels -- gives min / max(x[lane], x[lane ^ d]) for d = 1, 2, 16, 32 exactly as __shfl_xor does."""
+    import ctypes as C
+    import torch
+    from kangaroo_amd import _lib
+    L = _lib.load()
+    L.kfx_debug_wave_xor_check.restype = C.c_int
+    L.kfx_debug_wave_xor_check.argtypes = [C.c_uint, C.c_void_p, C.c_void_p]
+    out = torch.zeros(2, dtype=torch.int64, device="cuda")
+    for seed in (3, 77, 20261002):
+        assert L.kfx_debug_wave_xor_check(seed, C.c_void_p(out.data_ptr()), None) == 0
+    bad, tested = (int(v) for v in out.cpu())
+    assert tested == 3 * 64 * 256 * 64 * 8 and bad == 0, (bad, tested)
+
+
 def test_gpu_raycast_levels_equal_per_level_calls(roo):
     """kfx_raycast_sdf_levels (all pyramid levels of the tracking loop in one launch) writes, per level, exactly what
     kfx_raycast_sdf writes: fp32 and fp16 cells, odd level sizes, an empty level list, and the tracked pipeline
