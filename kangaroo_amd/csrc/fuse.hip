@@ -1149,8 +1149,10 @@ __global__ __launch_bounds__(256) void k_sdf_fuse_color_tiled(const FuseParams p
     __shared__ float s_box[4][9];
     __shared__ float s_dmax[4];
     __shared__ int s_bad[4];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int x0 = (blockIdx.x * 32 + (lane & 31)) * 2;
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // XCD-aware brick order, as k_sdf_fuse_tiled: the x-brick rotated by the z-brick
+    const int bxi = p.xcd_swizzle ? (int)((blockIdx.x + (blockIdx.z >> (p.xcd_swizzle - 1))) % gridDim.x) : (int)blockIdx.x;
+    const int x0 = (bxi * 32 + (lane & 31)) * 2;
     const int y = blockIdx.y * TB_Y + wv * 2 + (lane >> 5);
     const int zbeg = blockIdx.z * FUSE_ZC;
     const int zend = min(zbeg + FUSE_ZC, p.Z);
