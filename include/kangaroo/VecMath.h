@@ -35,3 +35,8 @@ KANGAROO_HD inline float3 max3(float3 a, float3 b) { return make_float3(fmaxf(a.
 KANGAROO_HD inline float3 xyz(float4 a) { return make_float3(a.x, a.y, a.z); }
 
 }
+
+// The reference keeps its vector helpers at global scope (include/kangaroo/CUDA_SDK/cutil_math.h) and applications call them
+// unqualified (main.cpp:221: length(vol.VoxelSizeUnits())): the ones applications use are visible there too.
+using roo::length;
+using roo::dot;

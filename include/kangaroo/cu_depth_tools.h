@@ -88,11 +88,11 @@ template<> inline void TextureDepth(Image<float4> img, const ImageKeyframe<uchar
     GpuNoteStatus(kfx_texture_depth(img.abi(), reinterpret_cast<const kfx_keyframe*>(&kf), 1, depth.abi(), norm.abi(), nullptr, T_wd.m, &Kdepth.fu, 0));
 }
 
-template<typename Tout, typename Tin, unsigned N>   // the reference spells N as size_t; Mat's row count is unsigned
+template<typename Tout, typename Tin, size_t N>   // (Mat's row count is unsigned: N is never deduced, callers name it, main.cpp:269)
 KANGAROO_EXPORT
 void TextureDepth(Image<Tout> img, const Mat<ImageKeyframe<Tin>,N> kfs, const Image<float> depth, const Image<float4> norm, const Image<float> phong, const Mat<float,3,4> T_wd, ImageIntrinsics Kdepth);
 
-template<> inline void TextureDepth(Image<float4> img, const Mat<ImageKeyframe<uchar3>,10> kfs, const Image<float> depth, const Image<float4> norm, const Image<float> phong, const Mat<float,3,4> T_wd, ImageIntrinsics Kdepth)
+template<> inline void TextureDepth<float4,uchar3,10>(Image<float4> img, const Mat<ImageKeyframe<uchar3>,10> kfs, const Image<float> depth, const Image<float4> norm, const Image<float> phong, const Mat<float,3,4> T_wd, ImageIntrinsics Kdepth)
 {
     GpuNoteStatus(kfx_texture_depth(img.abi(), reinterpret_cast<const kfx_keyframe*>(kfs.m), 10, depth.abi(), norm.abi(), phong.abi(), T_wd.m, &Kdepth.fu, 0));
 }

@@ -46,25 +46,25 @@ void RaycastSdf(Image<float> depth, Image<float4> norm, Image<float> img, const 
 
 // analytic renderers (reference cu_raycast.h:19-26, kernels cu_raycast.cu:202-310)
 KANGAROO_EXPORT inline
-void RaycastBox(Image<float> imgd, const Mat<float,3,4> T_wc, ImageIntrinsics K, const BoundingBox bbox )
+void RaycastBox(Image<float> depth, const Mat<float,3,4> T_wc, ImageIntrinsics K, const BoundingBox bbox )
 {
     const float3 lo = bbox.Min(), hi = bbox.Max();
     const float a[3] = {lo.x, lo.y, lo.z}, b[3] = {hi.x, hi.y, hi.z};
-    GpuCheckStatus(kfx_raycast_box(imgd.abi(), T_wc.m, &K.fu, a, b, 0));
+    GpuCheckStatus(kfx_raycast_box(depth.abi(), T_wc.m, &K.fu, a, b, 0));
 }
 
 KANGAROO_EXPORT inline
-void RaycastSphere(Image<float> imgd, Image<float> img, const Mat<float,3,4> T_wc, ImageIntrinsics K, float3 center, float r)
+void RaycastSphere(Image<float> depth, Image<float> img, const Mat<float,3,4> T_wc, ImageIntrinsics K, float3 center, float r)
 {
     const float c[3] = {center.x, center.y, center.z};
-    GpuCheckStatus(kfx_raycast_sphere(imgd.abi(), img.abi(), T_wc.m, &K.fu, c, r, 0));
+    GpuCheckStatus(kfx_raycast_sphere(depth.abi(), img.abi(), T_wc.m, &K.fu, c, r, 0));
 }
 
 KANGAROO_EXPORT inline
-void RaycastPlane(Image<float> imgd, Image<float> img, const Mat<float,3,4> T_wc, ImageIntrinsics K, const float3 n_w )
+void RaycastPlane(Image<float> depth, Image<float> img, const Mat<float,3,4> T_wc, ImageIntrinsics K, const float3 n_w )
 {
     const float n[3] = {n_w.x, n_w.y, n_w.z};
-    GpuCheckStatus(kfx_raycast_plane(imgd.abi(), img.abi(), T_wc.m, &K.fu, n, 0));
+    GpuCheckStatus(kfx_raycast_plane(depth.abi(), img.abi(), T_wc.m, &K.fu, n, 0));
 }
 
 // fp16-cell overload (config C5)

@@ -8,13 +8,17 @@
 namespace roo
 {
 
+// Level l is the NaN-aware 2 x 2 mean of level l - 1; levels whose source would be narrower or lower than two pixels keep
+// their contents (the level's size is (w >> l) x (h >> l), and a size of zero ends the chain).
 template<typename T, unsigned Levels, typename UpType>
 inline void BoxReduceIgnoreInvalid(Pyramid<T,Levels> pyramid)
 {
-    const int w = pyramid.imgs[0].w;
-    const int h = pyramid.imgs[0].h;
-    for(unsigned int l=1; l<Levels && (w>>l > 0) && (h>>l > 0); ++l) {
-        BoxHalfIgnoreInvalid<T,UpType,T>(pyramid.imgs[l], pyramid.imgs[l-1]);
+    Image<T>* finer = &pyramid.imgs[0];
+    size_t lw = finer->w >> 1, lh = finer->h >> 1;
+    for (unsigned level = 1; level < Levels && lw != 0 && lh != 0; ++level, lw >>= 1, lh >>= 1) {
+        Image<T>* coarser = &pyramid.imgs[level];
+        BoxHalfIgnoreInvalid<T,UpType,T>(*coarser, *finer);
+        finer = coarser;
     }
 }
 

@@ -1,4 +1,5 @@
-/* kfx_debug.h -- measurement aids exported by libkfx.so; not part of the drop-in boundary (include/kfx.h). */
+/* kfx_debug.h -- measurement aids and arithmetic self-checks exported by libkfx_debug.so (which links against libkfx.so);
+ * not part of the drop-in boundary (include/kfx.h) and not in the product library. */
 #ifndef KFX_DEBUG_H
 #define KFX_DEBUG_H
 

@@ -144,6 +144,22 @@ def load():
     return _lib
 
 
+_dbg = None
+
+
+def load_debug():
+    """libkfx_debug.so: the measurement aids and arithmetic self-checks of include/kfx_debug.h (tests / scripts only; the
+    product library libkfx.so does not contain them)."""
+    global _dbg
+    if _dbg is None:
+        load()
+        path = os.path.join(os.path.dirname(LIB_PATH), "libkfx_debug.so")
+        if not os.path.exists(path):
+            raise ImportError("kangaroo_amd: %s not found -- run `make -C kangaroo_amd/csrc`" % path)
+        _dbg = C.CDLL(path)
+    return _dbg
+
+
 def check(code):
     if code != 0:
         raise KfxError(code, load().kfx_last_error_string().decode())

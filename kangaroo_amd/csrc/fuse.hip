@@ -931,13 +931,18 @@ __global__ __launch_bounds__(256) void k_sdf_fuse_count(const FuseParams p, cons
 // SdfReset: contiguous fill of (trunc, 0) over [ptr, RowPtr(h-1,d-1)+w) (Volume.h:343-356).
 __global__ __launch_bounds__(256) void k_fill_sdf(float2* __restrict__ base, size_t n_cells, float val, float w)
 {
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // one workgroup = one contiguous 16 KiB chunk, four 16-byte nontemporal stores per thread and no loop: a pure write stream
+    const size_t i = (size_t)blockIdx.x * 1024 + threadIdx.x;
     const size_t n2 = n_cells / 2;
     v4f* b4 = reinterpret_cast<v4f*>(base);
     v4f v4;
     v4.x = val; v4.y = w; v4.z = val; v4.w = w;
-    for (size_t j = i; j < n2; j += stride) __builtin_nontemporal_store(v4, b4 + j);
+    if (i + 768 < n2) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) __builtin_nontemporal_store(v4, b4 + i + k * 256);
+    } else {
+        for (size_t j = i; j < n2; j += 256) __builtin_nontemporal_store(v4, b4 + j);
+    }
     if (i == 0 && (n_cells & 1)) base[n_cells - 1] = make_float2(val, w);
 }
 __global__ __launch_bounds__(256) void k_fill_sdf_unaligned(float2* __restrict__ base, size_t n_cells, float val, float w)
@@ -1661,7 +1666,7 @@ extern "C" int kfx_sdf_reset(const kfx_volume* vol, float trunc_dist, kfx_stream
     const int blocks = (int)std::min<size_t>((n / 2 + 255) / 256 + 1, 256 * 32);
     hipStream_t s = (hipStream_t)stream;
     if (((uintptr_t)vol->ptr & 15) == 0)
-        hipLaunchKernelGGL(k_fill_sdf, dim3(blocks), dim3(256), 0, s, (float2*)vol->ptr, n, trunc_dist, 0.0f);
+        hipLaunchKernelGGL(k_fill_sdf, dim3((unsigned)((n / 2 + 1023) / 1024 + 1)), dim3(256), 0, s, (float2*)vol->ptr, n, trunc_dist, 0.0f);
     else
         hipLaunchKernelGGL(k_fill_sdf_unaligned, dim3(blocks), dim3(256), 0, s, (float2*)vol->ptr, n, trunc_dist, 0.0f);
     return check_launch("kfx_sdf_reset");

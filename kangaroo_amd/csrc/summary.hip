@@ -6,7 +6,6 @@
 #include <new>
 
 #include "kfx_device.h"
-#include "../../include/kfx_debug.h"
 
 namespace kfx {
 
@@ -173,30 +172,4 @@ extern "C" int kfx_sdf_reset_tracked(const kfx_volume* vol, kfx_sdf_summary* s, 
                        nan ? __builtin_inff() : trunc_dist, nan ? -__builtin_inff() : trunc_dist, nan ? 1 : 0);
     s->dirty = 1;
     return check_launch("kfx_sdf_reset_tracked");
-}
-
-// test / diagnostics aid (include/kfx_debug.h): copies of R (float4 per brick) and of D built with `tol` into caller buffers
-extern "C" int kfx_debug_summary_export(kfx_sdf_summary* s, float tol, void* R_out, void* D_out, int dims_out[9], kfx_stream stream)
-{
-    if (!s || !dims_out) return set_error(KFX_E_NULL, "kfx_debug_summary_export: null argument");
-    dims_out[0] = s->nbx; dims_out[1] = s->nby; dims_out[2] = s->nbz;
-    dims_out[3] = s->n2x; dims_out[4] = s->n2y; dims_out[5] = s->n2z;
-    dims_out[6] = dims_out[7] = dims_out[8] = 0; // level 3 exists only inside the ray-march; here: the build's counters
-    const size_t n = (size_t)s->nbx * s->nby * s->nbz;
-    const size_t n_all = n + (size_t)s->n2x * s->n2y * s->n2z;
-    hipStream_t st = (hipStream_t)stream;
-    if (R_out && hipMemcpyAsync(R_out, s->R, n * sizeof(float4), hipMemcpyDeviceToDevice, st) != hipSuccess) return set_error(KFX_E_RANGE, "kfx_debug_summary_export: copy");
-    if (D_out) {
-        if (int e = summary_prepare(s, tol, st)) return e;
-        if (hipMemcpyAsync(D_out, s->D, n * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess ||
-            hipMemcpyAsync(static_cast<float*>(D_out) + n, s->D2, (n_all - n) * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
-            return set_error(KFX_E_RANGE, "kfx_debug_summary_export: copy");
-        int c[1024];
-        if (hipStreamSynchronize(st) != hipSuccess || hipMemcpy(c, s->useful2, s->n_partials * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess)
-            return set_error(KFX_E_RANGE, "kfx_debug_summary_export: copy");
-        int total = 0;
-        for (int i = 0; i < s->n_partials; ++i) total += c[i];
-        dims_out[6] = s->n_partials; dims_out[7] = 0; dims_out[8] = total; // partial counts, -, their sum
-    }
-    return 0;
 }

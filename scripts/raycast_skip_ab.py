@@ -48,12 +48,12 @@ for scene in ("full", "room"):
         import ctypes as C
         from kangaroo_amd import _lib
         L = _lib.load()
-        L.kfx_debug_summary_export.restype = C.c_int
-        L.kfx_debug_summary_export.argtypes = [C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.c_void_p]
+        _lib.load_debug().kfx_debug_summary_export.restype = C.c_int
+        _lib.load_debug().kfx_debug_summary_export.argtypes = [C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.c_void_p]
         dims = (C.c_int * 9)()
         Dall = torch.empty(64 * 64 * 64 + 16 * 16 * 16 + 64, dtype=torch.float32, device="cuda")
         R = torch.empty((64, 64, 64, 4), dtype=torch.float32, device="cuda")
-        L.kfx_debug_summary_export(summ.handle, 1e-5 if math == "fast" else 0.0, C.c_void_p(R.data_ptr()), C.c_void_p(Dall.data_ptr()), dims, None)
+        _lib.load_debug().kfx_debug_summary_export(summ.handle, 1e-5 if math == "fast" else 0.0, C.c_void_p(R.data_ptr()), C.c_void_p(Dall.data_ptr()), dims, None)
         torch.cuda.synchronize()
         D = Dall[:64 ** 3].view(64, 64, 64)
         st = R[..., 2].contiguous().view(torch.int32)

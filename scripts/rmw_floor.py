@@ -8,7 +8,7 @@ sys.path.insert(0, ROOT)
 import torch
 from kangaroo_amd import roo, _lib
 L = _lib.load()
-L.kfx_debug_rmw.argtypes = [_lib.PV, C.c_int, C.c_void_p]
+_lib.load_debug().kfx_debug_rmw.argtypes = [_lib.PV, C.c_int, C.c_void_p]
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 vol = roo.BoundedVolume(N, N, N)
 roo.SdfReset(vol, 0.0)
@@ -23,7 +23,7 @@ for v in list(names) + ["copy"]:
         if v == "copy":
             b.copy_(a)
         else:
-            assert L.kfx_debug_rmw(vol.ref(), v, C.c_void_p(torch.cuda.current_stream().cuda_stream)) == 0
+            assert _lib.load_debug().kfx_debug_rmw(vol.ref(), v, C.c_void_p(torch.cuda.current_stream().cuda_stream)) == 0
         e.record()
     torch.cuda.synchronize()
     ms = sorted(s.elapsed_time(e) for s, e in ev)[2:]

@@ -33,8 +33,9 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_debug_and_slab_headers_are_exported_too():
-    """include/kfx_debug.h (measurement aids) and include/kfx_slab.h (multi-GPU slab partition) declare symbols of
-    libkfx.so, except the RCCL transport, which lives in libkfx_rccl.so so that libkfx.so does not depend on librccl."""
+    """include/kfx_slab.h (multi-GPU slab partition) declares symbols of libkfx.so, except the RCCL transport, which lives in
+    libkfx_rccl.so so that libkfx.so does not depend on librccl; include/kfx_debug.h (measurement aids, arithmetic
+    self-checks) declares symbols of libkfx_debug.so only: the product library exports none of them."""
     def decl(path):
         src = re.sub(r"/\*.*?\*/", "", open(os.path.join(T.ROOT, "include", path)).read(), flags=re.S)
         return set(re.findall(r"\b(kfx_[a-z0-9_]+)\s*\(", src))
@@ -47,7 +48,11 @@ def test_debug_and_slab_headers_are_exported_too():
     assert os.path.exists(rccl_lib), "libkfx_rccl.so not built"
     rccl = exported(rccl_lib)
     dbg, slab = decl("kfx_debug.h"), decl("kfx_slab.h")
-    assert len(dbg) >= 4 and dbg <= main
+    dbg_lib = os.path.join(os.path.dirname(_lib.LIB_PATH), "libkfx_debug.so")
+    assert os.path.exists(dbg_lib), "libkfx_debug.so not built"
+    assert len(dbg) >= 4 and dbg <= exported(dbg_lib)
+    assert not any(n.startswith("kfx_debug") for n in main), "measurement aids inside the product library"
+    assert _lib.load_debug() is not None   # resolves its libkfx.so dependencies without a GPU
     assert "kfx_comm_create_rccl" in slab and len(slab) >= 7
     assert slab - {"kfx_comm_create_rccl"} <= main and "kfx_comm_create_rccl" in rccl
     needed = subprocess.check_output(["readelf", "-d", _lib.LIB_PATH]).decode()

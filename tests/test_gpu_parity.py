@@ -1240,8 +1240,8 @@ def test_gpu_division_by_uniform_divisor_is_the_ieee_quotient(roo):
     import torch
     from kangaroo_amd import _lib
     L = _lib.load()
-    L.kfx_debug_div_uniform_check.restype = C.c_int
-    L.kfx_debug_div_uniform_check.argtypes = [C.c_float, C.c_void_p, C.c_void_p]
+    _lib.load_debug().kfx_debug_div_uniform_check.restype = C.c_int
+    _lib.load_debug().kfx_debug_div_uniform_check.argtypes = [C.c_float, C.c_void_p, C.c_void_p]
     rng = np.random.default_rng(7)
     special = np.array([0x3fffffff, 0x3f800001, 0x3f7fffff, 0x40000000, 0x3faaaaab, 0x3f800000, 0x3fb504f3, 0x3fc00001], np.uint32).view(np.float32)
     divisors = [2.0, 1.8, 3.0, 0.1, 7.3, -2.5, 1e-9, 3e9, float(np.float32(2.0) / np.float32(511.0))] + [float(x) for x in special]
@@ -1251,7 +1251,7 @@ def test_gpu_division_by_uniform_divisor_is_the_ieee_quotient(roo):
     out = torch.zeros(2, dtype=torch.int64, device="cuda")
     for b in divisors:
         out.zero_()
-        assert L.kfx_debug_div_uniform_check(C.c_float(b), C.c_void_p(out.data_ptr()), None) == 0
+        assert _lib.load_debug().kfx_debug_div_uniform_check(C.c_float(b), C.c_void_p(out.data_ptr()), None) == 0
         bad, tested = (int(v) for v in out.cpu())
         assert tested > 1_300_000_000 and bad == 0, (b, bad, tested)
 
@@ -1266,18 +1266,18 @@ def test_gpu_shared_reciprocal_division_and_sqrt_are_the_ieee_results(roo):
     import torch
     from kangaroo_amd import _lib
     L = _lib.load()
-    L.kfx_debug_div_core_check.restype = C.c_int
-    L.kfx_debug_div_core_check.argtypes = [C.c_uint, C.c_int, C.c_void_p, C.c_void_p]
-    L.kfx_debug_sqrt_core_check.restype = C.c_int
-    L.kfx_debug_sqrt_core_check.argtypes = [C.c_void_p, C.c_void_p]
+    _lib.load_debug().kfx_debug_div_core_check.restype = C.c_int
+    _lib.load_debug().kfx_debug_div_core_check.argtypes = [C.c_uint, C.c_int, C.c_void_p, C.c_void_p]
+    _lib.load_debug().kfx_debug_sqrt_core_check.restype = C.c_int
+    _lib.load_debug().kfx_debug_sqrt_core_check.argtypes = [C.c_void_p, C.c_void_p]
     out = torch.zeros(2, dtype=torch.int64, device="cuda")
     for seed in (1, 20261002):
         out.zero_()
-        assert L.kfx_debug_div_core_check(seed, 24, C.c_void_p(out.data_ptr()), None) == 0
+        assert _lib.load_debug().kfx_debug_div_core_check(seed, 24, C.c_void_p(out.data_ptr()), None) == 0
         bad, tested = (int(v) for v in out.cpu())
         assert tested == (1 << 23) * 10 * 24 and bad == 0, (seed, bad, tested)
     out.zero_()
-    assert L.kfx_debug_sqrt_core_check(C.c_void_p(out.data_ptr()), None) == 0
+    assert _lib.load_debug().kfx_debug_sqrt_core_check(C.c_void_p(out.data_ptr()), None) == 0
     bad, tested = (int(v) for v in out.cpu())
     assert tested == 160 * (1 << 23) + 1 and bad == 0, (bad, tested)
 
@@ -1289,11 +1289,11 @@ def test_gpu_wave_reductions_without_the_lds_crossbar_equal_shuffles():
     import torch
     from kangaroo_amd import _lib
     L = _lib.load()
-    L.kfx_debug_wave_xor_check.restype = C.c_int
-    L.kfx_debug_wave_xor_check.argtypes = [C.c_uint, C.c_void_p, C.c_void_p]
+    _lib.load_debug().kfx_debug_wave_xor_check.restype = C.c_int
+    _lib.load_debug().kfx_debug_wave_xor_check.argtypes = [C.c_uint, C.c_void_p, C.c_void_p]
     out = torch.zeros(2, dtype=torch.int64, device="cuda")
     for seed in (3, 77, 20261002):
-        assert L.kfx_debug_wave_xor_check(seed, C.c_void_p(out.data_ptr()), None) == 0
+        assert _lib.load_debug().kfx_debug_wave_xor_check(seed, C.c_void_p(out.data_ptr()), None) == 0
     bad, tested = (int(v) for v in out.cpu())
     assert tested == 3 * 64 * 256 * 64 * 8 and bad == 0, (bad, tested)
 

@@ -20,15 +20,15 @@ def export(roo, summ, tol):
     import torch
     from kangaroo_amd import _lib
     L = _lib.load()
-    L.kfx_debug_summary_export.restype = C.c_int
-    L.kfx_debug_summary_export.argtypes = [C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.c_void_p]
+    _lib.load_debug().kfx_debug_summary_export.restype = C.c_int
+    _lib.load_debug().kfx_debug_summary_export.argtypes = [C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.c_void_p]
     dims = (C.c_int * 9)()
-    assert L.kfx_debug_summary_export(summ.handle, tol, None, None, dims, None) == 0
+    assert _lib.load_debug().kfx_debug_summary_export(summ.handle, tol, None, None, dims, None) == 0
     nbx, nby, nbz = dims[0], dims[1], dims[2]
     n1, n2, n3 = nbx * nby * nbz, dims[3] * dims[4] * dims[5], dims[6] * dims[7] * dims[8]
     R = torch.empty((nbz, nby, nbx, 4), dtype=torch.float32, device="cuda")
     Dall = torch.empty(n1 + n2 + n3, dtype=torch.float32, device="cuda")
-    assert L.kfx_debug_summary_export(summ.handle, tol, C.c_void_p(R.data_ptr()), C.c_void_p(Dall.data_ptr()), dims, None) == 0
+    assert _lib.load_debug().kfx_debug_summary_export(summ.handle, tol, C.c_void_p(R.data_ptr()), C.c_void_p(Dall.data_ptr()), dims, None) == 0
     torch.cuda.synchronize()
     D1 = Dall[:n1].view(nbz, nby, nbx)
     D2 = Dall[n1:n1 + n2].view(dims[5], dims[4], dims[3])
