@@ -20,6 +20,8 @@
 #include <thread>
 #include <vector>
 
+#include <unistd.h>
+
 #include <kangaroo/kangaroo.h>
 #include <kangaroo/SlabVolume.h>
 
@@ -30,7 +32,7 @@ struct Options {
     bool fast = false, rccl = false, broadcast_inputs = false;
     SlabVolume::HaloMode halo = SlabVolume::HaloExchange;
     SlabVolume::RaycastMode raycast = SlabVolume::Composite;
-    std::string rendezvous = "/tmp/kfx_slabs.id";
+    std::string rendezvous;   // default: /tmp/kfx_slabs.<uid>.<launch id>.id (default_rendezvous)
 };
 
 // analytic depth of the synthetic room: same scene as kinectfusion_headless.cpp / kangaroo_amd/scenes.py
@@ -197,6 +199,11 @@ int main(int argc, char** argv)
         const int local = el ? atoi(el) : rank;
         if (world > ndev) { fprintf(stderr, "kinectfusion_slabs: %d ranks need %d GPUs, this node shows %d\n", world, world, ndev); return 2; }
         GpuCheckStatus(kfx_set_device(local % ndev));
+        if (o.rendezvous.empty()) {   // unique per user and launch: the launcher's run id / port, else the parent (launcher) process
+            const char* id = getenv("TORCHELASTIC_RUN_ID");
+            if (!id || !*id) id = getenv("MASTER_PORT");
+            o.rendezvous = "/tmp/kfx_slabs." + std::to_string((long long)getuid()) + "." + (id && *id ? std::string(id) : "ppid" + std::to_string((long long)getppid())) + ".id";
+        }
         kfx_comm comm;
         const int st = kfx_comm_create_rccl(&comm, rank, world, o.rendezvous.c_str(), 120);
         if (st != 0) { fprintf(stderr, "kfx_comm_create_rccl failed: %d\n", st); return 3; }

@@ -183,6 +183,8 @@ def main():
     bmin, bmax, near, far = scenes.SCENES[scene]
     K = scenes.intrinsics(w, h)
     if distributed:
+        if args.overlap and args.halo == "exchange":
+            sys.exit("bench.py: --overlap needs --halo recompute (collective ordering, kangaroo_amd/pipeline.py)")
         pipe = SlabPipeline(roo, dist, (N, N, N), bmin, bmax, w, h, halo=args.halo, raycast=args.raycast, K=K, near=near, far=far,
                             overlap=args.overlap, inputs=args.inputs)
     else:
@@ -314,9 +316,12 @@ def main():
         base_halo, base_overlap, base_inputs = pipe.halo, pipe.overlap, pipe.inputs
         try:   # reported extras must never cost the headline line (errors in collectives are symmetric across ranks)
             variants["as_configured_fps"] = timed_fps(n_var)
+            pipe.wait_composite()
+            pipe.overlap = False   # the ghost-plane exchange never runs beside an overlapped merge (SlabPipeline.__init__)
             pipe.halo = "exchange" if base_halo == "recompute" else "recompute"
             variants["halo_%s_fps" % pipe.halo] = timed_fps(n_var)
             pipe.halo = base_halo
+            pipe.overlap = base_overlap
             if args.raycast == "composite":
                 pipe.wait_composite()
                 pipe.overlap = not base_overlap

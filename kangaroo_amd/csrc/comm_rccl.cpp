@@ -1,7 +1,11 @@
 // comm_rccl.cpp -- the RCCL transport behind kfx_comm (include/kfx_slab.h): one process per GPU, all-reduce and grouped
 // neighbour send / recv over xGMI.  Built into libkfx_rccl.so so that libkfx.so itself does not depend on librccl.
-// The ncclUniqueId travels through a file: rank 0 creates it atomically (write + rename), the others wait for it.
+// The ncclUniqueId travels through a file: rank 0 removes whatever is there, creates the file atomically (exclusive
+// temporary + rename) with a launch nonce in front of the id, the others wait for a file that is a regular file of this user,
+// carries their nonce and is not older than their own process -- a file left behind by a crashed run is never accepted.
 #include <chrono>
+#include <cstdint>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <new>
@@ -10,6 +14,8 @@
 
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
+#include <fcntl.h>
+#include <sys/stat.h>
 #include <unistd.h>
 
 #include "../../include/kfx_slab.h"
@@ -82,34 +88,86 @@ void rccl_destroy(kfx_comm* c)
     c->impl = nullptr;
 }
 
+// What a launcher gives every rank of one launch and no rank of another: folded into 64 bits (0 when nothing is set)
+uint64_t launch_nonce()
+{
+    uint64_t h = 1469598103934665603ull;
+    bool any = false;
+    for (const char* name : {"KFX_RUN_ID", "TORCHELASTIC_RUN_ID", "MASTER_PORT", "SLURM_JOB_ID", "SLURM_STEP_ID"}) {
+        const char* v = getenv(name);
+        if (!v || !*v) continue;
+        any = true;
+        for (const char* c = v; *c; ++c) h = (h ^ (unsigned char)*c) * 1099511628211ull;
+        h = (h ^ 0xffu) * 1099511628211ull;
+    }
+    return any ? (h | 1ull) : 0ull;
+}
+
+struct Rendezvous {
+    char magic[8];
+    uint64_t nonce;
+    ncclUniqueId id;
+};
+const char RDV_MAGIC[8] = {'K', 'F', 'X', 'R', 'D', 'V', '1', 0};
+
+// start of this process (the launcher starts the ranks together): st_mtime of /proc/self, or "now" where that is missing
+time_t process_start()
+{
+    struct stat st;
+    if (stat("/proc/self", &st) == 0) return st.st_mtime;
+    return time(nullptr);
+}
+
+int write_rendezvous(const char* path, const Rendezvous& rv)
+{
+    const std::string tmp = std::string(path) + ".tmp." + std::to_string((long long)getpid());
+    unlink(path);        // a file of an earlier run must not be readable while this one starts
+    unlink(tmp.c_str());
+    const int fd = open(tmp.c_str(), O_WRONLY | O_CREAT | O_EXCL | O_NOFOLLOW | O_CLOEXEC, 0600);
+    if (fd < 0) return KFX_E_RANGE;
+    const ssize_t n = write(fd, &rv, sizeof(rv));
+    const int c = close(fd);
+    if (n != (ssize_t)sizeof(rv) || c != 0 || rename(tmp.c_str(), path) != 0) {
+        unlink(tmp.c_str());
+        return KFX_E_RANGE;
+    }
+    return 0;
+}
+
+// 1: accepted, 0: not (yet) there / not ours / stale
+int read_rendezvous(const char* path, Rendezvous& rv, uint64_t nonce, time_t not_before)
+{
+    const int fd = open(path, O_RDONLY | O_NOFOLLOW | O_CLOEXEC);
+    if (fd < 0) return 0;
+    struct stat st;
+    bool ok = fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_uid == geteuid() && st.st_size == (off_t)sizeof(rv) &&
+              st.st_mtime + 2 >= not_before;
+    ok = ok && read(fd, &rv, sizeof(rv)) == (ssize_t)sizeof(rv) && memcmp(rv.magic, RDV_MAGIC, 8) == 0 && rv.nonce == nonce;
+    close(fd);
+    return ok ? 1 : 0;
+}
+
 } // namespace
 
 extern "C" int kfx_comm_create_rccl(kfx_comm* comm, int rank, int world, const char* rendezvous_file, int timeout_s)
 {
     if (!comm || (world > 1 && !rendezvous_file)) return KFX_E_NULL;
     if (world < 1 || rank < 0 || rank >= world) return KFX_E_RANGE;
-    ncclUniqueId id;
-    memset(&id, 0, sizeof(id));
+    Rendezvous rv;
+    memset(&rv, 0, sizeof(rv));
+    memcpy(rv.magic, RDV_MAGIC, 8);
+    rv.nonce = launch_nonce();
+    ncclUniqueId& id = rv.id;
     if (rank == 0) {
         const ncclResult_t r = ncclGetUniqueId(&id);
         if (r != ncclSuccess) return nccl_status(r);
-        if (world > 1) {
-            const std::string tmp = std::string(rendezvous_file) + ".tmp";
-            FILE* f = fopen(tmp.c_str(), "wb");
-            if (!f) return KFX_E_RANGE;
-            const size_t n = fwrite(&id, 1, sizeof(id), f);
-            fclose(f);
-            if (n != sizeof(id) || rename(tmp.c_str(), rendezvous_file) != 0) return KFX_E_RANGE;
-        }
+        if (world > 1)
+            if (int e = write_rendezvous(rendezvous_file, rv)) return e;
     } else {
+        const uint64_t nonce = rv.nonce;
+        const time_t started = process_start();
         const auto t0 = std::chrono::steady_clock::now();
-        for (;;) {
-            FILE* f = fopen(rendezvous_file, "rb");
-            if (f) {
-                const size_t n = fread(&id, 1, sizeof(id), f);
-                fclose(f);
-                if (n == sizeof(id)) break;
-            }
+        while (!read_rendezvous(rendezvous_file, rv, nonce, started)) {
             if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(timeout_s > 0 ? timeout_s : 60)) return KFX_E_RANGE;
             std::this_thread::sleep_for(std::chrono::milliseconds(20));
         }

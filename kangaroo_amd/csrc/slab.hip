@@ -70,7 +70,7 @@ struct ThreadGroup {
     const void* send_lo[MAX_THREAD_RANKS];
     const void* send_hi[MAX_THREAD_RANKS];
     size_t bytes_lo[MAX_THREAD_RANKS], bytes_hi[MAX_THREAD_RANKS];
-    int status = 0;
+    int err[MAX_THREAD_RANKS] = {};   // per-rank error of the collective in flight
 
     void wait_all()
     {
@@ -93,31 +93,41 @@ static int hip_status(hipError_t e, const char* what)
     return set_error((int)e, what);
 }
 
+// Every rank passes both barriers of a collective whatever happened locally: a rank that returned early on its own error
+// would leave its peers waiting on the condition variable for ever.  Local errors are posted in err[rank]; after the last
+// barrier every rank returns the first error any rank posted (err[] is cleared by its owner at the start of the next call,
+// which is behind that barrier for every reader).
+static int group_status(const ThreadGroup* g)
+{
+    for (int r = 0; r < g->world; ++r)
+        if (g->err[r]) return g->err[r];
+    return 0;
+}
+
 static int threads_all_reduce(kfx_comm* c, void* buf, size_t count, int op, kfx_stream stream)
 {
     ThreadGroup* g = static_cast<ThreadGroup*>(c->impl);
-    if (!buf && count) return set_error(KFX_E_NULL, "kfx_comm(threads) all_reduce: null buffer");
-    if (int e = hip_status(hipStreamSynchronize((hipStream_t)stream), "kfx_comm(threads) all_reduce")) return e; // this rank's producers are done
+    int st = 0;
+    if (!buf && count) st = set_error(KFX_E_NULL, "kfx_comm(threads) all_reduce: null buffer");
+    if (!st) st = hip_status(hipStreamSynchronize((hipStream_t)stream), "kfx_comm(threads) all_reduce"); // this rank's producers are done
+    g->err[c->rank] = st;
     g->buf[c->rank] = buf;
     g->wait_all();
-    if (c->rank == 0) {
-        int st = 0;
-        if (count) {
-            PtrList pl;
-            for (int r = 0; r < g->world; ++r) pl.p[r] = g->buf[r];
-            const dim3 grid((unsigned)((count + 255) / 256));
-            hipStream_t s = (hipStream_t)stream;
-            if (op == KFX_COMM_MIN_I64) hipLaunchKernelGGL((k_group_reduce<long long, 0>), grid, dim3(256), 0, s, pl, g->world, count);
-            else if (op == KFX_COMM_SUM_F32) hipLaunchKernelGGL((k_group_reduce<float, 1>), grid, dim3(256), 0, s, pl, g->world, count);
-            else if (op == KFX_COMM_SUM_I32) hipLaunchKernelGGL((k_group_reduce<int, 1>), grid, dim3(256), 0, s, pl, g->world, count);
-            else st = set_error(KFX_E_RANGE, "kfx_comm all_reduce: unknown op");
-            if (!st) st = check_launch("kfx_comm(threads) all_reduce");
-            if (!st) st = hip_status(hipStreamSynchronize(s), "kfx_comm(threads) all_reduce");
-        }
-        g->status = st;
+    if (c->rank == 0 && count && group_status(g) == 0) {
+        PtrList pl;
+        for (int r = 0; r < g->world; ++r) pl.p[r] = g->buf[r];
+        const dim3 grid((unsigned)((count + 255) / 256));
+        hipStream_t s = (hipStream_t)stream;
+        if (op == KFX_COMM_MIN_I64) hipLaunchKernelGGL((k_group_reduce<long long, 0>), grid, dim3(256), 0, s, pl, g->world, count);
+        else if (op == KFX_COMM_SUM_F32) hipLaunchKernelGGL((k_group_reduce<float, 1>), grid, dim3(256), 0, s, pl, g->world, count);
+        else if (op == KFX_COMM_SUM_I32) hipLaunchKernelGGL((k_group_reduce<int, 1>), grid, dim3(256), 0, s, pl, g->world, count);
+        else st = set_error(KFX_E_RANGE, "kfx_comm all_reduce: unknown op");
+        if (!st) st = check_launch("kfx_comm(threads) all_reduce");
+        if (!st) st = hip_status(hipStreamSynchronize(s), "kfx_comm(threads) all_reduce");
+        g->err[0] = st;
     }
     g->wait_all();
-    return g->status;
+    return group_status(g);
 }
 
 static int threads_exchange(kfx_comm* c, const void* send_lo, void* recv_lo, size_t bytes_lo, const void* send_hi, void* recv_hi,
@@ -125,40 +135,44 @@ static int threads_exchange(kfx_comm* c, const void* send_lo, void* recv_lo, siz
 {
     ThreadGroup* g = static_cast<ThreadGroup*>(c->impl);
     const int r = c->rank;
-    if (int e = hip_status(hipStreamSynchronize((hipStream_t)stream), "kfx_comm(threads) exchange")) return e;
+    int st = hip_status(hipStreamSynchronize((hipStream_t)stream), "kfx_comm(threads) exchange");
+    g->err[r] = st;
     g->send_lo[r] = send_lo; g->bytes_lo[r] = bytes_lo;
     g->send_hi[r] = send_hi; g->bytes_hi[r] = bytes_hi;
     g->wait_all();
-    int st = 0;
     hipStream_t s = (hipStream_t)stream;
-    if (r > 0 && bytes_lo) { // what rank - 1 sends upwards
+    if (!st && r > 0 && bytes_lo && g->err[r - 1] == 0) { // what rank - 1 sends upwards
         if (g->bytes_hi[r - 1] != bytes_lo) st = set_error(KFX_E_SHAPE, "kfx_comm exchange: neighbours disagree on the byte count");
         else st = hip_status(hipMemcpyAsync(recv_lo, g->send_hi[r - 1], bytes_lo, hipMemcpyDeviceToDevice, s), "kfx_comm(threads) exchange");
     }
-    if (!st && r + 1 < g->world && bytes_hi) { // what rank + 1 sends downwards
+    if (!st && r + 1 < g->world && bytes_hi && g->err[r + 1] == 0) { // what rank + 1 sends downwards
         if (g->bytes_lo[r + 1] != bytes_hi) st = set_error(KFX_E_SHAPE, "kfx_comm exchange: neighbours disagree on the byte count");
         else st = hip_status(hipMemcpyAsync(recv_hi, g->send_lo[r + 1], bytes_hi, hipMemcpyDeviceToDevice, s), "kfx_comm(threads) exchange");
     }
     if (!st) st = hip_status(hipStreamSynchronize(s), "kfx_comm(threads) exchange");
+    if (st) g->err[r] = st;   // (only this rank writes its slot; the readers of the first phase are past their reads of it
+                              //  or read a value that is an error either way)
     g->wait_all(); // nobody reuses a send buffer before its reader is done
-    return st;
+    return group_status(g);
 }
 
 static int threads_broadcast(kfx_comm* c, void* buf, size_t bytes, int root, kfx_stream stream)
 {
     ThreadGroup* g = static_cast<ThreadGroup*>(c->impl);
-    if (root < 0 || root >= g->world) return set_error(KFX_E_RANGE, "kfx_comm broadcast: root");
-    if (!buf && bytes) return set_error(KFX_E_NULL, "kfx_comm(threads) broadcast: null buffer");
-    if (int e = hip_status(hipStreamSynchronize((hipStream_t)stream), "kfx_comm(threads) broadcast")) return e; // the root's producers are done
+    int st = 0;
+    if (root < 0 || root >= g->world) st = set_error(KFX_E_RANGE, "kfx_comm broadcast: root");
+    if (!st && !buf && bytes) st = set_error(KFX_E_NULL, "kfx_comm(threads) broadcast: null buffer");
+    if (!st) st = hip_status(hipStreamSynchronize((hipStream_t)stream), "kfx_comm(threads) broadcast"); // the root's producers are done
+    g->err[c->rank] = st;
     g->buf[c->rank] = buf;
     g->wait_all();
-    int st = 0;
-    if (c->rank != root && bytes) {
+    if (!st && c->rank != root && bytes && g->err[root] == 0) {
         st = hip_status(hipMemcpyAsync(buf, g->buf[root], bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream), "kfx_comm(threads) broadcast");
         if (!st) st = hip_status(hipStreamSynchronize((hipStream_t)stream), "kfx_comm(threads) broadcast");
+        if (st) g->err[c->rank] = st;
     }
     g->wait_all(); // the root keeps its buffer untouched until every reader is done
-    return st;
+    return group_status(g);
 }
 
 static int threads_barrier(kfx_comm* c)

@@ -208,8 +208,17 @@ class SlabPipeline(FramePipeline):
         self.inputs = inputs
         # overlap (composite mode, known-pose streams): the merge of frame k's per-slab images -- two latency-bound
         # all-reduces and three small kernels -- runs on a second stream while the main stream already preprocesses and
-        # integrates frame k + 1; the merged images are complete after wait_composite().
+        # integrates frame k + 1; step() then returns before ray_d / ray_n / ray_i are merged: they are valid only after
+        # wait_composite() (bench.py's sync_all calls it; the next raycast_into waits for it by itself).
         self.overlap = bool(overlap)
+        # The overlapped merge issues its all-reduces from a side stream while the main stream may issue the ghost-plane
+        # send / recv of the next SdfFuse: two NCCL call sequences whose relative order can differ between ranks (and torch may
+        # route point-to-point through a communicator of its own) -- the classic collective-ordering deadlock.  Not allowed.
+        if self.overlap and halo == "exchange":
+            raise ValueError("SlabPipeline: overlap=True needs halo='recompute' (an overlapped merge next to the ghost-plane exchange "
+                             "would interleave collectives in rank-dependent order)")
+        if kw.get("track"):
+            raise ValueError("SlabPipeline: track=True (brick summary) is a single-volume feature; slabs march without it")
         self._side = self._merged = None
         self.halo = halo
         self.raycast_mode = raycast
@@ -301,6 +310,8 @@ class SlabPipeline(FramePipeline):
         self.wait_composite()   # the previous frame's merge still reads these images
         self.ops.RaycastSdf(d, n, i, self.vol, T_wc, K, self.near, self.far, self.trunc, True)
         if self.world > 1:
+            if self.overlap and self.halo == "exchange":
+                raise RuntimeError("SlabPipeline: overlapped merge with halo='exchange' (see __init__)")
             if self.overlap and hasattr(self.ops, "CompositePack"):
                 import torch
                 if self._side is None:
@@ -450,6 +461,10 @@ class TrackingSlabPipeline(SlabPipeline):
 
     def __init__(self, ops, dist, dims, boxmin, boxmax, w, h, its=None, icp_c=0.1, max_rmse=0.10, **kw):
         from . import tracking
+        if kw.get("inputs", "replicate") != "replicate":
+            raise ValueError("TrackingSlabPipeline: inputs='broadcast' is not implemented (every rank builds the frame's pyramids itself)")
+        if kw.get("overlap"):
+            raise ValueError("TrackingSlabPipeline: overlap=True is for known-pose streams (the tracker reads the merged images at once)")
         super().__init__(ops, dist, dims, boxmin, boxmax, w, h, **kw)
         self.tracking = tracking
         self.its = tuple(tracking.DEFAULT_ITS if its is None else its)

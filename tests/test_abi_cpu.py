@@ -167,3 +167,47 @@ def test_product_never_imports_the_oracle():
         p = os.path.join(T.ROOT, "include", f)
         if os.path.isfile(p):
             assert not re.search(r'#\s*include\s*[<"][^>"]*oracle', open(p).read())
+
+
+def test_rccl_rendezvous_rejects_stale_foreign_and_linked_files(tmp_path, monkeypatch):
+    """kfx_comm_create_rccl, ranks > 0 (comm_rccl.cpp): a rendezvous file left by an earlier run (older than this process), one
+    written for another launch (different nonce) and a symlink are all ignored -- the call times out with KFX_E_RANGE instead
+    of handing a foreign ncclUniqueId to ncclCommInitRank (which would hang).  Host-only: no GPU, no RCCL call is reached."""
+    import struct
+    import time
+    lib = os.path.join(os.path.dirname(_lib.LIB_PATH), "libkfx_rccl.so")
+    try:
+        R = C.CDLL(lib)
+    except OSError as e:   # librccl not loadable on this host
+        import pytest
+        pytest.skip("libkfx_rccl.so not loadable here: %r" % (e,))
+    R.kfx_comm_create_rccl.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.c_int]
+    comm = C.create_string_buffer(256)
+    monkeypatch.setenv("KFX_RUN_ID", "this-launch")
+    for k in ("TORCHELASTIC_RUN_ID", "MASTER_PORT", "SLURM_JOB_ID", "SLURM_STEP_ID"):
+        monkeypatch.delenv(k, raising=False)
+
+    def nonce(run_id):   # launch_nonce() of comm_rccl.cpp: FNV-1a over the values present, a 0xff separator after each
+        h = 1469598103934665603
+        for ch in run_id.encode():
+            h = ((h ^ ch) * 1099511628211) & (2 ** 64 - 1)
+        h = ((h ^ 0xff) * 1099511628211) & (2 ** 64 - 1)
+        return h | 1
+
+    def payload(run_id):
+        return b"KFXRDV1\0" + struct.pack("<Q", nonce(run_id)) + bytes(128)
+
+    path = tmp_path / "id"
+    # (1) right nonce, but older than this process
+    path.write_bytes(payload("this-launch"))
+    os.utime(path, (time.time() - 3600, time.time() - 3600))
+    assert R.kfx_comm_create_rccl(comm, 1, 2, str(path).encode(), 1) == -4   # KFX_E_RANGE: timed out
+    # (2) fresh, but another launch's nonce
+    path.write_bytes(payload("another-launch"))
+    assert R.kfx_comm_create_rccl(comm, 1, 2, str(path).encode(), 1) == -4
+    # (3) a symlink to a fresh, well-formed file
+    real = tmp_path / "real"
+    real.write_bytes(payload("this-launch"))
+    path.unlink()
+    path.symlink_to(real)
+    assert R.kfx_comm_create_rccl(comm, 1, 2, str(path).encode(), 1) == -4
