@@ -193,6 +193,11 @@ struct kfx_sdf_summary {
     size_t pitch, img_pitch;
     int dirty;                   // R changed since D was built
     float built_tol;             // tolerance D was built with
+    // class tables of the march (ClassView below): two bit planes per entry, fine level (8^3 or 16^3 cells) then 32^3 cells
+    unsigned* C;                 // device, sized for the finest level
+    int c_dirty;                 // R changed since C was built
+    float c_tol, c_vref;         // what C was built with
+    int c_shift;                 // fine level C was built for (log2 of its cells per entry)
 };
 namespace kfx {
 // Levels 2 and 3 summarise 4 x 4 x 4 entries of the level below: v > 0 / NaN as above when all of them agree, -1 = look
@@ -207,6 +212,32 @@ struct SummaryView {
     int force;      // 0: decide by the counter, 1: always use the summary, -1: never (KFX_RAYCAST_SUMMARY)
     int ox, oy, oz; // cell offset of the view inside the parent volume
 };
+// The class tables the march stages in LDS.  Per entry (a cube of 2^shift cells, together with the +1 cells a trilinear sample
+// based in it reads) two bits: 0 = sample; 1 = every cell holds vref (exact numerics: that bit pattern; fast numerics: within
+// tol) -- a sample there IS vref; 2 = every cell is NaN; 3 = every cell is NaN or holds vref -- the reference's step from
+// there is trunc either way (a NaN sample steps by trunc, cu_raycast.cu:77-80, and vref = trunc >= min_delta), only
+// last_sdf is undecided, and the march settles it with one sample if the next one is a crossing.  A row of entries along x
+// is stored as uint2 {plane 0, plane 1} per 32 entries.
+struct ClassLevel {
+    int shift;        // log2(cells per entry along an axis)
+    int ny;           // entries along y
+    int rw;           // 32-bit words per row of entries: 2 * ceil(nx / 32)
+    int first;        // first word of the level in the table
+};
+struct ClassView {
+    const unsigned* C;   // global copy (fine level, then the 32^3 level)
+    ClassLevel fine, coarse;
+    int words;           // total 32-bit words
+    float vref;          // the value of class 1 (= the launch's trunc_dist)
+    float tol;           // relative tolerance the tables were built with (0: exact numerics)
+    int amb_ok;          // class 3 may be skipped (trunc >= min_delta)
+    int ox, oy, oz;      // cell offset of the view inside the parent volume
+    float eps;           // margin (cells) that covers the error of the affine cell estimate
+    int max_skips;       // 0: never consult the tables (KFX_RAYCAST_SKIP_M=0: measures the kernel's own overhead)
+    int debug;           // KFX_RAYCAST_DEBUG_COUNTS: write per-ray counters instead of the images
+};
+int summary_classes_prepare(kfx_sdf_summary* s, float tol, float vref, int fine_shift, hipStream_t stream);
+void summary_class_layout(const kfx_sdf_summary* s, int fine_shift, ClassView& cv);
 // cell offset of a view of the summary's parent volume (same pitches, pointer inside the parent): 0 on success
 int summary_view_offset(const kfx_sdf_summary* s, const kfx_volume* view, int* ox, int* oy, int* oz);
 // (re)build D if R changed or the tolerance differs

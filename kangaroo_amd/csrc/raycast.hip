@@ -8,6 +8,7 @@
 // loads (the x and x+1 cells of an AoS row are contiguous) instead of eight 8-byte ones;
 // the gradient stencil is 20 distinct cells instead of 32 loads; missed rays skip the
 // (discarded) normal evaluation of the reference.
+#include <cmath>
 #include <cstdlib>
 
 #include <hip/hip_fp16.h>
@@ -191,6 +192,223 @@ __device__ __forceinline__ float raycast_pixel(const RayParams& p, const ColorGe
     return depth > 0 ? depth : __builtin_nanf(""); // the value written to the depth image
 }
 
+
+// ---------------------------------------------------------------------------------------
+// The march through the class tables (SKIP = 2; ClassView, kfx_device.h).  Every workgroup stages the tables -- a 32^3-cell
+// level and a finer one, two bits per entry -- in LDS.  An iteration of a ray is: up to `max_skips` steps that need no memory
+// (the position's entry says what a sample there would be: vref, NaN, or "vref or NaN": the reference's step is known, and
+// with it all following steps up to the entry's far side: bare lambda += delta additions, the reference's own, one per step),
+// then one sample where the entry says "sample".  The entry of a position comes from an affine estimate of the base-cell
+// coordinate, pf(lambda) = A + B lambda: three FMAs instead of the ~30 separately rounded operations of cell_of().  The
+// estimate is within `eps` cells of cell_of()'s coordinate (bound evaluated on the host from the box, the camera and the
+// march range), and a position closer than eps to a cell boundary -- where the two could disagree about the base cell -- is
+// sampled, with cell_of() itself: the skipped steps are exactly those of the reference march, so with the exact-numerics
+// tables (tol = 0: cells bit-equal to trunc, or NaN) depth, normals and shade stay bit-identical to the plain march.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ int class_lookup(const unsigned* tab, const ClassLevel& L, int gx, int gy, int gz)
+{
+    const int bx = gx >> L.shift, by = gy >> L.shift, bz = gz >> L.shift;
+    const uint2 w = *reinterpret_cast<const uint2*>(tab + L.first + (bz * L.ny + by) * L.rw + ((bx >> 5) << 1));
+    return (int)((w.x >> (bx & 31)) & 1u) | (int)(((w.y >> (bx & 31)) & 1u) << 1);
+}
+
+template <typename CELL, bool COLOR>
+__device__ __forceinline__ float raycast_pixel_classes(const RayParams& p, const RayParams& q, const ColorGeom& cv, const int u, const int v, const ClassView& cl, const unsigned* tab)
+{
+    // p: the launch parameters as kernel arguments (scalar registers); q: the workgroup's copy of them in LDS, read by the
+    // epilogue -- pose, intrinsics, output images and the gradient's geometry are then not held in scalar registers across the
+    // march (the loop's own uniforms fill the register file: 22 spilled SGPRs, each a v_readlane in the loop, without this)
+    if (u >= p.w || v >= p.h) return 0.f;
+
+    const V3 c_w = v3(p.T.m[3], p.T.m[7], p.T.m[11]);
+    const V3 ray_c = v3(((float)u - p.K.u0) / p.K.fu, ((float)v - p.K.v0) / p.K.fv, 1.0f);
+    const V3 ray_w = so3_mul(p.T, ray_c);
+    const V3 ta = div_cw(p.vol.bmin - c_w, ray_w);
+    const V3 tb = div_cw(p.vol.bmax - c_w, ray_w);
+    const V3 tmin = v3(fminf(ta.x, tb.x), fminf(ta.y, tb.y), fminf(ta.z, tb.z));
+    const V3 tmax = v3(fmaxf(ta.x, tb.x), fmaxf(ta.y, tb.y), fmaxf(ta.z, tb.z));
+    const float max_tmin = fmaxf(fmaxf(fmaxf(tmin.x, tmin.y), tmin.z), p.near);
+    const float min_tmax = fminf(fminf(fminf(tmax.x, tmax.y), tmax.z), p.far);
+
+    float depth = 0.0f;
+    int dbg_samples = 0, dbg_fail = 0, dbg_runs = 0, dbg_skipped = 0;
+    if (max_tmin < min_tmax) {
+        float lambda = max_tmin;
+        float last_sdf = __builtin_nanf("");
+        const float min_delta = p.voxel.x;
+        float delta = 0.f;
+        // base-cell coordinate along the ray (an estimate: see above), and what leaving an entry costs per axis
+        const V3 sc = v3(p.dims1.x / p.size.x, p.dims1.y / p.size.y, p.dims1.z / p.size.z);
+        const V3 pfA = v3((c_w.x - p.vol.bmin.x) * sc.x, (c_w.y - p.vol.bmin.y) * sc.y, (c_w.z - p.vol.bmin.z) * sc.z);
+        const V3 pfB = v3(ray_w.x * sc.x, ray_w.y * sc.y, ray_w.z * sc.z);
+        const V3 inv = v3(1.0f / pfB.x, 1.0f / pfB.y, 1.0f / pfB.z);   // +-inf for a ray parallel to an axis plane: that axis never ends a run
+        const float eps = cl.eps;
+        const float step_free = fmaxf(cl.vref, min_delta);               // the reference's delta for sdf = vref
+        const float inv_step_free = 1.0f / step_free, inv_trunc = 1.0f / p.trunc;
+        const float band = cl.tol * cl.vref;
+        bool pending = false;      // last_sdf is "vref or NaN": the last step left an entry of class 3
+        float lambda_prev = 0.f;   // where that step started
+        // The tables are consulted where they can help: at the start, after a run, and after a sample that came back as vref
+        // or NaN (free or unseen space); a sample with any other value lies in an entry of class 0.  After a class-0 answer the
+        // ray first leaves that entry (lam_retry).  A ray through a band of mixed values therefore marches as the plain kernel.
+        bool consult = cl.max_skips != 0;   // (KFX_RAYCAST_SKIP_M=0: never -- measures the kernel's own overhead)
+        float lam_retry = lambda;
+        int wait = 0, backoff = 1;   // samples to let pass before the next look at the tables: doubles with every class-0 answer
+        // One iteration of a wave: the lanes that sample request their cells; the lanes that consult the tables do so (LDS and
+        // arithmetic only) while those loads are in flight; then the sampling lanes wait, blend and step.  A lane whose
+        // entry turns out to be class 0 samples in the next iteration.
+        while (lambda < min_tmax) {
+            const bool look = consult && wait == 0 && lambda >= lam_retry;
+            CellPos c{};
+            RayF32::InFlight fl;
+            if (!look) {
+                c = cell_of(p, c_w + ray_w * lambda);
+                trilinear_issue(fl, p, c);
+            }
+            if (look) {
+                const float ex = __builtin_fmaf(pfB.x, lambda, pfA.x), ey = __builtin_fmaf(pfB.y, lambda, pfA.y), ez = __builtin_fmaf(pfB.z, lambda, pfA.z);
+                const float flx = floorf(ex), fly = floorf(ey), flz = floorf(ez);
+                const float lo_f = fminf(fminf(ex - flx, ey - fly), ez - flz), hi_f = fmaxf(fmaxf(ex - flx, ey - fly), ez - flz);
+                // inside [0, dims - 1) with the margin on every axis: the base cell is floor(pf), no clamp involved; and at least
+                // eps away from every cell boundary: cell_of() finds the same base cell
+                bool run = false;
+                if (fminf(fminf(ex, ey), ez) > eps && ex < p.dims1.x - eps && ey < p.dims1.y - eps && ez < p.dims1.z - eps && lo_f > eps && hi_f < 1.0f - eps) {
+                    const int gx = (int)flx + cl.ox, gy = (int)fly + cl.oy, gz = (int)flz + cl.oz;
+                    // the fine level answers "sample here?"; only a positive answer is worth the second look that may extend
+                    // the run to the whole 32^3-cell entry
+                    int cls = class_lookup(tab, cl.fine, gx, gy, gz), shift = cl.fine.shift;
+                    if (cls == 3 && !cl.amb_ok) cls = 0;
+                    if (cls != 0 && cl.fine.shift < 5) {
+                        int c5 = class_lookup(tab, cl.coarse, gx, gy, gz);
+                        if (c5 == 3 && !cl.amb_ok) c5 = 0;
+                        if (c5 != 0) { cls = c5; shift = 5; }
+                    }
+                    // the entry's cells are [lo, lo + L) per axis in the view's coordinates; its far side along the ray, pulled in
+                    // by the margin: positions up to there certainly have their base cell in the entry
+                    const float L = (float)(1 << shift);
+                    const float lox = (float)(((gx >> shift) << shift) - cl.ox), loy = (float)(((gy >> shift) << shift) - cl.oy),
+                                loz = (float)(((gz >> shift) << shift) - cl.oz);
+                    const float bx = pfB.x >= 0.f ? lox + L - eps : lox + eps, by = pfB.y >= 0.f ? loy + L - eps : loy + eps,
+                                bz = pfB.z >= 0.f ? loz + L - eps : loz + eps;
+                    const float lam_exit = fminf(fminf((bx - pfA.x) * inv.x, (by - pfA.y) * inv.y), (bz - pfA.z) * inv.z);
+                    if (cls != 0) {
+                        // the reference's step for a sample of vref (class 1) or NaN (2; 3: the two steps are equal), taken from
+                        // this position and from the following ones that still start inside the entry (and the box): n steps,
+                        // n - 1 <= (lam_last - lambda) / delta less a hundredth for the quotient's rounding
+                        delta = cls == 1 ? step_free : p.trunc;
+                        pending = cls == 3;
+                        last_sdf = cls == 1 ? cl.vref : __builtin_nanf("");
+                        const float lam_last = fminf(lam_exit, min_tmax);
+                        const float more = fminf(floorf((lam_last - lambda) * (cls == 1 ? inv_step_free : inv_trunc) - 0.01f), 4096.f);
+                        if (cl.tol > 0.f) {
+                            // fast numerics: the run in one multiply-add (the sum differs from n separately rounded additions by a
+                            // few ulp of lambda: far inside the mode's tolerance)
+                            const float nm = fmaxf(more, 0.f);
+                            lambda_prev = __builtin_fmaf(nm, delta, lambda);
+                            lambda = lambda_prev + delta;
+                            if (cl.debug) dbg_skipped += 1 + (int)nm;
+                        } else {
+                            // exact numerics: the reference's own additions, one per step
+                            lambda_prev = lambda;
+                            lambda += delta;
+                            for (int k = (int)more; k > 0; --k) { lambda_prev = lambda; lambda += delta; }
+                            if (cl.debug) dbg_skipped += 1 + max((int)more, 0);
+                        }
+                        if (cl.debug) dbg_runs += 1;
+                        backoff = 1;
+                        run = true;
+                    } else {
+                        lam_retry = lam_exit;   // class 0: nothing to learn before the ray has left this entry
+                    }
+                }
+                if (!run) {
+                    if (cl.debug) dbg_fail += 1;
+                    wait = backoff;
+                    backoff = min(backoff * 2, 32);
+                }
+            }
+            if (!look) {
+                const float sdf = trilinear_finish(fl, c);
+                dbg_samples += 1;
+                if (cl.debug > 1 && dbg_samples >= cl.debug) break;   // KFX_RAYCAST_DEBUG_COUNTS=N > 1: rays give up after N samples (tail experiments)
+                wait = max(wait - 1, 0);
+                if (sdf <= 0) {
+                    // a crossing needs the previous sample's value: the one thing a class-3 step left open
+                    if (pending) last_sdf = trilinear<CELL>(p, c_w + ray_w * lambda_prev);
+                    if (last_sdf > 0) {
+                        if (p.subpix) lambda = lambda + delta * sdf / (last_sdf - sdf);
+                        depth = lambda;
+                    }
+                    break;
+                }
+                delta = sdf > 0 ? fmaxf(sdf, min_delta) : p.trunc;
+                lambda += delta;
+                last_sdf = sdf;
+                pending = false;
+                consult = cl.max_skips != 0 && !(fabsf(sdf - cl.vref) > band);   // vref (within the tables' tolerance) or NaN
+            }
+        }
+    }
+
+    float* pd = reinterpret_cast<float*>(q.dptr + (size_t)v * q.dpitch) + u;
+    float* pi = reinterpret_cast<float*>(q.iptr + (size_t)v * q.ipitch) + u;
+    float4* pn = reinterpret_cast<float4*>(q.nptr + (size_t)v * q.npitch) + u;
+    if (cl.debug) {   // KFX_RAYCAST_DEBUG_COUNTS=1: per-ray counters instead of the images (scripts/raycast_classes_ab.py)
+        *pd = depth > 0 ? depth : __builtin_nanf("");
+        *pi = (float)dbg_samples;
+        *pn = make_float4((float)dbg_fail, (float)dbg_runs, (float)dbg_skipped, 0.f);
+        return 0.f;
+    }
+    if (depth > 0) {
+        // the ray again, from the LDS copy: the same expressions on the same values
+        const V3 cq = v3(q.T.m[3], q.T.m[7], q.T.m[11]);
+        const V3 rcq = v3(((float)u - q.K.u0) / q.K.fu, ((float)v - q.K.v0) / q.K.fv, 1.0f);
+        const V3 rq = so3_mul(q.T, rcq);
+        const V3 g = gradient<CELL>(q, cq + rq * depth);
+        const float len = length(g);
+        const V3 n_w = len > 0 ? div_s(g, len) : v3(0.f, 0.f, 1.f);
+        const V3 n_c = so3_mul_inv(q.T, n_w);
+        const V3 p_c = rcq * depth;
+        *pd = depth;
+        if constexpr (COLOR) *pi = trilinear<RayC32>(cv, cq + rq * depth);
+        else *pi = phong(p_c, n_c);
+        *pn = make_float4(n_c.x, n_c.y, n_c.z, 1.0f);
+    } else {
+        *pd = __builtin_nanf("");
+        *pi = 0.f;
+        *pn = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    return depth > 0 ? depth : __builtin_nanf("");
+}
+
+// workgroup prologue of the class-table kernels: the tables into LDS (16-byte loads, all in flight together)
+__device__ __forceinline__ void classes_stage(const ClassView& cl, unsigned* tab)
+{
+    const uint4* src = reinterpret_cast<const uint4*>(cl.C);
+    uint4* dst = reinterpret_cast<uint4*>(tab);
+    for (int i = threadIdx.x; i < (cl.words >> 2); i += blockDim.x) dst[i] = src[i];
+    __syncthreads();
+}
+
+template <typename CELL>
+__global__ __launch_bounds__(256) void k_raycast_sdf_classes(const RayParams p, const ClassView cl)
+{
+    extern __shared__ unsigned s_tab[];
+    __shared__ RayParams s_p;
+    if (threadIdx.x == 0) s_p = p;
+    classes_stage(cl, s_tab);   // (barrier inside)
+    int u, v;
+    if (p.sparse_lanes) {
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        if (lane >= p.sparse_lanes) return;
+        u = (blockIdx.x * 2 + (wv & 1)) * p.sparse_lanes + lane;
+        v = blockIdx.y * 2 + (wv >> 1);
+    } else {
+        ray_pixel_of(p, blockIdx.x, blockIdx.y, threadIdx.x, u, v);
+    }
+    raycast_pixel_classes<CELL, false>(p, s_p, ColorGeom{}, u, v, cl, s_tab);
+}
+
 // SKIP kernels, workgroup prologue: decide whether the summary is worth consulting and, if so, stage its coarse levels in
 // LDS (`s_sum`: level 2, n2 entries; then level 3, n3 entries).  Returns the (workgroup-uniform) decision.
 __device__ __forceinline__ bool summary_stage(const SummaryView& sv, float* s_sum, const float*& lds_D3, const float*& lds_D2)
@@ -325,6 +543,38 @@ __global__ __launch_bounds__(256) void k_raycast_sdf_levels(const RayParams base
     }
     const float kz = raycast_pixel<CELL, false, SKIP>(p, ColorGeom{}, u, v, sv, lds_D3, lds_D2, use_summary);
     if (lv.vptr && u < p.w && v < p.h) // the application's DepthToVbo(ray_v[l], ray_d[l], K[l]) (main.cpp:286), same expression
+        reinterpret_cast<float4*>(lv.vptr + (size_t)v * lv.vpitch)[u] =
+            make_float4(kz * ((float)u - p.K.u0) / p.K.fu, kz * ((float)v - p.K.v0) / p.K.fv, kz, 1.0f);
+}
+
+template <typename CELL>
+__global__ __launch_bounds__(256) void k_raycast_sdf_levels_classes(const RayParams base, const RayLevels L, const ClassView cl)
+{
+    extern __shared__ unsigned s_tab[];
+    __shared__ RayParams s_p;
+    int l = 0;
+    for (int k = 1; k < L.n; ++k)
+        if ((int)blockIdx.x >= L.lv[k].first_block) l = k; // uniform
+    const RayLevel& lv = L.lv[l];
+    RayParams p = base;
+    p.dptr = lv.dptr; p.nptr = lv.nptr; p.iptr = lv.iptr;
+    p.dpitch = lv.dpitch; p.npitch = lv.npitch; p.ipitch = lv.ipitch;
+    p.w = lv.w; p.h = lv.h;
+    p.K = lv.K;
+    if (threadIdx.x == 0) s_p = p;
+    classes_stage(cl, s_tab);   // before any lane leaves (barrier inside)
+    const int b = (int)blockIdx.x - lv.first_block;
+    int u, v;
+    if (lv.sparse) {
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        if (lane >= lv.sparse) return;
+        u = ((b % lv.blocks_x) * 2 + (wv & 1)) * lv.sparse + lane;
+        v = (b / lv.blocks_x) * 2 + (wv >> 1);
+    } else {
+        ray_pixel_of(p, b % lv.blocks_x, b / lv.blocks_x, threadIdx.x, u, v);
+    }
+    const float kz = raycast_pixel_classes<CELL, false>(p, s_p, ColorGeom{}, u, v, cl, s_tab);
+    if (lv.vptr && u < p.w && v < p.h)
         reinterpret_cast<float4*>(lv.vptr + (size_t)v * lv.vpitch)[u] =
             make_float4(kz * ((float)u - p.K.u0) / p.K.fu, kz * ((float)v - p.K.v0) / p.K.fv, kz, 1.0f);
 }
@@ -517,6 +767,58 @@ static int summary_view(SummaryView& sv, size_t* lds_bytes, kfx_sdf_summary* sum
     return 0;
 }
 
+// The class-table march's view of a summary for a launch on `vol` with camera T_wc: brings the tables up to date on `stream`,
+// evaluates the margin that covers the affine cell estimate, reports the LDS bytes.  *usable = 0: march plainly (the margin
+// would be too wide, or trunc is not positive).
+static int class_view(ClassView& cl, size_t* lds_bytes, int* usable, kfx_sdf_summary* summary, const kfx_volume* vol, const RayParams& p, kfx_stream stream)
+{
+    *usable = 0;
+    if (int e = summary_view_offset(summary, vol, &cl.ox, &cl.oy, &cl.oz)) return e;
+    if (!(p.trunc > 0.f) || !(p.trunc < __builtin_inff())) return 0;
+    static const int kb_env = [] { const char* e = getenv("KFX_RAYCAST_CLASS_KB"); const int v = e ? atoi(e) : 16; return v < 1 ? 1 : (v > 60 ? 60 : v); }();
+    static const int m_env = [] { const char* e = getenv("KFX_RAYCAST_SKIP_M"); const int v = e ? atoi(e) : 2; return v < 0 ? 0 : (v > 64 ? 64 : v); }();
+    int fine = 3;
+    for (; fine < 5; ++fine) {
+        summary_class_layout(summary, fine, cl);
+        if ((size_t)cl.words * 4 <= (size_t)kb_env * 1024) break;
+    }
+    summary_class_layout(summary, fine, cl);
+    if ((size_t)cl.words * 4 > 60 * 1024) return 0;
+    const float tol = math_mode() == KFX_MATH_FAST ? 1e-5f : 0.f;
+    if (int e = summary_classes_prepare(summary, tol, p.trunc, fine, (hipStream_t)stream)) return e;
+    cl.C = summary->C;
+    cl.vref = p.trunc;
+    cl.amb_ok = p.trunc >= p.voxel.x ? 1 : 0;   // class 3 needs equal steps for a vref and a NaN sample: max(trunc, min_delta) = trunc
+    cl.max_skips = m_env;
+    cl.tol = tol;
+    static const int dbg_env = [] { const char* e = getenv("KFX_RAYCAST_DEBUG_COUNTS"); return e ? atoi(e) : 0; }();
+    cl.debug = dbg_env;
+    // margin: |cell_of()'s coordinate - the affine estimate| per axis, from the roundings of both (u = 2^-24):
+    //   cell_of:   pos = c + ray lambda (2 roundings of magnitudes <= |pos| + |c|), - bmin, / size, * dims1
+    //   estimate:  A = (c - bmin) sc (3 roundings), B = ray sc (2), fma(B, lambda, A) (1); and the run's far side
+    //              (bound - A) / B, whose error in this axis' coordinate is 3 u (|bound| + |A|) whatever B is
+    const double u24 = 1.0 / 16777216.0;
+    double eps = 0.0;
+    const float bmin[3] = {p.vol.bmin.x, p.vol.bmin.y, p.vol.bmin.z}, bmax[3] = {p.vol.bmax.x, p.vol.bmax.y, p.vol.bmax.z};
+    const float size[3] = {p.size.x, p.size.y, p.size.z}, dims1[3] = {p.dims1.x, p.dims1.y, p.dims1.z};
+    const float cw[3] = {p.T.m[3], p.T.m[7], p.T.m[11]};
+    for (int a = 0; a < 3; ++a) {
+        if (!(size[a] > 0.f)) return 0;
+        const double sc = (double)dims1[a] / size[a];
+        const double pmax = std::fmax(std::fabs((double)bmin[a]), std::fabs((double)bmax[a])), ca = std::fabs((double)cw[a]);
+        const double A = std::fabs(((double)cw[a] - bmin[a]) * sc);
+        const double t = sc * (3.0 * pmax + 2.0 * ca + size[a]) * u24 + 2.0 * dims1[a] * u24;
+        const double e = u24 * (3.0 * A + 2.0 * sc * (pmax + ca) + dims1[a]) + 3.0 * u24 * (dims1[a] + A);
+        eps = std::fmax(eps, t + e);
+    }
+    eps *= 2.0;   // twice the bound
+    if (!(eps < 0.05)) return 0;
+    cl.eps = (float)std::fmax(eps, 1e-4);
+    *lds_bytes = (size_t)cl.words * sizeof(unsigned);
+    *usable = 1;
+    return 0;
+}
+
 template <typename CELL>
 static int raycast_levels_launch(int n_levels, const kfx_image* const* depth, const kfx_image* const* norm, const kfx_image* const* img,
                                  const kfx_image* const* vbo, const kfx_volume* vol, const float T_wc[12], const float* K, float near, float far,
@@ -556,6 +858,16 @@ static int raycast_levels_launch(int n_levels, const kfx_image* const* depth, co
     if (L.n == 0) return 0;
     if (summary) {
         if constexpr (CELL::BYTES == 8) {
+            static const int classes_env = [] { const char* e = getenv("KFX_RAYCAST_CLASSES"); return e ? atoi(e) : 1; }(); // 0: the round-2 region march
+            if (classes_env) {
+                ClassView cl;
+                size_t cl_bytes = 0;
+                int usable = 0;
+                if (int e = class_view(cl, &cl_bytes, &usable, summary, vol, base, stream)) return e;
+                if (usable) hipLaunchKernelGGL((k_raycast_sdf_levels_classes<CELL>), dim3(blocks), dim3(256), cl_bytes, (hipStream_t)stream, base, L, cl);
+                else hipLaunchKernelGGL((k_raycast_sdf_levels<CELL, false>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, base, L, SummaryView{});
+                return check_launch("kfx_raycast_sdf_levels_tracked");
+            }
             SummaryView sv;
             size_t lds_bytes = 0;
             if (int e = summary_view(sv, &lds_bytes, summary, vol, stream)) return e;
@@ -603,6 +915,18 @@ static int raycast_launch(const kfx_image* depth, const kfx_image* norm, const k
         set_geometry(cv, colorvol);
         hipLaunchKernelGGL((k_raycast_sdf<CELL, true>), grid, dim3(256), 0, (hipStream_t)stream, p, cv, SummaryView{});
     } else if (summary) {
+        static const int classes_env = [] { const char* e = getenv("KFX_RAYCAST_CLASSES"); return e ? atoi(e) : 1; }(); // 0: the round-2 region march
+        if constexpr (CELL::BYTES == 8) {
+            if (classes_env) {
+                ClassView cl;
+                size_t cl_bytes = 0;
+                int usable = 0;
+                if (int e = class_view(cl, &cl_bytes, &usable, summary, vol, p, stream)) return e;
+                if (usable) hipLaunchKernelGGL((k_raycast_sdf_classes<CELL>), grid, dim3(256), cl_bytes, (hipStream_t)stream, p, cl);
+                else hipLaunchKernelGGL((k_raycast_sdf<CELL, false>), grid, dim3(256), 0, (hipStream_t)stream, p, cv, SummaryView{});
+                return check_launch("kfx_raycast_sdf_tracked");
+            }
+        }
         SummaryView sv;
         size_t lds_bytes = 0;
         if (int e = summary_view(sv, &lds_bytes, summary, vol, stream)) return e;

@@ -51,7 +51,11 @@ struct RayF32 {
     {
         typedef float f4 __attribute__((ext_vector_type(4)));
         f4 a, b, c, d;
-        asm volatile("global_load_dwordx4 %0, %4, %8\n\t"
+        // s_nop 4: `base` may have just been written by a VALU instruction (v_readlane of a spilled SGPR, v_readfirstlane);
+        // a VMEM instruction that reads such an SGPR needs five wait states, and the compiler's hazard recogniser does not look
+        // inside an asm block (found as a memory fault in k_raycast_sdf_levels_classes: the first load used a stale base)
+        asm volatile("s_nop 4\n\t"
+                     "global_load_dwordx4 %0, %4, %8\n\t"
                      "global_load_dwordx4 %1, %5, %8\n\t"
                      "global_load_dwordx4 %2, %6, %8\n\t"
                      "global_load_dwordx4 %3, %7, %8\n\t"
@@ -60,6 +64,38 @@ struct RayF32 {
                      : "v"(o0), "v"(o1), "v"(o2), "v"(o3), "s"(base)
                      : "memory");
         c0 = make_float2(a.x, a.z); c1 = make_float2(b.x, b.z); c2 = make_float2(c.x, c.z); c3 = make_float2(d.x, d.z);
+    }
+    // The same loads split in two: issue() requests the four row pairs and returns at once, finish() waits for them.  Between
+    // the two the caller may run code that touches neither global memory nor the four result vectors (the class-table march
+    // runs its LDS lookups for the other lanes of the wave there): the compiler does not know the loads are in flight, the
+    // "+v" operands of finish() keep the vectors allocated and untouched until the wait has passed.
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    struct InFlight { f4v a, b, c, d; };
+    __device__ static __forceinline__ void issue_off32(InFlight& f, const unsigned char* base, unsigned o0, unsigned o1, unsigned o2, unsigned o3)
+    {
+        asm volatile("s_nop 4\n\t"
+                     "global_load_dwordx4 %0, %4, %8\n\t"
+                     "global_load_dwordx4 %1, %5, %8\n\t"
+                     "global_load_dwordx4 %2, %6, %8\n\t"
+                     "global_load_dwordx4 %3, %7, %8"
+                     : "=&v"(f.a), "=&v"(f.b), "=&v"(f.c), "=&v"(f.d)
+                     : "v"(o0), "v"(o1), "v"(o2), "v"(o3), "s"(base)
+                     : "memory");
+    }
+    __device__ static __forceinline__ void issue(InFlight& f, const unsigned char* base, size_t o0, size_t o1, size_t o2, size_t o3)
+    {
+        asm volatile("global_load_dwordx4 %0, %4, off\n\t"
+                     "global_load_dwordx4 %1, %5, off\n\t"
+                     "global_load_dwordx4 %2, %6, off\n\t"
+                     "global_load_dwordx4 %3, %7, off"
+                     : "=&v"(f.a), "=&v"(f.b), "=&v"(f.c), "=&v"(f.d)
+                     : "v"(base + o0), "v"(base + o1), "v"(base + o2), "v"(base + o3)
+                     : "memory");
+    }
+    __device__ static __forceinline__ void finish(InFlight& f, float2& c0, float2& c1, float2& c2, float2& c3)
+    {
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(f.a), "+v"(f.b), "+v"(f.c), "+v"(f.d) : : "memory");
+        c0 = make_float2(f.a.x, f.a.z); c1 = make_float2(f.b.x, f.b.z); c2 = make_float2(f.c.x, f.c.z); c3 = make_float2(f.d.x, f.d.z);
     }
 };
 struct __attribute__((aligned(4))) PairH { unsigned a, b; };
@@ -162,6 +198,27 @@ __device__ __forceinline__ float trilinear_at(const GEOM& p, const CellPos& c)
     }
     return lerp(lerp(lerp(c00.x, c00.y, fx), lerp(c10.x, c10.y, fx), fy),
                 lerp(lerp(c01.x, c01.y, fx), lerp(c11.x, c11.y, fx), fy), fz);
+}
+
+// trilinear_at() in two halves (fp32 cells): request the eight cells, and -- later -- wait for them and blend
+template <typename GEOM>
+__device__ __forceinline__ void trilinear_issue(RayF32::InFlight& f, const GEOM& p, const CellPos& c)
+{
+    if (p.off32) { // launch-uniform
+        const unsigned pitch = (unsigned)p.vol.pitch, img = (unsigned)p.vol.img_pitch;
+        const unsigned o = (unsigned)c.iz * img + (unsigned)c.iy * pitch + (unsigned)c.ix * 8u;
+        RayF32::issue_off32(f, p.vol.ptr, o, o + pitch, o + img, o + img + pitch);
+    } else {
+        const size_t o = (size_t)c.iz * p.vol.img_pitch + (size_t)c.iy * p.vol.pitch + (size_t)c.ix * 8;
+        RayF32::issue(f, p.vol.ptr, o, o + p.vol.pitch, o + p.vol.img_pitch, o + p.vol.img_pitch + p.vol.pitch);
+    }
+}
+__device__ __forceinline__ float trilinear_finish(RayF32::InFlight& f, const CellPos& c)
+{
+    float2 c00, c10, c01, c11;
+    RayF32::finish(f, c00, c10, c01, c11);
+    return lerp(lerp(lerp(c00.x, c00.y, c.fx), lerp(c10.x, c10.y, c.fx), c.fy),
+                lerp(lerp(c01.x, c01.y, c.fx), lerp(c11.x, c11.y, c.fx), c.fy), c.fz);
 }
 
 template <typename CELL, typename GEOM>

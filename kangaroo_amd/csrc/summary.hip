@@ -76,6 +76,79 @@ __global__ __launch_bounds__(256) void k_summary_build(const float4* __restrict_
     if (threadIdx.x == 0) partials[blockIdx.x] = s_useful[0] + s_useful[1] + s_useful[2] + s_useful[3];
 }
 
+// Class tables (ClassView, kfx_device.h).  One lane per entry, 64 consecutive entries of a row per wave; the two planes are
+// the wave's ballots.  An entry of 2^shift cells reads the summary bricks [b << (shift - 3), (b + 1) << (shift - 3)] per axis
+// (the last one holds the +1 cells), clamped to the grid.
+__global__ __launch_bounds__(256) void k_summary_classes(const float4* __restrict__ R, unsigned* __restrict__ C, int nbx, int nby, int nbz,
+                                                          int shift, int nx, int ny, int nz, int rw, float lo_ok, float hi_ok)
+{
+    const int lane = threadIdx.x & 63;
+    const int chunks = (nx + 63) >> 6;
+    const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wave >= (long long)chunks * ny * nz) return;
+    const int chunk = (int)(wave % chunks), by = (int)((wave / chunks) % ny), bz = (int)(wave / ((long long)chunks * ny));
+    const int bx = chunk * 64 + lane;
+    int cls = 0;
+    if (bx < nx) {
+        const int m = 1 << (shift - 3);
+        bool all_nan = true, all_free = true, all_either = true;
+        for (int z = bz * m; z <= bz * m + m; ++z)
+            for (int y = by * m; y <= by * m + m; ++y)
+                for (int x = bx * m; x <= bx * m + m; ++x) {
+                    const float4 r = R[((size_t)min(z, nbz - 1) * nby + min(y, nby - 1)) * nbx + min(x, nbx - 1)];
+                    const int st = __float_as_int(r.z);
+                    const bool in_band = r.x >= lo_ok && r.y <= hi_ok;   // every valued cell of the brick holds vref (false for the unknown state's infinite range)
+                    all_nan = all_nan && st == 1;
+                    all_free = all_free && st == 0 && in_band;
+                    all_either = all_either && (st == 1 || in_band);
+                }
+        cls = all_free ? 1 : (all_nan ? 2 : (all_either ? 3 : 0));
+    }
+    const unsigned long long p0 = __ballot(cls & 1), p1 = __ballot(cls & 2);
+    if (lane == 0) {
+        unsigned* row = C + ((size_t)bz * ny + by) * rw + chunk * 4;
+        row[0] = (unsigned)p0; row[1] = (unsigned)p1;
+        if (chunk * 4 + 2 < rw) { row[2] = (unsigned)(p0 >> 32); row[3] = (unsigned)(p1 >> 32); }
+    }
+}
+
+static void class_level(ClassLevel& L, int shift, int w, int h, int first)
+{
+    L.shift = shift;
+    L.ny = ceil_div(h, 1 << shift);
+    L.rw = 2 * ceil_div(ceil_div(w, 1 << shift), 32);
+    L.first = first;
+}
+static int class_level_words(const ClassLevel& L, int d) { return L.rw * L.ny * ceil_div(d, 1 << L.shift); }
+
+// layout of the tables for a fine level of 2^fine_shift cells (3 or 4; 5 = the coarse level only)
+void summary_class_layout(const kfx_sdf_summary* s, int fine_shift, ClassView& cv)
+{
+    class_level(cv.fine, fine_shift, s->w, s->h, 0);
+    const int fw = fine_shift < 5 ? class_level_words(cv.fine, s->d) : 0;
+    class_level(cv.coarse, 5, s->w, s->h, (fw + 3) & ~3);
+    cv.words = cv.coarse.first + ((class_level_words(cv.coarse, s->d) + 3) & ~3);
+}
+
+int summary_classes_prepare(kfx_sdf_summary* s, float tol, float vref, int fine_shift, hipStream_t stream)
+{
+    if (!s->c_dirty && s->c_tol == tol && s->c_vref == vref && s->c_shift == fine_shift) return 0;
+    ClassView cv;
+    summary_class_layout(s, fine_shift, cv);
+    const float lo_ok = vref - tol * vref, hi_ok = vref + tol * vref;
+    for (int pass = 0; pass < 2; ++pass) {
+        const ClassLevel& L = pass ? cv.coarse : cv.fine;
+        if (!pass && fine_shift >= 5) continue;
+        const int nx = ceil_div(s->w, 1 << L.shift), ny = L.ny, nz = ceil_div(s->d, 1 << L.shift);
+        const long long waves = (long long)ceil_div(nx, 64) * ny * nz;
+        hipLaunchKernelGGL(k_summary_classes, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, stream, s->R, s->C + L.first, s->nbx, s->nby, s->nbz,
+                           L.shift, nx, ny, nz, L.rw, lo_ok, hi_ok);
+        if (int e = check_launch("kfx_sdf_summary (classes)")) return e;
+    }
+    s->c_dirty = 0; s->c_tol = tol; s->c_vref = vref; s->c_shift = fine_shift;
+    return 0;
+}
+
 int summary_view_offset(const kfx_sdf_summary* s, const kfx_volume* view, int* ox, int* oy, int* oz)
 {
     if (!s || !view || !view->ptr) return set_error(KFX_E_NULL, "summary: null argument");
@@ -118,6 +191,7 @@ extern "C" int kfx_sdf_summary_create(kfx_sdf_summary** out, const kfx_volume* v
     s->base = static_cast<const unsigned char*>(vol->ptr);
     s->pitch = vol->pitch; s->img_pitch = vol->img_pitch;
     s->dirty = 1; s->built_tol = -1.f;
+    s->C = nullptr; s->c_dirty = 1; s->c_tol = -1.f; s->c_vref = 0.f; s->c_shift = 0;
     const size_t n = (size_t)s->nbx * s->nby * s->nbz;
     s->n2x = ceil_div(s->nbx, 4); s->n2y = ceil_div(s->nby, 4); s->n2z = ceil_div(s->nbz, 4);
     s->n3x = ceil_div(s->n2x, 4); s->n3y = ceil_div(s->n2y, 4); s->n3z = ceil_div(s->n2z, 4);
@@ -128,6 +202,16 @@ extern "C" int kfx_sdf_summary_create(kfx_sdf_summary** out, const kfx_volume* v
         if (s->R) (void)hipFree(s->R);
         delete s;
         return set_error(KFX_E_NODEVICE, "kfx_sdf_summary_create: hipMalloc");
+    }
+    {
+        ClassView cv;
+        summary_class_layout(s, 3, cv);   // the finest level is the largest table
+        if (hipMalloc((void**)&s->C, (size_t)cv.words * sizeof(unsigned)) != hipSuccess) {
+            (void)hipGetLastError();
+            (void)hipFree(s->R); (void)hipFree(s->D);
+            delete s;
+            return set_error(KFX_E_NODEVICE, "kfx_sdf_summary_create: hipMalloc");
+        }
     }
     s->D2 = s->D + ((n + 3) & ~(size_t)3);   // 16-byte aligned: the ray-march stages it with float4 loads
     s->D3 = s->D2 + n2;
@@ -142,6 +226,7 @@ extern "C" int kfx_sdf_summary_destroy(kfx_sdf_summary* s)
     if (!s) return 0;
     (void)hipFree(s->R);
     (void)hipFree(s->D);
+    (void)hipFree(s->C);
     delete s;
     return 0;
 }
@@ -153,7 +238,7 @@ extern "C" int kfx_sdf_summary_invalidate(kfx_sdf_summary* s, kfx_stream stream)
     if (!s) return set_error(KFX_E_NULL, "kfx_sdf_summary_invalidate: null summary");
     const size_t n = (size_t)s->nbx * s->nby * s->nbz;
     hipLaunchKernelGGL(k_summary_fill, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, s->R, n, -__builtin_inff(), __builtin_inff(), 2);
-    s->dirty = 1;
+    s->dirty = 1; s->c_dirty = 1;
     return check_launch("kfx_sdf_summary_invalidate");
 }
 
@@ -170,6 +255,6 @@ extern "C" int kfx_sdf_reset_tracked(const kfx_volume* vol, kfx_sdf_summary* s, 
     const bool nan = trunc_dist != trunc_dist;
     hipLaunchKernelGGL(k_summary_fill, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, s->R, n,
                        nan ? __builtin_inff() : trunc_dist, nan ? -__builtin_inff() : trunc_dist, nan ? 1 : 0);
-    s->dirty = 1;
+    s->dirty = 1; s->c_dirty = 1;
     return check_launch("kfx_sdf_reset_tracked");
 }

@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""RaycastSdf at 512^3 / 640x480 after a few tracked frames: plain march against the class-table march (environment knobs are
+read once per process, so run it once per configuration: KFX_RAYCAST_CLASSES, KFX_RAYCAST_CLASS_KB, KFX_RAYCAST_SKIP_M).
+Prints kernel times (median of 20 launches, HIP events), tracked / untracked SdfFuse times and the image differences."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+from kangaroo_amd import roo, scenes  # noqa: E402
+
+N, w, h = 512, 640, 480
+frames = int(os.environ.get("AB_FRAMES", "8"))
+tag = " ".join("%s=%s" % (k, os.environ[k]) for k in ("KFX_RAYCAST_CLASSES", "KFX_RAYCAST_CLASS_KB", "KFX_RAYCAST_SKIP_M") if k in os.environ) or "defaults"
+for scene in sys.argv[1:] or ("full", "room"):
+    bmin, bmax, near, far = scenes.SCENES[scene]
+    K = scenes.intrinsics(w, h)
+    tr = scenes.trunc_dist(bmin, bmax, (N, N, N))
+    for math in os.environ.get("AB_MATH", "fast,exact").split(","):
+        roo.set_math_mode(math)
+        vol = roo.BoundedVolume(N, N, N, bmin, bmax)
+        summ = roo.SdfSummary(vol)
+        roo.SdfReset(vol, float("nan"), summary=summ)
+        f, vbo, nrm = roo.Image(w, h), roo.Image(w, h, "f32x4"), roo.Image(w, h, "f32x4")
+        for i in range(frames):
+            T_wc = scenes.orbit_pose(i, 30)
+            roo.BilateralFilter(f, roo.Image(w, h).MemcpyFromHost(scenes.render_depth(scene, w, h, T_wc, K)), **scenes.BILATERAL)
+            roo.DepthToVbo(vbo, f, K)
+            roo.NormalsFromVbo(nrm, vbo)
+            roo.SdfFuse(vol, f, nrm, scenes.se3_inverse(T_wc), K, tr, scenes.MAX_W, scenes.MIN_COS_THETA, summary=summ)
+        T_wc = scenes.orbit_pose(frames - 1, 30)
+        out = {}
+        for name, kw in (("plain", {}), ("classes", {"summary": summ})):
+            imgs = [roo.Image(w, h), roo.Image(w, h, "f32x4"), roo.Image(w, h)]
+            ms = []
+            for i in range(24):
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                roo.RaycastSdf(*imgs, vol, T_wc, K, near, far, tr, True, **kw)
+                b.record()
+                torch.cuda.synchronize()
+                ms.append(a.elapsed_time(b))
+            out[name] = (float(np.median(ms[4:])), [im.MemcpyToHost() for im in imgs])
+        da, db = out["plain"][1][0], out["classes"][1][0]
+        both = np.isfinite(da) & np.isfinite(db)
+        same = all(np.array_equal(x, y, equal_nan=True) for x, y in zip(out["plain"][1], out["classes"][1]))
+        print("[%s] %-5s %-5s raycast plain %.4f ms, classes %.4f ms; identical images %s, hit flips %d, max |ddepth| %.3g (hits %d)" % (
+            tag, scene, math, out["plain"][0], out["classes"][0], same, int((np.isfinite(da) != np.isfinite(db)).sum()),
+            float(np.abs(da[both] - db[both]).max()) if both.any() else 0.0, int(both.sum())), flush=True)
+        del vol, summ
+        torch.cuda.empty_cache()
+        if os.environ.get("KFX_RAYCAST_DEBUG_COUNTS") == "1":   # per-ray counters of the class march (img = samples, norm = fails / runs / skipped)
+            cnt = out["classes"][1]
+            smp, fail, runs, skipped = cnt[2], cnt[1][..., 0], cnt[1][..., 1], cnt[1][..., 2]
+            steps = smp + skipped
+            act = steps > 0
+            print("      rays %d: steps mean %.1f max %d | samples mean %.1f p99 %d max %d | failed looks mean %.1f max %d | runs mean %.1f | skipped mean %.1f" % (
+                int(act.sum()), steps[act].mean(), int(steps.max()), smp[act].mean(), int(np.percentile(smp[act], 99)), int(smp.max()), fail[act].mean(), int(fail.max()),
+                runs[act].mean(), skipped[act].mean()))
+            W = smp.reshape(h // 2, 2, w // 32, 32).transpose(0, 2, 1, 3).reshape(-1, 64)       # per wave (32 x 2 tiles)
+            Wf = fail.reshape(h // 2, 2, w // 32, 32).transpose(0, 2, 1, 3).reshape(-1, 64)
+            Wr = runs.reshape(h // 2, 2, w // 32, 32).transpose(0, 2, 1, 3).reshape(-1, 64)
+            wmax = W.max(1)
+            print("      per wave: max-lane samples: mean %.1f p90 %d p99 %d max %d; waves with a lane > 60 samples: %d of %d; max-lane fails p99 %d; max-lane runs p99 %d" % (
+                wmax.mean(), int(np.percentile(wmax, 90)), int(np.percentile(wmax, 99)), int(wmax.max()), int((wmax > 60).sum()), len(wmax),
+                int(np.percentile(Wf.max(1), 99)), int(np.percentile(Wr.max(1), 99))))
+            for vv in range(0, h, 40):
+                print("      " + " ".join("%3d" % smp[vv, uu] for uu in range(0, w, 32)))

@@ -62,6 +62,10 @@ def check_conservative(vol, R):
     assert not bool((s1 & any_val).any()), "brick marked all-NaN holds values"
     assert not bool((s0 & any_nan).any()), "brick marked all-values holds NaN"
     assert bool((R[..., 0][s0] <= tmin[s0]).all()) and bool((R[..., 1][s0] >= tmax[s0]).all()), "range does not cover the brick"
+    # mixed / unknown bricks: whatever cells hold a value, the range covers them (the march's class 3 -- "NaN or +trunc" --
+    # relies on it; an invalidated brick has the infinite range)
+    s2 = (state == 2) & any_val
+    assert bool((R[..., 0][s2] <= tmin[s2]).all()) and bool((R[..., 1][s2] >= tmax[s2]).all()), "range of a mixed brick does not cover its values"
     return dict(uniform_ranges=int(s0.sum()), all_nan=int(s1.sum()), mixed=int((state == 2).sum()), true_all_nan=int(all_nan.sum()))
 
 
