@@ -31,12 +31,17 @@ int kfx_debug_sqrt_core_check(unsigned long long* d_out, kfx_stream stream);
  * d_out[0] += mismatches, d_out[1] += comparisons */
 int kfx_debug_wave_xor_check(unsigned seed, unsigned long long* d_out, kfx_stream stream);
 
-/* Copies of a kfx_sdf_summary's per-brick state for tests: R_out receives {lo, hi, state bits, 0} per 8 x 8 x 8 brick
- * (state 0: every cell has a value in [lo, hi], 1: every cell NaN, 2: mixed / unknown), D_out the ray-march's table built
- * with relative tolerance `tol`, level 1 (8^3 cells) followed by levels 2 (32^3) and 3 (128^3) (v > 0: uniform value, NaN:
- * all NaN, -2: sample, -1 on levels 2 / 3: look one level down); either may be NULL.  dims_out = entries along x, y, z of
- * levels 1 and 2, then (with D_out) {number of partial counts, 0, number of level-2 entries a ray can cross without sampling}.  Device buffers: R_out n1 float4, D_out (n1 + n2) floats. */
-int kfx_debug_summary_export(kfx_sdf_summary* s, float tol, void* R_out, void* D_out, int dims_out[9], kfx_stream stream);
+/* Copies of a kfx_sdf_summary's tables for tests: R_out receives {lo, hi, state bits, 0} per 8 x 8 x 8 brick (state 0: every
+ * cell has a value in [lo, hi], 1: every cell NaN, 2: every cell is NaN or has a value in [lo, hi]; an invalidated brick has
+ * the infinite range), C_out the ray-march's class tables built for relative tolerance `tol`, reference value `vref` and a fine
+ * level of 2^fine_shift cells (3, 4; 5: the 32^3-cell level only): per entry two bits in two planes, rows of entries along x
+ * as uint2 {plane 0, plane 1} per 32 entries -- 0 sample, 1 every cell (and the +1 cells a sample based in the entry reads)
+ * holds vref, 2 every cell NaN, 3 every cell NaN or vref.  dims_out = {bricks along x, y, z; fine level: first word, words per
+ * row, rows per plane of entries; the same for the 32^3 level; total words; number of 32^3-cell entries; the count of them with
+ * class != 0 as published by the last finished build (-1: none yet)}.  Device buffers: R_out n float4, C_out dims_out[9] words
+ * (call with C_out = NULL first to learn the size). */
+int kfx_debug_summary_export(kfx_sdf_summary* s, float tol, float vref, int fine_shift, void* R_out, void* C_out, int dims_out[12],
+                             kfx_stream stream);
 
 #ifdef __cplusplus
 }

@@ -266,28 +266,27 @@ extern "C" int kfx_debug_rmw(const kfx_volume* vol, int variant, kfx_stream stre
     return check_launch("kfx_debug_rmw");
 }
 
-// test / diagnostics aid (include/kfx_debug.h): copies of R (float4 per brick) and of D built with `tol` into caller buffers
-extern "C" int kfx_debug_summary_export(kfx_sdf_summary* s, float tol, void* R_out, void* D_out, int dims_out[9], kfx_stream stream)
+// test / diagnostics aid (include/kfx_debug.h): copies of R (float4 per brick) and of the class tables built for (tol, vref,
+// fine_shift) into caller buffers
+extern "C" int kfx_debug_summary_export(kfx_sdf_summary* s, float tol, float vref, int fine_shift, void* R_out, void* C_out, int dims_out[12],
+                                        kfx_stream stream)
 {
     if (!s || !dims_out) return set_error(KFX_E_NULL, "kfx_debug_summary_export: null argument");
+    if (fine_shift < 3 || fine_shift > 5) return set_error(KFX_E_RANGE, "kfx_debug_summary_export: fine_shift in [3, 5]");
+    ClassView cv;
+    summary_class_layout(s, fine_shift, cv);
     dims_out[0] = s->nbx; dims_out[1] = s->nby; dims_out[2] = s->nbz;
-    dims_out[3] = s->n2x; dims_out[4] = s->n2y; dims_out[5] = s->n2z;
-    dims_out[6] = dims_out[7] = dims_out[8] = 0; // level 3 exists only inside the ray-march; here: the build's counters
+    dims_out[3] = cv.fine.first; dims_out[4] = cv.fine.rw; dims_out[5] = cv.fine.ny;
+    dims_out[6] = cv.coarse.first; dims_out[7] = cv.coarse.rw; dims_out[8] = cv.coarse.ny;
+    dims_out[9] = cv.words; dims_out[10] = s->n_coarse; dims_out[11] = s->h_skippable ? *(volatile int*)s->h_skippable : -2;
     const size_t n = (size_t)s->nbx * s->nby * s->nbz;
-    const size_t n_all = n + (size_t)s->n2x * s->n2y * s->n2z;
     hipStream_t st = (hipStream_t)stream;
     if (R_out && hipMemcpyAsync(R_out, s->R, n * sizeof(float4), hipMemcpyDeviceToDevice, st) != hipSuccess) return set_error(KFX_E_RANGE, "kfx_debug_summary_export: copy");
-    if (D_out) {
-        if (int e = summary_prepare(s, tol, st)) return e;
-        if (hipMemcpyAsync(D_out, s->D, n * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess ||
-            hipMemcpyAsync(static_cast<float*>(D_out) + n, s->D2, (n_all - n) * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
+    if (C_out) {
+        if (int e = summary_classes_prepare(s, tol, vref, fine_shift, st)) return e;
+        if (hipMemcpyAsync(C_out, s->C, (size_t)cv.words * sizeof(unsigned), hipMemcpyDeviceToDevice, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
             return set_error(KFX_E_RANGE, "kfx_debug_summary_export: copy");
-        int c[1024];
-        if (hipStreamSynchronize(st) != hipSuccess || hipMemcpy(c, s->useful2, s->n_partials * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess)
-            return set_error(KFX_E_RANGE, "kfx_debug_summary_export: copy");
-        int total = 0;
-        for (int i = 0; i < s->n_partials; ++i) total += c[i];
-        dims_out[6] = s->n_partials; dims_out[7] = 0; dims_out[8] = total; // partial counts, -, their sum
+        dims_out[11] = s->h_skippable ? *(volatile int*)s->h_skippable : -2;   // (the build has finished: its count is published)
     }
     return 0;
 }

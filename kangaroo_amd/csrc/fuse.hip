@@ -1518,7 +1518,7 @@ static int fuse_launch(const kfx_volume* vol, const kfx_image* depth, const kfx_
         if (int e = kfx_sdf_summary_invalidate(summary, stream)) return e;
         track = false;
     }
-    if (summary) { summary->dirty = 1; summary->c_dirty = 1; }
+    if (summary) summary->c_dirty = 1;
     if (tiled && vec2 && small_images) {
         // slices per iteration: 2 in fast mode (memory-bound: more reads in flight), 4 where the large LDS tile leaves
         // only 3 workgroups per CU (1280x960 at 512^3: 0.568 -> 0.538 ms; at 6 workgroups per CU 4 is slower), 1 in exact

@@ -175,43 +175,25 @@ __host__ __device__ inline int ceil_div(int a, int b) { return (a + b - 1) / b; 
 
 // ---- brick summary of a TSDF volume (kfx_sdf_summary, include/kfx.h; summary.hip) -----------------------------------
 // R: one float4 {lo, hi, state, -} per 8 x 8 x 8 cells, kept current by the TRACK fuse kernels (state 0: every cell holds
-// a value in [lo, hi]; 1: every cell is NaN; 2: mixed / unknown).  D: what the ray-march reads, one float per brick, built
-// from R over the brick and its +1 neighbours (a trilinear sample based in the brick reads those cells): v > 0 = every
-// such cell equals v (exact numerics) or lies within `tol` of v (fast numerics); NaN = every cell is NaN; -2 = sample.
-// A ray crosses a brick in two or three steps, so D alone would only trade one dependent load per step for one per brick;
-// two coarser levels (32^3 and 128^3 cells) let it cross wide uniform regions with a handful of loads in total.
+// a value in [lo, hi]; 1: every cell is NaN; 2: every cell is NaN or holds a value in [lo, hi] -- an invalidated brick has
+// the infinite range).  C: what the ray-march reads (ClassView below), built from R on demand.
 struct kfx_sdf_summary {
     float4* R;
-    float* D;                    // level 1 (8^3 cells), then level 2 (32^3) behind it
-    float *D2, *D3;              // (D3 unused: level 3 is derived in LDS by the ray-march)
-    int* useful2;                // device: per-workgroup counts of level-2 entries a ray can cross without sampling (n_partials of them)
-    int n_partials;
     int nbx, nby, nbz;
-    int n2x, n2y, n2z, n3x, n3y, n3z;
     int w, h, d;                 // parent volume (cells)
     const unsigned char* base;   // parent volume storage
     size_t pitch, img_pitch;
-    int dirty;                   // R changed since D was built
-    float built_tol;             // tolerance D was built with
     // class tables of the march (ClassView below): two bit planes per entry, fine level (8^3 or 16^3 cells) then 32^3 cells
     unsigned* C;                 // device, sized for the finest level
     int c_dirty;                 // R changed since C was built
     float c_tol, c_vref;         // what C was built with
     int c_shift;                 // fine level C was built for (log2 of its cells per entry)
+    int n_coarse;                // 32^3-cell entries
+    int* d_count;                // device: {running count of 32^3-cell entries of class != 0, waves that have added theirs}
+    int* h_skippable;            // host-visible (pinned, mapped): the count the last finished build arrived at, -1 before the first
+    int* d_skippable;            // the device's address of the same word
 };
 namespace kfx {
-// Levels 2 and 3 summarise 4 x 4 x 4 entries of the level below: v > 0 / NaN as above when all of them agree, -1 = look
-// one level down (level 3) / some bricks below are uniform (level 2), -2 = nothing below is uniform.
-struct SummaryView {
-    const float *D, *D2, *D3;
-    int nbx, nby, n2x, n2y, n3x, n3y;
-    int n2, n3, n2z; // entries of levels 2 and 3
-    float tol;       // the tolerance level 2 was built with (level 3 is derived with the same)
-    const int* useful; // device: n_partials partial counts of level-2 entries a ray can cross without sampling
-    int n_partials;
-    int force;      // 0: decide by the counter, 1: always use the summary, -1: never (KFX_RAYCAST_SUMMARY)
-    int ox, oy, oz; // cell offset of the view inside the parent volume
-};
 // The class tables the march stages in LDS.  Per entry (a cube of 2^shift cells, together with the +1 cells a trilinear sample
 // based in it reads) two bits: 0 = sample; 1 = every cell holds vref (exact numerics: that bit pattern; fast numerics: within
 // tol) -- a sample there IS vref; 2 = every cell is NaN; 3 = every cell is NaN or holds vref -- the reference's step from
@@ -233,15 +215,11 @@ struct ClassView {
     int amb_ok;          // class 3 may be skipped (trunc >= min_delta)
     int ox, oy, oz;      // cell offset of the view inside the parent volume
     float eps;           // margin (cells) that covers the error of the affine cell estimate
-    int max_skips;       // 0: never consult the tables (KFX_RAYCAST_SKIP_M=0: measures the kernel's own overhead)
-    int debug;           // KFX_RAYCAST_DEBUG_COUNTS: write per-ray counters instead of the images
 };
 int summary_classes_prepare(kfx_sdf_summary* s, float tol, float vref, int fine_shift, hipStream_t stream);
 void summary_class_layout(const kfx_sdf_summary* s, int fine_shift, ClassView& cv);
 // cell offset of a view of the summary's parent volume (same pitches, pointer inside the parent): 0 on success
 int summary_view_offset(const kfx_sdf_summary* s, const kfx_volume* view, int* ox, int* oy, int* oz);
-// (re)build D if R changed or the tolerance differs
-int summary_prepare(kfx_sdf_summary* s, float tol, hipStream_t stream);
 } // namespace kfx
 
 // ---- host-side launch helpers (capi.hip) --------------------------------------

@@ -64,13 +64,8 @@ __device__ __forceinline__ void ray_pixel_of(const RayParams& p, int bx, int by,
 }
 
 // one ray: KernRaycastSdf (cu_raycast.cu:34-113) for pixel (u, v).
-// SKIP: a sample whose base cell lies in a brick the summary calls uniform (kfx_device.h, SummaryView: the brick and its
-// +1 neighbours hold one value, or only NaN) takes that value without reading the volume -- the blend of eight equal
-// cells is that cell (a + t (a - a) = a), so with the exact-numerics summary the march is the reference's, addition for
-// addition.  The brick's entry is kept in registers while consecutive samples stay in the brick.
-template <typename CELL, bool COLOR, bool SKIP = false>
-__device__ __forceinline__ float raycast_pixel(const RayParams& p, const ColorGeom& cv, const int u, const int v, const SummaryView sv = SummaryView{},
-                                               const float* lds_D3 = nullptr, const float* lds_D2 = nullptr, const bool use_summary = false)
+template <typename CELL, bool COLOR>
+__device__ __forceinline__ float raycast_pixel(const RayParams& p, const ColorGeom& cv, const int u, const int v)
 {
     if (u >= p.w || v >= p.h) return 0.f;
 
@@ -92,71 +87,8 @@ __device__ __forceinline__ float raycast_pixel(const RayParams& p, const ColorGe
         float last_sdf = __builtin_nanf("");
         const float min_delta = p.voxel.x;
         float delta = 0.f;
-        int cur_b2 = -1, cur_b3 = -1;       // summary entries of the current position (registers), per level
-        float cur_s2 = -1.f, cur_s3 = -1.f;
-        V3 pfA = v3(0.f, 0.f, 0.f), pfB = pfA; // SKIP: base-cell coordinate along the ray, pf(lambda) = pfA + pfB * lambda
-        if constexpr (SKIP) {
-            pfA = v3((c_w.x - p.vol.bmin.x) / p.size.x * p.dims1.x, (c_w.y - p.vol.bmin.y) / p.size.y * p.dims1.y, (c_w.z - p.vol.bmin.z) / p.size.z * p.dims1.z);
-            pfB = v3(ray_w.x / p.size.x * p.dims1.x, ray_w.y / p.size.y * p.dims1.y, ray_w.z / p.size.z * p.dims1.z);
-        }
-        bool wave_skips = SKIP && use_summary;   // this wave still consults the summary (equal in all marching lanes)
-        int n_iter = 0, n_sampled = 0;           // iterations so far (equal in all marching lanes), and those this lane sampled in
         while (lambda < min_tmax) {
-            float sdf;
-            if constexpr (SKIP) {
-                // A wave with rays along a border between observed and unobserved space (the frustum's sides) samples at nearly
-                // every step and would pay for both paths in every iteration: if some lane sampled in 4 of the first 8
-                // iterations, the wave gives up on the summary and marches plainly
-                if (wave_skips && n_iter == 8 && __ballot(n_sampled >= 4) != 0ull) wave_skips = false;
-                n_iter += 1;
-            }
-            if (SKIP && wave_skips) {
-                // A position whose base cell lies in a uniform (or never-observed) 32^3 / 128^3-cell region needs no memory
-                // beyond the LDS copy of the summary, and neither do the following steps up to the region's far side: the
-                // base-cell coordinate is affine in lambda (pf = A + B lambda), so the exit parameter of the region is three
-                // divisions away and the steps before it are bare additions -- the reference's own lambda += delta, one per
-                // step, so the exact march stays the reference's march.  (Re-deriving the cell at every skipped step costs as
-                // many instructions as a sample, and this kernel runs about one wave per SIMD, where an instruction issues
-                // every ~12 cycles: measured, per-step skipping gains nothing in S_room and bursts of it lose.)
-                const CellPos c = cell_of(p, c_w + ray_w * lambda);
-                const int gx = c.ix + sv.ox, gy = c.iy + sv.oy, gz = c.iz + sv.oz;
-                const int b3 = ((gz >> 7) * sv.n3y + (gy >> 7)) * sv.n3x + (gx >> 7);
-                if (b3 != cur_b3) { cur_s3 = lds_D3[b3]; cur_b3 = b3; }
-                float s = cur_s3;
-                int shift = 7;
-                if (s == -1.0f) {
-                    const int b2 = ((gz >> 5) * sv.n2y + (gy >> 5)) * sv.n2x + (gx >> 5);
-                    if (b2 != cur_b2) { cur_s2 = lds_D2[b2]; cur_b2 = b2; }
-                    s = cur_s2;
-                    shift = 5;
-                }
-                if (s > 0.f || s != s) {
-                    // the reference's step for sdf = s (s > 0: no crossing possible; NaN: step by trunc, cu_raycast.cu:77-80)
-                    delta = s > 0 ? fmaxf(s, min_delta) : p.trunc;
-                    last_sdf = s;
-                    // base cells [lo, lo + L) of the region in this view's coordinates; exit = first lambda with pf outside
-                    const float L = (float)(1 << shift);
-                    const float lox = (float)(((gx >> shift) << shift) - sv.ox), loy = (float)(((gy >> shift) << shift) - sv.oy),
-                                loz = (float)(((gz >> shift) << shift) - sv.oz);
-                    const float ex = (pfB.x > 0.f ? lox + L - pfA.x : lox - pfA.x) / pfB.x;   // +-inf / NaN when the ray is parallel
-                    const float ey = (pfB.y > 0.f ? loy + L - pfA.y : loy - pfA.y) / pfB.y;
-                    const float ez = (pfB.z > 0.f ? loz + L - pfA.z : loz - pfA.z) / pfB.z;
-                    float lam_exit = min_tmax;
-                    if (pfB.x != 0.f) lam_exit = fminf(lam_exit, ex);
-                    if (pfB.y != 0.f) lam_exit = fminf(lam_exit, ey);
-                    if (pfB.z != 0.f) lam_exit = fminf(lam_exit, ez);
-                    // steps that certainly stay inside: one fewer than fit (pfA / pfB are rounded: a step is ~3 cells, the
-                    // rounding error ~1e-4 cell); the step at the current position is always taken
-                    int k = (int)fminf(floorf((lam_exit - lambda) / delta) - 1.0f, 4096.f);
-                    lambda += delta;
-                    for (; k > 0; --k) lambda += delta;
-                    continue;
-                }
-                n_sampled += 1;
-                sdf = trilinear_at<CELL>(p, c);
-            } else {
-                sdf = trilinear<CELL>(p, c_w + ray_w * lambda);
-            }
+            const float sdf = trilinear<CELL>(p, c_w + ray_w * lambda);
             if (sdf <= 0) {
                 if (last_sdf > 0) {
                     if (p.subpix) lambda = lambda + delta * sdf / (last_sdf - sdf);
@@ -231,7 +163,6 @@ __device__ __forceinline__ float raycast_pixel_classes(const RayParams& p, const
     const float min_tmax = fminf(fminf(fminf(tmax.x, tmax.y), tmax.z), p.far);
 
     float depth = 0.0f;
-    int dbg_samples = 0, dbg_fail = 0, dbg_runs = 0, dbg_skipped = 0;
     if (max_tmin < min_tmax) {
         float lambda = max_tmin;
         float last_sdf = __builtin_nanf("");
@@ -251,7 +182,7 @@ __device__ __forceinline__ float raycast_pixel_classes(const RayParams& p, const
         // The tables are consulted where they can help: at the start, after a run, and after a sample that came back as vref
         // or NaN (free or unseen space); a sample with any other value lies in an entry of class 0.  After a class-0 answer the
         // ray first leaves that entry (lam_retry).  A ray through a band of mixed values therefore marches as the plain kernel.
-        bool consult = cl.max_skips != 0;   // (KFX_RAYCAST_SKIP_M=0: never -- measures the kernel's own overhead)
+        bool consult = true;
         float lam_retry = lambda;
         int wait = 0, backoff = 1;   // samples to let pass before the next look at the tables: doubles with every class-0 answer
         // One iteration of a wave: the lanes that sample request their cells; the lanes that consult the tables do so (LDS and
@@ -306,15 +237,12 @@ __device__ __forceinline__ float raycast_pixel_classes(const RayParams& p, const
                             const float nm = fmaxf(more, 0.f);
                             lambda_prev = __builtin_fmaf(nm, delta, lambda);
                             lambda = lambda_prev + delta;
-                            if (cl.debug) dbg_skipped += 1 + (int)nm;
                         } else {
                             // exact numerics: the reference's own additions, one per step
                             lambda_prev = lambda;
                             lambda += delta;
                             for (int k = (int)more; k > 0; --k) { lambda_prev = lambda; lambda += delta; }
-                            if (cl.debug) dbg_skipped += 1 + max((int)more, 0);
                         }
-                        if (cl.debug) dbg_runs += 1;
                         backoff = 1;
                         run = true;
                     } else {
@@ -322,15 +250,12 @@ __device__ __forceinline__ float raycast_pixel_classes(const RayParams& p, const
                     }
                 }
                 if (!run) {
-                    if (cl.debug) dbg_fail += 1;
                     wait = backoff;
                     backoff = min(backoff * 2, 32);
                 }
             }
             if (!look) {
                 const float sdf = trilinear_finish(fl, c);
-                dbg_samples += 1;
-                if (cl.debug > 1 && dbg_samples >= cl.debug) break;   // KFX_RAYCAST_DEBUG_COUNTS=N > 1: rays give up after N samples (tail experiments)
                 wait = max(wait - 1, 0);
                 if (sdf <= 0) {
                     // a crossing needs the previous sample's value: the one thing a class-3 step left open
@@ -345,7 +270,7 @@ __device__ __forceinline__ float raycast_pixel_classes(const RayParams& p, const
                 lambda += delta;
                 last_sdf = sdf;
                 pending = false;
-                consult = cl.max_skips != 0 && !(fabsf(sdf - cl.vref) > band);   // vref (within the tables' tolerance) or NaN
+                consult = !(fabsf(sdf - cl.vref) > band);   // vref (within the tables' tolerance) or NaN
             }
         }
     }
@@ -353,12 +278,6 @@ __device__ __forceinline__ float raycast_pixel_classes(const RayParams& p, const
     float* pd = reinterpret_cast<float*>(q.dptr + (size_t)v * q.dpitch) + u;
     float* pi = reinterpret_cast<float*>(q.iptr + (size_t)v * q.ipitch) + u;
     float4* pn = reinterpret_cast<float4*>(q.nptr + (size_t)v * q.npitch) + u;
-    if (cl.debug) {   // KFX_RAYCAST_DEBUG_COUNTS=1: per-ray counters instead of the images (scripts/raycast_classes_ab.py)
-        *pd = depth > 0 ? depth : __builtin_nanf("");
-        *pi = (float)dbg_samples;
-        *pn = make_float4((float)dbg_fail, (float)dbg_runs, (float)dbg_skipped, 0.f);
-        return 0.f;
-    }
     if (depth > 0) {
         // the ray again, from the LDS copy: the same expressions on the same values
         const V3 cq = v3(q.T.m[3], q.T.m[7], q.T.m[11]);
@@ -409,74 +328,9 @@ __global__ __launch_bounds__(256) void k_raycast_sdf_classes(const RayParams p, 
     raycast_pixel_classes<CELL, false>(p, s_p, ColorGeom{}, u, v, cl, s_tab);
 }
 
-// SKIP kernels, workgroup prologue: decide whether the summary is worth consulting and, if so, stage its coarse levels in
-// LDS (`s_sum`: level 2, n2 entries; then level 3, n3 entries).  Returns the (workgroup-uniform) decision.
-__device__ __forceinline__ bool summary_stage(const SummaryView& sv, float* s_sum, const float*& lds_D3, const float*& lds_D2)
+template <typename CELL, bool COLOR>
+__global__ __launch_bounds__(256) void k_raycast_sdf(const RayParams p, const ColorGeom cv)
 {
-    // worth it?  add up the table build's per-workgroup counts (at most 1024 of them: four loads per thread)
-    int useful = 0;
-    for (int i = threadIdx.x; i < sv.n_partials; i += 256) useful += sv.useful[i];
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) useful += __shfl_xor(useful, off, 64);
-    int* cnt = reinterpret_cast<int*>(s_sum);
-    if ((threadIdx.x & 63) == 0) cnt[threadIdx.x >> 6] = useful;
-    __syncthreads();
-    useful = cnt[0] + cnt[1] + cnt[2] + cnt[3];
-    __syncthreads(); // (s_sum is reused for the tables)
-    const bool use_summary = sv.force > 0 || (sv.force == 0 && (long long)useful * 10 >= (long long)sv.n2 * 9); // workgroup-uniform
-    if (!use_summary) return false;
-    // every workgroup stages level 2 in LDS (16-byte loads, all in flight together) and derives level 3 (4 x 4 x 4
-    // level-2 entries each) from it: a few hundred LDS operations instead of another launch per frame
-    float* l2 = s_sum;
-    float* l3 = s_sum + ((sv.n2 + 3) & ~3);
-    const int n4 = sv.n2 >> 2;
-    const float4* src4 = reinterpret_cast<const float4*>(sv.D2);
-    for (int i = threadIdx.x; i < n4; i += 256) reinterpret_cast<float4*>(l2)[i] = src4[i];
-    for (int i = (n4 << 2) + threadIdx.x; i < sv.n2; i += 256) l2[i] = sv.D2[i];
-    __syncthreads();
-    for (int i = threadIdx.x; i < sv.n3; i += 256) {
-        const int bx = i % sv.n3x, by = (i / sv.n3x) % sv.n3y, bz = i / (sv.n3x * sv.n3y);
-        float lo = __builtin_inff(), hi = -__builtin_inff();
-        bool all_nan = true, all_val = true, any_useful = false;
-        for (int dz = 0; dz < 4; ++dz)
-            for (int dy = 0; dy < 4; ++dy)
-                for (int dx = 0; dx < 4; ++dx) {
-                    const int x = bx * 4 + dx, y = by * 4 + dy, z = bz * 4 + dz;
-                    if (x >= sv.n2x || y >= sv.n2y || z >= sv.n2z) continue;
-                    const float v2 = l2[(z * sv.n2y + y) * sv.n2x + x];
-                    const bool isn = v2 != v2, isv = v2 > 0.f;
-                    all_nan = all_nan && isn;
-                    all_val = all_val && isv;
-                    any_useful = any_useful || isn || isv;
-                    if (isv) { lo = fminf(lo, v2); hi = fmaxf(hi, v2); }
-                }
-        float out = any_useful ? -1.0f : -2.0f;
-        if (all_nan) out = __builtin_nanf("");
-        else if (all_val && hi - lo <= sv.tol * hi) out = sv.tol > 0.f ? 0.5f * (lo + hi) : lo;
-        l3[i] = out;
-    }
-    __syncthreads();
-    lds_D3 = l3;
-    lds_D2 = l2;
-    return true;
-}
-
-template <typename CELL, bool COLOR, bool SKIP = false>
-__global__ __launch_bounds__(256) void k_raycast_sdf(const RayParams p, const ColorGeom cv, const SummaryView sv = SummaryView{})
-{
-    // SKIP: the two coarse summary levels are staged in LDS (level 3 always: at most a few hundred entries; level 2 when
-    // it fits `sv.lds2` entries), so that in wide uniform or hopeless regions a step costs no global access at all -- a
-    // dependent global load per step, even an L2 hit, is what the march is made of (measured: lookups in global memory
-    // made the march slower than sampling)
-    // The kernel lasts as long as its slowest wave, and a wave whose rays run along a border between observed and
-    // unobserved space (the frustum's sides) samples at every step whatever the summary says: the summary is used when at
-    // least three quarters of its 32^3-cell entries can be crossed without sampling (decided on the device from a counter the
-    // summary build leaves behind: no host synchronisation), otherwise the plain march runs (measured: S_full 0.162 ->
-    // 0.045 ms; S_room, where half the entries are mixed, 0.170 -> 0.225 ms if it were used).
-    extern __shared__ float s_sum[];   // SKIP: level 2 (n2 entries), then level 3 (n3), then one counter
-    const float *lds_D3 = nullptr, *lds_D2 = nullptr;
-    bool use_summary = false;
-    if constexpr (SKIP) use_summary = summary_stage(sv, s_sum, lds_D3, lds_D2);
     int u, v;
     if (p.sparse_lanes) { // only the first sparse_lanes lanes of a wave carry rays (a strip of one pixel row): small images
         const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -486,7 +340,7 @@ __global__ __launch_bounds__(256) void k_raycast_sdf(const RayParams p, const Co
     } else {
         ray_pixel_of(p, blockIdx.x, blockIdx.y, threadIdx.x, u, v);
     }
-    raycast_pixel<CELL, COLOR, SKIP>(p, cv, u, v, sv, lds_D3, lds_D2, use_summary);
+    raycast_pixel<CELL, COLOR>(p, cv, u, v);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -513,13 +367,9 @@ struct RayLevels {
     int n;
 };
 
-template <typename CELL, bool SKIP = false>
-__global__ __launch_bounds__(256) void k_raycast_sdf_levels(const RayParams base, const RayLevels L, const SummaryView sv = SummaryView{})
+template <typename CELL>
+__global__ __launch_bounds__(256) void k_raycast_sdf_levels(const RayParams base, const RayLevels L)
 {
-    extern __shared__ float s_sum[];
-    const float *lds_D3 = nullptr, *lds_D2 = nullptr;
-    bool use_summary = false;
-    if constexpr (SKIP) use_summary = summary_stage(sv, s_sum, lds_D3, lds_D2); // before any lane leaves (barriers inside)
     int l = 0;
     for (int k = 1; k < L.n; ++k)
         if ((int)blockIdx.x >= L.lv[k].first_block) l = k; // uniform
@@ -541,7 +391,7 @@ __global__ __launch_bounds__(256) void k_raycast_sdf_levels(const RayParams base
     } else {
         ray_pixel_of(p, b % lv.blocks_x, b / lv.blocks_x, threadIdx.x, u, v);
     }
-    const float kz = raycast_pixel<CELL, false, SKIP>(p, ColorGeom{}, u, v, sv, lds_D3, lds_D2, use_summary);
+    const float kz = raycast_pixel<CELL, false>(p, ColorGeom{}, u, v);
     if (lv.vptr && u < p.w && v < p.h) // the application's DepthToVbo(ray_v[l], ray_d[l], K[l]) (main.cpp:286), same expression
         reinterpret_cast<float4*>(lv.vptr + (size_t)v * lv.vpitch)[u] =
             make_float4(kz * ((float)u - p.K.u0) / p.K.fu, kz * ((float)v - p.K.v0) / p.K.fv, kz, 1.0f);
@@ -743,30 +593,6 @@ static int ray_params(RayParams& p, const kfx_image* depth, const kfx_image* nor
     return 0;
 }
 
-// The march's view of a summary for a launch on `vol` (the summary's volume or an aligned view of it): brings the tables up
-// to date on `stream` and reports the LDS bytes a SKIP kernel needs.
-// fast numerics: bricks whose values agree to 1e-5 count as uniform (observed free space: the running average of
-// +trunc drifts by a few ulp per frame); exact numerics: bit-identical cells only
-static int summary_view(SummaryView& sv, size_t* lds_bytes, kfx_sdf_summary* summary, const kfx_volume* vol, kfx_stream stream)
-{
-    if (int e = summary_view_offset(summary, vol, &sv.ox, &sv.oy, &sv.oz)) return e;
-    if (int e = summary_prepare(summary, math_mode() == KFX_MATH_FAST ? 1e-5f : 0.f, (hipStream_t)stream)) return e;
-    sv.D = summary->D; sv.D2 = summary->D2; sv.D3 = summary->D3;
-    sv.nbx = summary->nbx; sv.nby = summary->nby;
-    sv.n2x = summary->n2x; sv.n2y = summary->n2y;
-    sv.n3x = summary->n3x; sv.n3y = summary->n3y;
-    sv.n3 = summary->n3x * summary->n3y * summary->n3z;
-    sv.n2 = summary->n2x * summary->n2y * summary->n2z;
-    sv.n2z = summary->n2z;
-    sv.tol = math_mode() == KFX_MATH_FAST ? 1e-5f : 0.f;
-    sv.useful = summary->useful2;
-    sv.n_partials = summary->n_partials;
-    static const int force_env = [] { const char* e = getenv("KFX_RAYCAST_SUMMARY"); return e ? atoi(e) : 0; }(); // 1: always, -1: never, 0: by the counter
-    sv.force = force_env;
-    *lds_bytes = (size_t)(((sv.n2 + 3) & ~3) + sv.n3 + 4) * sizeof(float);
-    return 0;
-}
-
 // The class-table march's view of a summary for a launch on `vol` with camera T_wc: brings the tables up to date on `stream`,
 // evaluates the margin that covers the affine cell estimate, reports the LDS bytes.  *usable = 0: march plainly (the margin
 // would be too wide, or trunc is not positive).
@@ -776,7 +602,6 @@ static int class_view(ClassView& cl, size_t* lds_bytes, int* usable, kfx_sdf_sum
     if (int e = summary_view_offset(summary, vol, &cl.ox, &cl.oy, &cl.oz)) return e;
     if (!(p.trunc > 0.f) || !(p.trunc < __builtin_inff())) return 0;
     static const int kb_env = [] { const char* e = getenv("KFX_RAYCAST_CLASS_KB"); const int v = e ? atoi(e) : 16; return v < 1 ? 1 : (v > 60 ? 60 : v); }();
-    static const int m_env = [] { const char* e = getenv("KFX_RAYCAST_SKIP_M"); const int v = e ? atoi(e) : 2; return v < 0 ? 0 : (v > 64 ? 64 : v); }();
     int fine = 3;
     for (; fine < 5; ++fine) {
         summary_class_layout(summary, fine, cl);
@@ -786,13 +611,21 @@ static int class_view(ClassView& cl, size_t* lds_bytes, int* usable, kfx_sdf_sum
     if ((size_t)cl.words * 4 > 60 * 1024) return 0;
     const float tol = math_mode() == KFX_MATH_FAST ? 1e-5f : 0.f;
     if (int e = summary_classes_prepare(summary, tol, p.trunc, fine, (hipStream_t)stream)) return e;
+    // Worth it?  The march through the tables costs ~8 % per sampled step (table look-ups, staging); it pays where a fair part
+    // of the volume can be crossed without sampling.  The last finished table build left its count of such 32^3-cell entries
+    // in host-visible memory (no synchronisation: the figure may be a few frames old, it only steers a choice between two
+    // kernels that produce the same images): exact numerics on a running stream, where only never-observed space qualifies,
+    // fall back to the plain march this way.  KFX_RAYCAST_SUMMARY=1 always uses the tables, -1 never.
+    static const int force_env = [] { const char* e = getenv("KFX_RAYCAST_SUMMARY"); return e ? atoi(e) : 0; }();
+    if (force_env < 0) return 0;
+    if (force_env == 0 && summary->h_skippable) {
+        const int known = *(volatile int*)summary->h_skippable;
+        if (known >= 0 && (long long)known * 4 < summary->n_coarse) return 0;   // less than a quarter
+    }
     cl.C = summary->C;
     cl.vref = p.trunc;
     cl.amb_ok = p.trunc >= p.voxel.x ? 1 : 0;   // class 3 needs equal steps for a vref and a NaN sample: max(trunc, min_delta) = trunc
-    cl.max_skips = m_env;
     cl.tol = tol;
-    static const int dbg_env = [] { const char* e = getenv("KFX_RAYCAST_DEBUG_COUNTS"); return e ? atoi(e) : 0; }();
-    cl.debug = dbg_env;
     // margin: |cell_of()'s coordinate - the affine estimate| per axis, from the roundings of both (u = 2^-24):
     //   cell_of:   pos = c + ray lambda (2 roundings of magnitudes <= |pos| + |c|), - bmin, / size, * dims1
     //   estimate:  A = (c - bmin) sc (3 roundings), B = ray sc (2), fma(B, lambda, A) (1); and the run's far side
@@ -858,28 +691,19 @@ static int raycast_levels_launch(int n_levels, const kfx_image* const* depth, co
     if (L.n == 0) return 0;
     if (summary) {
         if constexpr (CELL::BYTES == 8) {
-            static const int classes_env = [] { const char* e = getenv("KFX_RAYCAST_CLASSES"); return e ? atoi(e) : 1; }(); // 0: the round-2 region march
-            if (classes_env) {
-                ClassView cl;
-                size_t cl_bytes = 0;
-                int usable = 0;
-                if (int e = class_view(cl, &cl_bytes, &usable, summary, vol, base, stream)) return e;
-                if (usable) hipLaunchKernelGGL((k_raycast_sdf_levels_classes<CELL>), dim3(blocks), dim3(256), cl_bytes, (hipStream_t)stream, base, L, cl);
-                else hipLaunchKernelGGL((k_raycast_sdf_levels<CELL, false>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, base, L, SummaryView{});
-                return check_launch("kfx_raycast_sdf_levels_tracked");
-            }
-            SummaryView sv;
-            size_t lds_bytes = 0;
-            if (int e = summary_view(sv, &lds_bytes, summary, vol, stream)) return e;
-            if (lds_bytes <= 60 * 1024) {
-                hipLaunchKernelGGL((k_raycast_sdf_levels<CELL, true>), dim3(blocks), dim3(256), lds_bytes, (hipStream_t)stream, base, L, sv);
+            ClassView cl;
+            size_t cl_bytes = 0;
+            int usable = 0;
+            if (int e = class_view(cl, &cl_bytes, &usable, summary, vol, base, stream)) return e;
+            if (usable) {
+                hipLaunchKernelGGL((k_raycast_sdf_levels_classes<CELL>), dim3(blocks), dim3(256), cl_bytes, (hipStream_t)stream, base, L, cl);
                 return check_launch("kfx_raycast_sdf_levels_tracked");
             }
         } else {
             return set_error(KFX_E_RANGE, "kfx_raycast_sdf_levels_tracked: fp32 cells only");
         }
     }
-    hipLaunchKernelGGL((k_raycast_sdf_levels<CELL, false>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, base, L, SummaryView{});
+    hipLaunchKernelGGL((k_raycast_sdf_levels<CELL>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, base, L);
     return check_launch("kfx_raycast_sdf_levels");
 }
 
@@ -913,31 +737,21 @@ static int raycast_launch(const kfx_image* depth, const kfx_image* norm, const k
             return set_error(KFX_E_SHAPE, "RaycastSdf(colour): colour volume dimensions / pitch");
         if (((uintptr_t)colorvol->ptr | colorvol->pitch | colorvol->img_pitch) & 3) return set_error(KFX_E_ALIGN, "RaycastSdf(colour): alignment");
         set_geometry(cv, colorvol);
-        hipLaunchKernelGGL((k_raycast_sdf<CELL, true>), grid, dim3(256), 0, (hipStream_t)stream, p, cv, SummaryView{});
+        hipLaunchKernelGGL((k_raycast_sdf<CELL, true>), grid, dim3(256), 0, (hipStream_t)stream, p, cv);
     } else if (summary) {
-        static const int classes_env = [] { const char* e = getenv("KFX_RAYCAST_CLASSES"); return e ? atoi(e) : 1; }(); // 0: the round-2 region march
         if constexpr (CELL::BYTES == 8) {
-            if (classes_env) {
-                ClassView cl;
-                size_t cl_bytes = 0;
-                int usable = 0;
-                if (int e = class_view(cl, &cl_bytes, &usable, summary, vol, p, stream)) return e;
-                if (usable) hipLaunchKernelGGL((k_raycast_sdf_classes<CELL>), grid, dim3(256), cl_bytes, (hipStream_t)stream, p, cl);
-                else hipLaunchKernelGGL((k_raycast_sdf<CELL, false>), grid, dim3(256), 0, (hipStream_t)stream, p, cv, SummaryView{});
-                return check_launch("kfx_raycast_sdf_tracked");
-            }
+            ClassView cl;
+            size_t cl_bytes = 0;
+            int usable = 0;
+            if (int e = class_view(cl, &cl_bytes, &usable, summary, vol, p, stream)) return e;
+            if (usable) hipLaunchKernelGGL((k_raycast_sdf_classes<CELL>), grid, dim3(256), cl_bytes, (hipStream_t)stream, p, cl);
+            else hipLaunchKernelGGL((k_raycast_sdf<CELL, false>), grid, dim3(256), 0, (hipStream_t)stream, p, cv);
+            return check_launch("kfx_raycast_sdf_tracked");
+        } else {
+            return set_error(KFX_E_RANGE, "kfx_raycast_sdf_tracked: fp32 cells only");
         }
-        SummaryView sv;
-        size_t lds_bytes = 0;
-        if (int e = summary_view(sv, &lds_bytes, summary, vol, stream)) return e;
-        if (lds_bytes > 60 * 1024) { // level 2 does not fit LDS (volumes beyond ~768^3): the plain march
-            hipLaunchKernelGGL((k_raycast_sdf<CELL, false>), grid, dim3(256), 0, (hipStream_t)stream, p, cv, SummaryView{});
-            return check_launch("kfx_raycast_sdf");
-        }
-        if constexpr (CELL::BYTES == 8) hipLaunchKernelGGL((k_raycast_sdf<CELL, false, true>), grid, dim3(256), lds_bytes, (hipStream_t)stream, p, cv, sv);
-        else return set_error(KFX_E_RANGE, "kfx_raycast_sdf_tracked: fp32 cells only");
     } else {
-        hipLaunchKernelGGL((k_raycast_sdf<CELL, false>), grid, dim3(256), 0, (hipStream_t)stream, p, cv, SummaryView{});
+        hipLaunchKernelGGL((k_raycast_sdf<CELL, false>), grid, dim3(256), 0, (hipStream_t)stream, p, cv);
     }
     return check_launch("kfx_raycast_sdf");
 }

@@ -1,7 +1,7 @@
 // summary.hip -- the brick summary of a TSDF volume (kfx_sdf_summary, include/kfx.h): creation, the conservative state
-// changes for writers that do not track (invalidate), SdfReset with tracking, and the dilation R -> D the ray-march reads.
-// The summary is maintained by k_sdf_fuse_tiled<..., TRACK> (fuse.hip) and consumed by k_raycast_sdf<..., SKIP>
-// (raycast.hip).  No reference counterpart: the reference's march samples the volume at every step (cu_raycast.cu:58-81).
+// changes for writers that do not track (invalidate), SdfReset with tracking, and the class tables R -> C the ray-march
+// stages in LDS.  The summary is maintained by k_sdf_fuse_tiled<..., TRACK> (fuse.hip) and consumed by
+// k_raycast_sdf_classes (raycast.hip).  No reference counterpart: the reference's march samples the volume at every step (cu_raycast.cu:58-81).
 #include <algorithm>
 #include <new>
 
@@ -15,77 +15,20 @@ __global__ __launch_bounds__(256) void k_summary_fill(float4* __restrict__ R, si
     if (i < n) R[i] = make_float4(lo, hi, __int_as_float(state), 0.f);
 }
 
-// One launch builds both tables: a wave per level-2 entry, one lane per level-1 brick of its 4 x 4 x 4 group.
-//   level 1: D[b] from R over b + {0, 1}^3 (clamped to the grid) -- a trilinear sample based in brick b reads those cells;
-//   level 2: uniform when every brick of the group is uniform (v > 0) and they agree within tol (the mid value is then
-//            within tol of every cell they cover), NaN when every brick is all-NaN, -1 when only some are (nothing the march
-//            uses: it samples), -2 when none is.
-// Level 3 (128^3 cells) is derived from level 2 by the ray-march itself, in LDS (raycast.hip).
-__global__ __launch_bounds__(256) void k_summary_build(const float4* __restrict__ R, float* __restrict__ D, float* __restrict__ D2,
-                                                        int nbx, int nby, int nbz, int n2x, int n2y, int n2, float tol, int* __restrict__ partials)
-{
-    __shared__ int s_useful[4];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    int useful = 0; // (per wave, lane 0)
-    for (int g = blockIdx.x * 4 + wv; g < n2; g += gridDim.x * 4) { // one wave per level-2 entry
-        const int bx = (g % n2x) * 4 + (lane & 3), by = ((g / n2x) % n2y) * 4 + ((lane >> 2) & 3), bz = (g / (n2x * n2y)) * 4 + (lane >> 4);
-        const bool exists = bx < nbx && by < nby && bz < nbz;
-        float v = -2.0f; // sample
-        if (exists) {
-            float lo = __builtin_inff(), hi = -__builtin_inff();
-            bool all_nan = true, all_val = true;
-#pragma unroll
-            for (int dz = 0; dz < 2; ++dz)
-#pragma unroll
-                for (int dy = 0; dy < 2; ++dy)
-#pragma unroll
-                    for (int dx = 0; dx < 2; ++dx) {
-                        const int x = min(bx + dx, nbx - 1), y = min(by + dy, nby - 1), z = min(bz + dz, nbz - 1);
-                        const float4 r = R[((size_t)z * nby + y) * nbx + x];
-                        const int st = __float_as_int(r.z);
-                        all_nan = all_nan && st == 1;
-                        all_val = all_val && st == 0;
-                        lo = fminf(lo, r.x);
-                        hi = fmaxf(hi, r.y);
-                    }
-            if (all_nan) v = __builtin_nanf("");
-            else if (all_val && lo > 0.f && hi < __builtin_inff() && hi - lo <= tol * hi) v = tol > 0.f ? 0.5f * (lo + hi) : lo;
-            D[((size_t)bz * nby + by) * nbx + bx] = v;
-        }
-        // the group's verdict: wave64 ballots and a min / max butterfly
-        const bool isn = v != v, isv = v > 0.f;
-        const unsigned long long m_exists = __ballot(exists), m_nan = __ballot(exists && isn), m_val = __ballot(exists && isv);
-        float lo = (exists && isv) ? v : __builtin_inff(), hi = (exists && isv) ? v : -__builtin_inff();
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            lo = fminf(lo, __shfl_xor(lo, off, 64));
-            hi = fmaxf(hi, __shfl_xor(hi, off, 64));
-        }
-        if (lane == 0) {
-            float out = (m_nan | m_val) ? -1.0f : -2.0f;
-            if (m_nan == m_exists) out = __builtin_nanf("");
-            else if (m_val == m_exists && hi - lo <= tol * hi) out = tol > 0.f ? 0.5f * (lo + hi) : lo;
-            D2[g] = out;
-            useful += (out > 0.f || out != out) ? 1 : 0;
-        }
-    }
-    // the workgroup's number of entries a ray can cross without sampling; the ray-march adds the partials up itself (a
-    // single counter would take an atomic per workgroup on one address: 4096 of them cost 0.1 ms, 1024 still 10 us)
-    if (lane == 0) s_useful[wv] = useful;
-    __syncthreads();
-    if (threadIdx.x == 0) partials[blockIdx.x] = s_useful[0] + s_useful[1] + s_useful[2] + s_useful[3];
-}
-
 // Class tables (ClassView, kfx_device.h).  One lane per entry, 64 consecutive entries of a row per wave; the two planes are
 // the wave's ballots.  An entry of 2^shift cells reads the summary bricks [b << (shift - 3), (b + 1) << (shift - 3)] per axis
 // (the last one holds the +1 cells), clamped to the grid.
+// count != nullptr (the 32^3-cell level): the waves add up their entries of class != 0; the last one to arrive publishes the
+// total in host-visible memory (*publish) and clears the counters for the next build -- the host reads that word without
+// synchronising (raycast.hip, class_view).
 __global__ __launch_bounds__(256) void k_summary_classes(const float4* __restrict__ R, unsigned* __restrict__ C, int nbx, int nby, int nbz,
-                                                          int shift, int nx, int ny, int nz, int rw, float lo_ok, float hi_ok)
+                                                          int shift, int nx, int ny, int nz, int rw, float lo_ok, float hi_ok,
+                                                          int* __restrict__ count, int* __restrict__ publish, int n_waves)
 {
     const int lane = threadIdx.x & 63;
     const int chunks = (nx + 63) >> 6;
     const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (wave >= (long long)chunks * ny * nz) return;
+    if (wave >= (long long)chunks * ny * nz) return;   // (n_waves = chunks * ny * nz: only those count)
     const int chunk = (int)(wave % chunks), by = (int)((wave / chunks) % ny), bz = (int)(wave / ((long long)chunks * ny));
     const int bx = chunk * 64 + lane;
     int cls = 0;
@@ -109,6 +52,16 @@ __global__ __launch_bounds__(256) void k_summary_classes(const float4* __restric
         unsigned* row = C + ((size_t)bz * ny + by) * rw + chunk * 4;
         row[0] = (unsigned)p0; row[1] = (unsigned)p1;
         if (chunk * 4 + 2 < rw) { row[2] = (unsigned)(p0 >> 32); row[3] = (unsigned)(p1 >> 32); }
+        if (count) {
+            atomicAdd(&count[0], __popcll(p0 | p1));
+            __threadfence();
+            if (atomicAdd(&count[1], 1) == n_waves - 1) {   // every wave's contribution is in
+                __threadfence();
+                const int total = atomicExch(&count[0], 0);
+                count[1] = 0;
+                __hip_atomic_store(publish, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
     }
 }
 
@@ -142,7 +95,7 @@ int summary_classes_prepare(kfx_sdf_summary* s, float tol, float vref, int fine_
         const int nx = ceil_div(s->w, 1 << L.shift), ny = L.ny, nz = ceil_div(s->d, 1 << L.shift);
         const long long waves = (long long)ceil_div(nx, 64) * ny * nz;
         hipLaunchKernelGGL(k_summary_classes, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, stream, s->R, s->C + L.first, s->nbx, s->nby, s->nbz,
-                           L.shift, nx, ny, nz, L.rw, lo_ok, hi_ok);
+                           L.shift, nx, ny, nz, L.rw, lo_ok, hi_ok, pass ? s->d_count : nullptr, pass ? s->d_skippable : nullptr, (int)waves);
         if (int e = check_launch("kfx_sdf_summary (classes)")) return e;
     }
     s->c_dirty = 0; s->c_tol = tol; s->c_vref = vref; s->c_shift = fine_shift;
@@ -163,19 +116,6 @@ int summary_view_offset(const kfx_sdf_summary* s, const kfx_volume* view, int* o
     return 0;
 }
 
-int summary_prepare(kfx_sdf_summary* s, float tol, hipStream_t stream)
-{
-    if (!s->dirty && s->built_tol == tol) return 0;
-    const int n2 = s->n2x * s->n2y * s->n2z;
-    s->n_partials = std::min(ceil_div(n2, 4), 1024);
-    hipLaunchKernelGGL(k_summary_build, dim3(s->n_partials), dim3(256), 0, stream, s->R, s->D, s->D2, s->nbx, s->nby, s->nbz,
-                       s->n2x, s->n2y, n2, tol, s->useful2);
-    if (int e = check_launch("kfx_sdf_summary (build)")) return e;
-    s->dirty = 0;
-    s->built_tol = tol;
-    return 0;
-}
-
 } // namespace kfx
 
 using namespace kfx;
@@ -190,33 +130,33 @@ extern "C" int kfx_sdf_summary_create(kfx_sdf_summary** out, const kfx_volume* v
     s->w = (int)vol->w; s->h = (int)vol->h; s->d = (int)vol->d;
     s->base = static_cast<const unsigned char*>(vol->ptr);
     s->pitch = vol->pitch; s->img_pitch = vol->img_pitch;
-    s->dirty = 1; s->built_tol = -1.f;
-    s->C = nullptr; s->c_dirty = 1; s->c_tol = -1.f; s->c_vref = 0.f; s->c_shift = 0;
+    s->R = nullptr; s->C = nullptr; s->d_count = nullptr; s->h_skippable = nullptr; s->d_skippable = nullptr;
+    s->c_dirty = 1; s->c_tol = -1.f; s->c_vref = 0.f; s->c_shift = 0;
+    s->n_coarse = ceil_div(s->w, 32) * ceil_div(s->h, 32) * ceil_div(s->d, 32);
     const size_t n = (size_t)s->nbx * s->nby * s->nbz;
-    s->n2x = ceil_div(s->nbx, 4); s->n2y = ceil_div(s->nby, 4); s->n2z = ceil_div(s->nbz, 4);
-    s->n3x = ceil_div(s->n2x, 4); s->n3y = ceil_div(s->n2y, 4); s->n3z = ceil_div(s->n2z, 4);
-    const size_t n2 = (size_t)s->n2x * s->n2y * s->n2z, n3 = (size_t)s->n3x * s->n3y * s->n3z;
-    s->R = nullptr; s->D = nullptr;
-    if (hipMalloc((void**)&s->R, n * sizeof(float4)) != hipSuccess || hipMalloc((void**)&s->D, (((n + 3) & ~(size_t)3) + n2 + n3 + 1024 + 8) * sizeof(float)) != hipSuccess) {
+    ClassView cv;
+    summary_class_layout(s, 3, cv);   // the finest level is the largest table
+    bool ok = hipMalloc((void**)&s->R, n * sizeof(float4)) == hipSuccess && hipMalloc((void**)&s->C, (size_t)cv.words * sizeof(unsigned)) == hipSuccess &&
+              hipMalloc((void**)&s->d_count, 2 * sizeof(int)) == hipSuccess && hipMemset(s->d_count, 0, 2 * sizeof(int)) == hipSuccess;
+    // the published count lives in pinned host memory the device can write; without it the march always uses the tables
+    if (ok && hipHostMalloc((void**)&s->h_skippable, sizeof(int), hipHostMallocMapped) == hipSuccess) {
+        *s->h_skippable = -1;
+        if (hipHostGetDevicePointer((void**)&s->d_skippable, s->h_skippable, 0) != hipSuccess) {
+            (void)hipHostFree(s->h_skippable);
+            s->h_skippable = nullptr;
+        }
+    } else {
+        s->h_skippable = nullptr;
+    }
+    if (ok && !s->h_skippable) {   // a device word nobody reads keeps the kernel's interface the same
         (void)hipGetLastError();
-        if (s->R) (void)hipFree(s->R);
-        delete s;
+        ok = hipMalloc((void**)&s->d_skippable, sizeof(int)) == hipSuccess;
+    }
+    if (!ok) {
+        (void)hipGetLastError();
+        kfx_sdf_summary_destroy(s);
         return set_error(KFX_E_NODEVICE, "kfx_sdf_summary_create: hipMalloc");
     }
-    {
-        ClassView cv;
-        summary_class_layout(s, 3, cv);   // the finest level is the largest table
-        if (hipMalloc((void**)&s->C, (size_t)cv.words * sizeof(unsigned)) != hipSuccess) {
-            (void)hipGetLastError();
-            (void)hipFree(s->R); (void)hipFree(s->D);
-            delete s;
-            return set_error(KFX_E_NODEVICE, "kfx_sdf_summary_create: hipMalloc");
-        }
-    }
-    s->D2 = s->D + ((n + 3) & ~(size_t)3);   // 16-byte aligned: the ray-march stages it with float4 loads
-    s->D3 = s->D2 + n2;
-    s->useful2 = reinterpret_cast<int*>(s->D3 + n3);
-    s->n_partials = 0;
     *out = s;
     return kfx_sdf_summary_invalidate(s, nullptr); // nothing is known about the volume's contents yet
 }
@@ -224,9 +164,12 @@ extern "C" int kfx_sdf_summary_create(kfx_sdf_summary** out, const kfx_volume* v
 extern "C" int kfx_sdf_summary_destroy(kfx_sdf_summary* s)
 {
     if (!s) return 0;
-    (void)hipFree(s->R);
-    (void)hipFree(s->D);
-    (void)hipFree(s->C);
+    (void)hipDeviceSynchronize();   // a table build may still be about to publish its count
+    if (s->R) (void)hipFree(s->R);
+    if (s->C) (void)hipFree(s->C);
+    if (s->d_count) (void)hipFree(s->d_count);
+    if (s->h_skippable) (void)hipHostFree(s->h_skippable);
+    else if (s->d_skippable) (void)hipFree(s->d_skippable);
     delete s;
     return 0;
 }
@@ -238,7 +181,7 @@ extern "C" int kfx_sdf_summary_invalidate(kfx_sdf_summary* s, kfx_stream stream)
     if (!s) return set_error(KFX_E_NULL, "kfx_sdf_summary_invalidate: null summary");
     const size_t n = (size_t)s->nbx * s->nby * s->nbz;
     hipLaunchKernelGGL(k_summary_fill, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, s->R, n, -__builtin_inff(), __builtin_inff(), 2);
-    s->dirty = 1; s->c_dirty = 1;
+    s->c_dirty = 1;
     return check_launch("kfx_sdf_summary_invalidate");
 }
 
@@ -255,6 +198,6 @@ extern "C" int kfx_sdf_reset_tracked(const kfx_volume* vol, kfx_sdf_summary* s, 
     const bool nan = trunc_dist != trunc_dist;
     hipLaunchKernelGGL(k_summary_fill, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, s->R, n,
                        nan ? __builtin_inff() : trunc_dist, nan ? -__builtin_inff() : trunc_dist, nan ? 1 : 0);
-    s->dirty = 1; s->c_dirty = 1;
+    s->c_dirty = 1;
     return check_launch("kfx_sdf_reset_tracked");
 }

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """RaycastSdf at 512^3 / 640x480 after a few tracked frames: plain march against the class-table march (environment knobs are
-read once per process, so run it once per configuration: KFX_RAYCAST_CLASSES, KFX_RAYCAST_CLASS_KB, KFX_RAYCAST_SKIP_M).
+read once per process, so run it once per configuration: KFX_RAYCAST_CLASSES, KFX_RAYCAST_CLASS_KB).
 Prints kernel times (median of 20 launches, HIP events), tracked / untracked SdfFuse times and the image differences."""
 import os
 import sys
@@ -13,7 +13,7 @@ from kangaroo_amd import roo, scenes  # noqa: E402
 
 N, w, h = 512, 640, 480
 frames = int(os.environ.get("AB_FRAMES", "8"))
-tag = " ".join("%s=%s" % (k, os.environ[k]) for k in ("KFX_RAYCAST_CLASSES", "KFX_RAYCAST_CLASS_KB", "KFX_RAYCAST_SKIP_M") if k in os.environ) or "defaults"
+tag = " ".join("%s=%s" % (k, os.environ[k]) for k in ("KFX_RAYCAST_CLASSES", "KFX_RAYCAST_CLASS_KB") if k in os.environ) or "defaults"
 for scene in sys.argv[1:] or ("full", "room"):
     bmin, bmax, near, far = scenes.SCENES[scene]
     K = scenes.intrinsics(w, h)
@@ -51,20 +51,3 @@ for scene in sys.argv[1:] or ("full", "room"):
             float(np.abs(da[both] - db[both]).max()) if both.any() else 0.0, int(both.sum())), flush=True)
         del vol, summ
         torch.cuda.empty_cache()
-        if os.environ.get("KFX_RAYCAST_DEBUG_COUNTS") == "1":   # per-ray counters of the class march (img = samples, norm = fails / runs / skipped)
-            cnt = out["classes"][1]
-            smp, fail, runs, skipped = cnt[2], cnt[1][..., 0], cnt[1][..., 1], cnt[1][..., 2]
-            steps = smp + skipped
-            act = steps > 0
-            print("      rays %d: steps mean %.1f max %d | samples mean %.1f p99 %d max %d | failed looks mean %.1f max %d | runs mean %.1f | skipped mean %.1f" % (
-                int(act.sum()), steps[act].mean(), int(steps.max()), smp[act].mean(), int(np.percentile(smp[act], 99)), int(smp.max()), fail[act].mean(), int(fail.max()),
-                runs[act].mean(), skipped[act].mean()))
-            W = smp.reshape(h // 2, 2, w // 32, 32).transpose(0, 2, 1, 3).reshape(-1, 64)       # per wave (32 x 2 tiles)
-            Wf = fail.reshape(h // 2, 2, w // 32, 32).transpose(0, 2, 1, 3).reshape(-1, 64)
-            Wr = runs.reshape(h // 2, 2, w // 32, 32).transpose(0, 2, 1, 3).reshape(-1, 64)
-            wmax = W.max(1)
-            print("      per wave: max-lane samples: mean %.1f p90 %d p99 %d max %d; waves with a lane > 60 samples: %d of %d; max-lane fails p99 %d; max-lane runs p99 %d" % (
-                wmax.mean(), int(np.percentile(wmax, 90)), int(np.percentile(wmax, 99)), int(wmax.max()), int((wmax > 60).sum()), len(wmax),
-                int(np.percentile(Wf.max(1), 99)), int(np.percentile(Wr.max(1), 99))))
-            for vv in range(0, h, 40):
-                print("      " + " ".join("%3d" % smp[vv, uu] for uu in range(0, w, 32)))

@@ -8,6 +8,13 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+# The tracked RaycastSdf chooses between the plain march and the march through the class tables from the share of the volume
+# the tables cover (raycast.hip, class_view).  The suite wants the table march exercised wherever a summary is passed, whatever
+# that share is: force it (read once, when libkfx.so is first used).  tests/test_gpu_summary.py checks the unforced choice in
+# a process of its own.
+os.environ.setdefault("KFX_RAYCAST_SUMMARY", "1")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

@@ -16,28 +16,57 @@ from kfx_testlib import oracle, scenes
 pytestmark = pytest.mark.gpu
 
 
-def export(roo, summ, tol):
+def export(roo, summ, tol, vref, fine_shift=4):
+    """R (per-brick ranges) and the march's class tables, decoded to one int8 class per entry: {shift: tensor[nz, ny, nx]}."""
     import torch
     from kangaroo_amd import _lib
-    L = _lib.load()
-    _lib.load_debug().kfx_debug_summary_export.restype = C.c_int
-    _lib.load_debug().kfx_debug_summary_export.argtypes = [C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.c_void_p]
-    dims = (C.c_int * 9)()
-    assert _lib.load_debug().kfx_debug_summary_export(summ.handle, tol, None, None, dims, None) == 0
+    f = _lib.load_debug().kfx_debug_summary_export
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.c_void_p]
+    dims = (C.c_int * 12)()
+    assert f(summ.handle, tol, vref, fine_shift, None, None, dims, None) == 0
     nbx, nby, nbz = dims[0], dims[1], dims[2]
-    n1, n2, n3 = nbx * nby * nbz, dims[3] * dims[4] * dims[5], dims[6] * dims[7] * dims[8]
     R = torch.empty((nbz, nby, nbx, 4), dtype=torch.float32, device="cuda")
-    Dall = torch.empty(n1 + n2 + n3, dtype=torch.float32, device="cuda")
-    assert _lib.load_debug().kfx_debug_summary_export(summ.handle, tol, C.c_void_p(R.data_ptr()), C.c_void_p(Dall.data_ptr()), dims, None) == 0
+    Cw = torch.zeros(dims[9], dtype=torch.int32, device="cuda")
+    assert f(summ.handle, tol, vref, fine_shift, C.c_void_p(R.data_ptr()), C.c_void_p(Cw.data_ptr()), dims, None) == 0
     torch.cuda.synchronize()
-    D1 = Dall[:n1].view(nbz, nby, nbx)
-    D2 = Dall[n1:n1 + n2].view(dims[5], dims[4], dims[3])
-    # the coarse levels may only promise what every level-1 entry below them promises
-    up = D2.repeat_interleave(4, 0).repeat_interleave(4, 1).repeat_interleave(4, 2)[:nbz, :nby, :nbx]
-    uni = up > 0
-    assert bool((D1[uni] > 0).all()) and bool(((D1[uni] - up[uni]).abs() <= tol * up[uni] + 0.0).all())
-    assert bool(torch.isnan(D1[torch.isnan(up)]).all())
-    return R, D1
+    W, H, D = summ.vol.w, summ.vol.h, summ.vol.d
+    classes = {}
+    for shift, (first, rw, ny) in ((fine_shift, dims[3:6]), (5, dims[6:9])):
+        m = 1 << shift
+        nx, nz = -(-W // m), -(-D // m)
+        assert ny == -(-H // m) and rw == 2 * (-(-nx // 32))
+        words = Cw[first:first + rw * ny * nz].view(nz, ny, rw // 2, 2).to(torch.int64) & 0xffffffff
+        bits = (words.unsqueeze(-1) >> torch.arange(32, device="cuda")) & 1           # [nz, ny, rw/2, plane, 32]
+        p0 = bits[..., 0, :].reshape(nz, ny, -1)[..., :nx]
+        p1 = bits[..., 1, :].reshape(nz, ny, -1)[..., :nx]
+        classes[shift] = (p0 | (p1 << 1)).to(torch.int8)
+    published, n_coarse = dims[11], dims[10]
+    assert published == int((classes[5] != 0).sum()) and n_coarse == classes[5].numel()   # the count the host steers by
+    return R, classes
+
+
+def check_classes(vol, classes, tol, vref):
+    """What the march relies on, against the volume's real contents: an entry of class 1 / 2 / 3 holds -- in its own cells and
+    in the +1 cells a trilinear sample based in it reads -- only vref (within tol) / only NaN / only NaN or vref."""
+    import torch
+    import torch.nn.functional as F
+    v = vol.tensor()[..., 0]
+    d, h, w = v.shape
+    flags = {1: (v - vref).abs() <= tol * vref, 2: torch.isnan(v)}
+    flags[3] = flags[1] | flags[2]
+    out = {}
+    for shift, cls in classes.items():
+        m = 1 << shift
+        nz, ny, nx = cls.shape
+        for k, fl in flags.items():
+            bad = (~fl).float()[None, None]
+            bad = F.pad(bad, (0, nx * m + 1 - w, 0, ny * m + 1 - h, 0, nz * m + 1 - d), value=0.0)   # cells outside the volume do not exist
+            holds = F.max_pool3d(bad, kernel_size=m + 1, stride=m)[0, 0] == 0                  # every cell of [b m, b m + m] satisfies the flag
+            wrong = (cls == k) & ~holds
+            assert not bool(wrong.any()), "class %d entries of the 2^%d level that the volume contradicts: %d" % (k, shift, int(wrong.sum()))
+        out[shift] = {k: int((cls == k).sum()) for k in range(4)}
+    return out
 
 
 def check_conservative(vol, R):
@@ -94,8 +123,12 @@ def test_gpu_tracked_fuse_and_raycast(roo, scene, N, w, h, dims, math):
             # (1) tracking never changes the volume
             assert T.nan_equal(va.MemcpyToHost(), vb.MemcpyToHost())
             # (2) the summary covers the volume's real contents
-            R, D = export(roo, summ, 1e-5 if math == "fast" else 0.0)
+            tol = 1e-5 if math == "fast" else 0.0
+            R, classes = export(roo, summ, tol, tr, fine_shift=4)
             stats = check_conservative(vb, R)
+            check_classes(vb, classes, tol, np.float32(tr))
+            R, classes = export(roo, summ, tol, tr, fine_shift=3)
+            counts = check_classes(vb, classes, tol, np.float32(tr))
             # (3) raycast with and without the summary
             a = [roo.Image(w, h), roo.Image(w, h, "f32x4"), roo.Image(w, h)]
             b = [roo.Image(w, h), roo.Image(w, h, "f32x4"), roo.Image(w, h)]
@@ -105,11 +138,11 @@ def test_gpu_tracked_fuse_and_raycast(roo, scene, N, w, h, dims, math):
             roo.RaycastSdf(*b, vb, T_wc, K, near, far, tr, True, summary=summ)
             da, db = a[0].MemcpyToHost(), b[0].MemcpyToHost()
             na, nb = a[1].MemcpyToHost(), b[1].MemcpyToHost()
-            n_uniform = int((D > 0).sum())
+            n_free, n_entries = counts[3][1] + counts[3][3], classes[3].numel()   # 8^3-cell entries holding +trunc (or +trunc / NaN)
             if math == "exact":
                 assert T.nan_equal(da, db) and T.nan_equal(na, nb) and T.nan_equal(a[2].MemcpyToHost(), b[2].MemcpyToHost())
                 if i == 0 and dims[2] % 8 == 0:
-                    assert n_uniform > 0      # first observation: +trunc everywhere in front of the surfaces, bit-identical
+                    assert n_free > 0      # first observation: +trunc everywhere in front of the surfaces, bit-identical
             else:
                 hit_a, hit_b = np.isfinite(da), np.isfinite(db)
                 assert (hit_a != hit_b).sum() <= max(3, 2e-4 * w * h), (hit_a != hit_b).sum()
@@ -118,7 +151,7 @@ def test_gpu_tracked_fuse_and_raycast(roo, scene, N, w, h, dims, math):
                 assert np.abs(da[both] - db[both]).max() < 1e-4, np.abs(da[both] - db[both]).max()
                 cosang = np.clip(np.sum(na[both][:, :3].astype(np.float64) * nb[both][:, :3], axis=1), -1, 1)
                 assert np.arccos(cosang).max() < 2e-3
-                assert n_uniform > (0.05 if dims[0] % 8 == 0 else 0.02) * D.numel(), (n_uniform, D.numel(), stats)   # observed free space is recognised frame after frame
+                assert n_free > (0.05 if dims[0] % 8 == 0 else 0.02) * n_entries, (n_free, n_entries, stats)   # observed free space is recognised frame after frame
         assert stats["all_nan"] > 0 or scene == "full"
     finally:
         roo.set_math_mode(prev)
@@ -195,16 +228,56 @@ def test_gpu_summary_views_and_untracked_writers(roo):
     assert same_images(vol)                                         # all NaN: every ray misses on both paths
     aligned = vol.SubVolume((16, 8, 24), (64, 80, 56))
     roo.SdfFuse(aligned, f, nrm, scenes.se3_inverse(T_wc), K, tr, scenes.MAX_W, scenes.MIN_COS_THETA, summary=summ)
-    R, D = export(roo, summ, 0.0)
+    R, classes = export(roo, summ, 0.0, tr)
     st = check_conservative(vol, R)
+    check_classes(vol, classes, 0.0, np.float32(tr))
     assert st["uniform_ranges"] > 0 and st["all_nan"] > 0 and st["mixed"] > 0   # mixed: partially observed bricks
     assert same_images(vol) and same_images(aligned)
     ragged = vol.SubVolume((3, 8, 24), (64, 80, 56))
     roo.SdfFuse(ragged, f, nrm, scenes.se3_inverse(T_wc), K, tr, scenes.MAX_W, scenes.MIN_COS_THETA, summary=summ)
-    R, D = export(roo, summ, 0.0)
-    assert check_conservative(vol, R)["mixed"] == R.shape[0] * R.shape[1] * R.shape[2] and int((D > 0).sum()) == 0
+    R, classes = export(roo, summ, 0.0, tr)
+    assert check_conservative(vol, R)["mixed"] == R.shape[0] * R.shape[1] * R.shape[2] and all(int((c != 0).sum()) == 0 for c in classes.values())
     assert same_images(vol) and same_images(ragged)
     roo.SdfReset(vol, float("nan"), summary=summ)
     roo.SdfSphere(vol, (0.0, 0.0, 3.0), 0.5)
     summ.invalidate()
     assert same_images(vol)
+
+
+def test_gpu_unforced_choice_between_plain_and_table_march(tmp_path):
+    """Without KFX_RAYCAST_SUMMARY the tracked RaycastSdf uses the tables only where at least a quarter of the 32^3-cell
+    entries can be crossed without sampling (the count the last finished table build published).  Either way the images are
+    those of the plain march (exact numerics: bit for bit) -- checked in a fresh process, the knob is read once."""
+    import subprocess
+    import sys
+    code = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import kfx_testlib as T
+from kfx_testlib import scenes
+from kangaroo_amd import roo
+N, w, h = 96, 160, 120
+for scene in ("room", "full"):
+    bmin, bmax, near, far = scenes.SCENES[scene]
+    K = scenes.intrinsics(w, h); tr = scenes.trunc_dist(bmin, bmax, (N, N, N))
+    vol = roo.BoundedVolume(N, N, N, bmin, bmax); summ = roo.SdfSummary(vol)
+    roo.SdfReset(vol, float("nan"), summary=summ)
+    f, vbo, nrm = roo.Image(w, h), roo.Image(w, h, "f32x4"), roo.Image(w, h, "f32x4")
+    for i in range(5):
+        T_wc = scenes.orbit_pose(i, 30)
+        roo.BilateralFilter(f, T.upload_image(roo, scenes.render_depth(scene, w, h, T_wc, K)), **scenes.BILATERAL)
+        roo.DepthToVbo(vbo, f, K); roo.NormalsFromVbo(nrm, vbo)
+        roo.SdfFuse(vol, f, nrm, scenes.se3_inverse(T_wc), K, tr, scenes.MAX_W, scenes.MIN_COS_THETA, summary=summ)
+        a = [roo.Image(w, h), roo.Image(w, h, "f32x4"), roo.Image(w, h)]
+        b = [roo.Image(w, h), roo.Image(w, h, "f32x4"), roo.Image(w, h)]
+        roo.RaycastSdf(*a, vol, T_wc, K, near, far, tr, True)
+        for _ in range(2):      # the second call sees the count the first call's table build published
+            roo.RaycastSdf(*b, vol, T_wc, K, near, far, tr, True, summary=summ)
+            torch.cuda.synchronize()
+            assert all(T.nan_equal(x.MemcpyToHost(), y.MemcpyToHost()) for x, y in zip(a, b)), (scene, i)
+print("ok")
+''' % (T.ROOT, __import__("os").path.join(T.ROOT, "tests"))
+    env = dict(__import__("os").environ)
+    env.pop("KFX_RAYCAST_SUMMARY", None)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stdout + out.stderr
