@@ -116,6 +116,14 @@ int kfx_sdf_fuse_count(const kfx_volume* vol, const kfx_image* depth, const kfx_
                        float mincostheta, unsigned flags, unsigned long long* d_count,
                        kfx_stream stream);
 
+/* Diagnostics (no reference counterpart): the march of kfx_raycast_sdf (fp32 cells) for a w x h image with every cell it reads
+ * -- the eight of each sample, the gradient stencil of each hit -- marked in d_bitmap (one bit per voxel, dense x-fastest
+ * index, ceil(w_vol h_vol d_vol / 32) words, zeroed by the caller).  Added to the DEVICE counters d_counters[4]: samples taken,
+ * rays that enter the box, hits, distinct voxels touched (U).  bench.py prices RaycastSdf's algorithmic bytes with it:
+ * 8 B x U + 24 B x w h.  Writes no image. */
+int kfx_raycast_sdf_count(const kfx_volume* vol, unsigned w, unsigned h, const float T_wc[12], const float K[4], float near, float far,
+                          float trunc_dist, int subpix, unsigned* d_bitmap, unsigned long long* d_counters, kfx_stream stream);
+
 /* roo::RaycastSdf(Image<float> depth, Image<float4> norm, Image<float> img,
  *                 const BoundedVolume<SDF_t>, const Mat<float,3,4> T_wc, ImageIntrinsics,
  *                 float near, float far, float trunc_dist, bool subpix)

@@ -189,7 +189,7 @@ struct kfx_sdf_summary {
     float c_tol, c_vref;         // what C was built with
     int c_shift;                 // fine level C was built for (log2 of its cells per entry)
     int n_coarse;                // 32^3-cell entries
-    int* d_count;                // device: {running count of 32^3-cell entries of class != 0, waves that have added theirs}
+    int* d_count;                // device: {running count of 32^3-cell entries of class != 0, workgroups that have added theirs}
     int* h_skippable;            // host-visible (pinned, mapped): the count the last finished build arrived at, -1 before the first
     int* d_skippable;            // the device's address of the same word
 };

@@ -343,6 +343,79 @@ __global__ __launch_bounds__(256) void k_raycast_sdf(const RayParams p, const Co
     raycast_pixel<CELL, COLOR>(p, cv, u, v);
 }
 
+// Diagnostics (kfx_raycast_sdf_count): the march of k_raycast_sdf with every cell a sample or a hit's gradient stencil reads
+// marked in a bitmap (one bit per voxel, dense x-fastest index): U = distinct voxels touched is the figure SURVEY.md 8(d)
+// prices RaycastSdf's algorithmic bytes with (8 B x U + 24 B x w h).  counters: {samples, rays that enter the box, hits, U}.
+__device__ __forceinline__ unsigned touch(unsigned* bitmap, const VolView& v, int x, int y, int z)
+{
+    const size_t i = ((size_t)z * v.h + y) * v.w + x;
+    const unsigned bit = 1u << (i & 31);
+    unsigned* word = bitmap + (i >> 5);
+    if (*reinterpret_cast<volatile unsigned*>(word) & bit) return 0u;
+    return (atomicOr(word, bit) & bit) ? 0u : 1u;
+}
+template <typename CELL>
+__global__ __launch_bounds__(256) void k_raycast_sdf_count(const RayParams p, unsigned* __restrict__ bitmap, unsigned long long* __restrict__ counters)
+{
+    int u, v;
+    ray_pixel_of(p, blockIdx.x, blockIdx.y, threadIdx.x, u, v);
+    unsigned n_samples = 0, n_new = 0, entered = 0, hit = 0;
+    if (u < p.w && v < p.h) {
+        const V3 c_w = v3(p.T.m[3], p.T.m[7], p.T.m[11]);
+        const V3 ray_c = v3(((float)u - p.K.u0) / p.K.fu, ((float)v - p.K.v0) / p.K.fv, 1.0f);
+        const V3 ray_w = so3_mul(p.T, ray_c);
+        const V3 ta = div_cw(p.vol.bmin - c_w, ray_w);
+        const V3 tb = div_cw(p.vol.bmax - c_w, ray_w);
+        const V3 tmin = v3(fminf(ta.x, tb.x), fminf(ta.y, tb.y), fminf(ta.z, tb.z));
+        const V3 tmax = v3(fmaxf(ta.x, tb.x), fmaxf(ta.y, tb.y), fmaxf(ta.z, tb.z));
+        const float max_tmin = fmaxf(fmaxf(fmaxf(tmin.x, tmin.y), tmin.z), p.near);
+        const float min_tmax = fminf(fminf(fminf(tmax.x, tmax.y), tmax.z), p.far);
+        float depth = 0.0f;
+        if (max_tmin < min_tmax) {
+            entered = 1;
+            float lambda = max_tmin, last_sdf = __builtin_nanf(""), delta = 0.f;
+            const float min_delta = p.voxel.x;
+            while (lambda < min_tmax) {
+                const CellPos c = cell_of(p, c_w + ray_w * lambda);
+                for (int k = 0; k < 8; ++k) n_new += touch(bitmap, p.vol, c.ix + (k & 1), c.iy + ((k >> 1) & 1), c.iz + (k >> 2));
+                n_samples += 1;
+                const float sdf = trilinear_at<CELL>(p, c);
+                if (sdf <= 0) {
+                    if (last_sdf > 0) {
+                        if (p.subpix) lambda = lambda + delta * sdf / (last_sdf - sdf);
+                        depth = lambda;
+                    }
+                    break;
+                }
+                delta = sdf > 0 ? fmaxf(sdf, min_delta) : p.trunc;
+                lambda += delta;
+                last_sdf = sdf;
+            }
+        }
+        if (depth > 0) { // the gradient's cells: {-1, 0, 1}^3 around its base cell with at most one coordinate at -1 (sampling.h)
+            hit = 1;
+            const V3 pos_v = div_cw(c_w + ray_w * depth - p.vol.bmin, p.size);
+            const int ix = (int)fmaxf(fminf(p.hi2.x, floorf(pos_v.x * p.dims1.x)), 1.f), iy = (int)fmaxf(fminf(p.hi2.y, floorf(pos_v.y * p.dims1.y)), 1.f),
+                      iz = (int)fmaxf(fminf(p.hi2.z, floorf(pos_v.z * p.dims1.z)), 1.f);
+            for (int dz = -1; dz < 2; ++dz)
+                for (int dy = -1; dy < 2; ++dy)
+                    for (int dx = -1; dx < 2; ++dx)
+                        if ((dx < 0) + (dy < 0) + (dz < 0) <= 1) n_new += touch(bitmap, p.vol, ix + dx, iy + dy, iz + dz);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        n_samples += __shfl_xor(n_samples, off, 64); n_new += __shfl_xor(n_new, off, 64);
+        entered += __shfl_xor(entered, off, 64); hit += __shfl_xor(hit, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (n_samples) atomicAdd(&counters[0], (unsigned long long)n_samples);
+        if (entered) atomicAdd(&counters[1], (unsigned long long)entered);
+        if (hit) atomicAdd(&counters[2], (unsigned long long)hit);
+        if (n_new) atomicAdd(&counters[3], (unsigned long long)n_new);
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // Several renderings of the same model in one launch.  The tracking loop raycasts the model at every pyramid level
 // that has ICP iterations (main.cpp:280-288: 640x480, 160x120, 80x60), and a coarse level takes as long as the
@@ -761,6 +834,20 @@ extern "C" int kfx_raycast_sdf(const kfx_image* depth, const kfx_image* norm, co
                                float far, float trunc_dist, int subpix, kfx_stream stream)
 {
     return raycast_launch<RayF32>(depth, norm, img, vol, T_wc, K, near, far, trunc_dist, subpix, stream);
+}
+
+extern "C" int kfx_raycast_sdf_count(const kfx_volume* vol, unsigned w, unsigned h, const float T_wc[12], const float K[4], float near, float far,
+                                     float trunc_dist, int subpix, unsigned* d_bitmap, unsigned long long* d_counters, kfx_stream stream)
+{
+    if (!d_bitmap || !d_counters) return set_error(KFX_E_NULL, "kfx_raycast_sdf_count: null argument");
+    // the image arguments of ray_params() only give the launch its size: nothing is written to them
+    kfx_image dummy = {(size_t)w * 16, (void*)(uintptr_t)16, w, h};
+    RayParams p;
+    if (int e = ray_params<RayF32>(p, &dummy, &dummy, &dummy, vol, T_wc, K, near, far, trunc_dist, subpix)) return e;
+    if (p.w == 0 || p.h == 0) return 0;
+    p.dptr = p.nptr = p.iptr = nullptr;
+    hipLaunchKernelGGL(k_raycast_sdf_count<RayF32>, dim3(ceil_div(p.w, 64), ceil_div(p.h, 4)), dim3(256), 0, (hipStream_t)stream, p, d_bitmap, d_counters);
+    return check_launch("kfx_raycast_sdf_count");
 }
 
 extern "C" int kfx_raycast_sdf_tracked(const kfx_image* depth, const kfx_image* norm, const kfx_image* img, const kfx_volume* vol,

@@ -16,35 +16,97 @@ __global__ __launch_bounds__(256) void k_summary_fill(float4* __restrict__ R, si
 }
 
 // Class tables (ClassView, kfx_device.h).  One lane per entry, 64 consecutive entries of a row per wave; the two planes are
-// the wave's ballots.  An entry of 2^shift cells reads the summary bricks [b << (shift - 3), (b + 1) << (shift - 3)] per axis
-// (the last one holds the +1 cells), clamped to the grid.
+// the wave's ballots.
+//   fine level (2^shift cells, shift 3 or 4): from the summary bricks [b << (shift - 3), (b + 1) << (shift - 3)] per axis
+//   (the last one holds the +1 cells), clamped to the grid;
+//   32^3-cell level: from the fine level's entries -- the cells [32 c, 32 c + 32] of entry c are exactly those of the fine
+//   entries [c m, c m + m) per axis (m = 32 >> shift; each fine entry already includes its +1 cells), so the class is the
+//   combination of m^3 two-bit reads instead of 125 brick ranges.  `src` = the fine level's words (same kernel, second launch).
 // count != nullptr (the 32^3-cell level): the waves add up their entries of class != 0; the last one to arrive publishes the
 // total in host-visible memory (*publish) and clears the counters for the next build -- the host reads that word without
 // synchronising (raycast.hip, class_view).
-__global__ __launch_bounds__(256) void k_summary_classes(const float4* __restrict__ R, unsigned* __restrict__ C, int nbx, int nby, int nbz,
-                                                          int shift, int nx, int ny, int nz, int rw, float lo_ok, float hi_ok,
-                                                          int* __restrict__ count, int* __restrict__ publish, int n_waves)
+struct ClassBuild {
+    const float4* R;
+    unsigned* C;
+    int nbx, nby, nbz;
+    int shift, nx, ny, nz, rw;
+    float lo_ok, hi_ok;
+    const unsigned* src;   // M == 0: the fine level's words
+    int src_shift, src_nx, src_ny, src_nz, src_rw;
+};
+// one wave = 64 consecutive entries of a row; returns (lane 0) the number of them with class != 0
+template <int M>   // summary bricks per fine entry and axis (1: 8^3 cells, 2: 16^3, 4: 32^3 straight from R); 0: combine `src`
+__device__ __forceinline__ int class_row(const ClassBuild& b, const long long wave)
 {
+    const float4* __restrict__ R = b.R;
+    unsigned* __restrict__ C = b.C;
+    const unsigned* __restrict__ src = b.src;
+    const int nbx = b.nbx, nby = b.nby, nbz = b.nbz, shift = b.shift, nx = b.nx, ny = b.ny, rw = b.rw;
+    const int src_shift = b.src_shift, src_nx = b.src_nx, src_ny = b.src_ny, src_nz = b.src_nz, src_rw = b.src_rw;
+    const float lo_ok = b.lo_ok, hi_ok = b.hi_ok;
     const int lane = threadIdx.x & 63;
     const int chunks = (nx + 63) >> 6;
-    const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (wave >= (long long)chunks * ny * nz) return;   // (n_waves = chunks * ny * nz: only those count)
     const int chunk = (int)(wave % chunks), by = (int)((wave / chunks) % ny), bz = (int)(wave / ((long long)chunks * ny));
     const int bx = chunk * 64 + lane;
     int cls = 0;
     if (bx < nx) {
-        const int m = 1 << (shift - 3);
         bool all_nan = true, all_free = true, all_either = true;
-        for (int z = bz * m; z <= bz * m + m; ++z)
-            for (int y = by * m; y <= by * m + m; ++y)
-                for (int x = bx * m; x <= bx * m + m; ++x) {
-                    const float4 r = R[((size_t)min(z, nbz - 1) * nby + min(y, nby - 1)) * nbx + min(x, nbx - 1)];
-                    const int st = __float_as_int(r.z);
-                    const bool in_band = r.x >= lo_ok && r.y <= hi_ok;   // every valued cell of the brick holds vref (false for the unknown state's infinite range)
-                    all_nan = all_nan && st == 1;
-                    all_free = all_free && st == 0 && in_band;
-                    all_either = all_either && (st == 1 || in_band);
-                }
+        if constexpr (M == 0) {
+            const int m = 1 << (shift - src_shift);   // 2 (16^3-cell fine level) or 4 (8^3)
+            // the m entries along x lie in one word pair (m divides 32): one 8-byte read per (y, z), all requested up front
+            for (int z0 = 0; z0 < m; z0 += 2) {
+                uint2 w2[2][4];
+#pragma unroll
+                for (int dz = 0; dz < 2; ++dz)
+#pragma unroll
+                    for (int dy = 0; dy < 4; ++dy) {
+                        const int z = min(bz * m + z0 + dz, src_nz - 1), y = min(by * m + min(dy, m - 1), src_ny - 1);
+                        w2[dz][dy] = *reinterpret_cast<const uint2*>(src + ((size_t)z * src_ny + y) * src_rw + (((bx * m) >> 5) << 1));
+                    }
+#pragma unroll
+                for (int dz = 0; dz < 2; ++dz)
+#pragma unroll
+                    for (int dy = 0; dy < 4; ++dy)
+                        for (int dx = 0; dx < m; ++dx) {
+                            const int x = min(bx * m + dx, src_nx - 1);   // (clamped entries repeat a neighbour: same verdict)
+                            const int c = (int)((w2[dz][dy].x >> (x & 31)) & 1u) | (int)(((w2[dz][dy].y >> (x & 31)) & 1u) << 1);
+                            all_free = all_free && c == 1;
+                            all_nan = all_nan && c == 2;
+                            all_either = all_either && c != 0;
+                        }
+            }
+        } else if constexpr (M > 2) {   // 125 ranges per entry: a loop (volumes whose finer tables do not fit LDS)
+            for (int z = bz * M; z <= bz * M + M; ++z)
+                for (int y = by * M; y <= by * M + M; ++y)
+                    for (int x = bx * M; x <= bx * M + M; ++x) {
+                        const float4 r = R[((size_t)min(z, nbz - 1) * nby + min(y, nby - 1)) * nbx + min(x, nbx - 1)];
+                        const int st = __float_as_int(r.z);
+                        const bool in_band = r.x >= lo_ok && r.y <= hi_ok;
+                        all_nan = all_nan && st == 1;
+                        all_free = all_free && st == 0 && in_band;
+                        all_either = all_either && (st == 1 || in_band);
+                    }
+        } else {
+            // (M + 1)^3 brick ranges, all requested before the first is looked at (fully unrolled: the loop form waited for
+            // each row of loads in turn, 9.5 us per launch at 512^3 against ~3)
+            float4 r[(M + 1) * (M + 1) * (M + 1)];
+#pragma unroll
+            for (int dz = 0; dz <= M; ++dz)
+#pragma unroll
+                for (int dy = 0; dy <= M; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx <= M; ++dx)
+                        r[(dz * (M + 1) + dy) * (M + 1) + dx] =
+                            R[((size_t)min(bz * M + dz, nbz - 1) * nby + min(by * M + dy, nby - 1)) * nbx + min(bx * M + dx, nbx - 1)];
+#pragma unroll
+            for (int k = 0; k < (M + 1) * (M + 1) * (M + 1); ++k) {
+                const int st = __float_as_int(r[k].z);
+                const bool in_band = r[k].x >= lo_ok && r[k].y <= hi_ok;   // every valued cell of the brick holds vref (false for the unknown state's infinite range)
+                all_nan = all_nan && st == 1;
+                all_free = all_free && st == 0 && in_band;
+                all_either = all_either && (st == 1 || in_band);
+            }
+        }
         cls = all_free ? 1 : (all_nan ? 2 : (all_either ? 3 : 0));
     }
     const unsigned long long p0 = __ballot(cls & 1), p1 = __ballot(cls & 2);
@@ -52,15 +114,38 @@ __global__ __launch_bounds__(256) void k_summary_classes(const float4* __restric
         unsigned* row = C + ((size_t)bz * ny + by) * rw + chunk * 4;
         row[0] = (unsigned)p0; row[1] = (unsigned)p1;
         if (chunk * 4 + 2 < rw) { row[2] = (unsigned)(p0 >> 32); row[3] = (unsigned)(p1 >> 32); }
-        if (count) {
-            atomicAdd(&count[0], __popcll(p0 | p1));
+    }
+    return __popcll(p0 | p1);
+}
+
+// the fine level: one wave per row of 64 entries
+template <int M>
+__global__ __launch_bounds__(256) void k_summary_classes(const ClassBuild b, const long long n_waves)
+{
+    const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wave < n_waves) class_row<M>(b, wave);
+}
+
+// the 32^3-cell level: the workgroups add up their entries of class != 0 (LDS), take a ticket, and the last one publishes the
+// total in host-visible memory and clears the counters for the next build -- the host reads that word without synchronising
+// (raycast.hip, class_view).  count = {running total, tickets taken}.
+template <int M>
+__global__ __launch_bounds__(256) void k_summary_classes_coarse(const ClassBuild b, const long long n_waves, int* __restrict__ count, int* __restrict__ publish)
+{
+    __shared__ int s_count[4];
+    const int wv = threadIdx.x >> 6;
+    const long long wave = (long long)blockIdx.x * 4 + wv;
+    const int n = wave < n_waves ? class_row<M>(b, wave) : 0;
+    if ((threadIdx.x & 63) == 0) s_count[wv] = n;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(&count[0], s_count[0] + s_count[1] + s_count[2] + s_count[3]);
+        __threadfence();
+        if (atomicAdd(&count[1], 1) == (int)gridDim.x - 1) {   // every workgroup's contribution is in
             __threadfence();
-            if (atomicAdd(&count[1], 1) == n_waves - 1) {   // every wave's contribution is in
-                __threadfence();
-                const int total = atomicExch(&count[0], 0);
-                count[1] = 0;
-                __hip_atomic_store(publish, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            }
+            const int total = atomicExch(&count[0], 0);
+            count[1] = 0;
+            __hip_atomic_store(publish, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
 }
@@ -92,10 +177,25 @@ int summary_classes_prepare(kfx_sdf_summary* s, float tol, float vref, int fine_
     for (int pass = 0; pass < 2; ++pass) {
         const ClassLevel& L = pass ? cv.coarse : cv.fine;
         if (!pass && fine_shift >= 5) continue;
-        const int nx = ceil_div(s->w, 1 << L.shift), ny = L.ny, nz = ceil_div(s->d, 1 << L.shift);
-        const long long waves = (long long)ceil_div(nx, 64) * ny * nz;
-        hipLaunchKernelGGL(k_summary_classes, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, stream, s->R, s->C + L.first, s->nbx, s->nby, s->nbz,
-                           L.shift, nx, ny, nz, L.rw, lo_ok, hi_ok, pass ? s->d_count : nullptr, pass ? s->d_skippable : nullptr, (int)waves);
+        ClassBuild b;
+        b.R = s->R; b.C = s->C + L.first;
+        b.nbx = s->nbx; b.nby = s->nby; b.nbz = s->nbz;
+        b.shift = L.shift; b.nx = ceil_div(s->w, 1 << L.shift); b.ny = L.ny; b.nz = ceil_div(s->d, 1 << L.shift); b.rw = L.rw;
+        b.lo_ok = lo_ok; b.hi_ok = hi_ok;
+        const bool from_fine = pass && fine_shift < 5;   // the 32^3-cell level combines the fine level's entries
+        b.src = from_fine ? s->C + cv.fine.first : nullptr;
+        b.src_shift = cv.fine.shift; b.src_nx = ceil_div(s->w, 1 << cv.fine.shift); b.src_ny = cv.fine.ny;
+        b.src_nz = ceil_div(s->d, 1 << cv.fine.shift); b.src_rw = cv.fine.rw;
+        const long long waves = (long long)ceil_div(b.nx, 64) * b.ny * b.nz;
+        if (pass) {
+            const dim3 grid((unsigned)((waves + 3) / 4));
+            if (from_fine) hipLaunchKernelGGL(k_summary_classes_coarse<0>, grid, dim3(256), 0, stream, b, waves, s->d_count, s->d_skippable);
+            else hipLaunchKernelGGL(k_summary_classes_coarse<4>, grid, dim3(256), 0, stream, b, waves, s->d_count, s->d_skippable);
+        } else if (L.shift == 3) {
+            hipLaunchKernelGGL(k_summary_classes<1>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, stream, b, waves);
+        } else {
+            hipLaunchKernelGGL(k_summary_classes<2>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, stream, b, waves);
+        }
         if (int e = check_launch("kfx_sdf_summary (classes)")) return e;
     }
     s->c_dirty = 0; s->c_tol = tol; s->c_vref = vref; s->c_shift = fine_shift;

@@ -80,6 +80,23 @@ class Image:
         dst.copy_(host)
         return self
 
+    def MemcpyFromPinned(self, host):
+        """Image::MemcpyFromHost from page-locked memory, asynchronous on the current stream: `host` is a pinned uint8 torch
+        tensor of h x (w * element size) bytes (pinned_like() makes one).  The copy is ordered before the launches that follow
+        on the stream; the caller keeps `host` unchanged until it has run."""
+        rowbytes = self.w * self.elem
+        dst = self.storage[self.offset: self.offset + self.pitch * (self.h - 1) + rowbytes]
+        dst = torch.as_strided(dst, (self.h, rowbytes), (self.pitch, 1))
+        dst.copy_(host, non_blocking=True)
+        return self
+
+    def pinned_like(self, arr):
+        """A page-locked host copy of `arr` in the layout MemcpyFromPinned takes."""
+        arr = np.ascontiguousarray(arr, dtype=self.np_dtype)
+        rowbytes = self.w * self.elem
+        assert arr.nbytes == rowbytes * self.h
+        return torch.from_numpy(arr.view(np.uint8).reshape(self.h, rowbytes).copy()).pin_memory()
+
     def MemcpyToHost(self):
         """Image::MemcpyToHost (Image.h:199-213) -> numpy (h, w[, 4])."""
         rowbytes = self.w * self.elem
@@ -295,6 +312,19 @@ def SdfFuseCount(vol, depth, norm, T_cw, K, trunc_dist, mincostheta, full_extent
     _lib.check(_lib.load().kfx_sdf_fuse_count(vol.ref(), depth.ref(), norm.ref(), t, k, trunc_dist, mincostheta,
                                               1 if full_extent else 0, C.c_void_p(cnt.data_ptr()), _stream(stream)))
     return int(cnt.item())
+
+
+def RaycastSdfCount(vol, w, h, T_wc, K, near, far, trunc_dist, subpix=True, stream=None):
+    """Diagnostics (kfx_raycast_sdf_count): what RaycastSdf's march for a w x h image reads -- dict(samples, rays, hits, U =
+    distinct voxels touched)."""
+    t, _t = _fp(T_wc, 12)
+    k, _k = _fp(K, 4)
+    bitmap = torch.zeros((vol.w * vol.h * vol.d + 31) // 32, dtype=torch.int32, device=vol.storage.device)
+    cnt = torch.zeros(4, dtype=torch.int64, device=vol.storage.device)
+    _lib.check(_lib.load().kfx_raycast_sdf_count(vol.ref(), w, h, t, k, near, far, trunc_dist, 1 if subpix else 0,
+                                                 C.c_void_p(bitmap.data_ptr()), C.c_void_p(cnt.data_ptr()), _stream(stream)))
+    c = cnt.tolist()
+    return dict(samples=c[0], rays=c[1], hits=c[2], U=c[3])
 
 
 def RaycastSdf(depth, norm, img, vol, T_wc, K, near, far, trunc_dist, subpix=True, stream=None, summary=None):

@@ -123,6 +123,11 @@ def test_gpu_fuse_raycast_vs_oracle(roo, scene, N, w, h, frames):
         assert T.nan_equal(rd.MemcpyToHost(), od.data), T.mismatch_report(rd.MemcpyToHost(), od.data)
         assert T.nan_equal(rn.MemcpyToHost(), on.data), T.mismatch_report(rn.MemcpyToHost(), on.data)
         assert T.nan_equal(ri.MemcpyToHost(), oi.data), T.mismatch_report(ri.MemcpyToHost(), oi.data)
+        # the march's diagnostics counters (bench.py's RaycastSdf roofline): samples, rays in the box, hits and distinct
+        # voxels touched equal the oracle's bitmap count
+        st, U = oracle.raycast_sdf_touch(od, on, oi, ovol, fr[-1]["T_wc"], K, near, far, tr, subpix)
+        got = roo.RaycastSdfCount(vol, w, h, fr[-1]["T_wc"], K, near, far, tr, subpix)
+        assert got == dict(samples=st["steps"], rays=st["rays"], hits=st["hits"], U=U), (got, st, U)
 
 
 def test_gpu_fuse_ragged_dims_and_padded_pitch(roo):
