@@ -171,7 +171,10 @@ int main(int argc, char** argv)
         else if (!strcmp(argv[i], "--fast")) o.fast = true;
         else if (!strcmp(argv[i], "--transport") && i + 1 < argc) o.rccl = !strcmp(argv[++i], "rccl");
         else if (!strcmp(argv[i], "--halo") && i + 1 < argc) o.halo = !strcmp(argv[++i], "recompute") ? SlabVolume::HaloRecompute : SlabVolume::HaloExchange;
-        else if (!strcmp(argv[i], "--raycast") && i + 1 < argc) o.raycast = !strcmp(argv[++i], "exact") ? SlabVolume::Exact : SlabVolume::Composite;
+        else if (!strcmp(argv[i], "--raycast") && i + 1 < argc) {
+            ++i;
+            o.raycast = !strcmp(argv[i], "exact") ? SlabVolume::Exact : (!strcmp(argv[i], "exact-allreduce") ? SlabVolume::ExactAllReduce : SlabVolume::Composite);
+        }
         else if (!strcmp(argv[i], "--inputs") && i + 1 < argc) o.broadcast_inputs = !strcmp(argv[++i], "broadcast");
         else if (!strcmp(argv[i], "--rendezvous") && i + 1 < argc) o.rendezvous = argv[++i];
         else { fprintf(stderr, "unknown argument %s\n", argv[i]); return 2; }
@@ -225,8 +228,8 @@ int main(int argc, char** argv)
     if (rank == 0) {
         printf("kinectfusion_slabs: %d^3 volume in %d slab(s) [%s], %dx%d, %d frames, %s math, halo %s, raycast %s%s: %.3f ms/frame (%.1f fps)\n",
                o.volres, world, o.rccl ? "RCCL, one process per GPU" : "threads sharing one GPU", o.w, o.h, o.frames, o.fast ? "fast" : "exact",
-               o.halo == SlabVolume::HaloExchange ? "exchange" : "recompute", o.raycast == SlabVolume::Exact ? "exact" : "composite",
-               o.raycast == SlabVolume::Exact ? (" (" + std::to_string(r0.rounds) + " rounds)").c_str() : "", r0.ms_per_frame, 1e3 / r0.ms_per_frame);
+               o.halo == SlabVolume::HaloExchange ? "exchange" : "recompute", o.raycast == SlabVolume::Exact ? "exact (hand-over)" : (o.raycast == SlabVolume::ExactAllReduce ? "exact (all-reduce per round)" : "composite"),
+               o.raycast != SlabVolume::Composite ? (" (" + std::to_string(r0.rounds) + " rounds)").c_str() : "", r0.ms_per_frame, 1e3 / r0.ms_per_frame);
         printf("checksums depth=%08x norm=%08x img=%08x volume=%08x hits=%zu ranks_agree=%d\n", r0.chk_d, r0.chk_n, r0.chk_i, r0.chk_vol, r0.hits,
                r0.status == 0 ? 1 : 0);
     }

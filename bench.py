@@ -45,8 +45,9 @@ def parse():
     ap.add_argument("--res", type=int, default=512, help="volume resolution N (N^3 voxels)")
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
-    ap.add_argument("--raycast", default="composite", choices=["composite", "exact"],
-                    help="multi-GPU raycast: per-slab march + nearest-hit composite, or the bit-exact march-state hand-over")
+    ap.add_argument("--raycast", default="composite", choices=["composite", "exact", "exact_allreduce"],
+                    help="multi-GPU raycast: per-slab march + nearest-hit composite; the bit-exact march-state hand-over between "
+                         "neighbour ranks (world + 1 stages, no host check in between); or its cross-check with an all-reduce per round")
     ap.add_argument("--halo", default="recompute", choices=["recompute", "exchange"],
                     help="N > 1: how ghost planes are kept current -- recomputed by each rank (no traffic) or "
                          "exchanged with the neighbours over RCCL point-to-point after each SdfFuse")
@@ -515,7 +516,7 @@ def main():
                 "ranks_agree": ranks_agree,
                 "raycast": ("brick summary: steps through uniform regions taken without reading the volume (kfx_raycast_sdf_tracked)"
                             if (not distributed and use_summary) else "plain march (kfx_raycast_sdf)"),
-                "partition": ("z-slabs x%d, inputs %s, ghost planes %s%s, raycast %s" % (n_gpus, "preprocessed by every rank" if args.inputs == "replicate" else "preprocessed by rank 0 and broadcast", args.halo, ", merge overlapped with the next frame" if args.overlap else "", "composite = all_reduce(MIN key) + all_reduce(SUM payload)" if args.raycast == "composite" else "exact = march state handed from slab to slab, one SUM all_reduce per round"))
+                "partition": ("z-slabs x%d, inputs %s, ghost planes %s%s, raycast %s" % (n_gpus, "preprocessed by every rank" if args.inputs == "replicate" else "preprocessed by rank 0 and broadcast", args.halo, ", merge overlapped with the next frame" if args.overlap else "", {"composite": "composite = all_reduce(MIN key) + all_reduce(SUM payload)", "exact": "exact = march state handed from slab to slab: world + 1 stages, neighbour send/recv between them, one all_reduce of the finalised pixels at the end", "exact_allreduce": "exact (cross-check) = one SUM all_reduce of the march state + a host-side termination test per round"}[args.raycast]))
                              if distributed else "single volume",
                 "math": {"fast": "fast (fp32 rcp/rsq + FMA: the reference's own -use_fast_math regime; whole chain against the exact oracle at this size, "
                                  "tests/test_gpu_chain.py: TSDF L-inf < 1e-4 on identically classified voxels (<= 2e-6 of them classified differently); raycast images: "

@@ -27,7 +27,9 @@ class SlabVolume
 {
 public:
     enum HaloMode { HaloExchange, HaloRecompute };   // ghost planes: from the neighbours (RCCL send / recv) or integrated redundantly
-    enum RaycastMode { Composite, Exact };           // nearest hit of per-slab marches, or the march state handed from slab to slab
+    // nearest hit of per-slab marches; the march state handed from slab to slab (neighbour exchanges, one synchronisation per
+    // frame); the same march with an all-reduce and a host check per round (the cross-check of the hand-over)
+    enum RaycastMode { Composite, Exact, ExactAllReduce };
 
     kfx_slab_layout layout;
     BoundedVolume<SDF_t, TargetDevice, Manage> local; // planes [layout.s0, layout.s1) of the whole volume
@@ -82,6 +84,9 @@ public:
         if (raycast == Exact) {
             GpuCheckStatus(kfx_slab_raycast_exact(depth.abi(), norm.abi(), img.abi(), (float*)state_, scratch_, local.abi(), &layout, T_wc.m,
                                                   &K.fu, near, far, trunc_dist, subpix ? 1 : 0, comm, 0, &last_rounds));
+        } else if (raycast == ExactAllReduce) {
+            GpuCheckStatus(kfx_slab_raycast_exact_allreduce(depth.abi(), norm.abi(), img.abi(), (float*)state_, scratch_, local.abi(), &layout, T_wc.m,
+                                                            &K.fu, near, far, trunc_dist, subpix ? 1 : 0, comm, 0, &last_rounds));
         } else {
             RaycastSdf(depth, norm, img, local, T_wc, K, near, far, trunc_dist, subpix);
             GpuCheckStatus(kfx_slab_composite(depth.abi(), norm.abi(), img.abi(), (long long*)key_, (float*)payload_, comm, 0));

@@ -90,14 +90,21 @@ int kfx_slab_exchange_halos(const kfx_volume* local, const kfx_slab_layout* L, k
 int kfx_slab_composite(const kfx_image* depth, const kfx_image* norm, const kfx_image* img, long long* key, float* payload,
                        kfx_comm* comm, kfx_stream stream);
 
-/* The exact march: rounds of kfx_raycast_sdf_slab, one SUM all-reduce of the touched pixels' march state per round and one
- * of the normals / shade at the end; every rank returns with the images of kfx_raycast_sdf on the whole volume, bit for
- * bit.  state: KFX_RAY_STATE_PLANES * w*h floats; scratch: kfx_slab_exact_scratch_bytes(w, h) bytes (device).  *rounds_out
- * (optional) receives the number of rounds (<= world + 2).  Synchronises the stream once per round (termination test). */
+/* The exact march.  A ray's march state (lambda, last_sdf, delta, status) travels with the ray from slab to slab: world + 1
+ * stages of kfx_raycast_sdf_slab -- each rank advances the rays whose current sample lies in the planes it owns -- with an
+ * exchange of the march planes between NEIGHBOUR ranks after each stage (point-to-point: one xGMI link per direction), then
+ * one all-reduce of the finalising ranks' results and one 4-byte read-back.  No host synchronisation between the stages.
+ * Every rank returns with the images of kfx_raycast_sdf on the whole volume, bit for bit.  state: KFX_RAY_STATE_PLANES * w*h
+ * floats; scratch: kfx_slab_exact_scratch_bytes(w, h) bytes (device).  *rounds_out (optional) receives the number of stages.
+ * kfx_slab_raycast_exact_allreduce is the cross-check: the same kernels with the state merged over ALL ranks after every
+ * round (one SUM all-reduce + one host-side termination test per round, <= world + 2 rounds); same images. */
 size_t kfx_slab_exact_scratch_bytes(size_t w, size_t h);
 int kfx_slab_raycast_exact(const kfx_image* depth, const kfx_image* norm, const kfx_image* img, float* state, void* scratch,
                            const kfx_volume* local, const kfx_slab_layout* L, const float T_wc[12], const float K[4],
                            float near, float far, float trunc_dist, int subpix, kfx_comm* comm, kfx_stream stream, int* rounds_out);
+int kfx_slab_raycast_exact_allreduce(const kfx_image* depth, const kfx_image* norm, const kfx_image* img, float* state, void* scratch,
+                                     const kfx_volume* local, const kfx_slab_layout* L, const float T_wc[12], const float K[4],
+                                     float near, float far, float trunc_dist, int subpix, kfx_comm* comm, kfx_stream stream, int* rounds_out);
 
 #ifdef __cplusplus
 }

@@ -42,6 +42,69 @@ __global__ __launch_bounds__(256) void k_state_merge(int* __restrict__ state, co
     if (__ballot(open) != 0ull && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
 }
 
+// ---- exact march, hand-over protocol (kfx_slab_raycast_exact) --------------------------------------------------------
+// A ray's march state travels with the ray: after a rank has marched its segment the state goes to the two neighbour ranks
+// only (planes 0-4 as they are: nothing is compacted, the receiver picks the rays that came its way), and a rank adopts from
+// a neighbour's planes the rays that neighbour advanced in this stage and that are still under way (status 0: marching, 3:
+// hit found, normal pending).  No rank ever acts on a stale copy: k_raycast_sdf_slab advances a ray only while the trilinear
+// base plane of its current sample is one the rank owns, a ray moves through the planes monotonically, so the plane of a
+// stale position belongs to a rank the ray has left -- and that rank holds the newer state.
+// fin[i] = this rank finalised pixel i (set its status to 1 hit / 2 miss), the one rank whose result counts at the end.
+__global__ __launch_bounds__(256) void k_handover_merge(int* __restrict__ state, const int* __restrict__ from_lo, const int* __restrict__ from_hi,
+                                                        int* __restrict__ fin, size_t n, int claim_untouched_misses)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const bool touched = state[4 * n + i] != 0;
+    const float status = __int_as_float(state[3 * n + i]);
+    if (touched && (status == 1.0f || status == 2.0f)) fin[i] = 1;
+    // rays that never enter the box are misses from the first stage on, on every rank alike: rank 0 answers for them
+    if (claim_untouched_misses && !touched && status == 2.0f) fin[i] = 1;
+    const int* src = nullptr;
+    if (from_lo && from_lo[4 * n + i] != 0) {
+        const float st = __int_as_float(from_lo[3 * n + i]);
+        if (st == 0.0f || st == 3.0f) src = from_lo;
+    }
+    if (!src && from_hi && from_hi[4 * n + i] != 0) {
+        const float st = __int_as_float(from_hi[3 * n + i]);
+        if (st == 0.0f || st == 3.0f) src = from_hi;
+    }
+    if (src) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) state[p * n + i] = src[p * n + i];
+    }
+}
+
+// contribution of this rank to the final images: lambda, status, normal, shade of the pixels it finalised, zero elsewhere
+// (integer bit patterns: NaN and -0 survive the SUM over ranks, where exactly one rank is non-zero)
+__global__ __launch_bounds__(256) void k_handover_contrib(const int* __restrict__ state, const int* __restrict__ fin, int* __restrict__ contrib, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const bool mine = fin[i] != 0;
+    contrib[0 * n + i] = mine ? state[0 * n + i] : 0;
+    contrib[1 * n + i] = mine ? state[3 * n + i] : 0;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) contrib[(2 + p) * n + i] = mine ? state[(5 + p) * n + i] : 0;
+}
+
+// the summed contributions back into the state; *open += pixels without a final status (none, unless the protocol is broken)
+__global__ __launch_bounds__(256) void k_handover_finish(int* __restrict__ state, const int* __restrict__ contrib, size_t n, int* __restrict__ open)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    bool bad = false;
+    if (i < n) {
+        state[0 * n + i] = contrib[0 * n + i];
+        state[3 * n + i] = contrib[1 * n + i];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) state[(5 + p) * n + i] = contrib[(2 + p) * n + i];
+        const float status = __int_as_float(contrib[1 * n + i]);
+        bad = !(status == 1.0f || status == 2.0f);
+    }
+    const unsigned long long m = __ballot(bad);
+    if (m != 0ull && (threadIdx.x & 63) == 0) atomicAdd(open, __popcll(m));
+}
+
 // ---- threads transport: reduction over the ranks' buffers by one kernel -------------------------------------------
 constexpr int MAX_THREAD_RANKS = 16;
 struct PtrList { void* p[MAX_THREAD_RANKS]; };
@@ -299,16 +362,79 @@ extern "C" int kfx_slab_composite(const kfx_image* depth, const kfx_image* norm,
     return kfx_composite_unpack(depth, norm, img, key, payload, stream);
 }
 
-extern "C" size_t kfx_slab_exact_scratch_bytes(size_t w, size_t h) { return (5 * w * h + 64) * sizeof(int); }
+extern "C" size_t kfx_slab_exact_scratch_bytes(size_t w, size_t h) { return (17 * w * h + 64) * sizeof(int); }
 
+static int exact_args(const kfx_image* depth, const kfx_image* norm, const kfx_image* img, float* state, void* scratch,
+                      const kfx_volume* local, const kfx_slab_layout* L, kfx_comm* comm, const char* who)
+{
+    if (!depth || !norm || !img || !state || !scratch || !local || !L || !comm) return set_error(KFX_E_NULL, who);
+    if (local->d != L->s1 - L->s0 || comm->rank != L->rank || comm->world != L->world)
+        return set_error(KFX_E_SHAPE, "kfx_slab_raycast_exact: volume / communicator do not match the layout");
+    return 0;
+}
+
+// The blueprint's hand-over: world + 1 march stages with a neighbour exchange of the march planes between
+// them -- a ray that enters at one end needs `world` stages to reach the other, one more lets a hit on a slab boundary have
+// its normal evaluated by the neighbour that owns the gradient's base plane --, then ONE all-reduce of the finalising ranks'
+// results and ONE read-back (the count of rays without a final status: zero).  No host synchronisation between the stages.
 extern "C" int kfx_slab_raycast_exact(const kfx_image* depth, const kfx_image* norm, const kfx_image* img, float* state, void* scratch,
                                       const kfx_volume* local, const kfx_slab_layout* L, const float T_wc[12], const float K[4],
                                       float near, float far, float trunc_dist, int subpix, kfx_comm* comm, kfx_stream stream,
                                       int* rounds_out)
 {
-    if (!depth || !norm || !img || !state || !scratch || !local || !L || !comm) return set_error(KFX_E_NULL, "kfx_slab_raycast_exact: null argument");
-    if (local->d != L->s1 - L->s0 || comm->rank != L->rank || comm->world != L->world)
-        return set_error(KFX_E_SHAPE, "kfx_slab_raycast_exact: volume / communicator do not match the layout");
+    if (int e = exact_args(depth, norm, img, state, scratch, local, L, comm, "kfx_slab_raycast_exact: null argument")) return e;
+    const int w = (int)depth->w, h = (int)depth->h;
+    const size_t n = (size_t)w * h;
+    if (n == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    int* from_lo = static_cast<int*>(scratch);
+    int* from_hi = from_lo + 5 * n;
+    int* fin = from_hi + 5 * n;
+    int* contrib = fin + n;
+    int* open = contrib + 6 * n;
+    int* istate = reinterpret_cast<int*>(state);
+    const kfx_slab slab = {L->full_d, L->s0, L->full_zmin, L->full_zmax};
+    const dim3 grid((unsigned)((n + 255) / 256));
+    const int world = comm->world, rank = comm->rank;
+    const int stages = world > 1 ? world + 1 : 1;
+    // a local failure must not keep this rank out of a collective its peers enter: remember it, go on, report it at the end
+    int status = 0;
+    auto note = [&](int e) { if (e && !status) status = e; };
+    if (world > 1) note(hip_status(hipMemsetAsync(fin, 0, (7 * n + 1) * sizeof(int), s), "kfx_slab_raycast_exact")); // fin, contrib, open
+    for (int stage = 0; stage < stages; ++stage) {
+        note(kfx_raycast_sdf_slab(state, stage == 0, local, &slab, (int)L->z0, (int)L->z1, w, h, T_wc, K, near, far, trunc_dist, subpix, stream));
+        if (world == 1) break;
+        const bool exchange = stage + 1 < stages;
+        if (exchange) note(comm->exchange(comm, istate, from_lo, 5 * n * sizeof(int), istate, from_hi, 5 * n * sizeof(int), stream));
+        hipLaunchKernelGGL(k_handover_merge, grid, dim3(256), 0, s, istate, (exchange && rank > 0) ? from_lo : nullptr,
+                           (exchange && rank + 1 < world) ? from_hi : nullptr, fin, n, (stage == 0 && rank == 0) ? 1 : 0);
+        note(check_launch("kfx_slab_raycast_exact"));
+    }
+    if (world > 1) {
+        hipLaunchKernelGGL(k_handover_contrib, grid, dim3(256), 0, s, istate, fin, contrib, n);
+        note(check_launch("kfx_slab_raycast_exact"));
+        note(comm->all_reduce(comm, contrib, 6 * n, KFX_COMM_SUM_I32, stream));
+        hipLaunchKernelGGL(k_handover_finish, grid, dim3(256), 0, s, istate, contrib, n, open);
+        note(check_launch("kfx_slab_raycast_exact"));
+        int n_open = 0;
+        note(hip_status(hipMemcpyAsync(&n_open, open, sizeof(int), hipMemcpyDeviceToHost, s), "kfx_slab_raycast_exact"));
+        note(hip_status(hipStreamSynchronize(s), "kfx_slab_raycast_exact"));   // the frame's one synchronisation
+        if (!status && n_open) status = set_error(KFX_E_RANGE, "kfx_slab_raycast_exact: rays without a final status after world + 1 stages");
+    }
+    if (rounds_out) *rounds_out = stages;
+    if (status) return status;
+    return kfx_raycast_state_to_images(depth, norm, img, state, stream);
+}
+
+// The cross-check of the hand-over: rounds of kfx_raycast_sdf_slab with one SUM all-reduce of the touched pixels' march state
+// per round (every rank always holds every ray's state) and a host-side termination test after each -- <= world + 2 rounds,
+// each a host synchronisation.  Same images, bit for bit.
+extern "C" int kfx_slab_raycast_exact_allreduce(const kfx_image* depth, const kfx_image* norm, const kfx_image* img, float* state, void* scratch,
+                                      const kfx_volume* local, const kfx_slab_layout* L, const float T_wc[12], const float K[4],
+                                      float near, float far, float trunc_dist, int subpix, kfx_comm* comm, kfx_stream stream,
+                                      int* rounds_out)
+{
+    if (int e = exact_args(depth, norm, img, state, scratch, local, L, comm, "kfx_slab_raycast_exact_allreduce: null argument")) return e;
     const int w = (int)depth->w, h = (int)depth->h;
     const size_t n = (size_t)w * h;
     if (n == 0) return 0;

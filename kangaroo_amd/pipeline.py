@@ -201,7 +201,7 @@ class SlabPipeline(FramePipeline):
         per direction); halo = "recompute": every rank integrates its ghost planes itself (the update is
         deterministic per voxel, so no traffic is needed) -- the cross-check of the exchange path."""
         assert halo in ("exchange", "recompute")
-        assert raycast in ("composite", "exact")
+        assert raycast in ("composite", "exact", "exact_allreduce")
         # inputs (SURVEY.md 8(e) "input distribution"): "replicate" = every rank filters the frame and derives the normal map
         # itself (no traffic); "broadcast" = rank 0 does, and its filtered depth + normal map (20 B per pixel) are broadcast
         assert inputs in ("replicate", "broadcast")
@@ -275,6 +275,23 @@ class SlabPipeline(FramePipeline):
         if target is not self.vol:
             self.exchange_halos()
 
+    def _p2p(self, ops):
+        """One batched group of point-to-point operations, complete on return as far as the current stream is concerned.
+        RCCL (backend "nccl") is stream-ordered: the requests' wait() chains the current stream behind the transfers.  gloo
+        with device tensors -- ranks sharing one GPU in the tests -- stages through the host without regard to the stream
+        that produces / consumes the tensors, so the device is synchronised on both sides of the batch."""
+        if not ops:
+            return
+        dist = self.dist
+        dev = ops[0].tensor.is_cuda and dist.get_backend() != "nccl"
+        if dev:
+            import torch
+            torch.cuda.synchronize()
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+        if dev:
+            torch.cuda.synchronize()
+
     def exchange_halos(self):
         """Refresh the ghost planes from the neighbours' owned planes (contiguous img_pitch-sized
         slices): rank r sends its first / last G owned planes down / up and receives the matching
@@ -290,9 +307,7 @@ class SlabPipeline(FramePipeline):
         if self.rank < self.world - 1 and hi_ghost > 0:
             ops.append(dist.P2POp(dist.isend, self.vol.planes(own1 - hi_ghost, own1), self.rank + 1))
             ops.append(dist.P2POp(dist.irecv, self.vol.planes(own1, own1 + hi_ghost), self.rank + 1))
-        if ops:
-            for req in dist.batch_isend_irecv(ops):
-                req.wait()
+        self._p2p(ops)
 
     def raycast(self, T_wc):
         """raycast = "composite": every rank marches its own slab from the slab's entry point and the nearest
@@ -306,6 +321,9 @@ class SlabPipeline(FramePipeline):
         identical on every rank afterwards."""
         if self.raycast_mode == "exact":
             self.raycast_exact(T_wc, d, n, i, K)
+            return
+        if self.raycast_mode == "exact_allreduce":
+            self.raycast_exact_allreduce(T_wc, d, n, i, K)
             return
         self.wait_composite()   # the previous frame's merge still reads these images
         self.ops.RaycastSdf(d, n, i, self.vol, T_wc, K, self.near, self.far, self.trunc, True)
@@ -379,11 +397,69 @@ class SlabPipeline(FramePipeline):
         return cache[key]
 
     def raycast_exact(self, T_wc, d=None, n=None, i=None, K=None):
-        """Rounds of kfx_raycast_sdf_slab.  In a round exactly one rank advances a given ray (the owner of the
-        trilinear base plane of its current sample), so the merge is one integer SUM all-reduce of the touched
-        pixels' march planes (lambda, last_sdf, delta, status, touched); untouched pixels are identical on all
-        ranks already.  A ray crosses the slabs monotonically in z: at most world + 2 rounds.  The normals
-        (planes 5-8, written by one rank per pixel) are merged once at the end."""
+        """The march state travels with the ray (the exact variant): world + 1 stages of kfx_raycast_sdf_slab
+        -- a rank advances the rays whose current sample lies in the planes it owns --, between them the march planes
+        (lambda, last_sdf, delta, status, touched) go to the two NEIGHBOUR ranks only, and a rank adopts the rays a
+        neighbour advanced that are still under way (status 0 marching, 3 hit with its normal pending).  A stale copy is
+        never acted on: its position lies in planes of a rank the ray has left.  A ray entering at one end needs `world`
+        stages, one more lets a hit on a slab boundary get its normal from the neighbour owning the gradient's base plane.
+        At the end ONE all-reduce sums the results of the ranks that finalised each pixel (integer bit patterns; rank 0
+        answers for rays that never enter the box).  No host synchronisation between the stages.  Depth, normals and
+        shade equal RaycastSdf on the whole volume bit for bit."""
+        import torch
+        dist, o = self.dist, self.ops
+        d, n, i = (self.ray_d, self.ray_n, self.ray_i) if d is None else (d, n, i)
+        K = self.K if K is None else K
+        w, h = d.w, d.h
+        D = self.dims[2]
+        slab = (D, self.s0, float(self.full_boxmin[2]), float(self.full_boxmax[2]))
+        st = self._scratch("state", (9, h, w), torch.float32, d)
+        march = st[0:5].view(torch.int32)   # contiguous planes 0..4
+        stages = self.world + 1 if self.world > 1 else 1
+        fin = torch.zeros((h, w), dtype=torch.bool, device=st.device)
+        from_lo = self._scratch("from_lo", (5, h, w), torch.int32, d) if self.rank > 0 else None
+        from_hi = self._scratch("from_hi", (5, h, w), torch.int32, d) if self.rank < self.world - 1 else None
+        for stage in range(stages):
+            o.RaycastSdfSlab(st, stage == 0, self.vol, slab, self.z0, self.z1, w, h, T_wc, K, self.near, self.far, self.trunc, True)
+            if self.world == 1:
+                break
+            status, touched = st[3], march[4] != 0
+            fin |= touched & ((status == 1) | (status == 2))
+            if stage == 0 and self.rank == 0:
+                fin |= ~touched & (status == 2)
+            if stage + 1 == stages:
+                break
+            ops = []
+            if from_lo is not None:
+                ops += [dist.P2POp(dist.isend, march, self.rank - 1), dist.P2POp(dist.irecv, from_lo, self.rank - 1)]
+            if from_hi is not None:
+                ops += [dist.P2POp(dist.isend, march, self.rank + 1), dist.P2POp(dist.irecv, from_hi, self.rank + 1)]
+            self._p2p(ops)
+            taken = torch.zeros_like(fin)
+            for buf in (from_lo, from_hi):
+                if buf is None:
+                    continue
+                bstat = buf[3].view(torch.float32)
+                take = (buf[4] != 0) & ((bstat == 0) | (bstat == 3)) & ~taken
+                march[0:4].copy_(torch.where(take.unsqueeze(0), buf[0:4], march[0:4]))
+                taken |= take
+        if self.world > 1:
+            allst = st.view(torch.int32)
+            contrib = torch.stack([allst[0], allst[3], allst[5], allst[6], allst[7], allst[8]])
+            contrib = torch.where(fin.unsqueeze(0), contrib, torch.zeros_like(contrib)).contiguous()
+            dist.all_reduce(contrib, op=dist.ReduceOp.SUM)
+            for k, p in enumerate((0, 3, 5, 6, 7, 8)):
+                allst[p].copy_(contrib[k])
+            final = (st[3] == 1) | (st[3] == 2)
+            assert bool(final.all()), "slab march: %d rays without a final status after world + 1 stages" % int((~final).sum())
+        self.rounds = stages
+        o.RaycastStateToImages(d, n, i, st)
+
+    def raycast_exact_allreduce(self, T_wc, d=None, n=None, i=None, K=None):
+        """The cross-check of raycast_exact: the same kernels with the state merged over ALL ranks after every round.  In a
+        round exactly one rank advances a given ray (the owner of the trilinear base plane of its current sample), so the
+        merge is one integer SUM all-reduce of the touched pixels' march planes; a host-side termination test follows every
+        round (at most world + 2 of them).  The normals (planes 5-8, written by one rank per pixel) are merged once at the end."""
         import torch
         dist, o = self.dist, self.ops
         d, n, i = (self.ray_d, self.ray_n, self.ray_i) if d is None else (d, n, i)

@@ -33,12 +33,14 @@ def test_cpp_slabs_exact_march_equals_single_volume():
     bit-identical to the one-slab run (which is the single-volume pipeline)."""
     ref = run(*COMMON, "--ranks", 1, "--raycast", "exact")
     assert ref["hits"] > 320 * 240 // 3 and ref["agree"] == 1
-    for ranks, halo in ((4, "exchange"), (3, "recompute"), (8, "exchange")):
-        got = run(*COMMON, "--ranks", ranks, "--raycast", "exact", "--halo", halo)
+    for ranks, halo, mode in ((4, "exchange", "exact"), (3, "recompute", "exact"), (8, "exchange", "exact"), (2, "exchange", "exact"),
+                              (4, "exchange", "exact-allreduce")):   # the last: the all-reduce cross-check of the hand-over
+        got = run(*COMMON, "--ranks", ranks, "--raycast", mode, "--halo", halo)
         assert got["agree"] == 1
         for k in ("depth", "norm", "img", "volume", "hits"):
-            assert got[k] == ref[k], (ranks, halo, k, got["text"], ref["text"])
-        assert re.search(r"\((\d+) rounds\)", got["text"]) and 1 < int(re.search(r"\((\d+) rounds\)", got["text"]).group(1)) <= ranks + 3
+            assert got[k] == ref[k], (ranks, halo, mode, k, got["text"], ref["text"])
+        rounds = int(re.search(r"\((\d+) rounds\)", got["text"]).group(1))
+        assert rounds == ranks + 1 if mode == "exact" else 1 < rounds <= ranks + 3   # hand-over: a fixed number of stages
 
 
 def test_cpp_slabs_inputs_broadcast_from_rank_zero():

@@ -70,13 +70,16 @@ def test_gpu_bench_overlapped_merge_two_ranks():
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     env["KFX_BENCH_BACKEND"] = "gloo"
     cmd = [sys.executable, os.path.join(T.ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--res", "128", "--no-cpu-baseline",
-           "--overlap", "--halo", "exchange"]
+           "--overlap"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=T.ROOT, env=env)
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert out.returncode == 0 and len(lines) == 1, out.stdout[-2000:] + out.stderr[-3000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["ranks_agree"] is True and "overlapped" in d["config"]["partition"]
-    assert d["multi_gpu_variants"]["halo_recompute_fps"] > 0 and d["multi_gpu_variants"]["overlap_off_fps"] > 0
+    assert d["multi_gpu_variants"]["halo_exchange_fps"] > 0 and d["multi_gpu_variants"]["overlap_off_fps"] > 0
+    # the overlapped merge next to the ghost-plane exchange would interleave collectives in rank-dependent order: refused
+    bad = subprocess.run(cmd + ["--halo", "exchange"], capture_output=True, text=True, timeout=300, cwd=T.ROOT, env=env)
+    assert bad.returncode != 0 and "--overlap needs --halo recompute" in bad.stderr + bad.stdout
 
 
 def test_gpu_bench_refuses_more_ranks_than_gpus():

@@ -136,12 +136,13 @@ def test_slab_pipeline_matches_single_volume(tmp_path, world, halo, inputs):
     assert (ranks[0]["norm"][~hit_got] == 0).all() and (ranks[0]["img"][~hit_got] == 0).all()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_exact_slab_raycast_is_bit_identical_to_single_volume(tmp_path, world):
-    """raycast="exact": the march state travels with the ray across the slabs, so depth, normals and shade
-    equal the single-volume RaycastSdf bit for bit on every rank."""
+@pytest.mark.parametrize("world,mode", [(2, "exact"), (3, "exact"), (4, "exact"), (3, "exact_allreduce")])
+def test_exact_slab_raycast_is_bit_identical_to_single_volume(tmp_path, world, mode):
+    """raycast="exact": the march state travels with the ray across the slabs (neighbour exchanges, world + 1 stages, no
+    host check in between), so depth, normals and shade equal the single-volume RaycastSdf bit for bit on every rank;
+    "exact_allreduce" is its cross-check (all-reduce + termination test per round)."""
     import oracle_ops as ops
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), "exchange", "exact"), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), "exchange", mode), nprocs=world, join=True)
     bmin, bmax, near, far = scenes.SCENES["room"]
     ref = FramePipeline(ops, (N, N, N), bmin, bmax, W, H, near=near, far=far)
     for i in range(FRAMES):
@@ -153,7 +154,7 @@ def test_exact_slab_raycast_is_bit_identical_to_single_volume(tmp_path, world):
     assert np.isfinite(ref.ray_d.data).mean() > 0.3
     for r in range(world):
         got = np.load(os.path.join(str(tmp_path), "rank%d.npz" % r))
-        assert 1 < int(got["rounds"]) <= world + 3
+        assert int(got["rounds"]) == world + 1 if mode == "exact" else 1 < int(got["rounds"]) <= world + 3
         assert T.nan_equal(got["depth"], ref.ray_d.data), T.mismatch_report(got["depth"], ref.ray_d.data)
         assert T.nan_equal(got["norm"], ref.ray_n.data), T.mismatch_report(got["norm"], ref.ray_n.data)
         assert T.nan_equal(got["img"], ref.ray_i.data), T.mismatch_report(got["img"], ref.ray_i.data)
