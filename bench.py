@@ -27,7 +27,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 N_ORBIT = 30
-PMC_TRAFFIC_FILE = "profiles/r02_pmc_traffic.json"
+PMC_TRAFFIC_FILE = "profiles/r03_pmc_traffic.json"
 
 
 def parse():
