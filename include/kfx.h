@@ -378,10 +378,14 @@ int kfx_raycast_state_to_images(const kfx_image* depth, const kfx_image* norm, c
  * The reference's march (cu_raycast.cu:58-81) reads eight cells at every step, ~100 dependent HBM misses per ray, most
  * of them in space the TSDF knows to be empty.  A kfx_sdf_summary keeps, per 8 x 8 x 8 cells, the range of the stored
  * values; the tracked SdfFuse maintains it as a by-product (one workgroup owns a summary brick: wave shuffles + LDS, no
- * atomics) and the tracked RaycastSdf takes its steps from it wherever a brick and its +1 neighbours hold one value:
- *   exact numerics: only where the cells are bit-identical (or all NaN) -- the images equal kfx_raycast_sdf bit for bit;
- *   fast numerics:  also where they agree to a relative 1e-5 (observed free space: the running average of +trunc drifts
+ * atomics).  The tracked RaycastSdf builds two-bit class tables from it (per 16^3 and 32^3 cells: every cell holds trunc_dist
+ * / every cell is NaN / every cell is one or the other), stages them in LDS and takes the reference's own steps through such
+ * entries without reading the volume:
+ *   exact numerics: only cells bit-equal to trunc_dist (or NaN) qualify -- the images equal kfx_raycast_sdf bit for bit;
+ *   fast numerics:  also cells within a relative 1e-5 of it (observed free space: the running average of +trunc drifts
  *                   by a few ulp per frame) -- depth within the fast-mode tolerance of the exact march.
+ * Where less than a quarter of the volume qualifies (the count the last table build published; KFX_RAYCAST_SUMMARY=1 / -1
+ * overrides) the tracked call runs the plain march: same images.
  * The summary describes the volume it was created for; views of that volume (SubBoundingVolume) may be passed to the
  * tracked calls.  Anything else that writes the volume (copies, kfx_sdf_sphere, untracked kfx_sdf_fuse) must be followed
  * by kfx_sdf_summary_invalidate.  A tracked SdfFuse whose view does not start on multiples of 8 cells, or that takes the
