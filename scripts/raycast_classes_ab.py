@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """RaycastSdf at 512^3 / 640x480 after a few tracked frames: plain march against the class-table march (environment knobs are
-read once per process, so run it once per configuration: KFX_RAYCAST_CLASSES, KFX_RAYCAST_CLASS_KB).
+read once per process, so run it once per configuration: KFX_RAYCAST_SUMMARY, KFX_RAYCAST_CLASS_KB).
 Prints kernel times (median of 20 launches, HIP events), tracked / untracked SdfFuse times and the image differences."""
 import os
 import sys
@@ -13,7 +13,7 @@ from kangaroo_amd import roo, scenes  # noqa: E402
 
 N, w, h = 512, 640, 480
 frames = int(os.environ.get("AB_FRAMES", "8"))
-tag = " ".join("%s=%s" % (k, os.environ[k]) for k in ("KFX_RAYCAST_CLASSES", "KFX_RAYCAST_CLASS_KB") if k in os.environ) or "defaults"
+tag = " ".join("%s=%s" % (k, os.environ[k]) for k in ("KFX_RAYCAST_SUMMARY", "KFX_RAYCAST_CLASS_KB") if k in os.environ) or "defaults"
 for scene in sys.argv[1:] or ("full", "room"):
     bmin, bmax, near, far = scenes.SCENES[scene]
     K = scenes.intrinsics(w, h)
