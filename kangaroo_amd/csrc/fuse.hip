@@ -224,6 +224,29 @@ __device__ __forceinline__ Obs finish_shared(const FuseParams& p, const V3 Pc, f
     return o;
 }
 
+// finish_shared with the x-differences of the bilinear cell taken from the tile (DXT kernels): d0 = c01 - c00 and d1 = c11 - c10
+// are the same single roundings whoever computes them, and every voxel that samples the cell uses them, so they are formed
+// once per texel while staging; lerp(a, b, fx) = a + fx * (b - a) becomes a + fx * d: two operations instead of three,
+// eight fewer per voxel, same bits.
+__device__ __forceinline__ Obs finish_shared_dx(const FuseParams& p, const V3 Pc, float yz, float fx, float fy, const float4 c00, const float4 d0,
+                                                const float4 c10, const float4 d1)
+{
+    Obs o;
+    const float md = lerp(c00.w + fx * d0.w, c10.w + fx * d1.w, fy);
+    V3 mdn;
+    mdn.x = lerp(c00.x + fx * d0.x, c10.x + fx * d1.x, fy);
+    mdn.y = lerp(c00.y + fx * d0.y, c10.y + fx * d1.y, fy);
+    mdn.z = lerp(c00.z + fx * d0.z, c10.z + fx * d1.z, fy);
+    const float nlen = -sqrt_core(dot(Pc, Pc));
+    const float costheta = div_core(dot(mdn, Pc), nlen, rcp_nr(nlen));
+    const float w = div_core(costheta, Pc.z, yz); // costheta * 1.0f / Pc.z
+    const float sd = costheta * (md - Pc.z);
+    o.ok = ((int)!(sd <= -p.trunc) & (int)isfinite(md) & (int)isfinite(w) & (int)(costheta > p.mincos)) != 0;
+    o.val = __builtin_amdgcn_fmed3f(sd, -p.trunc, p.trunc);
+    o.w = w;
+    return o;
+}
+
 __device__ __forceinline__ int med3_i32(int x, int lo, int hi) // clamp for lo <= hi
 {
     int r;
@@ -396,9 +419,12 @@ __global__ __launch_bounds__(256) void k_sdf_fuse(const FuseParams p)
 // Register budget (launch bounds): fast, ZU = 2: the 64 VGPRs of 8 waves per SIMD -- what the 1216-texel tile makes room
 // for; without the bound hipcc's allocation moves between 64 and 78 on unrelated edits.  Bit-exact, untracked: the 80 of 6
 // waves; one wave less costs 6 % (measured when an edit took it from 78 to 81).  scripts/check_fuse_codegen.py checks both.
-template <bool FAST, int ZU, typename CELL, int LX = 32, int WY = 4, int ZC = FUSE_ZC, bool TRACK = false>
+// DXT (bit-exact kernels): a texel is staged as {texel, difference to its right neighbour} -- 32 bytes, so `cap_px` texels take
+// twice the LDS; chosen by the host for ranges whose rectangles fit half the tile (finish_shared_dx).
+template <bool FAST, int ZU, typename CELL, int LX = 32, int WY = 4, int ZC = FUSE_ZC, bool TRACK = false, bool DXT = false>
 __global__ __launch_bounds__(256, (FAST && ZU == 2) ? 8 : ((!FAST && !TRACK) ? 6 : 1)) void k_sdf_fuse_tiled(const FuseParams p_arg, const int cap_px)
 {
+    static_assert(!DXT || (!FAST && !TRACK), "the difference tile belongs to the bit-exact, untracked kernels");
     // the uniforms of the per-voxel arithmetic live in vector registers (in_vgpr, kfx_device.h): an SGPR operand makes a
     // 3.3-cycle instruction a 5-cycle one
     FuseParams p = p_arg;
@@ -505,6 +531,9 @@ __global__ __launch_bounds__(256, (FAST && ZU == 2) ? 8 : ((!FAST && !TRACK) ? 6
         tx0 = (int)fx0; ty0 = (int)fy0;
         tw = (int)fx1 - tx0 + 1; th = (int)fy1 - ty0 + 1;
         use_tile = tw > 1 && th > 1 && tw * th <= cap_px;
+        // DXT: only the shared-reciprocal loop reads the {texel, difference} layout; a brick that fails its operand-range test
+        // (or KFX_FUSE_EXACT_SHARED=0) gathers from global memory
+        if constexpr (DXT) use_tile = use_tile && p.exact_shared && zmin >= 0x1p-20f && cmax <= 0x1p20f;
     }
     // Interior bricks: the rectangle of projections lies inside the band 2 <= pu < w - 2, 2 <= pv < h - 2 by a margin far
     // above the rounding of a projection (a voxel of an inner slice projects between the projections of its column's two
@@ -558,7 +587,7 @@ __global__ __launch_bounds__(256, (FAST && ZU == 2) ? 8 : ((!FAST && !TRACK) ? 6
                 for (int c = lane; c < tw; c += 64) {
                     const float4 n = nrow[c];
                     const float d = drow[c];
-                    s_tile[r * tw + c] = make_float4(n.x, n.y, n.z, d);
+                    s_tile[(r * tw + c) * (DXT ? 2 : 1)] = make_float4(n.x, n.y, n.z, d);
                     dmax = fmaxf(dmax, d);
                 }
             }
@@ -577,6 +606,16 @@ __global__ __launch_bounds__(256, (FAST && ZU == 2) ? 8 : ((!FAST && !TRACK) ? 6
         dmax = fmaxf(fmaxf(s_dmax[0], s_dmax[1]), fmaxf(s_dmax[2], s_dmax[3]));
         const float bound = -(p.trunc / p.mincos) * 1.001f;
         if (dmax + fabsf(dmax) * 1e-5f - zmin < bound) return; // also when every texel is NaN (dmax = -inf)
+    }
+    if constexpr (DXT) {   // (workgroup-uniform control flow up to here: every thread reaches the barrier)
+        if (use_tile) {
+            const int ntex = tw * th;
+            for (int t = tid; t < ntex; t += 256) {
+                const float4 a = s_tile[2 * t], b = s_tile[2 * min(t + 1, ntex - 1)]; // (the last column's difference is never read)
+                s_tile[2 * t + 1] = make_float4(b.x - a.x, b.y - a.y, b.z - a.z, b.w - a.w);
+            }
+        }
+        __syncthreads();
     }
     auto march = [&]() {
         // TRACK kernels keep every lane in the march (`live` only gates the updates): the per-group reductions below run in
@@ -696,17 +735,27 @@ __global__ __launch_bounds__(256, (FAST && ZU == 2) ? 8 : ((!FAST && !TRACK) ? 6
                         const float fix = floorf(pu), fiy = floorf(pv);
                         const int rx = (int)fix - tx0v, ry = (int)fiy - ty0v;
                         if constexpr (INTERIOR && !TRACK) { // every lane samples inside the image band and the rectangle
-                            const float4* t = s_tile + (ry * tw + rx);
-                            Corners c;
-                            c.c00 = t[0]; c.c01 = t[1]; c.c10 = t[tw]; c.c11 = t[tw + 1];
-                            o[v] = finish_shared(p, Pc, yz, pu - fix, pv - fiy, c);
+                            if constexpr (DXT) {
+                                const float4* t = s_tile + 2 * (ry * tw + rx);
+                                o[v] = finish_shared_dx(p, Pc, yz, pu - fix, pv - fiy, t[0], t[1], t[2 * tw], t[2 * tw + 1]);
+                            } else {
+                                const float4* t = s_tile + (ry * tw + rx);
+                                Corners c;
+                                c.c00 = t[0]; c.c01 = t[1]; c.c10 = t[tw]; c.c11 = t[tw + 1];
+                                o[v] = finish_shared(p, Pc, yz, pu - fix, pv - fiy, c);
+                            }
                         } else {
                             const bool inb = INTERIOR ? upd : (upd && in_bounds(p, pu, pv));
                             const bool inside = INTERIOR || ((unsigned)rx <= (unsigned)cxmax && (unsigned)ry <= (unsigned)cymax);
+                            if constexpr (DXT) {
+                                const float4* t = s_tile + 2 * (med3_i32(ry, 0, cymax) * tw + med3_i32(rx, 0, cxmax));
+                                o[v] = finish_shared_dx(p, Pc, yz, pu - fix, pv - fiy, t[0], t[1], t[2 * tw], t[2 * tw + 1]);
+                            } else {
                             const float4* t = s_tile + (med3_i32(ry, 0, cymax) * tw + med3_i32(rx, 0, cxmax));
                             Corners c;
                             c.c00 = t[0]; c.c01 = t[1]; c.c10 = t[tw]; c.c11 = t[tw + 1];
                             o[v] = finish_shared(p, Pc, yz, pu - fix, pv - fiy, c);
+                            }
                             o[v].ok = ((int)o[v].ok & (int)inb & (int)inside) != 0;
                             stray |= ((int)inb & (int)!inside) != 0;
                         }
@@ -1468,20 +1517,25 @@ static int tile_cap(const FuseParams& p, const Pose& T, const Intr& K, int z0, i
 // 512^3, 1280x960, 2-4 m (r = 2.2 ... 1.1; scripts/c3_brick_ab.py, fast / exact): 64 x 8 x 16 everywhere 0.591 / 0.799 ms,
 // 32 x 8 x 16 everywhere 0.537 / 0.732 ms, 32 x 8 x 8 0.586 / 0.749 ms (its staging and rectangle prologue are amortised
 // over half the slices); at 640x480 (r <= 1.05) the narrow brick costs 0-3 %.
-struct TilePlan { int small_brick, cap; };
+// dxt: the bit-exact kernel with {texel, x-difference} tiles (finish_shared_dx): 32 bytes per texel, so it is used where the
+// rectangle -- about (73 r + 5) x (14.7 r + 5) texels -- fits 768 texels, the 24 KiB that keep six workgroups on a CU
+// (r <= 0.64; KFX_FUSE_DXT=0 switches it off, a positive value sets the limit in hundredths).
+struct TilePlan { int small_brick, cap, dxt; };
 static TilePlan tile_plan(const FuseParams& p, const Pose& T, const Intr& K, int z0, int z1, int brick_env, bool fast)
 {
     const float r = px_per_voxel(p, T, K, z0, z1);
     const int small_brick = brick_env < 0 ? (r > 1.3f ? 1 : 0) : (brick_env != 0);
-    if (!small_brick) return TilePlan{0, tile_cap(p, T, K, z0, z1, fast)};
+    static const float r_dxt = [] { const char* e = getenv("KFX_FUSE_DXT"); return e ? 0.01f * (float)atoi(e) : 0.64f; }();
+    if (!small_brick && !fast && r_dxt > 0.f && r > 0.f && !(r > r_dxt)) return TilePlan{0, 768, 1};
+    if (!small_brick) return TilePlan{0, tile_cap(p, T, K, z0, z1, fast), 0};
     // three quarters of the worst-case rectangle: most bricks are nearer the optical axis than the image corner, and a
     // brick that does not fit still works (it gathers from global memory); measured at 1280x960 with one capacity for the
     // whole volume: 1984 texels 0.525 ms, 2496 0.543 ms, 3328 0.577 ms, per-range worst case 0.538 ms (fast mode)
     const float want = 0.75f * (r * 41.f + 5.f) * (r * 14.7f + 5.f);
     const int caps[] = {1216, 1600, 1984, 2496, 3328};
     for (int c : caps)
-        if (want <= (float)c) return TilePlan{small_brick, c};
-    return TilePlan{small_brick, 3328};
+        if (want <= (float)c) return TilePlan{small_brick, c, 0};
+    return TilePlan{small_brick, 3328, 0};
 }
 
 template <typename CELL>
@@ -1536,19 +1590,31 @@ static int fuse_launch(const kfx_volume* vol, const kfx_image* depth, const kfx_
         static const int brick_env = [] { const char* e = getenv("KFX_FUSE_BRICK"); return e ? atoi(e) : -1; }();
         auto plan_for = [&](int z0, int z1) -> TilePlan {
             TilePlan t = tile_plan(p, p.T, p.K, z0, z1, brick_env, fast);
-            if (cap_env) t.cap = cap_env;
+            if (track || CELL::BYTES != 8) { // the difference tile exists for the untracked fp32-cell kernel only
+                if (t.dxt) t = TilePlan{0, tile_cap(p, p.T, p.K, z0, z1, fast), 0};
+            }
+            if (cap_env) { t.cap = cap_env; t.dxt = 0; }
             return t;
         };
         const int zstep = 64;
+        // the difference tile only where it costs no extra launch: every range of the view must want it (S_room at 512^3,
+        // whose far third qualifies, lost 4 % to the third launch boundary; S_full gains 3 %)
+        bool all_dxt = true;
+        for (int z = 0; z < p.Z; z += zstep) all_dxt = all_dxt && plan_for(z, z + zstep < p.Z ? z + zstep : p.Z).dxt != 0;
+        auto plan_of = [&](int za, int zb) -> TilePlan {
+            TilePlan t = plan_for(za, zb);
+            if (t.dxt && !all_dxt) { t = TilePlan{0, tile_cap(p, p.T, p.K, za, zb, fast), 0}; if (cap_env) t.cap = cap_env; }
+            return t;
+        };
         int z0 = 0;
         while (z0 < p.Z) {
             int z1 = z0 + zstep < p.Z ? z0 + zstep : p.Z;
-            const TilePlan plan = plan_for(z0, z1);
+            const TilePlan plan = plan_of(z0, z1);
             const int cap_px = plan.cap;
             while (z1 < p.Z) { // extend over following ranges that want the same brick and capacity
                 const int z2 = z1 + zstep < p.Z ? z1 + zstep : p.Z;
-                const TilePlan nxt = plan_for(z1, z2);
-                if (nxt.cap != cap_px || nxt.small_brick != plan.small_brick) break;
+                const TilePlan nxt = plan_of(z1, z2);
+                if (nxt.cap != cap_px || nxt.small_brick != plan.small_brick || nxt.dxt != plan.dxt) break;
                 z1 = z2;
             }
             FuseParams q = p;
@@ -1556,7 +1622,7 @@ static int fuse_launch(const kfx_volume* vol, const kfx_image* depth, const kfx_
             q.zoff = p.zoff + z0;
             q.zoff_local = z0;
             q.Z = z1 - z0;
-            const size_t lds = (size_t)cap_px * sizeof(float4);
+            const size_t lds = (size_t)cap_px * sizeof(float4) * (plan.dxt ? 2 : 1);
             if constexpr (CELL::BYTES == 8) {
                 if (track) { // the same kernels with the summary epilogue (ZU = 2 fast, 1 exact)
                     const dim3 gw(ceil_div(q.X, TB_X), ceil_div(q.Y, TB_Y), ceil_div(q.Z, FUSE_ZC)), gn(ceil_div(q.X, 32), ceil_div(q.Y, 8), ceil_div(q.Z, 16));
@@ -1582,6 +1648,7 @@ static int fuse_launch(const kfx_volume* vol, const kfx_image* depth, const kfx_
                 else if (fast && zu == 2) hipLaunchKernelGGL((k_sdf_fuse_tiled<true, 2, CELL>), grid, dim3(256), lds, s, q, cap_px);
                 else if (fast) hipLaunchKernelGGL((k_sdf_fuse_tiled<true, 1, CELL>), grid, dim3(256), lds, s, q, cap_px);
                 else if (zu == 2) hipLaunchKernelGGL((k_sdf_fuse_tiled<false, 2, CELL>), grid, dim3(256), lds, s, q, cap_px);
+                else if (plan.dxt) hipLaunchKernelGGL((k_sdf_fuse_tiled<false, 1, CELL, 32, 4, FUSE_ZC, false, true>), grid, dim3(256), lds, s, q, cap_px);
                 else hipLaunchKernelGGL((k_sdf_fuse_tiled<false, 1, CELL>), grid, dim3(256), lds, s, q, cap_px);
             }
             z0 = z1;
