@@ -55,10 +55,12 @@ def parse():
                     help="N > 1: every rank preprocesses the frame itself, or rank 0 does and broadcasts the filtered depth + normal map")
     ap.add_argument("--overlap", action="store_true",
                     help="N > 1, composite raycast: merge frame k's images on a second stream under frame k+1's preprocess + SdfFuse")
-    ap.add_argument("--summary", action="store_true",
-                    help="fast math, 1 GPU: time the headline with the brick summary (kfx_sdf_summary: SdfFuse keeps value ranges per "
-                         "8^3 cells, RaycastSdf steps through uniformly free space without reading the volume).  Off by default: "
-                         "the tracking costs SdfFuse ~5 %; the default run reports the variant beside the headline instead")
+    ap.add_argument("--summary", nargs="?", const="on", default="auto", choices=["auto", "on", "off"],
+                    help="fast math, 1 GPU: the brick summary (kfx_sdf_summary: SdfFuse keeps value ranges per 8^3 cells, RaycastSdf "
+                         "marches through class tables built from them and crosses free / never-observed space without reading the "
+                         "volume).  auto (default): FramePipeline(track='auto') times both marches on frames 8-19 of the stream and "
+                         "keeps the faster (the table march wins in S_full, the plain one in S_room); on / off force it.  The line "
+                         "reports the other variant beside the headline")
     ap.add_argument("--prime", type=int, default=150,
                     help="untimed frames of the same stream run before the W warm-up steps, so that the timed steps see a volume in "
                          "steady state and settled clocks whatever W is (0 = start from the freshly reset volume)")
@@ -192,8 +194,8 @@ def main():
         # fast numerics: SdfFuse keeps a brick summary of the volume as a by-product and RaycastSdf takes its steps through
         # uniformly free / never-observed regions from it (same volume bits; depth within the fast-mode tolerance of the plain
         # march, tests/test_gpu_summary.py).  Exact numerics gain nothing from it (averaged +trunc values are not bit-uniform).
-        use_summary = args.math == "fast" and args.summary
-        pipe = FramePipeline(roo, (N, N, N), bmin, bmax, w, h, K=K, near=near, far=far, track=use_summary)
+        policy = args.summary if args.math == "fast" else "off"
+        pipe = FramePipeline(roo, (N, N, N), bmin, bmax, w, h, K=K, near=near, far=far, track={"auto": "auto", "on": True, "off": False}[policy])
 
     # synthetic depth stream, uploaded once: the timed region starts with inputs resident in HBM
     poses = [scenes.orbit_pose(i, N_ORBIT) for i in range(N_ORBIT)]
@@ -217,15 +219,27 @@ def main():
         pipe.preprocess(frames[i])
         n_updated.append(roo.SdfFuseCount(pipe.vol, pipe.filtered, pipe.normals, scenes.se3_inverse(poses[i]), K,
                                           pipe.trunc, pipe.mincostheta, full_extent=distributed))
-    for i in range(max(args.prime, 0)):   # the stream so far: whole orbits before the W warm-up steps
-        pipe.step(poses[i % N_ORBIT], frames[i % N_ORBIT])
-    for i in range(args.warmup):
-        pipe.step(poses[i % N_ORBIT], frames[i % N_ORBIT])
-
+    # Everything the host has to prepare comes BEFORE the priming frames, so that the GPU runs the stream -- priming, warm-up,
+    # timed steps -- with nothing but the contract's barrier + synchronize in between: an idle gap of tens of milliseconds
+    # (event creation, garbage collection) lets the clocks drop, and in the frame loops that run against the power limit the
+    # controller's overshoot afterwards stretches the next ~30 frames by up to 25 % (measured with KFX_BENCH_DUMP=1: 0.36 ->
+    # 0.46 -> 0.37 ms per tracked SdfFuse) -- the whole of a 20-step run whose W = 5 warm-up steps cannot absorb it.
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
     import gc
     gc.collect()
     gc.disable()   # a generation-2 collection inside the timed region stalls the launching thread for tens of ms (seen at --steps 200)
+    for i in range(max(args.prime, 0)):   # the stream so far: whole orbits before the W warm-up steps
+        pipe.step(poses[i % N_ORBIT], frames[i % N_ORBIT])
+    if not distributed:   # track="auto" decides on frames 8-19 of the stream: before the timed region, whatever --prime / --warmup are
+        extra = 0
+        while pipe.track_policy == "auto" and pipe.track_decision is None and extra < 256:
+            pipe.step(poses[extra % N_ORBIT], frames[extra % N_ORBIT])
+            torch.cuda.synchronize()
+            extra += 1
+    use_summary = bool(getattr(pipe, "track", False))   # what the timed frames run with
+
+    for i in range(args.warmup):
+        pipe.step(poses[i % N_ORBIT], frames[i % N_ORBIT])
     sync_all()
     t0 = time.perf_counter()
     for s in range(args.steps):
@@ -249,6 +263,9 @@ def main():
     fuse_ms = [ev[s][0].elapsed_time(ev[s][1]) for s in range(args.steps)]
     ray_ms = [ev[s][2].elapsed_time(ev[s][3]) for s in range(args.steps)]
     idx = [(args.warmup + s) % N_ORBIT for s in range(args.steps)]
+    if os.environ.get("KFX_BENCH_DUMP") and rank == 0:   # per-step kernel windows of the timed region (transients)
+        print("fuse_ms " + " ".join("%.3f" % v for v in fuse_ms[:64]), file=sys.stderr)
+        print("ray_ms " + " ".join("%.3f" % v for v in ray_ms[:64]), file=sys.stderr)
     alg_bytes = [16.0 * n_updated[i] + 20.0 * w * h for i in idx]
     fuse_avg_ms = float(np.mean(fuse_ms))
     bytes_avg = float(np.mean(alg_bytes))
@@ -331,6 +348,7 @@ def main():
     if getattr(pipe, "track", False):   # the other mode is timed on the plain kernels; the summary no longer describes the volume
         pipe.track = False
         pipe.summary.invalidate()
+    pipe._cal = None
     n_other = min(args.steps, 2 * N_ORBIT)   # whole orbits: launch times depend on the pose
     ev2 = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_other)]
     for s in range(2 * N_ORBIT):   # untimed: the first launches after the mode switch run on cold instruction caches / a settling clock
@@ -396,10 +414,40 @@ def main():
 
     # 1 GPU, fast numerics: the same frames with the brick summary switched on (tracked SdfFuse + RaycastSdf that steps through
     # uniform regions without reading the volume), reported beside the headline (not part of `value`)
-    summary_variant = None
+    summary_variant, plain_variant = None, None
+    if not distributed and args.math == "fast" and use_summary:
+        try:   # the headline ran through the tables: the same frames with the plain kernels beside it
+            pipe.track = False
+            n_pv = min(args.steps, 2 * N_ORBIT)
+            for s in range(N_ORBIT):
+                pipe.step(poses[s % N_ORBIT], frames[s % N_ORBIT])
+            evp = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(n_pv)]
+            sync_all()
+            t_pv = time.perf_counter()
+            for s in range(n_pv):
+                i = (args.warmup + s) % N_ORBIT
+                pipe.preprocess(frames[i])
+                evp[s][0].record()
+                pipe.fuse(poses[i])
+                evp[s][1].record()
+                evp[s][2].record()
+                pipe.raycast(poses[i])
+                evp[s][3].record()
+            sync_all()
+            dt_pv = time.perf_counter() - t_pv
+            pv_fuse = float(np.mean([e[0].elapsed_time(e[1]) for e in evp]))
+            pv_bytes = float(np.mean([16.0 * n_updated[(args.warmup + s) % N_ORBIT] + 20.0 * w * h for s in range(n_pv)]))
+            plain_variant = {"frames_per_sec": round(n_pv / dt_pv, 1), "steps": n_pv, "sdf_fuse_ms": round(pv_fuse, 5),
+                             "sdf_fuse_frac_of_peak": round(pv_bytes / (pv_fuse * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                             "raycast_sdf_ms": round(float(np.mean([e[2].elapsed_time(e[3]) for e in evp])), 5),
+                             "note": "kfx_sdf_fuse + kfx_raycast_sdf (no summary), same frames (bench.py --summary off makes it the headline)"}
+        except Exception as e:   # noqa: BLE001
+            plain_variant = {"error": repr(e)[:300]}
     if not distributed and args.math == "fast" and not use_summary and hasattr(roo, "SdfSummary"):
         try:   # a reported extra must never cost the headline line
             pipe.track = True
+            if pipe.summary is None:
+                pipe.summary = roo.SdfSummary(pipe.vol)
             pipe.reset()                      # SdfReset of volume and summary together
             n_sv = min(args.steps, 2 * N_ORBIT)
             for s in range(2 * N_ORBIT):   # untimed: the summary of a freshly reset volume settles within the first orbit
@@ -422,7 +470,7 @@ def main():
             summary_variant = {"frames_per_sec": round(n_sv / dt_sv, 1), "steps": n_sv,
                                "sdf_fuse_tracked_ms": round(float(np.mean([e[0].elapsed_time(e[1]) for e in ev3])), 5),
                                "raycast_sdf_tracked_ms": round(float(np.mean([e[2].elapsed_time(e[3]) for e in ev3])), 5),
-                               "note": "kfx_sdf_fuse_tracked + kfx_raycast_sdf_tracked on a freshly reset volume, same frames (bench.py --summary makes it the headline)"}
+                               "note": "kfx_sdf_fuse_tracked + kfx_raycast_sdf_tracked on a freshly reset volume, same frames (bench.py --summary on makes it the headline)"}
             pipe.track = False
             pipe.summary.invalidate()
         except Exception as e:   # noqa: BLE001
@@ -483,7 +531,7 @@ def main():
         try:
             with open(os.path.join(ROOT, PMC_TRAFFIC_FILE)) as fh:
                 tj = json.load(fh)
-            traffic = tj.get("%s_%s" % (scene, args.math), {}).get("traffic_bytes")
+            traffic = tj.get("%s_%s%s" % (scene, args.math, "_tracked" if use_summary else ""), {}).get("traffic_bytes")
             if traffic is not None:
                 traffic_source = "%s (separate rocprofv3 --pmc passes of this command, kernels of commit %s; not measured in this run)" % (
                     PMC_TRAFFIC_FILE, tj.get("_commit", "?"))
@@ -514,8 +562,10 @@ def main():
                 "volume": [N, N, N], "image": [w, h], "scene": scene,
                 "backend": os.environ.get("KFX_BENCH_BACKEND", "nccl (RCCL)") if distributed else None,
                 "ranks_agree": ranks_agree,
-                "raycast": ("brick summary: steps through uniform regions taken without reading the volume (kfx_raycast_sdf_tracked)"
+                "raycast": ("march through the class tables of the brick summary, kept current by the tracked SdfFuse (kfx_sdf_fuse_tracked + kfx_raycast_sdf_tracked)"
                             if (not distributed and use_summary) else "plain march (kfx_raycast_sdf)"),
+                "summary_policy": None if distributed else {"requested": args.summary if args.math == "fast" else "off (exact numerics)",
+                                                            "decision": getattr(pipe, "track_decision", None)},
                 "partition": ("z-slabs x%d, inputs %s, ghost planes %s%s, raycast %s" % (n_gpus, "preprocessed by every rank" if args.inputs == "replicate" else "preprocessed by rank 0 and broadcast", args.halo, ", merge overlapped with the next frame" if args.overlap else "", {"composite": "composite = all_reduce(MIN key) + all_reduce(SUM payload)", "exact": "exact = march state handed from slab to slab: world + 1 stages, neighbour send/recv between them, one all_reduce of the finalised pixels at the end", "exact_allreduce": "exact (cross-check) = one SUM all_reduce of the march state + a host-side termination test per round"}[args.raycast]))
                              if distributed else "single volume",
                 "math": {"fast": "fast (fp32 rcp/rsq + FMA: the reference's own -use_fast_math regime; whole chain against the exact oracle at this size, "
@@ -524,7 +574,8 @@ def main():
                          "exact": "exact (IEEE fp32, no FMA contraction, reference operation order; bit-identical to the oracle)"}[args.math],
             },
             "roofline": {
-                "kernel": "k_sdf_fuse_tiled<%s> (SdfFuse, %s math)" % ("true" if args.math == "fast" else "false", args.math),
+                "kernel": "k_sdf_fuse_tiled<%s%s> (SdfFuse, %s math%s)" % ("true" if args.math == "fast" else "false", ", TRACK" if use_summary else "", args.math,
+                                                                            ", keeping the brick summary current" if use_summary else ""),
                 "bound": "hbm",
                 "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS,
@@ -560,6 +611,8 @@ def main():
             out["multi_gpu_variants"] = variants
         if summary_variant is not None:
             out["brick_summary_variant"] = summary_variant
+        if plain_variant is not None:
+            out["plain_variant"] = plain_variant
         if not args.no_cpu_baseline and n_gpus == 1:
             try:
                 out["cpu_baseline"] = cpu_baseline(args, scene, args.cpu_frames)

@@ -281,3 +281,37 @@ print("ok")
     env.pop("KFX_RAYCAST_SUMMARY", None)
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0 and "ok" in out.stdout, out.stdout + out.stderr
+
+
+@pytest.mark.parametrize("scene", ["full", "room"])
+def test_gpu_frame_pipeline_auto_policy(roo, scene):
+    """FramePipeline(track="auto"): starts with the summary, times both marches on frames 8-19 of the stream (device events,
+    no synchronisation), decides once and carries on with the faster pair of kernels.  Whatever it decides, the volume equals
+    the untracked pipeline's bit for bit and the images stay within the fast-mode tolerance of the plain march."""
+    import torch
+    from kangaroo_amd.pipeline import FramePipeline
+    N, w, h = 128, 320, 240
+    bmin, bmax, near, far = scenes.SCENES[scene]
+    prev = roo.set_math_mode("fast")
+    try:
+        auto = FramePipeline(roo, (N, N, N), bmin, bmax, w, h, near=near, far=far, track="auto")
+        ref = FramePipeline(roo, (N, N, N), bmin, bmax, w, h, near=near, far=far, track=False)
+        assert auto.track_policy == "auto" and auto.track and auto.track_decision is None
+        for i in range(48):
+            T_wc = scenes.orbit_pose(i % 30, 30)
+            raw = T.upload_image(roo, scenes.render_depth(scene, w, h, T_wc, auto.K))
+            auto.step(T_wc, raw)
+            ref.step(T_wc, raw)
+            if i >= 30:
+                torch.cuda.synchronize()   # (the events of frames 8-19 have completed by now: the next frame decides)
+        assert auto.track_decision is not None and auto._cal is None, "no decision after 48 frames"
+        assert auto.track == auto.track_decision["chosen"].startswith("table march")
+        assert (auto.summary is not None) == auto.track
+        assert T.nan_equal(auto.vol.MemcpyToHost(), ref.vol.MemcpyToHost())
+        da, dr = auto.ray_d.MemcpyToHost(), ref.ray_d.MemcpyToHost()
+        ha, hr = np.isfinite(da), np.isfinite(dr)
+        assert (ha != hr).sum() <= max(3, 2e-4 * w * h)
+        both = ha & hr
+        assert both.sum() > 0.03 * w * h and np.abs(da[both] - dr[both]).max() < 1e-4
+    finally:
+        roo.set_math_mode(prev)
