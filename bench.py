@@ -55,12 +55,13 @@ def parse():
                     help="N > 1: every rank preprocesses the frame itself, or rank 0 does and broadcasts the filtered depth + normal map")
     ap.add_argument("--overlap", action="store_true",
                     help="N > 1, composite raycast: merge frame k's images on a second stream under frame k+1's preprocess + SdfFuse")
-    ap.add_argument("--summary", nargs="?", const="on", default="auto", choices=["auto", "on", "off"],
+    ap.add_argument("--summary", nargs="?", const="on", default="off", choices=["auto", "on", "off"],
                     help="fast math, 1 GPU: the brick summary (kfx_sdf_summary: SdfFuse keeps value ranges per 8^3 cells, RaycastSdf "
                          "marches through class tables built from them and crosses free / never-observed space without reading the "
-                         "volume).  auto (default): FramePipeline(track='auto') times both marches on frames 8-19 of the stream and "
-                         "keeps the faster (the table march wins in S_full, the plain one in S_room); on / off force it.  The line "
-                         "reports the other variant beside the headline")
+                         "volume).  off (default): the plain kernels -- the line's roofline is that of the untracked SdfFuse; on: "
+                         "always; auto: FramePipeline(track='auto') times both marches on frames 8-19 of the stream and keeps the "
+                         "faster (the table march wins in S_full: +15 %% frames/s, the plain one in S_room).  The line reports the "
+                         "other variant beside the headline")
     ap.add_argument("--prime", type=int, default=150,
                     help="untimed frames of the same stream run before the W warm-up steps, so that the timed steps see a volume in "
                          "steady state and settled clocks whatever W is (0 = start from the freshly reset volume)")

@@ -108,8 +108,10 @@ class FramePipeline:
         c = self._cal
         if c is None or c["frame"] < self.CAL_FIRST + self.CAL_FRAMES + 2 or len(c["ray"]) < self.CAL_FRAMES:
             return
-        if not all(e.query() for evs in c["fuse"] + c["ray"] for e in evs):
-            return   # still running: look again next frame
+        # the last event of the last timed frame (everything is on one stream: the earlier ones completed before it); one
+        # query every fourth frame -- polling all 60 events every frame makes the launching thread slower than the GPU
+        if c["frame"] % 4 or not c["ray"][-1][2].query():
+            return   # still running: look again later
         fuse = float(np.median([a.elapsed_time(b) for a, b in c["fuse"]]))
         tracked = float(np.median([a.elapsed_time(b) for a, b, _ in c["ray"]]))
         plain = float(np.median([b.elapsed_time(d) for _, b, d in c["ray"]]))

@@ -315,3 +315,35 @@ def test_gpu_frame_pipeline_auto_policy(roo, scene):
         assert both.sum() > 0.03 * w * h and np.abs(da[both] - dr[both]).max() < 1e-4
     finally:
         roo.set_math_mode(prev)
+
+
+@pytest.mark.parametrize("trunc_factor", [0.4, 1.0, 6.0])
+def test_gpu_table_march_with_unusual_truncation(roo, trunc_factor):
+    """trunc_dist below the voxel size (the reference's step for a +trunc sample is then min_delta, not trunc: class 3 --
+    "NaN or +trunc" -- must not be skipped), equal to it, and several voxels wide; and a raycast whose trunc_dist differs from
+    the one the volume was fused with (no entry holds the raycast's value: only NaN space is skipped).  Exact numerics:
+    images through the tables = images of the plain march, bit for bit."""
+    N, w, h = 96, 200, 150
+    scene = "room"
+    bmin, bmax, near, far = scenes.SCENES[scene]
+    K = scenes.intrinsics(w, h)
+    voxel = (bmax[0] - bmin[0]) / (N - 1)
+    tr = float(np.float32(trunc_factor * voxel))
+    vol = roo.BoundedVolume(N, N, N, bmin, bmax)
+    summ = roo.SdfSummary(vol)
+    roo.SdfReset(vol, float("nan"), summary=summ)
+    f, vbo, nrm = roo.Image(w, h), roo.Image(w, h, "f32x4"), roo.Image(w, h, "f32x4")
+    for i in range(2):
+        T_wc = scenes.orbit_pose(i, 30)
+        roo.BilateralFilter(f, T.upload_image(roo, scenes.render_depth(scene, w, h, T_wc, K)), **scenes.BILATERAL)
+        roo.DepthToVbo(vbo, f, K)
+        roo.NormalsFromVbo(nrm, vbo)
+        roo.SdfFuse(vol, f, nrm, scenes.se3_inverse(T_wc), K, tr, scenes.MAX_W, scenes.MIN_COS_THETA, summary=summ)
+        for ray_tr in (tr, float(np.float32(1.7 * tr))):
+            a = [roo.Image(w, h), roo.Image(w, h, "f32x4"), roo.Image(w, h)]
+            b = [roo.Image(w, h), roo.Image(w, h, "f32x4"), roo.Image(w, h)]
+            roo.RaycastSdf(*a, vol, T_wc, K, near, far, ray_tr, True)
+            roo.RaycastSdf(*b, vol, T_wc, K, near, far, ray_tr, True, summary=summ)
+            for x, y in zip(a, b):
+                assert T.nan_equal(x.MemcpyToHost(), y.MemcpyToHost()), (trunc_factor, i, ray_tr, T.mismatch_report(x.MemcpyToHost(), y.MemcpyToHost()))
+            assert np.isfinite(a[0].MemcpyToHost()).sum() > (100 if trunc_factor < 1 else 0.02 * w * h)   # (a band thinner than the minimum step is mostly stepped over)
