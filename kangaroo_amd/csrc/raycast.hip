@@ -126,16 +126,21 @@ __device__ __forceinline__ float raycast_pixel(const RayParams& p, const ColorGe
 
 
 // ---------------------------------------------------------------------------------------
-// The march through the class tables (SKIP = 2; ClassView, kfx_device.h).  Every workgroup stages the tables -- a 32^3-cell
-// level and a finer one, two bits per entry -- in LDS.  An iteration of a ray is: up to `max_skips` steps that need no memory
-// (the position's entry says what a sample there would be: vref, NaN, or "vref or NaN": the reference's step is known, and
-// with it all following steps up to the entry's far side: bare lambda += delta additions, the reference's own, one per step),
-// then one sample where the entry says "sample".  The entry of a position comes from an affine estimate of the base-cell
-// coordinate, pf(lambda) = A + B lambda: three FMAs instead of the ~30 separately rounded operations of cell_of().  The
-// estimate is within `eps` cells of cell_of()'s coordinate (bound evaluated on the host from the box, the camera and the
-// march range), and a position closer than eps to a cell boundary -- where the two could disagree about the base cell -- is
-// sampled, with cell_of() itself: the skipped steps are exactly those of the reference march, so with the exact-numerics
-// tables (tol = 0: cells bit-equal to trunc, or NaN) depth, normals and shade stay bit-identical to the plain march.
+// The march through the class tables (ClassView, kfx_device.h).  Every workgroup stages the tables -- a
+// 32^3-cell level and a finer one, two bits per entry -- in LDS.  In an iteration a ray does ONE of two things:
+//   * it consults the tables (LDS and arithmetic only): if the entry of its position says what a sample there would be --
+//     trunc, NaN, or "trunc or NaN" -- the reference's step is known, and with it every following step that still starts
+//     inside the entry: the whole run is taken at once (exact numerics: the reference's own lambda += delta additions, one
+//     per step; fast numerics: one multiply-add);
+//   * or it samples, exactly as the plain kernel does.
+// The sampling lanes of a wave request their cells first and the consulting lanes work while those loads are in flight.
+// The entry of a position comes from an affine estimate of the base-cell coordinate, pf(lambda) = A + B lambda: three FMAs
+// instead of the ~30 separately rounded operations of cell_of().  The estimate is within `eps` cells of cell_of()'s
+// coordinate (bound evaluated on the host from the box, the camera and the roundings of both, class_view()), a position
+// closer than eps to a cell boundary -- where the two could disagree about the base cell -- is sampled, with cell_of()
+// itself, and runs end eps inside the entry: the skipped steps are exactly those of the reference march, so with the
+// exact-numerics tables (tol = 0: cells bit-equal to trunc, or NaN) depth, normals and shade stay bit-identical to the
+// plain march.
 // ---------------------------------------------------------------------------------------
 __device__ __forceinline__ int class_lookup(const unsigned* tab, const ClassLevel& L, int gx, int gy, int gz)
 {
