@@ -14,15 +14,17 @@
 //   SdfFuse(work_vol, kin_d, kin_n, T_wl^-1, K, trunc_dist, max_w, mincostheta)            (:345-356)
 //
 // Host code only; all device work happens in libkfx behind the roo:: wrappers.
-// Usage: kinectfusion_headless [--res N] [--frames F] [--width W] [--height H] [--fast] [--track | --device-icp] [--fused-launches]
+// Usage: kinectfusion_headless [--res N] [--frames F] [--width W] [--height H] [--fast] [--track | --device-icp] [--fused-launches] [--summary]
 #include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <vector>
 
 #include <kangaroo/kangaroo.h>
+#include <kangaroo/SdfSummary.h>
 
 #include "pose_solve.h"
 
@@ -68,7 +70,7 @@ static Mat<float,3,4> OrbitPose(int i, int n)
 int main(int argc, char** argv)
 {
     int volres = 256, frames = 30, w = 640, h = 480;   // the application's defaults (main.cpp:90-91)
-    bool fast = false, track = false, device_icp = false, one_raycast = false;
+    bool fast = false, track = false, device_icp = false, one_raycast = false, use_summary = false;
     for (int i = 1; i < argc; ++i) {
         if (!strcmp(argv[i], "--res") && i + 1 < argc) volres = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--frames") && i + 1 < argc) frames = atoi(argv[++i]);
@@ -76,6 +78,7 @@ int main(int argc, char** argv)
         else if (!strcmp(argv[i], "--height") && i + 1 < argc) h = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--fast")) fast = true;
         else if (!strcmp(argv[i], "--track")) track = true;
+        else if (!strcmp(argv[i], "--summary")) use_summary = true;   // roo::SdfSummary: SdfFuse keeps it current, RaycastSdf marches through its class tables
         else if (!strcmp(argv[i], "--one-raycast") || !strcmp(argv[i], "--fused-launches")) one_raycast = true;   // additions beside the reference API: all pyramid levels rendered by one launch, vbo + normals in one launch
         else if (!strcmp(argv[i], "--device-icp")) track = device_icp = true;   // the refinement loop as one device-side chain
     }
@@ -102,6 +105,8 @@ int main(int argc, char** argv)
     Image<unsigned char, TargetDevice, Manage> dScratch(w * sizeof(LeastSquaresSystem<float,12>), h);  // main.cpp:111
     const float icp_c = 0.1f, max_rmse = 0.10f;                                                   // main.cpp:154,162
 
+    std::unique_ptr<SdfSummary> summary;
+    if (use_summary) summary.reset(new SdfSummary(vol));
     const float3 vs = vol.VoxelSizeUnits();
     const float trunc_dist = trunc_dist_factor * length(vs);   // main.cpp:221
 
@@ -116,6 +121,7 @@ int main(int argc, char** argv)
     std::vector<float> hdepth((size_t)w * h);
     double total_ms = 0, worst_pos_err = 0, rmse = 0;
     size_t hits = 0;
+    unsigned long long depth_sum = 1469598103934665603ull;
     int lost = 0;
     posesolve::SE3d T_wl_est;   // tracked pose (double, as Sophus::SE3d in the application)
     for (int i = 0; i < 3; ++i) {
@@ -138,8 +144,13 @@ int main(int argc, char** argv)
             }
         }
         if (f == 0) {
-            SdfReset(vol, std::numeric_limits<float>::quiet_NaN());
-            SdfFuse(vol, kin_d[0], kin_n[0], SE3inv(T_wl), K, trunc_dist, max_w, mincostheta);
+            if (use_summary) {
+                SdfReset(vol, std::numeric_limits<float>::quiet_NaN(), *summary);
+                SdfFuse(vol, *summary, kin_d[0], kin_n[0], SE3inv(T_wl), K, trunc_dist, max_w, mincostheta);
+            } else {
+                SdfReset(vol, std::numeric_limits<float>::quiet_NaN());
+                SdfFuse(vol, kin_d[0], kin_n[0], SE3inv(T_wl), K, trunc_dist, max_w, mincostheta);
+            }
         }
         const BoundingBox roi(T_wl, w, h, K, knear, kfar);
         BoundedVolume<SDF_t> work_vol = vol.SubBoundingVolume(roi);
@@ -151,12 +162,14 @@ int main(int argc, char** argv)
                 unsigned n = 0;
                 for (int l = 0; l < MaxLevels; ++l)
                     if (its[l] > 0) { rd[n] = ray_d[l]; rn[n] = ray_n[l]; ri[n] = ray_i[l]; rv[n] = ray_v[l]; Kl[n] = K[l]; ++n; }
-                RaycastSdfLevels(rd, rn, ri, n, work_vol, T_wl, Kl, knear, kfar, trunc_dist, true, rv);   // rv[l] = DepthToVbo(rd[l], K[l])
+                if (use_summary) RaycastSdfLevels(rd, rn, ri, n, work_vol, *summary, T_wl, Kl, knear, kfar, trunc_dist, true, rv);
+                else RaycastSdfLevels(rd, rn, ri, n, work_vol, T_wl, Kl, knear, kfar, trunc_dist, true, rv);   // rv[l] = DepthToVbo(rd[l], K[l])
             } else {
                 for (int l = 0; l < MaxLevels; ++l) {
                     if (its[l] > 0) {
                         const ImageIntrinsics Kl = K[l];
-                        RaycastSdf(ray_d[l], ray_n[l], ray_i[l], work_vol, T_wl, Kl, knear, kfar, trunc_dist, true);
+                        if (use_summary) RaycastSdf(ray_d[l], ray_n[l], ray_i[l], work_vol, *summary, T_wl, Kl, knear, kfar, trunc_dist, true);
+                        else RaycastSdf(ray_d[l], ray_n[l], ray_i[l], work_vol, T_wl, Kl, knear, kfar, trunc_dist, true);
                         DepthToVbo<float>(ray_v[l], ray_d[l], Kl);
                     }
                 }
@@ -229,17 +242,26 @@ int main(int argc, char** argv)
                 for (int i = 0; i < 3; ++i) e += (T_wl(i, 3) - poses[f](i, 3)) * (T_wl(i, 3) - poses[f](i, 3));
                 worst_pos_err = std::fmax(worst_pos_err, std::sqrt(e));
             }
-            if (f > 0 && tracking_good) SdfFuse(work_vol, kin_d[0], kin_n[0], SE3inv(T_wl), K, trunc_dist, max_w, mincostheta);
+            if (f > 0 && tracking_good) {
+                if (use_summary) SdfFuse(work_vol, *summary, kin_d[0], kin_n[0], SE3inv(T_wl), K, trunc_dist, max_w, mincostheta);
+                else SdfFuse(work_vol, kin_d[0], kin_n[0], SE3inv(T_wl), K, trunc_dist, max_w, mincostheta);
+            }
         }
         kfx_stream_synchronize(0);
         total_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         if (f == frames - 1) {
             ray_d[0].MemcpyToHost(hdepth.data());
             for (float d : hdepth) hits += std::isfinite(d) ? 1 : 0;
+            for (float d : hdepth) {   // FNV-1a over the bit patterns of the last rendering (tests compare runs by it)
+                unsigned u;
+                memcpy(&u, &d, 4);
+                depth_sum = (depth_sum ^ u) * 1099511628211ull;
+            }
         }
     }
-    printf("kinectfusion_headless: %d^3 volume, %dx%d, %d frames, %s math, %s poses: %.3f ms/frame (%.1f fps), last raycast hits %zu/%d\n",
-           volres, w, h, frames, fast ? "fast" : "exact", device_icp ? "ICP-tracked (device loop)" : (track ? "ICP-tracked" : "known"), total_ms / frames, 1e3 * frames / total_ms, hits, w * h);
+    printf("kinectfusion_headless: %d^3 volume, %dx%d, %d frames, %s math, %s poses: %.3f ms/frame (%.1f fps), last raycast hits %zu/%d%s, depth checksum %016llx\n",
+           volres, w, h, frames, fast ? "fast" : "exact", device_icp ? "ICP-tracked (device loop)" : (track ? "ICP-tracked" : "known"), total_ms / frames, 1e3 * frames / total_ms, hits, w * h,
+           use_summary ? " (brick summary)" : "", depth_sum);
     if (track) printf("  tracking: worst position error %.2f mm over the orbit (step between poses up to %.1f mm), final rmse %.4f, %d frames lost\n",
                       1e3 * worst_pos_err, 1e3 * 0.0105, rmse, lost);
     if (track && (lost > 0 || worst_pos_err > 0.02)) return 1;

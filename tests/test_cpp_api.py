@@ -105,3 +105,23 @@ def test_headless_kinectfusion_app(extra):
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "fps" in out.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("extra", [[], ["--track", "--fused-launches"]])
+def test_headless_app_with_brick_summary_renders_the_same_images(extra):
+    """--summary: roo::SdfSummary through the C++ overloads (tracked SdfReset / SdfFuse on the ROI views of the application,
+    RaycastSdf / RaycastSdfLevels through the class tables).  Exact numerics: the last rendering has the bit pattern of the
+    run without it -- with known poses and with the ICP loop (whose poses then agree too)."""
+    import re
+    _build()
+    env = dict(os.environ, KFX_RAYCAST_SUMMARY="1")   # always through the tables, whatever share of the volume they cover
+    sums = []
+    for flag in ([], ["--summary"]):
+        out = subprocess.run([os.path.join(APPS, "kinectfusion_headless"), "--res", "128", "--frames", "8"] + extra + flag,
+                             capture_output=True, text=True, timeout=600, env=env)
+        assert out.returncode == 0, out.stdout + out.stderr
+        m = re.search(r"last raycast hits (\d+)/\d+.*depth checksum ([0-9a-f]{16})", out.stdout)
+        assert m and int(m.group(1)) > 1000, out.stdout
+        sums.append(m.group(2))
+    assert sums[0] == sums[1], sums
