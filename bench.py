@@ -53,6 +53,9 @@ def parse():
                          "exchanged with the neighbours over RCCL point-to-point after each SdfFuse")
     ap.add_argument("--inputs", default="replicate", choices=["replicate", "broadcast"],
                     help="N > 1: every rank preprocesses the frame itself, or rank 0 does and broadcasts the filtered depth + normal map")
+    ap.add_argument("--images", default="all", choices=["all", "root"],
+                    help="N > 1, composite raycast: every rank ends up with the merged images (all-reduce of the winners' payload), or "
+                         "only rank 0 does (reduce: half the traffic)")
     ap.add_argument("--overlap", action="store_true",
                     help="N > 1, composite raycast: merge frame k's images on a second stream under frame k+1's preprocess + SdfFuse")
     ap.add_argument("--summary", nargs="?", const="on", default="off", choices=["auto", "on", "off"],
@@ -190,7 +193,7 @@ def main():
         if args.overlap and args.halo == "exchange":
             sys.exit("bench.py: --overlap needs --halo recompute (collective ordering, kangaroo_amd/pipeline.py)")
         pipe = SlabPipeline(roo, dist, (N, N, N), bmin, bmax, w, h, halo=args.halo, raycast=args.raycast, K=K, near=near, far=far,
-                            overlap=args.overlap, inputs=args.inputs)
+                            overlap=args.overlap, inputs=args.inputs, images=args.images)
     else:
         # fast numerics: SdfFuse keeps a brick summary of the volume as a by-product and RaycastSdf takes its steps through
         # uniformly free / never-observed regions from it (same volume bits; depth within the fast-mode tolerance of the plain
@@ -277,7 +280,9 @@ def main():
     hits = int(torch.isfinite(pipe.ray_d.tensor()).sum())
     assert hits > 0, "raycast produced no hits"
     ranks_agree = None
-    if distributed:   # after the composite every rank must hold the same images: compare a checksum of the depth bits
+    if distributed and args.images == "root":
+        ranks_agree = None   # only rank 0 holds the merged images
+    elif distributed:   # after the composite every rank must hold the same images: compare a checksum of the depth bits
         bits = torch.nan_to_num(pipe.ray_d.tensor(), nan=-1.0).contiguous().view(torch.int32).to(torch.int64)
         chk = torch.stack([bits.sum(), -bits.sum()])
         dist.all_reduce(chk, op=dist.ReduceOp.MAX)
@@ -392,7 +397,7 @@ def main():
             return round(n / float(tt.item()), 1)
         n_var = min(args.steps, 2 * N_ORBIT)
         variants = {"steps": n_var}
-        base_halo, base_overlap, base_inputs = pipe.halo, pipe.overlap, pipe.inputs
+        base_halo, base_overlap, base_inputs, base_images = pipe.halo, pipe.overlap, pipe.inputs, pipe.images
         try:   # reported extras must never cost the headline line (errors in collectives are symmetric across ranks)
             variants["as_configured_fps"] = timed_fps(n_var)
             pipe.wait_composite()
@@ -409,9 +414,15 @@ def main():
             pipe.overlap = base_overlap
             pipe.inputs = "broadcast" if base_inputs == "replicate" else "replicate"
             variants["inputs_%s_fps" % pipe.inputs] = timed_fps(n_var)
+            pipe.inputs = base_inputs
+            if args.raycast == "composite":
+                pipe.wait_composite()
+                pipe.images = "root" if base_images == "all" else "all"
+                variants["images_%s_fps" % pipe.images] = timed_fps(n_var)
+                pipe.wait_composite()
         except Exception as e:   # noqa: BLE001
             variants["error"] = repr(e)[:300]
-        pipe.halo, pipe.overlap, pipe.inputs = base_halo, base_overlap, base_inputs
+        pipe.halo, pipe.overlap, pipe.inputs, pipe.images = base_halo, base_overlap, base_inputs, base_images
 
     # 1 GPU, fast numerics: the same frames with the brick summary switched on (tracked SdfFuse + RaycastSdf that steps through
     # uniform regions without reading the volume), reported beside the headline (not part of `value`)
@@ -567,7 +578,7 @@ def main():
                             if (not distributed and use_summary) else "plain march (kfx_raycast_sdf)"),
                 "summary_policy": None if distributed else {"requested": args.summary if args.math == "fast" else "off (exact numerics)",
                                                             "decision": getattr(pipe, "track_decision", None)},
-                "partition": ("z-slabs x%d, inputs %s, ghost planes %s%s, raycast %s" % (n_gpus, "preprocessed by every rank" if args.inputs == "replicate" else "preprocessed by rank 0 and broadcast", args.halo, ", merge overlapped with the next frame" if args.overlap else "", {"composite": "composite = all_reduce(MIN key) + all_reduce(SUM payload)", "exact": "exact = march state handed from slab to slab: world + 1 stages, neighbour send/recv between them, one all_reduce of the finalised pixels at the end", "exact_allreduce": "exact (cross-check) = one SUM all_reduce of the march state + a host-side termination test per round"}[args.raycast]))
+                "partition": ("z-slabs x%d, inputs %s, ghost planes %s%s, raycast %s" % (n_gpus, "preprocessed by every rank" if args.inputs == "replicate" else "preprocessed by rank 0 and broadcast", args.halo, ", merge overlapped with the next frame" if args.overlap else "", {"composite": "composite = all_reduce(MIN key) + %s(SUM payload)" % ("reduce-to-rank-0" if args.images == "root" else "all_reduce"), "exact": "exact = march state handed from slab to slab: world + 1 stages, neighbour send/recv between them, one all_reduce of the finalised pixels at the end", "exact_allreduce": "exact (cross-check) = one SUM all_reduce of the march state + a host-side termination test per round"}[args.raycast]))
                              if distributed else "single volume",
                 "math": {"fast": "fast (fp32 rcp/rsq + FMA: the reference's own -use_fast_math regime; whole chain against the exact oracle at this size, "
                                  "tests/test_gpu_chain.py: TSDF L-inf < 1e-4 on identically classified voxels (<= 2e-6 of them classified differently); raycast images: "

@@ -256,7 +256,7 @@ class SlabPipeline(FramePipeline):
     GHOST = 2  # >= 1 for the trilinear z+1 corner and the gradient's z-1 / z+1 cells (Volume.h:240-289)
 
     def __init__(self, ops, dist, dims, boxmin, boxmax, w, h, halo="exchange", raycast="composite", kind="f32", overlap=False,
-                 inputs="replicate", **kw):
+                 inputs="replicate", images="all", **kw):
         """halo = "exchange": every rank integrates only the planes it owns and the ghost planes are
         refreshed from the two neighbours after each SdfFuse (point-to-point send/recv: one xGMI link
         per direction); halo = "recompute": every rank integrates its ghost planes itself (the update is
@@ -267,6 +267,13 @@ class SlabPipeline(FramePipeline):
         # itself (no traffic); "broadcast" = rank 0 does, and its filtered depth + normal map (20 B per pixel) are broadcast
         assert inputs in ("replicate", "broadcast")
         self.inputs = inputs
+        # images (composite mode): "all" = every rank ends up with the merged images (the second collective is an all-reduce);
+        # "root" = only rank 0 does (a reduce: half the traffic of the payload's all-reduce) -- a known-pose stream has one
+        # consumer of the rendering, and the tracking loop can solve on rank 0 and broadcast the 4 x 4 pose (TrackingSlabPipeline)
+        assert images in ("all", "root")
+        if images == "root" and raycast != "composite":
+            raise ValueError("SlabPipeline: images='root' is an option of the composite raycast")
+        self.images = images
         # overlap (composite mode, known-pose streams): the merge of frame k's per-slab images -- two latency-bound
         # all-reduces and three small kernels -- runs on a second stream while the main stream already preprocesses and
         # integrates frame k + 1; step() then returns before ray_d / ray_n / ray_i are merged: they are valid only after
@@ -444,9 +451,16 @@ class SlabPipeline(FramePipeline):
         self.dist.all_reduce(key, op=self.dist.ReduceOp.MIN)
         for (d, n, i), (kk, pp) in zip(outputs, parts):
             self.ops.CompositeSelect(d, n, i, kk, pp, self.rank)
-        self.dist.all_reduce(payload, op=self.dist.ReduceOp.SUM)
+        self._sum_payload(payload)
         for (d, n, i), (kk, pp) in zip(outputs, parts):
             self.ops.CompositeUnpack(d, n, i, kk, pp)
+
+    def _sum_payload(self, payload):
+        """The winners' normals / shade, summed over the ranks: on every rank, or (images = "root") on rank 0 only."""
+        if self.images == "root":
+            self.dist.reduce(payload, dst=0, op=self.dist.ReduceOp.SUM)
+        else:
+            self.dist.all_reduce(payload, op=self.dist.ReduceOp.SUM)
 
     def _scratch(self, name, shape, dtype, like):
         """Per-shape device scratch tensors (march state, composite key / payload), allocated once."""
@@ -566,8 +580,8 @@ class SlabPipeline(FramePipeline):
             self.ops.CompositePack(d, n, i, key, self.rank)
             dist.all_reduce(key, op=dist.ReduceOp.MIN)
             self.ops.CompositeSelect(d, n, i, key, payload, self.rank)
-            dist.all_reduce(payload, op=dist.ReduceOp.SUM)
-            self.ops.CompositeUnpack(d, n, i, key, payload)
+            self._sum_payload(payload)
+            self.ops.CompositeUnpack(d, n, i, key, payload)   # (images = "root": only rank 0's payload is the sum)
             return
         dt, nt, it = d.tensor(), n.tensor(), i.tensor()
         hit = torch.isfinite(dt)
@@ -578,7 +592,7 @@ class SlabPipeline(FramePipeline):
         payload = torch.zeros((h, w, 4), dtype=torch.float32, device=dt.device)   # {n.x, n.y, n.z, shade}; n.w = hit ? 1 : 0 comes out of the key
         payload[..., 0:3] = torch.where(mine.unsqueeze(-1), nt[..., 0:3], torch.zeros_like(nt[..., 0:3]))
         payload[..., 3] = torch.where(mine, it, torch.zeros_like(it))
-        dist.all_reduce(payload, op=dist.ReduceOp.SUM)
+        self._sum_payload(payload)
         win_bits = (key >> 8).to(torch.int32)
         any_hit = win_bits < 0x7F800000
         dt.copy_(torch.where(any_hit, win_bits.view(torch.float32), torch.full_like(dt, float("nan"))))
@@ -632,8 +646,24 @@ class TrackingSlabPipeline(SlabPipeline):
             self.raycast_levels_into([(self.pyr_d[l], self.pyr_n[l], self.pyr_i[l]) for l in lv], [self.K_levels[l] for l in lv], T34)
             for l in lv:
                 o.DepthToVbo(self.pyr_v[l], self.pyr_d[l], self.K_levels[l])
-            T_lp, self.rmse, self.tracking_good = tr.refine_pose(o, self.kin_v, self.pyr_v, self.pyr_n, self.K_levels,
-                                                                 self.scratch, self.debug, self.its, self.icp_c, self.max_rmse)
+            if self.images == "root" and self.world > 1:
+                # only rank 0 holds the merged model images: it solves, the others receive the pose (and the verdict)
+                import torch
+                msg = torch.zeros(18, dtype=torch.float64)
+                if self.rank == 0:
+                    T_lp, self.rmse, self.tracking_good = tr.refine_pose(o, self.kin_v, self.pyr_v, self.pyr_n, self.K_levels,
+                                                                         self.scratch, self.debug, self.its, self.icp_c, self.max_rmse)
+                    msg[:16] = torch.from_numpy(np.asarray(T_lp, np.float64).reshape(16))
+                    msg[16], msg[17] = float(self.rmse), 1.0 if self.tracking_good else 0.0
+                if self.dist.get_backend() == "nccl":
+                    msg = msg.to(self.pyr_d[0].tensor().device)
+                self.dist.broadcast(msg, src=0)
+                msg = msg.cpu()
+                T_lp = msg[:16].numpy().reshape(4, 4).copy()
+                self.rmse, self.tracking_good = float(msg[16]), bool(msg[17] != 0)
+            else:
+                T_lp, self.rmse, self.tracking_good = tr.refine_pose(o, self.kin_v, self.pyr_v, self.pyr_n, self.K_levels,
+                                                                     self.scratch, self.debug, self.its, self.icp_c, self.max_rmse)
             if self.tracking_good:
                 self.T_wl = self.T_wl @ tr.se3_inv(T_lp)
                 self._fuse_at(self.T_wl)

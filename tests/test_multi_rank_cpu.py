@@ -28,13 +28,13 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out_dir, halo, raycast="composite", inputs="replicate"):
+def _worker(rank, world, port, out_dir, halo, raycast="composite", inputs="replicate", images="all"):
     import oracle_ops as ops
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     bmin, bmax, near, far = scenes.SCENES["room"]
-    pipe = SlabPipeline(ops, dist, (N, N, N), bmin, bmax, W, H, halo=halo, raycast=raycast, near=near, far=far, inputs=inputs)
+    pipe = SlabPipeline(ops, dist, (N, N, N), bmin, bmax, W, H, halo=halo, raycast=raycast, near=near, far=far, inputs=inputs, images=images)
     K = pipe.K
     for i in range(FRAMES):
         T_wc = scenes.orbit_pose(i, 8)
@@ -160,14 +160,14 @@ def test_exact_slab_raycast_is_bit_identical_to_single_volume(tmp_path, world, m
         assert T.nan_equal(got["img"], ref.ray_i.data), T.mismatch_report(got["img"], ref.ray_i.data)
 
 
-def _tracking_worker(rank, world, port, out_dir, raycast):
+def _tracking_worker(rank, world, port, out_dir, raycast, images="all"):
     import oracle_ops as ops
     from kangaroo_amd.pipeline import TrackingSlabPipeline
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     bmin, bmax, near, far = scenes.SCENES["room"]
-    pipe = TrackingSlabPipeline(ops, dist, (N, N, N), bmin, bmax, 160, 120, halo="exchange", raycast=raycast, near=near, far=far)
+    pipe = TrackingSlabPipeline(ops, dist, (N, N, N), bmin, bmax, 160, 120, halo="exchange", raycast=raycast, near=near, far=far, images=images)
     poses = []
     for i in range(4):
         T_true = scenes.orbit_pose(i, 60)
@@ -205,3 +205,27 @@ def test_tracked_kinectfusion_on_slabs(tmp_path, raycast):
             assert T.nan_equal(r["vol"], ref.vol.data[s0:s1])
     else:
         assert np.abs(ranks[0]["poses"][:, :3, 3] - want[:, :3, 3]).max() < 5e-4
+
+
+def test_composite_to_root_and_pose_broadcast(tmp_path):
+    """images="root": the payload of the composite is reduced to rank 0 instead of all-reduced -- rank 0 ends up with exactly
+    the images of images="all"; in the tracked loop rank 0 alone solves and broadcasts the pose, and every rank integrates its
+    slab at it: same poses, same slabs as with every rank solving (world 3, gloo, oracle operators)."""
+    world = 3
+    a, b = tmp_path / "all", tmp_path / "root"
+    a.mkdir(); b.mkdir()
+    mp.spawn(_worker, args=(world, _free_port(), str(a), "recompute", "composite", "replicate", "all"), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), str(b), "recompute", "composite", "replicate", "root"), nprocs=world, join=True)
+    ra, rb = np.load(str(a / "rank0.npz")), np.load(str(b / "rank0.npz"))
+    for k in ("depth", "norm", "img"):
+        assert T.nan_equal(ra[k], rb[k]), k
+    assert np.isfinite(rb["depth"]).mean() > 0.3
+    for r in range(world):   # the volume never depended on the images
+        assert T.nan_equal(np.load(str(a / ("rank%d.npz" % r)))["vol"], np.load(str(b / ("rank%d.npz" % r)))["vol"])
+    ta, tb = tmp_path / "t_all", tmp_path / "t_root"
+    ta.mkdir(); tb.mkdir()
+    mp.spawn(_tracking_worker, args=(2, _free_port(), str(ta), "composite", "all"), nprocs=2, join=True)
+    mp.spawn(_tracking_worker, args=(2, _free_port(), str(tb), "composite", "root"), nprocs=2, join=True)
+    for r in range(2):
+        x, y = np.load(str(ta / ("track%d.npz" % r))), np.load(str(tb / ("track%d.npz" % r)))
+        assert np.array_equal(x["poses"], y["poses"]) and T.nan_equal(x["vol"], y["vol"])
