@@ -96,7 +96,7 @@ __device__ __forceinline__ float raycast_pixel(const RayParams& p, const ColorGe
                 }
                 break;
             }
-            delta = sdf > 0 ? fmaxf(sdf, min_delta) : p.trunc;
+            delta = march_step(sdf, min_delta, p.trunc);
             lambda += delta;
             last_sdf = sdf;
         }
@@ -271,7 +271,7 @@ __device__ __forceinline__ float raycast_pixel_classes(const RayParams& p, const
                     }
                     break;
                 }
-                delta = sdf > 0 ? fmaxf(sdf, min_delta) : p.trunc;
+                delta = march_step(sdf, min_delta, p.trunc);
                 lambda += delta;
                 last_sdf = sdf;
                 pending = false;
@@ -392,7 +392,7 @@ __global__ __launch_bounds__(256) void k_raycast_sdf_count(const RayParams p, un
                     }
                     break;
                 }
-                delta = sdf > 0 ? fmaxf(sdf, min_delta) : p.trunc;
+                delta = march_step(sdf, min_delta, p.trunc);
                 lambda += delta;
                 last_sdf = sdf;
             }
@@ -588,7 +588,7 @@ __global__ __launch_bounds__(256) void k_raycast_sdf_slab(const RayParams p, con
                 }
                 break;
             }
-            delta = sdf > 0 ? fmaxf(sdf, min_delta) : p.trunc;
+            delta = march_step(sdf, min_delta, p.trunc);
             lambda += delta;
             last_sdf = sdf;
         }

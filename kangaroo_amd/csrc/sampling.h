@@ -161,7 +161,9 @@ __device__ __forceinline__ V3 box_fraction(const GEOM& p, const V3 pos_w)
 {
     const V3 d = pos_w - p.vol.bmin;
     const float hi = fmaxf(fmaxf(fabsf(d.x), fabsf(d.y)), fabsf(d.z)), lo = fminf(fminf(fabsf(d.x), fabsf(d.y)), fabsf(d.z));
-    if (__builtin_expect(p.fastdiv && hi < 0x1p40f && lo > 0x1p-40f, 1))
+    // Both paths give the IEEE quotients, so the choice may be made per WAVE: one scalar branch instead of a divergent one
+    // (exec-mask bookkeeping for a path that is taken once in a million steps: a component within 2^-40 of the box's face).
+    if (__builtin_expect(p.fastdiv && __ballot(!(hi < 0x1p40f && lo > 0x1p-40f)) == 0ull, 1))
         return v3(div_uniform(d.x, p.size.x, p.inv_size.x), div_uniform(d.y, p.size.y, p.inv_size.y), div_uniform(d.z, p.size.z, p.inv_size.z));
     return div_cw(d, p.size);
 }
@@ -173,12 +175,22 @@ __device__ __forceinline__ CellPos cell_of(const GEOM& p, const V3 pos_w)
 {
     const V3 pos_v = box_fraction(p, pos_w);
     const V3 pf = v3(pos_v.x * p.dims1.x, pos_v.y * p.dims1.y, pos_v.z * p.dims1.z);
+    // max(min(dim - 2, floor(pf)), 0) as one v_med3_f32 per axis (0 <= dim - 2: the median IS the clamp; for a NaN coordinate
+    // the median picks 0 where the reference's fminf / fmaxf pick dim - 2, and the sample is NaN either way: its fraction is),
+    // and the clamped value, an integer below 2^24, serves as (float)ix: no conversion back
+    const float cx = __builtin_amdgcn_fmed3f(floorf(pf.x), 0.f, p.hi2.x), cy = __builtin_amdgcn_fmed3f(floorf(pf.y), 0.f, p.hi2.y),
+                cz = __builtin_amdgcn_fmed3f(floorf(pf.z), 0.f, p.hi2.z);
     CellPos c;
-    c.ix = (int)fmaxf(fminf(p.hi2.x, floorf(pf.x)), 0.f);
-    c.iy = (int)fmaxf(fminf(p.hi2.y, floorf(pf.y)), 0.f);
-    c.iz = (int)fmaxf(fminf(p.hi2.z, floorf(pf.z)), 0.f);
-    c.fx = pf.x - (float)c.ix; c.fy = pf.y - (float)c.iy; c.fz = pf.z - (float)c.iz;
+    c.ix = (int)cx; c.iy = (int)cy; c.iz = (int)cz;
+    c.fx = pf.x - cx; c.fy = pf.y - cy; c.fz = pf.z - cz;
     return c;
+}
+
+// the march's step for a sample (cu_raycast.cu:77-80): max(sdf, min_delta) in front of the surface, trunc behind it or for a
+// NaN sample.  fmaxf() costs a canonicalising v_max per operand; with sdf > 0 already known a compare-and-select is the same value.
+__device__ __forceinline__ float march_step(const float sdf, const float min_delta, const float trunc)
+{
+    return sdf > 0 ? (min_delta > sdf ? min_delta : sdf) : trunc;
 }
 
 // the eight cells of the sample and their blend (Volume.h:236-250)
