@@ -417,12 +417,13 @@ __global__ __launch_bounds__(256) void k_sdf_fuse(const FuseParams p)
 // whole summary bricks, so no atomics: DPP / permlane swaps reduce a wave's lanes, LDS the workgroup's waves).  RaycastSdf
 // uses it to step through uniformly free or never-observed space without touching the volume (raycast.hip).
 // Register budget (launch bounds): fast, ZU = 2: the 64 VGPRs of 8 waves per SIMD -- what the 1216-texel tile makes room
-// for; without the bound hipcc's allocation moves between 64 and 78 on unrelated edits.  Bit-exact, untracked: the 80 of 6
-// waves; one wave less costs 6 % (measured when an edit took it from 78 to 81).  scripts/check_fuse_codegen.py checks both.
+// for; without the bound hipcc's allocation moves between 64 and 78 on unrelated edits.  Bit-exact: the 80 of 6 waves; one
+// wave less costs 6 % (measured when an edit took the untracked kernel from 78 to 81; the tracked one took 86 unbounded and
+// fits 77 without scratch).  scripts/check_fuse_codegen.py checks both.
 // DXT (bit-exact kernels): a texel is staged as {texel, difference to its right neighbour} -- 32 bytes, so `cap_px` texels take
 // twice the LDS; chosen by the host for ranges whose rectangles fit half the tile (finish_shared_dx).
 template <bool FAST, int ZU, typename CELL, int LX = 32, int WY = 4, int ZC = FUSE_ZC, bool TRACK = false, bool DXT = false>
-__global__ __launch_bounds__(256, (FAST && ZU == 2) ? 8 : ((!FAST && !TRACK) ? 6 : 1)) void k_sdf_fuse_tiled(const FuseParams p_arg, const int cap_px)
+__global__ __launch_bounds__(256, (FAST && ZU == 2) ? 8 : (!FAST ? 6 : 1)) void k_sdf_fuse_tiled(const FuseParams p_arg, const int cap_px)
 {
     static_assert(!DXT || (!FAST && !TRACK), "the difference tile belongs to the bit-exact, untracked kernels");
     // the uniforms of the per-voxel arithmetic live in vector registers (in_vgpr, kfx_device.h): an SGPR operand makes a
@@ -542,7 +543,10 @@ __global__ __launch_bounds__(256, (FAST && ZU == 2) ? 8 : ((!FAST && !TRACK) ? 6
     // eight slow-class instructions and as many scalar ones per voxel (fast: 139 + 40 -> 123 + 19 vector + scalar
     // instructions per voxel pair, exact: 240 + 35 -> 219 + 15).  Measured: fast 0.3310 -> 0.3293 ms, exact 0.4425 -> 0.436 ms
     // at 512^3 -- far less than the instruction count: by now neither loop is bound by issue alone.
-    const bool interior = __builtin_amdgcn_readfirstlane((int)(use_tile && umin >= 2.01f && umax < p.dwb - 0.01f && vmin >= 2.01f && vmax < p.dhb - 0.01f)) != 0;
+    // (TRACK keeps the lanes beyond the volume's extents in the march, and those project anywhere: a brick cut by the extents
+    // takes the checked loop)
+    const bool whole = !TRACK || ((bxi + 1) * LX * 2 <= p.X && ((int)blockIdx.y + 1) * BY <= p.Y);
+    const bool interior = __builtin_amdgcn_readfirstlane((int)(use_tile && whole && umin >= 2.01f && umax < p.dwb - 0.01f && vmin >= 2.01f && vmax < p.dhb - 0.01f)) != 0;
     float dmax = -__builtin_inff(); // farthest finite depth in the rectangle (fmaxf skips NaN texels)
     if (use_tile) {
         // Cooperative staging, flat over the rectangle's texels (consecutive threads = consecutive texels of a row), four
@@ -734,7 +738,7 @@ __global__ __launch_bounds__(256, (FAST && ZU == 2) ? 8 : ((!FAST && !TRACK) ? 6
                         const float pv = p.K.v0 + div_core(p.K.fv * Pc.y, Pc.z, yz);
                         const float fix = floorf(pu), fiy = floorf(pv);
                         const int rx = (int)fix - tx0v, ry = (int)fiy - ty0v;
-                        if constexpr (INTERIOR && !TRACK) { // every lane samples inside the image band and the rectangle
+                        if constexpr (INTERIOR) { // every lane samples inside the image band and the rectangle
                             if constexpr (DXT) {
                                 const float4* t = s_tile + 2 * (ry * tw + rx);
                                 o[v] = finish_shared_dx(p, Pc, yz, pu - fix, pv - fiy, t[0], t[1], t[2 * tw], t[2 * tw + 1]);
@@ -827,7 +831,7 @@ __global__ __launch_bounds__(256, (FAST && ZU == 2) ? 8 : ((!FAST && !TRACK) ? 6
                             project<FAST>(p, Pc, pu, pv, iz);
                             const float fix = floorf(pu), fiy = floorf(pv);
                             const int rx = (int)fix - tx0v, ry = (int)fiy - ty0v;
-                            if constexpr (INTERIOR && !TRACK) { // every lane samples inside the image band and the rectangle
+                            if constexpr (INTERIOR) { // every lane samples inside the image band and the rectangle
                                 const float4* t = s_tile + (ry * tw + rx);
                                 Corners c;
                                 c.c00 = t[0]; c.c01 = t[1]; c.c10 = t[tw]; c.c11 = t[tw + 1];
