@@ -49,6 +49,9 @@ struct FuseParams {
     float trunc, max_w, mincos;
     unsigned dpitch, npitch; // image pitches as 32-bit values (valid when `small_images`)
     int exact_shared;        // exact mode: camera / thresholds allow the shared-reciprocal arithmetic (see finish_shared)
+    // serpentine sweep of the tracked launches (fuse_launch): z-bricks from the far end, and the planes [keep_z0, keep_z1) of
+    // this launch read with ordinary loads
+    int z_rev, keep_z0, keep_z1;
     // brick summary maintained by the TRACK kernels (kfx_sdf_summary, summary.hip): one float4 {lo, hi, state, -} per
     // 8 x 8 x 8 cells of the PARENT volume; (sum_bx0, sum_by0, sum_bz0) = brick index of this view's first cell
     float4* sum_R;
@@ -457,10 +460,12 @@ __global__ __launch_bounds__(256, (FAST && ZU == 2) ? 8 : (!FAST ? 6 : 1)) void 
     // an XCD still works on one x-slab at a time (all y-bricks of a layer), so the image columns its bricks stage stay
     // in its L2 (rotating by the y-brick as well made S_full 12 % slower: every XCD then cycles through the whole image).
     // Measured, interleaved on one box (scripts/ab_xcd_swizzle.sh): S_room fast 0.438 -> 0.410 ms, S_full unchanged.
-    const int bxi = p.xcd_swizzle ? (int)((blockIdx.x + (blockIdx.z >> (p.xcd_swizzle - 1))) % gridDim.x) : (int)blockIdx.x;
+    const int bzi = (TRACK && p.z_rev) ? (int)(gridDim.z - 1 - blockIdx.z) : (int)blockIdx.z;
+    const int bxi = p.xcd_swizzle ? (int)((blockIdx.x + (bzi >> (p.xcd_swizzle - 1))) % gridDim.x) : (int)blockIdx.x;
     const int x0 = (bxi * LX + (lane & (LX - 1))) * 2;
     const int y = blockIdx.y * BY + (wv % WY) * RW + lane / LX;
-    const int zbeg = blockIdx.z * ZC;
+    const int zbeg = bzi * ZC;
+    const bool keep = TRACK && zbeg >= p.keep_z0 && zbeg < p.keep_z1;
     const int zend = min(zbeg + ZC, p.Z);
     const int wz0 = zbeg + (wv / WY) * ZW, wz1 = min(wz0 + ZW, zend); // this wave's slices
     const bool live = x0 < p.X && y < p.Y;
@@ -684,6 +689,30 @@ __global__ __launch_bounds__(256, (FAST && ZU == 2) ? 8 : (!FAST ? 6 : 1)) void 
         };
         const bool upd = !TRACK || live;   // TRACK: a lane outside the extents observes like the others and updates nothing
 
+        // the cell pairs of up to ZU slices.  `keep` bricks (TRACK: the planes the next sweep starts with) use ordinary loads,
+        // which leave the lines in the 256 MiB memory-side cache.  Written as asm: given `keep ? plain load : nontemporal
+        // load` of one address hipcc emits a single plain load for both cases.  The loads are requested in place ("+v": no
+        // copy of a register whose data has not arrived), one wait covers them.
+        auto load_cells = [&](float4 (&c)[ZU], const bool (&any)[ZU], const unsigned char* at) {
+            if constexpr (TRACK && FAST && CELL::BYTES == 8 && ZU <= 2) {   // (the bit-exact kernels are bound by issue, not by memory)
+                if (keep) { // uniform
+                    v4f raw[ZU];
+    #pragma unroll
+                    for (int k = 0; k < ZU; ++k)
+                        if (any[k]) asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(raw[k]) : "v"(at + (size_t)k * p.vimg_pitch) : "memory");
+                    if constexpr (ZU == 1) asm volatile("s_waitcnt vmcnt(0)" : "+v"(raw[0]) : : "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" : "+v"(raw[0]), "+v"(raw[ZU - 1]) : : "memory");
+    #pragma unroll
+                    for (int k = 0; k < ZU; ++k)
+                        if (any[k]) c[k] = make_float4(raw[k].x, raw[k].y, raw[k].z, raw[k].w);
+                    return;
+                }
+            }
+    #pragma unroll
+            for (int k = 0; k < ZU; ++k)
+                if (any[k]) c[k] = CELL::ld2(at + (size_t)k * p.vimg_pitch);
+        };
+
         // one voxel's observation, corners from the LDS tile when the cell lies inside it
         auto observe_tile = [&](int v, float pz) -> Obs {
             Obs o;
@@ -790,9 +819,7 @@ __global__ __launch_bounds__(256, (FAST && ZU == 2) ? 8 : (!FAST ? 6 : 1)) void 
                         }
                     }
                     float4 c[ZU];
-    #pragma unroll
-                    for (int k = 0; k < ZU; ++k)
-                        if (any[k]) c[k] = CELL::ld2(cell + (size_t)k * p.vimg_pitch);
+                    load_cells(c, any, cell);
     #pragma unroll
                     for (int k = 0; k < ZU; ++k)
                         if (any[k]) {
@@ -867,9 +894,7 @@ __global__ __launch_bounds__(256, (FAST && ZU == 2) ? 8 : (!FAST ? 6 : 1)) void 
                 for (int k = 0; k < ZU; ++k)
                     if (z + k < wz1) note_pair(o[k][0].ok, o[k][1].ok); // uniform
                 float4 c[ZU];
-    #pragma unroll
-                for (int k = 0; k < ZU; ++k)
-                    if (any[k]) c[k] = CELL::ld2(cell + (size_t)k * p.vimg_pitch);
+                load_cells(c, any, cell);
     #pragma unroll
                 for (int k = 0; k < ZU; ++k)
                     if (any[k]) {
@@ -902,9 +927,7 @@ __global__ __launch_bounds__(256, (FAST && ZU == 2) ? 8 : (!FAST ? 6 : 1)) void 
                 }
             }
             float4 c[ZU];
-    #pragma unroll
-            for (int k = 0; k < ZU; ++k)
-                if (any[k]) c[k] = CELL::ld2(cell + (size_t)k * p.vimg_pitch);
+            load_cells(c, any, cell);
     #pragma unroll
             for (int k = 0; k < ZU; ++k)
                 if (any[k]) {
@@ -1479,6 +1502,7 @@ static int fuse_params(FuseParams& p, bool* small_images, const kfx_volume* vol,
     // KFX_FUSE_EXACT_SHARED=0 keeps hipcc's own division / square-root expansions (A/B, and the parity suite runs both)
     static const int shared_env = [] { const char* e = getenv("KFX_FUSE_EXACT_SHARED"); return e ? atoi(e) : 1; }();
     const float afu = fabsf(p.K.fu), afv = fabsf(p.K.fv);
+    p.z_rev = 0; p.keep_z0 = 0; p.keep_z1 = 0;
     p.exact_shared = shared_env && afu >= 0x1p-20f && afu <= 0x1p20f && afv >= 0x1p-20f && afv <= 0x1p20f &&
                      mincostheta >= 0x1p-20f && mincostheta < __builtin_inff() && trunc_dist > 0.f && trunc_dist < __builtin_inff();
     return 0;
@@ -1610,18 +1634,44 @@ static int fuse_launch(const kfx_volume* vol, const kfx_image* depth, const kfx_
             if (t.dxt && !all_dxt) { t = TilePlan{0, tile_cap(p, p.T, p.K, za, zb, fast), 0}; if (cap_env) t.cap = cap_env; }
             return t;
         };
-        int z0 = 0;
-        while (z0 < p.Z) {
+        // Tracked launches sweep the planes in serpentine order -- every other launch from the far end -- and read the last
+        // KFX_FUSE_KEEP_MB (default 256) of a sweep with ordinary loads: those planes stay in the 256 MiB memory-side cache
+        // and the next sweep starts on them.  (The volume is otherwise streamed nontemporally, which leaves nothing behind;
+        // untracked launches belong to loops whose plain march reads ~500 MB of the volume in between and evicts the tail.)
+        static const int keep_mb = [] { const char* e = getenv("KFX_FUSE_KEEP_MB"); return e ? atoi(e) : 256; }();
+        const int rev = (track && keep_mb > 0) ? (int)(summary->sweeps++ & 1u) : 0;
+        int keep_lo = 0, keep_hi = 0;   // planes read with ordinary loads (this view's local coordinates)
+        if (track && keep_mb > 0) {
+            const size_t plane = (size_t)p.vimg_pitch;
+            int n = (int)(((size_t)keep_mb << 20) / (plane ? plane : 1));
+            n = n / FUSE_ZC * FUSE_ZC;
+            if (n > p.Z) n = p.Z;
+            if (rev) { keep_lo = 0; keep_hi = n; } else { keep_lo = p.Z - n; keep_hi = p.Z; }
+        }
+        struct Range { int z0, z1; TilePlan plan; };
+        Range ranges[64];
+        int n_ranges = 0;
+        for (int z0 = 0; z0 < p.Z;) {
             int z1 = z0 + zstep < p.Z ? z0 + zstep : p.Z;
             const TilePlan plan = plan_of(z0, z1);
-            const int cap_px = plan.cap;
             while (z1 < p.Z) { // extend over following ranges that want the same brick and capacity
                 const int z2 = z1 + zstep < p.Z ? z1 + zstep : p.Z;
                 const TilePlan nxt = plan_of(z1, z2);
-                if (nxt.cap != cap_px || nxt.small_brick != plan.small_brick || nxt.dxt != plan.dxt) break;
+                if (nxt.cap != plan.cap || nxt.small_brick != plan.small_brick || nxt.dxt != plan.dxt) break;
                 z1 = z2;
             }
+            if (n_ranges == 64) { ranges[63].z1 = p.Z; break; } // (never: a range is at least 64 planes and plans change a few times at most)
+            ranges[n_ranges++] = Range{z0, z1, plan};
+            z0 = z1;
+        }
+        for (int ri = 0; ri < n_ranges; ++ri) {
+            const Range& rg = ranges[rev ? n_ranges - 1 - ri : ri];
+            const int z0 = rg.z0, z1 = rg.z1;
+            const TilePlan plan = rg.plan;
+            const int cap_px = plan.cap;
             FuseParams q = p;
+            q.z_rev = rev;
+            q.keep_z0 = keep_lo - z0; q.keep_z1 = keep_hi - z0;
             q.vptr = p.vptr + (size_t)z0 * p.vimg_pitch;
             q.zoff = p.zoff + z0;
             q.zoff_local = z0;
@@ -1634,7 +1684,6 @@ static int fuse_launch(const kfx_volume* vol, const kfx_image* depth, const kfx_
                     else if (plan.small_brick) hipLaunchKernelGGL((k_sdf_fuse_tiled<false, 1, CELL, 16, 2, 16, true>), gn, dim3(256), lds, s, q, cap_px);
                     else if (fast) hipLaunchKernelGGL((k_sdf_fuse_tiled<true, 2, CELL, 32, 4, FUSE_ZC, true>), gw, dim3(256), lds, s, q, cap_px);
                     else hipLaunchKernelGGL((k_sdf_fuse_tiled<false, 1, CELL, 32, 4, FUSE_ZC, true>), gw, dim3(256), lds, s, q, cap_px);
-                    z0 = z1;
                     continue;
                 }
             }
@@ -1655,7 +1704,6 @@ static int fuse_launch(const kfx_volume* vol, const kfx_image* depth, const kfx_
                 else if (plan.dxt) hipLaunchKernelGGL((k_sdf_fuse_tiled<false, 1, CELL, 32, 4, FUSE_ZC, false, true>), grid, dim3(256), lds, s, q, cap_px);
                 else hipLaunchKernelGGL((k_sdf_fuse_tiled<false, 1, CELL>), grid, dim3(256), lds, s, q, cap_px);
             }
-            z0 = z1;
         }
     } else if (vec2) {
         dim3 grid(ceil_div(p.X, 128), ceil_div(p.Y, FUSE_ROWS), ceil_div(p.Z, FUSE_ZC));

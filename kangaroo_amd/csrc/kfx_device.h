@@ -192,6 +192,7 @@ struct kfx_sdf_summary {
     int* d_count;                // device: {running count of 32^3-cell entries of class != 0, workgroups that have added theirs}
     int* h_skippable;            // host-visible (pinned, mapped): the count the last finished build arrived at, -1 before the first
     int* d_skippable;            // the device's address of the same word
+    unsigned sweeps;             // tracked SdfFuse launches so far: every other one walks the planes from the far end (fuse.hip)
 };
 namespace kfx {
 // The class tables the march stages in LDS.  Per entry (a cube of 2^shift cells, together with the +1 cells a trilinear sample

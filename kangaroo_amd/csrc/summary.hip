@@ -231,7 +231,7 @@ extern "C" int kfx_sdf_summary_create(kfx_sdf_summary** out, const kfx_volume* v
     s->base = static_cast<const unsigned char*>(vol->ptr);
     s->pitch = vol->pitch; s->img_pitch = vol->img_pitch;
     s->R = nullptr; s->C = nullptr; s->d_count = nullptr; s->h_skippable = nullptr; s->d_skippable = nullptr;
-    s->c_dirty = 1; s->c_tol = -1.f; s->c_vref = 0.f; s->c_shift = 0;
+    s->c_dirty = 1; s->c_tol = -1.f; s->c_vref = 0.f; s->c_shift = 0; s->sweeps = 0;
     s->n_coarse = ceil_div(s->w, 32) * ceil_div(s->h, 32) * ceil_div(s->d, 32);
     const size_t n = (size_t)s->nbx * s->nby * s->nbz;
     ClassView cv;

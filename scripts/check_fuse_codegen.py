@@ -53,6 +53,9 @@ def hot_block_waits(asm_path):
             if mm:
                 flush()
                 label, block = mm.group(1), []
+            elif src[i].strip() == ";;#ASMSTART":   # hand-written (the keep-loads of the tracked kernels and their wait): not hipcc's doing
+                while i < len(src) and src[i].strip() != ";;#ASMEND":
+                    i += 1
             elif src[i].startswith("\t") and not src[i].startswith("\t.") and not src[i].startswith("\t;"):
                 block.append(src[i].strip())
             i += 1
