@@ -58,16 +58,18 @@ def parse():
                          "only rank 0 does (reduce: half the traffic)")
     ap.add_argument("--overlap", action="store_true",
                     help="N > 1, composite raycast: merge frame k's images on a second stream under frame k+1's preprocess + SdfFuse")
-    ap.add_argument("--summary", nargs="?", const="on", default="off", choices=["auto", "on", "off"],
+    ap.add_argument("--summary", nargs="?", const="on", default="auto", choices=["auto", "on", "off"],
                     help="fast math, 1 GPU: the brick summary (kfx_sdf_summary: SdfFuse keeps value ranges per 8^3 cells, RaycastSdf "
                          "marches through class tables built from them and crosses free / never-observed space without reading the "
-                         "volume).  off (default): the plain kernels -- the line's roofline is that of the untracked SdfFuse; on: "
-                         "always; auto: FramePipeline(track='auto') times both marches on frames 8-19 of the stream and keeps the "
-                         "faster (the table march wins in S_full: +15 %% frames/s, the plain one in S_room).  The line reports the "
-                         "other variant beside the headline")
-    ap.add_argument("--prime", type=int, default=150,
+                         "volume).  auto (default): FramePipeline(track='auto') times both marches on frames 8-19 of the stream and "
+                         "keeps the faster (the table march in S_full: +19 %% frames/s, the plain one in S_room); on: always; off: "
+                         "the plain kernels.  The line reports the other variant beside the headline")
+    ap.add_argument("--prime", type=int, default=450,
                     help="untimed frames of the same stream run before the W warm-up steps, so that the timed steps see a volume in "
-                         "steady state and settled clocks whatever W is (0 = start from the freshly reset volume)")
+                         "steady state and settled clocks whatever W is (0 = start from the freshly reset volume).  450 = fifteen "
+                         "orbits, 0.2 s: --summary auto decides on frames 8-19, and the clocks take ~250 frames to settle after "
+                         "those twelve frames with two marches each (SdfFuse 0.30 -> 0.277 ms in S_room, measured with "
+                         "KFX_BENCH_DUMP=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=30, help="upper bound on the timed CPU-baseline frames (the sample also stops after ~12 s)")
     return ap.parse_args()
@@ -288,6 +290,23 @@ def main():
         dist.all_reduce(chk, op=dist.ReduceOp.MAX)
         ranks_agree = bool(int(chk[0].item()) == -int(chk[1].item()))
         assert ranks_agree, "ranks hold different composite images"
+
+    # The same SdfFuse launched back to back (no RaycastSdf in between), 24 launches after 6 untimed: in the frame loop the
+    # plain march leaves ~250 MB of the volume in the 256 MiB memory-side cache and the SdfFuse that follows reads them from
+    # there; back to back nothing precedes a launch but the previous sweep (EXPERIMENTS.md 5.4).
+    back_to_back = None
+    if not distributed:
+        for k in range(30):
+            if k == 6:
+                b0 = torch.cuda.Event(enable_timing=True); b0.record()
+            pipe.fuse(poses[(args.warmup + args.steps + k) % N_ORBIT])
+        b1 = torch.cuda.Event(enable_timing=True); b1.record()
+        torch.cuda.synchronize()
+        bb_ms = b0.elapsed_time(b1) / 24
+        bb_bytes = float(np.mean([16.0 * n_updated[(args.warmup + args.steps + k) % N_ORBIT] + 20.0 * w * h for k in range(6, 30)]))
+        back_to_back = {"avg_launch_ms": round(bb_ms, 5), "achieved": round(bb_bytes / (bb_ms * 1e-3) / 1e9, 1),
+                        "frac": round(bb_bytes / (bb_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                        "note": "24 launches of the same kernel with nothing in between (the frame loop's RaycastSdf leaves part of the volume in the memory-side cache)"}
 
     # RaycastSdf and BilateralFilter by SURVEY 8(d)'s figures (1 GPU; the volume is in the timed loop's steady state).
     # RaycastSdf: algorithmic bytes 8 B x U + 24 B x w h, U = distinct voxels the reference march reads for the pose
@@ -599,6 +618,7 @@ def main():
                 "avg_launch_ms": round(fuse_avg_ms, 5),
                 "updated_fraction": round(float(np.mean([n_updated[i] for i in idx])) / local_voxels, 4),
                 "full_sweep_GBps": round(16.0 * local_voxels / (fuse_avg_ms * 1e-3) / 1e9, 1),
+                "back_to_back": back_to_back,
                 "rmw_probe": rmw_probe,
                 "full_sweep_frac_of_best_rmw_probe": (round(16.0 * local_voxels / (fuse_avg_ms * 1e-3) / 1e9 / rmw_probe["best_GBps"], 4)
                                                       if rmw_probe and rmw_probe.get("best_GBps") else None),

@@ -319,8 +319,14 @@ __device__ __forceinline__ void accumulate(const Obs& o, float max_w, float& ova
     float val = CELL::q(o.val), w = CELL::q(o.w);
     if (ow > 0) {
         if constexpr (FAST) {
+            // the running average in incremental form, old + (new - old) w / (w + ow): the same value up to rounding, and a
+            // cell that is handed the value it already holds keeps it bit for bit.  (With (w val + ow oval) * rcp(w + ow) the
+            // +trunc of free space crept away from trunc by the reciprocal's bias, a few 1e-8 per frame: after ~800 frames
+            // no free region passed the class tables' 1e-5 test any more and the table march had nothing left to skip.)
+            // (fp32 cells; the half cells keep the reference's operation order, whose every intermediate is rounded to half)
             const float ws = CELL::q(w + ow);
-            val = CELL::q(CELL::q(__builtin_fmaf(w, val, ow * oval)) * __builtin_amdgcn_rcpf(ws));
+            if constexpr (CELL::BYTES == 8) val = __builtin_fmaf(w * __builtin_amdgcn_rcpf(ws), val - oval, oval);
+            else val = CELL::q(CELL::q(__builtin_fmaf(w, val, ow * oval)) * __builtin_amdgcn_rcpf(ws));
             w = ws;
         } else {
             val = CELL::q(w * val + ow * oval);

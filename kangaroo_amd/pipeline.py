@@ -96,7 +96,10 @@ class FramePipeline:
     # track="auto": frames CAL_FIRST ... CAL_FIRST + CAL_FRAMES - 1 of the stream are timed with device events (nothing
     # waits: the events are read a few frames later, once they have completed)
     CAL_FIRST, CAL_FRAMES = 8, 12
-    TRACK_FUSE_OVERHEAD = 0.08   # what keeping the summary current costs SdfFuse, as a fraction of its time (measured: 7-9 %)
+    # what the table march costs SdfFuse, as a fraction of its time (measured at 512^3: 4-6 %; the bookkeeping itself is 1.6 %,
+    # the rest is the part of the volume the plain march leaves in the memory-side cache for the next SdfFuse and the table
+    # march does not -- EXPERIMENTS.md 5.4)
+    TRACK_FUSE_OVERHEAD = 0.06
 
     def _calibrating(self):
         c = self._cal

@@ -347,3 +347,47 @@ def test_gpu_table_march_with_unusual_truncation(roo, trunc_factor):
             for x, y in zip(a, b):
                 assert T.nan_equal(x.MemcpyToHost(), y.MemcpyToHost()), (trunc_factor, i, ray_tr, T.mismatch_report(x.MemcpyToHost(), y.MemcpyToHost()))
             assert np.isfinite(a[0].MemcpyToHost()).sum() > (100 if trunc_factor < 1 else 0.02 * w * h)   # (a band thinner than the minimum step is mostly stepped over)
+
+
+@pytest.mark.parametrize("scene", ["full", "room"])
+def test_gpu_free_space_keeps_its_value_over_a_long_stream(roo, scene):
+    """Fast numerics, 1500 frames of the orbit: a cell that is handed +trunc every frame must keep +trunc bit for bit (the
+    running average is evaluated as old + (new - old) w / (w + ow)), so the class tables see as much free space at the end of
+    the stream as after its first orbits.  With (w val + ow oval) * rcp(w + ow) the stored value crept away from trunc by the
+    reciprocal's bias and after ~800 frames the table march had nothing left to skip."""
+    import torch
+    N, w, h = 128, 160, 120
+    bmin, bmax, near, far = scenes.SCENES[scene]
+    K = scenes.intrinsics(w, h)
+    tr = scenes.trunc_dist(bmin, bmax, (N, N, N))
+    prev = roo.get_math_mode()
+    roo.set_math_mode("fast")
+    try:
+        vol = roo.BoundedVolume(N, N, N, bmin, bmax)
+        summ = roo.SdfSummary(vol)
+        roo.SdfReset(vol, float("nan"), summary=summ)
+        frames = []
+        for i in range(30):
+            T_wc = scenes.orbit_pose(i, 30)
+            f, vbo, nrm = roo.Image(w, h), roo.Image(w, h, "f32x4"), roo.Image(w, h, "f32x4")
+            roo.BilateralFilter(f, T.upload_image(roo, scenes.render_depth(scene, w, h, T_wc, K)), **scenes.BILATERAL)
+            roo.DepthToVbo(vbo, f, K)
+            roo.NormalsFromVbo(nrm, vbo)
+            frames.append((scenes.se3_inverse(T_wc), f, nrm))
+        counts = {}
+        for k in range(1500):
+            T_cw, f, nrm = frames[k % 30]
+            roo.SdfFuse(vol, f, nrm, T_cw, K, tr, scenes.MAX_W, scenes.MIN_COS_THETA, summary=summ)
+            if k + 1 in (60, 1500):
+                _, classes = export(roo, summ, 1e-5, tr, fine_shift=3)
+                counts[k + 1] = check_classes(vol, classes, 1e-5, tr)
+            if k + 1 == 60:
+                free60 = (vol.tensor()[..., 0] == tr).clone()
+        free1500 = vol.tensor()[..., 0] == tr
+        assert int(free60.sum()) > N ** 3 // 20, "the scene should leave observed free space"
+        assert bool((free1500 | ~free60).all()), "%d cells held +trunc after two orbits and no longer do" % int((free60 & ~free1500).sum())
+        for shift in counts[60]:
+            n60, n1500 = counts[60][shift][1] + counts[60][shift][3], counts[1500][shift][1] + counts[1500][shift][3]
+            assert n1500 >= n60 and (n60 > 0 or shift != 3), (shift, counts)
+    finally:
+        roo.set_math_mode(prev)
