@@ -604,7 +604,7 @@ def main():
                                                             "decision": getattr(pipe, "track_decision", None)},
                 "partition": ("z-slabs x%d, inputs %s, ghost planes %s%s, raycast %s" % (n_gpus, "preprocessed by every rank" if args.inputs == "replicate" else "preprocessed by rank 0 and broadcast", args.halo, ", merge overlapped with the next frame" if args.overlap else "", {"composite": "composite = all_reduce(MIN key) + %s(SUM payload)" % ("reduce-to-rank-0" if args.images == "root" else "all_reduce"), "exact": "exact = march state handed from slab to slab: world + 1 stages, neighbour send/recv between them, one all_reduce of the finalised pixels at the end", "exact_allreduce": "exact (cross-check) = one SUM all_reduce of the march state + a host-side termination test per round"}[args.raycast]))
                              if distributed else "single volume",
-                "math": {"fast": "fast (fp32 rcp/rsq + FMA: the reference's own -use_fast_math regime; whole chain against the exact oracle at this size, "
+                "math": {"fast": "fast (fp32 rcp/rsq + FMA: the reference's own -use_fast_math regime, running average as old + (new - old) w / (w + old.w); whole chain against the exact oracle at this size, "
                                  "tests/test_gpu_chain.py: TSDF L-inf < 1e-4 on identically classified voxels (<= 2e-6 of them classified differently); raycast images: "
                                  "no hit / miss flip, depth < 1e-4 m on all but <= 2e-5 of the hits, normals < 2e-2 rad, shade < 1e-2)",
                          "exact": "exact (IEEE fp32, no FMA contraction, reference operation order; bit-identical to the oracle)"}[args.math],
