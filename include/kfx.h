@@ -410,7 +410,10 @@ int kfx_raycast_sdf_levels_tracked(int n_levels, const kfx_image* const* depth, 
 /* KFX_MATH_EXACT (default): IEEE fp32, no FMA contraction, correctly rounded div/sqrt, reference
  * operation order -- bit-identical to the CPU oracle.  KFX_MATH_FAST: hardware rcp/rsq (1 ulp),
  * FMA, shared reciprocals -- the regime of the reference's own build (-use_fast_math,
- * CMakeLists.txt:141); within the stated tolerance (TSDF L-inf < 1e-4), not bit-exact.
+ * CMakeLists.txt:141); within the stated tolerance (TSDF L-inf < 1e-4), not bit-exact.  The running
+ * average of fp32 cells (Sdf.h:25-32) is evaluated as old + (new - old) * (w / (w + old.w)): the same
+ * value up to rounding, and a cell that is handed the value it holds keeps it bit for bit (free space
+ * stays at +trunc over any number of frames, which the class tables of kfx_sdf_summary rely on).
  * Process-global; initial value from the environment variable KFX_MATH=exact|fast.
  * Currently affects kfx_sdf_fuse and kfx_raycast_sdf. */
 #define KFX_MATH_EXACT 0
