@@ -113,9 +113,9 @@ class FramePipeline:
             return
         # the last event of the last timed frame (everything is on one stream: the earlier ones completed before it); one
         # query every fourth frame -- polling all 60 events every frame makes the launching thread slower than the GPU
-        if c["frame"] % 4 or not c["ray"][-1][2].query():
+        if c["frame"] % 4 or not c["ray"][-1][2].query() or (c["fuse"] and not c["fuse"][-1][1].query()):
             return   # still running: look again later
-        fuse = float(np.median([a.elapsed_time(b) for a, b in c["fuse"]]))
+        fuse = float(np.median([a.elapsed_time(b) for a, b in c["fuse"]])) if c["fuse"] else 0.0   # (a tracking loop that fused none of the timed frames)
         tracked = float(np.median([a.elapsed_time(b) for a, b, _ in c["ray"]]))
         plain = float(np.median([b.elapsed_time(d) for _, b, d in c["ray"]]))
         keep = tracked + self.TRACK_FUSE_OVERHEAD * fuse < 0.97 * plain
@@ -126,36 +126,46 @@ class FramePipeline:
             self.summary = None
         self._cal = None
 
-    def fuse(self, T_wc):
+    def _timed_fuse(self, integrate):
+        """integrate(kw) launches the frame's SdfFuse with kw = {"summary": ...} or {}; timed while the auto policy calibrates."""
         kw = {"summary": self.summary} if self.track else {}
         cal = self._calibrating()
         if cal:
             import torch
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()
-        self.ops.SdfFuse(self.vol, self.filtered, self.normals, scenes.se3_inverse(T_wc), self.K, self.trunc,
-                         self.max_w, self.mincostheta, **kw)
+        integrate(kw)
         if cal:
             ev[1].record()
             self._cal["fuse"].append(ev)
 
-    def raycast(self, T_wc):
+    def _timed_raycast(self, render):
+        """render(kw) launches the frame's rendering(s) of the model.  While the auto policy calibrates, the same rendering is
+        repeated by the plain march, timed, into the same images (bit-identical in exact numerics, within the fast-mode
+        tolerance otherwise): the frame's output is a valid rendering either way."""
         kw = {"summary": self.summary} if self.track else {}
         cal = self._calibrating()
         if cal:
             import torch
             ev = tuple(torch.cuda.Event(enable_timing=True) for _ in range(3))
             ev[0].record()
-        self.ops.RaycastSdf(self.ray_d, self.ray_n, self.ray_i, self.vol, T_wc, self.K, self.near, self.far,
-                            self.trunc, True, **kw)
-        if cal:   # the same rendering by the plain march, timed, into the same images (bit-identical in exact numerics, within
-            ev[1].record()   # the fast-mode tolerance otherwise): the frame's output is a valid rendering either way
-            self.ops.RaycastSdf(self.ray_d, self.ray_n, self.ray_i, self.vol, T_wc, self.K, self.near, self.far, self.trunc, True)
+        render(kw)
+        if cal:
+            ev[1].record()
+            render({})
             ev[2].record()
             self._cal["ray"].append(ev)
         if self._cal is not None:
             self._cal["frame"] += 1
             self._calibrate()
+
+    def fuse(self, T_wc):
+        self._timed_fuse(lambda kw: self.ops.SdfFuse(self.vol, self.filtered, self.normals, scenes.se3_inverse(T_wc), self.K, self.trunc,
+                                                     self.max_w, self.mincostheta, **kw))
+
+    def raycast(self, T_wc):
+        self._timed_raycast(lambda kw: self.ops.RaycastSdf(self.ray_d, self.ray_n, self.ray_i, self.vol, T_wc, self.K, self.near, self.far,
+                                                           self.trunc, True, **kw))
 
     def step(self, T_wc, raw_image=None):
         """One frame: preprocess the new depth image, integrate it, render the model."""
@@ -216,15 +226,17 @@ class TrackingPipeline(FramePipeline):
         else:
             T34 = self.T_wl[:3].astype(np.float32)
             lv = [l for l in range(self.LEVELS) if self.its[l] > 0]
-            kw = {"summary": self.summary} if self.track else {}
-            if self.one_raycast:   # the per-level RaycastSdf + DepthToVbo calls as one launch: same images, overlapping marches
-                o.RaycastSdfLevels([(self.pyr_d[l], self.pyr_n[l], self.pyr_i[l], self.pyr_v[l]) for l in lv], self.vol, T34,
-                                   [self.K_levels[l] for l in lv], self.near, self.far, self.trunc, True, **kw)
-            else:
-                for l in lv:
-                    o.RaycastSdf(self.pyr_d[l], self.pyr_n[l], self.pyr_i[l], self.vol, T34, self.K_levels[l], self.near,
-                                 self.far, self.trunc, True, **kw)
-                    o.DepthToVbo(self.pyr_v[l], self.pyr_d[l], self.K_levels[l])
+
+            def render(kw):
+                if self.one_raycast:   # the per-level RaycastSdf + DepthToVbo calls as one launch: same images, overlapping marches
+                    o.RaycastSdfLevels([(self.pyr_d[l], self.pyr_n[l], self.pyr_i[l], self.pyr_v[l]) for l in lv], self.vol, T34,
+                                       [self.K_levels[l] for l in lv], self.near, self.far, self.trunc, True, **kw)
+                else:
+                    for l in lv:
+                        o.RaycastSdf(self.pyr_d[l], self.pyr_n[l], self.pyr_i[l], self.vol, T34, self.K_levels[l], self.near,
+                                     self.far, self.trunc, True, **kw)
+                        o.DepthToVbo(self.pyr_v[l], self.pyr_d[l], self.K_levels[l])
+            self._timed_raycast(render)   # track="auto": both marches are timed on frames 8-19 and the faster one stays
             if self.device_icp:
                 T_lp, self.rmse, _, self.tracking_good = o.IcpRefine(self.kin_v, self.pyr_v, self.pyr_n, self.K_levels, self.its,
                                                                      self.icp_c, self.max_rmse, self.scratch, self.debug)
@@ -239,8 +251,8 @@ class TrackingPipeline(FramePipeline):
 
     def _fuse_at(self, T_wl):
         T_cw = self.tracking.se3_inv(T_wl)[:3].astype(np.float32)
-        kw = {"summary": self.summary} if self.track else {}
-        self.ops.SdfFuse(self.vol, self.kin_d[0], self.kin_n[0], T_cw, self.K, self.trunc, self.max_w, self.mincostheta, **kw)
+        self._timed_fuse(lambda kw: self.ops.SdfFuse(self.vol, self.kin_d[0], self.kin_n[0], T_cw, self.K, self.trunc, self.max_w,
+                                                     self.mincostheta, **kw))
 
 
 def slab_range(d, rank, world):

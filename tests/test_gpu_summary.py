@@ -317,6 +317,36 @@ def test_gpu_frame_pipeline_auto_policy(roo, scene):
         roo.set_math_mode(prev)
 
 
+def test_gpu_tracking_pipeline_auto_policy(roo):
+    """TrackingPipeline(track="auto"): the loop with pose estimation times the pyramid rendering through the tables and by the
+    plain march on frames 8-19, decides once, and tracks the orbit like the untracked loop: same poses to within the fast-mode
+    tolerance of the renderings, same volume where both fused the same frames."""
+    import torch
+    from kangaroo_amd.pipeline import TrackingPipeline
+    N, w, h = 128, 320, 240
+    scene = "room"
+    bmin, bmax, near, far = scenes.SCENES[scene]
+    prev = roo.set_math_mode("fast")
+    try:
+        auto = TrackingPipeline(roo, (N, N, N), bmin, bmax, w, h, near=near, far=far, device_icp=True, track="auto")
+        ref = TrackingPipeline(roo, (N, N, N), bmin, bmax, w, h, near=near, far=far, device_icp=True, track=False)
+        assert auto.track_policy == "auto" and auto.track
+        worst = 0.0
+        for i in range(44):
+            T_wc = scenes.orbit_pose(i % 30, 30)
+            raw = T.upload_image(roo, scenes.render_depth(scene, w, h, T_wc, auto.K))
+            Ta = auto.step(T_wc if i == 0 else None, raw)
+            Tr = ref.step(T_wc if i == 0 else None, raw)
+            worst = max(worst, float(np.abs(Ta[:3, 3] - Tr[:3, 3]).max()))
+            assert auto.tracking_good and ref.tracking_good, i
+        assert auto.track_decision is not None and auto._cal is None, "no decision after 44 frames"
+        assert auto.track == auto.track_decision["chosen"].startswith("table march") and (auto.summary is not None) == auto.track
+        assert auto.track_decision["frames_timed"] == TrackingPipeline.CAL_FRAMES and auto.track_decision["raycast_plain_ms"] > 0
+        assert worst < 2e-4, worst   # metres: the two loops see renderings that differ within the fast-mode tolerance
+    finally:
+        roo.set_math_mode(prev)
+
+
 @pytest.mark.parametrize("trunc_factor", [0.4, 1.0, 6.0])
 def test_gpu_table_march_with_unusual_truncation(roo, trunc_factor):
     """trunc_dist below the voxel size (the reference's step for a +trunc sample is then min_delta, not trunc: class 3 --
