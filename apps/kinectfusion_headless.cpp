@@ -14,7 +14,8 @@
 //   SdfFuse(work_vol, kin_d, kin_n, T_wl^-1, K, trunc_dist, max_w, mincostheta)            (:345-356)
 //
 // Host code only; all device work happens in libkfx behind the roo:: wrappers.
-// Usage: kinectfusion_headless [--res N] [--frames F] [--width W] [--height H] [--fast] [--track | --device-icp] [--fused-launches] [--summary]
+// Usage: kinectfusion_headless [--res N] [--frames F] [--width W] [--height H] [--fast] [--track | --device-icp] [--fused-launches] [--summary | --summary-auto]
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -70,7 +71,7 @@ static Mat<float,3,4> OrbitPose(int i, int n)
 int main(int argc, char** argv)
 {
     int volres = 256, frames = 30, w = 640, h = 480;   // the application's defaults (main.cpp:90-91)
-    bool fast = false, track = false, device_icp = false, one_raycast = false, use_summary = false;
+    bool fast = false, track = false, device_icp = false, one_raycast = false, use_summary = false, summary_auto = false;
     for (int i = 1; i < argc; ++i) {
         if (!strcmp(argv[i], "--res") && i + 1 < argc) volres = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--frames") && i + 1 < argc) frames = atoi(argv[++i]);
@@ -79,6 +80,7 @@ int main(int argc, char** argv)
         else if (!strcmp(argv[i], "--fast")) fast = true;
         else if (!strcmp(argv[i], "--track")) track = true;
         else if (!strcmp(argv[i], "--summary")) use_summary = true;   // roo::SdfSummary: SdfFuse keeps it current, RaycastSdf marches through its class tables
+        else if (!strcmp(argv[i], "--summary-auto")) use_summary = summary_auto = true;   // ... and the application keeps it only if it pays (frames 8-19 time both marches)
         else if (!strcmp(argv[i], "--one-raycast") || !strcmp(argv[i], "--fused-launches")) one_raycast = true;   // additions beside the reference API: all pyramid levels rendered by one launch, vbo + normals in one launch
         else if (!strcmp(argv[i], "--device-icp")) track = device_icp = true;   // the refinement loop as one device-side chain
     }
@@ -106,6 +108,7 @@ int main(int argc, char** argv)
     const float icp_c = 0.1f, max_rmse = 0.10f;                                                   // main.cpp:154,162
 
     std::unique_ptr<SdfSummary> summary;
+    std::vector<double> cal_tables, cal_plain, cal_fuse;   // --summary-auto: host-clock times of frames 8-19
     if (use_summary) summary.reset(new SdfSummary(vol));
     const float3 vs = vol.VoxelSizeUnits();
     const float trunc_dist = trunc_dist_factor * length(vs);   // main.cpp:221
@@ -155,6 +158,7 @@ int main(int argc, char** argv)
         const BoundingBox roi(T_wl, w, h, K, knear, kfar);
         BoundedVolume<SDF_t> work_vol = vol.SubBoundingVolume(roi);
         if (work_vol.IsValid()) {
+            const auto render = [&](bool use_summary) {   // (the parameter shadows the setting: the calibration frames render both ways)
             if (one_raycast) {   // the same images from one launch: the levels' marches overlap (kfx_raycast_sdf_levels)
                 Image<float> rd[MaxLevels], ri[MaxLevels];
                 Image<float4> rn[MaxLevels], rv[MaxLevels];
@@ -173,6 +177,27 @@ int main(int argc, char** argv)
                         DepthToVbo<float>(ray_v[l], ray_d[l], Kl);
                     }
                 }
+            }
+            };
+            // --summary-auto, frames 8-19: the rendering through the class tables and, into the same images, by the plain march,
+            // each between two synchronisations and timed by the host clock (the plain march's time is instrumentation and is
+            // taken off the frame's); the frame's images are a valid rendering either way.  The policy of FramePipeline
+            // (kangaroo_amd/pipeline.py) in the application's terms.
+            const bool calibrating = summary_auto && use_summary && f >= 8 && f < 20;
+            if (calibrating) {
+                kfx_stream_synchronize(0);
+                const auto c0 = std::chrono::steady_clock::now();
+                render(true);
+                kfx_stream_synchronize(0);
+                const auto c1 = std::chrono::steady_clock::now();
+                render(false);
+                kfx_stream_synchronize(0);
+                const auto c2 = std::chrono::steady_clock::now();
+                cal_tables.push_back(std::chrono::duration<double, std::milli>(c1 - c0).count());
+                cal_plain.push_back(std::chrono::duration<double, std::milli>(c2 - c1).count());
+                total_ms -= cal_plain.back();
+            } else {
+                render(use_summary);
             }
             bool tracking_good = true;
             if (track && f > 0) {   // main.cpp:299-341
@@ -243,11 +268,25 @@ int main(int argc, char** argv)
                 worst_pos_err = std::fmax(worst_pos_err, std::sqrt(e));
             }
             if (f > 0 && tracking_good) {
+                if (calibrating) kfx_stream_synchronize(0);
+                const auto c0 = std::chrono::steady_clock::now();
                 if (use_summary) SdfFuse(work_vol, *summary, kin_d[0], kin_n[0], SE3inv(T_wl), K, trunc_dist, max_w, mincostheta);
                 else SdfFuse(work_vol, kin_d[0], kin_n[0], SE3inv(T_wl), K, trunc_dist, max_w, mincostheta);
+                if (calibrating) {
+                    kfx_stream_synchronize(0);
+                    cal_fuse.push_back(std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - c0).count());
+                }
             }
         }
         kfx_stream_synchronize(0);
+        if (summary_auto && use_summary && f == 19 && !cal_plain.empty()) {   // decide once: tables + what they cost SdfFuse against the plain march
+            const auto median = [](std::vector<double> v) { std::sort(v.begin(), v.end()); return v.empty() ? 0.0 : v[v.size() / 2]; };
+            const double tab = median(cal_tables), plain = median(cal_plain), fuse = median(cal_fuse);
+            const bool keep = tab + 0.06 * fuse < 0.97 * plain;
+            printf("  --summary-auto: raycast through the tables %.3f ms, plain %.3f ms, tracked SdfFuse %.3f ms -> %s\n", tab, plain, fuse,
+                   keep ? "table march" : "plain march");
+            if (!keep) { use_summary = false; summary.reset(); }
+        }
         total_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         if (f == frames - 1) {
             ray_d[0].MemcpyToHost(hdepth.data());

@@ -125,3 +125,26 @@ def test_headless_app_with_brick_summary_renders_the_same_images(extra):
         assert m and int(m.group(1)) > 1000, out.stdout
         sums.append(m.group(2))
     assert sums[0] == sums[1], sums
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("extra", [[], ["--device-icp", "--fused-launches"]])
+def test_headless_app_summary_auto_decides_and_renders_the_same_images(extra):
+    """--summary-auto: the application times the rendering through the class tables and by the plain march on frames 8-19,
+    keeps the faster from frame 20 on and says which.  Exact numerics: whichever it keeps, the last rendering has the bit
+    pattern of the run without the summary."""
+    import re
+    _build()
+    sums = []
+    for flag in ([], ["--summary-auto"]):
+        out = subprocess.run([os.path.join(APPS, "kinectfusion_headless"), "--res", "128", "--frames", "30"] + extra + flag,
+                             capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stdout + out.stderr
+        m = re.search(r"last raycast hits (\d+)/\d+.*depth checksum ([0-9a-f]{16})", out.stdout)
+        assert m and int(m.group(1)) > 1000, out.stdout
+        sums.append(m.group(2))
+        if flag:
+            d = re.search(r"--summary-auto: raycast through the tables ([0-9.]+) ms, plain ([0-9.]+) ms, tracked SdfFuse ([0-9.]+) ms -> (table|plain) march", out.stdout)
+            assert d and float(d.group(1)) > 0 and float(d.group(2)) > 0, out.stdout
+            assert ("(brick summary)" in out.stdout) == (d.group(4) == "table"), out.stdout
+    assert sums[0] == sums[1], sums
