@@ -697,8 +697,10 @@ __global__ __launch_bounds__(256, (FAST && ZU == 2) ? 8 : (!FAST ? 6 : 1)) void 
 
         // the cell pairs of up to ZU slices.  `keep` bricks (TRACK: the planes the next sweep starts with) use ordinary loads,
         // which leave the lines in the 256 MiB memory-side cache.  Written as asm: given `keep ? plain load : nontemporal
-        // load` of one address hipcc emits a single plain load for both cases.  The loads are requested in place ("+v": no
-        // copy of a register whose data has not arrived), one wait covers them.
+        // load` of one address hipcc emits a single plain load for both cases.  The compiler does not know the loads are in
+        // flight: the wait's "+v" operands keep the destination registers allocated and untouched until the data has arrived
+        // (the idiom of RayF32::issue / finish, sampling.h); tests/test_gpu_chain.py and test_gpu_summary.py compare the
+        // tracked volume with the untracked one bit for bit, at sizes where all and where a quarter of the planes take this path.
         auto load_cells = [&](float4 (&c)[ZU], const bool (&any)[ZU], const unsigned char* at) {
             if constexpr (TRACK && FAST && CELL::BYTES == 8 && ZU <= 2) {   // (the bit-exact kernels are bound by issue, not by memory)
                 if (keep) { // uniform
