@@ -82,17 +82,65 @@ def register_budget(asm_path):
     return out
 
 
+def keep_load_hazards(asm_path):
+    """The tracked fast kernels request the cells of the cached planes with hand-written `global_load_dwordx4 v[a:b], ..., off`
+    blocks and wait for them in a later `s_waitcnt vmcnt(0)` block (load_cells, fuse.hip).  hipcc does not know the loads are
+    in flight, so nothing it emits between a request and the next such wait may touch the destination registers.  Returns
+    (number of requests seen, [(kernel, line number, text)] of instructions that do)."""
+    src = open(asm_path).read().split("\n")
+    bad, seen = [], 0
+    kernel, pending, in_asm = None, {}, False
+    for n, line in enumerate(src):
+        m = re.match(r"^(_ZN3kfx16k_sdf_fuse_tiled\w+):", line)
+        if m:
+            kernel, pending = m.group(1), {}
+            continue
+        if kernel is None:
+            continue
+        if line.startswith(".Lfunc_end"):
+            kernel = None
+            continue
+        t = line.strip()
+        if t == ";;#ASMSTART":
+            in_asm = True
+            continue
+        if t == ";;#ASMEND":
+            in_asm = False
+            continue
+        if not line.startswith("\t") or t.startswith(".") or t.startswith(";"):
+            continue
+        if in_asm:
+            m = re.match(r"global_load_dwordx4 v\[(\d+):(\d+)\], v\[\d+:\d+\], off$", t)
+            if m:
+                seen += 1
+                pending[(int(m.group(1)), int(m.group(2)))] = n
+            elif t.startswith("s_waitcnt") and "vmcnt(0)" in t:
+                pending = {}
+            continue
+        if pending:
+            regs = set()
+            for a, b in re.findall(r"\bv\[(\d+):(\d+)\]", t):
+                regs.update(range(int(a), int(b) + 1))
+            regs.update(int(a) for a in re.findall(r"\bv(\d+)\b", t))
+            for (a, b) in pending:
+                if regs & set(range(a, b + 1)):
+                    bad.append((kernel, n + 1, t))
+    return seen, bad
+
+
 def main():
     if len(sys.argv) > 1:
         path = sys.argv[1]
         kernels, found = hot_block_waits(path)
         budget = register_budget(path)
+        keep_seen, keep_bad = keep_load_hazards(path)
     else:
         with tempfile.TemporaryDirectory() as d:
             path = os.path.join(d, "fuse.s")
             compile_to_asm(path)
             kernels, found = hot_block_waits(path)
             budget = register_budget(path)
+            keep_seen, keep_bad = keep_load_hazards(path)
     print("%d k_sdf_fuse_tiled instantiations, %d vector-memory waits inside observation blocks" % (kernels, len(found)))
     for f in found:
         print("  %s %s [%d] %s" % f)
@@ -100,7 +148,10 @@ def main():
     print("%d budgeted instantiations (fast two-slice: 64 VGPRs, bit-exact untracked: 80), %d over the VGPR / no-scratch budget" % (len(budget), len(over)))
     for b in over:
         print("  %s NumVgprs %s ScratchSize %s (budget %d)" % b)
-    return 1 if (found or kernels == 0 or over or not budget) else 0
+    print("%d hand-written cell requests in the tracked kernels, %d instructions touching their registers before the wait" % (keep_seen, len(keep_bad)))
+    for b in keep_bad[:20]:
+        print("  %s line %d: %s" % b)
+    return 1 if (found or kernels == 0 or over or not budget or keep_seen == 0 or keep_bad) else 0
 
 
 if __name__ == "__main__":

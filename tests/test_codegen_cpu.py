@@ -16,3 +16,5 @@ def test_fuse_voxel_loops_do_not_wait_for_vector_memory():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "check_fuse_codegen.py")], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "0 vector-memory waits" in out.stdout and ", 0 over the VGPR" in out.stdout
+    # the tracked fast kernels' hand-written loads of the cached planes: nothing touches a destination register before the wait
+    assert ", 0 instructions touching their registers before the wait" in out.stdout and " 0 hand-written" not in out.stdout
