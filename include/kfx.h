@@ -401,10 +401,66 @@ int kfx_sdf_fuse_tracked(const kfx_volume* vol, kfx_sdf_summary* s, const kfx_im
 int kfx_raycast_sdf_tracked(const kfx_image* depth, const kfx_image* norm, const kfx_image* img, const kfx_volume* vol,
                             kfx_sdf_summary* s, const float T_wc[12], const float K[4], float near, float far,
                             float trunc_dist, int subpix, kfx_stream stream);
+/* Diagnostics: kfx_raycast_sdf_count for the march kfx_raycast_sdf_tracked would run (the class-table march, or the plain one
+ * where the tracked call falls back to it).  d_counters[6], added to: samples taken, rays that enter the box, hits, distinct
+ * voxels read (U), table look-ups, bytes of class tables a workgroup stages (0: plain march).  bench.py prices the table
+ * march's algorithmic bytes with it: 8 B x U + table bytes + 24 B x w h. */
+int kfx_raycast_sdf_count_tracked(const kfx_volume* vol, kfx_sdf_summary* s, unsigned w, unsigned h, const float T_wc[12], const float K[4],
+                                  float near, float far, float trunc_dist, int subpix, unsigned* d_bitmap, unsigned long long* d_counters,
+                                  kfx_stream stream);
 /* kfx_raycast_sdf_levels (several renderings of the model in one launch) with the summary consulted in every march */
 int kfx_raycast_sdf_levels_tracked(int n_levels, const kfx_image* const* depth, const kfx_image* const* norm, const kfx_image* const* img,
                                    const kfx_image* const* vbo, const kfx_volume* vol, kfx_sdf_summary* s, const float T_wc[12],
                                    const float* K, float near, float far, float trunc_dist, int subpix, kfx_stream stream);
+
+/* Recompute the summary from what the volume holds (one pass over the parent volume: 8 B x cells of reads): the way back to a
+ * summary that describes the volume after writers that do not track (untracked kfx_sdf_fuse, copies, LoadPXM, kfx_sdf_sphere)
+ * -- every brick gets the exact range of its valued cells and the exact state, instead of kfx_sdf_summary_invalidate's
+ * "nothing is known".  fp32 cells. */
+int kfx_sdf_summary_rebuild(kfx_sdf_summary* s, kfx_stream stream);
+
+/* ---- one frame of the application's loop as ONE call (no reference counterpart in the operator API) ----------------
+ * The per-frame sequence of applications/kinectfusion/main.cpp:200-356 for a stream with known poses, enqueued by the
+ * library itself: BilateralFilter(filtered, raw) -> DepthToVbo(vbo, filtered, K) -> NormalsFromVbo(normals, vbo)
+ * (main.cpp:209-215) -> SdfFuse(vol, filtered, normals, T_cw, ...) (main.cpp:345-356) -> RaycastSdf(ray_*, vol, T_wc, ...)
+ * (main.cpp:286) -- exactly the launches the separate entry points above make, in that order on `stream`, so the images and
+ * the volume are bit-identical to calling them one by one; what it saves is the host time between launches (a frame is
+ * ~0.45 ms of GPU work at 512^3: an interpreter that issues seven calls per frame can fall behind it).
+ * A kfx_frame owns nothing but its optional brick summary and its timing events: volume and images are the caller's views.
+ *   kfx_frame_set_track(f, 1): SdfFuse / RaycastSdf go through kfx_sdf_fuse_tracked / kfx_raycast_sdf_tracked with a summary
+ *     the frame creates on first use and (re)builds from the volume's contents (kfx_sdf_summary_rebuild); 0: the plain pair.
+ *   kfx_frame_step(f, raw, T_wc, T_cw, parts, stream): raw NULL = cfg.raw; T_cw NULL = inverse of T_wc (R^T, -R^T t in double,
+ *     rounded once); parts = KFX_FRAME_* bits, 0 = all.
+ *   Timing: with cfg.timing_slots = n > 0 every step records four device events on `stream` (before the preprocess, before
+ *     SdfFuse, after SdfFuse, after RaycastSdf) in a ring of the last n frames.  kfx_frame_timings waits for the last of the
+ *     frames asked for and returns KFX_FRAME_TIMING_FIELDS floats per frame, in ms: preprocess, SdfFuse, RaycastSdf (tracked:
+ *     the class-table build included), the whole frame, and the period = start of this frame to the start of the next one (NaN
+ *     for the most recent frame) -- what a frames/s figure is made of.  Frames that have left the ring: KFX_E_RANGE. */
+typedef struct kfx_frame kfx_frame;
+typedef struct kfx_frame_config {
+    kfx_volume vol;                          /* BoundedVolume<SDF_t> (fp32 cells) */
+    kfx_image raw, filtered, vbo, normals;   /* depth in (metres), BilateralFilter out, DepthToVbo out, NormalsFromVbo out */
+    kfx_image ray_depth, ray_norm, ray_img;  /* RaycastSdf outputs */
+    float K[4];
+    float bilateral_gs, bilateral_gr, bilateral_minval;   /* main.cpp:149-151,209 */
+    unsigned bilateral_size;
+    float near, far, trunc_dist, max_w, mincostheta;      /* main.cpp:80-81,155-158,221 */
+    unsigned fuse_flags;                     /* KFX_FUSE_* */
+    int timing_slots;                        /* 0: no events */
+} kfx_frame_config;
+#define KFX_FRAME_PREPROCESS 1u
+#define KFX_FRAME_FUSE       2u
+#define KFX_FRAME_RAYCAST    4u
+#define KFX_FRAME_TIMING_FIELDS 5
+int kfx_frame_create(kfx_frame** out, const kfx_frame_config* cfg);
+int kfx_frame_destroy(kfx_frame* f);
+int kfx_frame_reset(kfx_frame* f, kfx_stream stream);             /* SdfReset(vol, NaN) (main.cpp:229), summary set to match */
+int kfx_frame_set_track(kfx_frame* f, int on, kfx_stream stream);
+int kfx_frame_get_track(const kfx_frame* f);
+kfx_sdf_summary* kfx_frame_summary(kfx_frame* f);                 /* the frame's own summary (NULL before the first set_track(1)) */
+long long kfx_frame_count(const kfx_frame* f);                    /* frames stepped so far = index of the next frame */
+int kfx_frame_step(kfx_frame* f, const kfx_image* raw, const float T_wc[12], const float* T_cw, unsigned parts, kfx_stream stream);
+int kfx_frame_timings(kfx_frame* f, long long first_frame, int n_frames, float* ms);
 
 /* ---- numerics mode --------------------------------------------------------------- */
 /* KFX_MATH_EXACT (default): IEEE fp32, no FMA contraction, correctly rounded div/sqrt, reference

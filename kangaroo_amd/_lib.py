@@ -44,6 +44,15 @@ class KfxSlab(C.Structure):
     _fields_ = [("full_d", C.c_size_t), ("z_offset", C.c_size_t), ("full_zmin", C.c_float), ("full_zmax", C.c_float)]
 
 
+class KfxFrameConfig(C.Structure):
+    """kfx_frame_config (include/kfx.h): the views and parameters of one frame of the application's loop."""
+    _fields_ = [("vol", KfxVolume), ("raw", KfxImage), ("filtered", KfxImage), ("vbo", KfxImage), ("normals", KfxImage),
+                ("ray_depth", KfxImage), ("ray_norm", KfxImage), ("ray_img", KfxImage), ("K", C.c_float * 4),
+                ("bilateral_gs", C.c_float), ("bilateral_gr", C.c_float), ("bilateral_minval", C.c_float), ("bilateral_size", C.c_uint),
+                ("near", C.c_float), ("far", C.c_float), ("trunc_dist", C.c_float), ("max_w", C.c_float), ("mincostheta", C.c_float),
+                ("fuse_flags", C.c_uint), ("timing_slots", C.c_int)]
+
+
 class KfxError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__("libkfx error %d: %s" % (code, msg))
@@ -123,6 +132,17 @@ SIGNATURES = {
     "kfx_sdf_reset_tracked": (C.c_int, [PV, C.c_void_p, C.c_float, C.c_void_p]),
     "kfx_sdf_fuse_tracked": (C.c_int, [PV, C.c_void_p, PI, PI, PF, PF, C.c_float, C.c_float, C.c_float, C.c_uint, C.c_void_p]),
     "kfx_raycast_sdf_tracked": (C.c_int, [PI, PI, PI, PV, C.c_void_p, PF, PF, C.c_float, C.c_float, C.c_float, C.c_int, C.c_void_p]),
+    "kfx_sdf_summary_rebuild": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "kfx_raycast_sdf_count_tracked": (C.c_int, [PV, C.c_void_p, C.c_uint, C.c_uint, PF, PF, C.c_float, C.c_float, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "kfx_frame_create": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(KfxFrameConfig)]),
+    "kfx_frame_destroy": (C.c_int, [C.c_void_p]),
+    "kfx_frame_reset": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "kfx_frame_set_track": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "kfx_frame_get_track": (C.c_int, [C.c_void_p]),
+    "kfx_frame_summary": (C.c_void_p, [C.c_void_p]),
+    "kfx_frame_count": (C.c_longlong, [C.c_void_p]),
+    "kfx_frame_step": (C.c_int, [C.c_void_p, PI, PF, PF, C.c_uint, C.c_void_p]),
+    "kfx_frame_timings": (C.c_int, [C.c_void_p, C.c_longlong, C.c_int, PF]),
     "kfx_raycast_sdf_levels_tracked": (C.c_int, [C.c_int, C.POINTER(PI), C.POINTER(PI), C.POINTER(PI), C.POINTER(PI), PV, C.c_void_p, PF, PF, C.c_float, C.c_float, C.c_float, C.c_int, C.c_void_p]),
 }
 

@@ -149,8 +149,12 @@ __device__ __forceinline__ int class_lookup(const unsigned* tab, const ClassLeve
     return (int)((w.x >> (bx & 31)) & 1u) | (int)(((w.y >> (bx & 31)) & 1u) << 1);
 }
 
-template <typename CELL, bool COLOR>
-__device__ __forceinline__ float raycast_pixel_classes(const RayParams& p, const RayParams& q, const ColorGeom& cv, const int u, const int v, const ClassView& cl, const unsigned* tab)
+// COUNT (kfx_raycast_sdf_count_tracked): the same march with every cell it reads marked in a bitmap and its samples, table
+// look-ups and hits counted in cnt[] = {samples, look-ups, hit, newly marked cells}; writes no image.
+__device__ __forceinline__ unsigned touch(unsigned* bitmap, const VolView& v, int x, int y, int z);
+template <typename CELL, bool COLOR, bool COUNT = false>
+__device__ __forceinline__ float raycast_pixel_classes(const RayParams& p, const RayParams& q, const ColorGeom& cv, const int u, const int v, const ClassView& cl, const unsigned* tab,
+                                                       unsigned* bitmap = nullptr, unsigned* cnt = nullptr)
 {
     // p: the launch parameters as kernel arguments (scalar registers); q: the workgroup's copy of them in LDS, read by the
     // epilogue -- pose, intrinsics, output images and the gradient's geometry are then not held in scalar registers across the
@@ -200,8 +204,13 @@ __device__ __forceinline__ float raycast_pixel_classes(const RayParams& p, const
             if (!look) {
                 c = cell_of(p, c_w + ray_w * lambda);
                 trilinear_issue(fl, p, c);
+                if constexpr (COUNT) {
+                    cnt[0] += 1;
+                    for (int k = 0; k < 8; ++k) cnt[3] += touch(bitmap, p.vol, c.ix + (k & 1), c.iy + ((k >> 1) & 1), c.iz + (k >> 2));
+                }
             }
             if (look) {
+                if constexpr (COUNT) cnt[1] += 1;
                 const float ex = __builtin_fmaf(pfB.x, lambda, pfA.x), ey = __builtin_fmaf(pfB.y, lambda, pfA.y), ez = __builtin_fmaf(pfB.z, lambda, pfA.z);
                 const float flx = floorf(ex), fly = floorf(ey), flz = floorf(ez);
                 const float lo_f = fminf(fminf(ex - flx, ey - fly), ez - flz), hi_f = fmaxf(fmaxf(ex - flx, ey - fly), ez - flz);
@@ -264,7 +273,14 @@ __device__ __forceinline__ float raycast_pixel_classes(const RayParams& p, const
                 wait = max(wait - 1, 0);
                 if (sdf <= 0) {
                     // a crossing needs the previous sample's value: the one thing a class-3 step left open
-                    if (pending) last_sdf = trilinear<CELL>(p, c_w + ray_w * lambda_prev);
+                    if (pending) {
+                        last_sdf = trilinear<CELL>(p, c_w + ray_w * lambda_prev);
+                        if constexpr (COUNT) {
+                            const CellPos cp = cell_of(p, c_w + ray_w * lambda_prev);
+                            cnt[0] += 1;
+                            for (int k = 0; k < 8; ++k) cnt[3] += touch(bitmap, p.vol, cp.ix + (k & 1), cp.iy + ((k >> 1) & 1), cp.iz + (k >> 2));
+                        }
+                    }
                     if (last_sdf > 0) {
                         if (p.subpix) lambda = lambda + delta * sdf / (last_sdf - sdf);
                         depth = lambda;
@@ -280,6 +296,19 @@ __device__ __forceinline__ float raycast_pixel_classes(const RayParams& p, const
         }
     }
 
+    if constexpr (COUNT) {   // the gradient's cells of a hit (the 20 of {-1, 0, 1}^3 with at most one coordinate at -1: sampling.h)
+        if (depth > 0) {
+            cnt[2] += 1;
+            const V3 pos_v = div_cw(c_w + ray_w * depth - p.vol.bmin, p.size);
+            const int ix = (int)fmaxf(fminf(p.hi2.x, floorf(pos_v.x * p.dims1.x)), 1.f), iy = (int)fmaxf(fminf(p.hi2.y, floorf(pos_v.y * p.dims1.y)), 1.f),
+                      iz = (int)fmaxf(fminf(p.hi2.z, floorf(pos_v.z * p.dims1.z)), 1.f);
+            for (int dz = -1; dz < 2; ++dz)
+                for (int dy = -1; dy < 2; ++dy)
+                    for (int dx = -1; dx < 2; ++dx)
+                        if ((dx < 0) + (dy < 0) + (dz < 0) <= 1) cnt[3] += touch(bitmap, p.vol, ix + dx, iy + dy, iz + dz);
+        }
+        return depth > 0 ? depth : __builtin_nanf("");
+    }
     float* pd = reinterpret_cast<float*>(q.dptr + (size_t)v * q.dpitch) + u;
     float* pi = reinterpret_cast<float*>(q.iptr + (size_t)v * q.ipitch) + u;
     float4* pn = reinterpret_cast<float4*>(q.nptr + (size_t)v * q.npitch) + u;
@@ -419,6 +448,45 @@ __global__ __launch_bounds__(256) void k_raycast_sdf_count(const RayParams p, un
         if (hit) atomicAdd(&counters[2], (unsigned long long)hit);
         if (n_new) atomicAdd(&counters[3], (unsigned long long)n_new);
     }
+}
+
+// the same for the march through the class tables: counters = {samples, rays that enter the box, hits, U, table look-ups, table bytes}
+template <typename CELL>
+__global__ __launch_bounds__(256) void k_raycast_sdf_classes_count(const RayParams p, const ClassView cl, unsigned* __restrict__ bitmap,
+                                                                   unsigned long long* __restrict__ counters)
+{
+    extern __shared__ unsigned s_tab[];
+    __shared__ RayParams s_p;
+    if (threadIdx.x == 0) s_p = p;
+    classes_stage(cl, s_tab);   // (barrier inside)
+    int u, v;
+    ray_pixel_of(p, blockIdx.x, blockIdx.y, threadIdx.x, u, v);
+    unsigned cnt[4] = {0u, 0u, 0u, 0u}, entered = 0;
+    if (u < p.w && v < p.h) {
+        const V3 c_w = v3(p.T.m[3], p.T.m[7], p.T.m[11]);
+        const V3 ray_c = v3(((float)u - p.K.u0) / p.K.fu, ((float)v - p.K.v0) / p.K.fv, 1.0f);
+        const V3 ray_w = so3_mul(p.T, ray_c);
+        const V3 ta = div_cw(p.vol.bmin - c_w, ray_w);
+        const V3 tb = div_cw(p.vol.bmax - c_w, ray_w);
+        const V3 tmin = v3(fminf(ta.x, tb.x), fminf(ta.y, tb.y), fminf(ta.z, tb.z));
+        const V3 tmax = v3(fmaxf(ta.x, tb.x), fmaxf(ta.y, tb.y), fmaxf(ta.z, tb.z));
+        entered = fmaxf(fmaxf(fmaxf(tmin.x, tmin.y), tmin.z), p.near) < fminf(fminf(fminf(tmax.x, tmax.y), tmax.z), p.far) ? 1u : 0u;
+        raycast_pixel_classes<CELL, false, true>(p, s_p, ColorGeom{}, u, v, cl, s_tab, bitmap, cnt);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        cnt[0] += __shfl_xor(cnt[0], off, 64); cnt[1] += __shfl_xor(cnt[1], off, 64);
+        cnt[2] += __shfl_xor(cnt[2], off, 64); cnt[3] += __shfl_xor(cnt[3], off, 64);
+        entered += __shfl_xor(entered, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (cnt[0]) atomicAdd(&counters[0], (unsigned long long)cnt[0]);
+        if (entered) atomicAdd(&counters[1], (unsigned long long)entered);
+        if (cnt[2]) atomicAdd(&counters[2], (unsigned long long)cnt[2]);
+        if (cnt[3]) atomicAdd(&counters[3], (unsigned long long)cnt[3]);
+        if (cnt[1]) atomicAdd(&counters[4], (unsigned long long)cnt[1]);
+    }
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) atomicAdd(&counters[5], (unsigned long long)cl.words * 4ull);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -853,6 +921,26 @@ extern "C" int kfx_raycast_sdf_count(const kfx_volume* vol, unsigned w, unsigned
     p.dptr = p.nptr = p.iptr = nullptr;
     hipLaunchKernelGGL(k_raycast_sdf_count<RayF32>, dim3(ceil_div(p.w, 64), ceil_div(p.h, 4)), dim3(256), 0, (hipStream_t)stream, p, d_bitmap, d_counters);
     return check_launch("kfx_raycast_sdf_count");
+}
+
+extern "C" int kfx_raycast_sdf_count_tracked(const kfx_volume* vol, kfx_sdf_summary* summary, unsigned w, unsigned h, const float T_wc[12], const float K[4],
+                                             float near, float far, float trunc_dist, int subpix, unsigned* d_bitmap, unsigned long long* d_counters,
+                                             kfx_stream stream)
+{
+    if (!d_bitmap || !d_counters || !summary) return set_error(KFX_E_NULL, "kfx_raycast_sdf_count_tracked: null argument");
+    kfx_image dummy = {(size_t)w * 16, (void*)(uintptr_t)16, w, h};
+    RayParams p;
+    if (int e = ray_params<RayF32>(p, &dummy, &dummy, &dummy, vol, T_wc, K, near, far, trunc_dist, subpix)) return e;
+    if (p.w == 0 || p.h == 0) return 0;
+    p.dptr = p.nptr = p.iptr = nullptr;
+    ClassView cl;
+    size_t cl_bytes = 0;
+    int usable = 0;
+    if (int e = class_view(cl, &cl_bytes, &usable, summary, vol, p, stream)) return e;
+    const dim3 grid(ceil_div(p.w, 64), ceil_div(p.h, 4));
+    if (usable) hipLaunchKernelGGL(k_raycast_sdf_classes_count<RayF32>, grid, dim3(256), cl_bytes, (hipStream_t)stream, p, cl, d_bitmap, d_counters);
+    else hipLaunchKernelGGL(k_raycast_sdf_count<RayF32>, grid, dim3(256), 0, (hipStream_t)stream, p, d_bitmap, d_counters);   // what the tracked call would launch
+    return check_launch("kfx_raycast_sdf_count_tracked");
 }
 
 extern "C" int kfx_raycast_sdf_tracked(const kfx_image* depth, const kfx_image* norm, const kfx_image* img, const kfx_volume* vol,

@@ -150,6 +150,56 @@ __global__ __launch_bounds__(256) void k_summary_classes_coarse(const ClassBuild
     }
 }
 
+// kfx_sdf_summary_rebuild: R from the volume itself.  One wave per 8 x 8 x 8 brick: a lane reads one row of eight cells (four
+// 16-byte loads: 64 contiguous bytes), keeps the range of the values and whether it saw a NaN / a value; DPP and permlane swaps
+// reduce the wave.  The states are the TRACK kernels' (kfx_device.h): 0 every cell valued, 1 every cell NaN, 2 both kinds --
+// with the exact range of the valued cells in every case, which is at least as tight as what tracking arrives at.
+__global__ __launch_bounds__(256) void k_summary_rebuild(float4* __restrict__ R, const unsigned char* __restrict__ base, size_t pitch, size_t img_pitch,
+                                                         int w, int h, int d, int nbx, int nby, int nbz, int aligned16)
+{
+    const long long brick = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (brick >= (long long)nbx * nby * nbz) return;   // wave-uniform
+    const int lane = threadIdx.x & 63;
+    const int bx = (int)(brick % nbx), by = (int)((brick / nbx) % nby), bz = (int)(brick / ((long long)nbx * nby));
+    const int y = by * 8 + (lane & 7), z = bz * 8 + (lane >> 3), x0 = bx * 8;
+    float lo = __builtin_inff(), hi = -__builtin_inff();
+    bool nan = false, val = false;
+    if (y < h && z < d) {
+        const unsigned char* row = base + (size_t)z * img_pitch + (size_t)y * pitch + (size_t)x0 * 8;
+        if (x0 + 8 <= w && aligned16) {
+            float4 c[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) c[k] = reinterpret_cast<const float4*>(row)[k];   // {val, w, val, w}
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float a = c[k].x, b = c[k].z;
+                nan = nan || a != a || b != b;
+                val = val || a == a || b == b;
+                lo = fminf(lo, fminf(a, b));   // (minNum / maxNum: a NaN operand leaves the other)
+                hi = fmaxf(hi, fmaxf(a, b));
+            }
+        } else {
+            for (int x = x0; x < w; ++x) {
+                const float a = *reinterpret_cast<const float*>(row + (size_t)(x - x0) * 8);
+                nan = nan || a != a;
+                val = val || a == a;
+                lo = fminf(lo, a);
+                hi = fmaxf(hi, a);
+            }
+        }
+    }
+    const auto fmin2 = [](float a, float b) { return fminf(a, b); };
+    const auto fmax2 = [](float a, float b) { return fmaxf(a, b); };
+    lo = wave_xor_combine<1>(lo, fmin2); hi = wave_xor_combine<1>(hi, fmax2);
+    lo = wave_xor_combine<2>(lo, fmin2); hi = wave_xor_combine<2>(hi, fmax2);
+#pragma unroll
+    for (int off = 4; off <= 8; off <<= 1) { lo = fminf(lo, __shfl_xor(lo, off, 64)); hi = fmaxf(hi, __shfl_xor(hi, off, 64)); }
+    lo = wave_xor_combine<16>(lo, fmin2); hi = wave_xor_combine<16>(hi, fmax2);
+    lo = wave_xor_combine<32>(lo, fmin2); hi = wave_xor_combine<32>(hi, fmax2);
+    const bool any_nan = __ballot(nan) != 0ull, any_val = __ballot(val) != 0ull;
+    if (lane == 0) R[brick] = make_float4(lo, hi, __int_as_float(any_val ? (any_nan ? 2 : 0) : 1), 0.f);
+}
+
 static void class_level(ClassLevel& L, int shift, int w, int h, int first)
 {
     L.shift = shift;
@@ -272,6 +322,17 @@ extern "C" int kfx_sdf_summary_destroy(kfx_sdf_summary* s)
     else if (s->d_skippable) (void)hipFree(s->d_skippable);
     delete s;
     return 0;
+}
+
+extern "C" int kfx_sdf_summary_rebuild(kfx_sdf_summary* s, kfx_stream stream)
+{
+    if (!s) return set_error(KFX_E_NULL, "kfx_sdf_summary_rebuild: null summary");
+    const long long n = (long long)s->nbx * s->nby * s->nbz;
+    const int aligned16 = ((((uintptr_t)s->base) | s->pitch | s->img_pitch) & 15) == 0;
+    hipLaunchKernelGGL(k_summary_rebuild, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, s->R, s->base, s->pitch, s->img_pitch,
+                       s->w, s->h, s->d, s->nbx, s->nby, s->nbz, aligned16);
+    s->c_dirty = 1;
+    return check_launch("kfx_sdf_summary_rebuild");
 }
 
 // After the volume was written by anything that does not track (memcpy, LoadPXM, SdfSphere, an untracked SdfFuse):

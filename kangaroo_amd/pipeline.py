@@ -35,23 +35,38 @@ def vbo_normals(ops, vbo, normals, depth, K):
 
 
 class FramePipeline:
+    # track="auto": the stream itself is the benchmark.  From frame CAL_FIRST on, three blocks of CAL_BLOCK frames each:
+    # tracked pair (SdfFuse keeping the summary + march through the class tables), plain pair (the summary goes stale), tracked
+    # pair again (summary rebuilt from the volume, kfx_sdf_summary_rebuild) -- whole frames, timed start to start.  The tables
+    # stay only if BOTH tracked blocks beat the plain block's median frame by CAL_MARGIN; otherwise the plain pair runs from
+    # then on.  Nothing is assumed about what tracking costs SdfFuse: the plain SdfFuse is in the plain block's frames.
+    CAL_FIRST, CAL_BLOCK, CAL_MARGIN = 8, 60, 0.05
+    USE_FRAME = True   # issue a frame through ONE library call (ops.Frame = kfx_frame) where the operator set has it
+
     def __init__(self, ops, dims, boxmin, boxmax, w, h, K=None, near=0.4, far=8.0, bilateral=None,
                  trunc_factor=scenes.TRUNC_DIST_FACTOR, max_w=scenes.MAX_W, mincostheta=scenes.MIN_COS_THETA,
-                 contiguous_images=False, track=False):
+                 contiguous_images=False, track=False, cal_first=None, cal_block=None, cal_margin=None, timing_slots=None):
         """track: keep a brick summary of the volume (ops.SdfSummary) current in SdfFuse and let RaycastSdf step through
         uniformly free / never-observed space without reading the volume (same volume bits; images bit-identical in
         exact numerics, within the fast-mode tolerance in fast numerics).  True / False, or "auto": start with the summary,
-        time both marches on a few frames of the stream itself and keep whichever makes the frame shorter (_calibrate):
+        time whole frames of the stream itself with and without it and keep whichever makes the frame shorter (see CAL_*):
         the table march wins where rays cross much free space (S_full: RaycastSdf 0.15 -> 0.05 ms) and loses where the
-        longest rays graze silhouettes (S_room), and which it is depends on the scene, not on anything known up front."""
+        longest rays graze silhouettes (S_room), and which it is depends on the scene, not on anything known up front.
+        During the calibration blocks the images come from the march of the block (bit-identical in exact numerics, within
+        the fast-mode tolerance otherwise); reset() re-arms the calibration for the new stream, recalibrate() at any frame."""
         self.ops = ops
         self.track_policy = "auto" if track == "auto" else ("on" if track else "off")
         self.track = bool(track) and hasattr(ops, "SdfSummary")
         if self.track_policy == "auto" and not self.track:
             self.track_policy = "off"
-        self.track_decision = None   # auto: dict(chosen=..., ms=...) once decided
-        self._cal = {"frame": 0, "fuse": [], "ray": [], "open": None} if self.track_policy == "auto" else None
+        self.cal_first = self.CAL_FIRST if cal_first is None else int(cal_first)
+        self.cal_block = self.CAL_BLOCK if cal_block is None else int(cal_block)
+        self.cal_margin = self.CAL_MARGIN if cal_margin is None else float(cal_margin)
+        self.track_decision = None   # auto: dict(chosen=..., ...) once decided
+        self.frames_done = 0         # frames stepped since construction / reset
+        self._cal = None
         self.summary = None
+        self.kframe = None
         self.dims = tuple(int(d) for d in dims)
         self.w, self.h = int(w), int(h)
         self.K = scenes.intrinsics(w, h) if K is None else np.asarray(K, np.float32)
@@ -70,108 +85,159 @@ class FramePipeline:
         self.ray_d = I(w, h, "f32", pitch=pf(4))
         self.ray_n = I(w, h, "f32x4", pitch=pf(16))
         self.ray_i = I(w, h, "f32", pitch=pf(4))
+        if self.USE_FRAME and hasattr(ops, "Frame") and getattr(self.vol, "kind", "f32") == "f32":
+            self.kframe = ops.Frame(self.vol, self.raw, self.filtered, self.vbo, self.normals, self.ray_d, self.ray_n, self.ray_i, self.K,
+                                    self.bil, self.near, self.far, self.trunc, self.max_w, self.mincostheta,
+                                    timing_slots=max(256, 3 * self.cal_block + 16, int(timing_slots or 0)))
+        track_now, self.track = self.track, False
+        self.set_track(track_now)
         self.reset()
 
     # -- overridable pieces ------------------------------------------------------
     def _alloc_volume(self, boxmin, boxmax):
         return self.ops.BoundedVolume(self.dims[0], self.dims[1], self.dims[2], boxmin, boxmax)
 
-    def reset(self):
-        """SdfReset(vol, NaN): 'never observed' = (NaN, 0) (main.cpp:229)."""
-        if self.track_policy == "auto" and self.track_decision is None and self._cal is not None:
-            self._cal = {"frame": 0, "fuse": [], "ray": [], "open": None}   # a new stream: calibrate on it
-        if self.track:
+    def set_track(self, on):
+        """Switch between the tracked pair of kernels and the plain pair.  Switching on (re)builds the summary from what the
+        volume holds, so it may follow any number of untracked frames."""
+        on = bool(on) and hasattr(self.ops, "SdfSummary")
+        if self.kframe is not None:
+            self.kframe.set_track(on)
+            self.summary = self.kframe.summary() if on else None
+        elif on and not self.track:
             if self.summary is None:
                 self.summary = self.ops.SdfSummary(self.vol)
+            self.summary.rebuild()
+        self.track = on
+
+    def recalibrate(self, first=None):
+        """track="auto": time the three blocks again, starting `first` frames from now (default: at once) -- e.g. once a
+        stream has reached its steady state."""
+        if self.track_policy != "auto":
+            return
+        self.track_decision = None
+        self._cal = {"first": self.frames_done + (0 if first is None else int(first)), "t": [], "clock": None}
+        self.set_track(True)
+
+    def reset(self):
+        """SdfReset(vol, NaN): 'never observed' = (NaN, 0) (main.cpp:229).  A new stream: track="auto" starts over with the
+        summary and calibrates on the new stream."""
+        self.frames_done = 0
+        if self.track_policy == "auto":
+            self.track_decision = None
+            # cal_first < 0: no calibration until the caller asks for one (recalibrate()); the tracked pair runs meanwhile
+            self._cal = {"first": self.cal_first, "t": [], "clock": None} if self.cal_first >= 0 else None
+            if not self.track:
+                self.set_track(True)
+        if self.kframe is not None:
+            self.kframe.reset()
+        elif self.track:
             self.ops.SdfReset(self.vol, float("nan"), summary=self.summary)
         else:
             self.ops.SdfReset(self.vol, float("nan"))
 
     def preprocess(self, raw_image=None):
+        if self.kframe is not None:
+            self.kframe.step(_IDENTITY, None, raw_image, self.kframe.PREPROCESS)
+            return
         o = self.ops
         src = self.raw if raw_image is None else raw_image
         o.BilateralFilter(self.filtered, src, self.bil["gs"], self.bil["gr"], self.bil["size"], self.bil["minval"])
         vbo_normals(o, self.vbo, self.normals, self.filtered, self.K)
 
-    # track="auto": frames CAL_FIRST ... CAL_FIRST + CAL_FRAMES - 1 of the stream are timed with device events (nothing
-    # waits: the events are read a few frames later, once they have completed)
-    CAL_FIRST, CAL_FRAMES = 8, 12
-    # what the table march costs SdfFuse, as a fraction of its time (measured at 512^3: 4-6 %; the bookkeeping itself is 1.6 %,
-    # the rest is the part of the volume the plain march leaves in the memory-side cache for the next SdfFuse and the table
-    # march does not -- EXPERIMENTS.md 5.4)
-    TRACK_FUSE_OVERHEAD = 0.06
+    # -- the auto policy ------------------------------------------------------------
+    def _policy_before(self):
+        """Called at the start of a frame while a calibration is pending: puts the pipeline into the state of the frame's block."""
+        c, B = self._cal, self.cal_block
+        k = self.frames_done - c["first"]   # this frame's index within the blocks
+        if k == 0 and self.kframe is not None:
+            c["kfirst"] = self.kframe.count
+        if k == B:
+            self.set_track(False)
+        elif k == 2 * B:
+            self.set_track(True)
+        if self.kframe is None:   # host clock (loops that synchronise every frame: the tracking loop's pose read-back)
+            import time
+            c["clock"] = time.perf_counter()
 
-    def _calibrating(self):
-        c = self._cal
-        return c is not None and c["open"] is None and self.CAL_FIRST <= c["frame"] < self.CAL_FIRST + self.CAL_FRAMES
-
-    def _calibrate(self):
-        """Decide once the timed frames have run: the table march stays if RaycastSdf through the tables, plus the tables'
-        build (inside the tracked call), plus SdfFuse's tracking overhead, beat the plain march by 3 %."""
-        c = self._cal
-        if c is None or c["frame"] < self.CAL_FIRST + self.CAL_FRAMES + 2 or len(c["ray"]) < self.CAL_FRAMES:
+    def _policy_after(self):
+        """Called at the end of a frame (frames_done counts it already): once the three blocks and one more frame -- whose start
+        ends the last period -- have been issued, read their times and decide."""
+        c, B = self._cal, self.cal_block
+        k = self.frames_done - 1 - c["first"]
+        if self.kframe is None and 0 <= k < 3 * B and c["clock"] is not None:
+            import time
+            c["t"].append((time.perf_counter() - c["clock"]) * 1e3)
+        if k < 3 * B:
             return
-        # the last event of the last timed frame (everything is on one stream: the earlier ones completed before it); one
-        # query every fourth frame -- polling all 60 events every frame makes the launching thread slower than the GPU
-        if c["frame"] % 4 or not c["ray"][-1][2].query() or (c["fuse"] and not c["fuse"][-1][1].query()):
-            return   # still running: look again later
-        fuse = float(np.median([a.elapsed_time(b) for a, b in c["fuse"]])) if c["fuse"] else 0.0   # (a tracking loop that fused none of the timed frames)
-        tracked = float(np.median([a.elapsed_time(b) for a, b, _ in c["ray"]]))
-        plain = float(np.median([b.elapsed_time(d) for _, b, d in c["ray"]]))
-        keep = tracked + self.TRACK_FUSE_OVERHEAD * fuse < 0.97 * plain
-        self.track_decision = {"chosen": "table march (tracked SdfFuse)" if keep else "plain march", "sdf_fuse_tracked_ms": round(fuse, 5),
-                               "raycast_tables_ms": round(tracked, 5), "raycast_plain_ms": round(plain, 5), "frames_timed": self.CAL_FRAMES}
-        if not keep:
-            self.track = False
-            self.summary = None
+        parts = None
+        if self.kframe is not None:
+            if self.kframe.count - c.get("kfirst", -1) != self.frames_done - c["first"]:
+                # the caller issued parts of frames by themselves in between (preprocess / fuse / raycast): the ring's frames are
+                # not the blocks' frames -- start over from here
+                self._cal = {"first": self.frames_done, "t": [], "clock": None}
+                self.set_track(True)
+                return
+            t = self.kframe.timings(c["kfirst"], 3 * B)   # waits for the last block's frames only; what is queued behind keeps the GPU busy
+            period = t[:, 4].astype(np.float64)
+            parts = t
+        else:
+            period = np.asarray(c["t"][:3 * B], np.float64)
+        med = [float(np.median(period[i * B:(i + 1) * B])) for i in range(3)]
+        keep = max(med[0], med[2]) <= (1.0 - self.cal_margin) * med[1]
+        d = {"chosen": "table march (tracked SdfFuse)" if keep else "plain march",
+             "frame_tracked_ms": [round(med[0], 5), round(med[2], 5)], "frame_plain_ms": round(med[1], 5),
+             "frames_per_block": B, "first_frame": c["first"], "margin": self.cal_margin,
+             "rule": "tables stay iff max(tracked block medians) <= (1 - margin) x plain block median (whole frames)",
+             "clock": "device events, frame start to next frame start" if self.kframe is not None else "host clock around step()"}
+        if parts is not None:
+            for name, col in (("sdf_fuse", 1), ("raycast", 2)):
+                d[name + "_tracked_ms"] = round(float(np.median(np.concatenate([parts[:B, col], parts[2 * B:, col]]))), 5)
+                d[name + "_plain_ms"] = round(float(np.median(parts[B:2 * B, col])), 5)
+        self.track_decision = d
         self._cal = None
+        if not keep:
+            self.set_track(False)
 
     def _timed_fuse(self, integrate):
-        """integrate(kw) launches the frame's SdfFuse with kw = {"summary": ...} or {}; timed while the auto policy calibrates."""
-        kw = {"summary": self.summary} if self.track else {}
-        cal = self._calibrating()
-        if cal:
-            import torch
-            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-            ev[0].record()
-        integrate(kw)
-        if cal:
-            ev[1].record()
-            self._cal["fuse"].append(ev)
+        """integrate(kw) launches the frame's SdfFuse with kw = {"summary": ...} or {} (loops that issue their own operators)."""
+        integrate({"summary": self.summary} if self.track else {})
 
     def _timed_raycast(self, render):
-        """render(kw) launches the frame's rendering(s) of the model.  While the auto policy calibrates, the same rendering is
-        repeated by the plain march, timed, into the same images (bit-identical in exact numerics, within the fast-mode
-        tolerance otherwise): the frame's output is a valid rendering either way."""
-        kw = {"summary": self.summary} if self.track else {}
-        cal = self._calibrating()
-        if cal:
-            import torch
-            ev = tuple(torch.cuda.Event(enable_timing=True) for _ in range(3))
-            ev[0].record()
-        render(kw)
-        if cal:
-            ev[1].record()
-            render({})
-            ev[2].record()
-            self._cal["ray"].append(ev)
-        if self._cal is not None:
-            self._cal["frame"] += 1
-            self._calibrate()
+        """render(kw) launches the frame's rendering(s) of the model."""
+        render({"summary": self.summary} if self.track else {})
 
     def fuse(self, T_wc):
+        if self.kframe is not None:
+            self.kframe.step(T_wc, scenes.se3_inverse(T_wc), None, self.kframe.FUSE)
+            return
         self._timed_fuse(lambda kw: self.ops.SdfFuse(self.vol, self.filtered, self.normals, scenes.se3_inverse(T_wc), self.K, self.trunc,
                                                      self.max_w, self.mincostheta, **kw))
 
     def raycast(self, T_wc):
+        if self.kframe is not None:
+            self.kframe.step(T_wc, None, None, self.kframe.RAYCAST)
+            return
         self._timed_raycast(lambda kw: self.ops.RaycastSdf(self.ray_d, self.ray_n, self.ray_i, self.vol, T_wc, self.K, self.near, self.far,
                                                            self.trunc, True, **kw))
 
     def step(self, T_wc, raw_image=None):
         """One frame: preprocess the new depth image, integrate it, render the model."""
-        self.preprocess(raw_image)
-        self.fuse(T_wc)
-        self.raycast(T_wc)
+        cal = self._cal is not None and self.frames_done >= self._cal["first"]
+        if cal:
+            self._policy_before()
+        if self.kframe is not None:
+            self.kframe.step(T_wc, scenes.se3_inverse(T_wc), raw_image)
+        else:
+            self.preprocess(raw_image)
+            self.fuse(T_wc)
+            self.raycast(T_wc)
+        self.frames_done += 1
+        if cal:
+            self._policy_after()
+
+
+_IDENTITY = np.array([[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 0]], np.float32)
 
 
 class TrackingPipeline(FramePipeline):
@@ -181,6 +247,7 @@ class TrackingPipeline(FramePipeline):
     then SdfFuse at the refined pose when tracking is good."""
 
     LEVELS = 4
+    USE_FRAME = False   # its frame has the pose estimation between rendering and integration: the operators are issued here
 
     def __init__(self, ops, dims, boxmin, boxmax, w, h, its=None, icp_c=0.1, max_rmse=0.10, device_icp=False, one_raycast=None, **kw):
         """device_icp: run the whole refinement loop on the GPU (ops.IcpRefine, one synchronisation per frame) instead
@@ -218,6 +285,9 @@ class TrackingPipeline(FramePipeline):
         """One frame.  The first frame is fused at T_wl_init (identity if None); later frames are tracked
         against the model.  Returns the current T_wl (4x4 float64)."""
         o, tr = self.ops, self.tracking
+        cal = self._cal is not None and self.frames_done >= self._cal["first"]
+        if cal:   # track="auto": whole frames of the three blocks, host clock around the step (the pose read-back synchronises)
+            self._policy_before()
         self.preprocess(raw_image)
         if self.frame == 0:
             if T_wl_init is not None:
@@ -236,7 +306,7 @@ class TrackingPipeline(FramePipeline):
                         o.RaycastSdf(self.pyr_d[l], self.pyr_n[l], self.pyr_i[l], self.vol, T34, self.K_levels[l], self.near,
                                      self.far, self.trunc, True, **kw)
                         o.DepthToVbo(self.pyr_v[l], self.pyr_d[l], self.K_levels[l])
-            self._timed_raycast(render)   # track="auto": both marches are timed on frames 8-19 and the faster one stays
+            self._timed_raycast(render)
             if self.device_icp:
                 T_lp, self.rmse, _, self.tracking_good = o.IcpRefine(self.kin_v, self.pyr_v, self.pyr_n, self.K_levels, self.its,
                                                                      self.icp_c, self.max_rmse, self.scratch, self.debug)
@@ -247,6 +317,9 @@ class TrackingPipeline(FramePipeline):
                 self.T_wl = self.T_wl @ tr.se3_inv(T_lp)
                 self._fuse_at(self.T_wl)
         self.frame += 1
+        self.frames_done += 1
+        if cal:
+            self._policy_after()
         return self.T_wl
 
     def _fuse_at(self, T_wl):
@@ -269,6 +342,7 @@ class SlabPipeline(FramePipeline):
     view BoundedVolume::SubBoundingVolume produces (BoundedVolume.h:156-164)."""
 
     GHOST = 2  # >= 1 for the trilinear z+1 corner and the gradient's z-1 / z+1 cells (Volume.h:240-289)
+    USE_FRAME = False   # slabs: the operators take slab arguments and collectives sit between them
 
     def __init__(self, ops, dist, dims, boxmin, boxmax, w, h, halo="exchange", raycast="composite", kind="f32", overlap=False,
                  inputs="replicate", images="all", **kw):

@@ -272,6 +272,10 @@ class SdfSummary:
     def invalidate(self, stream=None):
         _lib.check(_lib.load().kfx_sdf_summary_invalidate(self.handle, _stream(stream)))
 
+    def rebuild(self, stream=None):
+        """kfx_sdf_summary_rebuild: recompute every brick from what the volume holds (after writers that do not track)."""
+        _lib.check(_lib.load().kfx_sdf_summary_rebuild(self.handle, _stream(stream)))
+
     def __del__(self):
         try:
             if self.handle is not None and self.handle.value:
@@ -279,6 +283,94 @@ class SdfSummary:
                 self.handle = None
         except Exception:   # interpreter shutdown: the process is going away with its device memory
             pass
+
+
+class _FrameSummary:
+    """The summary a kfx_frame owns, in the shape the operators' summary= argument takes (handle only; never destroyed here)."""
+
+    def __init__(self, handle):
+        self.handle = C.c_void_p(handle)
+
+    def invalidate(self, stream=None):
+        _lib.check(_lib.load().kfx_sdf_summary_invalidate(self.handle, _stream(stream)))
+
+    def rebuild(self, stream=None):
+        _lib.check(_lib.load().kfx_sdf_summary_rebuild(self.handle, _stream(stream)))
+
+
+class Frame:
+    """kfx_frame (include/kfx.h): one frame of the application's loop (main.cpp:200-356, known poses) -- BilateralFilter ->
+    DepthToVbo -> NormalsFromVbo -> SdfFuse -> RaycastSdf -- enqueued by ONE library call on the current stream, with device
+    events around its parts.  The images and the volume are the caller's containers (kept alive here); results are
+    bit-identical to calling the operators one by one."""
+
+    PREPROCESS, FUSE, RAYCAST, ALL = 1, 2, 4, 7
+    FIELDS = 5   # timings(): preprocess, SdfFuse, RaycastSdf, whole frame, period to the next frame's start (ms)
+
+    def __init__(self, vol, raw, filtered, vbo, normals, ray_d, ray_n, ray_i, K, bilateral, near, far, trunc_dist, max_w, mincostheta,
+                 full_extent=False, timing_slots=0):
+        assert vol.kind == "f32"
+        self._keep = (vol, raw, filtered, vbo, normals, ray_d, ray_n, ray_i)
+        cfg = _lib.KfxFrameConfig()
+        cfg.vol = vol.view()
+        cfg.raw, cfg.filtered, cfg.vbo, cfg.normals = raw.view(), filtered.view(), vbo.view(), normals.view()
+        cfg.ray_depth, cfg.ray_norm, cfg.ray_img = ray_d.view(), ray_n.view(), ray_i.view()
+        for i, v in enumerate(np.asarray(K, np.float32).reshape(4)):
+            cfg.K[i] = float(v)
+        cfg.bilateral_gs, cfg.bilateral_gr = float(bilateral["gs"]), float(bilateral["gr"])
+        cfg.bilateral_minval, cfg.bilateral_size = float(bilateral["minval"]), int(bilateral["size"])
+        cfg.near, cfg.far, cfg.trunc_dist, cfg.max_w, cfg.mincostheta = float(near), float(far), float(trunc_dist), float(max_w), float(mincostheta)
+        cfg.fuse_flags = 1 if full_extent else 0
+        cfg.timing_slots = int(timing_slots)
+        self.timing_slots = int(timing_slots)
+        self.handle = C.c_void_p()
+        _lib.check(_lib.load().kfx_frame_create(C.byref(self.handle), C.byref(cfg)))
+        L = _lib.load()
+        self._step, self._h = L.kfx_frame_step, self.handle
+
+    def __del__(self):
+        try:
+            if self.handle is not None and self.handle.value:
+                _lib.load().kfx_frame_destroy(self.handle)
+                self.handle = None
+        except Exception:   # interpreter shutdown
+            pass
+
+    def reset(self, stream=None):
+        _lib.check(_lib.load().kfx_frame_reset(self.handle, _stream(stream)))
+
+    def set_track(self, on, stream=None):
+        _lib.check(_lib.load().kfx_frame_set_track(self.handle, 1 if on else 0, _stream(stream)))
+
+    @property
+    def track(self):
+        return bool(_lib.load().kfx_frame_get_track(self.handle))
+
+    @property
+    def count(self):
+        return int(_lib.load().kfx_frame_count(self.handle))
+
+    def summary(self):
+        h = _lib.load().kfx_frame_summary(self.handle)
+        return _FrameSummary(h) if h else None
+
+    def step(self, T_wc, T_cw=None, raw=None, parts=0, stream=None):
+        t, _t = _fp(T_wc, 12)
+        if T_cw is not None:
+            ti, _ti = _fp(T_cw, 12)
+        else:
+            ti = None
+        e = self._step(self._h, raw.ref() if raw is not None else None, t, ti, parts, _stream(stream))
+        if e:
+            _lib.check(e)
+
+    def timings(self, first, n):
+        """(n, 5) float32 array in ms for frames first .. first + n - 1: preprocess, SdfFuse, RaycastSdf, whole frame, period
+        (start of the frame to the start of the next; NaN for the most recent frame).  Waits for the last of them only."""
+        out = np.empty((max(n, 0), self.FIELDS), np.float32)
+        if n > 0:
+            _lib.check(_lib.load().kfx_frame_timings(self.handle, int(first), int(n), out.ctypes.data_as(_lib.PF)))
+        return out
 
 
 def SdfFuse(vol, depth, norm, T_cw, K, trunc_dist, maxw, mincostheta, full_extent=False, stream=None, slab=None, summary=None):
@@ -314,12 +406,19 @@ def SdfFuseCount(vol, depth, norm, T_cw, K, trunc_dist, mincostheta, full_extent
     return int(cnt.item())
 
 
-def RaycastSdfCount(vol, w, h, T_wc, K, near, far, trunc_dist, subpix=True, stream=None):
+def RaycastSdfCount(vol, w, h, T_wc, K, near, far, trunc_dist, subpix=True, stream=None, summary=None):
     """Diagnostics (kfx_raycast_sdf_count): what RaycastSdf's march for a w x h image reads -- dict(samples, rays, hits, U =
-    distinct voxels touched)."""
+    distinct voxels touched).  summary: the march RaycastSdf(..., summary=) runs instead (kfx_raycast_sdf_count_tracked), with
+    lookups = table look-ups and table_bytes = what a workgroup stages of the class tables (0: it fell back to the plain march)."""
     t, _t = _fp(T_wc, 12)
     k, _k = _fp(K, 4)
     bitmap = torch.zeros((vol.w * vol.h * vol.d + 31) // 32, dtype=torch.int32, device=vol.storage.device)
+    if summary is not None:
+        cnt = torch.zeros(6, dtype=torch.int64, device=vol.storage.device)
+        _lib.check(_lib.load().kfx_raycast_sdf_count_tracked(vol.ref(), summary.handle, w, h, t, k, near, far, trunc_dist, 1 if subpix else 0,
+                                                             C.c_void_p(bitmap.data_ptr()), C.c_void_p(cnt.data_ptr()), _stream(stream)))
+        c = cnt.tolist()
+        return dict(samples=c[0], rays=c[1], hits=c[2], U=c[3], lookups=c[4], table_bytes=c[5])
     cnt = torch.zeros(4, dtype=torch.int64, device=vol.storage.device)
     _lib.check(_lib.load().kfx_raycast_sdf_count(vol.ref(), w, h, t, k, near, far, trunc_dist, 1 if subpix else 0,
                                                  C.c_void_p(bitmap.data_ptr()), C.c_void_p(cnt.data_ptr()), _stream(stream)))

@@ -133,7 +133,7 @@ def test_every_compute_entry_point_rejects_null_arguments():
     return a negative KFX_E_* code (never a crash, never a launch) -- checked here without a GPU."""
     L = _lib.load()
     skip = {"kfx_version", "kfx_device_count", "kfx_last_error_string", "kfx_error_name", "kfx_free", "kfx_free_host",
-            "kfx_set_math_mode", "kfx_get_math_mode", "kfx_stream_synchronize", "kfx_alloc_host", "kfx_memcpy_2d", "kfx_set_device", "kfx_sdf_summary_destroy"}
+            "kfx_set_math_mode", "kfx_get_math_mode", "kfx_stream_synchronize", "kfx_alloc_host", "kfx_memcpy_2d", "kfx_set_device", "kfx_sdf_summary_destroy", "kfx_frame_destroy"}
     checked = 0
     for name, (restype, argtypes) in sorted(_lib.SIGNATURES.items()):
         if name in skip or restype is not C.c_int:

@@ -285,66 +285,125 @@ print("ok")
 
 @pytest.mark.parametrize("scene", ["full", "room"])
 def test_gpu_frame_pipeline_auto_policy(roo, scene):
-    """FramePipeline(track="auto"): starts with the summary, times both marches on frames 8-19 of the stream (device events,
-    no synchronisation), decides once and carries on with the faster pair of kernels.  Whatever it decides, the volume equals
-    the untracked pipeline's bit for bit and the images stay within the fast-mode tolerance of the plain march."""
-    import torch
+    """FramePipeline(track="auto"): starts with the summary, times three blocks of whole frames of the stream itself (tracked
+    pair, plain pair, tracked pair again -- device events recorded by kfx_frame_step), decides once and carries on with the
+    faster pair unless the tables win by the margin.  Whatever it decides, the volume equals the untracked pipeline's bit for
+    bit and the images stay within the fast-mode tolerance of the plain march; reset() re-arms the calibration."""
     from kangaroo_amd.pipeline import FramePipeline
     N, w, h = 128, 320, 240
     bmin, bmax, near, far = scenes.SCENES[scene]
     prev = roo.set_math_mode("fast")
     try:
-        auto = FramePipeline(roo, (N, N, N), bmin, bmax, w, h, near=near, far=far, track="auto")
+        auto = FramePipeline(roo, (N, N, N), bmin, bmax, w, h, near=near, far=far, track="auto", cal_first=4, cal_block=8)
         ref = FramePipeline(roo, (N, N, N), bmin, bmax, w, h, near=near, far=far, track=False)
+        assert auto.kframe is not None and ref.kframe is not None, "the HIP operator set issues frames through kfx_frame_step"
         assert auto.track_policy == "auto" and auto.track and auto.track_decision is None
-        for i in range(48):
+        states = []
+        for i in range(40):
             T_wc = scenes.orbit_pose(i % 30, 30)
             raw = T.upload_image(roo, scenes.render_depth(scene, w, h, T_wc, auto.K))
             auto.step(T_wc, raw)
             ref.step(T_wc, raw)
-            if i >= 30:
-                torch.cuda.synchronize()   # (the events of frames 8-19 have completed by now: the next frame decides)
-        assert auto.track_decision is not None and auto._cal is None, "no decision after 48 frames"
-        assert auto.track == auto.track_decision["chosen"].startswith("table march")
-        assert (auto.summary is not None) == auto.track
+            states.append(auto.track)
+        d = auto.track_decision
+        assert d is not None and auto._cal is None, "no decision after 40 frames"
+        assert states[4:12] == [True] * 8 and states[12:20] == [False] * 8 and states[20:28] == [True] * 8, states
+        assert auto.track == d["chosen"].startswith("table march") and (auto.summary is not None) == auto.track
+        assert d["frames_per_block"] == 8 and d["frame_plain_ms"] > 0 and min(d["frame_tracked_ms"]) > 0
+        assert d["sdf_fuse_plain_ms"] > 0 and d["sdf_fuse_tracked_ms"] > 0 and d["raycast_plain_ms"] > 0   # the plain SdfFuse is measured, not assumed
+        assert auto.track == (max(d["frame_tracked_ms"]) <= (1 - d["margin"]) * d["frame_plain_ms"])
         assert T.nan_equal(auto.vol.MemcpyToHost(), ref.vol.MemcpyToHost())
         da, dr = auto.ray_d.MemcpyToHost(), ref.ray_d.MemcpyToHost()
         ha, hr = np.isfinite(da), np.isfinite(dr)
         assert (ha != hr).sum() <= max(3, 2e-4 * w * h)
         both = ha & hr
         assert both.sum() > 0.03 * w * h and np.abs(da[both] - dr[both]).max() < 1e-4
+        auto.reset()   # a new stream: the policy starts over (round-3 advice)
+        assert auto.track and auto.track_decision is None and auto._cal is not None
     finally:
         roo.set_math_mode(prev)
 
 
 def test_gpu_tracking_pipeline_auto_policy(roo):
-    """TrackingPipeline(track="auto"): the loop with pose estimation times the pyramid rendering through the tables and by the
-    plain march on frames 8-19, decides once, and tracks the orbit like the untracked loop: same poses to within the fast-mode
-    tolerance of the renderings, same volume where both fused the same frames."""
-    import torch
+    """TrackingPipeline(track="auto"): the loop with pose estimation times whole frames of the three blocks with the host clock
+    (its pose read-back synchronises every frame), decides once, and tracks the orbit like the untracked loop: same poses to
+    within the fast-mode tolerance of the renderings."""
     from kangaroo_amd.pipeline import TrackingPipeline
     N, w, h = 128, 320, 240
     scene = "room"
     bmin, bmax, near, far = scenes.SCENES[scene]
     prev = roo.set_math_mode("fast")
     try:
-        auto = TrackingPipeline(roo, (N, N, N), bmin, bmax, w, h, near=near, far=far, device_icp=True, track="auto")
+        auto = TrackingPipeline(roo, (N, N, N), bmin, bmax, w, h, near=near, far=far, device_icp=True, track="auto", cal_first=4, cal_block=8)
         ref = TrackingPipeline(roo, (N, N, N), bmin, bmax, w, h, near=near, far=far, device_icp=True, track=False)
-        assert auto.track_policy == "auto" and auto.track
+        assert auto.track_policy == "auto" and auto.track and auto.kframe is None
         worst = 0.0
-        for i in range(44):
+        for i in range(36):
             T_wc = scenes.orbit_pose(i % 30, 30)
             raw = T.upload_image(roo, scenes.render_depth(scene, w, h, T_wc, auto.K))
             Ta = auto.step(T_wc if i == 0 else None, raw)
             Tr = ref.step(T_wc if i == 0 else None, raw)
             worst = max(worst, float(np.abs(Ta[:3, 3] - Tr[:3, 3]).max()))
             assert auto.tracking_good and ref.tracking_good, i
-        assert auto.track_decision is not None and auto._cal is None, "no decision after 44 frames"
-        assert auto.track == auto.track_decision["chosen"].startswith("table march") and (auto.summary is not None) == auto.track
-        assert auto.track_decision["frames_timed"] == TrackingPipeline.CAL_FRAMES and auto.track_decision["raycast_plain_ms"] > 0
+        d = auto.track_decision
+        assert d is not None and auto._cal is None, "no decision after 36 frames"
+        assert auto.track == d["chosen"].startswith("table march") and (auto.summary is not None or not auto.track)
+        assert d["frames_per_block"] == 8 and d["frame_plain_ms"] > 0 and d["clock"].startswith("host")
         assert worst < 2e-4, worst   # metres: the two loops see renderings that differ within the fast-mode tolerance
     finally:
         roo.set_math_mode(prev)
+
+
+def test_gpu_summary_rebuild_is_exact(roo):
+    """kfx_sdf_summary_rebuild: after frames fused WITHOUT tracking, the rebuilt summary holds for every brick the exact range
+    of its valued cells and the exact state -- at least as tight as what tracking keeps -- and the march through tables built
+    from it renders the plain march's images bit for bit (exact numerics)."""
+    import torch
+    N, w, h = 96, 200, 150
+    dims = (N, N - 12, N - 5)   # not multiples of 8: partial bricks on two axes
+    bmin, bmax, near, far = scenes.SCENES["room"]
+    K = scenes.intrinsics(w, h)
+    tr = scenes.trunc_dist(bmin, bmax, dims)
+    vol = roo.BoundedVolume(*dims, bmin, bmax)
+    summ = roo.SdfSummary(vol)
+    roo.SdfReset(vol, float("nan"))
+    f, vbo, nrm = roo.Image(w, h), roo.Image(w, h, "f32x4"), roo.Image(w, h, "f32x4")
+    for i in range(3):
+        T_wc = scenes.orbit_pose(i, 30)
+        raw = T.upload_image(roo, scenes.render_depth("room", w, h, T_wc, K))
+        roo.BilateralFilter(f, raw, **scenes.BILATERAL)
+        roo.DepthToVbo(vbo, f, K)
+        roo.NormalsFromVbo(nrm, vbo)
+        roo.SdfFuse(vol, f, nrm, scenes.se3_inverse(T_wc), K, tr, scenes.MAX_W, scenes.MIN_COS_THETA, full_extent=True)
+    summ.rebuild()
+    R, classes = export(roo, summ, 0.0, tr)
+    check_classes(vol, classes, 0.0, tr)
+    stats = check_conservative(vol, R)
+    assert stats["uniform_ranges"] > 0 and stats["all_nan"] > 0 and stats["mixed"] > 0, stats
+    # exactness: every brick's range IS the range of its valued cells, every state the true one
+    v = vol.tensor()[..., 0]
+    d_, h_, w_ = v.shape
+    nbz, nby, nbx = R.shape[:3]
+    pad = torch.full((nbz * 8, nby * 8, nbx * 8), float("nan"), device=v.device)
+    known = torch.zeros_like(pad, dtype=torch.bool)
+    pad[:d_, :h_, :w_] = v
+    known[:d_, :h_, :w_] = True
+    br = pad.view(nbz, 8, nby, 8, nbx, 8).permute(0, 2, 4, 1, 3, 5).reshape(nbz, nby, nbx, 512)
+    kn = known.view(nbz, 8, nby, 8, nbx, 8).permute(0, 2, 4, 1, 3, 5).reshape(nbz, nby, nbx, 512)
+    has, isn = ~torch.isnan(br) & kn, torch.isnan(br) & kn
+    tmin = torch.where(has, br, torch.full_like(br, float("inf"))).amin(-1)
+    tmax = torch.where(has, br, torch.full_like(br, float("-inf"))).amax(-1)
+    state = R[..., 2].contiguous().view(torch.int32)
+    want = torch.where(has.any(-1), torch.where(isn.any(-1), 2, 0), 1).to(torch.int32)
+    assert bool((state == want).all())
+    assert bool((R[..., 0] == tmin).all()) and bool((R[..., 1] == tmax).all())
+    T_wc = scenes.orbit_pose(2, 30)
+    a = [roo.Image(w, h), roo.Image(w, h, "f32x4"), roo.Image(w, h)]
+    b = [roo.Image(w, h), roo.Image(w, h, "f32x4"), roo.Image(w, h)]
+    roo.RaycastSdf(*a, vol, T_wc, K, near, far, tr, True)
+    roo.RaycastSdf(*b, vol, T_wc, K, near, far, tr, True, summary=summ)
+    for x, y in zip(a, b):
+        assert T.nan_equal(x.MemcpyToHost(), y.MemcpyToHost())
 
 
 @pytest.mark.parametrize("trunc_factor", [0.4, 1.0, 6.0])
