@@ -2,7 +2,9 @@
 // neighbour send / recv over xGMI.  Built into libkfx_rccl.so so that libkfx.so itself does not depend on librccl.
 // The ncclUniqueId travels through a file: rank 0 removes whatever is there, creates the file atomically (exclusive
 // temporary + rename) with a launch nonce in front of the id, the others wait for a file that is a regular file of this user,
-// carries their nonce and is not older than their own process -- a file left behind by a crashed run is never accepted.
+// carries their nonce and was not written long before their own process began (RDV_SLACK_S: the ranks of one launch start
+// within minutes of each other, and rank 0 may well publish before a slow rank has finished importing and initialising its
+// GPU) -- a file left behind by a crashed run is never accepted.
 #include <chrono>
 #include <cstdint>
 #include <cstdlib>
@@ -110,13 +112,40 @@ struct Rendezvous {
 };
 const char RDV_MAGIC[8] = {'K', 'F', 'X', 'R', 'D', 'V', '1', 0};
 
-// start of this process (the launcher starts the ranks together): st_mtime of /proc/self, or "now" where that is missing
+// Start of this process as wall-clock seconds: field 22 of /proc/self/stat (start time in clock ticks since boot; the
+// command name in field 2 may contain spaces and parentheses, so the fields are counted from the LAST ')') plus the boot time
+// `btime` of /proc/stat.  (The st_mtime of /proc/self is NOT it: procfs stamps that inode when it is first looked up, which
+// for a rank that spends seconds importing before it gets here is seconds late -- round-3 advice.)  "now" where procfs is missing.
 time_t process_start()
 {
-    struct stat st;
-    if (stat("/proc/self", &st) == 0) return st.st_mtime;
+    long long ticks = -1, btime = -1;
+    if (FILE* f = fopen("/proc/self/stat", "r")) {
+        char buf[2048];
+        const size_t n = fread(buf, 1, sizeof(buf) - 1, f);
+        fclose(f);
+        buf[n] = 0;
+        if (const char* p = strrchr(buf, ')')) {
+            int field = 2;   // p is at the end of field 2; field 3 (the state) follows
+            ++p;
+            while (*p) {
+                while (*p == ' ') ++p;
+                if (!*p) break;
+                if (++field == 22) { ticks = atoll(p); break; }
+                while (*p && *p != ' ') ++p;
+            }
+        }
+    }
+    if (FILE* f = fopen("/proc/stat", "r")) {
+        char line[256];
+        while (fgets(line, sizeof(line), f))
+            if (strncmp(line, "btime ", 6) == 0) { btime = atoll(line + 6); break; }
+        fclose(f);
+    }
+    const long hz = sysconf(_SC_CLK_TCK);
+    if (ticks >= 0 && btime > 0 && hz > 0) return (time_t)(btime + ticks / hz);
     return time(nullptr);
 }
+const time_t RDV_SLACK_S = 120;   // a rendezvous file may precede this process by this much and still belong to its launch
 
 int write_rendezvous(const char* path, const Rendezvous& rv)
 {
@@ -141,13 +170,23 @@ int read_rendezvous(const char* path, Rendezvous& rv, uint64_t nonce, time_t not
     if (fd < 0) return 0;
     struct stat st;
     bool ok = fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_uid == geteuid() && st.st_size == (off_t)sizeof(rv) &&
-              st.st_mtime + 2 >= not_before;
+              st.st_mtime + RDV_SLACK_S >= not_before;
     ok = ok && read(fd, &rv, sizeof(rv)) == (ssize_t)sizeof(rv) && memcmp(rv.magic, RDV_MAGIC, 8) == 0 && rv.nonce == nonce;
     close(fd);
     return ok ? 1 : 0;
 }
 
 } // namespace
+
+// Test hook (tests/test_abi_cpu.py; not part of include/kfx_slab.h): would a rank > 0 of this process accept the file at `path`
+// right now?  1 / 0.  Reaches no RCCL or HIP call.
+extern "C" int kfx_rccl_rendezvous_probe(const char* path)
+{
+    if (!path) return KFX_E_NULL;
+    Rendezvous rv;
+    return read_rendezvous(path, rv, launch_nonce(), process_start());
+}
+extern "C" long long kfx_rccl_process_start(void) { return (long long)process_start(); }
 
 extern "C" int kfx_comm_create_rccl(kfx_comm* comm, int rank, int world, const char* rendezvous_file, int timeout_s)
 {

@@ -278,7 +278,7 @@ extern "C" int kfx_debug_summary_export(kfx_sdf_summary* s, float tol, float vre
     dims_out[0] = s->nbx; dims_out[1] = s->nby; dims_out[2] = s->nbz;
     dims_out[3] = cv.fine.first; dims_out[4] = cv.fine.rw; dims_out[5] = cv.fine.ny;
     dims_out[6] = cv.coarse.first; dims_out[7] = cv.coarse.rw; dims_out[8] = cv.coarse.ny;
-    dims_out[9] = cv.words; dims_out[10] = s->n_coarse; dims_out[11] = s->h_skippable ? *(volatile int*)s->h_skippable : -2;
+    dims_out[9] = cv.words; dims_out[10] = s->n_coarse; dims_out[11] = (s->h_skippable && s->builds) ? ((volatile int*)s->h_skippable)[(s->builds - 1) % KFX_SUMMARY_RING] : -2;
     const size_t n = (size_t)s->nbx * s->nby * s->nbz;
     hipStream_t st = (hipStream_t)stream;
     if (R_out && hipMemcpyAsync(R_out, s->R, n * sizeof(float4), hipMemcpyDeviceToDevice, st) != hipSuccess) return set_error(KFX_E_RANGE, "kfx_debug_summary_export: copy");
@@ -286,7 +286,7 @@ extern "C" int kfx_debug_summary_export(kfx_sdf_summary* s, float tol, float vre
         if (int e = summary_classes_prepare(s, tol, vref, fine_shift, st)) return e;
         if (hipMemcpyAsync(C_out, s->C, (size_t)cv.words * sizeof(unsigned), hipMemcpyDeviceToDevice, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
             return set_error(KFX_E_RANGE, "kfx_debug_summary_export: copy");
-        dims_out[11] = s->h_skippable ? *(volatile int*)s->h_skippable : -2;   // (the build has finished: its count is published)
+        dims_out[11] = (s->h_skippable && s->builds) ? ((volatile int*)s->h_skippable)[(s->builds - 1) % KFX_SUMMARY_RING] : -2;   // (the build has finished: its count is published)
     }
     return 0;
 }

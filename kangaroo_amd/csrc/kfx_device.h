@@ -177,6 +177,7 @@ __host__ __device__ inline int ceil_div(int a, int b) { return (a + b - 1) / b; 
 // R: one float4 {lo, hi, state, -} per 8 x 8 x 8 cells, kept current by the TRACK fuse kernels (state 0: every cell holds
 // a value in [lo, hi]; 1: every cell is NaN; 2: every cell is NaN or holds a value in [lo, hi] -- an invalidated brick has
 // the infinite range).  C: what the ray-march reads (ClassView below), built from R on demand.
+#define KFX_SUMMARY_RING 8
 struct kfx_sdf_summary {
     float4* R;
     int nbx, nby, nbz;
@@ -190,8 +191,15 @@ struct kfx_sdf_summary {
     int c_shift;                 // fine level C was built for (log2 of its cells per entry)
     int n_coarse;                // 32^3-cell entries
     int* d_count;                // device: {running count of 32^3-cell entries of class != 0, workgroups that have added theirs}
-    int* h_skippable;            // host-visible (pinned, mapped): the count the last finished build arrived at, -1 before the first
-    int* d_skippable;            // the device's address of the same word
+    // The table builds publish their count of 32^3-cell entries of class != 0 in a host-visible ring (pinned, mapped): build b
+    // writes slot b % KFX_SUMMARY_RING and records build_done[b % KFX_SUMMARY_RING] behind it.  The tracked raycast chooses its
+    // kernel from the count of build b - 2 (raycast.hip, class_view): old enough to have finished without anybody waiting,
+    // and -- unlike "whatever the last finished build said" -- the same choice for the same sequence of calls.
+    int* h_skippable;            // the ring, host address (nullptr: no pinned memory; the tables are always used)
+    int* d_skippable;            // the ring, device address
+    hipEvent_t build_done[8];
+    unsigned builds;             // table builds issued so far
+    unsigned plain_calls;        // tracked raycasts since the choice last fell on the plain march (the tables are then rebuilt every 8th call only)
     unsigned sweeps;             // tracked SdfFuse launches so far: every other one walks the planes from the far end (fuse.hip)
 };
 namespace kfx {

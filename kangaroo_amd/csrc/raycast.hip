@@ -756,17 +756,28 @@ static int class_view(ClassView& cl, size_t* lds_bytes, int* usable, kfx_sdf_sum
     summary_class_layout(summary, fine, cl);
     if ((size_t)cl.words * 4 > 60 * 1024) return 0;
     const float tol = math_mode() == KFX_MATH_FAST ? 1e-5f : 0.f;
-    if (int e = summary_classes_prepare(summary, tol, p.trunc, fine, (hipStream_t)stream)) return e;
     // Worth it?  The march through the tables costs ~8 % per sampled step (table look-ups, staging); it pays where a fair part
-    // of the volume can be crossed without sampling.  The last finished table build left its count of such 32^3-cell entries
-    // in host-visible memory (no synchronisation: the figure may be a few frames old, it only steers a choice between two
-    // kernels that produce the same images): exact numerics on a running stream, where only never-observed space qualifies,
-    // fall back to the plain march this way.  KFX_RAYCAST_SUMMARY=1 always uses the tables, -1 never.
+    // of the volume can be crossed without sampling: at least a quarter of the 32^3-cell entries of class != 0.  Every table
+    // build publishes that count in a host-visible ring; the choice is made from the count of the build BEFORE THE PREVIOUS ONE
+    // (two frames old: finished long ago, so the event wait below returns at once) -- it only steers a choice between two
+    // kernels that render the same images, but in fast numerics "the same" means within tolerance, so the choice is made a
+    // function of the sequence of calls, not of how far the GPU happens to have got (round-3 advice).  Exact numerics on a
+    // running stream, where only never-observed space qualifies, fall back to the plain march this way; while the choice is
+    // "plain" the tables are rebuilt on every 8th call only.  KFX_RAYCAST_SUMMARY=1 always uses the tables, -1 never.
     static const int force_env = [] { const char* e = getenv("KFX_RAYCAST_SUMMARY"); return e ? atoi(e) : 0; }();
     if (force_env < 0) return 0;
-    if (force_env == 0 && summary->h_skippable) {
-        const int known = *(volatile int*)summary->h_skippable;
-        if (known >= 0 && (long long)known * 4 < summary->n_coarse) return 0;   // less than a quarter
+    const bool steer = force_env == 0 && summary->h_skippable;
+    if (steer && summary->plain_calls && (summary->plain_calls++ % 8u) != 0u) return 0;   // still plain: no build, no look
+    if (int e = summary_classes_prepare(summary, tol, p.trunc, fine, (hipStream_t)stream)) return e;
+    if (steer && summary->builds >= 3) {
+        const unsigned ref = (summary->builds - 3) % KFX_SUMMARY_RING;   // builds - 1 is the one just issued (or the last one)
+        (void)hipEventSynchronize(summary->build_done[ref]);
+        const int known = ((volatile int*)summary->h_skippable)[ref];
+        if (known >= 0 && (long long)known * 4 < summary->n_coarse) {   // less than a quarter
+            if (!summary->plain_calls) summary->plain_calls = 1;
+            return 0;
+        }
+        summary->plain_calls = 0;
     }
     cl.C = summary->C;
     cl.vref = p.trunc;

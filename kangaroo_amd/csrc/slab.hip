@@ -3,6 +3,7 @@
 // transport behind kfx_comm (RCCL: comm_rccl.cpp); this file only orders kernels and collectives on the caller's stream.
 // No reference counterpart (the reference is single-GPU); the host-side protocol is the one of
 // kangaroo_amd/pipeline.py::SlabPipeline, so that C / C++ applications can use slabs without Python.
+#include <atomic>
 #include <condition_variable>
 #include <mutex>
 #include <new>
@@ -133,7 +134,13 @@ struct ThreadGroup {
     const void* send_lo[MAX_THREAD_RANKS];
     const void* send_hi[MAX_THREAD_RANKS];
     size_t bytes_lo[MAX_THREAD_RANKS], bytes_hi[MAX_THREAD_RANKS];
-    int err[MAX_THREAD_RANKS] = {};   // per-rank error of the collective in flight
+    // per-rank error of a collective, double-buffered by the collective's sequence parity: a rank that has left collective k
+    // and already entered k + 1 posts into the other set while a slower peer may still be reading k's in group_status(); the
+    // set of k is written again in k + 2, which every rank enters only after it returned from k + 1 -- whose barriers all
+    // ranks passed after they had returned from k (round-3 advice).  seq[r] is rank r's own count of collectives.
+    std::atomic<int> err[2][MAX_THREAD_RANKS];
+    unsigned seq[MAX_THREAD_RANKS] = {};
+    ThreadGroup() { for (auto& set : err) for (auto& e : set) e.store(0); }
 
     void wait_all()
     {
@@ -157,13 +164,12 @@ static int hip_status(hipError_t e, const char* what)
 }
 
 // Every rank passes both barriers of a collective whatever happened locally: a rank that returned early on its own error
-// would leave its peers waiting on the condition variable for ever.  Local errors are posted in err[rank]; after the last
-// barrier every rank returns the first error any rank posted (err[] is cleared by its owner at the start of the next call,
-// which is behind that barrier for every reader).
-static int group_status(const ThreadGroup* g)
+// would leave its peers waiting on the condition variable for ever.  Local errors are posted in err[parity][rank]; after the
+// last barrier every rank returns the first error any rank posted for THIS collective, so all ranks return the same status.
+static int group_status(const ThreadGroup* g, int par)
 {
     for (int r = 0; r < g->world; ++r)
-        if (g->err[r]) return g->err[r];
+        if (const int e = g->err[par][r].load()) return e;
     return 0;
 }
 
@@ -173,10 +179,11 @@ static int threads_all_reduce(kfx_comm* c, void* buf, size_t count, int op, kfx_
     int st = 0;
     if (!buf && count) st = set_error(KFX_E_NULL, "kfx_comm(threads) all_reduce: null buffer");
     if (!st) st = hip_status(hipStreamSynchronize((hipStream_t)stream), "kfx_comm(threads) all_reduce"); // this rank's producers are done
-    g->err[c->rank] = st;
+    const int par = (int)(g->seq[c->rank]++ & 1u);
+    g->err[par][c->rank].store(st);
     g->buf[c->rank] = buf;
     g->wait_all();
-    if (c->rank == 0 && count && group_status(g) == 0) {
+    if (c->rank == 0 && count && group_status(g, par) == 0) {
         PtrList pl;
         for (int r = 0; r < g->world; ++r) pl.p[r] = g->buf[r];
         const dim3 grid((unsigned)((count + 255) / 256));
@@ -187,10 +194,10 @@ static int threads_all_reduce(kfx_comm* c, void* buf, size_t count, int op, kfx_
         else st = set_error(KFX_E_RANGE, "kfx_comm all_reduce: unknown op");
         if (!st) st = check_launch("kfx_comm(threads) all_reduce");
         if (!st) st = hip_status(hipStreamSynchronize(s), "kfx_comm(threads) all_reduce");
-        g->err[0] = st;
+        if (st) g->err[par][0].store(st);
     }
     g->wait_all();
-    return group_status(g);
+    return group_status(g, par);
 }
 
 static int threads_exchange(kfx_comm* c, const void* send_lo, void* recv_lo, size_t bytes_lo, const void* send_hi, void* recv_hi,
@@ -199,24 +206,25 @@ static int threads_exchange(kfx_comm* c, const void* send_lo, void* recv_lo, siz
     ThreadGroup* g = static_cast<ThreadGroup*>(c->impl);
     const int r = c->rank;
     int st = hip_status(hipStreamSynchronize((hipStream_t)stream), "kfx_comm(threads) exchange");
-    g->err[r] = st;
+    const int par = (int)(g->seq[r]++ & 1u);
+    g->err[par][r].store(st);
     g->send_lo[r] = send_lo; g->bytes_lo[r] = bytes_lo;
     g->send_hi[r] = send_hi; g->bytes_hi[r] = bytes_hi;
     g->wait_all();
     hipStream_t s = (hipStream_t)stream;
-    if (!st && r > 0 && bytes_lo && g->err[r - 1] == 0) { // what rank - 1 sends upwards
+    if (!st && r > 0 && bytes_lo && g->err[par][r - 1].load() == 0) { // what rank - 1 sends upwards
         if (g->bytes_hi[r - 1] != bytes_lo) st = set_error(KFX_E_SHAPE, "kfx_comm exchange: neighbours disagree on the byte count");
         else st = hip_status(hipMemcpyAsync(recv_lo, g->send_hi[r - 1], bytes_lo, hipMemcpyDeviceToDevice, s), "kfx_comm(threads) exchange");
     }
-    if (!st && r + 1 < g->world && bytes_hi && g->err[r + 1] == 0) { // what rank + 1 sends downwards
+    if (!st && r + 1 < g->world && bytes_hi && g->err[par][r + 1].load() == 0) { // what rank + 1 sends downwards
         if (g->bytes_lo[r + 1] != bytes_hi) st = set_error(KFX_E_SHAPE, "kfx_comm exchange: neighbours disagree on the byte count");
         else st = hip_status(hipMemcpyAsync(recv_hi, g->send_lo[r + 1], bytes_hi, hipMemcpyDeviceToDevice, s), "kfx_comm(threads) exchange");
     }
     if (!st) st = hip_status(hipStreamSynchronize(s), "kfx_comm(threads) exchange");
-    if (st) g->err[r] = st;   // (only this rank writes its slot; the readers of the first phase are past their reads of it
-                              //  or read a value that is an error either way)
+    if (st) g->err[par][r].store(st);   // (atomic: a neighbour may be reading the slot; it sees 0 or an error, and every rank
+                                        //  reads the final value after the barrier below)
     g->wait_all(); // nobody reuses a send buffer before its reader is done
-    return group_status(g);
+    return group_status(g, par);
 }
 
 static int threads_broadcast(kfx_comm* c, void* buf, size_t bytes, int root, kfx_stream stream)
@@ -226,16 +234,17 @@ static int threads_broadcast(kfx_comm* c, void* buf, size_t bytes, int root, kfx
     if (root < 0 || root >= g->world) st = set_error(KFX_E_RANGE, "kfx_comm broadcast: root");
     if (!st && !buf && bytes) st = set_error(KFX_E_NULL, "kfx_comm(threads) broadcast: null buffer");
     if (!st) st = hip_status(hipStreamSynchronize((hipStream_t)stream), "kfx_comm(threads) broadcast"); // the root's producers are done
-    g->err[c->rank] = st;
+    const int par = (int)(g->seq[c->rank]++ & 1u);
+    g->err[par][c->rank].store(st);
     g->buf[c->rank] = buf;
     g->wait_all();
-    if (!st && c->rank != root && bytes && g->err[root] == 0) {
+    if (!st && c->rank != root && bytes && g->err[par][root].load() == 0) {
         st = hip_status(hipMemcpyAsync(buf, g->buf[root], bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream), "kfx_comm(threads) broadcast");
         if (!st) st = hip_status(hipStreamSynchronize((hipStream_t)stream), "kfx_comm(threads) broadcast");
-        if (st) g->err[c->rank] = st;
+        if (st) g->err[par][c->rank].store(st);
     }
     g->wait_all(); // the root keeps its buffer untouched until every reader is done
-    return group_status(g);
+    return group_status(g, par);
 }
 
 static int threads_barrier(kfx_comm* c)

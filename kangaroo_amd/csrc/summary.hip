@@ -239,8 +239,12 @@ int summary_classes_prepare(kfx_sdf_summary* s, float tol, float vref, int fine_
         const long long waves = (long long)ceil_div(b.nx, 64) * b.ny * b.nz;
         if (pass) {
             const dim3 grid((unsigned)((waves + 3) / 4));
-            if (from_fine) hipLaunchKernelGGL(k_summary_classes_coarse<0>, grid, dim3(256), 0, stream, b, waves, s->d_count, s->d_skippable);
-            else hipLaunchKernelGGL(k_summary_classes_coarse<4>, grid, dim3(256), 0, stream, b, waves, s->d_count, s->d_skippable);
+            const unsigned slot = s->builds % KFX_SUMMARY_RING;
+            int* publish = s->d_skippable + (s->h_skippable ? slot : 0);
+            if (from_fine) hipLaunchKernelGGL(k_summary_classes_coarse<0>, grid, dim3(256), 0, stream, b, waves, s->d_count, publish);
+            else hipLaunchKernelGGL(k_summary_classes_coarse<4>, grid, dim3(256), 0, stream, b, waves, s->d_count, publish);
+            if (s->h_skippable) (void)hipEventRecord(s->build_done[slot], stream);
+            s->builds += 1;
         } else if (L.shift == 3) {
             hipLaunchKernelGGL(k_summary_classes<1>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, stream, b, waves);
         } else {
@@ -282,6 +286,8 @@ extern "C" int kfx_sdf_summary_create(kfx_sdf_summary** out, const kfx_volume* v
     s->pitch = vol->pitch; s->img_pitch = vol->img_pitch;
     s->R = nullptr; s->C = nullptr; s->d_count = nullptr; s->h_skippable = nullptr; s->d_skippable = nullptr;
     s->c_dirty = 1; s->c_tol = -1.f; s->c_vref = 0.f; s->c_shift = 0; s->sweeps = 0;
+    s->builds = 0; s->plain_calls = 0;
+    for (auto& e : s->build_done) e = nullptr;
     s->n_coarse = ceil_div(s->w, 32) * ceil_div(s->h, 32) * ceil_div(s->d, 32);
     const size_t n = (size_t)s->nbx * s->nby * s->nbz;
     ClassView cv;
@@ -289,9 +295,12 @@ extern "C" int kfx_sdf_summary_create(kfx_sdf_summary** out, const kfx_volume* v
     bool ok = hipMalloc((void**)&s->R, n * sizeof(float4)) == hipSuccess && hipMalloc((void**)&s->C, (size_t)cv.words * sizeof(unsigned)) == hipSuccess &&
               hipMalloc((void**)&s->d_count, 2 * sizeof(int)) == hipSuccess && hipMemset(s->d_count, 0, 2 * sizeof(int)) == hipSuccess;
     // the published count lives in pinned host memory the device can write; without it the march always uses the tables
-    if (ok && hipHostMalloc((void**)&s->h_skippable, sizeof(int), hipHostMallocMapped) == hipSuccess) {
-        *s->h_skippable = -1;
-        if (hipHostGetDevicePointer((void**)&s->d_skippable, s->h_skippable, 0) != hipSuccess) {
+    if (ok && hipHostMalloc((void**)&s->h_skippable, KFX_SUMMARY_RING * sizeof(int), hipHostMallocMapped) == hipSuccess) {
+        for (int i = 0; i < KFX_SUMMARY_RING; ++i) s->h_skippable[i] = -1;
+        bool evs = hipHostGetDevicePointer((void**)&s->d_skippable, s->h_skippable, 0) == hipSuccess;
+        for (int i = 0; evs && i < KFX_SUMMARY_RING; ++i) evs = hipEventCreateWithFlags(&s->build_done[i], hipEventDisableTiming) == hipSuccess;
+        if (!evs) {
+            for (auto& e : s->build_done) { if (e) (void)hipEventDestroy(e); e = nullptr; }
             (void)hipHostFree(s->h_skippable);
             s->h_skippable = nullptr;
         }
@@ -318,6 +327,7 @@ extern "C" int kfx_sdf_summary_destroy(kfx_sdf_summary* s)
     if (s->R) (void)hipFree(s->R);
     if (s->C) (void)hipFree(s->C);
     if (s->d_count) (void)hipFree(s->d_count);
+    for (auto& e : s->build_done) if (e) (void)hipEventDestroy(e);
     if (s->h_skippable) (void)hipHostFree(s->h_skippable);
     else if (s->d_skippable) (void)hipFree(s->d_skippable);
     delete s;

@@ -211,3 +211,47 @@ def test_rccl_rendezvous_rejects_stale_foreign_and_linked_files(tmp_path, monkey
     path.unlink()
     path.symlink_to(real)
     assert R.kfx_comm_create_rccl(comm, 1, 2, str(path).encode(), 1) == -4
+
+
+def test_rccl_rendezvous_accepts_a_rank_that_arrives_seconds_later(tmp_path):
+    """Round-3 advice: rank 0 publishes the id, rank 1 -- slower GPU init, import under 8-rank contention -- gets to the
+    rendezvous five seconds later and must still accept the file.  (The old test of "not older than this process" used the
+    st_mtime of /proc/self, which procfs stamps at the first lookup, i.e. when the late rank arrives: it rejected the valid file
+    until the timeout.)  Host-only through the library's probe hook: a fresh process whose first look at procfs comes after the
+    sleep; a file from long before the process began is still refused."""
+    import struct
+    import sys
+    import time
+    lib = os.path.join(os.path.dirname(_lib.LIB_PATH), "libkfx_rccl.so")
+    try:
+        C.CDLL(lib)
+    except OSError as e:
+        import pytest
+        pytest.skip("libkfx_rccl.so not loadable here: %r" % (e,))
+
+    def nonce(run_id):
+        h = 1469598103934665603
+        for ch in run_id.encode():
+            h = ((h ^ ch) * 1099511628211) & (2 ** 64 - 1)
+        h = ((h ^ 0xff) * 1099511628211) & (2 ** 64 - 1)
+        return h | 1
+
+    path = tmp_path / "id"
+    code = ("import ctypes, time, sys\n"
+            "time.sleep(5.0)\n"                                  # rank 1 is busy importing / initialising its GPU
+            "R = ctypes.CDLL(%r)\n"
+            "R.kfx_rccl_process_start.restype = ctypes.c_longlong\n"
+            "print(R.kfx_rccl_rendezvous_probe(%r.encode()), R.kfx_rccl_process_start(), time.time())\n") % (lib, str(path))
+    env = {k: v for k, v in os.environ.items() if k not in ("TORCHELASTIC_RUN_ID", "MASTER_PORT", "SLURM_JOB_ID", "SLURM_STEP_ID")}
+    env["KFX_RUN_ID"] = "late-rank"
+    t_launch = time.time()
+    proc = subprocess.Popen([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, text=True)
+    path.write_bytes(b"KFXRDV1\0" + struct.pack("<Q", nonce("late-rank")) + bytes(128))   # rank 0 publishes right after the launch
+    out = proc.communicate(timeout=60)[0].split()
+    assert proc.returncode == 0 and int(out[0]) == 1, out
+    assert abs(int(out[1]) - t_launch) <= 2, "process start from /proc/self/stat: %s vs %.1f" % (out[1], t_launch)
+    assert float(out[2]) - int(out[1]) >= 4.5           # it did arrive five seconds after it began
+    # ... and a file from an earlier run (an hour before this process began) is still refused
+    os.utime(path, (time.time() - 3600, time.time() - 3600))
+    probe = subprocess.run([sys.executable, "-c", code.replace("time.sleep(5.0)", "pass")], env=env, capture_output=True, text=True, timeout=60)
+    assert probe.returncode == 0 and int(probe.stdout.split()[0]) == 0, probe.stdout + probe.stderr
