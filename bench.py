@@ -77,7 +77,9 @@ def parse():
                          "whole frames -- tracked pair, plain pair, tracked pair -- and keeps the tables only if both tracked blocks beat "
                          "the plain block's median frame by 5 %% (S_full: they do, +15-19 %% frames/s; S_room: the plain pair stays); on: "
                          "always; off: the plain kernels.  The line reports the other variant beside the headline")
-    ap.add_argument("--prime", type=int, default=0, help="at least this many untimed frames of the stream before the W warm-up steps")
+    ap.add_argument("--prime", type=int, default=None,
+                    help="1 GPU: at least this many untimed frames of the stream before the W warm-up steps (default 0: --prime-seconds decides); "
+                         "N > 1: exactly this many (default 450)")
     ap.add_argument("--prime-seconds", type=float, default=2.0,
                     help="untimed frames run until the frame time is stationary AND at least this much GPU time has passed: a GPU "
                          "that was idle takes on the order of a second of work to settle its clocks (KFX_BENCH_DUMP=1 prints the blocks)")
@@ -272,7 +274,7 @@ def run_single(args, torch, roo, scenes, rank):
     gc.collect()
     gc.disable()   # a generation-2 collection inside the timed region stalls the launching thread for tens of ms (seen at --steps 200)
     # ---- untimed: until the frame time is stationary, then the pipeline's own choice of kernels, then stationary again ----
-    prime_log = [prime_stream(kf, step, args.prime_seconds, args.prime_cap_seconds, args.prime)]
+    prime_log = [prime_stream(kf, step, args.prime_seconds, args.prime_cap_seconds, args.prime or 0)]
     if pipe.track_policy == "auto":
         pipe.recalibrate()
         guard = 0
@@ -467,6 +469,8 @@ def run_single(args, torch, roo, scenes, rank):
         o_bytes = float(np.mean([alg[i] for i in io]))
         other_line = {"math": other, "avg_launch_ms": round(o_ms, 5), "achieved_GBps": round(o_bytes / (o_ms * 1e-3) / 1e9, 1),
                       "frac": round(o_bytes / (o_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "frames_per_sec": round(fps_o, 1),
+                      "kernels_ms": {"preprocess": round(float(np.mean(to[:, 0])), 5), "raycast_sdf": round(float(np.mean(to[:, 2])), 5),
+                                     "frame_events": round(float(np.mean(to[:, 3])), 5), "period": round(float(np.nanmean(to[:, 4])), 5)},
                       "note": "same frames, whole step (preprocess + fuse + raycast), plain kernels, %d steps after %d untimed ones" % (n_other, 2 * N_ORBIT)}
     except Exception as e:   # noqa: BLE001
         other_line = {"math": other, "error": repr(e)[:300]}
@@ -612,7 +616,7 @@ def run_slabs(args, torch, dist, roo, scenes, rank, world):
             e.record()
     gc.collect()
     gc.disable()
-    n_prime = max(args.prime, 450)
+    n_prime = 450 if args.prime is None else max(args.prime, 0)
     for i in range(n_prime):
         pipe.step(poses[i % N_ORBIT], frames[i % N_ORBIT])
     for i in range(args.warmup):
