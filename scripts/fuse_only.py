@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Minimal SdfFuse-only workload for PMC collection: 512^3, 640x480, N launches."""
+"""Minimal SdfFuse-only workload for PMC collection: 512^3, N launches.  Usage: fuse_only.py [scene] [reps] [width] [height] [math]
+(640x480 = BASELINE config C2, 1280 960 = C3)."""
 import os
 import sys
 
@@ -10,7 +11,11 @@ from kangaroo_amd import roo, scenes  # noqa: E402
 
 scene = sys.argv[1] if len(sys.argv) > 1 else "full"
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 4
-N, w, h = 512, 640, 480
+N = 512
+w = int(sys.argv[3]) if len(sys.argv) > 3 else 640
+h = int(sys.argv[4]) if len(sys.argv) > 4 else 480
+if len(sys.argv) > 5:
+    roo.set_math_mode(sys.argv[5])
 bmin, bmax, near, far = scenes.SCENES[scene]
 K = scenes.intrinsics(w, h)
 tr = scenes.trunc_dist(bmin, bmax, (N, N, N))
