@@ -80,7 +80,7 @@ int main(int argc, char** argv)
         else if (!strcmp(argv[i], "--fast")) fast = true;
         else if (!strcmp(argv[i], "--track")) track = true;
         else if (!strcmp(argv[i], "--summary")) use_summary = true;   // roo::SdfSummary: SdfFuse keeps it current, RaycastSdf marches through its class tables
-        else if (!strcmp(argv[i], "--summary-auto")) use_summary = summary_auto = true;   // ... and the application keeps it only if it pays (frames 8-19 time both marches)
+        else if (!strcmp(argv[i], "--summary-auto")) use_summary = summary_auto = true;   // ... and the application keeps it only if it pays (whole frames timed with and without it)
         else if (!strcmp(argv[i], "--one-raycast") || !strcmp(argv[i], "--fused-launches")) one_raycast = true;   // additions beside the reference API: all pyramid levels rendered by one launch, vbo + normals in one launch
         else if (!strcmp(argv[i], "--device-icp")) track = device_icp = true;   // the refinement loop as one device-side chain
     }
@@ -108,7 +108,13 @@ int main(int argc, char** argv)
     const float icp_c = 0.1f, max_rmse = 0.10f;                                                   // main.cpp:154,162
 
     std::unique_ptr<SdfSummary> summary;
-    std::vector<double> cal_tables, cal_plain, cal_fuse;   // --summary-auto: host-clock times of frames 8-19
+    // --summary-auto: the policy of FramePipeline (kangaroo_amd/pipeline.py) in the application's terms.  Three blocks of
+    // CAL_BLOCK whole frames from frame CAL_FIRST on -- tracked pair of kernels, plain pair (the summary goes stale), tracked
+    // pair again (summary rebuilt from the volume) --, each frame timed by the host clock between the loop's own
+    // synchronisations; the tables stay only if BOTH tracked blocks beat the plain block's median frame by 5 %.
+    const int CAL_FIRST = 4, CAL_BLOCK = 8;
+    std::vector<double> cal_ms;
+    bool cal_done = !summary_auto;
     if (use_summary) summary.reset(new SdfSummary(vol));
     const float3 vs = vol.VoxelSizeUnits();
     const float trunc_dist = trunc_dist_factor * length(vs);   // main.cpp:221
@@ -135,6 +141,11 @@ int main(int argc, char** argv)
         Mat<float,3,4> T_wl = track ? T_wl_est.matrix3x4<Mat<float,3,4> >() : poses[f];
         dKinectMeters.MemcpyFromHost(depth_frames[f].data());   // the host->device boundary of main.cpp:203
         const auto t0 = std::chrono::steady_clock::now();
+        if (!cal_done && summary) {   // the block this frame belongs to
+            const int k = f - CAL_FIRST;
+            if (k == CAL_BLOCK) use_summary = false;
+            else if (k == 2 * CAL_BLOCK) { summary->Rebuild(); use_summary = true; }
+        }
         ElementwiseScaleBias<float,float,float>(dKinectMeters, dKinectMeters, 1.0f / 1000.0f);
         BilateralFilter<float,float>(kin_d[0], dKinectMeters, bigs, bigr, biwin, 0.2f);
         BoxReduceIgnoreInvalid<float,MaxLevels,float>(kin_d);
@@ -179,26 +190,7 @@ int main(int argc, char** argv)
                 }
             }
             };
-            // --summary-auto, frames 8-19: the rendering through the class tables and, into the same images, by the plain march,
-            // each between two synchronisations and timed by the host clock (the plain march's time is instrumentation and is
-            // taken off the frame's); the frame's images are a valid rendering either way.  The policy of FramePipeline
-            // (kangaroo_amd/pipeline.py) in the application's terms.
-            const bool calibrating = summary_auto && use_summary && f >= 8 && f < 20;
-            if (calibrating) {
-                kfx_stream_synchronize(0);
-                const auto c0 = std::chrono::steady_clock::now();
-                render(true);
-                kfx_stream_synchronize(0);
-                const auto c1 = std::chrono::steady_clock::now();
-                render(false);
-                kfx_stream_synchronize(0);
-                const auto c2 = std::chrono::steady_clock::now();
-                cal_tables.push_back(std::chrono::duration<double, std::milli>(c1 - c0).count());
-                cal_plain.push_back(std::chrono::duration<double, std::milli>(c2 - c1).count());
-                total_ms -= cal_plain.back();
-            } else {
-                render(use_summary);
-            }
+            render(use_summary);
             bool tracking_good = true;
             if (track && f > 0) {   // main.cpp:299-341
                 posesolve::SE3d T_lp;
@@ -268,26 +260,26 @@ int main(int argc, char** argv)
                 worst_pos_err = std::fmax(worst_pos_err, std::sqrt(e));
             }
             if (f > 0 && tracking_good) {
-                if (calibrating) kfx_stream_synchronize(0);
-                const auto c0 = std::chrono::steady_clock::now();
                 if (use_summary) SdfFuse(work_vol, *summary, kin_d[0], kin_n[0], SE3inv(T_wl), K, trunc_dist, max_w, mincostheta);
                 else SdfFuse(work_vol, kin_d[0], kin_n[0], SE3inv(T_wl), K, trunc_dist, max_w, mincostheta);
-                if (calibrating) {
-                    kfx_stream_synchronize(0);
-                    cal_fuse.push_back(std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - c0).count());
-                }
             }
         }
         kfx_stream_synchronize(0);
-        if (summary_auto && use_summary && f == 19 && !cal_plain.empty()) {   // decide once: tables + what they cost SdfFuse against the plain march
-            const auto median = [](std::vector<double> v) { std::sort(v.begin(), v.end()); return v.empty() ? 0.0 : v[v.size() / 2]; };
-            const double tab = median(cal_tables), plain = median(cal_plain), fuse = median(cal_fuse);
-            const bool keep = tab + 0.06 * fuse < 0.97 * plain;
-            printf("  --summary-auto: raycast through the tables %.3f ms, plain %.3f ms, tracked SdfFuse %.3f ms -> %s\n", tab, plain, fuse,
-                   keep ? "table march" : "plain march");
-            if (!keep) { use_summary = false; summary.reset(); }
+        const double frame_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        if (!cal_done && f >= CAL_FIRST) {
+            cal_ms.push_back(frame_ms);
+            if ((int)cal_ms.size() == 3 * CAL_BLOCK) {   // decide once
+                const auto median = [&](int first) { std::vector<double> v(cal_ms.begin() + first, cal_ms.begin() + first + CAL_BLOCK);
+                                                     std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
+                const double t1 = median(0), plain = median(CAL_BLOCK), t2 = median(2 * CAL_BLOCK);
+                const bool keep = std::fmax(t1, t2) <= 0.95 * plain;
+                printf("  --summary-auto: frame with the tables %.3f / %.3f ms, plain kernels %.3f ms -> %s march\n", t1, t2, plain, keep ? "table" : "plain");
+                use_summary = keep;
+                if (!keep) summary.reset();
+                cal_done = true;
+            }
         }
-        total_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        total_ms += frame_ms;
         if (f == frames - 1) {
             ray_d[0].MemcpyToHost(hdepth.data());
             for (float d : hdepth) hits += std::isfinite(d) ? 1 : 0;

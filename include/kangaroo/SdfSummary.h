@@ -32,6 +32,8 @@ public:
     SdfSummary& operator=(const SdfSummary&) = delete;
     // after the volume was written by anything but the overloads below
     void Invalidate() { GpuCheckStatus(kfx_sdf_summary_invalidate(handle_, 0)); }
+    // ... or recompute it from what the volume holds (one pass over the volume): exact ranges and states for every brick
+    void Rebuild() { GpuCheckStatus(kfx_sdf_summary_rebuild(handle_, 0)); }
     kfx_sdf_summary* get() const { return handle_; }
 
 private:

@@ -327,22 +327,30 @@ __global__ __launch_bounds__(256) void k_march_probe(const ProbeParams p)
     const int S = p.S;
     // box origin in cells for the current stage (x / y fixed for the probe: the slopes are small enough for the box's margin)
     const int bx0 = (int)cx - 1, by0 = (int)cy - 1;
-    auto stage_loads = [&](int z0, float4 (&reg)[PROBE_REGS], int& n) {   // the box's rows as 16-byte loads (two cells each), round-robin over the threads
+    // the box's rows as 16-byte loads (two cells each), round-robin over the threads; fully unrolled so that reg[] stays in
+    // registers and all of a thread's loads are in flight together
+    auto stage_loads = [&](int z0, float4 (&reg)[PROBE_REGS], int& n) {
+        const int pairs_per_row = PROBE_BX / 2, total = pairs_per_row * PROBE_BY * (S + 1);
         n = 0;
-        const int pairs_per_row = PROBE_BX / 2, rows = PROBE_BY * (S + 1);
-        for (int i = tid; i < pairs_per_row * rows && n < PROBE_REGS; i += 256, ++n) {
-            const int row = i / pairs_per_row, px = i % pairs_per_row;
-            const int zz = row / PROBE_BY, yy = row % PROBE_BY;
-            reg[n] = *reinterpret_cast<const float4*>(p.base + (size_t)min(z0 + zz, p.D - 1) * p.img + (size_t)(by0 + yy) * p.pitch + (size_t)(bx0 + 2 * px) * 8);
+#pragma unroll
+        for (int k = 0; k < PROBE_REGS; ++k) {
+            const int i = tid + k * 256;
+            if (i < total) {
+                const int row = i / pairs_per_row, px = i % pairs_per_row;
+                const int zz = row / PROBE_BY, yy = row % PROBE_BY;
+                reg[k] = *reinterpret_cast<const float4*>(p.base + (size_t)min(z0 + zz, p.D - 1) * p.img + (size_t)(by0 + yy) * p.pitch + (size_t)(bx0 + 2 * px) * 8);
+            }
         }
     };
-    auto stage_store = [&](const float4 (&reg)[PROBE_REGS], int n) {
-        const int pairs_per_row = PROBE_BX / 2;
-        int k = 0;
-        for (int i = tid; k < n; i += 256, ++k) {
-            const int row = i / pairs_per_row, px = i % pairs_per_row;
-            s_box[row * PROBE_BX + 2 * px] = reg[k].x;
-            s_box[row * PROBE_BX + 2 * px + 1] = reg[k].z;
+    auto stage_store = [&](const float4 (&reg)[PROBE_REGS], int) {
+        const int pairs_per_row = PROBE_BX / 2, total = pairs_per_row * PROBE_BY * (S + 1);
+#pragma unroll
+        for (int k = 0; k < PROBE_REGS; ++k) {
+            const int i = tid + k * 256;
+            if (i < total) {
+                const int row = i / pairs_per_row, px = i % pairs_per_row;
+                *reinterpret_cast<float2*>(&s_box[row * PROBE_BX + 2 * px]) = make_float2(reg[k].x, reg[k].z);
+            }
         }
     };
     float4 reg[PROBE_REGS];

@@ -130,9 +130,9 @@ def test_headless_app_with_brick_summary_renders_the_same_images(extra):
 @pytest.mark.gpu
 @pytest.mark.parametrize("extra", [[], ["--device-icp", "--fused-launches"]])
 def test_headless_app_summary_auto_decides_and_renders_the_same_images(extra):
-    """--summary-auto: the application times the rendering through the class tables and by the plain march on frames 8-19,
-    keeps the faster from frame 20 on and says which.  Exact numerics: whichever it keeps, the last rendering has the bit
-    pattern of the run without the summary."""
+    """--summary-auto: the application times whole frames in three blocks of eight (tracked pair of kernels, plain pair, tracked
+    pair again after roo::SdfSummary::Rebuild), keeps the tables only if both tracked blocks win by 5 % and says which it kept.
+    Exact numerics: whichever it keeps, the last rendering has the bit pattern of the run without the summary."""
     import re
     _build()
     sums = []
@@ -144,7 +144,7 @@ def test_headless_app_summary_auto_decides_and_renders_the_same_images(extra):
         assert m and int(m.group(1)) > 1000, out.stdout
         sums.append(m.group(2))
         if flag:
-            d = re.search(r"--summary-auto: raycast through the tables ([0-9.]+) ms, plain ([0-9.]+) ms, tracked SdfFuse ([0-9.]+) ms -> (table|plain) march", out.stdout)
-            assert d and float(d.group(1)) > 0 and float(d.group(2)) > 0, out.stdout
+            d = re.search(r"--summary-auto: frame with the tables ([0-9.]+) / ([0-9.]+) ms, plain kernels ([0-9.]+) ms -> (table|plain) march", out.stdout)
+            assert d and float(d.group(1)) > 0 and float(d.group(2)) > 0 and float(d.group(3)) > 0, out.stdout
             assert ("(brick summary)" in out.stdout) == (d.group(4) == "table"), out.stdout
     assert sums[0] == sums[1], sums
