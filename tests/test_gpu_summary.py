@@ -283,6 +283,53 @@ print("ok")
     assert out.returncode == 0 and "ok" in out.stdout, out.stdout + out.stderr
 
 
+def test_gpu_unforced_choice_is_a_function_of_the_calls(tmp_path):
+    """Round-3 advice: with KFX_RAYCAST_SUMMARY unset the tracked RaycastSdf chooses between the table march and the plain march
+    from a count a table build published -- and in fast numerics the two agree within tolerance only, so the choice must not
+    depend on how far the GPU happens to have got.  It is taken from the count of the build before the previous one (a ring of
+    published counts): the same sequence of calls renders the same bits, run after run, with the host racing ahead or
+    synchronising after every frame.  S_room at 96^3 crosses the quarter threshold while the stream develops, so both kernels
+    are in play."""
+    import subprocess
+    import sys
+    code = r'''
+import sys, hashlib, numpy as np, torch
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import kfx_testlib as T
+from kfx_testlib import scenes
+from kangaroo_amd import roo
+from kangaroo_amd.pipeline import FramePipeline
+sync_every_frame = sys.argv[1] == "1"
+roo.set_math_mode("fast")
+N, w, h = 96, 200, 150
+out = []
+for scene in ("room", "full"):
+    bmin, bmax, near, far = scenes.SCENES[scene]
+    pipe = FramePipeline(roo, (N, N, N), bmin, bmax, w, h, near=near, far=far, track=True)
+    frames = [T.upload_image(roo, scenes.render_depth(scene, w, h, scenes.orbit_pose(i, 30), pipe.K)) for i in range(30)]
+    keep = []
+    for i in range(45):
+        pipe.step(scenes.orbit_pose(i %% 30, 30), frames[i %% 30])
+        if sync_every_frame:
+            torch.cuda.synchronize()
+        keep.append(pipe.ray_d.tensor().clone())
+    torch.cuda.synchronize()
+    hsh = hashlib.sha256()
+    for t in keep:
+        hsh.update(t.cpu().numpy().tobytes())
+    out.append(hsh.hexdigest())
+print("HASH", " ".join(out))
+''' % (T.ROOT, __import__("os").path.join(T.ROOT, "tests"))
+    env = dict(__import__("os").environ)
+    env.pop("KFX_RAYCAST_SUMMARY", None)
+    hashes = []
+    for mode in ("0", "1", "0"):
+        out = subprocess.run([sys.executable, "-c", code, mode], capture_output=True, text=True, timeout=600, env=env)
+        assert out.returncode == 0 and "HASH" in out.stdout, out.stdout + out.stderr
+        hashes.append([l for l in out.stdout.splitlines() if l.startswith("HASH")][0])
+    assert hashes[0] == hashes[1] == hashes[2], hashes
+
+
 @pytest.mark.parametrize("scene", ["full", "room"])
 def test_gpu_frame_pipeline_auto_policy(roo, scene):
     """FramePipeline(track="auto"): starts with the summary, times three blocks of whole frames of the stream itself (tracked
