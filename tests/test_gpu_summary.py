@@ -283,6 +283,38 @@ print("ok")
     assert out.returncode == 0 and "ok" in out.stdout, out.stdout + out.stderr
 
 
+def test_gpu_tracked_march_counts_its_own_work(roo):
+    """kfx_raycast_sdf_count_tracked (bench.py's roofline_raycast): the class-table march with every cell it reads marked in a
+    bitmap.  Same rays, same hits as the plain march's count; fewer samples and cells (it crosses free space without reading the
+    volume), every cell it reads is one the plain march reads too (same positions), table look-ups and table bytes reported."""
+    N, w, h = 96, 200, 150
+    bmin, bmax, near, far = scenes.SCENES["full"]
+    K = scenes.intrinsics(w, h)
+    tr = scenes.trunc_dist(bmin, bmax, (N, N, N))
+    vol = roo.BoundedVolume(N, N, N, bmin, bmax)
+    summ = roo.SdfSummary(vol)
+    roo.SdfReset(vol, float("nan"), summary=summ)
+    f, vbo, nrm = roo.Image(w, h), roo.Image(w, h, "f32x4"), roo.Image(w, h, "f32x4")
+    # one frame, exact numerics: a cell observed once in front of the wall holds the clamped +trunc bit for bit, so free space qualifies
+    T_wc = scenes.orbit_pose(0, 30)
+    roo.BilateralFilter(f, T.upload_image(roo, scenes.render_depth("full", w, h, T_wc, K)), **scenes.BILATERAL)
+    roo.DepthToVbo(vbo, f, K)
+    roo.NormalsFromVbo(nrm, vbo)
+    roo.SdfFuse(vol, f, nrm, scenes.se3_inverse(T_wc), K, tr, scenes.MAX_W, scenes.MIN_COS_THETA, summary=summ)
+    plain = roo.RaycastSdfCount(vol, w, h, T_wc, K, near, far, tr, True)
+    tab = roo.RaycastSdfCount(vol, w, h, T_wc, K, near, far, tr, True, summary=summ)
+    assert tab["rays"] == plain["rays"] > 0 and tab["hits"] == plain["hits"] > 0
+    assert tab["table_bytes"] > 0 and tab["lookups"] > 0, tab          # (the suite forces the table march: tests/conftest.py)
+    assert 0 < tab["samples"] < 0.5 * plain["samples"], (tab, plain)
+    assert 0 < tab["U"] < plain["U"], (tab, plain)
+    # the images of the two marches are the same bits (exact numerics), so the hits' gradient stencils are the same cells
+    a = [roo.Image(w, h), roo.Image(w, h, "f32x4"), roo.Image(w, h)]
+    b = [roo.Image(w, h), roo.Image(w, h, "f32x4"), roo.Image(w, h)]
+    roo.RaycastSdf(*a, vol, T_wc, K, near, far, tr, True)
+    roo.RaycastSdf(*b, vol, T_wc, K, near, far, tr, True, summary=summ)
+    assert all(T.nan_equal(x.MemcpyToHost(), y.MemcpyToHost()) for x, y in zip(a, b))
+
+
 def test_gpu_unforced_choice_is_a_function_of_the_calls(tmp_path):
     """Round-3 advice: with KFX_RAYCAST_SUMMARY unset the tracked RaycastSdf chooses between the table march and the plain march
     from a count a table build published -- and in fast numerics the two agree within tolerance only, so the choice must not
