@@ -379,8 +379,8 @@ int kfx_raycast_state_to_images(const kfx_image* depth, const kfx_image* norm, c
  * of them in space the TSDF knows to be empty.  A kfx_sdf_summary keeps, per 8 x 8 x 8 cells, the range of the stored
  * values; the tracked SdfFuse maintains it as a by-product (one workgroup owns a summary brick: wave shuffles + LDS, no
  * atomics).  The tracked RaycastSdf builds two-bit class tables from it (per 16^3 and 32^3 cells: every cell holds trunc_dist
- * / every cell is NaN / every cell is one or the other), stages them in LDS and takes the reference's own steps through such
- * entries without reading the volume:
+ * / every cell is NaN / every cell is one or the other), stages them in LDS, derives the same classes for 64^3 and 128^3 cells
+ * there, and takes the reference's own steps through such entries without reading the volume:
  *   exact numerics: only cells bit-equal to trunc_dist (or NaN) qualify -- the images equal kfx_raycast_sdf bit for bit;
  *   fast numerics:  also cells within a relative 1e-5 of it (observed free space: the running average of +trunc drifts
  *                   by a few ulp per frame) -- depth within the fast-mode tolerance of the exact march.

@@ -224,7 +224,19 @@ struct ClassView {
     int amb_ok;          // class 3 may be skipped (trunc >= min_delta)
     int ox, oy, oz;      // cell offset of the view inside the parent volume
     float eps;           // margin (cells) that covers the error of the affine cell estimate
+    // Coarser levels (64^3 and 128^3 cells) are not built in global memory: every raycast workgroup derives them in LDS from
+    // the 32^3-cell level it has just staged (an entry = the combination of its 2 x 2 x 2 children, which include their +1
+    // cells), behind the staged words.  nx5 / nz5: entries of the 32^3-cell level along x / z (ny5 = coarse.ny); top_n: how
+    // many coarser levels there are (0-2); lds_words: staged words + the derived levels.
+    int nx5, nz5, top_n, lds_words;
 };
+// geometry of a level derived from a finer one with nx x ny x nz entries, placed at word `first`
+inline __host__ __device__ void class_level_up(const int nx, const int ny, const int nz, const int shift, const int first, ClassLevel& L, int& ux, int& uz, int& words)
+{
+    ux = (nx + 1) >> 1; uz = (nz + 1) >> 1;
+    L.shift = shift; L.ny = (ny + 1) >> 1; L.rw = 2 * ((ux + 31) >> 5); L.first = first;
+    words = (L.rw * L.ny * uz + 3) & ~3;
+}
 int summary_classes_prepare(kfx_sdf_summary* s, float tol, float vref, int fine_shift, hipStream_t stream);
 void summary_class_layout(const kfx_sdf_summary* s, int fine_shift, ClassView& cv);
 // cell offset of a view of the summary's parent volume (same pitches, pointer inside the parent): 0 on success

@@ -142,6 +142,10 @@ __device__ __forceinline__ float raycast_pixel(const RayParams& p, const ColorGe
 // exact-numerics tables (tol = 0: cells bit-equal to trunc, or NaN) depth, normals and shade stay bit-identical to the
 // plain march.
 // ---------------------------------------------------------------------------------------
+// The coarser levels of the workgroup (ClassView::top_n of them: 64^3 and 128^3 cells, derived in LDS by classes_stage), described
+// where the march can read them without holding them in registers across its loop.
+struct TopLevels { ClassLevel lv[2]; int n; };
+
 __device__ __forceinline__ int class_lookup(const unsigned* tab, const ClassLevel& L, int gx, int gy, int gz)
 {
     const int bx = gx >> L.shift, by = gy >> L.shift, bz = gz >> L.shift;
@@ -154,7 +158,7 @@ __device__ __forceinline__ int class_lookup(const unsigned* tab, const ClassLeve
 __device__ __forceinline__ unsigned touch(unsigned* bitmap, const VolView& v, int x, int y, int z);
 template <typename CELL, bool COLOR, bool COUNT = false>
 __device__ __forceinline__ float raycast_pixel_classes(const RayParams& p, const RayParams& q, const ColorGeom& cv, const int u, const int v, const ClassView& cl, const unsigned* tab,
-                                                       unsigned* bitmap = nullptr, unsigned* cnt = nullptr)
+                                                       const TopLevels& top, unsigned* bitmap = nullptr, unsigned* cnt = nullptr)
 {
     // p: the launch parameters as kernel arguments (scalar registers); q: the workgroup's copy of them in LDS, read by the
     // epilogue -- pose, intrinsics, output images and the gradient's geometry are then not held in scalar registers across the
@@ -227,6 +231,20 @@ __device__ __forceinline__ float raycast_pixel_classes(const RayParams& p, const
                         int c5 = class_lookup(tab, cl.coarse, gx, gy, gz);
                         if (c5 == 3 && !cl.amb_ok) c5 = 0;
                         if (c5 != 0) { cls = c5; shift = 5; }
+                    }
+                    // ... and a run through 32^3 cells may be one through 64^3 or 128^3 (the levels the workgroup derived in LDS):
+                    // wide free or never-observed space is crossed in a third of the look-ups
+                    if (shift == 5 && cl.top_n > 0) {
+                        int c6 = class_lookup(tab, top.lv[0], gx, gy, gz);
+                        if (c6 == 3 && !cl.amb_ok) c6 = 0;
+                        if (c6 != 0) {
+                            cls = c6; shift = 6;
+                            if (cl.top_n > 1) {
+                                int c7 = class_lookup(tab, top.lv[1], gx, gy, gz);
+                                if (c7 == 3 && !cl.amb_ok) c7 = 0;
+                                if (c7 != 0) { cls = c7; shift = 7; }
+                            }
+                        }
                     }
                     // the entry's cells are [lo, lo + L) per axis in the view's coordinates; its far side along the ray, pulled in
                     // by the margin: positions up to there certainly have their base cell in the entry
@@ -334,13 +352,69 @@ __device__ __forceinline__ float raycast_pixel_classes(const RayParams& p, const
     return depth > 0 ? depth : __builtin_nanf("");
 }
 
-// workgroup prologue of the class-table kernels: the tables into LDS (16-byte loads, all in flight together)
-__device__ __forceinline__ void classes_stage(const ClassView& cl, unsigned* tab)
+// one derived level: entry (bx, by, bz) = combination of the 2 x 2 x 2 entries of `src` below it (edge entries repeat a
+// neighbour: same verdict).  One entry per thread and round: rows are padded to a power of two (or to whole waves when they are
+// longer than a wave), so a wave's 64 lanes hold whole rows side by side, the two bit planes are its ballots, and the first
+// lane of each row writes the row's share of them.
+__device__ __forceinline__ void classes_level_up(unsigned* tab, const ClassLevel& src, int snx, int snz, const ClassLevel& dst, int dnx, int dnz)
+{
+    const int lane = threadIdx.x & 63;
+    int lg = 0;                                      // log2 of the padded row length, at most 6 ...
+    while ((1 << lg) < dnx && lg < 6) ++lg;
+    const int chunks = (dnx + 63) >> 6;              // ... rows longer than a wave take `chunks` waves
+    const int px = chunks > 1 ? chunks << 6 : 1 << lg;
+    const int total = px * dst.ny * dnz;
+    for (int e0 = 0; e0 < total; e0 += 256) {        // uniform: every wave runs the same number of rounds (ballots below)
+        const int e = e0 + (int)threadIdx.x;
+        const int bx = chunks > 1 ? e % px : e & (px - 1), r = chunks > 1 ? e / px : e >> lg;
+        const int by = r % dst.ny, bz = r / dst.ny;
+        int cls = 0;
+        if (e < total && bx < dnx) {
+            bool all_free = true, all_nan = true, all_either = true;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int x = min(2 * bx + (k & 1), snx - 1), y = min(2 * by + ((k >> 1) & 1), src.ny - 1), z = min(2 * bz + (k >> 2), snz - 1);
+                const uint2 w = *reinterpret_cast<const uint2*>(tab + src.first + (z * src.ny + y) * src.rw + ((x >> 5) << 1));
+                const int c = (int)((w.x >> (x & 31)) & 1u) | (int)(((w.y >> (x & 31)) & 1u) << 1);
+                all_free = all_free && c == 1;
+                all_nan = all_nan && c == 2;
+                all_either = all_either && c != 0;
+            }
+            cls = all_free ? 1 : (all_nan ? 2 : (all_either ? 3 : 0));
+        }
+        const unsigned long long p0 = __ballot(cls & 1), p1 = __ballot(cls & 2);
+        if (e < total && (bx & 63) == 0 && (chunks > 1 || bx == 0)) {   // first lane of a row (or of a row's 64-entry chunk)
+            const int sh = chunks > 1 ? 0 : lane;                        // where the row's bits start in the ballots
+            const unsigned long long m = (chunks > 1 || lg == 6) ? ~0ull : ((1ull << (1 << lg)) - 1ull);
+            const unsigned long long r0 = (p0 >> sh) & m, r1 = (p1 >> sh) & m;
+            unsigned* out = tab + dst.first + (bz * dst.ny + by) * dst.rw + (bx >> 6) * 4;
+            out[0] = (unsigned)r0; out[1] = (unsigned)r1;
+            if ((bx >> 6) * 4 + 2 < dst.rw) { out[2] = (unsigned)(r0 >> 32); out[3] = (unsigned)(r1 >> 32); }
+        }
+    }
+}
+
+// workgroup prologue of the class-table kernels: the tables into LDS (16-byte loads, all in flight together), then the
+// coarser levels derived from the 32^3-cell level
+__device__ __forceinline__ void classes_stage(const ClassView& cl, unsigned* tab, TopLevels& top)
 {
     const uint4* src = reinterpret_cast<const uint4*>(cl.C);
     uint4* dst = reinterpret_cast<uint4*>(tab);
     for (int i = threadIdx.x; i < (cl.words >> 2); i += blockDim.x) dst[i] = src[i];
+    ClassLevel l6, l7;
+    int nx6, nz6, nx7, nz7, w6, w7;
+    class_level_up(cl.nx5, cl.coarse.ny, cl.nz5, 6, cl.words, l6, nx6, nz6, w6);
+    class_level_up(nx6, l6.ny, nz6, 7, cl.words + w6, l7, nx7, nz7, w7);
+    if (threadIdx.x == 0) { top.lv[0] = l6; top.lv[1] = l7; top.n = cl.top_n; }
     __syncthreads();
+    if (cl.top_n > 0) {   // launch-uniform
+        classes_level_up(tab, cl.coarse, cl.nx5, cl.nz5, l6, nx6, nz6);
+        __syncthreads();
+        if (cl.top_n > 1) {
+            classes_level_up(tab, l6, nx6, nz6, l7, nx7, nz7);
+            __syncthreads();
+        }
+    }
 }
 
 template <typename CELL>
@@ -348,8 +422,9 @@ __global__ __launch_bounds__(256) void k_raycast_sdf_classes(const RayParams p, 
 {
     extern __shared__ unsigned s_tab[];
     __shared__ RayParams s_p;
+    __shared__ TopLevels s_top;
     if (threadIdx.x == 0) s_p = p;
-    classes_stage(cl, s_tab);   // (barrier inside)
+    classes_stage(cl, s_tab, s_top);   // (barriers inside)
     int u, v;
     if (p.sparse_lanes) {
         const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -359,7 +434,7 @@ __global__ __launch_bounds__(256) void k_raycast_sdf_classes(const RayParams p, 
     } else {
         ray_pixel_of(p, blockIdx.x, blockIdx.y, threadIdx.x, u, v);
     }
-    raycast_pixel_classes<CELL, false>(p, s_p, ColorGeom{}, u, v, cl, s_tab);
+    raycast_pixel_classes<CELL, false>(p, s_p, ColorGeom{}, u, v, cl, s_tab, s_top);
 }
 
 template <typename CELL, bool COLOR>
@@ -457,8 +532,9 @@ __global__ __launch_bounds__(256) void k_raycast_sdf_classes_count(const RayPara
 {
     extern __shared__ unsigned s_tab[];
     __shared__ RayParams s_p;
+    __shared__ TopLevels s_top;
     if (threadIdx.x == 0) s_p = p;
-    classes_stage(cl, s_tab);   // (barrier inside)
+    classes_stage(cl, s_tab, s_top);   // (barriers inside)
     int u, v;
     ray_pixel_of(p, blockIdx.x, blockIdx.y, threadIdx.x, u, v);
     unsigned cnt[4] = {0u, 0u, 0u, 0u}, entered = 0;
@@ -471,7 +547,7 @@ __global__ __launch_bounds__(256) void k_raycast_sdf_classes_count(const RayPara
         const V3 tmin = v3(fminf(ta.x, tb.x), fminf(ta.y, tb.y), fminf(ta.z, tb.z));
         const V3 tmax = v3(fmaxf(ta.x, tb.x), fmaxf(ta.y, tb.y), fmaxf(ta.z, tb.z));
         entered = fmaxf(fmaxf(fmaxf(tmin.x, tmin.y), tmin.z), p.near) < fminf(fminf(fminf(tmax.x, tmax.y), tmax.z), p.far) ? 1u : 0u;
-        raycast_pixel_classes<CELL, false, true>(p, s_p, ColorGeom{}, u, v, cl, s_tab, bitmap, cnt);
+        raycast_pixel_classes<CELL, false, true>(p, s_p, ColorGeom{}, u, v, cl, s_tab, s_top, bitmap, cnt);
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -557,8 +633,9 @@ __global__ __launch_bounds__(256) void k_raycast_sdf_levels_classes(const RayPar
     p.dpitch = lv.dpitch; p.npitch = lv.npitch; p.ipitch = lv.ipitch;
     p.w = lv.w; p.h = lv.h;
     p.K = lv.K;
+    __shared__ TopLevels s_top;
     if (threadIdx.x == 0) s_p = p;
-    classes_stage(cl, s_tab);   // before any lane leaves (barrier inside)
+    classes_stage(cl, s_tab, s_top);   // before any lane leaves (barriers inside)
     const int b = (int)blockIdx.x - lv.first_block;
     int u, v;
     if (lv.sparse) {
@@ -569,7 +646,7 @@ __global__ __launch_bounds__(256) void k_raycast_sdf_levels_classes(const RayPar
     } else {
         ray_pixel_of(p, b % lv.blocks_x, b / lv.blocks_x, threadIdx.x, u, v);
     }
-    const float kz = raycast_pixel_classes<CELL, false>(p, s_p, ColorGeom{}, u, v, cl, s_tab);
+    const float kz = raycast_pixel_classes<CELL, false>(p, s_p, ColorGeom{}, u, v, cl, s_tab, s_top);
     if (lv.vptr && u < p.w && v < p.h)
         reinterpret_cast<float4*>(lv.vptr + (size_t)v * lv.vpitch)[u] =
             make_float4(kz * ((float)u - p.K.u0) / p.K.fu, kz * ((float)v - p.K.v0) / p.K.fv, kz, 1.0f);
@@ -804,7 +881,20 @@ static int class_view(ClassView& cl, size_t* lds_bytes, int* usable, kfx_sdf_sum
     eps *= 2.0;   // twice the bound
     if (!(eps < 0.05)) return 0;
     cl.eps = (float)std::fmax(eps, 1e-4);
-    *lds_bytes = (size_t)cl.words * sizeof(unsigned);
+    // the coarser levels every workgroup derives in LDS (classes_stage): 64^3 cells where the 32^3-cell level has more than one
+    // entry along some axis, 128^3 cells likewise on top of that
+    cl.nx5 = ceil_div(summary->w, 32); cl.nz5 = ceil_div(summary->d, 32);
+    static const int top_env = [] { const char* e = getenv("KFX_RAYCAST_TOP_LEVELS"); const int v = e ? atoi(e) : 2; return v < 0 ? 0 : (v > 2 ? 2 : v); }();
+    ClassLevel l6, l7;
+    int nx6, nz6, nx7, nz7, w6, w7;
+    class_level_up(cl.nx5, cl.coarse.ny, cl.nz5, 6, cl.words, l6, nx6, nz6, w6);
+    class_level_up(nx6, l6.ny, nz6, 7, cl.words + w6, l7, nx7, nz7, w7);
+    cl.top_n = 0;
+    if (cl.nx5 > 1 || cl.coarse.ny > 1 || cl.nz5 > 1) cl.top_n = 1;
+    if (cl.top_n && (nx6 > 1 || l6.ny > 1 || nz6 > 1)) cl.top_n = 2;
+    if (cl.top_n > top_env) cl.top_n = top_env;
+    cl.lds_words = cl.words + (cl.top_n > 0 ? w6 : 0) + (cl.top_n > 1 ? w7 : 0);
+    *lds_bytes = (size_t)cl.lds_words * sizeof(unsigned);
     *usable = 1;
     return 0;
 }

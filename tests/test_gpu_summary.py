@@ -315,6 +315,59 @@ def test_gpu_tracked_march_counts_its_own_work(roo):
     assert all(T.nan_equal(x.MemcpyToHost(), y.MemcpyToHost()) for x, y in zip(a, b))
 
 
+def test_gpu_coarser_levels_derived_in_lds_skip_more_and_change_nothing(tmp_path):
+    """The 64^3- and 128^3-cell levels every raycast workgroup derives in LDS from the 32^3-cell level (classes_stage, raycast.hip):
+    exact numerics, 256^3 (four and two entries per axis) and a ragged 200 x 168 x 232 volume, both scenes, several frames --
+    the images are the plain march's bit for bit with the levels on (default) and off (KFX_RAYCAST_TOP_LEVELS=0, read once per
+    process), and with them the march needs fewer table look-ups for the same samples."""
+    import subprocess
+    import sys
+    code = r'''
+import sys, json, numpy as np, torch
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import kfx_testlib as T
+from kfx_testlib import scenes
+from kangaroo_amd import roo
+out = {}
+for scene, dims, (w, h) in (("full", (256, 256, 256), (320, 240)), ("room", (256, 256, 256), (320, 240)), ("room", (200, 168, 232), (200, 150))):
+    bmin, bmax, near, far = scenes.SCENES[scene]
+    K = scenes.intrinsics(w, h); tr = scenes.trunc_dist(bmin, bmax, dims)
+    vol = roo.BoundedVolume(*dims, bmin, bmax); summ = roo.SdfSummary(vol)
+    roo.SdfReset(vol, float("nan"), summary=summ)
+    f, vbo, nrm = roo.Image(w, h), roo.Image(w, h, "f32x4"), roo.Image(w, h, "f32x4")
+    look = samp = 0
+    for i in range(3):
+        T_wc = scenes.orbit_pose(3 * i, 30)
+        roo.BilateralFilter(f, T.upload_image(roo, scenes.render_depth(scene, w, h, T_wc, K)), **scenes.BILATERAL)
+        roo.DepthToVbo(vbo, f, K); roo.NormalsFromVbo(nrm, vbo)
+        roo.SdfFuse(vol, f, nrm, scenes.se3_inverse(T_wc), K, tr, scenes.MAX_W, scenes.MIN_COS_THETA, full_extent=True, summary=summ)
+        a = [roo.Image(w, h), roo.Image(w, h, "f32x4"), roo.Image(w, h)]
+        b = [roo.Image(w, h), roo.Image(w, h, "f32x4"), roo.Image(w, h)]
+        roo.RaycastSdf(*a, vol, T_wc, K, near, far, tr, True)
+        roo.RaycastSdf(*b, vol, T_wc, K, near, far, tr, True, summary=summ)
+        torch.cuda.synchronize()
+        assert all(T.nan_equal(x.MemcpyToHost(), y.MemcpyToHost()) for x, y in zip(a, b)), (scene, dims, i)
+        assert np.isfinite(a[0].MemcpyToHost()).sum() > 0.05 * w * h
+        c = roo.RaycastSdfCount(vol, w, h, T_wc, K, near, far, tr, True, summary=summ)
+        assert c["table_bytes"] > 0
+        look += c["lookups"]; samp += c["samples"]
+    out["%%s-%%d" %% (scene, dims[0])] = [look, samp]
+print("RES", json.dumps(out))
+''' % (T.ROOT, __import__("os").path.join(T.ROOT, "tests"))
+    import json
+    res = {}
+    for levels in ("0", "2"):
+        env = dict(__import__("os").environ, KFX_RAYCAST_SUMMARY="1", KFX_RAYCAST_TOP_LEVELS=levels)
+        out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+        assert out.returncode == 0 and "RES" in out.stdout, out.stdout + out.stderr
+        res[levels] = json.loads([l for l in out.stdout.splitlines() if l.startswith("RES")][0][4:])
+    for key in res["0"]:
+        (l0, s0), (l2, s2) = res["0"][key], res["2"][key]
+        assert 0 < s2 <= s0, (key, res)          # positions at an entry's rim are sampled rather than skipped: fewer rims, a few samples fewer
+        assert l2 <= l0, (key, res)
+    assert res["2"]["full-256"][0] < 0.9 * res["0"]["full-256"][0], res   # wide free space: fewer look-ups
+
+
 def test_gpu_unforced_choice_is_a_function_of_the_calls(tmp_path):
     """Round-3 advice: with KFX_RAYCAST_SUMMARY unset the tracked RaycastSdf chooses between the table march and the plain march
     from a count a table build published -- and in fast numerics the two agree within tolerance only, so the choice must not
