@@ -246,6 +246,10 @@ def run_single(args, torch, roo, scenes, rank):
     kf = pipe.kframe
     if kf is None:
         sys.exit("bench.py: the operator set has no kfx_frame (libkfx too old?)")
+    # An event is a marker between two launches and costs the stream a few microseconds (all four of a frame: 2.7 % of frames/s,
+    # measured): the untimed and the timed frames record the two around SdfFuse -- its window for `roofline`, and the frame period
+    # (before-SdfFuse to before-SdfFuse) -- and the parts of a frame are read from frames with all four events afterwards.
+    pipe.set_timing(kf.EVENTS_FUSE)
 
     # synthetic depth stream, uploaded once: the timed region starts with inputs resident in HBM
     poses = [scenes.orbit_pose(i, N_ORBIT) for i in range(N_ORBIT)]
@@ -295,17 +299,26 @@ def run_single(args, torch, roo, scenes, rank):
     elapsed = time.perf_counter() - t0
     gc.enable()
 
-    t = kf.timings(first, args.steps)   # device events recorded by kfx_frame_step on the launch stream
-    pre_ms, fuse_ms, ray_ms, frame_ms = t[:, 0], t[:, 1], t[:, 2], t[:, 3]
+    t = kf.timings(first, args.steps)   # device events recorded by kfx_frame_step on the launch stream around SdfFuse
+    fuse_ms = t[:, 1]
+    # the parts of the same frames, from 60 more of them with all four events (untimed; they cost 2-3 % of the frame rate)
+    pipe.set_timing(kf.EVENTS_ALL)
+    for _ in range(N_ORBIT):
+        step()
+    f_parts = kf.count
+    i_parts = [step() for _ in range(2 * N_ORBIT)]
+    tp = kf.timings(f_parts, 2 * N_ORBIT)
+    pre_ms, ray_ms, frame_ms = tp[:, 0], tp[:, 2], tp[:, 3]
     if os.environ.get("KFX_BENCH_DUMP"):   # per-step windows of the timed region and the priming blocks (transients)
         for pl in prime_log:
             print("prime_blocks_ms " + " ".join("%.4f" % v for v in pl["block_mean_frame_ms"]), file=sys.stderr)
         print("fuse_ms " + " ".join("%.3f" % v for v in fuse_ms[:64]), file=sys.stderr)
-        print("ray_ms " + " ".join("%.3f" % v for v in ray_ms[:64]), file=sys.stderr)
-        print("pre_ms " + " ".join("%.3f" % v for v in pre_ms[:64]), file=sys.stderr)
         print("period_ms " + " ".join("%.3f" % v for v in t[:64, 4]), file=sys.stderr)
+        print("parts: ray_ms " + " ".join("%.3f" % v for v in ray_ms[:30]), file=sys.stderr)
+        print("parts: pre_ms " + " ".join("%.3f" % v for v in pre_ms[:30]), file=sys.stderr)
     fuse_avg_ms = float(np.mean(fuse_ms))
     ray_avg_ms = float(np.mean(ray_ms))
+    ray_idx = i_parts   # the poses RaycastSdf's figures are averaged over
     bytes_avg = float(np.mean([alg[i] for i in idx]))
     achieved = bytes_avg / (fuse_avg_ms * 1e-3) / 1e9
     voxels = pipe.vol.w * pipe.vol.h * pipe.vol.d
@@ -389,10 +402,10 @@ def run_single(args, torch, roo, scenes, rank):
     try:
         ref_cnt = [roo.RaycastSdfCount(pipe.vol, w, h, poses[i], K, near, far, pipe.trunc, True) for i in range(N_ORBIT)]
         cnt = [roo.RaycastSdfCount(pipe.vol, w, h, poses[i], K, near, far, pipe.trunc, True, summary=pipe.summary) for i in range(N_ORBIT)] if use_summary else ref_cnt
-        U = float(np.mean([cnt[i]["U"] for i in idx]))
-        smp = float(np.mean([cnt[i]["samples"] for i in idx]))
-        tab = float(np.mean([cnt[i].get("table_bytes", 0) for i in idx]))
-        U_ref = float(np.mean([ref_cnt[i]["U"] for i in idx]))
+        U = float(np.mean([cnt[i]["U"] for i in ray_idx]))
+        smp = float(np.mean([cnt[i]["samples"] for i in ray_idx]))
+        tab = float(np.mean([cnt[i].get("table_bytes", 0) for i in ray_idx]))
+        U_ref = float(np.mean([ref_cnt[i]["U"] for i in ray_idx]))
         ray_bytes = 8.0 * U + tab + 24.0 * w * h
         ray_traffic, ray_traffic_src = pmc_traffic("raycast_%s_%s%s" % (scene, args.math, "_tracked" if use_summary else "")) if (N, w, h) == (512, 640, 480) else (None, None)
         roofline_raycast = {
@@ -402,11 +415,12 @@ def run_single(args, torch, roo, scenes, rank):
             "traffic": ray_traffic, "traffic_source": ray_traffic_src,
             "algorithmic_bytes_per_launch": round(ray_bytes), "distinct_voxels": round(U), "class_table_bytes": round(tab),
             "avg_launch_ms": round(ray_avg_ms, 5), "includes": "the per-frame build of the class tables (two small launches)" if use_summary else None,
+            "timing": "hipEvents around the RaycastSdf call of %d frames of the same stream stepped with all four events right after the timed region" % (2 * N_ORBIT),
             "samples_per_launch": round(smp), "Gsamples_per_s": round(smp / (ray_avg_ms * 1e-3) / 1e9, 3),
             "gather_64B_GBps": round(64.0 * 4 * smp / (ray_avg_ms * 1e-3) / 1e9, 1),
-            "table_lookups_per_launch": round(float(np.mean([cnt[i].get("lookups", 0) for i in idx]))),
-            "rays_in_box": round(float(np.mean([cnt[i]["rays"] for i in idx]))), "hits": round(float(np.mean([cnt[i]["hits"] for i in idx]))),
-            "reference_U": round(U_ref), "reference_samples": round(float(np.mean([ref_cnt[i]["samples"] for i in idx]))),
+            "table_lookups_per_launch": round(float(np.mean([cnt[i].get("lookups", 0) for i in ray_idx]))),
+            "rays_in_box": round(float(np.mean([cnt[i]["rays"] for i in ray_idx]))), "hits": round(float(np.mean([cnt[i]["hits"] for i in ray_idx]))),
+            "reference_U": round(U_ref), "reference_samples": round(float(np.mean([ref_cnt[i]["samples"] for i in ray_idx]))),
             "reference_bytes": round(8.0 * U_ref + 24.0 * w * h),
             "note": "U, samples and look-ups are this kernel's own (counted by a bitmap instantiation of the same march); reference_* are the "
                     "reference march's for the same poses (what the images depend on)"}
@@ -569,9 +583,14 @@ def run_single(args, torch, roo, scenes, rank):
             "torch_copy_GBps": None if copy_GBps is None else round(copy_GBps, 1),
             "note": "whole volume",
         },
-        "kernels_ms": {"preprocess": round(float(np.mean(pre_ms)), 5), "sdf_fuse": round(fuse_avg_ms, 5), "raycast_sdf": round(ray_avg_ms, 5),
-                       "frame_events": round(float(np.mean(frame_ms)), 5), "frame_total": round(1e3 * elapsed / args.steps, 5),
-                       "between_frames": round(1e3 * elapsed / args.steps - float(np.mean(frame_ms)), 5)},
+        "kernels_ms": {"sdf_fuse": round(fuse_avg_ms, 5), "frame_total": round(1e3 * elapsed / args.steps, 5),
+                       "frame_period_events": round(float(np.nanmean(t[:, 4])), 5),
+                       "parts": {"preprocess": round(float(np.mean(pre_ms)), 5), "sdf_fuse": round(float(np.mean(tp[:, 1])), 5),
+                                 "raycast_sdf": round(ray_avg_ms, 5), "frame_events": round(float(np.mean(frame_ms)), 5),
+                                 "period": round(float(np.nanmean(tp[:, 4])), 5),
+                                 "note": "%d frames of the same stream with all four events recorded, right after the timed region; the timed "
+                                         "steps record the two around SdfFuse only (an event is a marker between launches: four per frame cost "
+                                         "2-3 %% of the frame rate)" % (2 * N_ORBIT)}},
         "sdf_fuse_other_mode": other_line,
     }
     for key, val in (("roofline_raycast", roofline_raycast), ("bilateral", bilateral_line), ("transfer_inclusive", transfer_line),

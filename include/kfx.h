@@ -435,7 +435,8 @@ int kfx_sdf_summary_rebuild(kfx_sdf_summary* s, kfx_stream stream);
  *     SdfFuse, after SdfFuse, after RaycastSdf) in a ring of the last n frames.  kfx_frame_timings waits for the last of the
  *     frames asked for and returns KFX_FRAME_TIMING_FIELDS floats per frame, in ms: preprocess, SdfFuse, RaycastSdf (tracked:
  *     the class-table build included), the whole frame, and the period = start of this frame to the start of the next one (NaN
- *     for the most recent frame) -- what a frames/s figure is made of.  Frames that have left the ring: KFX_E_RANGE. */
+ *     for the most recent frame; measured between the first event a frame records and the same event of the next frame) -- what a
+ *     frames/s figure is made of.  Frames that have left the ring: KFX_E_RANGE. */
 typedef struct kfx_frame kfx_frame;
 typedef struct kfx_frame_config {
     kfx_volume vol;                          /* BoundedVolume<SDF_t> (fp32 cells) */
@@ -452,6 +453,8 @@ typedef struct kfx_frame_config {
 #define KFX_FRAME_FUSE       2u
 #define KFX_FRAME_RAYCAST    4u
 #define KFX_FRAME_TIMING_FIELDS 5
+#define KFX_FRAME_EVENTS_ALL  15u  /* before the preprocess, before SdfFuse, after SdfFuse, after RaycastSdf */
+#define KFX_FRAME_EVENTS_FUSE  6u  /* the two around SdfFuse: its window and the frame period (before-SdfFuse to before-SdfFuse) */
 int kfx_frame_create(kfx_frame** out, const kfx_frame_config* cfg);
 int kfx_frame_destroy(kfx_frame* f);
 int kfx_frame_reset(kfx_frame* f, kfx_stream stream);             /* SdfReset(vol, NaN) (main.cpp:229), summary set to match */
@@ -461,6 +464,10 @@ kfx_sdf_summary* kfx_frame_summary(kfx_frame* f);                 /* the frame's
 long long kfx_frame_count(const kfx_frame* f);                    /* frames stepped so far = index of the next frame */
 int kfx_frame_step(kfx_frame* f, const kfx_image* raw, const float T_wc[12], const float* T_cw, unsigned parts, kfx_stream stream);
 int kfx_frame_timings(kfx_frame* f, long long first_frame, int n_frames, float* ms);
+/* Which of the four events the following steps record (KFX_FRAME_EVENTS_*; 0: none).  An event is a marker between two launches
+ * of the stream and is not free: all four cost 2.7 % of a 0.42 ms frame (measured), so a loop that is itself being timed records
+ * the two around SdfFuse only.  Fields that need an event the frame did not record come back as NaN. */
+int kfx_frame_set_timing(kfx_frame* f, unsigned mask);
 
 /* ---- numerics mode --------------------------------------------------------------- */
 /* KFX_MATH_EXACT (default): IEEE fp32, no FMA contraction, correctly rounded div/sqrt, reference

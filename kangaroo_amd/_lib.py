@@ -143,6 +143,7 @@ SIGNATURES = {
     "kfx_frame_count": (C.c_longlong, [C.c_void_p]),
     "kfx_frame_step": (C.c_int, [C.c_void_p, PI, PF, PF, C.c_uint, C.c_void_p]),
     "kfx_frame_timings": (C.c_int, [C.c_void_p, C.c_longlong, C.c_int, PF]),
+    "kfx_frame_set_timing": (C.c_int, [C.c_void_p, C.c_uint]),
     "kfx_raycast_sdf_levels_tracked": (C.c_int, [C.c_int, C.POINTER(PI), C.POINTER(PI), C.POINTER(PI), C.POINTER(PI), PV, C.c_void_p, PF, PF, C.c_float, C.c_float, C.c_float, C.c_int, C.c_void_p]),
 }
 

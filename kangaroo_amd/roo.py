@@ -305,6 +305,7 @@ class Frame:
     bit-identical to calling the operators one by one."""
 
     PREPROCESS, FUSE, RAYCAST, ALL = 1, 2, 4, 7
+    EVENTS_ALL, EVENTS_FUSE, EVENTS_NONE = 15, 6, 0   # kfx_frame_set_timing: all four events / the two around SdfFuse / none
     FIELDS = 5   # timings(): preprocess, SdfFuse, RaycastSdf, whole frame, period to the next frame's start (ms)
 
     def __init__(self, vol, raw, filtered, vbo, normals, ray_d, ray_n, ray_i, K, bilateral, near, far, trunc_dist, max_w, mincostheta,
@@ -353,6 +354,11 @@ class Frame:
     def summary(self):
         h = _lib.load().kfx_frame_summary(self.handle)
         return _FrameSummary(h) if h else None
+
+    def set_timing(self, mask):
+        """Which events the following steps record (EVENTS_*): every event is a marker between two launches and costs the stream
+        a few microseconds; fields of timings() that need an unrecorded event are NaN."""
+        _lib.check(_lib.load().kfx_frame_set_timing(self.handle, int(mask)))
 
     def step(self, T_wc, T_cw=None, raw=None, parts=0, stream=None):
         t, _t = _fp(T_wc, 12)

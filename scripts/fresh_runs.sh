@@ -14,7 +14,7 @@ try:
     d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
     r, pv = d["roofline"], d.get("plain_variant") or {}
     print("run %s: %.1f frames/s  fuse %.4f ms frac %.4f  ray %.4f  total %.4f  plain_variant %s  prime %s  decision %s" % (
-        sys.argv[2], d["value"], r["avg_launch_ms"], r["frac"], d["kernels_ms"].get("raycast_sdf", -1), d["kernels_ms"]["frame_total"],
+        sys.argv[2], d["value"], r["avg_launch_ms"], r["frac"], d["kernels_ms"].get("parts", {}).get("raycast_sdf", d["kernels_ms"].get("raycast_sdf", -1)), d["kernels_ms"]["frame_total"],
         pv.get("frames_per_sec"), d.get("prime"), (d["config"].get("summary_policy") or {}).get("decision")))
 except Exception as e:
     print("run %s: failed (%r)" % (sys.argv[2], e))

@@ -71,6 +71,17 @@ def test_gpu_frame_step_equals_the_separate_calls(roo, math, track):
         fr.step(T_wc, None, raw)
         with pytest.raises(roo.KfxError):
             fr.timings(0, 40)   # more frames than were stepped
+        # kfx_frame_set_timing: only the two events around SdfFuse (what a loop that is being timed records), then none
+        fr.set_timing(fr.EVENTS_FUSE)
+        n0 = fr.count
+        for i in range(3):
+            fr.step(scenes.orbit_pose(i, 30), None, raw)
+        fr.set_timing(fr.EVENTS_NONE)
+        fr.step(T_wc, None, raw)
+        t = fr.timings(n0, 4)
+        assert np.all(t[:3, 1] > 0) and np.all(np.isnan(t[:3, [0, 2, 3]])), t      # SdfFuse window only
+        assert np.all(t[:2, 4] > t[:2, 1]) and np.isnan(t[2, 4])                   # period: before-SdfFuse to before-SdfFuse; the next frame recorded nothing
+        assert np.all(np.isnan(t[3]))
     finally:
         roo.set_math_mode(prev)
 

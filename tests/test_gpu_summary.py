@@ -442,7 +442,8 @@ def test_gpu_frame_pipeline_auto_policy(roo, scene):
         assert states[4:12] == [True] * 8 and states[12:20] == [False] * 8 and states[20:28] == [True] * 8, states
         assert auto.track == d["chosen"].startswith("table march") and (auto.summary is not None) == auto.track
         assert d["frames_per_block"] == 8 and d["frame_plain_ms"] > 0 and min(d["frame_tracked_ms"]) > 0
-        assert d["sdf_fuse_plain_ms"] > 0 and d["sdf_fuse_tracked_ms"] > 0 and d["raycast_plain_ms"] > 0   # the plain SdfFuse is measured, not assumed
+        assert d["sdf_fuse_plain_ms"] > 0 and d["sdf_fuse_tracked_ms"] > 0 and d["rest_of_frame_plain_ms"] > 0   # the plain SdfFuse is measured, not assumed
+        assert auto.timing == 0   # ... with events recorded during the blocks only
         assert auto.track == (max(d["frame_tracked_ms"]) <= (1 - d["margin"]) * d["frame_plain_ms"])
         assert T.nan_equal(auto.vol.MemcpyToHost(), ref.vol.MemcpyToHost())
         da, dr = auto.ray_d.MemcpyToHost(), ref.ray_d.MemcpyToHost()
