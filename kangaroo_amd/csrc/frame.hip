@@ -62,7 +62,7 @@ extern "C" int kfx_frame_create(kfx_frame** out, const kfx_frame_config* cfg)
         }
         for (int i = 0; i < f->slots; ++i) { f->ev_frame[i] = -1; f->ev_mask[i] = 0; }
         for (int i = 0; i < f->slots * 4; ++i) {
-            const hipError_t e = hipEventCreate(&f->ev[i]);
+            const hipError_t e = hipEventCreate(&f->ev[i]);   // (hipEventReleaseToDevice events cost the stream the same: measured)
             if (e != hipSuccess) {
                 (void)hipGetLastError();
                 for (int k = 0; k < i; ++k) (void)hipEventDestroy(f->ev[k]);
