@@ -301,6 +301,65 @@ int main()
         CHECK(shits > sw * sh / 4);
     }
 
+    // ---- kfx_frame_step: the frame's five roo:: calls as one C call (include/kfx.h), same bits, device events around its parts ----
+    {
+        const int M = 64, sw = 160, sh = 120;
+        const ImageIntrinsics Ks(142.5855, 142.5855, sw / 2.0 - 0.5, sh / 2.0 - 0.5);
+        const BoundingBox box(make_float3(-1, -1, 2), make_float3(1, 1, 4));
+        BoundedVolume<SDF_t, TargetDevice, Manage> va(M, M, M, box), vb(M, M, M, box);
+        Image<float, TargetDevice, Manage> raw(sw, sh), fa(sw, sh), fb(sw, sh), da(sw, sh), db(sw, sh), ia(sw, sh), ib(sw, sh);
+        Image<float4, TargetDevice, Manage> va4(sw, sh), vb4(sw, sh), nna(sw, sh), nnb(sw, sh), ra(sw, sh), rb(sw, sh);
+        std::vector<float> wall((size_t)sw * sh, 3.5f);
+        for (int v = 30; v < 90; ++v)
+            for (int u = 40; u < 120; ++u) wall[(size_t)v * sw + u] = 2.8f + 0.001f * (float)((u * 7 + v * 3) % 11);
+        raw.MemcpyFromHost(wall.data());
+        const float tr = 2.0f * length(va.VoxelSizeUnits());
+        kfx_frame_config cfg;
+        memset(&cfg, 0, sizeof(cfg));
+        cfg.vol = *vb.abi(); cfg.raw = *raw.abi(); cfg.filtered = *fb.abi(); cfg.vbo = *vb4.abi(); cfg.normals = *nnb.abi();
+        cfg.ray_depth = *db.abi(); cfg.ray_norm = *rb.abi(); cfg.ray_img = *ib.abi();
+        cfg.K[0] = Ks.fu; cfg.K[1] = Ks.fv; cfg.K[2] = Ks.u0; cfg.K[3] = Ks.v0;
+        cfg.bilateral_gs = 1.5f; cfg.bilateral_gr = 0.1f; cfg.bilateral_minval = 0.2f; cfg.bilateral_size = 3;
+        cfg.near = 0.4f; cfg.far = 8.0f; cfg.trunc_dist = tr; cfg.max_w = 1000.0f; cfg.mincostheta = 0.1f;
+        cfg.timing_slots = 8;
+        kfx_frame* fr = nullptr;
+        CHECK(kfx_frame_create(&fr, &cfg) == 0 && fr != nullptr);
+        SdfReset(va, NAN);
+        CHECK(kfx_frame_reset(fr, 0) == 0);
+        Mat<float,3,4> T = SE3Identity();
+        for (int f = 0; f < 3; ++f) {
+            T(0, 3) = 0.01f * (float)f;
+            BilateralFilter<float,float>(fa, raw, 1.5f, 0.1f, 3, 0.2f);
+            DepthToVbo<float>(va4, fa, Ks);
+            NormalsFromVbo(nna, va4);
+            SdfFuse(va, fa, nna, SE3inv(T), Ks, tr, 1000.0f, 0.1f);
+            RaycastSdf(da, ra, ia, va, T, Ks, 0.4f, 8.0f, tr, true);
+            const Mat<float,3,4> Tinv = SE3inv(T);
+            CHECK(kfx_frame_step(fr, nullptr, T.m, Tinv.m, 0, 0) == 0);
+        }
+        CHECK(kfx_frame_count(fr) == 3);
+        float ms[3 * KFX_FRAME_TIMING_FIELDS];
+        CHECK(kfx_frame_timings(fr, 0, 3, ms) == 0);
+        CHECK(ms[1] > 0.f && ms[2] > 0.f && ms[3] >= ms[1] + ms[2] && ms[4] >= ms[3] * 0.999f);
+        CHECK(kfx_frame_timings(fr, 0, 9, ms) == KFX_E_RANGE);
+        Volume<SDF_t, TargetHost, Manage> ha(M, M, M), hb(M, M, M);
+        CHECK(kfx_memcpy_2d(ha.ptr, ha.pitch, va.ptr, va.pitch, M * sizeof(SDF_t), (size_t)M * M, 2, 0) == 0);
+        CHECK(kfx_memcpy_2d(hb.ptr, hb.pitch, vb.ptr, vb.pitch, M * sizeof(SDF_t), (size_t)M * M, 2, 0) == 0);
+        CHECK(memcmp(ha.ptr, hb.ptr, ha.pitch * M * M) == 0);
+        std::vector<float> hda((size_t)sw * sh), hdb((size_t)sw * sh);
+        std::vector<float4> hna((size_t)sw * sh), hnb((size_t)sw * sh);
+        da.MemcpyToHost(hda.data()); db.MemcpyToHost(hdb.data());
+        nna.MemcpyToHost(hna.data()); nnb.MemcpyToHost(hnb.data());
+        int fhits = 0;
+        for (size_t i = 0; i < hda.size(); ++i) {
+            if (std::isfinite(hda[i])) ++fhits;
+            CHECK(same(hda[i], hdb[i]));
+            CHECK(same(hna[i].x, hnb[i].x) && same(hna[i].y, hnb[i].y) && same(hna[i].z, hnb[i].z) && hna[i].w == hnb[i].w);
+        }
+        CHECK(fhits > sw * sh / 4);
+        CHECK(kfx_frame_destroy(fr) == 0);
+    }
+
     printf("roo_api_test: %s (%d ray hits checked)\n", g_fail ? "FAILED" : "all checks passed", nhit);
     return g_fail ? 1 : 0;
 }
