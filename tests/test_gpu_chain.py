@@ -182,6 +182,13 @@ def _image_report(gd, gn, gi, od, on, oi):
     inl = dd <= IMG_DEPTH_TOL
     rep["common_hits"] = int(both.sum())
     rep["depth_outliers"] = int((~inl).sum())
+    # pixels beyond ANY of the three tolerances (a ray that catches another cell configuration at a silhouette may keep its depth
+    # and change its normal), and the worst values over the others
+    beyond = (dd > IMG_DEPTH_TOL) | (ang > IMG_NORMAL_TOL_RAD) | (di > IMG_SHADE_TOL)
+    rep["pixels_beyond_any_tolerance"] = int(beyond.sum())
+    rep["normal_outliers"], rep["shade_outliers"] = int((ang > IMG_NORMAL_TOL_RAD).sum()), int((di > IMG_SHADE_TOL).sum())
+    if (~beyond).any():
+        rep["within_tolerance_max"] = {"depth": float(dd[~beyond].max()), "normal_angle": float(ang[~beyond].max()), "shade": float(di[~beyond].max())}
     for name, v in (("depth", dd), ("normal_angle", ang), ("shade", di)):
         rep[name + "_max"] = float(v.max())
         rep[name + "_max_inliers"] = float(v[inl].max())
