@@ -255,3 +255,33 @@ def test_rccl_rendezvous_accepts_a_rank_that_arrives_seconds_later(tmp_path):
     os.utime(path, (time.time() - 3600, time.time() - 3600))
     probe = subprocess.run([sys.executable, "-c", code.replace("time.sleep(5.0)", "pass")], env=env, capture_output=True, text=True, timeout=60)
     assert probe.returncode == 0 and int(probe.stdout.split()[0]) == 0, probe.stdout + probe.stderr
+
+
+def test_frame_object_validates_its_views_without_a_gpu():
+    """kfx_frame_create (include/kfx.h) checks the caller's views before any HIP call: with no timing slots it needs no device, so
+    the argument errors -- and a well-formed create / destroy -- are checked here."""
+    L = _lib.load()
+    cfg = _lib.KfxFrameConfig()
+    h = C.c_void_p()
+    assert L.kfx_frame_create(C.byref(h), None) == -1 and L.kfx_frame_create(None, C.byref(cfg)) == -1
+    assert L.kfx_frame_create(C.byref(h), C.byref(cfg)) == -1                     # null volume
+    fake = 0x10000
+    cfg.vol = _lib.KfxVolume(64 * 8, fake, 64, 64, 64 * 8 * 64, 64)
+    assert L.kfx_frame_create(C.byref(h), C.byref(cfg)) == -2                     # image views missing
+    w, hh = 40, 30
+    f1, f4 = _lib.KfxImage(w * 4, fake, w, hh), _lib.KfxImage(w * 16, fake, w, hh)
+    cfg.raw, cfg.filtered, cfg.vbo, cfg.normals, cfg.ray_depth, cfg.ray_norm, cfg.ray_img = f1, f1, f4, f4, f1, f4, f1
+    cfg.timing_slots = -1
+    assert L.kfx_frame_create(C.byref(h), C.byref(cfg)) == -4                     # KFX_E_RANGE
+    cfg.timing_slots = 0
+    cfg.vbo = _lib.KfxImage((w + 1) * 16, fake, w + 1, hh)
+    assert L.kfx_frame_create(C.byref(h), C.byref(cfg)) == -2                     # the preprocess images differ in size
+    cfg.vbo = _lib.KfxImage(w * 8, fake, w, hh)
+    assert L.kfx_frame_create(C.byref(h), C.byref(cfg)) == -2                     # pitch below a row of float4
+    cfg.vbo = f4
+    assert L.kfx_frame_create(C.byref(h), C.byref(cfg)) == 0 and h.value
+    assert L.kfx_frame_get_track(h) == 0 and L.kfx_frame_count(h) == 0 and L.kfx_frame_summary(h) is None
+    assert L.kfx_frame_set_timing(h, 16) == -4 and L.kfx_frame_set_timing(h, 6) == 0
+    out = (C.c_float * 5)()
+    assert L.kfx_frame_timings(h, 0, 1, out) == -4                                # created without timing slots
+    assert L.kfx_frame_destroy(h) == 0
