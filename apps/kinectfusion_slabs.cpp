@@ -32,6 +32,7 @@ struct Options {
     bool fast = false, rccl = false, broadcast_inputs = false;
     SlabVolume::HaloMode halo = SlabVolume::HaloExchange;
     SlabVolume::RaycastMode raycast = SlabVolume::Composite;
+    SlabVolume::MergeMode merge = SlabVolume::MergeDirect;
     std::string rendezvous;   // default: /tmp/kfx_slabs.<uid>.<launch id>.id (default_rendezvous)
 };
 
@@ -96,6 +97,7 @@ static void RunRank(const Options& o, kfx_comm* comm, const std::vector<std::vec
     Image<float, TargetDevice, Manage> dMeters(w, h), dFiltered(w, h), ray_d(w, h), ray_i(w, h);
     Image<float4, TargetDevice, Manage> dVbo(w, h), dNormals(w, h), ray_n(w, h);
     SlabVolume slab(o.volres, o.volres, o.volres, bb, comm, o.halo, o.raycast);
+    slab.merge = o.merge;
     // the whole volume's voxel size (the local view has the same spacing in x / y; z spacing is the full volume's)
     const float3 vs = make_float3(2.0f / (o.volres - 1), 2.0f / (o.volres - 1), 2.0f / (o.volres - 1));
     const float trunc_dist = 2.0f * length(vs);
@@ -175,6 +177,7 @@ int main(int argc, char** argv)
             ++i;
             o.raycast = !strcmp(argv[i], "exact") ? SlabVolume::Exact : (!strcmp(argv[i], "exact-allreduce") ? SlabVolume::ExactAllReduce : SlabVolume::Composite);
         }
+        else if (!strcmp(argv[i], "--merge") && i + 1 < argc) o.merge = !strcmp(argv[++i], "allreduce") ? SlabVolume::MergeAllReduce : SlabVolume::MergeDirect;
         else if (!strcmp(argv[i], "--inputs") && i + 1 < argc) o.broadcast_inputs = !strcmp(argv[++i], "broadcast");
         else if (!strcmp(argv[i], "--rendezvous") && i + 1 < argc) o.rendezvous = argv[++i];
         else { fprintf(stderr, "unknown argument %s\n", argv[i]); return 2; }
@@ -228,7 +231,7 @@ int main(int argc, char** argv)
     if (rank == 0) {
         printf("kinectfusion_slabs: %d^3 volume in %d slab(s) [%s], %dx%d, %d frames, %s math, halo %s, raycast %s%s: %.3f ms/frame (%.1f fps)\n",
                o.volres, world, o.rccl ? "RCCL, one process per GPU" : "threads sharing one GPU", o.w, o.h, o.frames, o.fast ? "fast" : "exact",
-               o.halo == SlabVolume::HaloExchange ? "exchange" : "recompute", o.raycast == SlabVolume::Exact ? "exact (hand-over)" : (o.raycast == SlabVolume::ExactAllReduce ? "exact (all-reduce per round)" : "composite"),
+               o.halo == SlabVolume::HaloExchange ? "exchange" : "recompute", o.raycast == SlabVolume::Exact ? "exact (hand-over)" : (o.raycast == SlabVolume::ExactAllReduce ? "exact (all-reduce per round)" : (o.merge == SlabVolume::MergeDirect ? "composite (direct-send merge)" : "composite (all-reduce merge)")),
                o.raycast != SlabVolume::Composite ? (" (" + std::to_string(r0.rounds) + " rounds)").c_str() : "", r0.ms_per_frame, 1e3 / r0.ms_per_frame);
         printf("checksums depth=%08x norm=%08x img=%08x volume=%08x hits=%zu ranks_agree=%d\n", r0.chk_d, r0.chk_n, r0.chk_i, r0.chk_vol, r0.hits,
                r0.status == 0 ? 1 : 0);

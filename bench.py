@@ -68,6 +68,10 @@ def parse():
     ap.add_argument("--images", default="all", choices=["all", "root"],
                     help="N > 1, composite raycast: every rank ends up with the merged images (all-reduce of the winners' payload), or "
                          "only rank 0 does (reduce: half the traffic)")
+    ap.add_argument("--merge", default="direct", choices=["direct", "allreduce"],
+                    help="N > 1, composite raycast: direct = every rank owns a strip of the image: all-to-all of the strips, nearest hit per "
+                         "pixel at the owner, all-gather of the merged strips (each byte crosses one xGMI link once per phase, all links at once); "
+                         "allreduce = MIN all-reduce of (depth, rank) keys + SUM all-reduce of the winners' payload.  Same images")
     ap.add_argument("--overlap", action="store_true",
                     help="N > 1, composite raycast: merge frame k's images on a second stream under frame k+1's preprocess + SdfFuse")
     ap.add_argument("--summary", nargs="?", const="on", default="auto", choices=["auto", "on", "off"],
@@ -218,6 +222,8 @@ def prime_stream(kf, step, min_s, cap_s, min_frames, tol=0.02):
         if len(firsts) >= 2:
             t = kf.timings(firsts[-2], BLOCK)
             means.append(float(np.mean(t[:, 4])))
+            if not np.isfinite(means[-1]):   # (frames stepped without the SdfFuse events have no period: nothing to wait for)
+                break
             gpu_s += means[-1] * BLOCK * 1e-3
         if len(means) >= 3:
             a, b, c = means[-3:]
@@ -610,7 +616,7 @@ def run_slabs(args, torch, dist, roo, scenes, rank, world):
     if args.overlap and args.halo == "exchange":
         sys.exit("bench.py: --overlap needs --halo recompute (collective ordering, kangaroo_amd/pipeline.py)")
     pipe = SlabPipeline(roo, dist, (N, N, N), bmin, bmax, w, h, halo=args.halo, raycast=args.raycast, K=K, near=near, far=far,
-                        overlap=args.overlap, inputs=args.inputs, images=args.images)
+                        overlap=args.overlap, inputs=args.inputs, images=args.images, merge=args.merge)
     poses = [scenes.orbit_pose(i, N_ORBIT) for i in range(N_ORBIT)]
     frames = []
     for T_wc in poses:
@@ -700,18 +706,24 @@ def run_slabs(args, torch, dist, roo, scenes, rank, world):
         lo_ghost, hi_ghost = pipe.z0 - pipe.s0, pipe.s1 - pipe.z1
         halo_bytes = (lo_ghost * (1 if rank > 0 else 0) + hi_ghost * (1 if rank < world - 1 else 0)) * pipe.vol.img_pitch   # received (= sent) per SdfFuse
         halo_ms = event_ms(pipe.exchange_halos, 5) if world > 1 else 0.0
-        merge_ms = None
+        merge_ms, other_merge_ms = None, None
         if args.raycast == "composite" and world > 1:
             pipe.wait_composite()
             merge_ms = event_ms(lambda: pipe.composite(pipe.ray_d, pipe.ray_n, pipe.ray_i), 5)
+            pipe.merge = "allreduce" if args.merge == "direct" else "direct"   # the other merge on the same images, by itself
+            pipe.raycast(poses[idx[-1]])
+            pipe.wait_composite()
+            other_merge_ms = event_ms(lambda: pipe.composite(pipe.ray_d, pipe.ray_n, pipe.ray_i), 5)
+            pipe.merge = args.merge
             pipe.raycast(poses[idx[-1]])   # (the images are a rendering again)
             pipe.wait_composite()
         mine = torch.tensor([fuse_avg_ms, ray_avg_ms, halo_ms, -1.0 if merge_ms is None else merge_ms, float(halo_bytes), float(pipe.z1 - pipe.z0),
-                             float(local_voxels)], dtype=torch.float64, device="cuda")
+                             float(local_voxels), -1.0 if other_merge_ms is None else other_merge_ms], dtype=torch.float64, device="cuda")
         allr = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
         per_rank = [{"rank": r, "sdf_fuse_ms": round(float(v[0]), 5), "raycast_sdf_plus_merge_ms": round(float(v[1]), 5),
                      "halo_exchange_ms": round(float(v[2]), 5), "composite_merge_ms": None if float(v[3]) < 0 else round(float(v[3]), 5),
+                     "composite_merge_%s_ms" % ("allreduce" if args.merge == "direct" else "direct"): None if float(v[7]) < 0 else round(float(v[7]), 5),
                      "halo_bytes_received_per_fuse": int(v[4]), "planes_owned": int(v[5]), "voxels_stored": int(v[6])} for r, v in enumerate(allr)]
     except Exception as e:   # noqa: BLE001  (symmetric across ranks: every rank takes the same path)
         per_rank = {"error": repr(e)[:300]}
@@ -734,7 +746,7 @@ def run_slabs(args, torch, dist, roo, scenes, rank, world):
         return round(n / float(tv.item()), 1)
     n_var = min(args.steps, 2 * N_ORBIT)
     variants = {"steps": n_var}
-    base_halo, base_overlap, base_inputs, base_images = pipe.halo, pipe.overlap, pipe.inputs, pipe.images
+    base_halo, base_overlap, base_inputs, base_images, base_merge = pipe.halo, pipe.overlap, pipe.inputs, pipe.images, pipe.merge
     try:   # reported extras must never cost the headline line (errors in collectives are symmetric across ranks)
         variants["as_configured_fps"] = timed_fps(n_var)
         pipe.wait_composite()
@@ -757,16 +769,22 @@ def run_slabs(args, torch, dist, roo, scenes, rank, world):
             pipe.images = "root" if base_images == "all" else "all"
             variants["images_%s_fps" % pipe.images] = timed_fps(n_var)
             pipe.wait_composite()
+            pipe.images = base_images
+            pipe.merge = "allreduce" if base_merge == "direct" else "direct"
+            variants["merge_%s_fps" % pipe.merge] = timed_fps(n_var)
+            pipe.wait_composite()
     except Exception as e:   # noqa: BLE001
         variants["error"] = repr(e)[:300]
-    pipe.halo, pipe.overlap, pipe.inputs, pipe.images = base_halo, base_overlap, base_inputs, base_images
+    pipe.halo, pipe.overlap, pipe.inputs, pipe.images, pipe.merge = base_halo, base_overlap, base_inputs, base_images, base_merge
 
     out = None
     if rank == 0:
         partition = "z-slabs x%d, inputs %s, ghost planes %s%s, raycast %s" % (
             world, "preprocessed by every rank" if args.inputs == "replicate" else "preprocessed by rank 0 and broadcast", args.halo,
             ", merge overlapped with the next frame" if args.overlap else "",
-            {"composite": "composite = all_reduce(MIN key) + %s(SUM payload)" % ("reduce-to-rank-0" if args.images == "root" else "all_reduce"),
+            {"composite": ("composite = all_to_all(image strips to their owners) + nearest hit per pixel + %s(merged strips)" % ("gather-to-rank-0" if args.images == "root" else "all_gather")
+                           if args.merge == "direct" else
+                           "composite = all_reduce(MIN key) + %s(SUM payload)" % ("reduce-to-rank-0" if args.images == "root" else "all_reduce")),
              "exact": "exact = march state handed from slab to slab: world + 1 stages, neighbour send/recv between them, one all_reduce of the finalised pixels at the end",
              "exact_allreduce": "exact (cross-check) = one SUM all_reduce of the march state + a host-side termination test per round"}[args.raycast])
         out = {

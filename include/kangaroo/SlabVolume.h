@@ -30,6 +30,8 @@ public:
     // nearest hit of per-slab marches; the march state handed from slab to slab (neighbour exchanges, one synchronisation per
     // frame); the same march with an all-reduce and a host check per round (the cross-check of the hand-over)
     enum RaycastMode { Composite, Exact, ExactAllReduce };
+    // Composite: image strips sent to their owners and back (all-to-all + all-gather over the xGMI mesh), or two all-reduces
+    enum MergeMode { MergeDirect, MergeAllReduce };
 
     kfx_slab_layout layout;
     BoundedVolume<SDF_t, TargetDevice, Manage> local; // planes [layout.s0, layout.s1) of the whole volume
@@ -37,6 +39,7 @@ public:
     kfx_comm* comm;
     HaloMode halo;
     RaycastMode raycast;
+    MergeMode merge;
     int last_rounds;
 
     SlabVolume(size_t w, size_t h, size_t d, const BoundingBox& bbox, kfx_comm* comm_, HaloMode halo_ = HaloExchange,
@@ -44,12 +47,13 @@ public:
         : layout(MakeLayout(d, bbox, comm_, ghost)),
           local(w, h, layout.s1 - layout.s0, BoundingBox(make_float3(bbox.Min().x, bbox.Min().y, layout.local_zmin),
                                                            make_float3(bbox.Max().x, bbox.Max().y, layout.local_zmax))),
-          full_bbox(bbox), comm(comm_), halo(halo_), raycast(raycast_), last_rounds(0), key_(0), payload_(0), state_(0), scratch_(0), cap_(0)
+          full_bbox(bbox), comm(comm_), halo(halo_), raycast(raycast_), merge(MergeDirect), last_rounds(0), key_(0), payload_(0), state_(0), scratch_(0),
+          strips_(0), cap_(0), strips_cap_(0)
     {
     }
     ~SlabVolume()
     {
-        kfx_free(key_); kfx_free(payload_); kfx_free(state_); kfx_free(scratch_);
+        kfx_free(key_); kfx_free(payload_); kfx_free(state_); kfx_free(scratch_); kfx_free(strips_);
     }
     SlabVolume(const SlabVolume&) = delete;
     SlabVolume& operator=(const SlabVolume&) = delete;
@@ -89,7 +93,19 @@ public:
                                                             &K.fu, near, far, trunc_dist, subpix ? 1 : 0, comm, 0, &last_rounds));
         } else {
             RaycastSdf(depth, norm, img, local, T_wc, K, near, far, trunc_dist, subpix);
-            GpuCheckStatus(kfx_slab_composite(depth.abi(), norm.abi(), img.abi(), (long long*)key_, (float*)payload_, comm, 0));
+            if (merge == MergeDirect && comm->all_to_all && comm->all_gather) {
+                const size_t need = kfx_slab_composite_direct_scratch_bytes(depth.w, depth.h, comm->world);
+                if (need > strips_cap_) {
+                    size_t pitch;
+                    kfx_free(strips_);
+                    strips_ = 0; strips_cap_ = 0;
+                    GpuCheckStatus(kfx_alloc_pitched(&strips_, &pitch, need, 1));
+                    strips_cap_ = need;
+                }
+                GpuCheckStatus(kfx_slab_composite_direct(depth.abi(), norm.abi(), img.abi(), strips_, comm, 0));
+            } else {
+                GpuCheckStatus(kfx_slab_composite(depth.abi(), norm.abi(), img.abi(), (long long*)key_, (float*)payload_, comm, 0));
+            }
         }
     }
 
@@ -100,8 +116,8 @@ private:
         GpuCheckStatus(kfx_slab_layout_init(&L, d, bbox.Min().z, bbox.Max().z, c->rank, c->world, ghost));
         return L;
     }
-    void* key_; void* payload_; void* state_; void* scratch_;
-    size_t cap_;
+    void* key_; void* payload_; void* state_; void* scratch_; void* strips_;
+    size_t cap_, strips_cap_;
     void Reserve(size_t n)
     {
         if (n <= cap_) return;

@@ -352,6 +352,25 @@ int kfx_composite_select(const kfx_image* depth, const kfx_image* norm, const kf
 int kfx_composite_unpack(const kfx_image* depth, const kfx_image* norm, const kfx_image* img, const long long* key,
                          const float* payload, kfx_stream stream);
 
+/* The direct-send composite (xGMI is a full mesh of point-to-point links: every pair of GPUs has its own).  Rank j owns strip j of
+ * the image -- pixels [j S, (j + 1) S) in row-major order, S = kfx_composite_strip_pixels(w, h, world) (the last strip is padded) --
+ * and a buffer of strips is world x KFX_COMPOSITE_STRIP_PLANES x S floats: per strip the planes {depth (+inf: miss), n.x, n.y, n.z,
+ * shade}.
+ *   pack:   send = this rank's images cut into strips           then all-to-all: strip j goes to rank j (recv[r] = rank r's copy)
+ *   merge:  merged (KFX_COMPOSITE_STRIP_PLANES x S) = per pixel the copy with the nearest depth, the lowest rank on ties -- the
+ *           winner of the key's minimum above                   then all-gather of `merged` (or a gather to one rank)
+ *   unpack: the gathered strips back into depth (NaN: miss) / norm (w = hit ? 1 : 0) / img
+ * Per rank and phase 20 B x (world - 1) / world x w h bytes leave over world - 1 links at once.  rank_stride: floats between rank r's
+ * strip and rank r + 1's in a buffer of strips (0: dense, KFX_COMPOSITE_STRIP_PLANES x S) -- several images (pyramid levels) can
+ * share one buffer, and one pair of collectives, with the strips of a rank side by side. */
+#define KFX_COMPOSITE_STRIP_PLANES 5
+size_t kfx_composite_strip_pixels(size_t w, size_t h, int world);
+int kfx_composite_strips_pack(const kfx_image* depth, const kfx_image* norm, const kfx_image* img, float* send, size_t rank_stride, int world,
+                              kfx_stream stream);
+int kfx_composite_strips_merge(const float* recv, float* merged, size_t strip_pixels, size_t rank_stride, int world, kfx_stream stream);
+int kfx_composite_strips_unpack(const kfx_image* depth, const kfx_image* norm, const kfx_image* img, const float* strips, size_t rank_stride,
+                                int world, kfx_stream stream);
+
 /* Exact multi-GPU march ("exact variant").  One round of one rank: rays whose current sample
  * falls into a trilinear base cell this rank owns, [own_lo, own_hi) (global plane indices), are advanced until
  * they hit, leave the volume, or step into another rank's cells; lambda / last_sdf / delta travel in `state`

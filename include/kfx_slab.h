@@ -11,12 +11,12 @@
  *
  *   per frame and rank:  kfx_sdf_fuse_slab (kfx.h) on the owned planes            -- no communication, bit-identical
  *                        kfx_slab_exchange_halos                                  -- ghost planes from the two neighbours
- *                        kfx_raycast_sdf on the local view + kfx_slab_composite   -- nearest hit of all slabs (2 all-reduces)
+ *                        kfx_raycast_sdf on the local view + kfx_slab_composite[_direct] -- nearest hit of all slabs (all-to-all + all-gather of image strips, or 2 all-reduces)
  *                     or kfx_slab_raycast_exact                                   -- march state handed from slab to slab,
  *                                                                                    bit-identical to the single-volume march
  *
  * Collectives go through a kfx_comm, a small table of transport functions.  Two transports ship:
- *   kfx_comm_create_rccl     (libkfx_rccl.so, links librccl): one PROCESS per GPU, RCCL all-reduce / grouped send-recv over
+ *   kfx_comm_create_rccl     (libkfx_rccl.so, links librccl): one PROCESS per GPU, RCCL all-reduce / all-gather / grouped send-recv over
  *                            xGMI.  Rendezvous of the ncclUniqueId through a file.
  *   kfx_comm_create_threads  (libkfx.so): the ranks are host THREADS of one process sharing one device -- the emulation
  *                            used to exercise the slab logic where only one GPU exists (tests, apps --transport threads).
@@ -50,6 +50,11 @@ typedef struct kfx_comm {
     /* `bytes` of a dense device buffer from rank `root` to every rank (the filtered depth / normal maps of a frame when only
      * one rank runs the preprocessing, SURVEY.md 8(e) "input distribution") */
     int (*broadcast)(struct kfx_comm* c, void* buf, size_t bytes, int root, kfx_stream stream);
+    /* personalised exchange over the full mesh: chunk r of `send` (bytes_per_rank each) goes to rank r, chunk r of `recv` comes
+     * from rank r (one grouped send / recv per peer: every xGMI link at once); and its counterpart, every rank's `send`
+     * (bytes_per_rank) to chunk `rank` of every rank's `recv`.  The direct-send composite's two phases. */
+    int (*all_to_all)(struct kfx_comm* c, const void* send, void* recv, size_t bytes_per_rank, kfx_stream stream);
+    int (*all_gather)(struct kfx_comm* c, const void* send, void* recv, size_t bytes_per_rank, kfx_stream stream);
 } kfx_comm;
 
 /* In-process transport: fills comms[0 .. world) for `world` host threads of this process that share the current device;
@@ -89,6 +94,12 @@ int kfx_slab_exchange_halos(const kfx_volume* local, const kfx_slab_layout* L, k
  * on return every rank holds the merged images.  key: w*h int64, payload: KFX_COMPOSITE_PAYLOAD*w*h float, dense device scratch of the caller. */
 int kfx_slab_composite(const kfx_image* depth, const kfx_image* norm, const kfx_image* img, long long* key, float* payload,
                        kfx_comm* comm, kfx_stream stream);
+/* The same merge by direct sends (kfx.h, kfx_composite_strips_*): every rank owns one strip of the image; one all-to-all brings the
+ * world copies of a strip to its owner, the owner keeps the nearest hit per pixel, one all-gather returns the merged strips.  Same
+ * winner per pixel, same images (a -0 component of a winning normal stays -0 here and becomes +0 in the payload's sum).  scratch:
+ * kfx_slab_composite_direct_scratch_bytes(w, h, world) bytes of device memory. */
+size_t kfx_slab_composite_direct_scratch_bytes(size_t w, size_t h, int world);
+int kfx_slab_composite_direct(const kfx_image* depth, const kfx_image* norm, const kfx_image* img, void* scratch, kfx_comm* comm, kfx_stream stream);
 
 /* The exact march.  A ray's march state (lambda, last_sdf, delta, status) travels with the ray from slab to slab: world + 1
  * stages of kfx_raycast_sdf_slab -- each rank advances the rays whose current sample lies in the planes it owns -- with an

@@ -113,6 +113,10 @@ SIGNATURES = {
     "kfx_composite_pack": (C.c_int, [PI, PI, PI, C.c_void_p, C.c_int, C.c_void_p]),
     "kfx_composite_select": (C.c_int, [PI, PI, PI, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "kfx_composite_unpack": (C.c_int, [PI, PI, PI, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "kfx_composite_strip_pixels": (C.c_size_t, [C.c_size_t, C.c_size_t, C.c_int]),
+    "kfx_composite_strips_pack": (C.c_int, [PI, PI, PI, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),
+    "kfx_composite_strips_merge": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p]),
+    "kfx_composite_strips_unpack": (C.c_int, [PI, PI, PI, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),
     "kfx_alloc_pitched": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_size_t, C.c_size_t]),
     "kfx_free": (C.c_int, [C.c_void_p]),
     "kfx_alloc_host": (C.c_int, [C.POINTER(C.c_void_p), C.c_size_t]),

@@ -72,6 +72,31 @@ int rccl_broadcast(kfx_comm* c, void* buf, size_t bytes, int root, kfx_stream st
     return nccl_status(ncclBroadcast(buf, buf, bytes, ncclInt8, root, im->comm, (hipStream_t)stream));
 }
 
+// One grouped send / recv per peer: RCCL runs them concurrently, each pair over its own xGMI link
+int rccl_all_to_all(kfx_comm* c, const void* send, void* recv, size_t bytes, kfx_stream stream)
+{
+    RcclImpl* im = static_cast<RcclImpl*>(c->impl);
+    if (bytes == 0) return 0;
+    if (!send || !recv) return KFX_E_NULL;
+    hipStream_t s = (hipStream_t)stream;
+    ncclResult_t r = ncclGroupStart();
+    for (int k = 0; k < c->world && r == ncclSuccess; ++k) {
+        const int peer = (c->rank + k) % c->world;   // (the own chunk too: a device-local copy inside the group)
+        r = ncclSend(static_cast<const char*>(send) + (size_t)peer * bytes, bytes, ncclInt8, peer, im->comm, s);
+        if (r == ncclSuccess) r = ncclRecv(static_cast<char*>(recv) + (size_t)peer * bytes, bytes, ncclInt8, peer, im->comm, s);
+    }
+    const ncclResult_t e = ncclGroupEnd();
+    return nccl_status(r != ncclSuccess ? r : e);
+}
+
+int rccl_all_gather(kfx_comm* c, const void* send, void* recv, size_t bytes, kfx_stream stream)
+{
+    RcclImpl* im = static_cast<RcclImpl*>(c->impl);
+    if (bytes == 0) return 0;
+    if (!send || !recv) return KFX_E_NULL;
+    return nccl_status(ncclAllGather(send, recv, bytes, ncclInt8, im->comm, (hipStream_t)stream));
+}
+
 int rccl_barrier(kfx_comm* c)
 {
     RcclImpl* im = static_cast<RcclImpl*>(c->impl);
@@ -231,6 +256,8 @@ extern "C" int kfx_comm_create_rccl(kfx_comm* comm, int rank, int world, const c
     comm->barrier = rccl_barrier;
     comm->destroy = rccl_destroy;
     comm->broadcast = rccl_broadcast;
+    comm->all_to_all = rccl_all_to_all;
+    comm->all_gather = rccl_all_gather;
     if (rank == 0 && world > 1) { // every rank has joined once ncclCommInitRank returns: the file has served its purpose
         rccl_barrier(comm);
         unlink(rendezvous_file);

@@ -189,15 +189,16 @@ extern "C" int kfx_frame_timings(kfx_frame* f, long long first_frame, int n_fram
     const auto slot_of = [&](long long fr) { return (int)(fr % f->slots); };
     const auto first_event = [](unsigned m) { for (int k = 0; k < 4; ++k) if (m & (1u << k)) return k; return -1; };
     const auto last_event = [](unsigned m) { for (int k = 3; k >= 0; --k) if (m & (1u << k)) return k; return -1; };
-    // wait for the latest event any of the answers needs (events of one stream complete in order): the next frame's first event
-    // -- the end of the last period -- or, failing that, the last event of the latest frame asked for that recorded any
+    // wait for the latest event any of the answers needs (events of one stream complete in order): the end of the last frame's
+    // period -- the next frame's copy of the last frame's first event -- or, failing that, the last event of the latest frame
+    // asked for that recorded any
     {
+        const auto recorded = [&](long long fr) { return fr >= 0 && fr < f->frames && f->ev_frame[slot_of(fr)] == fr ? (unsigned)f->ev_mask[slot_of(fr)] : 0u; };
         hipEvent_t wait_for = nullptr;
-        if (last + 1 < f->frames && f->ev_frame[slot_of(last + 1)] == last + 1 && f->ev_mask[slot_of(last + 1)])
-            wait_for = f->ev[(size_t)slot_of(last + 1) * 4 + first_event(f->ev_mask[slot_of(last + 1)])];
+        const int b = first_event(recorded(last));
+        if (b >= 0 && (recorded(last + 1) & (1u << b))) wait_for = f->ev[(size_t)slot_of(last + 1) * 4 + b];
         for (long long fr = last; !wait_for && fr >= first_frame; --fr)
-            if (f->ev_frame[slot_of(fr)] == fr && f->ev_mask[slot_of(fr)])
-                wait_for = f->ev[(size_t)slot_of(fr) * 4 + last_event(f->ev_mask[slot_of(fr)])];
+            if (recorded(fr)) wait_for = f->ev[(size_t)slot_of(fr) * 4 + last_event(recorded(fr))];
         if (wait_for) {
             const hipError_t he = hipEventSynchronize(wait_for);
             if (he != hipSuccess) { (void)hipGetLastError(); return set_error((int)he, "kfx_frame_timings: hipEventSynchronize"); }

@@ -247,6 +247,36 @@ static int threads_broadcast(kfx_comm* c, void* buf, size_t bytes, int root, kfx
     return group_status(g, par);
 }
 
+// all_to_all (gather = false): recv chunk r <- chunk `rank` of rank r's send; all_gather (gather = true): recv chunk r <- rank r's send
+static int threads_mesh(kfx_comm* c, const void* send, void* recv, size_t bytes, bool gather, kfx_stream stream)
+{
+    ThreadGroup* g = static_cast<ThreadGroup*>(c->impl);
+    const int r = c->rank;
+    int st = 0;
+    if ((!send || !recv) && bytes) st = set_error(KFX_E_NULL, "kfx_comm(threads) all_to_all / all_gather: null buffer");
+    if (!st) st = hip_status(hipStreamSynchronize((hipStream_t)stream), "kfx_comm(threads) all_to_all / all_gather"); // this rank's producers are done
+    const int par = (int)(g->seq[r]++ & 1u);
+    g->err[par][r].store(st);
+    g->send_lo[r] = send; g->bytes_lo[r] = bytes;
+    g->wait_all();
+    hipStream_t s = (hipStream_t)stream;
+    for (int k = 0; k < g->world && !st && bytes; ++k) {
+        const int from = (r + k) % g->world;
+        if (g->err[par][from].load() != 0) continue;
+        if (g->bytes_lo[from] != bytes) { st = set_error(KFX_E_SHAPE, "kfx_comm all_to_all / all_gather: ranks disagree on the byte count"); break; }
+        const unsigned char* src = static_cast<const unsigned char*>(g->send_lo[from]) + (gather ? 0 : (size_t)r * bytes);
+        st = hip_status(hipMemcpyAsync(static_cast<unsigned char*>(recv) + (size_t)from * bytes, src, bytes, hipMemcpyDeviceToDevice, s),
+                        "kfx_comm(threads) all_to_all / all_gather");
+    }
+    if (!st) st = hip_status(hipStreamSynchronize(s), "kfx_comm(threads) all_to_all / all_gather");
+    if (st) g->err[par][r].store(st);
+    g->wait_all(); // nobody reuses a send buffer before its readers are done
+    return group_status(g, par);
+}
+
+static int threads_all_to_all(kfx_comm* c, const void* send, void* recv, size_t bytes, kfx_stream stream) { return threads_mesh(c, send, recv, bytes, false, stream); }
+static int threads_all_gather(kfx_comm* c, const void* send, void* recv, size_t bytes, kfx_stream stream) { return threads_mesh(c, send, recv, bytes, true, stream); }
+
 static int threads_barrier(kfx_comm* c)
 {
     static_cast<ThreadGroup*>(c->impl)->wait_all();
@@ -279,6 +309,8 @@ extern "C" int kfx_comm_create_threads(kfx_comm* comms, int world)
         comms[r].barrier = threads_barrier;
         comms[r].destroy = threads_destroy;
         comms[r].broadcast = threads_broadcast;
+        comms[r].all_to_all = threads_all_to_all;
+        comms[r].all_gather = threads_all_gather;
     }
     return 0;
 }
@@ -369,6 +401,31 @@ extern "C" int kfx_slab_composite(const kfx_image* depth, const kfx_image* norm,
     if (int e = kfx_composite_select(depth, norm, img, key, payload, comm->rank, stream)) return e;
     if (int e = comm->all_reduce(comm, payload, KFX_COMPOSITE_PAYLOAD * n, KFX_COMM_SUM_F32, stream)) return e;
     return kfx_composite_unpack(depth, norm, img, key, payload, stream);
+}
+
+extern "C" size_t kfx_slab_composite_direct_scratch_bytes(size_t w, size_t h, int world)
+{
+    if (world < 1) return 0;   // send strips, received / gathered strips, this rank's merged strip
+    return (2 * (size_t)world + 1) * KFX_COMPOSITE_STRIP_PLANES * kfx_composite_strip_pixels(w, h, world) * sizeof(float);
+}
+
+extern "C" int kfx_slab_composite_direct(const kfx_image* depth, const kfx_image* norm, const kfx_image* img, void* scratch, kfx_comm* comm,
+                                         kfx_stream stream)
+{
+    if (!comm || !depth) return set_error(KFX_E_NULL, "kfx_slab_composite_direct: null argument");
+    if (comm->world == 1) return 0;
+    if (!scratch) return set_error(KFX_E_NULL, "kfx_slab_composite_direct: null scratch");
+    if (!comm->all_to_all || !comm->all_gather) return set_error(KFX_E_RANGE, "kfx_slab_composite_direct: the transport has no all_to_all / all_gather");
+    const int W = comm->world;
+    const size_t S = kfx_composite_strip_pixels(depth->w, depth->h, W), strip = KFX_COMPOSITE_STRIP_PLANES * S;
+    float* send = static_cast<float*>(scratch);
+    float* recv = send + (size_t)W * strip;
+    float* merged = recv + (size_t)W * strip;
+    if (int e = kfx_composite_strips_pack(depth, norm, img, send, 0, W, stream)) return e;
+    if (int e = comm->all_to_all(comm, send, recv, strip * sizeof(float), stream)) return e;
+    if (int e = kfx_composite_strips_merge(recv, merged, S, 0, W, stream)) return e;
+    if (int e = comm->all_gather(comm, merged, recv, strip * sizeof(float), stream)) return e;
+    return kfx_composite_strips_unpack(depth, norm, img, recv, 0, W, stream);
 }
 
 extern "C" size_t kfx_slab_exact_scratch_bytes(size_t w, size_t h) { return (17 * w * h + 64) * sizeof(int); }

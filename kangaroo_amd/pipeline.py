@@ -360,7 +360,7 @@ class SlabPipeline(FramePipeline):
     USE_FRAME = False   # slabs: the operators take slab arguments and collectives sit between them
 
     def __init__(self, ops, dist, dims, boxmin, boxmax, w, h, halo="exchange", raycast="composite", kind="f32", overlap=False,
-                 inputs="replicate", images="all", **kw):
+                 inputs="replicate", images="all", merge="direct", **kw):
         """halo = "exchange": every rank integrates only the planes it owns and the ghost planes are
         refreshed from the two neighbours after each SdfFuse (point-to-point send/recv: one xGMI link
         per direction); halo = "recompute": every rank integrates its ghost planes itself (the update is
@@ -378,6 +378,13 @@ class SlabPipeline(FramePipeline):
         if images == "root" and raycast != "composite":
             raise ValueError("SlabPipeline: images='root' is an option of the composite raycast")
         self.images = images
+        # merge (composite mode): how the per-slab images become one.  "direct" = every rank owns one strip of the image: one
+        # all-to-all sends each strip to its owner, the owner keeps the nearest hit per pixel, one all-gather (images = "root": a
+        # gather) returns the merged strips -- each byte crosses one link once per phase, all links of the xGMI mesh at once;
+        # "allreduce" = a MIN all-reduce of (depth, rank) keys + a SUM all-reduce of the winners' payload (whole images through
+        # whatever ring / tree the library builds).  Same winner per pixel, same images.
+        assert merge in ("direct", "allreduce")
+        self.merge = merge
         # overlap (composite mode, known-pose streams): the merge of frame k's per-slab images -- two latency-bound
         # all-reduces and three small kernels -- runs on a second stream while the main stream already preprocesses and
         # integrates frame k + 1; step() then returns before ray_d / ray_n / ray_i are merged: they are valid only after
@@ -526,8 +533,8 @@ class SlabPipeline(FramePipeline):
     def raycast_levels_into(self, outputs, K_levels, T_wc):
         """Several renderings of the model from one pose (the tracking loop's pyramid levels): outputs = [(d, n, i), ...].
         Composite mode renders them with one launch where the operator set has RaycastSdfLevels and merges them with ONE
-        pair of all-reduces (keys and payloads of all levels side by side) instead of a pair per level; the images equal
-        those of per-level raycast_into calls.  Exact mode hands the march over level by level."""
+        pair of collectives (the strips -- or keys and payloads -- of all levels side by side) instead of a pair per level; the
+        images equal those of per-level raycast_into calls.  Exact mode hands the march over level by level."""
         if self.raycast_mode == "exact":
             for (d, n, i), K in zip(outputs, K_levels):
                 self.raycast_exact(T_wc, d, n, i, K)
@@ -538,6 +545,9 @@ class SlabPipeline(FramePipeline):
             for (d, n, i), K in zip(outputs, K_levels):
                 self.ops.RaycastSdf(d, n, i, self.vol, T_wc, K, self.near, self.far, self.trunc, True)
         if self.world == 1:
+            return
+        if self.merge == "direct" and hasattr(self.ops, "CompositeStripsPack"):
+            self.composite_direct_levels(outputs)
             return
         if not hasattr(self.ops, "CompositePack"):
             for d, n, i in outputs:
@@ -668,8 +678,103 @@ class SlabPipeline(FramePipeline):
         self.rounds = rounds
         o.RaycastStateToImages(d, n, i, st)
 
+    def _all_to_all(self, recv, send):
+        """recv[r] = rank r's send[self.rank] (dense tensors of shape (world, ...))."""
+        dist = self.dist
+        if dist.get_backend() == "nccl":
+            dist.all_to_all_single(recv, send)   # RCCL: one grouped send / recv per peer, every link of the mesh at once
+            return
+        recv[self.rank].copy_(send[self.rank])
+        ops = []
+        for k in range(1, self.world):   # (gloo: the tests' transport; device tensors are staged through the host, see _p2p)
+            to, frm = (self.rank + k) % self.world, (self.rank - k) % self.world
+            ops += [dist.P2POp(dist.isend, send[to], to), dist.P2POp(dist.irecv, recv[frm], frm)]
+        self._p2p(ops)
+
+    def _gather_strips(self, full, part):
+        """full[r] = rank r's part: on every rank, or (images = "root") on rank 0 only."""
+        dist = self.dist
+        if dist.get_backend() == "nccl":
+            if self.images == "root":
+                dist.gather(part, [full[r] for r in range(self.world)] if self.rank == 0 else None, dst=0)
+            else:
+                dist.all_gather_into_tensor(full, part)
+            return
+        full[self.rank].copy_(part)
+        ops = []
+        for k in range(1, self.world):
+            to, frm = (self.rank + k) % self.world, (self.rank - k) % self.world
+            if self.images != "root" or to == 0:
+                ops.append(dist.P2POp(dist.isend, part, to))
+            if self.images != "root" or self.rank == 0:
+                ops.append(dist.P2POp(dist.irecv, full[frm], frm))
+        self._p2p(ops)
+
+    def composite_direct_levels(self, outputs):
+        """The direct-send merge of several images at once (pyramid levels: outputs = [(d, n, i), ...]): a rank's strips of all
+        levels lie side by side in one buffer, so the whole set costs ONE all-to-all and ONE all-gather."""
+        import torch
+        o, W = self.ops, self.world
+        planes = 5
+        S = [o.CompositeStripPixels(d.w, d.h, W) for d, _, _ in outputs]
+        offs = [0]
+        for s_l in S:
+            offs.append(offs[-1] + planes * s_l)
+        total = offs[-1]
+        like = outputs[0][0]
+        send = self._scratch("strips_send", (W, total), torch.float32, like)
+        recv = self._scratch("strips_recv", (W, total), torch.float32, like)
+        merged = self._scratch("strips_merged", (total,), torch.float32, like)
+        for (d, n, i), off in zip(outputs, offs):
+            o.CompositeStripsPack(d, n, i, send, W, offset=off, rank_stride=total)
+        self._all_to_all(recv, send)
+        for s_l, off in zip(S, offs):
+            o.CompositeStripsMerge(recv, merged, s_l, W, offset=off, rank_stride=total, merged_offset=off)
+        self._gather_strips(recv, merged)      # (recv is free again: it becomes the gathered strips)
+        if self.images != "root" or self.rank == 0:
+            for (d, n, i), off in zip(outputs, offs):
+                o.CompositeStripsUnpack(d, n, i, recv, W, offset=off, rank_stride=total)
+
+    def composite_direct(self, d, n, i):
+        """The direct-send merge (include/kfx.h, kfx_composite_strips_*): strips to their owners, nearest hit per pixel, strips
+        back.  Operator sets without the kernels (the oracle-backed CPU stand-in of the tests) use the tensor expressions."""
+        if hasattr(self.ops, "CompositeStripsPack"):
+            self.composite_direct_levels([(d, n, i)])
+            return
+        import torch
+        W = self.world
+        w, h = d.w, d.h
+        planes = 5
+        dt, nt, it = d.tensor(), n.tensor(), i.tensor()
+        P = w * h
+        S = ((P + W - 1) // W + 63) // 64 * 64   # kfx_composite_strip_pixels
+        hit = torch.isfinite(dt)
+        img = torch.zeros((planes, W * S), dtype=torch.float32, device=dt.device)
+        img[0] = float("inf")
+        img[0, :P] = torch.where(hit, dt, torch.full_like(dt, float("inf"))).reshape(-1)
+        for c in range(3):
+            img[1 + c, :P] = torch.where(hit, nt[..., c], torch.zeros_like(dt)).reshape(-1)
+        img[4, :P] = torch.where(hit, it, torch.zeros_like(it)).reshape(-1)
+        send = img.reshape(planes, W, S).permute(1, 0, 2).contiguous()
+        recv = torch.empty_like(send)
+        self._all_to_all(recv, send)
+        bits = recv[:, 0].contiguous().view(torch.int32).to(torch.int64)
+        win = torch.argmin((bits << 8) | torch.arange(W, device=dt.device).reshape(W, 1), dim=0)
+        merged = torch.gather(recv, 0, win.reshape(1, 1, S).expand(1, planes, S))[0].contiguous()
+        full = torch.empty_like(send)
+        self._gather_strips(full, merged)
+        if self.images == "root" and self.rank != 0:
+            return
+        out = full.permute(1, 0, 2).reshape(planes, W * S)[:, :P]
+        any_hit = torch.isfinite(out[0]).reshape(h, w)
+        dt.copy_(torch.where(any_hit, out[0].reshape(h, w), torch.full_like(dt, float("nan"))))
+        for c in range(3):
+            nt[..., c].copy_(out[1 + c].reshape(h, w))
+        nt[..., 3].copy_(any_hit.to(torch.float32))
+        it.copy_(out[4].reshape(h, w))
+
     def composite(self, d=None, n=None, i=None):
-        """Nearest hit over all slabs.  key = depth bits (positive floats order like ints) in the
+        """Nearest hit over all slabs (merge = "direct": composite_direct above).  key = depth bits (positive floats order like ints) in the
         high word, rank in the low byte; misses use +inf.  One MIN all-reduce picks the winner,
         one SUM all-reduce broadcasts its normal / shade (four floats per pixel; the depth and the hit flag travel in the key).  With the HIP
         operator set the per-pixel glue is three fused kernels; operator sets without them (the
@@ -678,6 +783,9 @@ class SlabPipeline(FramePipeline):
         dist = self.dist
         d, n, i = (self.ray_d, self.ray_n, self.ray_i) if d is None else (d, n, i)
         w, h = d.w, d.h
+        if self.merge == "direct":
+            self.composite_direct(d, n, i)
+            return
         if hasattr(self.ops, "CompositePack"):
             key = self._scratch("key", (w * h,), torch.int64, d)
             payload = self._scratch("payload", (w * h * 4,), torch.float32, d)

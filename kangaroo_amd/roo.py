@@ -561,6 +561,34 @@ def CompositeUnpack(depth, norm, img, key, payload, stream=None):
                                                 C.c_void_p(payload.data_ptr()), _stream(stream)))
 
 
+STRIP_PLANES = 5   # KFX_COMPOSITE_STRIP_PLANES
+
+
+def CompositeStripPixels(w, h, world):
+    """kfx_composite_strip_pixels: pixels per strip of the direct-send composite (the last strip is padded)."""
+    return int(_lib.load().kfx_composite_strip_pixels(w, h, world))
+
+
+def CompositeStripsPack(depth, norm, img, send, world, offset=0, rank_stride=0, stream=None):
+    """kfx_composite_strips_pack: this rank's images cut into strips; strip j's 5 planes of S floats start at float
+    offset + j * rank_stride of the tensor `send` (rank_stride 0: dense, world x 5 x S)."""
+    _lib.check(_lib.load().kfx_composite_strips_pack(depth.ref(), norm.ref(), img.ref(), C.c_void_p(send.data_ptr() + 4 * offset), rank_stride, world,
+                                                     _stream(stream)))
+
+
+def CompositeStripsMerge(recv, merged, strip_pixels, world, offset=0, rank_stride=0, merged_offset=0, stream=None):
+    """kfx_composite_strips_merge: merged (5 x S at float merged_offset) = per pixel the nearest of the world copies in recv
+    (rank r's at float offset + r * rank_stride)."""
+    _lib.check(_lib.load().kfx_composite_strips_merge(C.c_void_p(recv.data_ptr() + 4 * offset), C.c_void_p(merged.data_ptr() + 4 * merged_offset),
+                                                      strip_pixels, rank_stride, world, _stream(stream)))
+
+
+def CompositeStripsUnpack(depth, norm, img, strips, world, offset=0, rank_stride=0, stream=None):
+    """kfx_composite_strips_unpack: the gathered strips back into the depth / normal / shade images."""
+    _lib.check(_lib.load().kfx_composite_strips_unpack(depth.ref(), norm.ref(), img.ref(), C.c_void_p(strips.data_ptr() + 4 * offset), rank_stride, world,
+                                                       _stream(stream)))
+
+
 def RaycastSdfSlab(state, init, vol, slab, own_lo, own_hi, w, h, T_wc, K, near, far, trunc_dist, subpix=True, stream=None):
     """kfx_raycast_sdf_slab: one round of the exact multi-GPU march; `state` is a dense float32 tensor (9, h, w)."""
     assert state.dtype == torch.float32 and state.is_contiguous() and tuple(state.shape) == (9, h, w)

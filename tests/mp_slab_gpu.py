@@ -76,6 +76,19 @@ if not tracking:
         for p_, q_ in zip(x, y):
             assert same(p_.MemcpyToHost(), q_.MemcpyToHost()), "rank %d: merged levels differ from level-by-level" % rank
     assert same(a[0][0].MemcpyToHost(), d)
+    # (2d) the direct-send merge (strips: all-to-all + all-gather, the default) = the key / payload merge (two all-reduces), for one
+    # image and for several levels at once
+    if raycast == "composite":
+        assert pipe.merge == "direct"
+        pipe.merge = "allreduce"
+        c, e = mk(), mk()
+        for (dd, nn, ii), Kl in zip(c, Ks):
+            pipe.raycast_into(dd, nn, ii, Kl, T_last)
+        pipe.raycast_levels_into(e, Ks, T_last)
+        pipe.merge = "direct"
+        for x, y, z in zip(a, c, e):
+            for p_, q_, r_ in zip(x, y, z):
+                assert same(p_.MemcpyToHost(), q_.MemcpyToHost()) and same(p_.MemcpyToHost(), r_.MemcpyToHost()), "rank %d: direct merge differs from the all-reduce merge" % rank
     # (3) all ranks hold the same images
     chk = torch.tensor(np.nan_to_num(d, nan=-1.0).view(np.int32).astype(np.int64).sum()).reshape(1)
     both = torch.cat([chk, -chk])

@@ -59,8 +59,17 @@ def test_cpp_slabs_composite_and_fast_mode():
     for fast in ((), ("--fast",)):
         ref = run(*COMMON, *fast, "--ranks", 1, "--raycast", "composite")
         got = run(*COMMON, *fast, "--ranks", 4, "--raycast", "composite", "--halo", "exchange")
-        assert got["agree"] == 1 and got["volume"] == ref["volume"]
+        assert got["agree"] == 1 and got["volume"] == ref["volume"] and "direct-send merge" in got["text"]
         assert abs(got["hits"] - ref["hits"]) <= 0.01 * ref["hits"]
+        # the direct-send merge (default: kfx_slab_composite_direct, all-to-all + all-gather of image strips) picks the winners of
+        # the key / payload merge (--merge allreduce: kfx_slab_composite): same depth bits, same hits
+        other = run(*COMMON, *fast, "--ranks", 4, "--raycast", "composite", "--halo", "exchange", "--merge", "allreduce")
+        assert other["agree"] == 1 and "all-reduce merge" in other["text"]
+        assert other["depth"] == got["depth"] and other["hits"] == got["hits"] and other["volume"] == got["volume"]
+    for ranks in (3, 5):   # strips that do not divide the image evenly
+        a = run(*COMMON, "--ranks", ranks, "--raycast", "composite")
+        b = run(*COMMON, "--ranks", ranks, "--raycast", "composite", "--merge", "allreduce")
+        assert a["agree"] == 1 and b["agree"] == 1 and a["depth"] == b["depth"] and a["hits"] == b["hits"]
 
 
 def test_cpp_slabs_rccl_transport_single_rank(tmp_path):

@@ -82,6 +82,16 @@ def test_gpu_frame_step_equals_the_separate_calls(roo, math, track):
         assert np.all(t[:3, 1] > 0) and np.all(np.isnan(t[:3, [0, 2, 3]])), t      # SdfFuse window only
         assert np.all(t[:2, 4] > t[:2, 1]) and np.isnan(t[2, 4])                   # period: before-SdfFuse to before-SdfFuse; the next frame recorded nothing
         assert np.all(np.isnan(t[3]))
+        # a frame with the SdfFuse events only followed by one with all four, read back without a synchronisation in between: the
+        # period ends at the next frame's before-SdfFuse event (not at its first event), and timings() waits for that one
+        fr.set_timing(fr.EVENTS_FUSE)
+        n1 = fr.count
+        fr.step(T_wc, None, raw)
+        fr.set_timing(fr.EVENTS_ALL)
+        for i in range(3):
+            fr.step(scenes.orbit_pose(i, 30), None, raw)
+        t = fr.timings(n1, 1)
+        assert t[0, 4] > t[0, 1] > 0 and np.all(np.isnan(t[0, [0, 2, 3]])), t
     finally:
         roo.set_math_mode(prev)
 

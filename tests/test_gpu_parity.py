@@ -650,6 +650,60 @@ def test_gpu_composite_kernels_match_tensor_expressions(roo):
     assert (n[~np.isfinite(d)] == 0).all() and (n[np.isfinite(d)][:, 3] == 1).all()
 
 
+@pytest.mark.parametrize("world,w,h", [(2, 160, 120), (3, 161, 97), (8, 160, 120)])
+def test_gpu_direct_send_composite_kernels(roo, world, w, h):
+    """kfx_composite_strips_pack / merge / unpack (the direct-send merge), with the all-to-all and the all-gather emulated on one
+    GPU over `world` overlapping slabs of one volume, against the key / payload composite of the kernels above: the same winner
+    per pixel, the same images (image sizes that do not divide by the rank count: the last strip is padded)."""
+    import torch
+    from kangaroo_amd.pipeline import slab_range
+    N = 64
+    ovol = T.make_volume(N, "room")
+    K, tr, fr = T.fuse_frames_oracle(ovol, "room", w, h, 2)
+    vol = T.upload_volume(roo, ovol)
+    bmin, bmax, near, far = scenes.SCENES["room"]
+    T_wc = fr[-1]["T_wc"]
+    ranks = []
+    for r in range(world):
+        z0, z1 = slab_range(N, r, world)
+        rd, rn, ri = roo.Image(w, h, pitch=w * 4), roo.Image(w, h, "f32x4", pitch=w * 16), roo.Image(w, h, pitch=w * 4)
+        roo.RaycastSdf(rd, rn, ri, vol.ZSlab(max(z0 - 2, 0), min(z1 + 2, N)), T_wc, K, near, far, tr, True)
+        ranks.append((rd, rn, ri))
+    # the key / payload composite (MIN and SUM over the ranks emulated elementwise)
+    kbuf = [torch.empty(w * h, dtype=torch.int64, device="cuda") for _ in ranks]
+    for r, (rd, rn, ri) in enumerate(ranks):
+        roo.CompositePack(rd, rn, ri, kbuf[r], r)
+    key = torch.stack(kbuf).min(dim=0).values
+    pbuf = [torch.empty(w * h * 4, dtype=torch.float32, device="cuda") for _ in ranks]
+    for r, (rd, rn, ri) in enumerate(ranks):
+        roo.CompositeSelect(rd, rn, ri, key, pbuf[r], r)
+    pay = torch.stack(pbuf).sum(dim=0)
+    wd, wn, wi = roo.Image(w, h, pitch=w * 4), roo.Image(w, h, "f32x4", pitch=w * 16), roo.Image(w, h, pitch=w * 4)
+    roo.CompositeUnpack(wd, wn, wi, key, pay)
+    want = [x.MemcpyToHost() for x in (wd, wn, wi)]
+    # the direct-send merge
+    S = roo.CompositeStripPixels(w, h, world)
+    assert S % 64 == 0 and S * world >= w * h > (S - 64) * world
+    send = [torch.full((world, roo.STRIP_PLANES, S), float("nan"), device="cuda") for _ in ranks]
+    for r, (rd, rn, ri) in enumerate(ranks):
+        roo.CompositeStripsPack(rd, rn, ri, send[r], world)
+    full = torch.empty((world, roo.STRIP_PLANES, S), device="cuda")
+    for j in range(world):   # rank j: receives strip j of every rank, merges, its result is slot j of the all-gather
+        recv = torch.stack([send[r][j] for r in range(world)]).contiguous()
+        merged = torch.empty((roo.STRIP_PLANES, S), device="cuda")
+        roo.CompositeStripsMerge(recv, merged, S, world)
+        full[j] = merged
+    gd, gn, gi = roo.Image(w, h, pitch=w * 4), roo.Image(w, h, "f32x4", pitch=w * 16), roo.Image(w, h, pitch=w * 4)
+    roo.CompositeStripsUnpack(gd, gn, gi, full, world)
+    got = [x.MemcpyToHost() for x in (gd, gn, gi)]
+    assert np.isfinite(got[0]).mean() > 0.3
+    for a, b in zip(got, want):   # (values: a -0 of a winner's normal stays -0 here and becomes +0 in the sum)
+        assert np.array_equal(a, b, equal_nan=True)
+    # the winner is the nearest of the per-rank hits
+    stack = np.stack([np.where(np.isfinite(rd.MemcpyToHost()), rd.MemcpyToHost(), np.inf) for rd, _, _ in ranks])
+    assert np.array_equal(np.where(np.isfinite(got[0]), got[0], np.inf), stack.min(axis=0))
+
+
 @pytest.mark.parametrize("world,ghost", [(2, 2), (4, 1), (5, 3)])
 def test_gpu_exact_slab_raycast_rounds(roo, world, ghost):
     """SURVEY 8(e) exact variant: `world` slabs of one volume marched in rounds with the state merge of

@@ -28,13 +28,14 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out_dir, halo, raycast="composite", inputs="replicate", images="all"):
+def _worker(rank, world, port, out_dir, halo, raycast="composite", inputs="replicate", images="all", merge="direct"):
     import oracle_ops as ops
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     bmin, bmax, near, far = scenes.SCENES["room"]
-    pipe = SlabPipeline(ops, dist, (N, N, N), bmin, bmax, W, H, halo=halo, raycast=raycast, near=near, far=far, inputs=inputs, images=images)
+    pipe = SlabPipeline(ops, dist, (N, N, N), bmin, bmax, W, H, halo=halo, raycast=raycast, near=near, far=far, inputs=inputs, images=images,
+                        merge=merge)
     K = pipe.K
     for i in range(FRAMES):
         T_wc = scenes.orbit_pose(i, 8)
@@ -205,6 +206,22 @@ def test_tracked_kinectfusion_on_slabs(tmp_path, raycast):
             assert T.nan_equal(r["vol"], ref.vol.data[s0:s1])
     else:
         assert np.abs(ranks[0]["poses"][:, :3, 3] - want[:, :3, 3]).max() < 5e-4
+
+
+@pytest.mark.parametrize("world,images", [(2, "all"), (3, "all"), (3, "root")])
+def test_direct_send_merge_equals_the_all_reduce_merge(tmp_path, world, images):
+    """merge="direct" (strips to their owners by all-to-all, nearest hit per pixel, strips back by all-gather / gather) against
+    merge="allreduce" (MIN of keys + SUM of payloads): the same winner per pixel, so the same images (a -0 component of a winning
+    normal comes back as -0 from the direct merge and as +0 from the sum: compared as values)."""
+    a, b = tmp_path / "direct", tmp_path / "allreduce"
+    a.mkdir(); b.mkdir()
+    mp.spawn(_worker, args=(world, _free_port(), str(a), "recompute", "composite", "replicate", images, "direct"), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), str(b), "recompute", "composite", "replicate", images, "allreduce"), nprocs=world, join=True)
+    for r in range(world if images == "all" else 1):
+        x, y = np.load(str(a / ("rank%d.npz" % r))), np.load(str(b / ("rank%d.npz" % r)))
+        assert np.isfinite(x["depth"]).mean() > 0.3
+        for k in ("depth", "norm", "img"):
+            assert np.array_equal(x[k], y[k], equal_nan=True), (r, k)
 
 
 def test_composite_to_root_and_pose_broadcast(tmp_path):
