@@ -56,6 +56,9 @@ def test_gpu_bench_two_ranks_smoke(raycast):
         assert r["halo_bytes_received_per_fuse"] == 2 * 128 * 128 * 8          # two ghost planes of 128 x 128 cells from the one neighbour
         assert r["planes_owned"] == 64 and r["voxels_stored"] == 128 * 128 * 66
         assert (r["composite_merge_ms"] is not None and r["composite_merge_ms"] > 0) == (raycast == "composite")
+        assert (r["composite_merge_allreduce_ms"] is not None and r["composite_merge_allreduce_ms"] > 0) == (raycast == "composite")   # the other merge, by itself
+    if raycast == "composite":
+        assert "all_to_all" in d["config"]["partition"] and d["multi_gpu_variants"]["merge_allreduce_fps"] > 0
     assert d["kernels_ms"]["sdf_fuse"] == pr[0]["sdf_fuse_ms"]
 
 
