@@ -684,9 +684,16 @@ class SlabPipeline(FramePipeline):
         if dist.get_backend() == "nccl":
             dist.all_to_all_single(recv, send)   # RCCL: one grouped send / recv per peer, every link of the mesh at once
             return
+        if send.is_cuda:   # gloo with device tensors (the tests' ranks sharing one GPU): its point-to-point path takes ~0.1 s per
+            import torch   # message, its all-reduce does not -- every rank's strips summed as integers into one table (bits survive)
+            table = torch.zeros((self.world,) + tuple(send.shape), dtype=torch.int32, device=send.device)
+            table[self.rank] = send.view(torch.int32)
+            dist.all_reduce(table)
+            recv.copy_(table[:, self.rank].view(torch.float32))
+            return
         recv[self.rank].copy_(send[self.rank])
         ops = []
-        for k in range(1, self.world):   # (gloo: the tests' transport; device tensors are staged through the host, see _p2p)
+        for k in range(1, self.world):   # gloo, host tensors (the CPU tests)
             to, frm = (self.rank + k) % self.world, (self.rank - k) % self.world
             ops += [dist.P2POp(dist.isend, send[to], to), dist.P2POp(dist.irecv, recv[frm], frm)]
         self._p2p(ops)
@@ -699,6 +706,13 @@ class SlabPipeline(FramePipeline):
                 dist.gather(part, [full[r] for r in range(self.world)] if self.rank == 0 else None, dst=0)
             else:
                 dist.all_gather_into_tensor(full, part)
+            return
+        if part.is_cuda:   # (gloo with device tensors: as in _all_to_all; every rank ends up with the strips)
+            import torch
+            table = torch.zeros(tuple(full.shape), dtype=torch.int32, device=part.device)
+            table[self.rank] = part.view(torch.int32).reshape(table[self.rank].shape)
+            dist.all_reduce(table)
+            full.copy_(table.view(torch.float32))
             return
         full[self.rank].copy_(part)
         ops = []
