@@ -100,3 +100,53 @@ def test_cpp_slabs_c4_1024_cubed_in_eight_slabs():
     assert got["agree"] == 1 and ref["hits"] > 640 * 480 // 3
     for k in ("depth", "norm", "img", "volume", "hits"):
         assert got[k] == ref[k], (k, got["text"], ref["text"])
+
+
+def test_rccl_transport_collectives_on_a_one_rank_communicator(tmp_path):
+    """Every function of the RCCL transport's table (libkfx_rccl.so: ncclAllReduce, ncclAllGather, ncclBroadcast, grouped
+    ncclSend / ncclRecv -- the neighbour exchange and the direct merge's all-to-all) on the one GPU of the box: a one-rank
+    communicator is the identity, through the calls N ranks make (kfx_slab_composite_direct returns early for one rank, so the
+    application test above never reaches all_to_all / all_gather)."""
+    import ctypes as C
+    import torch
+    from kangaroo_amd import _lib
+
+    class Comm(C.Structure):   # kfx_comm (include/kfx_slab.h)
+        pass
+    P, V, Z = C.POINTER(Comm), C.c_void_p, C.c_size_t
+    Comm._fields_ = [("rank", C.c_int), ("world", C.c_int), ("impl", V),
+                     ("all_reduce", C.CFUNCTYPE(C.c_int, P, V, Z, C.c_int, V)),
+                     ("exchange", C.CFUNCTYPE(C.c_int, P, V, V, Z, V, V, Z, V)),
+                     ("barrier", C.CFUNCTYPE(C.c_int, P)),
+                     ("destroy", C.CFUNCTYPE(None, P)),
+                     ("broadcast", C.CFUNCTYPE(C.c_int, P, V, Z, C.c_int, V)),
+                     ("all_to_all", C.CFUNCTYPE(C.c_int, P, V, V, Z, V)),
+                     ("all_gather", C.CFUNCTYPE(C.c_int, P, V, V, Z, V))]
+    R = C.CDLL(os.path.join(os.path.dirname(_lib.LIB_PATH), "libkfx_rccl.so"))
+    R.kfx_comm_create_rccl.argtypes = [P, C.c_int, C.c_int, C.c_char_p, C.c_int]
+    torch.cuda.set_device(0)
+    torch.zeros(1, device="cuda")   # the caller selects and initialises its device
+    comm = Comm()
+    assert R.kfx_comm_create_rccl(C.byref(comm), 0, 1, str(tmp_path / "id").encode(), 30) == 0
+    try:
+        assert comm.rank == 0 and comm.world == 1
+        st = V(torch.cuda.current_stream().cuda_stream)
+        a = torch.arange(1000, dtype=torch.float32, device="cuda") - 7.5
+        b = torch.full_like(a, float("nan"))
+        want = a.clone()
+        assert comm.all_to_all(C.byref(comm), V(a.data_ptr()), V(b.data_ptr()), a.numel() * 4, st) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(b, want)
+        b.fill_(float("nan"))
+        assert comm.all_gather(C.byref(comm), V(a.data_ptr()), V(b.data_ptr()), a.numel() * 4, st) == 0
+        assert comm.all_reduce(C.byref(comm), V(a.data_ptr()), a.numel(), 1, st) == 0            # KFX_COMM_SUM_F32
+        k = torch.arange(1000, dtype=torch.int64, device="cuda") * 3 - 11
+        assert comm.all_reduce(C.byref(comm), V(k.data_ptr()), k.numel(), 0, st) == 0            # KFX_COMM_MIN_I64
+        assert comm.broadcast(C.byref(comm), V(a.data_ptr()), a.numel() * 4, 0, st) == 0
+        assert comm.exchange(C.byref(comm), V(a.data_ptr()), V(b.data_ptr()), 64, V(a.data_ptr()), V(b.data_ptr()), 64, st) == 0   # no neighbours: nothing moves
+        assert comm.barrier(C.byref(comm)) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(b, want) and torch.equal(a, want) and torch.equal(k, torch.arange(1000, dtype=torch.int64, device="cuda") * 3 - 11)
+        assert comm.all_reduce(C.byref(comm), V(a.data_ptr()), a.numel(), 99, st) != 0           # unknown operation
+    finally:
+        comm.destroy(C.byref(comm))
