@@ -195,7 +195,7 @@ static int strip_params(StripParams& p, const kfx_image* depth, const kfx_image*
     if ((((uintptr_t)norm->ptr | norm->pitch) & 15) || (((uintptr_t)depth->ptr | depth->pitch | (uintptr_t)img->ptr | img->pitch | (uintptr_t)buf) & 3))
         return set_error(KFX_E_ALIGN, "composite strips: alignment");
     const size_t S = kfx_composite_strip_pixels(depth->w, depth->h, world);
-    if (S > 0xffffffffull) return set_error(KFX_E_RANGE, "composite strips: image too large");
+    if (S > 0x7fffffffull) return set_error(KFX_E_RANGE, "composite strips: image too large");
     if (stride && stride < KFX_COMPOSITE_STRIP_PLANES * S) return set_error(KFX_E_SHAPE, "composite strips: rank stride smaller than a strip");
     p = StripParams{(unsigned char*)depth->ptr, (unsigned char*)norm->ptr, (unsigned char*)img->ptr, depth->pitch, norm->pitch, img->pitch,
                     buf, stride ? stride : KFX_COMPOSITE_STRIP_PLANES * S, (int)depth->w, (int)depth->h, world, (unsigned)S};
@@ -215,7 +215,7 @@ extern "C" int kfx_composite_strips_pack(const kfx_image* depth, const kfx_image
 extern "C" int kfx_composite_strips_merge(const float* recv, float* merged, size_t strip_pixels, size_t rank_stride, int world, kfx_stream stream)
 {
     if (!recv || !merged) return set_error(KFX_E_NULL, "kfx_composite_strips_merge: null argument");
-    if (world < 1 || world > 256 || strip_pixels > 0xffffffffull) return set_error(KFX_E_RANGE, "kfx_composite_strips_merge: world / strip size");
+    if (world < 1 || world > 256 || strip_pixels > 0x7fffffffull) return set_error(KFX_E_RANGE, "kfx_composite_strips_merge: world / strip size");
     if (((uintptr_t)recv | (uintptr_t)merged) & 3) return set_error(KFX_E_ALIGN, "kfx_composite_strips_merge: alignment");
     if (rank_stride && rank_stride < KFX_COMPOSITE_STRIP_PLANES * strip_pixels) return set_error(KFX_E_SHAPE, "kfx_composite_strips_merge: rank stride smaller than a strip");
     if (strip_pixels == 0) return 0;

@@ -285,3 +285,23 @@ def test_frame_object_validates_its_views_without_a_gpu():
     out = (C.c_float * 5)()
     assert L.kfx_frame_timings(h, 0, 1, out) == -4                                # created without timing slots
     assert L.kfx_frame_destroy(h) == 0
+
+
+def test_composite_strip_layout_and_argument_checks_without_a_gpu():
+    """kfx_composite_strip_pixels (the direct-send merge's strip size: whole 256-byte planes, the last strip padded) and the
+    argument validation of the three strip kernels' entry points (no launch is reached)."""
+    L = _lib.load()
+    S = L.kfx_composite_strip_pixels
+    assert S(640, 480, 8) == 38400 and S(640, 480, 1) == 307200 and S(161, 97, 3) == 5248 and S(1, 1, 4) == 64
+    assert S(640, 480, 0) == 0 and S(0, 0, 2) == 0
+    for w, h, n in ((640, 480, 8), (161, 97, 3), (320, 240, 7)):
+        s = S(w, h, n)
+        assert s % 64 == 0 and s * n >= w * h > (s - 64) * n
+    assert L.kfx_composite_strips_merge(None, None, 64, 0, 2, None) == -1                     # KFX_E_NULL
+    buf = C.create_string_buffer(4096)
+    assert L.kfx_composite_strips_merge(buf, buf, 64, 0, 0, None) == -4                       # KFX_E_RANGE: world
+    assert L.kfx_composite_strips_merge(buf, buf, 64, 100, 2, None) == -2                     # KFX_E_SHAPE: rank stride smaller than a strip
+    assert L.kfx_composite_strips_pack(None, None, None, buf, 0, 2, None) == -1
+    assert L.kfx_composite_strips_unpack(None, None, None, buf, 0, 2, None) == -1
+    assert L.kfx_slab_composite_direct(None, None, None, None, None, None) == -1
+    assert L.kfx_slab_composite_direct_scratch_bytes(640, 480, 8) == (2 * 8 + 1) * 5 * 38400 * 4

@@ -39,7 +39,7 @@ def _assert_images(r, w, h):
     assert r["miss_pixels_equal"], r
 
 
-FRAMES = 300
+FRAMES = int(os.environ.get("KFX_STREAM_FRAMES", "300"))   # (scripts/stream_parity_512.py runs longer streams at the benchmarked size)
 N_ORBIT = 30
 
 
@@ -138,7 +138,7 @@ def test_gpu_fast_stream_of_300_frames_vs_exact_oracle(roo, scene, N, w, h, trac
         od, on, oi = o["images"]
         img = _image_report(pipe.ray_d.MemcpyToHost(), pipe.ray_n.MemcpyToHost(), pipe.ray_i.MemcpyToHost(), od, on, oi)
         rep["images"] = img
-        _report("fast_stream_%s_%d_%s" % (scene, N, "tracked" if track else "plain"), rep)
+        _report("fast_stream_%s_%d_%s%s" % (scene, N, "tracked" if track else "plain", "" if FRAMES == 300 else "_%dframes" % FRAMES), rep)
 
         budget = max(8, int(FLIP_FRACTION * N ** 3 * FRAMES))
         assert rep["observed_by_oracle"] > 0.3 * N ** 3, rep
