@@ -72,8 +72,10 @@ def parse():
                     help="N > 1, composite raycast: direct = every rank owns a strip of the image: all-to-all of the strips, nearest hit per "
                          "pixel at the owner, all-gather of the merged strips (each byte crosses one xGMI link once per phase, all links at once); "
                          "allreduce = MIN all-reduce of (depth, rank) keys + SUM all-reduce of the winners' payload.  Same images")
-    ap.add_argument("--overlap", action="store_true",
-                    help="N > 1, composite raycast: merge frame k's images on a second stream under frame k+1's preprocess + SdfFuse")
+    ap.add_argument("--overlap", dest="overlap", action="store_true", default=None,
+                    help="N > 1, composite raycast: merge frame k's images on a second stream under frame k+1's preprocess + SdfFuse "
+                         "(default where nothing else communicates: composite raycast, ghost planes recomputed, inputs replicated)")
+    ap.add_argument("--no-overlap", dest="overlap", action="store_false", help="N > 1: merge each frame's images before the next frame starts")
     ap.add_argument("--summary", nargs="?", const="on", default="auto", choices=["auto", "on", "off"],
                     help="fast math, 1 GPU: the brick summary (kfx_sdf_summary: SdfFuse keeps value ranges per 8^3 cells, RaycastSdf "
                          "marches through class tables built from them and crosses free / never-observed space without reading the "
@@ -613,10 +615,14 @@ def run_slabs(args, torch, dist, roo, scenes, rank, world):
     N, w, h, scene = args.res, args.width, args.height, args.scene
     bmin, bmax, near, far = scenes.SCENES[scene]
     K = scenes.intrinsics(w, h)
-    if args.overlap and args.halo == "exchange":
-        sys.exit("bench.py: --overlap needs --halo recompute (collective ordering, kangaroo_amd/pipeline.py)")
+    # the overlapped merge issues its collectives from a second stream: allowed only where the main stream issues none (ghost planes
+    # recomputed, inputs replicated) -- two streams of collectives could interleave in rank-dependent order
+    can_overlap = args.raycast == "composite" and args.halo == "recompute" and args.inputs == "replicate"
+    if args.overlap and not can_overlap:
+        sys.exit("bench.py: --overlap needs --raycast composite, --halo recompute and --inputs replicate (collective ordering, kangaroo_amd/pipeline.py)")
+    overlap = can_overlap if args.overlap is None else bool(args.overlap)
     pipe = SlabPipeline(roo, dist, (N, N, N), bmin, bmax, w, h, halo=args.halo, raycast=args.raycast, K=K, near=near, far=far,
-                        overlap=args.overlap, inputs=args.inputs, images=args.images, merge=args.merge)
+                        overlap=overlap, inputs=args.inputs, images=args.images, merge=args.merge)
     poses = [scenes.orbit_pose(i, N_ORBIT) for i in range(N_ORBIT)]
     frames = []
     for T_wc in poses:
@@ -750,22 +756,19 @@ def run_slabs(args, torch, dist, roo, scenes, rank, world):
     try:   # reported extras must never cost the headline line (errors in collectives are symmetric across ranks)
         variants["as_configured_fps"] = timed_fps(n_var)
         pipe.wait_composite()
-        pipe.overlap = False   # the ghost-plane exchange never runs beside an overlapped merge (SlabPipeline.__init__)
+        pipe.overlap = False   # the ghost-plane exchange and the input broadcast never run beside an overlapped merge (SlabPipeline.__init__)
         pipe.halo = "exchange" if base_halo == "recompute" else "recompute"
         variants["halo_%s_fps" % pipe.halo] = timed_fps(n_var)
         pipe.halo = base_halo
-        pipe.overlap = base_overlap
-        if args.raycast == "composite":
-            pipe.wait_composite()
-            pipe.overlap = not base_overlap
-            variants["overlap_%s_fps" % ("on" if pipe.overlap else "off")] = timed_fps(n_var)
-            pipe.wait_composite()
-        pipe.overlap = base_overlap
         pipe.inputs = "broadcast" if base_inputs == "replicate" else "replicate"
         variants["inputs_%s_fps" % pipe.inputs] = timed_fps(n_var)
         pipe.inputs = base_inputs
         if args.raycast == "composite":
-            pipe.wait_composite()
+            if base_overlap or can_overlap:   # the merge overlapped / not overlapped with the next frame
+                pipe.overlap = not base_overlap
+                variants["overlap_%s_fps" % ("on" if pipe.overlap else "off")] = timed_fps(n_var)
+                pipe.wait_composite()
+            pipe.overlap = base_overlap
             pipe.images = "root" if base_images == "all" else "all"
             variants["images_%s_fps" % pipe.images] = timed_fps(n_var)
             pipe.wait_composite()
@@ -781,7 +784,7 @@ def run_slabs(args, torch, dist, roo, scenes, rank, world):
     if rank == 0:
         partition = "z-slabs x%d, inputs %s, ghost planes %s%s, raycast %s" % (
             world, "preprocessed by every rank" if args.inputs == "replicate" else "preprocessed by rank 0 and broadcast", args.halo,
-            ", merge overlapped with the next frame" if args.overlap else "",
+            ", merge overlapped with the next frame" if overlap else "",
             {"composite": ("composite = all_to_all(image strips to their owners) + nearest hit per pixel + %s(merged strips)" % ("gather-to-rank-0" if args.images == "root" else "all_gather")
                            if args.merge == "direct" else
                            "composite = all_reduce(MIN key) + %s(SUM payload)" % ("reduce-to-rank-0" if args.images == "root" else "all_reduce")),

@@ -393,9 +393,9 @@ class SlabPipeline(FramePipeline):
         # The overlapped merge issues its all-reduces from a side stream while the main stream may issue the ghost-plane
         # send / recv of the next SdfFuse: two NCCL call sequences whose relative order can differ between ranks (and torch may
         # route point-to-point through a communicator of its own) -- the classic collective-ordering deadlock.  Not allowed.
-        if self.overlap and halo == "exchange":
-            raise ValueError("SlabPipeline: overlap=True needs halo='recompute' (an overlapped merge next to the ghost-plane exchange "
-                             "would interleave collectives in rank-dependent order)")
+        if self.overlap and (halo == "exchange" or inputs == "broadcast"):
+            raise ValueError("SlabPipeline: overlap=True needs halo='recompute' and inputs='replicate' (an overlapped merge next to the "
+                             "ghost-plane exchange or the input broadcast would interleave collectives in rank-dependent order)")
         if kw.get("track"):
             raise ValueError("SlabPipeline: track=True (brick summary) is a single-volume feature; slabs march without it")
         self._side = self._merged = None
@@ -507,8 +507,8 @@ class SlabPipeline(FramePipeline):
         self.wait_composite()   # the previous frame's merge still reads these images
         self.ops.RaycastSdf(d, n, i, self.vol, T_wc, K, self.near, self.far, self.trunc, True)
         if self.world > 1:
-            if self.overlap and self.halo == "exchange":
-                raise RuntimeError("SlabPipeline: overlapped merge with halo='exchange' (see __init__)")
+            if self.overlap and (self.halo == "exchange" or self.inputs == "broadcast"):
+                raise RuntimeError("SlabPipeline: overlapped merge with halo='exchange' or inputs='broadcast' (see __init__)")
             if self.overlap and hasattr(self.ops, "CompositePack"):
                 import torch
                 if self._side is None:

@@ -57,8 +57,11 @@ def test_gpu_bench_two_ranks_smoke(raycast):
         assert r["planes_owned"] == 64 and r["voxels_stored"] == 128 * 128 * 66
         assert (r["composite_merge_ms"] is not None and r["composite_merge_ms"] > 0) == (raycast == "composite")
         assert (r["composite_merge_allreduce_ms"] is not None and r["composite_merge_allreduce_ms"] > 0) == (raycast == "composite")   # the other merge, by itself
-    if raycast == "composite":
-        assert "all_to_all" in d["config"]["partition"] and d["multi_gpu_variants"]["merge_allreduce_fps"] > 0
+    if raycast == "composite":   # the default: direct-send merge, overlapped with the next frame (nothing else communicates)
+        assert "all_to_all" in d["config"]["partition"] and "overlapped" in d["config"]["partition"]
+        assert d["multi_gpu_variants"]["merge_allreduce_fps"] > 0 and d["multi_gpu_variants"]["overlap_off_fps"] > 0
+    else:
+        assert "overlapped" not in d["config"]["partition"] and "overlap_on_fps" not in d["multi_gpu_variants"]
     assert d["kernels_ms"]["sdf_fuse"] == pr[0]["sdf_fuse_ms"]
 
 
@@ -68,12 +71,13 @@ def test_gpu_bench_spawns_its_own_ranks():
     import json
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     env["KFX_BENCH_BACKEND"] = "gloo"
-    cmd = [sys.executable, os.path.join(T.ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--res", "128", "--no-cpu-baseline", "--prime", "6"]
+    cmd = [sys.executable, os.path.join(T.ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--res", "128", "--no-cpu-baseline", "--prime", "6",
+           "--no-overlap"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=T.ROOT, env=env)
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert out.returncode == 0 and len(lines) == 1, out.stdout[-2000:] + out.stderr[-3000:]
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["config"]["ranks_agree"] is True
+    assert d["n_gpus"] == 2 and d["config"]["ranks_agree"] is True and "overlapped" not in d["config"]["partition"]
     v = d["multi_gpu_variants"]   # the other ghost-plane policy and the overlapped merge, timed in the same run
     assert v["as_configured_fps"] > 0 and v["halo_exchange_fps"] > 0 and v["overlap_on_fps"] > 0
 
@@ -93,7 +97,7 @@ def test_gpu_bench_overlapped_merge_two_ranks():
     assert d["multi_gpu_variants"]["halo_exchange_fps"] > 0 and d["multi_gpu_variants"]["overlap_off_fps"] > 0
     # the overlapped merge next to the ghost-plane exchange would interleave collectives in rank-dependent order: refused
     bad = subprocess.run(cmd + ["--halo", "exchange"], capture_output=True, text=True, timeout=300, cwd=T.ROOT, env=env)
-    assert bad.returncode != 0 and "--overlap needs --halo recompute" in bad.stderr + bad.stdout
+    assert bad.returncode != 0 and "--overlap needs" in bad.stderr + bad.stdout
 
 
 def test_gpu_bench_refuses_more_ranks_than_gpus():
