@@ -706,6 +706,64 @@ def test_gpu_direct_send_composite_kernels(roo, world, w, h):
     assert np.array_equal(np.where(np.isfinite(got[0]), got[0], np.inf), stack.min(axis=0))
 
 
+def test_gpu_fuzz_direct_send_composite_kernels(roo):
+    """Random image sizes (1 x 1 upwards), rank counts 1-9, pitched and dense images, depths with ties between ranks, NaN / inf
+    misses, -0 and denormal payloads: pack / merge / unpack against a numpy model of "nearest finite depth wins, the lowest
+    rank on ties" -- bit for bit (the direct merge moves values, it does not add them)."""
+    import torch
+    rng = np.random.default_rng(20261002)
+    for case in range(48):
+        w, h = int(rng.integers(1, 200)), int(rng.integers(1, 120))
+        world = int(rng.integers(1, 10))
+        dense = bool(rng.integers(0, 2))
+        ranks, host = [], []
+        pool = rng.uniform(0.4, 8.0, size=8).astype(np.float32)   # few distinct depths: many ties
+        for r in range(world):
+            d = rng.choice(pool, size=(h, w)).astype(np.float32) if case % 3 == 0 else rng.uniform(0.4, 8.0, size=(h, w)).astype(np.float32)
+            miss = rng.random((h, w)) < 0.4
+            d[miss] = rng.choice(np.array([np.nan, np.inf], np.float32), size=int(miss.sum()))
+            n = rng.standard_normal((h, w, 4)).astype(np.float32)
+            n[..., 3] = 1.0
+            n[rng.random((h, w)) < 0.05, 0] = -0.0
+            n[rng.random((h, w)) < 0.05, 1] = np.float32(1e-41)   # denormal
+            i = rng.random((h, w)).astype(np.float32)
+            rd = roo.Image(w, h, pitch=w * 4 if dense else None)
+            rn = roo.Image(w, h, "f32x4", pitch=w * 16 if dense else None)
+            ri = roo.Image(w, h, pitch=w * 4 if dense else None)
+            rd.MemcpyFromHost(d); rn.MemcpyFromHost(n); ri.MemcpyFromHost(i)
+            ranks.append((rd, rn, ri))
+            host.append((d, n, i))
+        S = roo.CompositeStripPixels(w, h, world)
+        send = [torch.full((world, roo.STRIP_PLANES, S), float("nan"), device="cuda") for _ in ranks]
+        for r, (rd, rn, ri) in enumerate(ranks):
+            roo.CompositeStripsPack(rd, rn, ri, send[r], world)
+        full = torch.empty((world, roo.STRIP_PLANES, S), device="cuda")
+        for j in range(world):
+            recv = torch.stack([send[r][j] for r in range(world)]).contiguous()
+            merged = torch.empty((roo.STRIP_PLANES, S), device="cuda")
+            roo.CompositeStripsMerge(recv, merged, S, world)
+            full[j] = merged
+        gd, gn, gi = ranks[0]   # unpack over rank 0's own images, as the pipeline does
+        roo.CompositeStripsUnpack(gd, gn, gi, full, world)
+        got_d, got_n, got_i = gd.MemcpyToHost(), gn.MemcpyToHost(), gi.MemcpyToHost()
+        # numpy model
+        depth = np.stack([np.where(np.isfinite(d), d, np.inf) for d, _, _ in host])
+        win = depth.argmin(axis=0)                     # first minimum = lowest rank on ties
+        best = depth.min(axis=0)
+        hit = np.isfinite(best)
+        want_d = np.where(hit, best, np.nan).astype(np.float32)
+        nn = np.stack([n for _, n, _ in host])
+        ii = np.stack([i for _, _, i in host])
+        yy, xx = np.meshgrid(np.arange(h), np.arange(w), indexing="ij")
+        want_n = np.where(hit[..., None], nn[win, yy, xx], 0).astype(np.float32)
+        want_n[..., 3] = hit.astype(np.float32)
+        want_i = np.where(hit, ii[win, yy, xx], 0).astype(np.float32)
+        tag = (case, w, h, world, dense)
+        assert np.array_equal(got_d.view(np.uint32)[hit], want_d.view(np.uint32)[hit]) and np.isnan(got_d[~hit]).all(), tag
+        assert np.array_equal(got_n.view(np.uint32), want_n.view(np.uint32)), tag
+        assert np.array_equal(got_i.view(np.uint32), want_i.view(np.uint32)), tag
+
+
 @pytest.mark.parametrize("world,ghost", [(2, 2), (4, 1), (5, 3)])
 def test_gpu_exact_slab_raycast_rounds(roo, world, ghost):
     """SURVEY 8(e) exact variant: `world` slabs of one volume marched in rounds with the state merge of
