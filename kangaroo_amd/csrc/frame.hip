@@ -159,22 +159,31 @@ extern "C" int kfx_frame_step(kfx_frame* f, const kfx_image* raw, const float T_
     }
     const hipStream_t s = (hipStream_t)stream;
     int e = 0;
-    if (m & 1u) (void)hipEventRecord(ev[0], s);
-    if (parts & KFX_FRAME_PREPROCESS) {
+    const auto record = [&](int k) {   // (a failed record leaves an event that timings() would wait on for ever: reported, the frame stops)
+        if (!(m & (1u << k))) return;
+        const hipError_t he = hipEventRecord(ev[k], s);
+        if (he != hipSuccess) {
+            (void)hipGetLastError();
+            f->ev_mask[(int)(f->frames % f->slots)] &= (unsigned char)~(1u << k);
+            if (!e) e = set_error((int)he, "kfx_frame_step: hipEventRecord");
+        }
+    };
+    record(0);
+    if (!e && (parts & KFX_FRAME_PREPROCESS)) {
         e = kfx_bilateral_f32(&c.filtered, src, c.bilateral_gs, c.bilateral_gr, c.bilateral_size, c.bilateral_minval, 1, stream);
         if (!e) e = kfx_depth_to_vbo_normals_f32(&c.vbo, &c.normals, &c.filtered, c.K, 1.0f, stream);
     }
-    if (m & 2u) (void)hipEventRecord(ev[1], s);
+    record(1);
     if (!e && (parts & KFX_FRAME_FUSE)) {
         if (f->track) e = kfx_sdf_fuse_tracked(&c.vol, f->summary, &c.filtered, &c.normals, T_cw, c.K, c.trunc_dist, c.max_w, c.mincostheta, c.fuse_flags, stream);
         else e = kfx_sdf_fuse(&c.vol, &c.filtered, &c.normals, T_cw, c.K, c.trunc_dist, c.max_w, c.mincostheta, c.fuse_flags, stream);
     }
-    if (m & 4u) (void)hipEventRecord(ev[2], s);
+    record(2);
     if (!e && (parts & KFX_FRAME_RAYCAST)) {
         if (f->track) e = kfx_raycast_sdf_tracked(&c.ray_depth, &c.ray_norm, &c.ray_img, &c.vol, f->summary, T_wc, c.K, c.near, c.far, c.trunc_dist, 1, stream);
         else e = kfx_raycast_sdf(&c.ray_depth, &c.ray_norm, &c.ray_img, &c.vol, T_wc, c.K, c.near, c.far, c.trunc_dist, 1, stream);
     }
-    if (m & 8u) (void)hipEventRecord(ev[3], s);
+    record(3);
     f->frames += 1;
     return e;
 }
