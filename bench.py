@@ -85,7 +85,7 @@ def parse():
                          "always; off: the plain kernels.  The line reports the other variant beside the headline")
     ap.add_argument("--prime", type=int, default=None,
                     help="1 GPU: at least this many untimed frames of the stream before the W warm-up steps (default 0: --prime-seconds decides); "
-                         "N > 1: exactly this many (default 450)")
+                         "N > 1: exactly this many (default: --prime-seconds of frames at the pace of a first block, at least 450)")
     ap.add_argument("--prime-seconds", type=float, default=2.0,
                     help="untimed frames run until the frame time is stationary AND at least this much GPU time has passed: a GPU "
                          "that was idle takes on the order of a second of work to settle its clocks (KFX_BENCH_DUMP=1 prints the blocks)")
@@ -647,9 +647,25 @@ def run_slabs(args, torch, dist, roo, scenes, rank, world):
             e.record()
     gc.collect()
     gc.disable()
-    n_prime = 450 if args.prime is None else max(args.prime, 0)
-    for i in range(n_prime):
-        pipe.step(poses[i % N_ORBIT], frames[i % N_ORBIT])
+    # untimed frames: --prime says exactly how many; otherwise as many as make --prime-seconds of work at the pace of a first
+    # block (at least 450): at 8 ranks a frame is a fraction of a 1-GPU frame and 450 of them would be over before the clocks of a
+    # GPU that was idle have settled.  The count is agreed between the ranks (every frame has collectives).
+    if args.prime is not None:
+        n_prime = max(args.prime, 0)
+        for i in range(n_prime):
+            pipe.step(poses[i % N_ORBIT], frames[i % N_ORBIT])
+    else:
+        sync_all()
+        t_b = time.perf_counter()
+        for i in range(BLOCK):
+            pipe.step(poses[i % N_ORBIT], frames[i % N_ORBIT])
+        sync_all()
+        tb = torch.tensor([time.perf_counter() - t_b], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tb, op=dist.ReduceOp.MAX)
+        per_frame = max(float(tb.item()) / BLOCK, 1e-6)
+        n_prime = BLOCK + max(450 - BLOCK, min(int(args.prime_seconds / per_frame), 60000))
+        for i in range(BLOCK, n_prime):
+            pipe.step(poses[i % N_ORBIT], frames[i % N_ORBIT])
     for i in range(args.warmup):
         pipe.step(poses[i % N_ORBIT], frames[i % N_ORBIT])
     sync_all()
