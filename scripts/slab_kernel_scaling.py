@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Per-rank kernel time of the Z-slab pipeline for world = 1, 2, 4, 8 at 512^3 / 640x480, measured on ONE GPU by running
 each rank's slab work in turn (SdfFuse of its planes + ghosts through kfx_sdf_fuse_slab, RaycastSdf of its slab, the
-composite pack / select / unpack kernels).  No collectives are included: this is the compute side of the strong-scaling
+kernels of the composite merge: strips pack / merge / unpack of the direct-send merge, and pack / select / unpack of the all-reduce
+merge).  No collectives are included: this is the compute side of the strong-scaling
 curve the 8-GPU driver run measures (max over ranks = the slowest rank's kernels).  Usage: python scripts/slab_kernel_scaling.py"""
 import os
 import sys
@@ -54,16 +55,25 @@ for world in (1, 2, 4, 8):
         fuse = lambda: roo.SdfFuse(v, f, nrm, T_cw, K, tr, scenes.MAX_W, scenes.MIN_COS_THETA, full_extent=True, slab=(N, s0, bmin[2], bmax[2]))
         ray = lambda: roo.RaycastSdf(rd, rn, ri, v, T_wc, K, near, far, tr, True)
 
-        def comp():
+        def comp_allreduce():
             roo.CompositePack(rd, rn, ri, key, r)
             roo.CompositeSelect(rd, rn, ri, key, payload, r)
             roo.CompositeUnpack(rd, rn, ri, key, payload)
+        S = roo.CompositeStripPixels(w, h, world)
+        send = torch.zeros((world, roo.STRIP_PLANES, S), device="cuda")
+        recv = torch.zeros((world, roo.STRIP_PLANES, S), device="cuda")
+        merged = torch.zeros((roo.STRIP_PLANES, S), device="cuda")
+
+        def comp():
+            roo.CompositeStripsPack(rd, rn, ri, send, world)
+            roo.CompositeStripsMerge(recv, merged, S, world)
+            roo.CompositeStripsUnpack(rd, rn, ri, recv, world)
         for _ in range(2):
             fuse()
-        per_rank.append((timed(fuse), timed(ray), timed(comp) if world > 1 else 0.0))
+        per_rank.append((timed(fuse), timed(ray), timed(comp) if world > 1 else 0.0, timed(comp_allreduce) if world > 1 else 0.0))
         del v
         torch.cuda.empty_cache()
-    tot = [a + b + c for a, b, c in per_rank]
+    tot = [a + b + c for a, b, c, _ in per_rank]
     worst = int(np.argmax(tot))
-    print("world %d: slowest rank %d: fuse %.3f + raycast %.3f + composite kernels %.3f = %.3f ms  (preprocess 0.03 ms and the two "
-          "all-reduces of 2.4 MB / 6.1 MB come on top); mean over ranks %.3f ms" % (world, worst, *per_rank[worst], tot[worst], float(np.mean(tot))), flush=True)
+    print("world %d: slowest rank %d: fuse %.3f + raycast %.3f + merge kernels %.3f (all-reduce merge's: %.3f) = %.3f ms  (preprocess 0.03 ms and the "
+          "merge's two collectives come on top); mean over ranks %.3f ms" % (world, worst, *per_rank[worst], tot[worst], float(np.mean(tot))), flush=True)
