@@ -9,7 +9,10 @@ resident in HBM: BilateralFilter -> DepthToVbo -> NormalsFromVbo -> SdfFuse -> R
 (BASELINE.json configs[1]: 512^3 TSDF SdfFuse + RaycastSdf, 640x480, 1x MI355X; the cheap
 preprocess chain is included so that a step is a whole frame).  Frames follow a 30-pose orbit
 with known poses (no ICP).  N > 1: the 512^3 volume is Z-slab partitioned over
-the ranks (strong scaling), see kangaroo_amd/pipeline.py.
+the ranks (strong scaling), see kangaroo_amd/pipeline.py: every rank integrates and renders its slab, the renderings are merged by
+direct sends over the xGMI mesh (image strips to their owners by all-to-all, nearest hit per pixel, strips back by all-gather),
+the merge of frame k overlapped with frame k+1 where it is the only traffic; the line also times the other policies
+(`multi_gpu_variants`) and every rank's parts (`per_rank`).
 
 1 GPU: every frame is ONE library call (kfx_frame_step, include/kfx.h) that enqueues the frame's launches and records
 device events around its parts, so neither the launch rate nor the kernel times depend on the interpreter.  Before the W
