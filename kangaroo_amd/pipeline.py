@@ -457,19 +457,25 @@ class SlabPipeline(FramePipeline):
     def _p2p(self, ops):
         """One batched group of point-to-point operations, complete on return as far as the current stream is concerned.
         RCCL (backend "nccl") is stream-ordered: the requests' wait() chains the current stream behind the transfers.  gloo
-        with device tensors -- ranks sharing one GPU in the tests -- stages through the host without regard to the stream
-        that produces / consumes the tensors, so the device is synchronised on both sides of the batch."""
+        with device tensors -- ranks sharing one GPU in the tests -- goes through host copies made here, with the device
+        synchronised on both sides of the batch."""
         if not ops:
             return
         dist = self.dist
-        dev = ops[0].tensor.is_cuda and dist.get_backend() != "nccl"
-        if dev:
+        if ops[0].tensor.is_cuda and dist.get_backend() != "nccl":
+            # gloo's own path for device tensors takes ~0.1 s per message: stage through host copies here (test transport only)
             import torch
             torch.cuda.synchronize()
+            host = [(op, op.tensor.cpu() if op.op is dist.isend else torch.empty(op.tensor.shape, dtype=op.tensor.dtype)) for op in ops]
+            for req in dist.batch_isend_irecv([dist.P2POp(op.op, t, op.peer) for op, t in host]):
+                req.wait()
+            for op, t in host:
+                if op.op is not dist.isend:
+                    op.tensor.copy_(t)
+            torch.cuda.synchronize()
+            return
         for req in dist.batch_isend_irecv(ops):
             req.wait()
-        if dev:
-            torch.cuda.synchronize()
 
     def exchange_halos(self):
         """Refresh the ghost planes from the neighbours' owned planes (contiguous img_pitch-sized
