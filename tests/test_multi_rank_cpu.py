@@ -208,7 +208,7 @@ def test_tracked_kinectfusion_on_slabs(tmp_path, raycast):
         assert np.abs(ranks[0]["poses"][:, :3, 3] - want[:, :3, 3]).max() < 5e-4
 
 
-@pytest.mark.parametrize("world,images", [(2, "all"), (3, "all"), (3, "root")])
+@pytest.mark.parametrize("world,images", [(2, "all"), (3, "all"), (3, "root"), (8, "all")])
 def test_direct_send_merge_equals_the_all_reduce_merge(tmp_path, world, images):
     """merge="direct" (strips to their owners by all-to-all, nearest hit per pixel, strips back by all-gather / gather) against
     merge="allreduce" (MIN of keys + SUM of payloads): the same winner per pixel, so the same images (a -0 component of a winning
