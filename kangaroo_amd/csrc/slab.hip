@@ -257,7 +257,7 @@ static int threads_mesh(kfx_comm* c, const void* send, void* recv, size_t bytes,
     if (!st) st = hip_status(hipStreamSynchronize((hipStream_t)stream), "kfx_comm(threads) all_to_all / all_gather"); // this rank's producers are done
     const int par = (int)(g->seq[r]++ & 1u);
     g->err[par][r].store(st);
-    g->send_lo[r] = send; g->bytes_lo[r] = bytes;
+    g->send_lo[r] = send; g->bytes_lo[r] = bytes;   // (the exchange's slots: one collective at a time uses the group)
     g->wait_all();
     hipStream_t s = (hipStream_t)stream;
     for (int k = 0; k < g->world && !st && bytes; ++k) {
