@@ -64,10 +64,11 @@ int kfx_comm_create_threads(kfx_comm* comms, int world);
 
 /* RCCL transport (libkfx_rccl.so).  rank 0 removes any existing `rendezvous_file` and writes the ncclUniqueId there (exclusive
  * temporary + rename, mode 0600, no symlinks followed) behind a launch nonce folded from KFX_RUN_ID / TORCHELASTIC_RUN_ID /
- * MASTER_PORT / SLURM_JOB_ID; the other ranks wait (at most timeout_s seconds) for a regular file of this user that carries
- * their nonce and is not older than their own process, so a file left by a crashed run is never taken for this run's.  Use a
- * path that is unique per launch where possible.  The caller has selected its device (hipSetDevice) beforehand.  Returns 0,
- * KFX_E_*, or 1000 + ncclResult_t. */
+ * MASTER_PORT / SLURM_JOB_ID and from the ranks' PARENT process (pid + start time: the launcher; KFX_RDV_PARENT=0 leaves it out
+ * for ranks started by hand from different shells -- give those a KFX_RUN_ID that is unique per launch); the other ranks wait (at
+ * most timeout_s seconds) for a regular file of this user that carries their nonce and does not precede their own process by
+ * more than the launch skew (10 s; KFX_RDV_SLACK_S), so a file left by a crashed run is never taken for this run's.  The caller
+ * has selected its device (hipSetDevice) beforehand.  Returns 0, KFX_E_*, or 1000 + ncclResult_t. */
 int kfx_comm_create_rccl(kfx_comm* comm, int rank, int world, const char* rendezvous_file, int timeout_s);
 
 /* ---- slab layout --------------------------------------------------------------------------------------------- */

@@ -2,9 +2,13 @@
 // neighbour send / recv over xGMI.  Built into libkfx_rccl.so so that libkfx.so itself does not depend on librccl.
 // The ncclUniqueId travels through a file: rank 0 removes whatever is there, creates the file atomically (exclusive
 // temporary + rename) with a launch nonce in front of the id, the others wait for a file that is a regular file of this user,
-// carries their nonce and was not written long before their own process began (RDV_SLACK_S: the ranks of one launch start
-// within minutes of each other, and rank 0 may well publish before a slow rank has finished importing and initialising its
-// GPU) -- a file left behind by a crashed run is never accepted.
+// carries their nonce and was not written before their own process began, give or take the launch skew between ranks
+// (rdv_slack_s(): 10 s, KFX_RDV_SLACK_S overrides; process_start() is the real start of the process, so a rank that spends a
+// minute importing still accepts the file rank 0 published meanwhile).  The nonce folds in the PARENT process (pid + its start
+// time) beside the launcher's environment: the ranks of one launch are children of one launcher, a relaunch has another -- a
+// file left behind by a crashed run with the same MASTER_PORT is refused whatever its age (round-4 advice: torchrun's default
+// port made the environment part static across relaunches).  KFX_RDV_PARENT=0 leaves the parent out (ranks started by hand from
+// different shells: give them a KFX_RUN_ID that is unique per launch instead).
 #include <chrono>
 #include <cstdint>
 #include <cstdlib>
@@ -115,17 +119,53 @@ void rccl_destroy(kfx_comm* c)
     c->impl = nullptr;
 }
 
-// What a launcher gives every rank of one launch and no rank of another: folded into 64 bits (0 when nothing is set)
+// Field 22 of /proc/<pid>/stat: the start time of a process in clock ticks since boot (-1: unreadable).  The command name in
+// field 2 may contain spaces and parentheses, so the fields are counted from the LAST ')'.
+long long start_ticks(const char* stat_path)
+{
+    long long ticks = -1;
+    if (FILE* f = fopen(stat_path, "r")) {
+        char buf[2048];
+        const size_t n = fread(buf, 1, sizeof(buf) - 1, f);
+        fclose(f);
+        buf[n] = 0;
+        if (const char* p = strrchr(buf, ')')) {
+            int field = 2;   // p is at the end of field 2; field 3 (the state) follows
+            ++p;
+            while (*p) {
+                while (*p == ' ') ++p;
+                if (!*p) break;
+                if (++field == 22) { ticks = atoll(p); break; }
+                while (*p && *p != ' ') ++p;
+            }
+        }
+    }
+    return ticks;
+}
+
+// What every rank of one launch has and no rank of another: the launcher's environment values and the launcher itself (parent
+// pid + the parent's start time), folded into 64 bits.
 uint64_t launch_nonce()
 {
     uint64_t h = 1469598103934665603ull;
+    const auto fold = [&](const char* v) {
+        for (const char* c = v; *c; ++c) h = (h ^ (unsigned char)*c) * 1099511628211ull;
+        h = (h ^ 0xffu) * 1099511628211ull;
+    };
     bool any = false;
     for (const char* name : {"KFX_RUN_ID", "TORCHELASTIC_RUN_ID", "MASTER_PORT", "SLURM_JOB_ID", "SLURM_STEP_ID"}) {
         const char* v = getenv(name);
         if (!v || !*v) continue;
         any = true;
-        for (const char* c = v; *c; ++c) h = (h ^ (unsigned char)*c) * 1099511628211ull;
-        h = (h ^ 0xffu) * 1099511628211ull;
+        fold(v);
+    }
+    const char* par = getenv("KFX_RDV_PARENT");
+    if (!par || atoi(par) != 0) {
+        const long long ppid = (long long)getppid();
+        const std::string path = "/proc/" + std::to_string(ppid) + "/stat";
+        const std::string id = "ppid:" + std::to_string(ppid) + ":" + std::to_string(start_ticks(path.c_str()));
+        any = true;
+        fold(id.c_str());
     }
     return any ? (h | 1ull) : 0ull;
 }
@@ -143,23 +183,8 @@ const char RDV_MAGIC[8] = {'K', 'F', 'X', 'R', 'D', 'V', '1', 0};
 // for a rank that spends seconds importing before it gets here is seconds late -- round-3 advice.)  "now" where procfs is missing.
 time_t process_start()
 {
-    long long ticks = -1, btime = -1;
-    if (FILE* f = fopen("/proc/self/stat", "r")) {
-        char buf[2048];
-        const size_t n = fread(buf, 1, sizeof(buf) - 1, f);
-        fclose(f);
-        buf[n] = 0;
-        if (const char* p = strrchr(buf, ')')) {
-            int field = 2;   // p is at the end of field 2; field 3 (the state) follows
-            ++p;
-            while (*p) {
-                while (*p == ' ') ++p;
-                if (!*p) break;
-                if (++field == 22) { ticks = atoll(p); break; }
-                while (*p && *p != ' ') ++p;
-            }
-        }
-    }
+    long long btime = -1;
+    const long long ticks = start_ticks("/proc/self/stat");
     if (FILE* f = fopen("/proc/stat", "r")) {
         char line[256];
         while (fgets(line, sizeof(line), f))
@@ -170,7 +195,18 @@ time_t process_start()
     if (ticks >= 0 && btime > 0 && hz > 0) return (time_t)(btime + ticks / hz);
     return time(nullptr);
 }
-const time_t RDV_SLACK_S = 120;   // a rendezvous file may precede this process by this much and still belong to its launch
+// A rendezvous file may precede this process by this much and still belong to its launch: the skew between the starts of the
+// ranks of one launch (a launcher forks them within milliseconds; a shell loop within seconds), NOT the time a rank takes to get
+// here -- process_start() is the real start.  10 s; KFX_RDV_SLACK_S overrides (0 ... 3600).
+time_t rdv_slack_s()
+{
+    static const time_t slack = [] {
+        const char* e = getenv("KFX_RDV_SLACK_S");
+        const long v = e && *e ? atol(e) : 10;
+        return (time_t)(v < 0 ? 0 : (v > 3600 ? 3600 : v));
+    }();
+    return slack;
+}
 
 int write_rendezvous(const char* path, const Rendezvous& rv)
 {
@@ -195,7 +231,7 @@ int read_rendezvous(const char* path, Rendezvous& rv, uint64_t nonce, time_t not
     if (fd < 0) return 0;
     struct stat st;
     bool ok = fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_uid == geteuid() && st.st_size == (off_t)sizeof(rv) &&
-              st.st_mtime + RDV_SLACK_S >= not_before;
+              st.st_mtime + rdv_slack_s() >= not_before;
     ok = ok && read(fd, &rv, sizeof(rv)) == (ssize_t)sizeof(rv) && memcmp(rv.magic, RDV_MAGIC, 8) == 0 && rv.nonce == nonce;
     close(fd);
     return ok ? 1 : 0;
@@ -212,6 +248,7 @@ extern "C" int kfx_rccl_rendezvous_probe(const char* path)
     return read_rendezvous(path, rv, launch_nonce(), process_start());
 }
 extern "C" long long kfx_rccl_process_start(void) { return (long long)process_start(); }
+extern "C" unsigned long long kfx_rccl_launch_nonce(void) { return (unsigned long long)launch_nonce(); }
 
 extern "C" int kfx_comm_create_rccl(kfx_comm* comm, int rank, int world, const char* rendezvous_file, int timeout_s)
 {

@@ -169,12 +169,7 @@ def test_product_never_imports_the_oracle():
             assert not re.search(r'#\s*include\s*[<"][^>"]*oracle', open(p).read())
 
 
-def test_rccl_rendezvous_rejects_stale_foreign_and_linked_files(tmp_path, monkeypatch):
-    """kfx_comm_create_rccl, ranks > 0 (comm_rccl.cpp): a rendezvous file left by an earlier run (older than this process), one
-    written for another launch (different nonce) and a symlink are all ignored -- the call times out with KFX_E_RANGE instead
-    of handing a foreign ncclUniqueId to ncclCommInitRank (which would hang).  Host-only: no GPU, no RCCL call is reached."""
-    import struct
-    import time
+def _rccl_lib():
     lib = os.path.join(os.path.dirname(_lib.LIB_PATH), "libkfx_rccl.so")
     try:
         R = C.CDLL(lib)
@@ -182,35 +177,64 @@ def test_rccl_rendezvous_rejects_stale_foreign_and_linked_files(tmp_path, monkey
         import pytest
         pytest.skip("libkfx_rccl.so not loadable here: %r" % (e,))
     R.kfx_comm_create_rccl.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.c_int]
+    R.kfx_rccl_launch_nonce.restype = C.c_ulonglong
+    R.kfx_rccl_process_start.restype = C.c_longlong
+    return lib, R
+
+
+_RDV_ENV = ("TORCHELASTIC_RUN_ID", "MASTER_PORT", "SLURM_JOB_ID", "SLURM_STEP_ID", "KFX_RDV_SLACK_S", "KFX_RDV_PARENT")
+
+
+def _rdv_payload(nonce):
+    import struct
+    return b"KFXRDV1\0" + struct.pack("<Q", nonce) + bytes(128)
+
+
+def test_rccl_rendezvous_rejects_stale_foreign_and_linked_files(tmp_path, monkeypatch):
+    """kfx_comm_create_rccl, ranks > 0 (comm_rccl.cpp): a rendezvous file left by an earlier run (older than this process), one
+    written for another launch (different nonce) and a symlink are all ignored -- the call times out with KFX_E_RANGE instead
+    of handing a foreign ncclUniqueId to ncclCommInitRank (which would hang).  Host-only: no GPU, no RCCL call is reached."""
+    import time
+    lib, R = _rccl_lib()
     comm = C.create_string_buffer(256)
     monkeypatch.setenv("KFX_RUN_ID", "this-launch")
-    for k in ("TORCHELASTIC_RUN_ID", "MASTER_PORT", "SLURM_JOB_ID", "SLURM_STEP_ID"):
+    for k in _RDV_ENV:
         monkeypatch.delenv(k, raising=False)
-
-    def nonce(run_id):   # launch_nonce() of comm_rccl.cpp: FNV-1a over the values present, a 0xff separator after each
-        h = 1469598103934665603
-        for ch in run_id.encode():
-            h = ((h ^ ch) * 1099511628211) & (2 ** 64 - 1)
-        h = ((h ^ 0xff) * 1099511628211) & (2 ** 64 - 1)
-        return h | 1
-
-    def payload(run_id):
-        return b"KFXRDV1\0" + struct.pack("<Q", nonce(run_id)) + bytes(128)
+    mine = R.kfx_rccl_launch_nonce()   # the environment's values + this process's parent (the launcher of a real run)
+    monkeypatch.setenv("KFX_RUN_ID", "another-launch")
+    other = R.kfx_rccl_launch_nonce()
+    monkeypatch.setenv("KFX_RUN_ID", "this-launch")
+    assert mine != other and mine & 1 and R.kfx_rccl_launch_nonce() == mine
 
     path = tmp_path / "id"
+    # (0) control: fresh, right nonce -> accepted
+    path.write_bytes(_rdv_payload(mine))
+    assert R.kfx_rccl_rendezvous_probe(str(path).encode()) == 1
     # (1) right nonce, but older than this process
-    path.write_bytes(payload("this-launch"))
     os.utime(path, (time.time() - 3600, time.time() - 3600))
     assert R.kfx_comm_create_rccl(comm, 1, 2, str(path).encode(), 1) == -4   # KFX_E_RANGE: timed out
     # (2) fresh, but another launch's nonce
-    path.write_bytes(payload("another-launch"))
+    path.write_bytes(_rdv_payload(other))
     assert R.kfx_comm_create_rccl(comm, 1, 2, str(path).encode(), 1) == -4
     # (3) a symlink to a fresh, well-formed file
     real = tmp_path / "real"
-    real.write_bytes(payload("this-launch"))
+    real.write_bytes(_rdv_payload(mine))
     path.unlink()
     path.symlink_to(real)
     assert R.kfx_comm_create_rccl(comm, 1, 2, str(path).encode(), 1) == -4
+
+
+def _probe_child(lib, path, env, sleep_s=0.0):
+    """A fresh process (a `rank 1`) that looks at the rendezvous file `sleep_s` seconds after it began:
+    (accepted?, its nonce, its process start, the time of the probe)."""
+    import sys
+    code = ("import ctypes, time, sys\n"
+            "time.sleep(%r)\n"
+            "R = ctypes.CDLL(%r)\n"
+            "R.kfx_rccl_process_start.restype = ctypes.c_longlong\n"
+            "R.kfx_rccl_launch_nonce.restype = ctypes.c_ulonglong\n"
+            "print(R.kfx_rccl_rendezvous_probe(%r.encode()), R.kfx_rccl_launch_nonce(), R.kfx_rccl_process_start(), time.time())\n") % (sleep_s, lib, str(path))
+    return subprocess.Popen([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
 
 
 def test_rccl_rendezvous_accepts_a_rank_that_arrives_seconds_later(tmp_path):
@@ -219,42 +243,63 @@ def test_rccl_rendezvous_accepts_a_rank_that_arrives_seconds_later(tmp_path):
     st_mtime of /proc/self, which procfs stamps at the first lookup, i.e. when the late rank arrives: it rejected the valid file
     until the timeout.)  Host-only through the library's probe hook: a fresh process whose first look at procfs comes after the
     sleep; a file from long before the process began is still refused."""
-    import struct
-    import sys
     import time
-    lib = os.path.join(os.path.dirname(_lib.LIB_PATH), "libkfx_rccl.so")
-    try:
-        C.CDLL(lib)
-    except OSError as e:
-        import pytest
-        pytest.skip("libkfx_rccl.so not loadable here: %r" % (e,))
-
-    def nonce(run_id):
-        h = 1469598103934665603
-        for ch in run_id.encode():
-            h = ((h ^ ch) * 1099511628211) & (2 ** 64 - 1)
-        h = ((h ^ 0xff) * 1099511628211) & (2 ** 64 - 1)
-        return h | 1
-
+    lib, R = _rccl_lib()
     path = tmp_path / "id"
-    code = ("import ctypes, time, sys\n"
-            "time.sleep(5.0)\n"                                  # rank 1 is busy importing / initialising its GPU
-            "R = ctypes.CDLL(%r)\n"
-            "R.kfx_rccl_process_start.restype = ctypes.c_longlong\n"
-            "print(R.kfx_rccl_rendezvous_probe(%r.encode()), R.kfx_rccl_process_start(), time.time())\n") % (lib, str(path))
-    env = {k: v for k, v in os.environ.items() if k not in ("TORCHELASTIC_RUN_ID", "MASTER_PORT", "SLURM_JOB_ID", "SLURM_STEP_ID")}
+    env = {k: v for k, v in os.environ.items() if k not in _RDV_ENV}
     env["KFX_RUN_ID"] = "late-rank"
+    # the nonce of this launch's ranks = children of THIS process: ask one
+    first = _probe_child(lib, path, env)
+    nonce = int(first.communicate(timeout=60)[0].split()[1])
     t_launch = time.time()
-    proc = subprocess.Popen([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, text=True)
-    path.write_bytes(b"KFXRDV1\0" + struct.pack("<Q", nonce("late-rank")) + bytes(128))   # rank 0 publishes right after the launch
+    proc = _probe_child(lib, path, env, sleep_s=5.0)    # rank 1 is busy importing / initialising its GPU
+    path.write_bytes(_rdv_payload(nonce))               # rank 0 publishes right after the launch
     out = proc.communicate(timeout=60)[0].split()
     assert proc.returncode == 0 and int(out[0]) == 1, out
-    assert abs(int(out[1]) - t_launch) <= 2, "process start from /proc/self/stat: %s vs %.1f" % (out[1], t_launch)
-    assert float(out[2]) - int(out[1]) >= 4.5           # it did arrive five seconds after it began
+    assert abs(int(out[2]) - t_launch) <= 2, "process start from /proc/self/stat: %s vs %.1f" % (out[2], t_launch)
+    assert float(out[3]) - int(out[2]) >= 4.5           # it did arrive five seconds after it began
     # ... and a file from an earlier run (an hour before this process began) is still refused
     os.utime(path, (time.time() - 3600, time.time() - 3600))
-    probe = subprocess.run([sys.executable, "-c", code.replace("time.sleep(5.0)", "pass")], env=env, capture_output=True, text=True, timeout=60)
-    assert probe.returncode == 0 and int(probe.stdout.split()[0]) == 0, probe.stdout + probe.stderr
+    probe = _probe_child(lib, path, env)
+    so, se = probe.communicate(timeout=60)
+    assert probe.returncode == 0 and int(so.split()[0]) == 0, so + se
+
+
+def test_rccl_rendezvous_refuses_the_file_of_a_crashed_run_of_the_same_port(tmp_path):
+    """Round-4 advice: torchrun's default MASTER_PORT makes the environment part of the nonce static across relaunches, and a
+    run that crashed inside ncclCommInitRank leaves its file behind.  (a) With the environment's nonce alone (KFX_RDV_PARENT=0) a
+    file 30 s older than the new rank is outside the launch skew (10 s) and refused, one 3 s older is accepted, and KFX_RDV_SLACK_S
+    moves the limit.  (b) By default the nonce also carries the launcher (the ranks' parent process): the same environment under
+    another parent gives another nonce, so the crashed run's file is refused whatever its age."""
+    import sys
+    import time
+    lib, R = _rccl_lib()
+    path = tmp_path / "id"
+    env = {k: v for k, v in os.environ.items() if k not in _RDV_ENV and k != "KFX_RUN_ID"}
+    env["MASTER_PORT"] = "29500"
+    # (a) environment-only nonce: the age test is what protects
+    env_a = dict(env, KFX_RDV_PARENT="0")
+    nonce_a = int(_probe_child(lib, path, env_a).communicate(timeout=60)[0].split()[1])
+    path.write_bytes(_rdv_payload(nonce_a))
+    for age, slack, want in ((30, None, 0), (60, None, 0), (3, None, 1), (30, "120", 1), (3, "0", 0)):
+        os.utime(path, (time.time() - age, time.time() - age))
+        e = dict(env_a) if slack is None else dict(env_a, KFX_RDV_SLACK_S=slack)
+        so, se = _probe_child(lib, path, e).communicate(timeout=60)
+        assert int(so.split()[0]) == want, (age, slack, so, se)
+    # (b) default: a relaunch has another launcher -> another nonce, even for a fresh file
+    nonce_here = int(_probe_child(lib, path, env).communicate(timeout=60)[0].split()[1])
+    via = ("import subprocess, sys\n"
+           "sys.exit(subprocess.call([sys.executable, '-c', sys.argv[1]]))\n")
+    inner = ("import ctypes\n"
+             "R = ctypes.CDLL(%r)\n"
+             "R.kfx_rccl_launch_nonce.restype = ctypes.c_ulonglong\n"
+             "print(R.kfx_rccl_rendezvous_probe(%r.encode()), R.kfx_rccl_launch_nonce())\n") % (lib, str(path))
+    path.write_bytes(_rdv_payload(nonce_here))   # the file of the run whose launcher is THIS process, fresh
+    assert int(_probe_child(lib, path, env).communicate(timeout=60)[0].split()[0]) == 1
+    out = subprocess.run([sys.executable, "-c", via, inner], env=env, capture_output=True, text=True, timeout=60)
+    got = out.stdout.split()
+    assert out.returncode == 0 and int(got[0]) == 0 and int(got[1]) != nonce_here, out.stdout + out.stderr
+    assert nonce_a != nonce_here
 
 
 def test_frame_object_validates_its_views_without_a_gpu():
