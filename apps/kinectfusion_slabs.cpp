@@ -30,6 +30,9 @@ using namespace roo;
 struct Options {
     int volres = 256, frames = 10, w = 640, h = 480, ranks = 1;
     bool fast = false, rccl = false, broadcast_inputs = false;
+    bool frame_driver = false;   // --driver frame: one kfx_slab_frame_step call per frame instead of the roo:: calls
+    bool overlap = false;        // --overlap (frame driver, composite): the merge of frame k under frame k + 1
+    int tiles = 0;               // --tiles T: exact hand-over pipelined over T image row-tiles (0: whole-image stages; the frame driver's default: 4)
     SlabVolume::HaloMode halo = SlabVolume::HaloExchange;
     SlabVolume::RaycastMode raycast = SlabVolume::Composite;
     SlabVolume::MergeMode merge = SlabVolume::MergeDirect;
@@ -98,10 +101,34 @@ static void RunRank(const Options& o, kfx_comm* comm, const std::vector<std::vec
     Image<float4, TargetDevice, Manage> dVbo(w, h), dNormals(w, h), ray_n(w, h);
     SlabVolume slab(o.volres, o.volres, o.volres, bb, comm, o.halo, o.raycast);
     slab.merge = o.merge;
+    slab.tiles = o.tiles;
     // the whole volume's voxel size (the local view has the same spacing in x / y; z spacing is the full volume's)
     const float3 vs = make_float3(2.0f / (o.volres - 1), 2.0f / (o.volres - 1), 2.0f / (o.volres - 1));
     const float trunc_dist = 2.0f * length(vs);
     SdfReset(slab.local, std::numeric_limits<float>::quiet_NaN());
+
+    // --driver frame: the same frame as ONE library call per rank (kfx_slab_frame, include/kfx_slab.h)
+    kfx_slab_frame* kframe = nullptr;
+    if (o.frame_driver) {
+        if (o.raycast == SlabVolume::ExactAllReduce) { fprintf(stderr, "--driver frame: --raycast exact or composite\n"); exit(2); }
+        kfx_slab_frame_config fc;
+        memset(&fc, 0, sizeof(fc));
+        fc.local = *slab.local.abi();
+        fc.layout = slab.layout;
+        fc.raw = *dMeters.abi(); fc.filtered = *dFiltered.abi(); fc.vbo = *dVbo.abi(); fc.normals = *dNormals.abi();
+        fc.ray_depth = *ray_d.abi(); fc.ray_norm = *ray_n.abi(); fc.ray_img = *ray_i.abi();
+        fc.K[0] = K.fu; fc.K[1] = K.fv; fc.K[2] = K.u0; fc.K[3] = K.v0;
+        fc.bilateral_gs = bigs; fc.bilateral_gr = bigr; fc.bilateral_minval = 0.2f; fc.bilateral_size = biwin;
+        fc.near = knear; fc.far = kfar; fc.trunc_dist = trunc_dist; fc.max_w = max_w; fc.mincostheta = mincostheta;
+        fc.halo = o.halo == SlabVolume::HaloExchange ? KFX_SLAB_HALO_EXCHANGE : KFX_SLAB_HALO_RECOMPUTE;
+        fc.raycast = o.raycast == SlabVolume::Exact ? KFX_SLAB_RAYCAST_EXACT : KFX_SLAB_RAYCAST_COMPOSITE;
+        fc.merge = o.merge == SlabVolume::MergeDirect ? KFX_SLAB_MERGE_DIRECT : KFX_SLAB_MERGE_ALLREDUCE;
+        fc.inputs = o.broadcast_inputs ? KFX_SLAB_INPUTS_BROADCAST : KFX_SLAB_INPUTS_REPLICATE;
+        fc.overlap = o.overlap ? 1 : 0;
+        fc.tiles = o.tiles;
+        fc.timing_slots = 16;
+        GpuCheckStatus(kfx_slab_frame_create(&kframe, &fc, comm));
+    }
 
     double total_ms = 0;
     for (int f = 0; f < o.frames; ++f) {
@@ -109,6 +136,16 @@ static void RunRank(const Options& o, kfx_comm* comm, const std::vector<std::vec
         dMeters.MemcpyFromHost(const_cast<float*>(depth_mm[f].data()));
         comm->barrier(comm);
         const auto t0 = std::chrono::steady_clock::now();
+        if (kframe) {
+            // (the sensor's millimetres -> metres is the application's step, main.cpp:208; every rank holds the raw frame)
+            ElementwiseScaleBias<float,float,float>(dMeters, dMeters, 1.0f / 1000.0f);
+            const Mat<float,3,4> T_cw = SE3inv(T_wl);
+            GpuCheckStatus(kfx_slab_frame_step(kframe, 0, T_wl.m, T_cw.m, 0, 0));
+            GpuCheckStatus(kfx_slab_frame_sync(kframe, 0));
+            comm->barrier(comm);
+            total_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            continue;
+        }
         if (!o.broadcast_inputs || comm->rank == 0) {   // --inputs broadcast: rank 0 preprocesses, the maps travel to the others
             ElementwiseScaleBias<float,float,float>(dMeters, dMeters, 1.0f / 1000.0f);
             BilateralFilter<float,float>(dFiltered, dMeters, bigs, bigr, biwin, 0.2f);
@@ -123,7 +160,8 @@ static void RunRank(const Options& o, kfx_comm* comm, const std::vector<std::vec
         total_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     }
     res->ms_per_frame = total_ms / o.frames;
-    res->rounds = slab.last_rounds;
+    res->rounds = kframe ? kfx_slab_frame_last_steps(kframe) : slab.last_rounds;
+    if (kframe) kfx_slab_frame_destroy(kframe);
 
     // checksums: images (identical on every rank after the merge) and the owned planes of the volume, summed over the ranks
     std::vector<float> hd((size_t)w * h), hi((size_t)w * h);
@@ -180,6 +218,9 @@ int main(int argc, char** argv)
         else if (!strcmp(argv[i], "--merge") && i + 1 < argc) o.merge = !strcmp(argv[++i], "allreduce") ? SlabVolume::MergeAllReduce : SlabVolume::MergeDirect;
         else if (!strcmp(argv[i], "--inputs") && i + 1 < argc) o.broadcast_inputs = !strcmp(argv[++i], "broadcast");
         else if (!strcmp(argv[i], "--rendezvous") && i + 1 < argc) o.rendezvous = argv[++i];
+        else if (!strcmp(argv[i], "--driver") && i + 1 < argc) o.frame_driver = !strcmp(argv[++i], "frame");
+        else if (!strcmp(argv[i], "--tiles") && i + 1 < argc) o.tiles = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--overlap")) o.overlap = true;
         else { fprintf(stderr, "unknown argument %s\n", argv[i]); return 2; }
     }
     const int ndev = kfx_device_count();
@@ -229,8 +270,8 @@ int main(int argc, char** argv)
         comms[0].destroy(&comms[0]);
     }
     if (rank == 0) {
-        printf("kinectfusion_slabs: %d^3 volume in %d slab(s) [%s], %dx%d, %d frames, %s math, halo %s, raycast %s%s: %.3f ms/frame (%.1f fps)\n",
-               o.volres, world, o.rccl ? "RCCL, one process per GPU" : "threads sharing one GPU", o.w, o.h, o.frames, o.fast ? "fast" : "exact",
+        printf("kinectfusion_slabs: %d^3 volume in %d slab(s) [%s%s], %dx%d, %d frames, %s math, halo %s, raycast %s%s: %.3f ms/frame (%.1f fps)\n",
+               o.volres, world, o.rccl ? "RCCL, one process per GPU" : "threads sharing one GPU", o.frame_driver ? "; one kfx_slab_frame_step per frame" : "", o.w, o.h, o.frames, o.fast ? "fast" : "exact",
                o.halo == SlabVolume::HaloExchange ? "exchange" : "recompute", o.raycast == SlabVolume::Exact ? "exact (hand-over)" : (o.raycast == SlabVolume::ExactAllReduce ? "exact (all-reduce per round)" : (o.merge == SlabVolume::MergeDirect ? "composite (direct-send merge)" : "composite (all-reduce merge)")),
                o.raycast != SlabVolume::Composite ? (" (" + std::to_string(r0.rounds) + " rounds)").c_str() : "", r0.ms_per_frame, 1e3 / r0.ms_per_frame);
         printf("checksums depth=%08x norm=%08x img=%08x volume=%08x hits=%zu ranks_agree=%d\n", r0.chk_d, r0.chk_n, r0.chk_i, r0.chk_vol, r0.hits,

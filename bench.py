@@ -60,9 +60,14 @@ def parse():
     ap.add_argument("--res", type=int, default=512, help="volume resolution N (N^3 voxels)")
     ap.add_argument("--width", type=int, default=None)
     ap.add_argument("--height", type=int, default=None)
-    ap.add_argument("--raycast", default="composite", choices=["composite", "exact", "exact_allreduce"],
-                    help="multi-GPU raycast: per-slab march + nearest-hit composite; the bit-exact march-state hand-over between "
-                         "neighbour ranks (world + 1 stages, no host check in between); or its cross-check with an all-reduce per round")
+    ap.add_argument("--raycast", default="exact", choices=["exact", "composite", "exact_allreduce"],
+                    help="multi-GPU raycast: exact (default) = the march state handed from slab to slab over the neighbour links, bit-identical to the "
+                         "single volume; composite = per-slab march + nearest-hit merge (rays restart at slab entries: a throughput variant outside "
+                         "the image tolerance); exact_allreduce = the hand-over's cross-check with an all-reduce per round (--driver python)")
+    ap.add_argument("--driver", default="c", choices=["c", "python"],
+                    help="N > 1: c (default) = one kfx_slab_frame_step call per frame and rank, collectives enqueued by the library (libkfx_rccl.so); "
+                         "python = SlabPipeline issues the operators and torch.distributed collectives one by one")
+    ap.add_argument("--tiles", type=int, default=0, help="N > 1, exact raycast, --driver c: image row-tiles of the hand-over (0: the library's default, 4)")
     ap.add_argument("--halo", default="recompute", choices=["recompute", "exchange"],
                     help="N > 1: how ghost planes are kept current -- recomputed by each rank (no traffic) or "
                          "exchanged with the neighbours over RCCL point-to-point after each SdfFuse")
@@ -612,9 +617,13 @@ def run_single(args, torch, roo, scenes, rank):
 
 
 def run_slabs(args, torch, dist, roo, scenes, rank, world):
-    """N > 1: the volume in Z-slabs, one rank per GPU (strong scaling).  Returns the JSON object on rank 0, None elsewhere."""
+    """N > 1: the volume in Z-slabs, one rank per GPU (strong scaling).  Returns the JSON object on rank 0, None elsewhere.
+    --driver c (default): every frame is ONE kfx_slab_frame_step call per rank (include/kfx_slab.h) -- the launches and the
+    collectives are enqueued by the library, through libkfx_rccl.so's RCCL communicator (one process per GPU) or, for the tests'
+    gloo ranks sharing a GPU, through the process group; --driver python: SlabPipeline issues operators and torch.distributed
+    collectives one by one (the cross-check; timed beside the headline as `driver_python_fps`)."""
     import gc
-    from kangaroo_amd.pipeline import SlabPipeline
+    from kangaroo_amd.pipeline import FramePipeline, SlabPipeline
     N, w, h, scene = args.res, args.width, args.height, args.scene
     bmin, bmax, near, far = scenes.SCENES[scene]
     K = scenes.intrinsics(w, h)
@@ -624,8 +633,25 @@ def run_slabs(args, torch, dist, roo, scenes, rank, world):
     if args.overlap and not can_overlap:
         sys.exit("bench.py: --overlap needs --raycast composite, --halo recompute and --inputs replicate (collective ordering, kangaroo_amd/pipeline.py)")
     overlap = can_overlap if args.overlap is None else bool(args.overlap)
+    c_driver = args.driver == "c"
+    if c_driver and (args.images != "all" or args.raycast == "exact_allreduce"):
+        sys.exit("bench.py: --images root and --raycast exact_allreduce are options of --driver python")
+    comm, comm_text = None, "torch.distributed (%s)" % dist.get_backend()
+    if c_driver:
+        from kangaroo_amd import slab as kslab
+        if dist.get_backend() == "nccl":
+            # the library's own RCCL communicator (libkfx_rccl.so): the ncclUniqueId travels through a file named after the launch
+            rdv = os.path.join(os.environ.get("TMPDIR", "/tmp"), "kfx_bench.%d.%s.id" % (os.getuid(), os.environ.get("MASTER_PORT", "0")))
+            comm = kslab.Comm.rccl(rank, world, rdv, 180)
+            comm_text = "libkfx_rccl.so: RCCL communicator of the library (grouped ncclSend / ncclRecv, ncclAllReduce, ncclAllGather), collectives enqueued on the launch stream by kfx_slab_frame_step"
+        else:
+            comm = kslab.Comm.torch(dist)
+            comm_text = "kfx_slab_frame_step with its collectives routed through torch.distributed (%s) callbacks -- the smoke-test transport for ranks sharing a GPU" % dist.get_backend()
+    steps_cap = max(256, args.steps + 4 * BLOCK + 64)
     pipe = SlabPipeline(roo, dist, (N, N, N), bmin, bmax, w, h, halo=args.halo, raycast=args.raycast, K=K, near=near, far=far,
-                        overlap=overlap, inputs=args.inputs, images=args.images, merge=args.merge)
+                        overlap=overlap, inputs=args.inputs, images=args.images, merge=args.merge, driver=args.driver, comm=comm, tiles=args.tiles,
+                        timing_slots=steps_cap)
+    sf = pipe.sframe
     poses = [scenes.orbit_pose(i, N_ORBIT) for i in range(N_ORBIT)]
     frames = []
     for T_wc in poses:
@@ -634,7 +660,10 @@ def run_slabs(args, torch, dist, roo, scenes, rank, world):
         frames.append(im)
 
     def sync_all():
-        pipe.wait_composite()
+        if sf is not None:
+            sf.sync()
+        else:
+            pipe.wait_composite()
         torch.cuda.synchronize()
         dist.barrier()
         torch.cuda.synchronize()
@@ -644,15 +673,19 @@ def run_slabs(args, torch, dist, roo, scenes, rank, world):
         pipe.preprocess(frames[i])
         n_updated.append(roo.SdfFuseCount(pipe.vol, pipe.filtered, pipe.normals, scenes.se3_inverse(poses[i]), K, pipe.trunc, pipe.mincostheta, full_extent=True))
     # everything the host has to prepare comes BEFORE the priming frames (an idle gap right before the timed region lets the clocks drop)
-    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
-    for e4 in ev:   # (torch creates an event at its first record(): not inside the timed region)
-        for e in e4:
-            e.record()
+    ev = None
+    if sf is None:
+        ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
+        for e4 in ev:   # (torch creates an event at its first record(): not inside the timed region)
+            for e in e4:
+                e.record()
     gc.collect()
     gc.disable()
     # untimed frames: --prime says exactly how many; otherwise as many as make --prime-seconds of work at the pace of a first
     # block (at least 450): at 8 ranks a frame is a fraction of a 1-GPU frame and 450 of them would be over before the clocks of a
     # GPU that was idle have settled.  The count is agreed between the ranks (every frame has collectives).
+    if sf is not None:
+        sf.set_timing(False)
     if args.prime is not None:
         n_prime = max(args.prime, 0)
         for i in range(n_prime):
@@ -669,20 +702,28 @@ def run_slabs(args, torch, dist, roo, scenes, rank, world):
         n_prime = BLOCK + max(450 - BLOCK, min(int(args.prime_seconds / per_frame), 60000))
         for i in range(BLOCK, n_prime):
             pipe.step(poses[i % N_ORBIT], frames[i % N_ORBIT])
+    if sf is not None:
+        sf.set_timing(True)   # five markers per frame around its parts (the exact march is one part: its stages have no gaps to hide)
     for i in range(args.warmup):
         pipe.step(poses[i % N_ORBIT], frames[i % N_ORBIT])
     sync_all()
+    first = sf.count if sf is not None else 0
     t0 = time.perf_counter()
-    for s in range(args.steps):
-        i = (args.warmup + s) % N_ORBIT
-        T_wc = poses[i]
-        pipe.preprocess(frames[i])
-        ev[s][0].record()            # events on the stream the kernels are launched on (torch's current stream: the one roo passes to libkfx)
-        pipe.fuse(T_wc)
-        ev[s][1].record()
-        ev[s][2].record()
-        pipe.raycast(T_wc)
-        ev[s][3].record()
+    if sf is not None:
+        for s in range(args.steps):
+            i = (args.warmup + s) % N_ORBIT
+            pipe.step(poses[i], frames[i])
+    else:
+        for s in range(args.steps):
+            i = (args.warmup + s) % N_ORBIT
+            T_wc = poses[i]
+            pipe.preprocess(frames[i])
+            ev[s][0].record()            # events on the stream the kernels are launched on (torch's current stream: the one roo passes to libkfx)
+            pipe.fuse(T_wc)
+            ev[s][1].record()
+            ev[s][2].record()
+            pipe.raycast(T_wc)
+            ev[s][3].record()
     sync_all()
     elapsed = time.perf_counter() - t0
     gc.enable()
@@ -690,8 +731,15 @@ def run_slabs(args, torch, dist, roo, scenes, rank, world):
     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     elapsed = float(tt.item())
 
-    fuse_ms = [ev[s][0].elapsed_time(ev[s][1]) for s in range(args.steps)]
-    ray_ms = [ev[s][2].elapsed_time(ev[s][3]) for s in range(args.steps)]
+    pre_avg_ms, merge_avg_ms, frame_ev_ms = None, None, None
+    if sf is not None:
+        t = sf.timings(first, args.steps)   # preprocess, sdf_fuse (+ ghost planes), raycast, merge, frame, period
+        fuse_ms, ray_ms = t[:, 1], (t[:, 2] + np.nan_to_num(t[:, 3]))
+        pre_avg_ms, frame_ev_ms = float(np.mean(t[:, 0])), float(np.mean(t[:, 4]))
+        merge_avg_ms = float(np.mean(t[:, 3])) if np.isfinite(t[:, 3]).all() else None
+    else:
+        fuse_ms = [ev[s][0].elapsed_time(ev[s][1]) for s in range(args.steps)]
+        ray_ms = [ev[s][2].elapsed_time(ev[s][3]) for s in range(args.steps)]
     idx = [(args.warmup + s) % N_ORBIT for s in range(args.steps)]
     fuse_avg_ms, ray_avg_ms = float(np.mean(fuse_ms)), float(np.mean(ray_ms))
     bytes_avg = float(np.mean([16.0 * n_updated[i] + 20.0 * w * h for i in idx]))
@@ -700,12 +748,12 @@ def run_slabs(args, torch, dist, roo, scenes, rank, world):
     hits = int(torch.isfinite(pipe.ray_d.tensor()).sum()) if (args.images == "all" or rank == 0) else 1
     assert hits > 0, "raycast produced no hits"
     ranks_agree = None
-    if args.images != "root":   # after the composite every rank must hold the same images: compare a checksum of the depth bits
+    if args.images != "root":   # after the merge every rank must hold the same images: compare a checksum of the depth bits
         bits = torch.nan_to_num(pipe.ray_d.tensor(), nan=-1.0).contiguous().view(torch.int32).to(torch.int64)
         chk = torch.stack([bits.sum(), -bits.sum()])
         dist.all_reduce(chk, op=dist.ReduceOp.MAX)
         ranks_agree = bool(int(chk[0].item()) == -int(chk[1].item()))
-        assert ranks_agree, "ranks hold different composite images"
+        assert ranks_agree, "ranks hold different images"
 
     # ---- what a first run on real links has to show without a second attempt (round-3 verdict item 8): every rank's kernel
     # times, the ghost-plane exchange and the image merge timed by themselves, and what the communicator sees ----
@@ -721,18 +769,18 @@ def run_slabs(args, torch, dist, roo, scenes, rank, world):
         torch.cuda.synchronize()
         return a.elapsed_time(b) / reps
 
-    comm = {"n_ranks": dist.get_world_size(), "backend": dist.get_backend()}
+    comm_info = {"n_ranks": dist.get_world_size(), "backend": dist.get_backend(), "frame_collectives": comm_text}
     try:
-        comm["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version()) if dist.get_backend() == "nccl" else None
+        comm_info["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version()) if dist.get_backend() == "nccl" else None
     except Exception as e:   # noqa: BLE001
-        comm["rccl_version"] = "unknown (%r)" % (e,)
+        comm_info["rccl_version"] = "unknown (%r)" % (e,)
     per_rank = None
     try:
         lo_ghost, hi_ghost = pipe.z0 - pipe.s0, pipe.s1 - pipe.z1
         halo_bytes = (lo_ghost * (1 if rank > 0 else 0) + hi_ghost * (1 if rank < world - 1 else 0)) * pipe.vol.img_pitch   # received (= sent) per SdfFuse
-        halo_ms = event_ms(pipe.exchange_halos, 5) if world > 1 else 0.0
-        merge_ms, other_merge_ms = None, None
-        if args.raycast == "composite" and world > 1:
+        halo_ms = event_ms(pipe.exchange_halos, 5) if world > 1 else 0.0   # (torch.distributed point-to-point of the ghost planes, by itself)
+        merge_ms, other_merge_ms = merge_avg_ms, None
+        if sf is None and args.raycast == "composite" and world > 1:
             pipe.wait_composite()
             merge_ms = event_ms(lambda: pipe.composite(pipe.ray_d, pipe.ray_n, pipe.ray_i), 5)
             pipe.merge = "allreduce" if args.merge == "direct" else "direct"   # the other merge on the same images, by itself
@@ -743,19 +791,22 @@ def run_slabs(args, torch, dist, roo, scenes, rank, world):
             pipe.raycast(poses[idx[-1]])   # (the images are a rendering again)
             pipe.wait_composite()
         mine = torch.tensor([fuse_avg_ms, ray_avg_ms, halo_ms, -1.0 if merge_ms is None else merge_ms, float(halo_bytes), float(pipe.z1 - pipe.z0),
-                             float(local_voxels), -1.0 if other_merge_ms is None else other_merge_ms], dtype=torch.float64, device="cuda")
+                             float(local_voxels), -1.0 if other_merge_ms is None else other_merge_ms, -1.0 if pre_avg_ms is None else pre_avg_ms,
+                             -1.0 if frame_ev_ms is None else frame_ev_ms], dtype=torch.float64, device="cuda")
         allr = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
-        per_rank = [{"rank": r, "sdf_fuse_ms": round(float(v[0]), 5), "raycast_sdf_plus_merge_ms": round(float(v[1]), 5),
-                     "halo_exchange_ms": round(float(v[2]), 5), "composite_merge_ms": None if float(v[3]) < 0 else round(float(v[3]), 5),
-                     "composite_merge_%s_ms" % ("allreduce" if args.merge == "direct" else "direct"): None if float(v[7]) < 0 else round(float(v[7]), 5),
+        opt = lambda x: None if float(x) < 0 else round(float(x), 5)   # noqa: E731
+        per_rank = [{"rank": r, "preprocess_ms": opt(v[8]), "sdf_fuse_ms": round(float(v[0]), 5), "raycast_sdf_plus_merge_ms": round(float(v[1]), 5),
+                     "frame_events_ms": opt(v[9]), "halo_exchange_ms": round(float(v[2]), 5), "composite_merge_ms": opt(v[3]),
+                     "composite_merge_%s_ms" % ("allreduce" if args.merge == "direct" else "direct"): opt(v[7]),
                      "halo_bytes_received_per_fuse": int(v[4]), "planes_owned": int(v[5]), "voxels_stored": int(v[6])} for r, v in enumerate(allr)]
     except Exception as e:   # noqa: BLE001  (symmetric across ranks: every rank takes the same path)
         per_rank = {"error": repr(e)[:300]}
 
-    # the same frames with the other ghost-plane policy (RCCL neighbour exchange vs redundant integration: same bits) and with
-    # the composite merge overlapped / not overlapped with the next frame -- reported beside the headline so that one multi-GPU
-    # run of the default command measures all of them (not part of `value`)
+    # ---- the same frames under the other policies, reported beside the headline so that ONE multi-GPU run of the default command
+    # measures all of them (not part of `value`): the north-star sentence itself -- ghost planes exchanged over RCCL + the ray
+    # hand-over --, the hand-over with other tile counts, the composite (a throughput variant outside the image tolerance) with
+    # its merges and the merge overlapped with the next frame, the input broadcast, and the interpreter-driven loop ----
     def timed_fps(n):
         for s in range(3):
             i = (args.warmup + s) % N_ORBIT
@@ -771,44 +822,112 @@ def run_slabs(args, torch, dist, roo, scenes, rank, world):
         return round(n / float(tv.item()), 1)
     n_var = min(args.steps, 2 * N_ORBIT)
     variants = {"steps": n_var}
-    base_halo, base_overlap, base_inputs, base_images, base_merge = pipe.halo, pipe.overlap, pipe.inputs, pipe.images, pipe.merge
+    base = dict(halo=args.halo, raycast=args.raycast, merge=args.merge, inputs=args.inputs, overlap=overlap)
     try:   # reported extras must never cost the headline line (errors in collectives are symmetric across ranks)
         variants["as_configured_fps"] = timed_fps(n_var)
-        pipe.wait_composite()
-        pipe.overlap = False   # the ghost-plane exchange and the input broadcast never run beside an overlapped merge (SlabPipeline.__init__)
-        pipe.halo = "exchange" if base_halo == "recompute" else "recompute"
-        variants["halo_%s_fps" % pipe.halo] = timed_fps(n_var)
-        pipe.halo = base_halo
-        pipe.inputs = "broadcast" if base_inputs == "replicate" else "replicate"
-        variants["inputs_%s_fps" % pipe.inputs] = timed_fps(n_var)
-        pipe.inputs = base_inputs
-        if args.raycast == "composite":
-            if base_overlap or can_overlap:   # the merge overlapped / not overlapped with the next frame
-                pipe.overlap = not base_overlap
-                variants["overlap_%s_fps" % ("on" if pipe.overlap else "off")] = timed_fps(n_var)
+        if sf is not None:
+            plan = [("raycast_exact_fps", dict(base, raycast="exact", overlap=False)),
+                    ("halo_exchange+raycast_exact_fps", dict(base, raycast="exact", halo="exchange", overlap=False)),
+                    ("raycast_exact_tiles_1_fps", dict(base, raycast="exact", overlap=False, tiles=1)),
+                    ("raycast_exact_tiles_8_fps", dict(base, raycast="exact", overlap=False, tiles=8)),
+                    ("raycast_composite_fps", dict(base, raycast="composite", overlap=False)),
+                    ("raycast_composite_overlapped_fps", dict(base, raycast="composite", halo="recompute", inputs="replicate", overlap=True)),
+                    ("raycast_composite_merge_allreduce_fps", dict(base, raycast="composite", merge="allreduce", overlap=False)),
+                    ("halo_%s_fps" % ("exchange" if args.halo == "recompute" else "recompute"),
+                     dict(base, halo="exchange" if args.halo == "recompute" else "recompute", overlap=False)),
+                    ("inputs_%s_fps" % ("broadcast" if args.inputs == "replicate" else "replicate"),
+                     dict(base, inputs="broadcast" if args.inputs == "replicate" else "replicate", overlap=False))]
+            for name, cfg in plan:
+                cfg = dict(cfg)
+                cfg.setdefault("tiles", args.tiles)
+                pipe.configure(**cfg)
+                variants[name] = timed_fps(n_var)
+            pipe.configure(**dict(base, tiles=args.tiles))
+            # the interpreter-driven loop on the same slabs (operators and torch.distributed collectives one by one)
+            keep = pipe
+            try:
+                py = SlabPipeline(roo, dist, (N, N, N), bmin, bmax, w, h, halo=args.halo, raycast=args.raycast, K=K, near=near, far=far,
+                                  overlap=False, inputs=args.inputs, merge=args.merge, driver="python")
+                pipe = py
+                for s in range(N_ORBIT):
+                    pipe.step(poses[s % N_ORBIT], frames[s % N_ORBIT])
+                variants["driver_python_fps"] = timed_fps(n_var)
+                pipe = keep
+                del py
+            except Exception as e:   # noqa: BLE001
+                pipe = keep
+                variants["driver_python_error"] = repr(e)[:200]
+        else:
+            base_halo, base_overlap, base_inputs, base_images, base_merge = pipe.halo, pipe.overlap, pipe.inputs, pipe.images, pipe.merge
+            pipe.wait_composite()
+            pipe.overlap = False   # the ghost-plane exchange and the input broadcast never run beside an overlapped merge (SlabPipeline.__init__)
+            pipe.halo = "exchange" if base_halo == "recompute" else "recompute"
+            variants["halo_%s_fps" % pipe.halo] = timed_fps(n_var)
+            pipe.halo = base_halo
+            pipe.inputs = "broadcast" if base_inputs == "replicate" else "replicate"
+            variants["inputs_%s_fps" % pipe.inputs] = timed_fps(n_var)
+            pipe.inputs = base_inputs
+            if args.raycast == "composite":
+                if base_overlap or can_overlap:   # the merge overlapped / not overlapped with the next frame
+                    pipe.overlap = not base_overlap
+                    variants["overlap_%s_fps" % ("on" if pipe.overlap else "off")] = timed_fps(n_var)
+                    pipe.wait_composite()
+                pipe.overlap = base_overlap
+                pipe.images = "root" if base_images == "all" else "all"
+                variants["images_%s_fps" % pipe.images] = timed_fps(n_var)
                 pipe.wait_composite()
-            pipe.overlap = base_overlap
-            pipe.images = "root" if base_images == "all" else "all"
-            variants["images_%s_fps" % pipe.images] = timed_fps(n_var)
-            pipe.wait_composite()
-            pipe.images = base_images
-            pipe.merge = "allreduce" if base_merge == "direct" else "direct"
-            variants["merge_%s_fps" % pipe.merge] = timed_fps(n_var)
-            pipe.wait_composite()
+                pipe.images = base_images
+                pipe.merge = "allreduce" if base_merge == "direct" else "direct"
+                variants["merge_%s_fps" % pipe.merge] = timed_fps(n_var)
+                pipe.wait_composite()
+            pipe.halo, pipe.overlap, pipe.inputs, pipe.images, pipe.merge = base_halo, base_overlap, base_inputs, base_images, base_merge
     except Exception as e:   # noqa: BLE001
         variants["error"] = repr(e)[:300]
-    pipe.halo, pipe.overlap, pipe.inputs, pipe.images, pipe.merge = base_halo, base_overlap, base_inputs, base_images, base_merge
+
+    # ---- the N = 1 point of THIS machine with the SAME kernels (the plain SdfFuse + plain march, one kfx_frame_step per frame, no
+    # brick summary -- slabs march without it): what a strong-scaling efficiency of `value` is to be computed against.  Every rank
+    # runs it on its own GPU (1 GiB more), rank 0's figure is reported. ----
+    baseline = None
+    try:
+        sync_all()
+        one = FramePipeline(roo, (N, N, N), bmin, bmax, w, h, K=K, near=near, far=far, track=False, timing_slots=256)
+        for i in range(4 * N_ORBIT):
+            one.step(poses[i % N_ORBIT], frames[i % N_ORBIT])
+        torch.cuda.synchronize()
+        t_1 = time.perf_counter()
+        n_1 = 2 * N_ORBIT
+        for i in range(n_1):
+            one.step(poses[i % N_ORBIT], frames[i % N_ORBIT])
+        torch.cuda.synchronize()
+        baseline = {"frames_per_sec": round(n_1 / (time.perf_counter() - t_1), 1), "steps": n_1,
+                    "note": "this rank's GPU alone on the whole %d^3 volume: kfx_sdf_fuse + kfx_raycast_sdf (no brick summary), one kfx_frame_step per frame, "
+                            "%d steps after %d untimed ones -- the same kernels the slabs run (the N = 1 headline of bench.py --gpus 1 may "
+                            "run the tracked pair, which slabs do not have)" % (N, n_1, 4 * N_ORBIT)}
+        del one
+        torch.cuda.empty_cache()
+        dist.barrier()
+    except Exception as e:   # noqa: BLE001
+        baseline = {"error": repr(e)[:300]}
 
     out = None
     if rank == 0:
+        tiles_text = "" if args.raycast != "exact" or sf is None else ", %d image row-tiles" % (args.tiles or 4)
         partition = "z-slabs x%d, inputs %s, ghost planes %s%s, raycast %s" % (
             world, "preprocessed by every rank" if args.inputs == "replicate" else "preprocessed by rank 0 and broadcast", args.halo,
             ", merge overlapped with the next frame" if overlap else "",
             {"composite": ("composite = all_to_all(image strips to their owners) + nearest hit per pixel + %s(merged strips)" % ("gather-to-rank-0" if args.images == "root" else "all_gather")
                            if args.merge == "direct" else
                            "composite = all_reduce(MIN key) + %s(SUM payload)" % ("reduce-to-rank-0" if args.images == "root" else "all_reduce")),
-             "exact": "exact = march state handed from slab to slab: world + 1 stages, neighbour send/recv between them, one all_reduce of the finalised pixels at the end",
+             "exact": ("exact = march state handed from slab to slab as tokens over image row-tiles (world + tiles - 1 steps of one tile-sized neighbour "
+                       "send/recv each, one whole-image stage for the normals of hits that fell back across a slab boundary, one all_reduce of the finalised pixels)%s" % tiles_text
+                       if sf is not None else
+                       "exact = march state handed from slab to slab: world + 1 stages, neighbour send/recv between them, one all_reduce of the finalised pixels at the end"),
              "exact_allreduce": "exact (cross-check) = one SUM all_reduce of the march state + a host-side termination test per round"}[args.raycast])
+        parity = ("bit-identical to RaycastSdf on the single volume (tests/test_cpp_slabs.py, tests/mp_slab_gpu.py: 2 / 3 / 4 / 8 ranks, 1 / 4 / 8 tiles)"
+                  if args.raycast != "composite" else
+                  "OUTSIDE the single-GPU image tolerance: the march restarts at each slab entry, so silhouette rays can end differently -- 512^3 / 8 slabs, "
+                  "S_room: 85 of 307 200 pixels change between hit and miss (2.8e-4 against the 2e-5 of tests/test_gpu_chain.py), depth of common hits "
+                  "within 2.3e-5 m (99 %%); a throughput variant, --raycast exact is the default")
         out = {
             "metric": "kinectfusion_frames_per_sec_640x480_to_512cubed_tsdf",
             "value": round(args.steps / elapsed, 3),
@@ -823,12 +942,17 @@ def run_slabs(args, torch, dist, roo, scenes, rank, world):
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
+            "strong_scaling_baseline_fps": None if not baseline else baseline.get("frames_per_sec"),
+            "strong_scaling_baseline": baseline,
             "config": {
                 "workload": workload_text(args, n_prime, True),
                 "volume": [N, N, N], "image": [w, h], "scene": scene,
                 "backend": os.environ.get("KFX_BENCH_BACKEND", "nccl (RCCL)"), "ranks_agree": ranks_agree,
-                "raycast": "plain march (kfx_raycast_sdf) per slab", "summary_policy": None,
-                "partition": partition, "communicator": comm,
+                "driver": ("c: one kfx_slab_frame_step call per frame and rank (launches and collectives enqueued by libkfx)" if sf is not None else
+                           "python: SlabPipeline issues operators and torch.distributed collectives one by one"),
+                "raycast": "plain march (kfx_raycast_sdf%s) per slab" % ("_slab, state carried across slabs" if args.raycast != "composite" else ""),
+                "raycast_mode": args.raycast, "raycast_parity": parity, "summary_policy": None,
+                "partition": partition, "communicator": comm_info,
                 "math": MATH_TEXT[args.math],
             },
             "roofline": {
@@ -836,15 +960,23 @@ def run_slabs(args, torch, dist, roo, scenes, rank, world):
                 "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": None, "traffic_source": None,
                 "algorithmic_bytes_per_launch": round(bytes_avg), "avg_launch_ms": round(fuse_avg_ms, 5),
-                "timing": "torch.cuda events on torch's current stream, which is the stream every launch of this run is issued on",
+                "timing": ("hipEvents recorded by kfx_slab_frame_step on the launch stream around the SdfFuse call of every timed step" if sf is not None else
+                           "torch.cuda events on torch's current stream, which is the stream every launch of this run is issued on"),
                 "updated_fraction": round(float(np.mean([n_updated[i] for i in idx])) / local_voxels, 4),
                 "full_sweep_GBps": round(16.0 * local_voxels / (fuse_avg_ms * 1e-3) / 1e9, 1),
                 "note": "rank-0 slab (with its ghost planes when they are recomputed)",
             },
-            "kernels_ms": {"sdf_fuse": round(fuse_avg_ms, 5), "raycast_sdf+composite": round(ray_avg_ms, 5), "frame_total": round(1e3 * elapsed / args.steps, 5)},
+            "kernels_ms": {"preprocess": None if pre_avg_ms is None else round(pre_avg_ms, 5), "sdf_fuse": round(fuse_avg_ms, 5),
+                           "raycast_sdf+%s" % ("handover" if args.raycast != "composite" else "composite"): round(ray_avg_ms, 5),
+                           "frame_events": None if frame_ev_ms is None else round(frame_ev_ms, 5), "frame_total": round(1e3 * elapsed / args.steps, 5),
+                           "host_gap": None if frame_ev_ms is None else round(1e3 * elapsed / args.steps - frame_ev_ms, 5)},
             "per_rank": per_rank,
             "multi_gpu_variants": variants,
         }
+    if comm is not None and c_driver and dist.get_backend() == "nccl":
+        pipe.sframe = None
+        del sf
+        comm.destroy()
     return out
 
 

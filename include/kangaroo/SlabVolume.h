@@ -40,6 +40,7 @@ public:
     HaloMode halo;
     RaycastMode raycast;
     MergeMode merge;
+    int tiles;        // Exact: 0 = whole-image stages (kfx_slab_raycast_exact); >= 1 = the hand-over pipelined over this many image row-tiles
     int last_rounds;
 
     SlabVolume(size_t w, size_t h, size_t d, const BoundingBox& bbox, kfx_comm* comm_, HaloMode halo_ = HaloExchange,
@@ -47,13 +48,13 @@ public:
         : layout(MakeLayout(d, bbox, comm_, ghost)),
           local(w, h, layout.s1 - layout.s0, BoundingBox(make_float3(bbox.Min().x, bbox.Min().y, layout.local_zmin),
                                                            make_float3(bbox.Max().x, bbox.Max().y, layout.local_zmax))),
-          full_bbox(bbox), comm(comm_), halo(halo_), raycast(raycast_), merge(MergeDirect), last_rounds(0), key_(0), payload_(0), state_(0), scratch_(0),
-          strips_(0), cap_(0), strips_cap_(0)
+          full_bbox(bbox), comm(comm_), halo(halo_), raycast(raycast_), merge(MergeDirect), tiles(0), last_rounds(0), key_(0), payload_(0), state_(0), scratch_(0),
+          strips_(0), tiled_(0), cap_(0), strips_cap_(0), tiled_cap_(0)
     {
     }
     ~SlabVolume()
     {
-        kfx_free(key_); kfx_free(payload_); kfx_free(state_); kfx_free(scratch_); kfx_free(strips_);
+        kfx_free(key_); kfx_free(payload_); kfx_free(state_); kfx_free(scratch_); kfx_free(strips_); kfx_free(tiled_);
     }
     SlabVolume(const SlabVolume&) = delete;
     SlabVolume& operator=(const SlabVolume&) = delete;
@@ -85,7 +86,18 @@ public:
                  float trunc_dist, bool subpix = true)
     {
         Reserve(depth.w * depth.h);
-        if (raycast == Exact) {
+        if (raycast == Exact && tiles > 0) {
+            const size_t need = kfx_slab_exact_tiled_scratch_bytes(depth.w, depth.h, tiles);
+            if (need > tiled_cap_) {
+                size_t pitch;
+                kfx_free(tiled_);
+                tiled_ = 0; tiled_cap_ = 0;
+                GpuCheckStatus(kfx_alloc_pitched(&tiled_, &pitch, need, 1));
+                tiled_cap_ = need;
+            }
+            GpuCheckStatus(kfx_slab_raycast_exact_tiled(depth.abi(), norm.abi(), img.abi(), tiled_, local.abi(), &layout, T_wc.m, &K.fu, near, far, trunc_dist,
+                                                        subpix ? 1 : 0, tiles, comm, 0, 0, &last_rounds));
+        } else if (raycast == Exact) {
             GpuCheckStatus(kfx_slab_raycast_exact(depth.abi(), norm.abi(), img.abi(), (float*)state_, scratch_, local.abi(), &layout, T_wc.m,
                                                   &K.fu, near, far, trunc_dist, subpix ? 1 : 0, comm, 0, &last_rounds));
         } else if (raycast == ExactAllReduce) {
@@ -116,8 +128,8 @@ private:
         GpuCheckStatus(kfx_slab_layout_init(&L, d, bbox.Min().z, bbox.Max().z, c->rank, c->world, ghost));
         return L;
     }
-    void* key_; void* payload_; void* state_; void* scratch_; void* strips_;
-    size_t cap_, strips_cap_;
+    void* key_; void* payload_; void* state_; void* scratch_; void* strips_; void* tiled_;
+    size_t cap_, strips_cap_, tiled_cap_;
     void Reserve(size_t n)
     {
         if (n <= cap_) return;

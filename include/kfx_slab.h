@@ -55,12 +55,24 @@ typedef struct kfx_comm {
      * (bytes_per_rank) to chunk `rank` of every rank's `recv`.  The direct-send composite's two phases. */
     int (*all_to_all)(struct kfx_comm* c, const void* send, void* recv, size_t bytes_per_rank, kfx_stream stream);
     int (*all_gather)(struct kfx_comm* c, const void* send, void* recv, size_t bytes_per_rank, kfx_stream stream);
+    /* neighbour exchange whose four legs have their own sizes (0 / a missing neighbour skips a leg): what this rank sends down
+     * must be what rank - 1 receives from above, and so on.  The tile-pipelined hand-over's steps. */
+    int (*exchange_v)(struct kfx_comm* c, const void* send_lo, size_t bytes_send_lo, void* recv_lo, size_t bytes_recv_lo,
+                      const void* send_hi, size_t bytes_send_hi, void* recv_hi, size_t bytes_recv_hi, kfx_stream stream);
 } kfx_comm;
+/* A transport of the caller's own fills the table itself: zero-initialise the struct first (entries after `destroy` are optional and
+ * are tested against NULL; the table has grown at its end between versions of this header). */
 
 /* In-process transport: fills comms[0 .. world) for `world` host threads of this process that share the current device;
  * every collective must be called by all of them (each with its own comms[r]).  Destroy through comms[0] after the threads
  * have joined. */
 int kfx_comm_create_threads(kfx_comm* comms, int world);
+
+/* Loop-back transport (libkfx.so) for measuring ONE rank of a `world`-rank job on one GPU: every collective moves the bytes a
+ * real one would deliver to this rank, but from this rank's own buffers (all_reduce: nothing arrives, all_to_all / all_gather:
+ * device-local copies, exchange: the send buffers come back).  The frame's kernels, launches and copies are those of a real
+ * rank; the images are NOT a rendering (nobody marched the other slabs).  Host-overhead and kernel-time floors only. */
+int kfx_comm_create_loopback(kfx_comm* comm, int rank, int world);
 
 /* RCCL transport (libkfx_rccl.so).  rank 0 removes any existing `rendezvous_file` and writes the ncclUniqueId there (exclusive
  * temporary + rename, mode 0600, no symlinks followed) behind a launch nonce folded from KFX_RUN_ID / TORCHELASTIC_RUN_ID /
@@ -117,6 +129,80 @@ int kfx_slab_raycast_exact(const kfx_image* depth, const kfx_image* norm, const 
 int kfx_slab_raycast_exact_allreduce(const kfx_image* depth, const kfx_image* norm, const kfx_image* img, float* state, void* scratch,
                                      const kfx_volume* local, const kfx_slab_layout* L, const float T_wc[12], const float K[4],
                                      float near, float far, float trunc_dist, int subpix, kfx_comm* comm, kfx_stream stream, int* rounds_out);
+
+/* The hand-over pipelined over image row-tiles ("<= 7 hops pipelined over image tiles").  A ray moves
+ * through the slabs monotonically, so the march state of a tile travels as a token: upwards 0 -> 1 -> ... -> world - 1 (rays
+ * with rising z) and downwards at the same time; rank r marches tile t when the upward token reaches it (step r + t) and when
+ * the downward one does (step world - 1 - r + t), and passes the tile's five march planes on to ONE neighbour -- a message of
+ * 1 / tiles of the image per link and step, world + tiles - 1 steps, against world stages of whole images.  Every rank
+ * initialises every ray itself (the entry slab's owner starts it); a rank adopts a neighbour's copy of a ray when that copy is
+ * NEWER than its own (a final or hit status beats "marching", a larger lambda beats a smaller) and still under way.  One last
+ * stage with a whole-image neighbour exchange lets a hit whose sub-step interpolation fell back across a slab boundary get its
+ * normal from the rank that owns the gradient's base plane; then one all-reduce of the finalising ranks' results.  Same samples,
+ * same images as kfx_raycast_sdf on the whole volume, bit for bit, for any number of tiles.
+ * scratch: kfx_slab_exact_tiled_scratch_bytes(w, h, tiles) bytes of device memory.  h_open: NULL -- the call synchronises the
+ * stream at its end and fails with KFX_E_RANGE if a ray is left without a final status; else a host-visible (pinned) word that
+ * receives that count asynchronously: the call returns without synchronising and the CALLER checks the word once the stream
+ * has passed (kfx_slab_frame does).  Needs comm->exchange_v. */
+size_t kfx_slab_exact_tiled_scratch_bytes(size_t w, size_t h, int tiles);
+int kfx_slab_raycast_exact_tiled(const kfx_image* depth, const kfx_image* norm, const kfx_image* img, void* scratch,
+                                 const kfx_volume* local, const kfx_slab_layout* L, const float T_wc[12], const float K[4],
+                                 float near, float far, float trunc_dist, int subpix, int tiles, kfx_comm* comm, kfx_stream stream,
+                                 int* h_open, int* steps_out);
+
+/* ---- a slab rank's frame as ONE call ---------------------------------------------------------------------------
+ * kfx_frame_step's counterpart for N > 1 (include/kfx.h: a frame is a fraction of a millisecond of GPU work, and a host that
+ * issues it operator by operator leaves gaps of the same order): BilateralFilter -> DepthToVbo + NormalsFromVbo (or rank 0's,
+ * broadcast) -> kfx_sdf_fuse_slab on this rank's planes (+ ghost-plane exchange) -> the slab raycast and its collectives, all
+ * enqueued by one call on the caller's stream, with device events around the parts in a ring.
+ *   raycast  EXACT (default): kfx_slab_raycast_exact_tiled -- bit-identical to the single volume (the path BASELINE's north
+ *            star names: march state handed from slab to slab over the neighbour links);
+ *            COMPOSITE: kfx_raycast_sdf on the local view + nearest-hit merge (direct sends or two all-reduces); the march
+ *            restarts at each slab entry, so silhouette rays can end differently (512^3 / 8 slabs, S_room: 85 of 307 200
+ *            pixels change between hit and miss) -- a throughput variant outside the image tolerance of the single-GPU path.
+ *   overlap  (COMPOSITE, halo RECOMPUTE, inputs REPLICATE only): the merge of frame k runs on the frame's own side stream under
+ *            frame k + 1's preprocessing and SdfFuse; the images are valid after kfx_slab_frame_wait. */
+#define KFX_SLAB_HALO_RECOMPUTE    0
+#define KFX_SLAB_HALO_EXCHANGE     1
+#define KFX_SLAB_RAYCAST_EXACT     0
+#define KFX_SLAB_RAYCAST_COMPOSITE 1
+#define KFX_SLAB_MERGE_DIRECT      0
+#define KFX_SLAB_MERGE_ALLREDUCE   1
+#define KFX_SLAB_INPUTS_REPLICATE  0
+#define KFX_SLAB_INPUTS_BROADCAST  1
+typedef struct kfx_slab_frame kfx_slab_frame;
+typedef struct kfx_slab_frame_config {
+    kfx_volume local;                        /* this rank's stored planes [layout.s0, layout.s1), box = local_zmin .. local_zmax */
+    kfx_slab_layout layout;
+    kfx_image raw, filtered, vbo, normals;   /* the whole frame's images (every rank holds them) */
+    kfx_image ray_depth, ray_norm, ray_img;  /* the merged rendering */
+    float K[4];
+    float bilateral_gs, bilateral_gr, bilateral_minval;
+    unsigned bilateral_size;
+    float near, far, trunc_dist, max_w, mincostheta;
+    int halo, raycast, merge, inputs;        /* KFX_SLAB_* */
+    int overlap;                             /* 1: composite merge under the next frame (see above) */
+    int tiles;                               /* exact raycast: image row-tiles of the hand-over (>= 1; 0: the library's default, 4) */
+    int unchecked;                           /* 1: do not fail when the exact march leaves rays open (loop-back measurements) */
+    int timing_slots;                        /* 0: no events */
+} kfx_slab_frame_config;
+#define KFX_SLAB_FRAME_TIMING_FIELDS 6      /* ms: preprocess (+ broadcast), SdfFuse (+ ghost planes), RaycastSdf kernels or the whole exact march,
+                                               composite merge (NaN: exact), frame (first to last event), period (to the next frame's first event) */
+int kfx_slab_frame_create(kfx_slab_frame** out, const kfx_slab_frame_config* cfg, kfx_comm* comm);
+int kfx_slab_frame_destroy(kfx_slab_frame* f);
+/* change the policies between frames (bench.py times the variants on one object); a value < 0 keeps the current one */
+int kfx_slab_frame_configure(kfx_slab_frame* f, int halo, int raycast, int merge, int inputs, int overlap, int tiles);
+int kfx_slab_frame_reset(kfx_slab_frame* f, kfx_stream stream);   /* SdfReset(local, NaN) */
+int kfx_slab_frame_step(kfx_slab_frame* f, const kfx_image* raw, const float T_wc[12], const float* T_cw, unsigned parts, kfx_stream stream);
+/* make `stream` wait for an overlapped merge and report a failed exact march of an earlier frame (KFX_E_RANGE) */
+int kfx_slab_frame_wait(kfx_slab_frame* f, kfx_stream stream);
+/* synchronise `stream` and whatever the frame object still has in flight (an overlapped merge on its side stream); reports a failed
+ * exact march of any frame so far */
+int kfx_slab_frame_sync(kfx_slab_frame* f, kfx_stream stream);
+long long kfx_slab_frame_count(const kfx_slab_frame* f);
+int kfx_slab_frame_set_timing(kfx_slab_frame* f, int on);
+int kfx_slab_frame_timings(kfx_slab_frame* f, long long first_frame, int n_frames, float* ms);
+int kfx_slab_frame_last_steps(const kfx_slab_frame* f);           /* stages of the last exact march (world + tiles - 1 + 1) */
 
 #ifdef __cplusplus
 }

@@ -51,20 +51,29 @@ int rccl_all_reduce(kfx_comm* c, void* buf, size_t count, int op, kfx_stream str
     return nccl_status(ncclAllReduce(buf, buf, count, dt, ro, im->comm, (hipStream_t)stream));
 }
 
-int rccl_exchange(kfx_comm* c, const void* send_lo, void* recv_lo, size_t bytes_lo, const void* send_hi, void* recv_hi, size_t bytes_hi,
-                  kfx_stream stream)
+// one batched group of point-to-point operations with the two neighbour ranks; every leg has its own size (0: skipped)
+int rccl_exchange_v(kfx_comm* c, const void* send_lo, size_t bytes_send_lo, void* recv_lo, size_t bytes_recv_lo, const void* send_hi, size_t bytes_send_hi,
+                    void* recv_hi, size_t bytes_recv_hi, kfx_stream stream)
 {
     RcclImpl* im = static_cast<RcclImpl*>(c->impl);
     hipStream_t s = (hipStream_t)stream;
-    const bool lo = c->rank > 0 && bytes_lo, hi = c->rank + 1 < c->world && bytes_hi;
-    if (!lo && !hi) return 0;
+    const bool has_lo = c->rank > 0, has_hi = c->rank + 1 < c->world;
+    const bool sl = has_lo && bytes_send_lo, rl = has_lo && bytes_recv_lo, sh = has_hi && bytes_send_hi, rh = has_hi && bytes_recv_hi;
+    if (!sl && !rl && !sh && !rh) return 0;
+    if ((sl && !send_lo) || (rl && !recv_lo) || (sh && !send_hi) || (rh && !recv_hi)) return KFX_E_NULL;
     ncclResult_t r = ncclGroupStart();
-    if (r == ncclSuccess && lo) r = ncclSend(send_lo, bytes_lo, ncclInt8, c->rank - 1, im->comm, s);
-    if (r == ncclSuccess && lo) r = ncclRecv(recv_lo, bytes_lo, ncclInt8, c->rank - 1, im->comm, s);
-    if (r == ncclSuccess && hi) r = ncclSend(send_hi, bytes_hi, ncclInt8, c->rank + 1, im->comm, s);
-    if (r == ncclSuccess && hi) r = ncclRecv(recv_hi, bytes_hi, ncclInt8, c->rank + 1, im->comm, s);
+    if (r == ncclSuccess && sl) r = ncclSend(send_lo, bytes_send_lo, ncclInt8, c->rank - 1, im->comm, s);
+    if (r == ncclSuccess && rl) r = ncclRecv(recv_lo, bytes_recv_lo, ncclInt8, c->rank - 1, im->comm, s);
+    if (r == ncclSuccess && sh) r = ncclSend(send_hi, bytes_send_hi, ncclInt8, c->rank + 1, im->comm, s);
+    if (r == ncclSuccess && rh) r = ncclRecv(recv_hi, bytes_recv_hi, ncclInt8, c->rank + 1, im->comm, s);
     const ncclResult_t e = ncclGroupEnd();
     return nccl_status(r != ncclSuccess ? r : e);
+}
+
+int rccl_exchange(kfx_comm* c, const void* send_lo, void* recv_lo, size_t bytes_lo, const void* send_hi, void* recv_hi, size_t bytes_hi,
+                  kfx_stream stream)
+{
+    return rccl_exchange_v(c, send_lo, bytes_lo, recv_lo, bytes_lo, send_hi, bytes_hi, recv_hi, bytes_hi, stream);
 }
 
 int rccl_broadcast(kfx_comm* c, void* buf, size_t bytes, int root, kfx_stream stream)
@@ -295,6 +304,7 @@ extern "C" int kfx_comm_create_rccl(kfx_comm* comm, int rank, int world, const c
     comm->broadcast = rccl_broadcast;
     comm->all_to_all = rccl_all_to_all;
     comm->all_gather = rccl_all_gather;
+    comm->exchange_v = rccl_exchange_v;
     if (rank == 0 && world > 1) { // every rank has joined once ncclCommInitRank returns: the file has served its purpose
         rccl_barrier(comm);
         unlink(rendezvous_file);

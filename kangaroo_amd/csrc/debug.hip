@@ -409,6 +409,15 @@ extern "C" int kfx_debug_march_probe(const kfx_volume* vol, int mode, int steps,
     if (mode < 0 || mode > 3 || steps < 1 || S < 1 || S + 1 > PROBE_MAXZ || workgroups < 1) return set_error(KFX_E_RANGE, "kfx_debug_march_probe: parameters");
     if ((int)vol->d < steps + S + 4 || vol->w < 2 * PROBE_BX || vol->h < 2 * PROBE_BY) return set_error(KFX_E_SHAPE, "kfx_debug_march_probe: volume too small for the march");
     if ((double)vol->img_pitch * (double)vol->d >= 4294967296.0) return set_error(KFX_E_RANGE, "kfx_debug_march_probe: volumes below 4 GiB");
+    // a workgroup's rays span 31 r cells in x and 7 r in y from its tile's corner (+ the mode-0 drift of 0.05 / 0.02 cells per
+    // step): modes 1-3 read them from the 56 x 20-cell LDS box (corner at -1, the sample's +1 cell), mode 0 from the volume
+    if (!(r > 0.f) || !(r <= 1.6f)) return set_error(KFX_E_RANGE, "kfx_debug_march_probe: r in (0, 1.6]");
+    if (mode == 0) {
+        const int tiles_x = (int)vol->w - 8 > PROBE_BX + 8 ? ((int)vol->w - 8) / (PROBE_BX + 8) : 1;
+        const float x_far = 4.f + (float)((tiles_x - 1) * (PROBE_BX + 8)) + 31.f * r + 0.05f * (float)steps + 2.f;
+        const float y_far = 4.f + (float)((int)vol->h - PROBE_BY - 8 > 1 ? (int)vol->h - PROBE_BY - 9 : 0) + 7.f * r + 0.02f * (float)steps + 2.f;
+        if (!(x_far < (float)vol->w) || !(y_far < (float)vol->h)) return set_error(KFX_E_SHAPE, "kfx_debug_march_probe: the drifting rays of mode 0 would leave the volume");
+    }
     ProbeParams p;
     p.base = (const unsigned char*)vol->ptr; p.pitch = (unsigned)vol->pitch; p.img = (unsigned)vol->img_pitch;
     p.W = (int)vol->w; p.H = (int)vol->h; p.D = (int)vol->d;

@@ -667,7 +667,16 @@ __global__ __launch_bounds__(256) void k_raycast_sdf_levels_classes(const RayPar
 // ranks' states with one integer SUM all-reduce of the touched pixels' planes 0-4.
 // ---------------------------------------------------------------------------------------
 struct SlabRay {
-    float* state;       // 9 planes of h*w floats
+    // State of tile t (rows [t R, (t + 1) R) of the image, pixel q = (v - t R) w + u of it): march planes 0-4 at
+    // state + (t * 5 + k) * P + q, normal / shade planes 5-8 at result + (t * 4 + k - 5) * P + q.  One tile of R = h rows with
+    // P = w h and result = state + 5 P is the dense [9][h w] layout of kfx_raycast_sdf_slab.
+    float* state;
+    float* result;
+    size_t P;           // plane stride in pixels (>= R w)
+    int R;              // rows per tile
+    int v0, v1;         // rows this launch processes
+    int* fin;           // optional, dense w h: set where THIS launch gives a ray its final status (and, with claim_misses, where
+    int claim_misses;   //   the initialisation finds a ray that never enters the box: one rank answers for those)
     int own_lo, own_hi; // owned trilinear base cells (global plane indices)
     int avail_lo, avail_hi; // planes stored locally (global indices)
     int init;           // 1: (re)initialise the state from the ray / box intersection
@@ -689,10 +698,13 @@ __global__ __launch_bounds__(256) void k_raycast_sdf_slab(const RayParams p, con
 {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int u = blockIdx.x * 64 + (wv & 1) * 32 + (lane & 31); // wave = 32 x 2 pixels, as k_raycast_sdf's default
-    const int v = blockIdx.y * 4 + (wv >> 1) * 2 + (lane >> 5);
-    if (u >= p.w || v >= p.h) return;
-    const size_t plane = (size_t)p.w * p.h;
-    float* st = sl.state + (size_t)v * p.w + u; // plane k at st[k * plane]
+    const int v = sl.v0 + blockIdx.y * 4 + (wv >> 1) * 2 + (lane >> 5);
+    if (u >= p.w || v >= sl.v1) return;
+    const size_t plane = sl.P;
+    const int tile = v / sl.R;
+    const size_t q = (size_t)(v - tile * sl.R) * p.w + u;
+    float* st = sl.state + (size_t)tile * 5 * plane + q;   // plane k at st[k * plane]
+    float* rs = sl.result + (size_t)tile * 4 * plane + q;  // normal x / y / z, shade
 
     const V3 c_w = v3(p.T.m[3], p.T.m[7], p.T.m[11]);
     const V3 ray_c = v3(((float)u - p.K.u0) / p.K.fu, ((float)v - p.K.v0) / p.K.fv, 1.0f);
@@ -710,7 +722,8 @@ __global__ __launch_bounds__(256) void k_raycast_sdf_slab(const RayParams p, con
         last_sdf = __builtin_nanf("");
         delta = 0.f;
         status = (max_tmin < min_tmax) ? 0.f : 2.f;
-        st[5 * plane] = 0.f; st[6 * plane] = 0.f; st[7 * plane] = 0.f; st[8 * plane] = 0.f;
+        rs[0] = 0.f; rs[plane] = 0.f; rs[2 * plane] = 0.f; rs[3 * plane] = 0.f;
+        if (sl.fin) sl.fin[(size_t)v * p.w + u] = (sl.claim_misses && status == 2.f) ? 1 : 0;
     } else {
         lambda = st[0]; last_sdf = st[plane]; delta = st[2 * plane]; status = st[3 * plane];
     }
@@ -746,13 +759,15 @@ __global__ __launch_bounds__(256) void k_raycast_sdf_slab(const RayParams p, con
             const float len = length(g);
             const V3 n_w = len > 0 ? div_s(g, len) : v3(0.f, 0.f, 1.f);
             const V3 n_c = so3_mul_inv(p.T, n_w);
-            st[5 * plane] = n_c.x; st[6 * plane] = n_c.y; st[7 * plane] = n_c.z;
-            st[8 * plane] = phong(ray_c * lambda, n_c);
+            rs[0] = n_c.x; rs[plane] = n_c.y; rs[2 * plane] = n_c.z;
+            rs[3 * plane] = phong(ray_c * lambda, n_c);
             status = 1.f;
         }
     }
+    const bool changed = lambda != lambda_in || status != status_in;
     st[0] = lambda; st[plane] = last_sdf; st[2 * plane] = delta; st[3 * plane] = status;
-    st[4 * plane] = (lambda != lambda_in || status != status_in) ? 1.0f : 0.0f;
+    st[4 * plane] = changed ? 1.0f : 0.0f;
+    if (sl.fin && changed && (status == 1.f || status == 2.f)) sl.fin[(size_t)v * p.w + u] = 1;
 }
 
 // state -> the three output images (hit: depth / normal / shade; otherwise NaN / 0 / 0)
@@ -895,6 +910,10 @@ static int class_view(ClassView& cl, size_t* lds_bytes, int* usable, kfx_sdf_sum
     if (cl.top_n > top_env) cl.top_n = top_env;
     cl.lds_words = cl.words + (cl.top_n > 0 ? w6 : 0) + (cl.top_n > 1 ? w7 : 0);
     *lds_bytes = (size_t)cl.lds_words * sizeof(unsigned);
+    // the launch asks for the staged tables PLUS the derived levels PLUS the kernels' static LDS (RayParams, TopLevels, the
+    // levels kernel's table): the whole must stay below the 64 KiB a launch may have, or the launch fails where the plain march
+    // would have worked (round-4 advice: the 60 KiB test above sees the staged words only)
+    if (*lds_bytes + sizeof(RayParams) + sizeof(TopLevels) + 2048 > 64 * 1024) return 0;
     *usable = 1;
     return 0;
 }
@@ -1037,7 +1056,12 @@ extern "C" int kfx_raycast_sdf_count_tracked(const kfx_volume* vol, kfx_sdf_summ
     ClassView cl;
     size_t cl_bytes = 0;
     int usable = 0;
-    if (int e = class_view(cl, &cl_bytes, &usable, summary, vol, p, stream)) return e;
+    // a diagnostics call must not steer the calls that follow: class_view() advances the plain / table choice's call counter
+    // (the tables it may build are a pure function of the summary: harmless)
+    const unsigned plain_calls = summary->plain_calls;
+    const int ce = class_view(cl, &cl_bytes, &usable, summary, vol, p, stream);
+    summary->plain_calls = plain_calls;
+    if (ce) return ce;
     const dim3 grid(ceil_div(p.w, 64), ceil_div(p.h, 4));
     if (usable) hipLaunchKernelGGL(k_raycast_sdf_classes_count<RayF32>, grid, dim3(256), cl_bytes, (hipStream_t)stream, p, cl, d_bitmap, d_counters);
     else hipLaunchKernelGGL(k_raycast_sdf_count<RayF32>, grid, dim3(256), 0, (hipStream_t)stream, p, d_bitmap, d_counters);   // what the tracked call would launch
@@ -1094,15 +1118,17 @@ extern "C" int kfx_raycast_sdf_color(const kfx_image* depth, const kfx_image* no
 // [slab->z_offset, slab->z_offset + vol->d) of the full volume described by `slab`; the rank owns the
 // trilinear base cells [own_lo, own_hi).  `state` is KFX_RAY_STATE_PLANES dense planes of h*w floats; init != 0 starts the rays.
 template <typename CELL>
-static int raycast_slab_launch(float* state, int init, const kfx_volume* vol, const kfx_slab* slab, int own_lo, int own_hi,
+static int raycast_slab_launch(const SlabRay& geom, const kfx_volume* vol, const kfx_slab* slab, int own_lo, int own_hi,
                                     int w, int h, const float T_wc[12], const float K[4], float near, float far,
                                     float trunc_dist, int subpix, kfx_stream stream)
 {
-    if (!state || !vol || !vol->ptr || !slab || !T_wc || !K) return set_error(KFX_E_NULL, "RaycastSdf(slab): null argument");
-    if (w <= 0 || h <= 0) return 0;
+    if (!geom.state || !geom.result || !vol || !vol->ptr || !slab || !T_wc || !K) return set_error(KFX_E_NULL, "RaycastSdf(slab): null argument");
+    if (w <= 0 || h <= 0 || geom.v1 <= geom.v0) return 0;
+    if (geom.R < 1 || geom.v0 < 0 || geom.v1 > h || geom.P < (size_t)geom.R * (size_t)w) return set_error(KFX_E_SHAPE, "RaycastSdf(slab): tile geometry");
     if (slab->full_d < 3 || slab->z_offset + vol->d > slab->full_d || vol->w < 3 || vol->h < 3)
         return set_error(KFX_E_SHAPE, "RaycastSdf(slab): slab outside the full volume");
-    if ((((uintptr_t)vol->ptr | vol->pitch | vol->img_pitch) & (CELL::BYTES - 1)) || ((uintptr_t)state & 3)) return set_error(KFX_E_ALIGN, "RaycastSdf(slab): alignment");
+    if ((((uintptr_t)vol->ptr | vol->pitch | vol->img_pitch) & (CELL::BYTES - 1)) || (((uintptr_t)geom.state | (uintptr_t)geom.result | (uintptr_t)geom.fin) & 3))
+        return set_error(KFX_E_ALIGN, "RaycastSdf(slab): alignment");
     RayParams p;
     // full-volume geometry, virtual base pointer (never dereferenced outside [avail_lo, avail_hi))
     p.vol.ptr = (unsigned char*)vol->ptr - (ptrdiff_t)slab->z_offset * (ptrdiff_t)vol->img_pitch;
@@ -1130,24 +1156,46 @@ static int raycast_slab_launch(float* state, int init, const kfx_volume* vol, co
     p.subpix = subpix ? 1 : 0;
     p.tile_log2w = 3;
     p.wg_log2x = 1;
-    SlabRay sl{state, own_lo, own_hi, (int)slab->z_offset, (int)(slab->z_offset + vol->d), init ? 1 : 0};
-    dim3 grid(ceil_div(w, 64), ceil_div(h, 4));
+    SlabRay sl = geom;
+    sl.own_lo = own_lo; sl.own_hi = own_hi;
+    sl.avail_lo = (int)slab->z_offset; sl.avail_hi = (int)(slab->z_offset + vol->d);
+    dim3 grid(ceil_div(w, 64), ceil_div(sl.v1 - sl.v0, 4));
     hipLaunchKernelGGL(k_raycast_sdf_slab<CELL>, grid, dim3(256), 0, (hipStream_t)stream, p, sl);
     return check_launch("kfx_raycast_sdf_slab");
+}
+
+// the dense [9][h w] state of kfx_raycast_sdf_slab as one tile
+static SlabRay dense_state(float* state, int init, int w, int h)
+{
+    SlabRay g{};
+    const size_t n = (size_t)(w > 0 ? w : 0) * (size_t)(h > 0 ? h : 0);
+    g.state = state; g.result = state ? state + 5 * n : nullptr; g.P = n; g.R = h > 0 ? h : 1; g.v0 = 0; g.v1 = h; g.fin = nullptr; g.claim_misses = 0;
+    g.init = init ? 1 : 0;
+    return g;
+}
+
+extern "C" int kfx_raycast_sdf_slab_tiles(float* state, float* result, size_t plane_stride, int rows_per_tile, int v0, int v1, int init, int* fin,
+                                          int claim_misses, const kfx_volume* vol, const kfx_slab* slab, int own_lo, int own_hi, int w, int h,
+                                          const float T_wc[12], const float K[4], float near, float far, float trunc_dist, int subpix, kfx_stream stream)
+{
+    SlabRay g{};
+    g.state = state; g.result = result; g.P = plane_stride; g.R = rows_per_tile; g.v0 = v0; g.v1 = v1; g.fin = fin; g.claim_misses = claim_misses ? 1 : 0;
+    g.init = init ? 1 : 0;
+    return raycast_slab_launch<RayF32>(g, vol, slab, own_lo, own_hi, w, h, T_wc, K, near, far, trunc_dist, subpix, stream);
 }
 
 extern "C" int kfx_raycast_sdf_slab(float* state, int init, const kfx_volume* vol, const kfx_slab* slab, int own_lo, int own_hi,
                                     int w, int h, const float T_wc[12], const float K[4], float near, float far,
                                     float trunc_dist, int subpix, kfx_stream stream)
 {
-    return raycast_slab_launch<RayF32>(state, init, vol, slab, own_lo, own_hi, w, h, T_wc, K, near, far, trunc_dist, subpix, stream);
+    return raycast_slab_launch<RayF32>(dense_state(state, init, w, h), vol, slab, own_lo, own_hi, w, h, T_wc, K, near, far, trunc_dist, subpix, stream);
 }
 
 extern "C" int kfx_raycast_sdf_slab_h(float* state, int init, const kfx_volume* vol, const kfx_slab* slab, int own_lo, int own_hi,
                                       int w, int h, const float T_wc[12], const float K[4], float near, float far,
                                       float trunc_dist, int subpix, kfx_stream stream)
 {
-    return raycast_slab_launch<RayF16>(state, init, vol, slab, own_lo, own_hi, w, h, T_wc, K, near, far, trunc_dist, subpix, stream);
+    return raycast_slab_launch<RayF16>(dense_state(state, init, w, h), vol, slab, own_lo, own_hi, w, h, T_wc, K, near, far, trunc_dist, subpix, stream);
 }
 
 extern "C" int kfx_raycast_state_to_images(const kfx_image* depth, const kfx_image* norm, const kfx_image* img, const float* state,

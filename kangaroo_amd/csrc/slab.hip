@@ -106,6 +106,81 @@ __global__ __launch_bounds__(256) void k_handover_finish(int* __restrict__ state
     if (m != 0ull && (threadIdx.x & 63) == 0) atomicAdd(open, __popcll(m));
 }
 
+// ---- tile-pipelined hand-over (kfx_slab_raycast_exact_tiled) ---------------------------------------------------------
+// State per row-tile t (kfx.h, kfx_raycast_sdf_slab_tiles): march planes at M + (t * 5 + k) * P, results at Rz + (t * 4 + k) * P.
+// "Newer wins": a ray's copies on different ranks are snapshots of ONE march; status 1 / 2 (final) is later than 3 (hit, normal
+// pending) is later than 0 (marching), and of two marching snapshots the one with the larger lambda is later (every step adds a
+// positive delta).  A rank never advances a stale copy -- it advances a ray only while the base plane of its current sample is
+// one it owns, and a kernel run leaves no marching ray of the tile inside the rank's own planes -- so adopting the neighbour's
+// newer, still-open snapshot is all the merging there is.
+__device__ __forceinline__ int snapshot_order(float status) { return status == 0.0f ? 0 : (status == 3.0f ? 1 : 2); }
+
+// mine, a, b: [tiles][5][P] (a / b may be null); pixel i < count of tile blockIdx.y
+__global__ __launch_bounds__(256) void k_adopt_newer(int* __restrict__ mine, const int* __restrict__ a, const int* __restrict__ b, size_t P, size_t count)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= count) return;
+    const size_t base = (size_t)blockIdx.y * 5 * P + i;
+    float m_lambda = __int_as_float(mine[base]), m_status = __int_as_float(mine[base + 3 * P]);
+    bool took = false;
+    int t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int* src = k ? b : a;
+        if (!src) continue;
+        const float n_status = __int_as_float(src[base + 3 * P]);
+        if (!(n_status == 0.0f || n_status == 3.0f)) continue;   // final snapshots stay with the rank that finalised them
+        const float n_lambda = __int_as_float(src[base]);
+        const int on = snapshot_order(n_status), om = snapshot_order(m_status);
+        if (on > om || (on == 0 && om == 0 && n_lambda > m_lambda)) {
+            t0 = src[base]; t1 = src[base + P]; t2 = src[base + 2 * P]; t3 = src[base + 3 * P];
+            m_lambda = n_lambda; m_status = n_status;
+            took = true;
+        }
+    }
+    if (took) { mine[base] = t0; mine[base + P] = t1; mine[base + 2 * P] = t2; mine[base + 3 * P] = t3; }
+}
+
+// this rank's contribution to the final images, dense [6][n]: lambda, status, normal, shade of the pixels it finalised
+__global__ __launch_bounds__(256) void k_tiles_contrib(const int* __restrict__ M, const int* __restrict__ Rz, const int* __restrict__ fin,
+                                                       int* __restrict__ contrib, int w, int h, int R, size_t P)
+{
+    const int u = blockIdx.x * 64 + (threadIdx.x & 63), v = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (u >= w || v >= h) return;
+    const size_t n = (size_t)w * h, i = (size_t)v * w + u;
+    const int t = v / R;
+    const size_t q = (size_t)(v - t * R) * w + u;
+    const int* st = M + (size_t)t * 5 * P + q;
+    const int* rs = Rz + (size_t)t * 4 * P + q;
+    const bool mine = fin[i] != 0;
+    contrib[i] = mine ? st[0] : 0;
+    contrib[n + i] = mine ? st[3 * P] : 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) contrib[(2 + k) * n + i] = mine ? rs[k * P] : 0;
+}
+
+struct OutImages { unsigned char *dptr, *nptr, *iptr; size_t dpitch, npitch, ipitch; int w, h; };
+
+// the summed contributions -> depth / normal / shade images (cu_raycast.cu:92-102); *open += pixels without a final status
+__global__ __launch_bounds__(256) void k_tiles_finish(const OutImages o, const int* __restrict__ contrib, int* __restrict__ open)
+{
+    const int u = blockIdx.x * 64 + (threadIdx.x & 63), v = blockIdx.y * 4 + (threadIdx.x >> 6);
+    bool bad = false;
+    if (u < o.w && v < o.h) {
+        const size_t n = (size_t)o.w * o.h, i = (size_t)v * o.w + u;
+        const float depth = __int_as_float(contrib[i]), status = __int_as_float(contrib[n + i]);
+        bad = !(status == 1.0f || status == 2.0f);
+        const bool hit = status == 1.0f && depth > 0.0f;
+        *(reinterpret_cast<float*>(o.dptr + (size_t)v * o.dpitch) + u) = hit ? depth : __builtin_nanf("");
+        *(reinterpret_cast<float*>(o.iptr + (size_t)v * o.ipitch) + u) = hit ? __int_as_float(contrib[5 * n + i]) : 0.0f;
+        *(reinterpret_cast<float4*>(o.nptr + (size_t)v * o.npitch) + u) =
+            hit ? make_float4(__int_as_float(contrib[2 * n + i]), __int_as_float(contrib[3 * n + i]), __int_as_float(contrib[4 * n + i]), 1.0f)
+                : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const unsigned long long m = __ballot(bad);
+    if (m != 0ull && (threadIdx.x & 63) == 0) atomicAdd(open, __popcll(m));
+}
+
 // ---- threads transport: reduction over the ranks' buffers by one kernel -------------------------------------------
 constexpr int MAX_THREAD_RANKS = 16;
 struct PtrList { void* p[MAX_THREAD_RANKS]; };
@@ -133,7 +208,7 @@ struct ThreadGroup {
     void* buf[MAX_THREAD_RANKS];
     const void* send_lo[MAX_THREAD_RANKS];
     const void* send_hi[MAX_THREAD_RANKS];
-    size_t bytes_lo[MAX_THREAD_RANKS], bytes_hi[MAX_THREAD_RANKS];
+    size_t bytes_lo[MAX_THREAD_RANKS], bytes_hi[MAX_THREAD_RANKS];   // what a rank SENDS down / up
     // per-rank error of a collective, double-buffered by the collective's sequence parity: a rank that has left collective k
     // and already entered k + 1 posts into the other set while a slower peer may still be reading k's in group_status(); the
     // set of k is written again in k + 2, which every rank enters only after it returned from k + 1 -- whose barriers all
@@ -200,31 +275,41 @@ static int threads_all_reduce(kfx_comm* c, void* buf, size_t count, int op, kfx_
     return group_status(g, par);
 }
 
-static int threads_exchange(kfx_comm* c, const void* send_lo, void* recv_lo, size_t bytes_lo, const void* send_hi, void* recv_hi,
-                            size_t bytes_hi, kfx_stream stream)
+static int threads_exchange_v(kfx_comm* c, const void* send_lo, size_t bytes_send_lo, void* recv_lo, size_t bytes_recv_lo, const void* send_hi,
+                              size_t bytes_send_hi, void* recv_hi, size_t bytes_recv_hi, kfx_stream stream)
 {
     ThreadGroup* g = static_cast<ThreadGroup*>(c->impl);
     const int r = c->rank;
     int st = hip_status(hipStreamSynchronize((hipStream_t)stream), "kfx_comm(threads) exchange");
     const int par = (int)(g->seq[r]++ & 1u);
     g->err[par][r].store(st);
-    g->send_lo[r] = send_lo; g->bytes_lo[r] = bytes_lo;
-    g->send_hi[r] = send_hi; g->bytes_hi[r] = bytes_hi;
+    g->send_lo[r] = send_lo; g->bytes_lo[r] = r > 0 ? bytes_send_lo : 0;
+    g->send_hi[r] = send_hi; g->bytes_hi[r] = r + 1 < g->world ? bytes_send_hi : 0;
     g->wait_all();
     hipStream_t s = (hipStream_t)stream;
-    if (!st && r > 0 && bytes_lo && g->err[par][r - 1].load() == 0) { // what rank - 1 sends upwards
-        if (g->bytes_hi[r - 1] != bytes_lo) st = set_error(KFX_E_SHAPE, "kfx_comm exchange: neighbours disagree on the byte count");
-        else st = hip_status(hipMemcpyAsync(recv_lo, g->send_hi[r - 1], bytes_lo, hipMemcpyDeviceToDevice, s), "kfx_comm(threads) exchange");
+    if (!st && r > 0 && bytes_recv_lo && g->err[par][r - 1].load() == 0) { // what rank - 1 sends upwards
+        if (g->bytes_hi[r - 1] != bytes_recv_lo) st = set_error(KFX_E_SHAPE, "kfx_comm exchange: neighbours disagree on the byte count");
+        else st = hip_status(hipMemcpyAsync(recv_lo, g->send_hi[r - 1], bytes_recv_lo, hipMemcpyDeviceToDevice, s), "kfx_comm(threads) exchange");
+    } else if (!st && r > 0 && g->err[par][r - 1].load() == 0 && g->bytes_hi[r - 1] != 0) {
+        st = set_error(KFX_E_SHAPE, "kfx_comm exchange: the lower neighbour sends what this rank does not receive");
     }
-    if (!st && r + 1 < g->world && bytes_hi && g->err[par][r + 1].load() == 0) { // what rank + 1 sends downwards
-        if (g->bytes_lo[r + 1] != bytes_hi) st = set_error(KFX_E_SHAPE, "kfx_comm exchange: neighbours disagree on the byte count");
-        else st = hip_status(hipMemcpyAsync(recv_hi, g->send_lo[r + 1], bytes_hi, hipMemcpyDeviceToDevice, s), "kfx_comm(threads) exchange");
+    if (!st && r + 1 < g->world && bytes_recv_hi && g->err[par][r + 1].load() == 0) { // what rank + 1 sends downwards
+        if (g->bytes_lo[r + 1] != bytes_recv_hi) st = set_error(KFX_E_SHAPE, "kfx_comm exchange: neighbours disagree on the byte count");
+        else st = hip_status(hipMemcpyAsync(recv_hi, g->send_lo[r + 1], bytes_recv_hi, hipMemcpyDeviceToDevice, s), "kfx_comm(threads) exchange");
+    } else if (!st && r + 1 < g->world && g->err[par][r + 1].load() == 0 && g->bytes_lo[r + 1] != 0) {
+        st = set_error(KFX_E_SHAPE, "kfx_comm exchange: the upper neighbour sends what this rank does not receive");
     }
     if (!st) st = hip_status(hipStreamSynchronize(s), "kfx_comm(threads) exchange");
     if (st) g->err[par][r].store(st);   // (atomic: a neighbour may be reading the slot; it sees 0 or an error, and every rank
                                         //  reads the final value after the barrier below)
     g->wait_all(); // nobody reuses a send buffer before its reader is done
     return group_status(g, par);
+}
+
+static int threads_exchange(kfx_comm* c, const void* send_lo, void* recv_lo, size_t bytes_lo, const void* send_hi, void* recv_hi,
+                            size_t bytes_hi, kfx_stream stream)
+{
+    return threads_exchange_v(c, send_lo, bytes_lo, recv_lo, bytes_lo, send_hi, bytes_hi, recv_hi, bytes_hi, stream);
 }
 
 static int threads_broadcast(kfx_comm* c, void* buf, size_t bytes, int root, kfx_stream stream)
@@ -311,7 +396,50 @@ extern "C" int kfx_comm_create_threads(kfx_comm* comms, int world)
         comms[r].broadcast = threads_broadcast;
         comms[r].all_to_all = threads_all_to_all;
         comms[r].all_gather = threads_all_gather;
+        comms[r].exchange_v = threads_exchange_v;
     }
+    return 0;
+}
+
+// ---- loop-back transport (kfx_slab.h): one rank of a `world`-rank job measured by itself ------------------------------
+namespace {
+int loop_copy(void* dst, const void* src, size_t bytes, kfx_stream stream)
+{
+    if (!bytes || !dst || !src || dst == src) return 0;
+    return hip_status(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream), "kfx_comm(loopback)");
+}
+int loop_all_reduce(kfx_comm*, void*, size_t, int, kfx_stream) { return 0; }   // nothing arrives: the buffer is the "sum"
+int loop_exchange_v(kfx_comm* c, const void* send_lo, size_t bsl, void* recv_lo, size_t brl, const void* send_hi, size_t bsh, void* recv_hi,
+                    size_t brh, kfx_stream stream)
+{
+    // what would arrive from below is as large as what this rank sends up, and vice versa: the own buffers come back
+    if (c->rank > 0) if (int e = loop_copy(recv_lo, send_hi ? send_hi : send_lo, brl < (send_hi ? bsh : bsl) ? brl : (send_hi ? bsh : bsl), stream)) return e;
+    if (c->rank + 1 < c->world) if (int e = loop_copy(recv_hi, send_lo ? send_lo : send_hi, brh < (send_lo ? bsl : bsh) ? brh : (send_lo ? bsl : bsh), stream)) return e;
+    return 0;
+}
+int loop_exchange(kfx_comm* c, const void* send_lo, void* recv_lo, size_t bytes_lo, const void* send_hi, void* recv_hi, size_t bytes_hi, kfx_stream stream)
+{
+    return loop_exchange_v(c, send_lo, bytes_lo, recv_lo, bytes_lo, send_hi, bytes_hi, recv_hi, bytes_hi, stream);
+}
+int loop_barrier(kfx_comm*) { return hip_status(hipDeviceSynchronize(), "kfx_comm(loopback) barrier"); }
+void loop_destroy(kfx_comm* c) { if (c) c->impl = nullptr; }
+int loop_broadcast(kfx_comm*, void*, size_t, int, kfx_stream) { return 0; }
+int loop_all_to_all(kfx_comm* c, const void* send, void* recv, size_t bytes, kfx_stream stream) { return loop_copy(recv, send, bytes * (size_t)c->world, stream); }
+int loop_all_gather(kfx_comm* c, const void* send, void* recv, size_t bytes, kfx_stream stream)
+{
+    for (int r = 0; r < c->world; ++r)
+        if (int e = loop_copy(static_cast<unsigned char*>(recv) + (size_t)r * bytes, send, bytes, stream)) return e;
+    return 0;
+}
+} // namespace
+
+extern "C" int kfx_comm_create_loopback(kfx_comm* comm, int rank, int world)
+{
+    if (!comm) return set_error(KFX_E_NULL, "kfx_comm_create_loopback: null comm");
+    if (world < 1 || rank < 0 || rank >= world) return set_error(KFX_E_RANGE, "kfx_comm_create_loopback: 0 <= rank < world");
+    comm->rank = rank; comm->world = world; comm->impl = nullptr;
+    comm->all_reduce = loop_all_reduce; comm->exchange = loop_exchange; comm->barrier = loop_barrier; comm->destroy = loop_destroy;
+    comm->broadcast = loop_broadcast; comm->all_to_all = loop_all_to_all; comm->all_gather = loop_all_gather; comm->exchange_v = loop_exchange_v;
     return 0;
 }
 
@@ -414,6 +542,9 @@ extern "C" int kfx_slab_composite_direct(const kfx_image* depth, const kfx_image
 {
     if (!comm || !depth) return set_error(KFX_E_NULL, "kfx_slab_composite_direct: null argument");
     if (comm->world == 1) return 0;
+    // argument errors every rank makes alike come back before any collective; from here on a LOCAL failure (a launch error) must
+    // not keep this rank out of the two collectives its peers enter -- they would wait for ever (round-4 advice): it is
+    // remembered, the collectives are entered all the same, and the first error is returned at the end
     if (!scratch) return set_error(KFX_E_NULL, "kfx_slab_composite_direct: null scratch");
     if (!comm->all_to_all || !comm->all_gather) return set_error(KFX_E_RANGE, "kfx_slab_composite_direct: the transport has no all_to_all / all_gather");
     const int W = comm->world;
@@ -421,10 +552,13 @@ extern "C" int kfx_slab_composite_direct(const kfx_image* depth, const kfx_image
     float* send = static_cast<float*>(scratch);
     float* recv = send + (size_t)W * strip;
     float* merged = recv + (size_t)W * strip;
-    if (int e = kfx_composite_strips_pack(depth, norm, img, send, 0, W, stream)) return e;
-    if (int e = comm->all_to_all(comm, send, recv, strip * sizeof(float), stream)) return e;
-    if (int e = kfx_composite_strips_merge(recv, merged, S, 0, W, stream)) return e;
-    if (int e = comm->all_gather(comm, merged, recv, strip * sizeof(float), stream)) return e;
+    int status = 0;
+    auto note = [&](int e) { if (e && !status) status = e; };
+    note(kfx_composite_strips_pack(depth, norm, img, send, 0, W, stream));
+    note(comm->all_to_all(comm, send, recv, strip * sizeof(float), stream));
+    note(kfx_composite_strips_merge(recv, merged, S, 0, W, stream));
+    note(comm->all_gather(comm, merged, recv, strip * sizeof(float), stream));
+    if (status) return status;
     return kfx_composite_strips_unpack(depth, norm, img, recv, 0, W, stream);
 }
 
@@ -534,4 +668,133 @@ extern "C" int kfx_slab_raycast_exact_allreduce(const kfx_image* depth, const kf
         if (int e = comm->all_reduce(comm, istate + 5 * n, 4 * n, KFX_COMM_SUM_I32, stream)) return e;
     if (rounds_out) *rounds_out = rounds;
     return kfx_raycast_state_to_images(depth, norm, img, state, stream);
+}
+
+// ---- the hand-over pipelined over image row-tiles (kfx_slab.h) -------------------------------------------------------------
+namespace {
+struct TiledScratch {
+    size_t P, n;       // plane stride of a tile (pixels), pixels of the image
+    int R, T;          // rows per tile, tiles
+    int *M, *Rz, *from_lo, *from_hi, *fin, *contrib, *open;
+};
+// the scratch buffer's parts; returns its size in ints (scratch may be null: sizes only)
+size_t tiled_layout(TiledScratch& t, void* scratch, size_t w, size_t h, int tiles)
+{
+    t.T = tiles < 1 ? 1 : (tiles > (int)h ? (int)(h ? h : 1) : tiles);
+    t.R = (int)((h + (size_t)t.T - 1) / (size_t)t.T);
+    t.T = (int)((h + (size_t)t.R - 1) / (size_t)(t.R ? t.R : 1));   // (tiles that are not empty)
+    t.P = ((size_t)t.R * w + 63) / 64 * 64;
+    t.n = w * h;
+    int* base = static_cast<int*>(scratch);
+    size_t o = 0;
+    const auto take = [&](size_t ints) { int* q = base ? base + o : nullptr; o += ints; return q; };
+    t.M = take((size_t)t.T * 5 * t.P);
+    t.Rz = take((size_t)t.T * 4 * t.P);
+    t.from_lo = take((size_t)t.T * 5 * t.P);
+    t.from_hi = take((size_t)t.T * 5 * t.P);
+    t.fin = take((t.n + 63) / 64 * 64);
+    t.contrib = take((6 * t.n + 63) / 64 * 64);
+    t.open = take(64);
+    return o;
+}
+} // namespace
+
+extern "C" size_t kfx_slab_exact_tiled_scratch_bytes(size_t w, size_t h, int tiles)
+{
+    if (w == 0 || h == 0) return 256;
+    TiledScratch t;
+    return tiled_layout(t, nullptr, w, h, tiles) * sizeof(int);
+}
+
+extern "C" int kfx_slab_raycast_exact_tiled(const kfx_image* depth, const kfx_image* norm, const kfx_image* img, void* scratch,
+                                            const kfx_volume* local, const kfx_slab_layout* L, const float T_wc[12], const float K[4],
+                                            float near, float far, float trunc_dist, int subpix, int tiles, kfx_comm* comm, kfx_stream stream,
+                                            int* h_open, int* steps_out)
+{
+    if (!depth || !norm || !img || !scratch || !local || !L || !comm || !T_wc || !K || !depth->ptr || !norm->ptr || !img->ptr)
+        return set_error(KFX_E_NULL, "kfx_slab_raycast_exact_tiled: null argument");
+    if (local->d != L->s1 - L->s0 || comm->rank != L->rank || comm->world != L->world)
+        return set_error(KFX_E_SHAPE, "kfx_slab_raycast_exact_tiled: volume / communicator do not match the layout");
+    if (depth->w < img->w || depth->h < img->h || norm->w < img->w || norm->h < img->h || depth->pitch < img->w * 4 || img->pitch < img->w * 4 ||
+        norm->pitch < img->w * 16)
+        return set_error(KFX_E_SHAPE, "kfx_slab_raycast_exact_tiled: image sizes");
+    if ((((uintptr_t)depth->ptr | depth->pitch | (uintptr_t)img->ptr | img->pitch) & 3) || (((uintptr_t)norm->ptr | norm->pitch) & 15) || ((uintptr_t)scratch & 15))
+        return set_error(KFX_E_ALIGN, "kfx_slab_raycast_exact_tiled: alignment");
+    const int world = comm->world, rank = comm->rank;
+    if (world > 1 && !comm->exchange_v) return set_error(KFX_E_RANGE, "kfx_slab_raycast_exact_tiled: the transport has no exchange_v");
+    const int w = (int)img->w, h = (int)img->h;
+    if (w == 0 || h == 0) return 0;
+    TiledScratch t;
+    tiled_layout(t, scratch, (size_t)w, (size_t)h, tiles);
+    const int T = t.T, R = t.R;
+    const size_t P = t.P, tile_bytes = 5 * P * sizeof(int);
+    hipStream_t s = (hipStream_t)stream;
+    const kfx_slab slab = {L->full_d, L->s0, L->full_zmin, L->full_zmax};
+    // a local failure must not keep this rank out of a collective its peers enter: remember it, go on, report it at the end
+    int status = 0;
+    auto note = [&](int e) { if (e && !status) status = e; };
+    auto march = [&](int v0, int v1, int init) {
+        note(kfx_raycast_sdf_slab_tiles(reinterpret_cast<float*>(t.M), reinterpret_cast<float*>(t.Rz), P, R, v0, v1, init, t.fin, rank == 0 ? 1 : 0, local, &slab,
+                                        (int)L->z0, (int)L->z1, w, h, T_wc, K, near, far, trunc_dist, subpix, stream));
+    };
+    auto rows_of = [&](int tile, int& v0, int& v1) { v0 = tile * R; v1 = v0 + R < h ? v0 + R : h; };
+    note(hip_status(hipMemsetAsync(t.open, 0, sizeof(int), s), "kfx_slab_raycast_exact_tiled"));
+    // every rank starts every ray itself (and marches those that begin in its own planes)
+    march(0, h, 1);
+    int steps = 0;
+    if (world > 1) {
+        const size_t cnt = (size_t)R * (size_t)w;
+        for (int d = 0; d < world + T - 1; ++d, ++steps) {
+            const int A = d - rank, B = d - (world - 1 - rank);   // the tiles the upward / downward token brings to this rank now
+            const bool a_ok = A >= 0 && A < T, b_ok = B >= 0 && B < T;
+            int v0, v1;
+            if (a_ok) { rows_of(A, v0, v1); march(v0, v1, 0); }
+            if (b_ok && !(a_ok && B == A)) { rows_of(B, v0, v1); march(v0, v1, 0); }
+            // pass the tokens on: tile A upwards, tile B downwards; what arrives is the tile this rank marches in the next step
+            const bool up = a_ok && rank + 1 < world, down = b_ok && rank > 0;
+            const bool from_below = rank > 0 && A + 1 >= 0 && A + 1 < T, from_above = rank + 1 < world && B + 1 >= 0 && B + 1 < T;
+            note(comm->exchange_v(comm, down ? t.M + (size_t)B * 5 * P : nullptr, down ? tile_bytes : 0, from_below ? t.from_lo : nullptr, from_below ? tile_bytes : 0,
+                                  up ? t.M + (size_t)A * 5 * P : nullptr, up ? tile_bytes : 0, from_above ? t.from_hi : nullptr, from_above ? tile_bytes : 0, stream));
+            if (from_below && from_above && A == B) {
+                hipLaunchKernelGGL(k_adopt_newer, dim3((unsigned)((cnt + 255) / 256), 1), dim3(256), 0, s, t.M + (size_t)(A + 1) * 5 * P, t.from_lo, t.from_hi, P, cnt);
+                note(check_launch("kfx_slab_raycast_exact_tiled"));
+            } else {
+                if (from_below) {
+                    hipLaunchKernelGGL(k_adopt_newer, dim3((unsigned)((cnt + 255) / 256), 1), dim3(256), 0, s, t.M + (size_t)(A + 1) * 5 * P, t.from_lo, (const int*)nullptr, P, cnt);
+                    note(check_launch("kfx_slab_raycast_exact_tiled"));
+                }
+                if (from_above) {
+                    hipLaunchKernelGGL(k_adopt_newer, dim3((unsigned)((cnt + 255) / 256), 1), dim3(256), 0, s, t.M + (size_t)(B + 1) * 5 * P, t.from_hi, (const int*)nullptr, P, cnt);
+                    note(check_launch("kfx_slab_raycast_exact_tiled"));
+                }
+            }
+        }
+        // one more stage over the whole image: a hit whose sub-step interpolation fell back across a slab boundary has its normal
+        // evaluated by the neighbour that owns the gradient's base plane
+        const size_t all = (size_t)T * tile_bytes;
+        note(comm->exchange_v(comm, rank > 0 ? t.M : nullptr, rank > 0 ? all : 0, rank > 0 ? t.from_lo : nullptr, rank > 0 ? all : 0,
+                              rank + 1 < world ? t.M : nullptr, rank + 1 < world ? all : 0, rank + 1 < world ? t.from_hi : nullptr, rank + 1 < world ? all : 0, stream));
+        hipLaunchKernelGGL(k_adopt_newer, dim3((unsigned)((cnt + 255) / 256), (unsigned)T), dim3(256), 0, s, t.M, rank > 0 ? t.from_lo : (const int*)nullptr,
+                           rank + 1 < world ? t.from_hi : (const int*)nullptr, P, cnt);
+        note(check_launch("kfx_slab_raycast_exact_tiled"));
+        march(0, h, 0);
+        ++steps;
+    }
+    const dim3 grid2(ceil_div(w, 64), ceil_div(h, 4));
+    hipLaunchKernelGGL(k_tiles_contrib, grid2, dim3(256), 0, s, t.M, t.Rz, t.fin, t.contrib, w, h, R, P);
+    note(check_launch("kfx_slab_raycast_exact_tiled"));
+    if (world > 1) note(comm->all_reduce(comm, t.contrib, 6 * t.n, KFX_COMM_SUM_I32, stream));
+    const OutImages out{(unsigned char*)depth->ptr, (unsigned char*)norm->ptr, (unsigned char*)img->ptr, depth->pitch, norm->pitch, img->pitch, w, h};
+    hipLaunchKernelGGL(k_tiles_finish, grid2, dim3(256), 0, s, out, t.contrib, t.open);
+    note(check_launch("kfx_slab_raycast_exact_tiled"));
+    if (steps_out) *steps_out = steps + 1;   // (+ the initialising march)
+    if (h_open) {
+        note(hip_status(hipMemcpyAsync(h_open, t.open, sizeof(int), hipMemcpyDeviceToHost, s), "kfx_slab_raycast_exact_tiled"));
+        return status;
+    }
+    int n_open = 0;
+    note(hip_status(hipMemcpyAsync(&n_open, t.open, sizeof(int), hipMemcpyDeviceToHost, s), "kfx_slab_raycast_exact_tiled"));
+    note(hip_status(hipStreamSynchronize(s), "kfx_slab_raycast_exact_tiled"));
+    if (!status && n_open) status = set_error(KFX_E_RANGE, "kfx_slab_raycast_exact_tiled: rays without a final status after the hand-over");
+    return status;
 }

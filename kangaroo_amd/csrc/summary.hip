@@ -179,7 +179,8 @@ __global__ __launch_bounds__(256) void k_summary_rebuild(float4* __restrict__ R,
                 hi = fmaxf(hi, fmaxf(a, b));
             }
         } else {
-            for (int x = x0; x < w; ++x) {
+            const int x1 = x0 + 8 < w ? x0 + 8 : w;   // this brick's eight cells (fewer in the volume's last brick)
+            for (int x = x0; x < x1; ++x) {
                 const float a = *reinterpret_cast<const float*>(row + (size_t)(x - x0) * 8);
                 nan = nan || a != a;
                 val = val || a == a;

@@ -360,8 +360,14 @@ class SlabPipeline(FramePipeline):
     USE_FRAME = False   # slabs: the operators take slab arguments and collectives sit between them
 
     def __init__(self, ops, dist, dims, boxmin, boxmax, w, h, halo="exchange", raycast="composite", kind="f32", overlap=False,
-                 inputs="replicate", images="all", merge="direct", **kw):
-        """halo = "exchange": every rank integrates only the planes it owns and the ghost planes are
+                 inputs="replicate", images="all", merge="direct", driver="python", comm=None, tiles=0, **kw):
+        """driver = "c": every frame is ONE library call per rank (kfx_slab_frame_step, include/kfx_slab.h: the launches AND the
+        collectives are enqueued by the library through `comm`, a kangaroo_amd.slab.Comm -- RCCL for one process per GPU; default:
+        Comm.torch(dist), the collectives of the process group the caller has set up); driver = "python": this class issues the
+        operators and torch.distributed collectives one by one (the cross-check, and what the CPU tests run on the oracle-backed
+        operator set).  Same bits either way.  tiles: row-tiles of the exact hand-over (C driver; 0 = the library's default).
+
+        halo = "exchange": every rank integrates only the planes it owns and the ghost planes are
         refreshed from the two neighbours after each SdfFuse (point-to-point send/recv: one xGMI link
         per direction); halo = "recompute": every rank integrates its ghost planes itself (the update is
         deterministic per voxel, so no traffic is needed) -- the cross-check of the exchange path."""
@@ -412,7 +418,38 @@ class SlabPipeline(FramePipeline):
         self.z0, self.z1 = slab_range(d, self.rank, self.world)
         self.s0, self.s1 = max(self.z0 - self.GHOST, 0), min(self.z1 + self.GHOST, d)
         kw["contiguous_images"] = True  # collectives operate on dense tensors
+        assert driver in ("python", "c")
+        self.driver, self.sframe, self.comm = driver, None, comm
+        timing_slots = kw.pop("timing_slots", None)
         super().__init__(ops, dims, boxmin, boxmax, w, h, **kw)
+        if driver == "c":
+            if raycast == "exact_allreduce" or images != "all" or kind != "f32":
+                raise ValueError("SlabPipeline(driver='c'): raycast 'exact' or 'composite', images='all', fp32 cells")
+            from . import slab as S
+            if self.comm is None:
+                self.comm = S.Comm.torch(dist)
+            lay = S.layout(d, float(self.full_boxmin[2]), float(self.full_boxmax[2]), self.rank, self.world, self.GHOST)
+            assert (lay.z0, lay.z1, lay.s0, lay.s1) == (self.z0, self.z1, self.s0, self.s1)
+            self.sframe = S.SlabFrame(self.comm, self.vol, lay, self.raw, self.filtered, self.vbo, self.normals, self.ray_d, self.ray_n, self.ray_i, self.K,
+                                      self.bil, self.near, self.far, self.trunc, self.max_w, self.mincostheta, halo=halo, raycast=raycast, merge=merge,
+                                      inputs=inputs, overlap=overlap, tiles=tiles, timing_slots=int(timing_slots or 256))
+
+    def configure(self, **kw):
+        """Change policies between frames (halo, raycast, merge, inputs, overlap, tiles): bench.py times the variants on one pipeline."""
+        names = {"halo": "halo", "raycast": "raycast_mode", "merge": "merge", "inputs": "inputs", "overlap": "overlap"}
+        self.wait_composite()
+        if self.sframe is not None:
+            self.sframe.configure(**kw)
+        for k, v in kw.items():
+            if k in names:
+                setattr(self, names[k], v)
+
+    def step(self, T_wc, raw_image=None):
+        if self.sframe is not None:
+            self.sframe.step(T_wc, scenes.se3_inverse(T_wc), raw_image)
+            self.frames_done += 1
+            return
+        super().step(T_wc, raw_image)
 
     def _alloc_volume(self, boxmin, boxmax):
         W, H, D = self.dims
@@ -428,6 +465,9 @@ class SlabPipeline(FramePipeline):
         return self.ops.BoundedVolume(W, H, self.s1 - self.s0, lo, hi)
 
     def preprocess(self, raw_image=None):
+        if self.sframe is not None:
+            self.sframe.step(_IDENTITY, None, raw_image, 1)   # KFX_FRAME_PREPROCESS (the broadcast included)
+            return
         if self.inputs == "broadcast" and self.world > 1:
             if self.rank == 0:
                 super().preprocess(raw_image)
@@ -439,6 +479,9 @@ class SlabPipeline(FramePipeline):
     def fuse(self, T_wc, T_cw=None):
         """T_cw: world -> camera transform to use instead of the float32 inverse of T_wc (the tracking loop inverts
         its pose in float64, main.cpp:345-356)."""
+        if self.sframe is not None:
+            self.sframe.step(T_wc, scenes.se3_inverse(T_wc) if T_cw is None else T_cw, None, 2)   # KFX_FRAME_FUSE (+ ghost planes)
+            return
         # a slab's plane count is usually not a multiple of 8: full_extent="slab" integrates exactly the voxels roo::SdfFuse
         # integrates on the whole volume (x / y extents (dim/8)*8, planes below (D/8)*8), whatever the partition
         D = self.dims[2]
@@ -499,6 +542,9 @@ class SlabPipeline(FramePipeline):
         hit wins (one MIN + one SUM all-reduce; rays re-enter each slab with a fresh step, so depths can differ
         from the single-volume march in the last bits).  raycast = "exact": the march state travels with the
         ray from slab to slab (raycast_exact), bit-identical to RaycastSdf on the whole volume."""
+        if self.sframe is not None:
+            self.sframe.step(T_wc, None, None, 4)   # KFX_FRAME_RAYCAST (+ the hand-over / the merge)
+            return
         self.raycast_into(self.ray_d, self.ray_n, self.ray_i, self.K, T_wc)
 
     def raycast_into(self, d, n, i, K, T_wc):
@@ -531,6 +577,9 @@ class SlabPipeline(FramePipeline):
 
     def wait_composite(self):
         """Make the current stream wait for an overlapped merge (no-op otherwise)."""
+        if self.sframe is not None:
+            self.sframe.wait()
+            return
         if self._merged is not None:
             import torch
             torch.cuda.current_stream().wait_event(self._merged)

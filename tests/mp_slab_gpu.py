@@ -21,6 +21,7 @@ import kfx_testlib as T  # noqa: E402
 
 halo, raycast = sys.argv[1], sys.argv[2]
 tracking = len(sys.argv) > 3 and sys.argv[3] == "tracking"
+cframe = len(sys.argv) > 3 and sys.argv[3] == "cframe"   # the frame as ONE kfx_slab_frame_step call per rank, collectives through Comm.torch(dist)
 torch.cuda.set_device(0)
 dist.init_process_group("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
@@ -32,7 +33,43 @@ def same(a, b):
     return T.nan_equal(a, b)
 
 
-if not tracking:
+if cframe:
+    # kfx_slab_frame (include/kfx_slab.h) under real collectives: the C call's bits against the operator-by-operator SlabPipeline
+    # (composite: the same restart semantics, so the same images) and against the single volume (exact: bit-identical, any tile count)
+    variants = [dict(tiles=1), dict(tiles=4), dict(tiles=7)] if raycast == "exact" else [dict(merge="direct"), dict(merge="allreduce"), dict(merge="direct", overlap=True)]
+    if halo == "exchange":
+        variants = [v for v in variants if not v.get("overlap")] + [dict(inputs="broadcast")]
+    py = SlabPipeline(roo, dist, (N, N, N), bmin, bmax, W, H, halo=halo, raycast=raycast, near=near, far=far)
+    ref = FramePipeline(roo, (N, N, N), bmin, bmax, W, H, near=near, far=far)
+    cs = [SlabPipeline(roo, dist, (N, N, N), bmin, bmax, W, H, halo=halo, raycast=raycast, near=near, far=far, driver="c", **v) for v in variants]
+    for i in range(FRAMES):
+        T_wc = scenes.orbit_pose(i, 8)
+        depth = scenes.render_depth(scene, W, H, T_wc, py.K)
+        for p_ in [py, ref] + cs:
+            p_.raw.MemcpyFromHost(depth)
+        py.step(T_wc)
+        ref.preprocess()
+        roo.SdfFuse(ref.vol, ref.filtered, ref.normals, scenes.se3_inverse(T_wc), ref.K, ref.trunc, ref.max_w, ref.mincostheta)
+        ref.raycast(T_wc)
+        for c_ in cs:
+            c_.step(T_wc)
+    for c_ in cs:
+        c_.sframe.sync()
+    torch.cuda.synchronize()
+    full = ref.vol.MemcpyToHost()
+    want = [x.MemcpyToHost() for x in ((ref.ray_d, ref.ray_n, ref.ray_i) if raycast == "exact" else (py.ray_d, py.ray_n, py.ray_i))]
+    for v, c_ in zip(variants, cs):
+        assert same(c_.vol.MemcpyToHost(), full[c_.s0:c_.s1]), "rank %d %r: slab planes differ from the single volume" % (rank, v)
+        got = [x.MemcpyToHost() for x in (c_.ray_d, c_.ray_n, c_.ray_i)]
+        for a_, b_ in zip(got, want):
+            assert same(a_, b_), "rank %d %r: the C frame's images differ" % (rank, v)
+        if raycast == "exact":
+            T_ = c_.sframe.last_steps
+            assert T_ == world + v["tiles"] - 1 + 2 if "tiles" in v else T_ > 0, (v, T_)
+        t = c_.sframe.timings(c_.sframe.count - 2, 2)
+        assert t.shape == (2, 6) and np.isfinite(t[:, :3]).all() and (t[:, :3] >= 0).all() and np.isfinite(t[0, 5]), t
+        assert np.isfinite(t[:, 3]).all() == (raycast == "composite")
+elif not tracking:
     pipe = SlabPipeline(roo, dist, (N, N, N), bmin, bmax, W, H, halo=halo, raycast=raycast, near=near, far=far)
     ref = FramePipeline(roo, (N, N, N), bmin, bmax, W, H, near=near, far=far)
     for i in range(FRAMES):

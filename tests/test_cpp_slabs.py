@@ -43,6 +43,50 @@ def test_cpp_slabs_exact_march_equals_single_volume():
         assert rounds == ranks + 1 if mode == "exact" else 1 < rounds <= ranks + 3   # hand-over: a fixed number of stages
 
 
+def test_cpp_slabs_tiled_handover_equals_single_volume():
+    """The hand-over pipelined over image row-tiles (kfx_slab_raycast_exact_tiled: the march state of a tile travels as a token
+    up and down the rank order, one tile-sized message per link and step): volume and all three images bit-identical to the
+    one-slab run for 2 / 3 / 4 / 8 rank threads and 1 / 4 / 8 tiles (240 rows: 8 tiles of 30; 7 tiles: the last one short)."""
+    ref = run(*COMMON, "--ranks", 1, "--raycast", "exact")
+    one = run(*COMMON, "--ranks", 1, "--raycast", "exact", "--tiles", 4)
+    for k in ("depth", "norm", "img", "volume", "hits"):
+        assert one[k] == ref[k], (k, one["text"], ref["text"])
+    for ranks, halo in ((2, "exchange"), (3, "recompute"), (4, "exchange"), (8, "recompute")):
+        for tiles in (1, 4, 8) + ((7,) if ranks == 3 else ()):
+            got = run(*COMMON, "--ranks", ranks, "--raycast", "exact", "--halo", halo, "--tiles", tiles)
+            assert got["agree"] == 1
+            for k in ("depth", "norm", "img", "volume", "hits"):
+                assert got[k] == ref[k], (ranks, halo, tiles, k, got["text"], ref["text"])
+            rounds = int(re.search(r"\((\d+) rounds\)", got["text"]).group(1))
+            assert rounds == ranks + tiles - 1 + 2, (ranks, tiles, rounds)   # the initialising march, world + tiles - 1 token steps, the normals' stage
+
+
+def test_cpp_slabs_frame_driver_equals_the_operator_calls():
+    """--driver frame: every rank issues its frame as ONE kfx_slab_frame_step call (preprocess, kfx_sdf_fuse_slab, ghost planes,
+    the slab raycast and its collectives enqueued by the library).  Same volume and image bits as the roo:: calls of the default
+    driver -- exact (default 4 tiles, and 1 / 8), composite with either merge, the merge overlapped with the next frame, inputs
+    broadcast, ghost planes exchanged or recomputed."""
+    for ranks in (2, 3, 4, 8):
+        ref = run(*COMMON, "--ranks", 1, "--raycast", "exact")
+        for extra in (("--halo", "recompute"), ("--halo", "exchange", "--tiles", 8), ("--halo", "exchange", "--inputs", "broadcast", "--tiles", 1)):
+            got = run(*COMMON, "--ranks", ranks, "--raycast", "exact", "--driver", "frame", *extra)
+            assert got["agree"] == 1 and "one kfx_slab_frame_step per frame" in got["text"]
+            for k in ("depth", "norm", "img", "volume", "hits"):
+                assert got[k] == ref[k], (ranks, extra, k, got["text"], ref["text"])
+    for ranks in (2, 4, 5):
+        for merge in ("direct", "allreduce"):
+            ops = run(*COMMON, "--ranks", ranks, "--raycast", "composite", "--halo", "recompute", "--merge", merge)
+            for extra in ((), ("--overlap",)):
+                got = run(*COMMON, "--ranks", ranks, "--raycast", "composite", "--halo", "recompute", "--merge", merge, "--driver", "frame", *extra)
+                assert got["agree"] == 1
+                for k in ("depth", "norm", "img", "volume", "hits"):
+                    assert got[k] == ops[k], (ranks, merge, extra, k, got["text"], ops["text"])
+    # the overlapped merge beside the ghost-plane exchange would interleave collectives in rank-dependent order: refused
+    bad = subprocess.run([APP, *[str(a) for a in COMMON], "--ranks", "2", "--raycast", "composite", "--halo", "exchange", "--driver", "frame", "--overlap"],
+                         capture_output=True, text=True, timeout=120)
+    assert bad.returncode != 0 and "overlap needs" in bad.stdout + bad.stderr
+
+
 def test_cpp_slabs_inputs_broadcast_from_rank_zero():
     """--inputs broadcast: only rank 0 filters the frame and derives the normal map; kfx_slab_broadcast_inputs (pitched
     images: staged densely) hands both to the other ranks.  Same bits everywhere as with every rank preprocessing."""
@@ -111,17 +155,8 @@ def test_rccl_transport_collectives_on_a_one_rank_communicator(tmp_path):
     import torch
     from kangaroo_amd import _lib
 
-    class Comm(C.Structure):   # kfx_comm (include/kfx_slab.h)
-        pass
-    P, V, Z = C.POINTER(Comm), C.c_void_p, C.c_size_t
-    Comm._fields_ = [("rank", C.c_int), ("world", C.c_int), ("impl", V),
-                     ("all_reduce", C.CFUNCTYPE(C.c_int, P, V, Z, C.c_int, V)),
-                     ("exchange", C.CFUNCTYPE(C.c_int, P, V, V, Z, V, V, Z, V)),
-                     ("barrier", C.CFUNCTYPE(C.c_int, P)),
-                     ("destroy", C.CFUNCTYPE(None, P)),
-                     ("broadcast", C.CFUNCTYPE(C.c_int, P, V, Z, C.c_int, V)),
-                     ("all_to_all", C.CFUNCTYPE(C.c_int, P, V, V, Z, V)),
-                     ("all_gather", C.CFUNCTYPE(C.c_int, P, V, V, Z, V))]
+    from kangaroo_amd.slab import KfxComm as Comm   # kfx_comm (include/kfx_slab.h)
+    P, V = C.POINTER(Comm), C.c_void_p
     R = C.CDLL(os.path.join(os.path.dirname(_lib.LIB_PATH), "libkfx_rccl.so"))
     R.kfx_comm_create_rccl.argtypes = [P, C.c_int, C.c_int, C.c_char_p, C.c_int]
     torch.cuda.set_device(0)
@@ -144,6 +179,7 @@ def test_rccl_transport_collectives_on_a_one_rank_communicator(tmp_path):
         assert comm.all_reduce(C.byref(comm), V(k.data_ptr()), k.numel(), 0, st) == 0            # KFX_COMM_MIN_I64
         assert comm.broadcast(C.byref(comm), V(a.data_ptr()), a.numel() * 4, 0, st) == 0
         assert comm.exchange(C.byref(comm), V(a.data_ptr()), V(b.data_ptr()), 64, V(a.data_ptr()), V(b.data_ptr()), 64, st) == 0   # no neighbours: nothing moves
+        assert comm.exchange_v(C.byref(comm), V(a.data_ptr()), 64, V(b.data_ptr()), 128, V(a.data_ptr()), 32, V(b.data_ptr()), 16, st) == 0   # likewise
         assert comm.barrier(C.byref(comm)) == 0
         torch.cuda.synchronize()
         assert torch.equal(b, want) and torch.equal(a, want) and torch.equal(k, torch.arange(1000, dtype=torch.int64, device="cuda") * 3 - 11)

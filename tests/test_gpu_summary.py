@@ -487,19 +487,31 @@ def test_gpu_tracking_pipeline_auto_policy(roo):
         roo.set_math_mode(prev)
 
 
-def test_gpu_summary_rebuild_is_exact(roo):
+@pytest.mark.parametrize("unaligned_view", [False, True])
+def test_gpu_summary_rebuild_is_exact(roo, unaligned_view):
     """kfx_sdf_summary_rebuild: after frames fused WITHOUT tracking, the rebuilt summary holds for every brick the exact range
     of its valued cells and the exact state -- at least as tight as what tracking keeps -- and the march through tables built
-    from it renders the plain march's images bit for bit (exact numerics)."""
+    from it renders the plain march's images bit for bit (exact numerics).  unaligned_view: the summary of a view whose first
+    cell sits at an odd x of its parent (pointer 8-byte aligned only: the rebuild's scalar path, eight cells per row and brick
+    -- round-4 advice: it read to the end of the row)."""
     import torch
     N, w, h = 96, 200, 150
     dims = (N, N - 12, N - 5)   # not multiples of 8: partial bricks on two axes
     bmin, bmax, near, far = scenes.SCENES["room"]
     K = scenes.intrinsics(w, h)
     tr = scenes.trunc_dist(bmin, bmax, dims)
-    vol = roo.BoundedVolume(*dims, bmin, bmax)
+    if unaligned_view:
+        parent = roo.BoundedVolume(dims[0] + 3, dims[1] + 2, dims[2] + 1, bmin, bmax)
+        roo.SdfReset(parent, 0.25)   # (cells around the view hold a value no cell of the view will: a read beyond a brick shows)
+        vol = parent.SubVolume((1, 2, 1), dims)
+        assert vol.ptr % 16 == 8
+    else:
+        vol = roo.BoundedVolume(*dims, bmin, bmax)
     summ = roo.SdfSummary(vol)
-    roo.SdfReset(vol, float("nan"))
+    if unaligned_view:   # (SdfReset fills the contiguous span of a view, padding and the parent's cells in between included)
+        vol.tensor()[...] = torch.tensor([float("nan"), 0.0], device="cuda")
+    else:
+        roo.SdfReset(vol, float("nan"))
     f, vbo, nrm = roo.Image(w, h), roo.Image(w, h, "f32x4"), roo.Image(w, h, "f32x4")
     for i in range(3):
         T_wc = scenes.orbit_pose(i, 30)
