@@ -72,6 +72,7 @@ int main(int argc, char** argv)
 {
     int volres = 256, frames = 30, w = 640, h = 480;   // the application's defaults (main.cpp:90-91)
     bool fast = false, track = false, device_icp = false, one_raycast = false, use_summary = false, summary_auto = false;
+    int drop_frame = -1;   // --drop-frame F: frame F arrives with no valid depth at all (a sensor drop-out): tracking is lost, the next frame recovers
     for (int i = 1; i < argc; ++i) {
         if (!strcmp(argv[i], "--res") && i + 1 < argc) volres = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--frames") && i + 1 < argc) frames = atoi(argv[++i]);
@@ -83,6 +84,7 @@ int main(int argc, char** argv)
         else if (!strcmp(argv[i], "--summary-auto")) use_summary = summary_auto = true;   // ... and the application keeps it only if it pays (whole frames timed with and without it)
         else if (!strcmp(argv[i], "--one-raycast") || !strcmp(argv[i], "--fused-launches")) one_raycast = true;   // additions beside the reference API: all pyramid levels rendered by one launch, vbo + normals in one launch
         else if (!strcmp(argv[i], "--device-icp")) track = device_icp = true;   // the refinement loop as one device-side chain
+        else if (!strcmp(argv[i], "--drop-frame") && i + 1 < argc) drop_frame = atoi(argv[++i]);
     }
     if (kfx_device_count() < 1) { fprintf(stderr, "no HIP device\n"); return 2; }
     kfx_set_math_mode(fast ? KFX_MATH_FAST : KFX_MATH_EXACT);
@@ -125,13 +127,15 @@ int main(int argc, char** argv)
         poses[f] = OrbitPose(f, 30);
         RenderRoom(depth_frames[f], w, h, poses[f], K);
         for (float& d : depth_frames[f]) d *= 1000.0f;   // the sensor delivers millimetres (main.cpp:208)
+        if (f == drop_frame) for (float& d : depth_frames[f]) d = std::numeric_limits<float>::quiet_NaN();
     }
 
     std::vector<float> hdepth((size_t)w * h);
     double total_ms = 0, worst_pos_err = 0, rmse = 0;
     size_t hits = 0;
     unsigned long long depth_sum = 1469598103934665603ull;
-    int lost = 0;
+    int lost = 0, resets = 0;
+    posesolve::SE3d T_anchor;   // the world frame of the estimate in the frame of the known poses (identity until tracking is lost and the model is reset)
     posesolve::SE3d T_wl_est;   // tracked pose (double, as Sophus::SE3d in the application)
     for (int i = 0; i < 3; ++i) {
         for (int j = 0; j < 3; ++j) T_wl_est.R[i][j] = poses[0](i, j);
@@ -157,7 +161,22 @@ int main(int argc, char** argv)
                 NormalsFromVbo(kin_n[l], kin_v[l]);
             }
         }
-        if (f == 0) {
+        // main.cpp:223-242: `if (Pushed(reset) || !std::isfinite(f_rmse))` -- the first frame, and the frame after tracking was lost
+        // altogether (no correspondence left: rmse = sqrt(0 / 0)): the world frame restarts at the current camera (T_wl = SE3d()), the
+        // model is reset to "never observed" and the current frame is fused; the frame then goes on like any other (it is tracked
+        // against the model it has just founded and fused again, as in the reference's loop).
+        const bool recover = track && f > 0 && !std::isfinite(rmse);
+        if (recover) {
+            for (int i = 0; i < 3; ++i) {   // where the new world frame sits in the frame of the known poses: at this frame's true camera
+                for (int j = 0; j < 3; ++j) T_anchor.R[i][j] = poses[f](i, j);
+                T_anchor.t[i] = poses[f](i, 3);
+            }
+            T_wl_est = posesolve::SE3d();
+            T_wl = T_wl_est.matrix3x4<Mat<float,3,4> >();
+            rmse = 0;
+            ++resets;
+        }
+        if (f == 0 || recover) {
             if (use_summary) {
                 SdfReset(vol, std::numeric_limits<float>::quiet_NaN(), *summary);
                 SdfFuse(vol, *summary, kin_d[0], kin_n[0], SE3inv(T_wl), K, trunc_dist, max_w, mincostheta);
@@ -255,9 +274,10 @@ int main(int argc, char** argv)
                 if (tracking_good) T_wl_est = T_wl_est * T_lp.inverse();
                 else ++lost;
                 T_wl = T_wl_est.matrix3x4<Mat<float,3,4> >();
+                const posesolve::SE3d T_abs = T_anchor * T_wl_est;   // the estimate in the frame of the known poses
                 double e = 0;
-                for (int i = 0; i < 3; ++i) e += (T_wl(i, 3) - poses[f](i, 3)) * (T_wl(i, 3) - poses[f](i, 3));
-                worst_pos_err = std::fmax(worst_pos_err, std::sqrt(e));
+                for (int i = 0; i < 3; ++i) e += (T_abs.t[i] - poses[f](i, 3)) * (T_abs.t[i] - poses[f](i, 3));
+                if (f != drop_frame) worst_pos_err = std::fmax(worst_pos_err, std::sqrt(e));   // (a frame without depth has no estimate)
             }
             if (f > 0 && tracking_good) {
                 if (use_summary) SdfFuse(work_vol, *summary, kin_d[0], kin_n[0], SE3inv(T_wl), K, trunc_dist, max_w, mincostheta);
@@ -293,8 +313,9 @@ int main(int argc, char** argv)
     printf("kinectfusion_headless: %d^3 volume, %dx%d, %d frames, %s math, %s poses: %.3f ms/frame (%.1f fps), last raycast hits %zu/%d%s, depth checksum %016llx\n",
            volres, w, h, frames, fast ? "fast" : "exact", device_icp ? "ICP-tracked (device loop)" : (track ? "ICP-tracked" : "known"), total_ms / frames, 1e3 * frames / total_ms, hits, w * h,
            use_summary ? " (brick summary)" : "", depth_sum);
-    if (track) printf("  tracking: worst position error %.2f mm over the orbit (step between poses up to %.1f mm), final rmse %.4f, %d frames lost\n",
-                      1e3 * worst_pos_err, 1e3 * 0.0105, rmse, lost);
-    if (track && (lost > 0 || worst_pos_err > 0.02)) return 1;
+    if (track) printf("  tracking: worst position error %.2f mm over the orbit (step between poses up to %.1f mm), final rmse %.4f, %d frames lost, %d resets\n",
+                      1e3 * worst_pos_err, 1e3 * 0.0105, rmse, lost, resets);
+    const int expect_lost = (track && drop_frame > 0 && drop_frame < frames) ? 1 : 0;
+    if (track && (lost != expect_lost || resets != (expect_lost && drop_frame + 1 < frames ? 1 : 0) || worst_pos_err > 0.02)) return 1;
     return hits > (size_t)(w * h) / 4 ? 0 : 1;
 }

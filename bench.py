@@ -37,7 +37,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 N_ORBIT = 30
-PMC_TRAFFIC_FILES = ("profiles/r04_pmc_traffic.json", "profiles/r03_pmc_traffic.json")   # the first that exists
+PMC_TRAFFIC_FILES = ("profiles/r05_pmc_traffic.json", "profiles/r04_pmc_traffic.json")   # the first that exists
 BLOCK = 60   # frames per priming / calibration block: two orbits (launch times depend on the pose)
 
 
@@ -99,6 +99,10 @@ def parse():
                          "that was idle takes on the order of a second of work to settle its clocks (KFX_BENCH_DUMP=1 prints the blocks)")
     ap.add_argument("--prime-cap-seconds", type=float, default=8.0, help="give up waiting for a stationary frame time after this much GPU time")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-legs", action="store_true",
+                    help="1 GPU, default configuration: skip the two reported legs that follow the headline in the same process -- `room_variant` "
+                         "(the same loop on scene S_room, the fps scene of SURVEY 8(d)) and `tracked_variant` (the application's loop with the "
+                         "projective ICP between rendering and integration: TrackingPipeline(device_icp=True) on S_room)")
     ap.add_argument("--cpu-frames", type=int, default=30, help="upper bound on the timed CPU-baseline frames (the sample also stops after ~12 s)")
     args = ap.parse_args()
     if args.scene is None:
@@ -206,7 +210,14 @@ def pmc_traffic(key):
     """HBM bytes per launch from PMC passes.  Counters need their own rocprofv3 runs (FETCH_SIZE and WRITE_SIZE do not fit one pass
     and must not be combined with the timed run), so the figure comes from the committed summary of those passes over this same
     command (scripts/gpu_profile.sh -> profiles/<tag>/summary.txt -> the traffic file); `traffic_source` names the file and what it
-    was collected on: it is NOT measured in this run."""
+    was collected on: it is NOT measured in this run.  The file records the digest of the kernel sources it was taken on
+    (kfx_kernel_source_id, scripts/make_pmc_traffic.py): a figure of other kernels than the loaded library's is not reported --
+    traffic comes back None and the source says why (round-4 verdict, item 8)."""
+    from kangaroo_amd import _lib
+    L = _lib.load()
+    family = "raycast" if key.startswith("raycast_") else "fuse"
+    have = L.kfx_kernel_source_id(family.encode()).decode()
+    why = None
     for name in PMC_TRAFFIC_FILES:
         try:
             with open(os.path.join(ROOT, name)) as fh:
@@ -214,9 +225,15 @@ def pmc_traffic(key):
         except (OSError, ValueError):
             continue
         t = tj.get(key, {}).get("traffic_bytes")
-        if t is not None:
-            return t, "%s (separate rocprofv3 --pmc passes of this command, kernels of %s; not measured in this run)" % (name, tj.get("_commit", "?"))
-    return None, None
+        if t is None:
+            continue
+        took = (tj.get("_kernel_source_id") or {}).get(family)
+        if took != have or tj.get("_kfx_version") != int(L.kfx_version()):
+            why = why or ("not reported: %s was taken on %s kernels %s (libkfx %s), this library is built from %s (libkfx %d) -- re-run "
+                          "scripts/gpu_profile.sh and scripts/make_pmc_traffic.py" % (name, family, took or "of an unrecorded revision", tj.get("_kfx_version", "?"), have, int(L.kfx_version())))
+            continue
+        return t, "%s (separate rocprofv3 --pmc passes of this command on the %s kernels %s; not measured in this run)" % (name, family, have)
+    return None, why
 
 
 def prime_stream(kf, step, min_s, cap_s, min_frames, tol=0.02):
@@ -244,6 +261,122 @@ def prime_stream(kf, step, min_s, cap_s, min_frames, tol=0.02):
             break
     return {"frames": issued, "gpu_s": round(gpu_s, 3), "stationary": bool(stationary), "block_frames": BLOCK, "tolerance": tol,
             "block_mean_frame_ms": [round(m, 4) for m in means]}
+
+
+def room_leg(args, torch, roo, scenes, n_steps):
+    """The headline's loop on scene S_room (the scene for parity + frames/s; S_full, the roofline scene, is what `value`
+    is quoted on): same volume and image size, same protocol in short -- untimed frames until the frame time is stationary (the
+    clocks are warm: 0.5 s), the pipeline's own choice of kernels (three blocks of 60 whole frames), settle, n_steps timed frames."""
+    from kangaroo_amd.pipeline import FramePipeline
+    N, w, h, scene = args.res, args.width, args.height, "room"
+    bmin, bmax, near, far = scenes.SCENES[scene]
+    K = scenes.intrinsics(w, h)
+    policy = args.summary if args.math == "fast" else "off"
+    pipe = FramePipeline(roo, (N, N, N), bmin, bmax, w, h, K=K, near=near, far=far, track={"auto": "auto", "on": True, "off": False}[policy],
+                         cal_first=-1, cal_block=BLOCK, timing_slots=max(256, n_steps + 4 * BLOCK + 64))
+    kf = pipe.kframe
+    pipe.set_timing(kf.EVENTS_FUSE)
+    poses = [scenes.orbit_pose(i, N_ORBIT) for i in range(N_ORBIT)]
+    frames = []
+    for T_wc in poses:
+        im = roo.Image(w, h, "f32", pitch=pipe.raw.pitch)
+        im.MemcpyFromHost(scenes.render_depth(scene, w, h, T_wc, K))
+        frames.append(im)
+    n_updated = []
+    for i in range(N_ORBIT):
+        pipe.preprocess(frames[i])
+        n_updated.append(roo.SdfFuseCount(pipe.vol, pipe.filtered, pipe.normals, scenes.se3_inverse(poses[i]), K, pipe.trunc, pipe.mincostheta))
+    cursor = [0]
+
+    def step():
+        i = cursor[0] % N_ORBIT
+        cursor[0] += 1
+        pipe.step(poses[i], frames[i])
+        return i
+    prime = [prime_stream(kf, step, 0.5, 2.0, 0)]
+    if pipe.track_policy == "auto":
+        pipe.recalibrate()
+        guard = 0
+        while pipe.track_decision is None and guard < 8 * BLOCK:
+            step()
+            guard += 1
+        prime.append(prime_stream(kf, step, 0.1, 1.0, 3 * BLOCK))
+    torch.cuda.synchronize()
+    first = kf.count
+    t0 = time.perf_counter()
+    idx = [step() for _ in range(n_steps)]
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    t = kf.timings(first, n_steps)
+    fuse_ms = float(np.mean(t[:, 1]))
+    pipe.set_timing(kf.EVENTS_ALL)
+    for _ in range(N_ORBIT):
+        step()
+    f_parts = kf.count
+    for _ in range(2 * N_ORBIT):
+        step()
+    tp = kf.timings(f_parts, 2 * N_ORBIT)
+    bytes_avg = float(np.mean([16.0 * n_updated[i] + 20.0 * w * h for i in idx]))
+    use_summary = bool(pipe.track)
+    traffic, traffic_source = pmc_traffic("%s_%s%s" % (scene, args.math, "_tracked" if use_summary else "")) if (N, w, h) == (512, 640, 480) else (None, None)
+    out = {"scene": "S_room", "frames_per_sec": round(n_steps / elapsed, 1), "steps": n_steps, "prime": cursor[0] - n_steps - 3 * N_ORBIT,
+           "ms_per_step": round(1e3 * elapsed / n_steps, 4),
+           "sdf_fuse_ms": round(fuse_ms, 5), "sdf_fuse_achieved_GBps": round(bytes_avg / (fuse_ms * 1e-3) / 1e9, 1),
+           "sdf_fuse_frac_of_peak": round(bytes_avg / (fuse_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": round(bytes_avg),
+           "updated_fraction": round(float(np.mean([n_updated[i] for i in idx])) / (N ** 3), 4),
+           "sdf_fuse_traffic": traffic, "sdf_fuse_traffic_source": traffic_source,
+           "raycast_sdf_ms": round(float(np.mean(tp[:, 2])), 5), "preprocess_ms": round(float(np.mean(tp[:, 0])), 5),
+           "raycast": "march through the class tables (tracked SdfFuse)" if use_summary else "plain march (kfx_raycast_sdf)",
+           "summary_policy": {"requested": policy, "decision": pipe.track_decision},
+           "priming_block_mean_frame_ms": [pl["block_mean_frame_ms"][-3:] for pl in prime],
+           "note": "the headline's loop (one kfx_frame_step per frame, same volume / image size / numerics) on the furnished-room scene, timed in the "
+                   "same process right after the headline: %d steps between two synchronisations" % n_steps}
+    del pipe, frames
+    torch.cuda.empty_cache()
+    return out
+
+
+def tracked_leg(args, torch, roo, scenes, n_steps):
+    """True end-to-end KinectFusion (main.cpp:200-356 with pose estimation on): per frame the depth pyramid, the
+    model rendered at the last pose on the ICP levels, the projective point-plane ICP (device-resident loop, kfx_icp_refine: one
+    synchronisation per frame for the pose), SdfFuse at the refined pose.  Scene S_room (S_full is a single wall: its in-plane motion
+    is unobservable); the orbit's poses are NOT given after frame 0 -- `worst_position_error_mm` is what the tracker ends up with."""
+    from kangaroo_amd.pipeline import TrackingPipeline
+    N, w, h, scene = args.res, args.width, args.height, "room"
+    bmin, bmax, near, far = scenes.SCENES[scene]
+    K = scenes.intrinsics(w, h)
+    pipe = TrackingPipeline(roo, (N, N, N), bmin, bmax, w, h, K=K, near=near, far=far, device_icp=True, track=False)
+    poses = [scenes.orbit_pose(i, N_ORBIT) for i in range(N_ORBIT)]
+    frames = []
+    for T_wc in poses:
+        im = roo.Image(w, h, "f32", pitch=pipe.raw.pitch)
+        im.MemcpyFromHost(scenes.render_depth(scene, w, h, T_wc, K))
+        frames.append(im)
+    worst, lost = 0.0, 0
+
+    def run(n, first):
+        nonlocal worst, lost
+        for k in range(n):
+            i = (first + k) % N_ORBIT
+            T = pipe.step(poses[i] if first + k == 0 else None, frames[i])
+            worst = max(worst, float(np.linalg.norm(T[:3, 3] - poses[i][:3, 3])))
+            lost += 0 if pipe.tracking_good else 1
+    run(2 * N_ORBIT, 0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(n_steps, 2 * N_ORBIT)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    out = {"scene": "S_room", "frames_per_sec": round(n_steps / elapsed, 1), "steps": n_steps, "ms_per_step": round(1e3 * elapsed / n_steps, 4),
+           "worst_position_error_mm": round(1e3 * worst, 3), "frames_lost": lost, "resets": pipe.resets, "final_rmse": round(float(pipe.rmse), 6),
+           "loop": "TrackingPipeline(device_icp=True): BilateralFilter + depth pyramid + per-level DepthToVbo / NormalsFromVbo -> RaycastSdf on levels "
+                   "0, 2, 3 (one launch) -> kfx_icp_refine (6 iterations over 3 levels, its = {1, 0, 2, 3}, solved on the device) -> one pose read-back "
+                   "-> SdfFuse at the estimated pose; the Python loop issues the operators (the C++ application's loop: apps/kinectfusion_headless --device-icp)",
+           "note": "%d frames of the orbit tracked from depth alone after %d untimed ones; position error against the known orbit over all of them "
+                   "(steps between poses up to 10.5 mm)" % (n_steps, 2 * N_ORBIT)}
+    del pipe, frames
+    torch.cuda.empty_cache()
+    return out
 
 
 def run_single(args, torch, roo, scenes, rank):
@@ -552,6 +685,22 @@ def run_single(args, torch, roo, scenes, rank):
 
     traffic, traffic_source = pmc_traffic("%s_%s%s" % (scene, args.math, "_tracked" if use_summary else "")) if (N, w, h) == (512, 640, 480) else (None, None)
     n_prime_total = n_prime
+    # ---- the two legs SURVEY 8(d) / 8(f) name beside the roofline scene, driver-timed in the default command: S_room (the fps scene)
+    # through the same loop, and the tracked loop (ICP between rendering and integration).  Reported extras: never `value`. ----
+    room_variant, tracked_variant = None, None
+    track_decision = pipe.track_decision
+    if args.config == "c2" and scene == "full" and not args.no_extra_legs:
+        del pipe, kf, frames   # (one 512^3 volume at a time is plenty; the legs build their own pipelines)
+        torch.cuda.empty_cache()
+        gc.collect()
+        try:
+            room_variant = room_leg(args, torch, roo, scenes, min(args.steps, 4 * N_ORBIT))
+        except Exception as e:   # noqa: BLE001
+            room_variant = {"error": repr(e)[:300]}
+        try:
+            tracked_variant = tracked_leg(args, torch, roo, scenes, min(args.steps, 2 * N_ORBIT))
+        except Exception as e:   # noqa: BLE001
+            tracked_variant = {"error": repr(e)[:300]}
     out = {
         "metric": "kinectfusion_frames_per_sec_640x480_to_512cubed_tsdf",
         "value": round(args.steps / elapsed, 3),
@@ -571,7 +720,7 @@ def run_single(args, torch, roo, scenes, rank):
             "volume": [N, N, N], "image": [w, h], "scene": scene, "backend": None, "ranks_agree": None,
             "raycast": ("march through the class tables of the brick summary, kept current by the tracked SdfFuse (kfx_sdf_fuse_tracked + kfx_raycast_sdf_tracked)"
                         if use_summary else "plain march (kfx_raycast_sdf)"),
-            "summary_policy": {"requested": args.summary if args.math == "fast" else "off (exact numerics)", "decision": pipe.track_decision},
+            "summary_policy": {"requested": args.summary if args.math == "fast" else "off (exact numerics)", "decision": track_decision},
             "priming": prime_log,
             "partition": "single volume",
             "math": MATH_TEXT[args.math],
@@ -610,7 +759,8 @@ def run_single(args, torch, roo, scenes, rank):
         "sdf_fuse_other_mode": other_line,
     }
     for key, val in (("roofline_raycast", roofline_raycast), ("bilateral", bilateral_line), ("transfer_inclusive", transfer_line),
-                     ("brick_summary_variant", summary_variant), ("plain_variant", plain_variant)):
+                     ("brick_summary_variant", summary_variant), ("plain_variant", plain_variant), ("room_variant", room_variant),
+                     ("tracked_variant", tracked_variant)):
         if val is not None:
             out[key] = val
     return out

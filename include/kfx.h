@@ -517,6 +517,10 @@ int kfx_get_math_mode(void);
 const char* kfx_last_error_string(void); /* thread-local, never NULL */
 const char* kfx_error_name(int code);    /* hipGetErrorString for >0, KFX_E_* names for <0 */
 int kfx_version(void);                   /* major*100 + minor */
+/* A digest of the sources the kernels of a family ("fuse": SdfFuse, "raycast": RaycastSdf and the class tables) were compiled
+ * from ("" for an unknown family).  Committed measurements of a kernel (profiles/..._pmc_traffic.json) carry it; bench.py reports
+ * a counter figure only when it was taken on the kernels it is running. */
+const char* kfx_kernel_source_id(const char* family);
 int kfx_device_count(void);
 int kfx_set_device(int device);          /* hipSetDevice for the calling thread (one rank per GPU: include/kfx_slab.h) */
 

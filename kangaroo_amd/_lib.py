@@ -130,6 +130,7 @@ SIGNATURES = {
     "kfx_set_math_mode": (C.c_int, [C.c_int]),
     "kfx_get_math_mode": (C.c_int, []),
     "kfx_version": (C.c_int, []),
+    "kfx_kernel_source_id": (C.c_char_p, [C.c_char_p]),
     "kfx_device_count": (C.c_int, []),
     "kfx_set_device": (C.c_int, [C.c_int]),
     "kfx_sdf_summary_create": (C.c_int, [C.POINTER(C.c_void_p), PV]),

@@ -60,6 +60,7 @@ struct FuseParams {
     int sum_w, sum_h, sum_d; // parent volume dimensions in cells
     int zoff_local;          // first plane of this launch within the view (fuse_launch splits the view into z-ranges)
     int xcd_swizzle;         // tiled kernels: n > 0 rotates the x-brick of a workgroup by (z-brick >> (n - 1)) (see k_sdf_fuse_tiled)
+    int fuse_cull;           // fast tiled kernels: the brick cull by the tile's own costheta bound (KFX_FUSE_CULL=0 switches it off)
 };
 
 struct Obs {
@@ -454,7 +455,7 @@ __global__ __launch_bounds__(256, (FAST && ZU == 2) ? 8 : (!FAST ? 6 : 1)) void 
     extern __shared__ __attribute__((aligned(16))) float4 s_tile[];
     __shared__ float s_pz[ZC];
     __shared__ float s_box[4][6];
-    __shared__ float s_dmax[4];
+    __shared__ float s_dmax[4], s_cmin[4];
     __shared__ int s_bad[4];
     __shared__ float4 s_tz[ZC]; // exact mode: {pz, T(0,2)*pz, T(1,2)*pz, T(2,2)*pz} per slice
     // (the wave index through readfirstlane: the compiler cannot tell that tid >> 6 is wave-uniform, and without it the slice
@@ -620,7 +621,44 @@ __global__ __launch_bounds__(256, (FAST && ZU == 2) ? 8 : (!FAST ? 6 : 1)) void 
     if (use_tile && p.mincos > 0.f && p.trunc > 0.f) {
         dmax = fmaxf(fmaxf(s_dmax[0], s_dmax[1]), fmaxf(s_dmax[2], s_dmax[3]));
         const float bound = -(p.trunc / p.mincos) * 1.001f;
-        if (dmax + fabsf(dmax) * 1e-5f - zmin < bound) return; // also when every texel is NaN (dmax = -inf)
+        const float dfar = dmax + fabsf(dmax) * 1e-5f;
+        if (dfar - zmin < bound) return; // also when every texel is NaN (dmax = -inf)
+        // Fast kernels, beyond that.  A voxel that lies D = Z - md behind the surface it sees is updated only if mincos < costheta AND
+        // costheta D < trunc, and costheta -- the interpolated normal against the voxel's own viewing direction -- is at least
+        // c_min = the smallest value any texel of the rectangle gives with ITS viewing direction, less what one pixel of direction
+        // can change (a bilinear sample is a convex combination of its cell's texels; a texel that is not finite makes every
+        // sample of its cells NaN or infinite, which the predicate rejects, so such texels do not count).  With c = max(mincos,
+        // c_min) no voxel with D >= trunc / c can change: a brick that lies that far behind the FARTHEST depth it sees is skipped
+        // whole.  The test above knows c = mincos only -- ten truncation bands for the application's mincostheta = 0.1; behind a
+        // wall seen face-on one band is enough, behind the room's side walls (seen at costheta ~ 0.3) three.  c_min costs one pass
+        // over the staged tile and is evaluated only for bricks that lie more than a band behind everything they see.  Which
+        // bricks are evaluated changes, never a value: same bits (the parity, chain and fuzz suites compare with the oracle).
+        if constexpr (FAST && !DXT && CELL::BYTES == 8) {
+            const float band = p.trunc * 1.001f;
+            if (zmin - dfar > band && p.fuse_cull) { // (uniform)
+                float c = __builtin_inff();
+                const int ntex = tw * th;
+                const float inv_tw = 1.0f / (float)tw;
+                const float ifu = __builtin_amdgcn_rcpf(p.K.fu), ifv = __builtin_amdgcn_rcpf(p.K.fv);
+                const float slack = 3.0f * fmaxf(fabsf(ifu), fabsf(ifv));   // |change of a unit direction| over one pixel, with room
+                for (int t = tid; t < ntex; t += 256) {
+                    const float4 q = s_tile[t];
+                    const int r = (int)(((float)t + 0.5f) * inv_tw);
+                    const int cc = t - r * tw;
+                    const float dx = ((float)(tx0 + cc) - p.K.u0) * ifu, dy = ((float)(ty0 + r) - p.K.v0) * ifv;
+                    const float rs = __builtin_amdgcn_rsqf(__builtin_fmaf(dx, dx, __builtin_fmaf(dy, dy, 1.0f)));
+                    const float dotn = __builtin_fmaf(q.x, dx, __builtin_fmaf(q.y, dy, q.z));
+                    const float ct = -dotn * rs - (fabsf(q.x) + fabsf(q.y) + fabsf(q.z)) * slack - 1e-4f;
+                    if (isfinite(ct) && isfinite(q.w)) c = fminf(c, ct);
+                }
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) c = fminf(c, __shfl_xor(c, off, 64));
+                if (lane == 0) s_cmin[wv] = c;
+                __syncthreads();
+                c = fminf(fminf(s_cmin[0], s_cmin[1]), fminf(s_cmin[2], s_cmin[3]));
+                if ((zmin - dfar) * fmaxf(p.mincos, c) >= band) return;   // (c = +inf: no finite texel at all -- the test above has returned)
+            }
+        }
     }
     if constexpr (DXT) {   // (workgroup-uniform control flow up to here: every thread reaches the barrier)
         if (use_tile) {
@@ -1506,6 +1544,8 @@ static int fuse_params(FuseParams& p, bool* small_images, const kfx_volume* vol,
     p.sum_nbx = p.sum_nby = p.sum_bx0 = p.sum_by0 = p.sum_bz0 = p.sum_w = p.sum_h = p.sum_d = p.zoff_local = 0;
     static const int swizzle_env = [] { const char* e = getenv("KFX_FUSE_XCD_SWIZZLE"); const int v = e ? atoi(e) : 1; return v < 0 ? 0 : (v > 8 ? 8 : v); }();
     p.xcd_swizzle = swizzle_env;
+    static const int cull_env = [] { const char* e = getenv("KFX_FUSE_CULL"); return e ? atoi(e) : 1; }();
+    p.fuse_cull = cull_env;
     // launch-wide half of the operand-range test of the exact kernel's shared-reciprocal arithmetic (finish_shared);
     // KFX_FUSE_EXACT_SHARED=0 keeps hipcc's own division / square-root expansions (A/B, and the parity suite runs both)
     static const int shared_env = [] { const char* e = getenv("KFX_FUSE_EXACT_SHARED"); return e ? atoi(e) : 1; }();

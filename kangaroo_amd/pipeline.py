@@ -287,6 +287,7 @@ class TrackingPipeline(FramePipeline):
         self.T_wl = np.eye(4)
         self.frame = 0
         self.rmse, self.tracking_good = 0.0, True
+        self.resets = 0   # recoveries after tracking was lost altogether (main.cpp:223-242)
 
     def preprocess(self, raw_image=None):
         o = self.ops
@@ -304,11 +305,21 @@ class TrackingPipeline(FramePipeline):
         if cal:   # track="auto": whole frames of the three blocks, host clock around the step (the pose read-back synchronises)
             self._policy_before()
         self.preprocess(raw_image)
-        if self.frame == 0:
+        # main.cpp:223-242, `if (Pushed(reset) || !std::isfinite(f_rmse))`: when the last refinement found no correspondence at all
+        # (rmse = sqrt(0 / 0): a frame without depth, a model out of view) the application starts over -- T_wl = identity (the world
+        # frame restarts at the current camera; T_wl_init if the caller gives one), the volume back to "never observed", the current
+        # frame fused -- and the frame then goes on like any other: it is tracked against the model it has just founded.
+        recover = self.frame > 0 and not np.isfinite(self.rmse)
+        if recover:
+            self.T_wl = np.eye(4)
+            self._reset_model()
+            self.rmse, self.tracking_good = 0.0, True
+            self.resets += 1
+        if self.frame == 0 or recover:
             if T_wl_init is not None:
                 self.T_wl = np.vstack([np.asarray(T_wl_init, np.float64).reshape(3, 4), [0, 0, 0, 1]])
             self._fuse_at(self.T_wl)
-        else:
+        if self.frame > 0:
             T34 = self.T_wl[:3].astype(np.float32)
             lv = [l for l in range(self.LEVELS) if self.its[l] > 0]
 
@@ -341,6 +352,13 @@ class TrackingPipeline(FramePipeline):
         T_cw = self.tracking.se3_inv(T_wl)[:3].astype(np.float32)
         self._timed_fuse(lambda kw: self.ops.SdfFuse(self.vol, self.kin_d[0], self.kin_n[0], T_cw, self.K, self.trunc, self.max_w,
                                                      self.mincostheta, **kw))
+
+    def _reset_model(self):
+        """SdfReset(vol, NaN) (main.cpp:229), the brick summary set to match."""
+        if self.track:
+            self.ops.SdfReset(self.vol, float("nan"), summary=self.summary)
+        else:
+            self.ops.SdfReset(self.vol, float("nan"))
 
 
 def slab_range(d, rank, world):
@@ -911,17 +929,24 @@ class TrackingSlabPipeline(SlabPipeline):
         self.T_wl = np.eye(4)
         self.frame = 0
         self.rmse, self.tracking_good = 0.0, True
+        self.resets = 0
 
     preprocess = TrackingPipeline.preprocess
 
     def step(self, T_wl_init=None, raw_image=None):
         o, tr = self.ops, self.tracking
         self.preprocess(raw_image)
-        if self.frame == 0:
+        recover = self.frame > 0 and not np.isfinite(self.rmse)   # main.cpp:223-242, as TrackingPipeline.step (every rank sees the same rmse)
+        if recover:
+            self.T_wl = np.eye(4)
+            self.ops.SdfReset(self.vol, float("nan"))
+            self.rmse, self.tracking_good = 0.0, True
+            self.resets += 1
+        if self.frame == 0 or recover:
             if T_wl_init is not None:
                 self.T_wl = np.vstack([np.asarray(T_wl_init, np.float64).reshape(3, 4), [0, 0, 0, 1]])
             self._fuse_at(self.T_wl)
-        else:
+        if self.frame > 0:
             T34 = self.T_wl[:3].astype(np.float32)
             lv = [l for l in range(self.LEVELS) if self.its[l] > 0]
             self.raycast_levels_into([(self.pyr_d[l], self.pyr_n[l], self.pyr_i[l]) for l in lv], [self.K_levels[l] for l in lv], T34)

@@ -175,7 +175,15 @@ class Comm:
         def guard(fn):
             def call(*a):
                 try:
-                    fn(*a)
+                    # everything torch issues here -- copies, RCCL collectives -- goes to the stream the library is enqueueing the
+                    # frame on (the last argument of every collective: the caller's stream, or the frame's side stream for an
+                    # overlapped merge), not to whatever torch's current stream happens to be
+                    st = a[-1] if len(a) > 1 else None
+                    if st:
+                        with torch.cuda.stream(torch.cuda.ExternalStream(int(st))):
+                            fn(*a)
+                    else:
+                        fn(*a)
                     return 0
                 except Exception as e:   # noqa: BLE001  (a Python exception must not unwind through C)
                     import sys
@@ -245,6 +253,7 @@ class Comm:
             if nccl:
                 dist.all_to_all_single(r_, s_)
                 return
+            sync()   # (the producer may have run on another stream than the one this copy is issued on)
             r_[rank].copy_(s_[rank])
             ops = []
             for k in range(1, world):

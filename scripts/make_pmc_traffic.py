@@ -3,8 +3,11 @@
 scripts/gpu_profile.sh summaries (S_full and S_room runs of `python bench.py`) into the traffic file bench.py reads
 (profiles/r04_pmc_traffic.json): per kernel family (2 x FETCH_SIZE + WRITE_SIZE) KiB -> bytes."""
 import json
+import os
 import re
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def sections(path):
@@ -59,6 +62,12 @@ def main():
         d["room_exact"] = entry(room, exact_room[0])
     d["raycast_full_exact"], d["raycast_room_exact"] = d["raycast_full_fast"], d["raycast_room_fast"]   # the plain march is one kernel in both modes
     d = {k: v for k, v in d.items() if v is not None}
+    # which kernels the passes ran on: bench.py reports a figure only while the library it loads is built from the same sources
+    # (the summaries and this file are made on the GPU box, from the library that was profiled)
+    from kangaroo_amd import _lib
+    L = _lib.load()
+    d["_kfx_version"] = int(L.kfx_version())
+    d["_kernel_source_id"] = {fam: L.kfx_kernel_source_id(fam.encode()).decode() for fam in ("fuse", "raycast")}
     json.dump(d, open(dst, "w"), indent=1)
     for k, v in d.items():
         if isinstance(v, dict):

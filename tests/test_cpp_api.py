@@ -108,6 +108,20 @@ def test_headless_kinectfusion_app(extra):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("extra", [["--track"], ["--device-icp", "--fused-launches"], ["--track", "--summary"]])
+def test_headless_app_recovers_after_a_frame_without_depth(extra):
+    """The application's recovery path (main.cpp:223-242) in the C++ loop: --drop-frame 4 delivers one frame without any valid
+    depth -> that frame is lost (rmse NaN, nothing fused), the next one resets the model (T_wl = identity, SdfReset(vol, NaN)),
+    fuses itself and is tracked from there; the app exits 0 only with exactly one lost frame, one reset and the orbit followed
+    (in the frame of the known poses) within 2 cm."""
+    _build()
+    out = subprocess.run([os.path.join(APPS, "kinectfusion_headless"), "--res", "128", "--frames", "10", "--drop-frame", "4"] + extra,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "1 frames lost, 1 resets" in out.stdout, out.stdout
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("extra", [[], ["--track", "--fused-launches"]])
 def test_headless_app_with_brick_summary_renders_the_same_images(extra):
     """--summary: roo::SdfSummary through the C++ overloads (tracked SdfReset / SdfFuse on the ROI views of the application,

@@ -903,6 +903,38 @@ def test_gpu_tracking_pipeline_follows_the_orbit(roo):
     assert worst < 0.2 * drift_if_static, (worst, drift_if_static)
 
 
+@pytest.mark.parametrize("device_icp", [False, True])
+def test_gpu_tracking_pipeline_recovers_after_a_frame_without_depth(roo, device_icp):
+    """The application's recovery path (main.cpp:223-242) on the GPU, host solve loop and device-resident ICP loop: one all-NaN
+    depth frame mid-orbit -> no correspondence, rmse NaN, nothing fused, pose kept; next frame -> T_wl = identity, SdfReset(NaN),
+    the frame fused, tracking goes on in the new world frame (= that frame's camera)."""
+    from kangaroo_amd.pipeline import TrackingPipeline
+    N, w, h, drop = 128, 320, 240, 4
+    bmin, bmax, near, far = scenes.SCENES["room"]
+    pipe = TrackingPipeline(roo, (N, N, N), bmin, bmax, w, h, near=near, far=far, device_icp=device_icp)
+    anchor = None
+    for i in range(10):
+        T_true = scenes.orbit_pose(i, 30)
+        depth = scenes.render_depth("room", w, h, T_true, pipe.K)
+        if i == drop:
+            depth = np.full_like(depth, np.nan)
+        pipe.raw.MemcpyFromHost(depth)
+        before = pipe.T_wl.copy()
+        T_est = pipe.step(T_wl_init=T_true if i == 0 else None)
+        if i == drop:
+            assert not pipe.tracking_good and not np.isfinite(pipe.rmse) and np.array_equal(T_est, before) and pipe.resets == 0
+            continue
+        if i == drop + 1:
+            assert pipe.resets == 1
+            anchor = np.vstack([T_true, [0, 0, 0, 1]])
+        assert pipe.tracking_good and np.isfinite(pipe.rmse), i
+        T_abs = T_est if anchor is None else anchor @ T_est
+        assert np.linalg.norm(T_abs[:3, 3] - T_true[:3, 3]) < 5e-3, (i, T_abs[:3, 3], T_true[:3, 3])
+    assert pipe.resets == 1
+    v = pipe.vol.tensor()[..., 0]
+    assert bool(v.isnan().any()) and int(v.isfinite().sum()) > 0.2 * N ** 3
+
+
 # ---------------------------------------------------------------------------------
 # colour fusion / colour raycast (SURVEY 8(f) row f-3)
 # ---------------------------------------------------------------------------------

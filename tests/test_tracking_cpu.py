@@ -165,3 +165,35 @@ def test_tracking_pipeline_follows_the_orbit():
         worst = max(worst, float(np.linalg.norm(T_est[:3, 3] - T_true[:3, 3])))
     drift_if_static = float(np.linalg.norm(scenes.orbit_pose(frames - 1, 60)[:3, 3] - scenes.orbit_pose(0, 60)[:3, 3]))
     assert worst < 0.35 * drift_if_static, (worst, drift_if_static)
+
+
+def test_tracking_pipeline_recovers_after_a_frame_without_depth():
+    """main.cpp:223-242: a frame with no valid depth leaves the refinement without a single correspondence (rmse = sqrt(0 / 0)):
+    the frame is not fused, the pose stays; on the NEXT frame the application starts over -- T_wl = identity, SdfReset(vol, NaN),
+    the current frame fused -- and tracks on from there, in a world frame that sits at that frame's camera."""
+    import oracle_ops as ops
+    from kangaroo_amd.pipeline import TrackingPipeline
+    N, w, h = 64, 160, 120
+    bmin, bmax, near, far = scenes.SCENES["room"]
+    pipe = TrackingPipeline(ops, (N, N, N), bmin, bmax, w, h, near=near, far=far)
+    drop, anchor = 3, None
+    for i in range(8):
+        T_true = scenes.orbit_pose(i, 60)
+        depth = scenes.render_depth("room", w, h, T_true, pipe.K)
+        if i == drop:
+            depth = np.full_like(depth, np.nan)
+        pipe.raw.MemcpyFromHost(depth)
+        before = pipe.T_wl.copy()
+        T_est = pipe.step(T_wl_init=T_true if i == 0 else None)
+        if i == drop:
+            assert not pipe.tracking_good and not np.isfinite(pipe.rmse) and np.array_equal(T_est, before) and pipe.resets == 0
+            continue
+        if i == drop + 1:
+            assert pipe.resets == 1
+            anchor = np.vstack([T_true, [0, 0, 0, 1]])   # the new world frame = this frame's camera
+        assert pipe.tracking_good and np.isfinite(pipe.rmse), i
+        T_abs = T_est if anchor is None else anchor @ T_est
+        assert np.linalg.norm(T_abs[:3, 3] - T_true[:3, 3]) < 1e-2, (i, T_abs[:3, 3], T_true[:3, 3])
+    assert pipe.resets == 1
+    # the model was rebuilt from the frames after the drop-out only: cells the first three frames alone had observed are unknown again
+    assert np.isnan(pipe.vol.data[..., 0]).any() and np.isfinite(pipe.vol.data[..., 0]).sum() > 0.2 * N ** 3
