@@ -11,6 +11,7 @@
 // k*S + l), the levels S < 64 are wave64 lane shifts -- so a block's sum is bit-identical to the
 // reference's.  The sum over blocks (thrust::reduce: order unspecified in the reference) is a fixed order
 // here: thread t of one 256-thread group adds blocks t, t+256, ... in turn, then the same tree.
+#include <cstdlib>
 #include <string.h>
 
 #include "kfx_device.h"
@@ -74,32 +75,19 @@ struct IcpParams {
     float* sums;        // gridDim.x * gridDim.y systems of 29 words
 };
 
-__global__ __launch_bounds__(256) void k_icp_point_plane(const IcpParams p)
+// one pixel's contribution (cu_model_refinement.cu:541-590) and its debug colour
+__device__ __forceinline__ void icp_pixel(Lss& sum, float4& dbg, const ImgView& Pl_img, const ImgView& Pr_img, const ImgView& Nr_img, const Pose& KT_lr,
+                                          const Pose& T_rl, const float c, const unsigned u, const unsigned v)
 {
-    extern __shared__ float lds[];
-    const int n = blockDim.x * blockDim.y;
-    const int tid = threadIdx.y * blockDim.x + threadIdx.x;
-    const unsigned u = blockIdx.x * blockDim.x + threadIdx.x;
-    const unsigned v = blockIdx.y * blockDim.y + threadIdx.y;
-
-    Lss sum;
-    lss_zero(sum);
-
-    Pose KT_lr = p.KT_lr, T_rl = p.T_rl;
-    if (p.dev_pose) { // uniform loads: the pose was written by k_lss_final_solve of the previous iteration
-#pragma unroll
-        for (int i = 0; i < 12; ++i) { KT_lr.m[i] = p.dev_pose[i]; T_rl.m[i] = p.dev_pose[12 + i]; }
-    }
-    const float4 Pr = row<float4>(p.Pr, v)[u];
-    const float4 Nr = row<float4>(p.Nr, v)[u];
+    const float4 Pr = row<float4>(Pr_img, v)[u];
+    const float4 Nr = row<float4>(Nr_img, v)[u];
     const V3 KPl = se3_mul(KT_lr, v3(Pr.x, Pr.y, Pr.z));
     const float plx = KPl.x / KPl.z, ply = KPl.y / KPl.z;
-    float4 dbg;
     // Image::InBounds(pl, 3): border <= x && x < (w - border) with w converted to float (Image.h:288-291)
-    if (isfinite(Pr.z) && Nr.w == 1.0f && 3.0f <= plx && plx < ((float)p.Pl.w - 3.0f) && 3.0f <= ply && ply < ((float)p.Pl.h - 3.0f)) {
+    if (isfinite(Pr.z) && Nr.w == 1.0f && 3.0f <= plx && plx < ((float)Pl_img.w - 3.0f) && 3.0f <= ply && ply < ((float)Pl_img.h - 3.0f)) {
         // GetNearestNeighbour: Get(u + 0.5, v + 0.5) -- the sum is a double, truncated to int (Image.h:337-340)
         const int nx = (int)((double)plx + 0.5), ny = (int)((double)ply + 0.5);
-        const float4 Pl = row<float4>(p.Pl, ny)[nx];
+        const float4 Pl = row<float4>(Pl_img, ny)[nx];
         if (isfinite(Pl.z)) {
             const V3 _Pr = se3_mul(T_rl, v3(Pl.x, Pl.y, Pl.z));
             const V3 Dr = v3(_Pr.x - Pr.x, _Pr.y - Pr.y, _Pr.z - Pr.z);
@@ -115,9 +103,9 @@ __global__ __launch_bounds__(256) void k_icp_point_plane(const IcpParams p)
             J[5] = -dot(v3(-_Pr.y, _Pr.x, 0.f), N);
             // LSReweightTukey (reweighting.h:22-28)
             const float absr = fabsf(y);
-            const float roc = y / p.c;
+            const float roc = y / c;
             const float omroc2 = 1.0f - roc * roc;
-            const float tukey = (absr <= p.c) ? omroc2 * omroc2 : 0.0f;
+            const float tukey = (absr <= c) ? omroc2 * omroc2 : 0.0f;
             const float w = (1.0f / Pr.z) * tukey;
             const float yw = y * w;
 #pragma unroll
@@ -136,6 +124,26 @@ __global__ __launch_bounds__(256) void k_icp_point_plane(const IcpParams p)
     } else {
         dbg = make_float4(1.f, 0.f, 0.f, 1.f);
     }
+}
+
+__global__ __launch_bounds__(256) void k_icp_point_plane(const IcpParams p)
+{
+    extern __shared__ float lds[];
+    const int n = blockDim.x * blockDim.y;
+    const int tid = threadIdx.y * blockDim.x + threadIdx.x;
+    const unsigned u = blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned v = blockIdx.y * blockDim.y + threadIdx.y;
+
+    Lss sum;
+    lss_zero(sum);
+
+    Pose KT_lr = p.KT_lr, T_rl = p.T_rl;
+    if (p.dev_pose) { // uniform loads: the pose was written by k_lss_final_solve of the previous iteration
+#pragma unroll
+        for (int i = 0; i < 12; ++i) { KT_lr.m[i] = p.dev_pose[i]; T_rl.m[i] = p.dev_pose[12 + i]; }
+    }
+    float4 dbg;
+    icp_pixel(sum, dbg, p.Pl, p.Pr, p.Nr, KT_lr, T_rl, p.c, u, v);
     if (p.dbg) reinterpret_cast<float4*>(p.dbg + (size_t)v * p.dbg_pitch)[u] = dbg;
 
     lss_tree(sum, tid, n, lds);
@@ -340,6 +348,148 @@ __global__ __launch_bounds__(256) void k_lss_final_solve(float* sums, const int 
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// The whole refinement -- every level, every iteration -- as ONE launch (round-4 verdict, item 6: the chain above is 13 launches
+// of 5-9 us of work each, and a frame's budget is 0.4 ms).  A fixed number of workgroups stays resident and walks the schedule:
+//   A. the workgroups share out the level's pixel blocks (the reference's launch geometry: gcd(w, 16) x gcd(h, 16) pixels,
+//      launch_utils.h:61-65) and leave each block's system in `sums` -- the same per-pixel function, the same tree
+//      (lss_tree), so the same bits as k_icp_point_plane;
+//   B. one grid-wide barrier (an arrival counter and a generation word in device memory: release fence + atomic add; the last
+//      one to arrive advances the generation, the others poll it with s_sleep between two looks, then an acquire fence);
+//   C. EVERY workgroup adds up the blocks' systems in k_lss_final's fixed order and takes the 6 x 6 step by itself (thread 0,
+//      float64: deterministic, so all workgroups hold the same pose without a second barrier or a broadcast); workgroup 0 leaves
+//      the result in the RefineState.
+// `sums` is double-buffered by iteration parity: a workgroup may already be writing the next iteration's block systems while a
+// slower one still adds up this iteration's.  Every poll is bounded: if a workgroup never arrives (the grid was not resident
+// after all), the others set the abort word, leave, and the host reports KFX_E_RANGE instead of waiting for a watchdog.
+// The grid is at most the device's resident capacity for this kernel (hipOccupancyMaxActiveBlocksPerMultiprocessor).
+// ---------------------------------------------------------------------------------------
+struct IcpLevelDev {
+    ImgView Pl, Pr, Nr;
+    float K[4];
+    int iterations, rotation_only;
+    int bx, by, gx, gy;   // block shape (pixels), blocks along x / y
+};
+struct IcpPersistent {
+    IcpLevelDev lv[4];
+    int n_levels;
+    float c, max_rmse;
+    unsigned char* dbg;
+    size_t dbg_pitch;
+    int dbg_w, dbg_h;
+    float* sums[2];        // block systems, by iteration parity
+    RefineState* st;       // result (workgroup 0)
+    unsigned* bar;         // [0] arrivals, [1] generation, [2] abort
+};
+
+__device__ __forceinline__ bool grid_barrier(unsigned* bar, const unsigned n_groups, unsigned& gen)
+{
+    __shared__ int s_ok;
+    __syncthreads();
+    if (threadIdx.x == 0 && threadIdx.y == 0) {
+        int ok = 1;
+        __threadfence();   // release: this workgroup's block systems are visible device-wide before it is counted
+        const unsigned arrived = __hip_atomic_fetch_add(&bar[0], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (arrived == n_groups - 1) {
+            __hip_atomic_store(&bar[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&bar[1], gen + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            unsigned spins = 0;
+            while (__hip_atomic_load(&bar[1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == gen) {
+                if (__hip_atomic_load(&bar[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u || ++spins > (1u << 22)) {   // ~ a second
+                    __hip_atomic_store(&bar[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ok = 0;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+            }
+        }
+        __threadfence();   // acquire: the other workgroups' systems
+        s_ok = ok;
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // (every wave: nothing it loads from here on may be older than the barrier)
+    gen += 1;
+    return s_ok != 0;
+}
+
+__global__ __launch_bounds__(256) void k_icp_refine_persistent(const IcpPersistent q)
+{
+    __shared__ float lds[LSS_WORDS * 128];
+    __shared__ float s_sum[LSS_WORDS];
+    __shared__ RefineState s_st;
+    const int tid = threadIdx.x;
+    const unsigned G = gridDim.x;
+    unsigned gen = 0;   // (the host zeroes the barrier words before the launch)
+    int first = -1;
+    for (int l = 0; l < q.n_levels; ++l)
+        if (q.lv[l].iterations > 0 && q.lv[l].gx > 0 && q.lv[l].gy > 0) { first = l; break; }
+    if (tid == 0) {
+        for (int i = 0; i < 12; ++i) s_st.T[i] = (i % 5 == 0) ? 1.0 : 0.0;
+        s_st.rmse = 0.0; s_st.obs = 0.0; s_st.good = 1.0;
+        float k0[4] = {0.f, 0.f, 0.f, 0.f};
+        if (first >= 0) for (int i = 0; i < 4; ++i) k0[i] = q.lv[first].K[i];
+        publish_pose(&s_st, k0);
+    }
+    __syncthreads();
+    int parity = 0;
+    bool alive = true;
+    for (int l = 0; l < q.n_levels && alive; ++l) {
+        const IcpLevelDev& L = q.lv[l];
+        if (L.iterations <= 0 || L.gx <= 0 || L.gy <= 0) continue;
+        const int n = L.bx * L.by, nblocks = L.gx * L.gy;
+        const int tx = tid % L.bx, ty = tid / L.bx;
+        int nxt = -1;
+        for (int m = l + 1; m < q.n_levels; ++m)
+            if (q.lv[m].iterations > 0 && q.lv[m].gx > 0 && q.lv[m].gy > 0) { nxt = m; break; }
+        const bool dbg_on = q.dbg && q.dbg_w >= L.Pl.w && q.dbg_h >= L.Pl.h;
+        for (int it = 0; it < L.iterations && alive; ++it, parity ^= 1) {
+            float* sums = q.sums[parity];
+            Pose KT_lr, T_rl;
+#pragma unroll
+            for (int i = 0; i < 12; ++i) { KT_lr.m[i] = s_st.pose[i]; T_rl.m[i] = s_st.pose[12 + i]; }
+            // ---- A: this workgroup's share of the pixel blocks ----
+            for (int b = (int)blockIdx.x; b < nblocks; b += (int)G) {
+                const unsigned u = (unsigned)((b % L.gx) * L.bx + tx), v = (unsigned)((b / L.gx) * L.by + ty);
+                Lss sum;
+                lss_zero(sum);
+                if (tid < n) {
+                    float4 dbg;
+                    icp_pixel(sum, dbg, L.Pl, L.Pr, L.Nr, KT_lr, T_rl, q.c, u, v);
+                    if (dbg_on) reinterpret_cast<float4*>(q.dbg + (size_t)v * q.dbg_pitch)[u] = dbg;
+                }
+                lss_tree(sum, tid, n, lds);
+                if (tid == 0) lss_store(sums + (size_t)b * LSS_WORDS, sum);
+                __syncthreads();   // (lds is reused by the next block's tree)
+            }
+            // ---- B ----
+            alive = grid_barrier(q.bar, G, gen);
+            if (!alive) break;
+            // ---- C: the sum over the blocks in k_lss_final's order, and the step ----
+            Lss acc;
+            lss_zero(acc);
+            for (int b = tid; b < nblocks; b += 256) {
+                const float* sp = sums + (size_t)b * LSS_WORDS;
+#pragma unroll
+                for (int k = 0; k < 28; ++k) acc.f[k] += __builtin_nontemporal_load(sp + k);   // (written by other workgroups during this launch: never through the scalar cache)
+                acc.obs += __float_as_uint(__builtin_nontemporal_load(sp + 28));
+            }
+            lss_tree(acc, tid, 256, lds);
+            if (tid == 0) {
+                lss_store(s_sum, acc);
+                const float* Kn = (it + 1 < L.iterations || nxt < 0) ? L.K : q.lv[nxt].K;
+                float kn[4] = {Kn[0], Kn[1], Kn[2], Kn[3]};
+                icp_solve_step(&s_st, s_sum, L.rotation_only, q.max_rmse, kn);
+            }
+            __syncthreads();
+        }
+    }
+    if (blockIdx.x == 0 && tid == 0) {
+        if (!alive) s_st.good = -1.0;   // the grid never met: reported by the host
+        *q.st = s_st;
+    }
+}
+
 static unsigned gcd_u(unsigned a, unsigned b) { return b == 0 ? a : gcd_u(b, a % b); }
 
 } // namespace kfx
@@ -427,6 +577,73 @@ extern "C" int kfx_icp_refine(const kfx_icp_level* levels, int n_levels, float c
     hipStream_t s = (hipStream_t)stream;
     float* sums = (float*)workspace->ptr;
     RefineState* st = (RefineState*)((unsigned char*)workspace->ptr + state_off);
+    // One persistent launch (k_icp_refine_persistent) where the workspace has room for the second set of block systems and the
+    // barrier words, the levels fit its table and the device can hold the grid; KFX_ICP_PERSISTENT=0 keeps the chain of launches.
+    static const int persistent_env = [] { const char* e = getenv("KFX_ICP_PERSISTENT"); return e ? atoi(e) : 1; }();
+    const size_t sums2_off = (state_off + sizeof(RefineState) + 255) / 256 * 256, bar_off = sums2_off + state_off;
+    bool fits = persistent_env != 0 && n_levels <= 4 && bar_off + 256 <= workspace->pitch * workspace->h;
+    for (int l = 0; l < n_levels && fits; ++l) {
+        const kfx_icp_level& L = levels[l];
+        if (L.iterations <= 0 || L.Pl.w == 0 || L.Pl.h == 0) continue;
+        if (gcd_u((unsigned)L.Pl.w, 16) * gcd_u((unsigned)L.Pl.h, 16) > 256u || L.Pl.w > 0x7fffffffull || L.Pl.h > 0x7fffffffull) fits = false;
+    }
+    if (fits) {
+        static int capacity = -1;   // workgroups of this kernel the device holds at once
+        if (capacity < 0) {
+            int dev = 0, cus = 0, per_cu = 0;
+            if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
+                hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_icp_refine_persistent, 256, 0) == hipSuccess)
+                capacity = cus * (per_cu < 2 ? per_cu : 2);   // two per CU are plenty (a level has at most a few blocks per workgroup); well inside what fits
+            else
+                capacity = 0;
+            (void)hipGetLastError();
+        }
+        if (capacity >= 1) {
+            IcpPersistent q;
+            memset(&q, 0, sizeof(q));
+            size_t most = 1;
+            for (int l = 0; l < n_levels; ++l) {
+                const kfx_icp_level& L = levels[l];
+                IcpLevelDev& d = q.lv[l];
+                d.iterations = (L.Pl.w && L.Pl.h) ? L.iterations : 0;
+                d.rotation_only = L.rotation_only ? 1 : 0;
+                for (int i = 0; i < 4; ++i) d.K[i] = L.K[i];
+                if (d.iterations <= 0) continue;
+                d.Pl = ImgView{(const unsigned char*)L.Pl.ptr, L.Pl.pitch, (int)L.Pl.w, (int)L.Pl.h};
+                d.Pr = ImgView{(const unsigned char*)L.Pr.ptr, L.Pr.pitch, (int)L.Pr.w, (int)L.Pr.h};
+                d.Nr = ImgView{(const unsigned char*)L.Nr.ptr, L.Nr.pitch, (int)L.Nr.w, (int)L.Nr.h};
+                d.bx = (int)gcd_u((unsigned)L.Pl.w, 16); d.by = (int)gcd_u((unsigned)L.Pl.h, 16);
+                d.gx = (int)(L.Pl.w / d.bx); d.gy = (int)(L.Pl.h / d.by);
+                if ((size_t)d.gx * d.gy > most) most = (size_t)d.gx * d.gy;
+            }
+            q.n_levels = n_levels;
+            q.c = c; q.max_rmse = max_rmse;
+            const bool dbg = debug && debug->ptr && !(((uintptr_t)debug->ptr | debug->pitch) & 15);
+            q.dbg = dbg ? (unsigned char*)debug->ptr : nullptr;
+            q.dbg_pitch = dbg ? debug->pitch : 0;
+            q.dbg_w = dbg ? (int)debug->w : 0; q.dbg_h = dbg ? (int)debug->h : 0;
+            q.sums[0] = sums;
+            q.sums[1] = (float*)((unsigned char*)workspace->ptr + sums2_off);
+            q.st = st;
+            q.bar = (unsigned*)((unsigned char*)workspace->ptr + bar_off);
+            const unsigned grid = (unsigned)((size_t)capacity < most ? (size_t)capacity : most);
+            hipError_t he = hipMemsetAsync(q.bar, 0, 64, s);
+            if (he != hipSuccess) { (void)hipGetLastError(); return set_error((int)he, "kfx_icp_refine: hipMemsetAsync"); }
+            hipLaunchKernelGGL(k_icp_refine_persistent, dim3(grid), dim3(256), 0, s, q);
+            if (int e0 = check_launch("kfx_icp_refine")) return e0;
+            thread_local double* stage_p = nullptr;
+            if (!stage_p && hipHostMalloc((void**)&stage_p, 15 * sizeof(double), hipHostMallocDefault) != hipSuccess) return set_error(KFX_E_RANGE, "kfx_icp_refine: pinned staging");
+            hipError_t e = hipMemcpyAsync(stage_p, st, 15 * sizeof(double), hipMemcpyDeviceToHost, s);
+            if (e == hipSuccess) e = hipStreamSynchronize(s);
+            if (e != hipSuccess) return set_error((int)e, hipGetErrorString(e));
+            if (stage_p[14] < 0.0) return set_error(KFX_E_RANGE, "kfx_icp_refine: the persistent grid never met at its barrier (not resident)");
+            for (int i = 0; i < 12; ++i) T_lp[i] = stage_p[i];
+            if (rmse) *rmse = (float)stage_p[12];
+            if (obs) *obs = (unsigned)stage_p[13];
+            if (tracking_good) *tracking_good = stage_p[14] != 0.0 ? 1 : 0;
+            return 0;
+        }
+    }
     // flatten the schedule so that every solve knows the intrinsics of the evaluation that follows it
     int first = -1;
     for (int l = 0; l < n_levels; ++l)

@@ -73,6 +73,14 @@ def _L():
             "kfx_comm_create_threads": (C.c_int, [_P, C.c_int]),
             "kfx_comm_create_loopback": (C.c_int, [_P, C.c_int, C.c_int]),
             "kfx_slab_layout_init": (C.c_int, [PL, C.c_size_t, C.c_float, C.c_float, C.c_int, C.c_int, C.c_int]),
+            "kfx_slab_broadcast_inputs": (C.c_int, [PI, PI, V, C.c_int, _P, V]),
+            "kfx_slab_exchange_halos": (C.c_int, [PV, PL, _P, V]),
+            "kfx_slab_composite": (C.c_int, [PI, PI, PI, V, V, _P, V]),
+            "kfx_slab_composite_direct_scratch_bytes": (C.c_size_t, [C.c_size_t, C.c_size_t, C.c_int]),
+            "kfx_slab_composite_direct": (C.c_int, [PI, PI, PI, V, _P, V]),
+            "kfx_slab_exact_scratch_bytes": (C.c_size_t, [C.c_size_t, C.c_size_t]),
+            "kfx_slab_raycast_exact": (C.c_int, [PI, PI, PI, V, V, PV, PL, PF, PF, C.c_float, C.c_float, C.c_float, C.c_int, _P, V, C.POINTER(C.c_int)]),
+            "kfx_slab_raycast_exact_allreduce": (C.c_int, [PI, PI, PI, V, V, PV, PL, PF, PF, C.c_float, C.c_float, C.c_float, C.c_int, _P, V, C.POINTER(C.c_int)]),
             "kfx_slab_exact_tiled_scratch_bytes": (C.c_size_t, [C.c_size_t, C.c_size_t, C.c_int]),
             "kfx_slab_raycast_exact_tiled": (C.c_int, [PI, PI, PI, V, PV, PL, PF, PF, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, _P, V,
                                                        C.POINTER(C.c_int), C.POINTER(C.c_int)]),

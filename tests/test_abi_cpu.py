@@ -350,3 +350,58 @@ def test_composite_strip_layout_and_argument_checks_without_a_gpu():
     assert L.kfx_composite_strips_unpack(None, None, None, buf, 0, 2, None) == -1
     assert L.kfx_slab_composite_direct(None, None, None, None, None, None) == -1
     assert L.kfx_slab_composite_direct_scratch_bytes(640, 480, 8) == (2 * 8 + 1) * 5 * 38400 * 4
+
+
+def test_slab_frame_and_tiled_march_validate_their_arguments_without_a_gpu():
+    """kfx_slab_frame_create / kfx_slab_raycast_exact_tiled (include/kfx_slab.h) check views, layout and policies before any HIP call;
+    the in-process and loop-back transports are plain host objects; the ctypes mirrors have the C structs' sizes."""
+    from kangaroo_amd import slab
+    L = slab._L()
+    # sizes of the C structs (gcc) against the ctypes mirrors
+    src = os.path.join(T.ROOT, "include")
+    code = '#include <cstdio>\n#include "kfx_slab.h"\nint main(){ printf("%zu %zu %zu\\n", sizeof(kfx_slab_frame_config), sizeof(kfx_comm), sizeof(kfx_slab_layout)); }\n'
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        open(os.path.join(td, "s.cpp"), "w").write(code)
+        subprocess.check_call(["g++", "-I", src, os.path.join(td, "s.cpp"), "-o", os.path.join(td, "s")])
+        sizes = [int(x) for x in subprocess.check_output([os.path.join(td, "s")]).split()]
+    assert sizes == [C.sizeof(slab.KfxSlabFrameConfig), C.sizeof(slab.KfxComm), C.sizeof(slab.KfxSlabLayout)]
+    comms = slab.Comm.threads(3)
+    assert [c.rank for c in comms] == [0, 1, 2] and all(c.world == 3 for c in comms) and bool(comms[1].c.exchange_v)
+    comms[0].destroy()
+    lb = slab.Comm.loopback(3, 8)
+    assert (lb.rank, lb.world) == (3, 8) and bool(lb.c.all_to_all) and bool(lb.c.exchange_v)
+    assert L.kfx_comm_create_loopback(None, 0, 1) == -1 and L.kfx_comm_create_loopback(C.byref(slab.KfxComm()), 2, 2) == -4
+    # the frame object
+    h = C.c_void_p()
+    cfg = slab.KfxSlabFrameConfig()
+    assert L.kfx_slab_frame_create(C.byref(h), None, lb.ref()) == -1 and L.kfx_slab_frame_create(C.byref(h), C.byref(cfg), None) == -1
+    assert L.kfx_slab_frame_create(C.byref(h), C.byref(cfg), lb.ref()) == -1            # null volume
+    fake, w, hh = 0x10000, 40, 30
+    lay = slab.layout(64, 2.0, 4.0, 3, 8, 2)
+    cfg.layout = lay
+    cfg.local = _lib.KfxVolume(64 * 8, fake, 64, 64, 64 * 8 * 64, lay.s1 - lay.s0)
+    assert L.kfx_slab_frame_create(C.byref(h), C.byref(cfg), lb.ref()) == -2            # image views missing
+    f1, f4 = _lib.KfxImage(w * 4, fake, w, hh), _lib.KfxImage(w * 16, fake, w, hh)
+    cfg.raw, cfg.filtered, cfg.vbo, cfg.normals, cfg.ray_depth, cfg.ray_norm, cfg.ray_img = f1, f1, f4, f4, f1, f4, f1
+    other = slab.Comm.loopback(2, 8)
+    assert L.kfx_slab_frame_create(C.byref(h), C.byref(cfg), other.ref()) == -2        # the communicator's rank is not the layout's
+    cfg.local.d = 5
+    assert L.kfx_slab_frame_create(C.byref(h), C.byref(cfg), lb.ref()) == -2            # plane count does not match the layout
+    cfg.local.d = lay.s1 - lay.s0
+    for field, bad in (("halo", 2), ("raycast", 7), ("merge", -1), ("inputs", 3), ("tiles", 65)):
+        setattr(cfg, field, bad)
+        assert L.kfx_slab_frame_create(C.byref(h), C.byref(cfg), lb.ref()) == -4, field
+        setattr(cfg, field, 0)
+    cfg.overlap, cfg.raycast = 1, slab.RAYCAST["exact"]                                   # an overlapped merge belongs to the composite ...
+    assert L.kfx_slab_frame_create(C.byref(h), C.byref(cfg), lb.ref()) == -4 and b"overlap needs" in L.kfx_last_error_string()
+    cfg.raycast, cfg.halo = slab.RAYCAST["composite"], slab.HALO["exchange"]             # ... with nothing else communicating
+    assert L.kfx_slab_frame_create(C.byref(h), C.byref(cfg), lb.ref()) == -4
+    cfg.timing_slots, cfg.overlap = -1, 0
+    assert L.kfx_slab_frame_create(C.byref(h), C.byref(cfg), lb.ref()) == -4
+    assert L.kfx_slab_frame_step(None, None, None, None, 0, None) == -1 and L.kfx_slab_frame_wait(None, None) == -1
+    assert L.kfx_slab_frame_count(None) == 0 and L.kfx_slab_frame_destroy(None) == 0
+    # the tiled hand-over: scratch size grows with the tile count only by the padding of the last tile, arguments are checked
+    one, four = L.kfx_slab_exact_tiled_scratch_bytes(640, 480, 1), L.kfx_slab_exact_tiled_scratch_bytes(640, 480, 4)
+    assert one == four == (5 + 4 + 5 + 5 + 1 + 6) * 640 * 480 * 4 + 256 and L.kfx_slab_exact_tiled_scratch_bytes(640, 487, 8) >= one
+    assert L.kfx_slab_raycast_exact_tiled(None, None, None, None, None, None, None, None, 0.4, 4.0, 0.01, 1, 4, None, None, None, None) == -1

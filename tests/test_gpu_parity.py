@@ -8,6 +8,7 @@ cu_bilateral.cu:31-32), so it is compared with a stated tolerance of 2e-6 relati
 """
 import json
 import os
+import subprocess
 
 import numpy as np
 import pytest
@@ -1323,6 +1324,50 @@ def test_gpu_device_resident_icp_loop(roo):
         assert pipe.tracking_good
         worst = max(worst, float(np.linalg.norm(T_est[:3, 3] - T_true[:3, 3])))
     assert worst < 0.2 * float(np.linalg.norm(scenes.orbit_pose(frames - 1, 30)[:3, 3] - scenes.orbit_pose(0, 30)[:3, 3]))
+
+
+def test_gpu_persistent_icp_kernel_equals_the_chain_of_launches():
+    """kfx_icp_refine as ONE persistent launch (k_icp_refine_persistent: all levels and iterations, a grid-wide barrier between
+    the block systems and the step, every workgroup solving for itself) against the chain of thirteen launches
+    (KFX_ICP_PERSISTENT=0): the same per-pixel function, block tree, block order and float64 step, so the same pose, rmse and
+    observation count BIT FOR BIT -- at 640x480 (1200 blocks over the resident grid: several per workgroup) and 160x120, for the
+    application's schedule and two others, repeated calls (the barrier words are re-armed per call)."""
+    import json
+    import sys
+    code = r"""
+import json, sys
+import numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+from kangaroo_amd import roo, scenes
+import kfx_testlib as T
+import test_tracking_cpu as TT
+out = []
+for w, h in ((640, 480), (160, 120)):
+    K = scenes.intrinsics(w, h)
+    T_wp, T_wl = scenes.orbit_pose(0, 60), scenes.orbit_pose(1, 60)
+    _, ray_v, ray_n, Ks = TT.pyramid_maps("room", w, h, T_wp, K)
+    _, kin_v, _, _ = TT.pyramid_maps("room", w, h, T_wl, K)
+    up = lambda imgs: [T.upload_image(roo, im.data) for im in imgs]
+    g_kin, g_rv, g_rn = up(kin_v), up(ray_v), up(ray_n)
+    ws, dbg = roo.Image(w * 232, h, "u8"), roo.Image(w, h, "f32x4")
+    for its in ((1, 0, 2, 3), (4, 3, 3, 3), (2, 0, 0, 0)):
+        for rep in range(3):
+            Tm, rmse, obs, good = roo.IcpRefine(g_kin, g_rv, g_rn, Ks, its, 0.1, 0.10, ws, dbg)
+            out.append([np.asarray(Tm, np.float64).tobytes().hex(), float(np.float32(rmse)).hex(), int(obs), bool(good), dbg.MemcpyToHost().tobytes().hex()[:4096]])
+print("RESULT " + json.dumps(out))
+""" % (T.ROOT, os.path.join(T.ROOT, "tests"))
+    res = {}
+    for knob in ("0", "1"):
+        o = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, KFX_ICP_PERSISTENT=knob), capture_output=True, text=True, timeout=900, cwd=T.ROOT)
+        line = [l for l in o.stdout.splitlines() if l.startswith("RESULT ")]
+        assert o.returncode == 0 and line, o.stdout[-2000:] + o.stderr[-3000:]
+        res[knob] = json.loads(line[0][7:])
+    assert len(res["0"]) == len(res["1"]) == 18
+    for a, b in zip(res["0"], res["1"]):
+        assert a == b, (a[:4], b[:4])
+        assert a[2] > 0
+    for k in range(0, 18, 3):   # repeated calls give the same answer
+        assert res["1"][k] == res["1"][k + 1] == res["1"][k + 2]
 
 
 def test_gpu_texture_depth(roo):
