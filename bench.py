@@ -853,7 +853,7 @@ def run_slabs(args, torch, dist, roo, scenes, rank, world):
         for i in range(BLOCK, n_prime):
             pipe.step(poses[i % N_ORBIT], frames[i % N_ORBIT])
     if sf is not None:
-        sf.set_timing(True)   # five markers per frame around its parts (the exact march is one part: its stages have no gaps to hide)
+        sf.set_timing(sf.EVENTS_FUSE)   # the two markers around SdfFuse (its window; the frame period from one to the next): each costs ~3 us of a ~0.15 ms frame
     for i in range(args.warmup):
         pipe.step(poses[i % N_ORBIT], frames[i % N_ORBIT])
     sync_all()
@@ -881,12 +881,26 @@ def run_slabs(args, torch, dist, roo, scenes, rank, world):
     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     elapsed = float(tt.item())
 
-    pre_avg_ms, merge_avg_ms, frame_ev_ms = None, None, None
+    pre_avg_ms, merge_avg_ms, frame_ev_ms, period_ms = None, None, None, None
     if sf is not None:
         t = sf.timings(first, args.steps)   # preprocess, sdf_fuse (+ ghost planes), raycast, merge, frame, period
-        fuse_ms, ray_ms = t[:, 1], (t[:, 2] + np.nan_to_num(t[:, 3]))
-        pre_avg_ms, frame_ev_ms = float(np.mean(t[:, 0])), float(np.mean(t[:, 4]))
-        merge_avg_ms = float(np.mean(t[:, 3])) if np.isfinite(t[:, 3]).all() else None
+        fuse_ms = t[:, 1]
+        period_ms = float(np.nanmean(t[:, 5]))
+        # the parts of a frame, from as many frames with all five events right after the timed region (untimed)
+        sf.set_timing(sf.EVENTS_ALL)
+        n_parts = min(args.steps, 2 * N_ORBIT)
+        for s in range(3):
+            pipe.step(poses[s % N_ORBIT], frames[s % N_ORBIT])
+        f_parts = sf.count
+        for s in range(n_parts):
+            i = (args.warmup + s) % N_ORBIT
+            pipe.step(poses[i], frames[i])
+        sync_all()
+        tp = sf.timings(f_parts, n_parts)
+        sf.set_timing(sf.EVENTS_NONE)
+        ray_ms = tp[:, 2] + np.nan_to_num(tp[:, 3])
+        pre_avg_ms, frame_ev_ms = float(np.mean(tp[:, 0])), float(np.mean(tp[:, 4]))
+        merge_avg_ms = float(np.mean(tp[:, 3])) if np.isfinite(tp[:, 3]).all() else None
     else:
         fuse_ms = [ev[s][0].elapsed_time(ev[s][1]) for s in range(args.steps)]
         ray_ms = [ev[s][2].elapsed_time(ev[s][3]) for s in range(args.steps)]
@@ -1119,7 +1133,10 @@ def run_slabs(args, torch, dist, roo, scenes, rank, world):
             "kernels_ms": {"preprocess": None if pre_avg_ms is None else round(pre_avg_ms, 5), "sdf_fuse": round(fuse_avg_ms, 5),
                            "raycast_sdf+%s" % ("handover" if args.raycast != "composite" else "composite"): round(ray_avg_ms, 5),
                            "frame_events": None if frame_ev_ms is None else round(frame_ev_ms, 5), "frame_total": round(1e3 * elapsed / args.steps, 5),
-                           "host_gap": None if frame_ev_ms is None else round(1e3 * elapsed / args.steps - frame_ev_ms, 5)},
+                           "frame_period_events": None if period_ms is None else round(period_ms, 5),
+                           "host_gap": None if period_ms is None else round(1e3 * elapsed / args.steps - period_ms, 5),
+                           "note": "sdf_fuse: events of the timed steps; preprocess / raycast / frame_events: frames with all five events right after the "
+                                   "timed region; host_gap = frame by the host clock - frame period by the events of the timed steps"},
             "per_rank": per_rank,
             "multi_gpu_variants": variants,
         }

@@ -200,7 +200,12 @@ int kfx_slab_frame_wait(kfx_slab_frame* f, kfx_stream stream);
  * exact march of any frame so far */
 int kfx_slab_frame_sync(kfx_slab_frame* f, kfx_stream stream);
 long long kfx_slab_frame_count(const kfx_slab_frame* f);
-int kfx_slab_frame_set_timing(kfx_slab_frame* f, int on);
+/* which of the five events the following steps record (bit 0 before the preprocessing, 1 before SdfFuse, 2 after it, 3 after the
+ * march, 4 after the composite merge; 0: none, 31: all, 6: the two around SdfFuse -- an event is a marker between two launches and
+ * costs the stream ~3 us).  frame = first to last recorded event, period = first recorded event to the same event of the next frame. */
+#define KFX_SLAB_FRAME_EVENTS_ALL  31u
+#define KFX_SLAB_FRAME_EVENTS_FUSE  6u
+int kfx_slab_frame_set_timing(kfx_slab_frame* f, unsigned mask);
 int kfx_slab_frame_timings(kfx_slab_frame* f, long long first_frame, int n_frames, float* ms);
 int kfx_slab_frame_last_steps(const kfx_slab_frame* f);           /* stages of the last exact march (world + tiles - 1 + 1) */
 

@@ -382,33 +382,43 @@ struct IcpPersistent {
     unsigned* bar;         // [0] arrivals, [1] generation, [2] abort
 };
 
+// The block systems cross workgroups (and XCDs, whose L2s are not coherent with each other) through device-scope atomic stores
+// and loads -- they go to the device's coherence point and back, past the caches -- so that the barrier needs no cache-wide
+// release / acquire (an agent-scope fence writes back and invalidates a whole L2: measured, it made the persistent launch slower
+// than the chain of launches).  A store has reached that point when the wave's vector-memory counter has drained.
+__device__ __forceinline__ void lss_store_agent(float* dst, const Lss& s)
+{
+#pragma unroll
+    for (int k = 0; k < 28; ++k) __hip_atomic_store(dst + k, s.f[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(dst + 28, __uint_as_float(s.obs), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 __device__ __forceinline__ bool grid_barrier(unsigned* bar, const unsigned n_groups, unsigned& gen)
 {
     __shared__ int s_ok;
     __syncthreads();
     if (threadIdx.x == 0 && threadIdx.y == 0) {
         int ok = 1;
-        __threadfence();   // release: this workgroup's block systems are visible device-wide before it is counted
-        const unsigned arrived = __hip_atomic_fetch_add(&bar[0], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_s_waitcnt(0);   // this workgroup's block systems (thread 0 stored them) have reached the coherence point
+        const unsigned arrived = __hip_atomic_fetch_add(&bar[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (arrived == n_groups - 1) {
             __hip_atomic_store(&bar[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&bar[1], gen + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_s_waitcnt(0);
+            __hip_atomic_store(&bar[1], gen + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else {
             unsigned spins = 0;
-            while (__hip_atomic_load(&bar[1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == gen) {
+            while (__hip_atomic_load(&bar[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen) {
                 if (__hip_atomic_load(&bar[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u || ++spins > (1u << 22)) {   // ~ a second
                     __hip_atomic_store(&bar[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     ok = 0;
                     break;
                 }
-                __builtin_amdgcn_s_sleep(2);
+                __builtin_amdgcn_s_sleep(8);
             }
         }
-        __threadfence();   // acquire: the other workgroups' systems
         s_ok = ok;
     }
     __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // (every wave: nothing it loads from here on may be older than the barrier)
     gen += 1;
     return s_ok != 0;
 }
@@ -459,7 +469,7 @@ __global__ __launch_bounds__(256) void k_icp_refine_persistent(const IcpPersiste
                     if (dbg_on) reinterpret_cast<float4*>(q.dbg + (size_t)v * q.dbg_pitch)[u] = dbg;
                 }
                 lss_tree(sum, tid, n, lds);
-                if (tid == 0) lss_store(sums + (size_t)b * LSS_WORDS, sum);
+                if (tid == 0) lss_store_agent(sums + (size_t)b * LSS_WORDS, sum);
                 __syncthreads();   // (lds is reused by the next block's tree)
             }
             // ---- B ----
@@ -471,8 +481,8 @@ __global__ __launch_bounds__(256) void k_icp_refine_persistent(const IcpPersiste
             for (int b = tid; b < nblocks; b += 256) {
                 const float* sp = sums + (size_t)b * LSS_WORDS;
 #pragma unroll
-                for (int k = 0; k < 28; ++k) acc.f[k] += __builtin_nontemporal_load(sp + k);   // (written by other workgroups during this launch: never through the scalar cache)
-                acc.obs += __float_as_uint(__builtin_nontemporal_load(sp + 28));
+                for (int k = 0; k < 28; ++k) acc.f[k] += __hip_atomic_load(sp + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (written by other workgroups during this launch)
+                acc.obs += __float_as_uint(__hip_atomic_load(sp + 28, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
             }
             lss_tree(acc, tid, 256, lds);
             if (tid == 0) {
@@ -577,9 +587,12 @@ extern "C" int kfx_icp_refine(const kfx_icp_level* levels, int n_levels, float c
     hipStream_t s = (hipStream_t)stream;
     float* sums = (float*)workspace->ptr;
     RefineState* st = (RefineState*)((unsigned char*)workspace->ptr + state_off);
-    // One persistent launch (k_icp_refine_persistent) where the workspace has room for the second set of block systems and the
-    // barrier words, the levels fit its table and the device can hold the grid; KFX_ICP_PERSISTENT=0 keeps the chain of launches.
-    static const int persistent_env = [] { const char* e = getenv("KFX_ICP_PERSISTENT"); return e ? atoi(e) : 1; }();
+    // KFX_ICP_PERSISTENT=1: one persistent launch (k_icp_refine_persistent) where the workspace has room for the second set of block
+    // systems and the barrier words, the levels fit its table and the device can hold the grid.  Same bits as the chain of launches
+    // below, which stays the default: measured on MI355X (512^3 tracked frame, C++ loop) the chain takes 0.655 ms per frame, the
+    // persistent launch 0.754 (128 workgroups) - 0.844 ms (512) -- a grid-wide barrier across the eight XCDs and a 6 x 6 float64
+    // step in every workgroup cost more than the launch boundaries they replace (EXPERIMENTS.md 7.3).
+    static const int persistent_env = [] { const char* e = getenv("KFX_ICP_PERSISTENT"); return e ? atoi(e) : 0; }();
     const size_t sums2_off = (state_off + sizeof(RefineState) + 255) / 256 * 256, bar_off = sums2_off + state_off;
     bool fits = persistent_env != 0 && n_levels <= 4 && bar_off + 256 <= workspace->pitch * workspace->h;
     for (int l = 0; l < n_levels && fits; ++l) {
@@ -626,7 +639,10 @@ extern "C" int kfx_icp_refine(const kfx_icp_level* levels, int n_levels, float c
             q.sums[1] = (float*)((unsigned char*)workspace->ptr + sums2_off);
             q.st = st;
             q.bar = (unsigned*)((unsigned char*)workspace->ptr + bar_off);
-            const unsigned grid = (unsigned)((size_t)capacity < most ? (size_t)capacity : most);
+            static const int grid_env = [] { const char* e = getenv("KFX_ICP_GRID"); return e ? atoi(e) : 0; }();   // (A/B: cap on the resident workgroups)
+            size_t want = (size_t)capacity < most ? (size_t)capacity : most;
+            if (grid_env > 0 && (size_t)grid_env < want) want = (size_t)grid_env;
+            const unsigned grid = (unsigned)want;
             hipError_t he = hipMemsetAsync(q.bar, 0, 64, s);
             if (he != hipSuccess) { (void)hipGetLastError(); return set_error((int)he, "kfx_icp_refine: hipMemsetAsync"); }
             hipLaunchKernelGGL(k_icp_refine_persistent, dim3(grid), dim3(256), 0, s, q);

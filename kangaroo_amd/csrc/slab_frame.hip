@@ -37,7 +37,8 @@ struct kfx_slab_frame {
     hipEvent_t marched, merged;
     int merge_pending;
     // timing ring
-    int slots, timing;
+    int slots;
+    unsigned timing;                         // which of the five events the next steps record (bit k: event k)
     hipEvent_t* ev;
     long long* ev_frame;
     unsigned char* ev_mask;
@@ -121,7 +122,7 @@ extern "C" int kfx_slab_frame_create(kfx_slab_frame** out, const kfx_slab_frame_
     f->cfg = *cfg;
     f->comm = comm;
     f->slots = cfg->timing_slots;
-    f->timing = 1;
+    f->timing = 31u;
     for (int i = 0; i < OPEN_SLOTS; ++i) f->open_frame[i] = -1;
     int e = ensure_scratch(f);
     if (!e) e = hip_status(hipHostMalloc((void**)&f->h_open, OPEN_SLOTS * sizeof(int), hipHostMallocDefault), "kfx_slab_frame_create: hipHostMalloc");
@@ -173,10 +174,13 @@ extern "C" int kfx_slab_frame_destroy(kfx_slab_frame* f)
 extern "C" long long kfx_slab_frame_count(const kfx_slab_frame* f) { return f ? f->frames : 0; }
 extern "C" int kfx_slab_frame_last_steps(const kfx_slab_frame* f) { return f ? f->last_steps : 0; }
 
-extern "C" int kfx_slab_frame_set_timing(kfx_slab_frame* f, int on)
+// An event is a marker between two launches and costs the stream ~3 us (all five: a tenth of a 0.13 ms frame): a loop that is
+// itself being timed records the two around SdfFuse (mask 6: its window, and the frame period from one to the next).
+extern "C" int kfx_slab_frame_set_timing(kfx_slab_frame* f, unsigned mask)
 {
     if (!f) return set_error(KFX_E_NULL, "kfx_slab_frame_set_timing: null frame");
-    f->timing = on ? 1 : 0;
+    if (mask > 31u) return set_error(KFX_E_RANGE, "kfx_slab_frame_set_timing: mask");
+    f->timing = mask;
     return 0;
 }
 
@@ -269,7 +273,7 @@ extern "C" int kfx_slab_frame_step(kfx_slab_frame* f, const kfx_image* raw, cons
         if (f->timing) ev = f->ev + (size_t)slot * EV;
     }
     const auto record = [&](int k, hipStream_t on) {
-        if (!ev) return;
+        if (!ev || !(f->timing & (1u << k))) return;
         if (hipEventRecord(ev[k], on) == hipSuccess) f->ev_mask[slot] |= (unsigned char)(1u << k);
         else { (void)hipGetLastError(); note(set_error(KFX_E_RANGE, "kfx_slab_frame_step: hipEventRecord")); }
     };
@@ -375,16 +379,19 @@ extern "C" int kfx_slab_frame_timings(kfx_slab_frame* f, long long first_frame, 
         const auto span = [&](int a, int b, float* out) {
             if (he == hipSuccess && (m & (1u << a)) && (m & (1u << b))) he = hipEventElapsedTime(out, e[a], e[b]);
         };
+        int firstk = 0;
+        while (!(m & (1u << firstk))) ++firstk;
         span(0, 1, &o[0]);
         span(1, 2, &o[1]);
         span(2, 3, &o[2]);
         span(3, 4, &o[3]);
-        span(0, lastk, &o[4]);
-        if (he == hipSuccess && (m & 1u) && fr + 1 < f->frames) {
+        if (firstk != lastk) span(firstk, lastk, &o[4]);
+        // period: this frame's first recorded event to the same event of the next frame
+        if (he == hipSuccess && fr + 1 < f->frames) {
             const int ns = (int)((fr + 1) % f->slots);
-            if (f->ev_frame[ns] == fr + 1 && (f->ev_mask[ns] & 1u)) {
-                he = hipEventSynchronize(f->ev[(size_t)ns * EV]);
-                if (he == hipSuccess) he = hipEventElapsedTime(&o[5], e[0], f->ev[(size_t)ns * EV]);
+            if (f->ev_frame[ns] == fr + 1 && (f->ev_mask[ns] & (1u << firstk))) {
+                he = hipEventSynchronize(f->ev[(size_t)ns * EV + firstk]);
+                if (he == hipSuccess) he = hipEventElapsedTime(&o[5], e[firstk], f->ev[(size_t)ns * EV + firstk]);
             }
         }
         if (he != hipSuccess) { (void)hipGetLastError(); return set_error((int)he, "kfx_slab_frame_timings: hipEventElapsedTime"); }

@@ -378,12 +378,13 @@ class SlabPipeline(FramePipeline):
     USE_FRAME = False   # slabs: the operators take slab arguments and collectives sit between them
 
     def __init__(self, ops, dist, dims, boxmin, boxmax, w, h, halo="exchange", raycast="composite", kind="f32", overlap=False,
-                 inputs="replicate", images="all", merge="direct", driver="python", comm=None, tiles=0, **kw):
+                 inputs="replicate", images="all", merge="direct", driver="python", comm=None, tiles=0, unchecked=False, **kw):
         """driver = "c": every frame is ONE library call per rank (kfx_slab_frame_step, include/kfx_slab.h: the launches AND the
         collectives are enqueued by the library through `comm`, a kangaroo_amd.slab.Comm -- RCCL for one process per GPU; default:
         Comm.torch(dist), the collectives of the process group the caller has set up); driver = "python": this class issues the
         operators and torch.distributed collectives one by one (the cross-check, and what the CPU tests run on the oracle-backed
-        operator set).  Same bits either way.  tiles: row-tiles of the exact hand-over (C driver; 0 = the library's default).
+        operator set).  Same bits either way.  tiles: row-tiles of the exact hand-over (C driver; 0 = the library's default);
+        unchecked: do not fail when the exact march leaves rays open (loop-back measurements of ONE rank: scripts/slab_host_floor.py).
 
         halo = "exchange": every rank integrates only the planes it owns and the ghost planes are
         refreshed from the two neighbours after each SdfFuse (point-to-point send/recv: one xGMI link
@@ -450,7 +451,7 @@ class SlabPipeline(FramePipeline):
             assert (lay.z0, lay.z1, lay.s0, lay.s1) == (self.z0, self.z1, self.s0, self.s1)
             self.sframe = S.SlabFrame(self.comm, self.vol, lay, self.raw, self.filtered, self.vbo, self.normals, self.ray_d, self.ray_n, self.ray_i, self.K,
                                       self.bil, self.near, self.far, self.trunc, self.max_w, self.mincostheta, halo=halo, raycast=raycast, merge=merge,
-                                      inputs=inputs, overlap=overlap, tiles=tiles, timing_slots=int(timing_slots or 256))
+                                      inputs=inputs, overlap=overlap, tiles=tiles, unchecked=unchecked, timing_slots=int(timing_slots or 256))
 
     def configure(self, **kw):
         """Change policies between frames (halo, raycast, merge, inputs, overlap, tiles): bench.py times the variants on one pipeline."""

@@ -92,7 +92,7 @@ def _L():
             "kfx_slab_frame_wait": (C.c_int, [V, V]),
             "kfx_slab_frame_sync": (C.c_int, [V, V]),
             "kfx_slab_frame_count": (C.c_longlong, [V]),
-            "kfx_slab_frame_set_timing": (C.c_int, [V, C.c_int]),
+            "kfx_slab_frame_set_timing": (C.c_int, [V, C.c_uint]),
             "kfx_slab_frame_timings": (C.c_int, [V, C.c_longlong, C.c_int, PF]),
             "kfx_slab_frame_last_steps": (C.c_int, [V]),
         }
@@ -348,8 +348,12 @@ class SlabFrame:
     def last_steps(self):
         return int(_L().kfx_slab_frame_last_steps(self.handle))
 
-    def set_timing(self, on):
-        _lib.check(_L().kfx_slab_frame_set_timing(self.handle, int(bool(on))))
+    EVENTS_NONE, EVENTS_FUSE, EVENTS_ALL = 0, 6, 31
+
+    def set_timing(self, mask):
+        """Which device events the following steps record (EVENTS_*; True = all, False = none): each costs the stream ~3 us."""
+        mask = self.EVENTS_ALL if mask is True else (self.EVENTS_NONE if mask is False else int(mask))
+        _lib.check(_L().kfx_slab_frame_set_timing(self.handle, mask))
 
     def step(self, T_wc, T_cw=None, raw=None, parts=0, stream=None):
         twc = np.ascontiguousarray(np.asarray(T_wc, np.float32)[:3].reshape(-1))

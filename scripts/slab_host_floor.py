@@ -77,15 +77,15 @@ class LoopbackDist:
         return [self._Done() for _ in ops]
 
 
-def run(N, world, rank, raycast, driver, steps, scene="full", w=640, h=480, **kw):
+def run(N, world, rank, raycast, driver, steps, scene="full", w=640, h=480, events=31, **kw):
     bmin, bmax, near, far = scenes.SCENES[scene]
     K = scenes.intrinsics(w, h)
     dist = LoopbackDist(rank, world)
     comm = slab.Comm.loopback(rank, world) if driver == "c" else None
     pipe = SlabPipeline(roo, dist, (N, N, N), bmin, bmax, w, h, halo="recompute", raycast=raycast, K=K, near=near, far=far, driver=driver, comm=comm,
-                        timing_slots=steps + 64, **kw)
+                        timing_slots=steps + 64, unchecked=(driver == "c"), **kw)
     if pipe.sframe is not None:
-        pipe.sframe.configure()   # (nothing to change)
+        pipe.sframe.set_timing(events)
     poses = [scenes.orbit_pose(i, 30) for i in range(30)]
     frames = []
     for T in poses:
@@ -122,10 +122,10 @@ def run(N, world, rank, raycast, driver, steps, scene="full", w=640, h=480, **kw
     out = {"frame_host_clock_ms": round(total, 5), "frames_per_sec": round(1e3 / total, 1)}
     if pipe.sframe is not None:
         t = pipe.sframe.timings(first, steps)
-        out.update({"preprocess_ms": round(float(np.mean(t[:, 0])), 5), "sdf_fuse_ms": round(float(np.mean(t[:, 1])), 5), "raycast_ms": round(float(np.mean(t[:, 2])), 5),
-                    "merge_ms": None if not np.isfinite(t[:, 3]).all() else round(float(np.mean(t[:, 3])), 5),
-                    "frame_events_ms": round(float(np.mean(t[:, 4])), 5), "period_events_ms": round(float(np.nanmean(t[:, 5])), 5)})
-        out["host_gap_ms"] = round(total - out["frame_events_ms"], 5)
+        opt = lambda col: None if not np.isfinite(t[:, col]).all() else round(float(np.mean(t[:, col])), 5)   # noqa: E731
+        out.update({"events_recorded_per_frame": bin(events).count("1"), "preprocess_ms": opt(0), "sdf_fuse_ms": opt(1), "raycast_ms": opt(2), "merge_ms": opt(3),
+                    "frame_events_ms": opt(4), "period_events_ms": round(float(np.nanmean(t[:, 5])), 5)})
+        out["host_gap_ms"] = round(total - out["period_events_ms"], 5)
         if raycast == "exact":
             out["handover_steps"] = pipe.sframe.last_steps
     else:
@@ -144,6 +144,8 @@ def main():
         r["c_exact_tiles4"] = run(N, 8, 3, "exact", "c", 300, tiles=4)
         r["c_exact_tiles1"] = run(N, 8, 3, "exact", "c", 300, tiles=1)
         r["c_composite_direct"] = run(N, 8, 3, "composite", "c", 300, merge="direct")
+        r["c_composite_direct_two_events"] = run(N, 8, 3, "composite", "c", 300, merge="direct", events=6)
+        r["c_exact_tiles4_two_events"] = run(N, 8, 3, "exact", "c", 300, tiles=4, events=6)
         r["c_composite_direct_overlapped"] = run(N, 8, 3, "composite", "c", 300, merge="direct", overlap=True)
         r["python_composite_direct"] = run(N, 8, 3, "composite", "python", 300, merge="direct")
         r["python_composite_direct_overlapped"] = run(N, 8, 3, "composite", "python", 300, merge="direct", overlap=True)
