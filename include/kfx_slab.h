@@ -207,7 +207,7 @@ long long kfx_slab_frame_count(const kfx_slab_frame* f);
 #define KFX_SLAB_FRAME_EVENTS_FUSE  6u
 int kfx_slab_frame_set_timing(kfx_slab_frame* f, unsigned mask);
 int kfx_slab_frame_timings(kfx_slab_frame* f, long long first_frame, int n_frames, float* ms);
-int kfx_slab_frame_last_steps(const kfx_slab_frame* f);           /* stages of the last exact march (world + tiles - 1 + 1) */
+int kfx_slab_frame_last_steps(const kfx_slab_frame* f);           /* steps of the last exact march: world + tiles - 1 token steps + the normals' stage */
 
 #ifdef __cplusplus
 }

@@ -89,8 +89,8 @@ SIGNATURES = {
                                        C.c_float, C.c_float, C.c_float, C.c_int, C.c_void_p]),
     "kfx_raycast_sdf_slab_h": (C.c_int, [C.c_void_p, C.c_int, PV, C.POINTER(KfxSlab), C.c_int, C.c_int, C.c_int, C.c_int, PF, PF,
                                        C.c_float, C.c_float, C.c_float, C.c_int, C.c_void_p]),
-    "kfx_raycast_sdf_slab_tiles": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, PV,
-                                             C.POINTER(KfxSlab), C.c_int, C.c_int, C.c_int, C.c_int, PF, PF, C.c_float, C.c_float, C.c_float, C.c_int, C.c_void_p]),
+    "kfx_raycast_sdf_slab_tiles": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                             PV, C.POINTER(KfxSlab), C.c_int, C.c_int, C.c_int, C.c_int, PF, PF, C.c_float, C.c_float, C.c_float, C.c_int, C.c_void_p]),
     "kfx_raycast_state_to_images": (C.c_int, [PI, PI, PI, C.c_void_p, C.c_void_p]),
     "kfx_sdf_fuse_color": (C.c_int, [PV, PV, PI, PI, PF, PF, PI, PF, PF, C.c_float, C.c_float, C.c_float, C.c_uint, C.c_void_p]),
     "kfx_raycast_sdf_color": (C.c_int, [PI, PI, PI, PV, PV, PF, PF, C.c_float, C.c_float, C.c_float, C.c_int, C.c_void_p]),

@@ -680,7 +680,17 @@ struct SlabRay {
     int own_lo, own_hi; // owned trilinear base cells (global plane indices)
     int avail_lo, avail_hi; // planes stored locally (global indices)
     int init;           // 1: (re)initialise the state from the ray / box intersection
+    // Snapshots of the same rays received from the two neighbour ranks (march planes 0-3 as above; null: none): before marching, a
+    // ray takes a neighbour's snapshot when that one is NEWER than its own and still under way (kfx_slab_raycast_exact_tiled).
+    // adopt_tile_major: the buffers hold every tile ([tiles][5][P]) instead of just the tile of this launch ([5][P]).
+    const float* adopt_lo;
+    const float* adopt_hi;
+    int adopt_tile_major;
 };
+
+// Snapshots of one march order by progress: status 1 / 2 (final) after 3 (hit, normal pending) after 0 (marching), and of two
+// marching snapshots the one with the larger lambda is later (every step adds a positive delta).
+__device__ __forceinline__ int snapshot_order(float status) { return status == 0.0f ? 0 : (status == 3.0f ? 1 : 2); }
 
 __device__ __forceinline__ int cell_z(const RayParams& p, const V3 pos_w)
 {
@@ -726,6 +736,21 @@ __global__ __launch_bounds__(256) void k_raycast_sdf_slab(const RayParams p, con
         if (sl.fin) sl.fin[(size_t)v * p.w + u] = (sl.claim_misses && status == 2.f) ? 1 : 0;
     } else {
         lambda = st[0]; last_sdf = st[plane]; delta = st[2 * plane]; status = st[3 * plane];
+    }
+    // a neighbour's newer, still open snapshot of this ray replaces the rank's own (a stale copy is never advanced: its position
+    // lies in planes of a rank the ray has left, and final snapshots stay with the rank that finalised them)
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const float* src = k ? sl.adopt_hi : sl.adopt_lo;
+        if (!src) continue;
+        src += (sl.adopt_tile_major ? (size_t)tile * 5 * plane : (size_t)0) + q;
+        const float n_status = src[3 * plane];
+        if (!(n_status == 0.f || n_status == 3.f)) continue;
+        const float n_lambda = src[0];
+        const int on = snapshot_order(n_status), om = snapshot_order(status);
+        if (on > om || (on == 0 && om == 0 && n_lambda > lambda)) {
+            lambda = n_lambda; last_sdf = src[plane]; delta = src[2 * plane]; status = n_status;
+        }
     }
     const float lambda_in = lambda, status_in = status;
 
@@ -1171,16 +1196,22 @@ static SlabRay dense_state(float* state, int init, int w, int h)
     const size_t n = (size_t)(w > 0 ? w : 0) * (size_t)(h > 0 ? h : 0);
     g.state = state; g.result = state ? state + 5 * n : nullptr; g.P = n; g.R = h > 0 ? h : 1; g.v0 = 0; g.v1 = h; g.fin = nullptr; g.claim_misses = 0;
     g.init = init ? 1 : 0;
+    g.adopt_lo = g.adopt_hi = nullptr; g.adopt_tile_major = 0;
     return g;
 }
 
 extern "C" int kfx_raycast_sdf_slab_tiles(float* state, float* result, size_t plane_stride, int rows_per_tile, int v0, int v1, int init, int* fin,
-                                          int claim_misses, const kfx_volume* vol, const kfx_slab* slab, int own_lo, int own_hi, int w, int h,
-                                          const float T_wc[12], const float K[4], float near, float far, float trunc_dist, int subpix, kfx_stream stream)
+                                          int claim_misses, const float* adopt_lo, const float* adopt_hi, int adopt_tile_major, const kfx_volume* vol,
+                                          const kfx_slab* slab, int own_lo, int own_hi, int w, int h, const float T_wc[12], const float K[4], float near,
+                                          float far, float trunc_dist, int subpix, kfx_stream stream)
 {
     SlabRay g{};
     g.state = state; g.result = result; g.P = plane_stride; g.R = rows_per_tile; g.v0 = v0; g.v1 = v1; g.fin = fin; g.claim_misses = claim_misses ? 1 : 0;
     g.init = init ? 1 : 0;
+    g.adopt_lo = adopt_lo; g.adopt_hi = adopt_hi; g.adopt_tile_major = adopt_tile_major ? 1 : 0;
+    if (((uintptr_t)adopt_lo | (uintptr_t)adopt_hi) & 3) return set_error(KFX_E_ALIGN, "RaycastSdf(slab): alignment of the received snapshots");
+    if (!adopt_tile_major && (adopt_lo || adopt_hi) && rows_per_tile > 0 && (v0 / rows_per_tile != (v1 - 1) / rows_per_tile))
+        return set_error(KFX_E_SHAPE, "RaycastSdf(slab): one-tile snapshots with rows of several tiles");
     return raycast_slab_launch<RayF32>(g, vol, slab, own_lo, own_hi, w, h, T_wc, K, near, far, trunc_dist, subpix, stream);
 }
 

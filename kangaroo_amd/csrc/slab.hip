@@ -112,34 +112,7 @@ __global__ __launch_bounds__(256) void k_handover_finish(int* __restrict__ state
 // pending) is later than 0 (marching), and of two marching snapshots the one with the larger lambda is later (every step adds a
 // positive delta).  A rank never advances a stale copy -- it advances a ray only while the base plane of its current sample is
 // one it owns, and a kernel run leaves no marching ray of the tile inside the rank's own planes -- so adopting the neighbour's
-// newer, still-open snapshot is all the merging there is.
-__device__ __forceinline__ int snapshot_order(float status) { return status == 0.0f ? 0 : (status == 3.0f ? 1 : 2); }
-
-// mine, a, b: [tiles][5][P] (a / b may be null); pixel i < count of tile blockIdx.y
-__global__ __launch_bounds__(256) void k_adopt_newer(int* __restrict__ mine, const int* __restrict__ a, const int* __restrict__ b, size_t P, size_t count)
-{
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= count) return;
-    const size_t base = (size_t)blockIdx.y * 5 * P + i;
-    float m_lambda = __int_as_float(mine[base]), m_status = __int_as_float(mine[base + 3 * P]);
-    bool took = false;
-    int t0 = 0, t1 = 0, t2 = 0, t3 = 0;
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const int* src = k ? b : a;
-        if (!src) continue;
-        const float n_status = __int_as_float(src[base + 3 * P]);
-        if (!(n_status == 0.0f || n_status == 3.0f)) continue;   // final snapshots stay with the rank that finalised them
-        const float n_lambda = __int_as_float(src[base]);
-        const int on = snapshot_order(n_status), om = snapshot_order(m_status);
-        if (on > om || (on == 0 && om == 0 && n_lambda > m_lambda)) {
-            t0 = src[base]; t1 = src[base + P]; t2 = src[base + 2 * P]; t3 = src[base + 3 * P];
-            m_lambda = n_lambda; m_status = n_status;
-            took = true;
-        }
-    }
-    if (took) { mine[base] = t0; mine[base + P] = t1; mine[base + 2 * P] = t2; mine[base + 3 * P] = t3; }
-}
+// newer, still-open snapshot is all the merging there is; k_raycast_sdf_slab does it at the start of a visit (raycast.hip).
 
 // this rank's contribution to the final images, dense [6][n]: lambda, status, normal, shade of the pixels it finalised
 __global__ __launch_bounds__(256) void k_tiles_contrib(const int* __restrict__ M, const int* __restrict__ Rz, const int* __restrict__ fin,
@@ -724,6 +697,7 @@ extern "C" int kfx_slab_raycast_exact_tiled(const kfx_image* depth, const kfx_im
     if (world > 1 && !comm->exchange_v) return set_error(KFX_E_RANGE, "kfx_slab_raycast_exact_tiled: the transport has no exchange_v");
     const int w = (int)img->w, h = (int)img->h;
     if (w == 0 || h == 0) return 0;
+    if (tiles > 64) tiles = 64;
     TiledScratch t;
     tiled_layout(t, scratch, (size_t)w, (size_t)h, tiles);
     const int T = t.T, R = t.R;
@@ -733,51 +707,51 @@ extern "C" int kfx_slab_raycast_exact_tiled(const kfx_image* depth, const kfx_im
     // a local failure must not keep this rank out of a collective its peers enter: remember it, go on, report it at the end
     int status = 0;
     auto note = [&](int e) { if (e && !status) status = e; };
-    auto march = [&](int v0, int v1, int init) {
-        note(kfx_raycast_sdf_slab_tiles(reinterpret_cast<float*>(t.M), reinterpret_cast<float*>(t.Rz), P, R, v0, v1, init, t.fin, rank == 0 ? 1 : 0, local, &slab,
+    // one launch per visit of a tile: it initialises the tile's rays when this is the rank's first visit, takes over what the
+    // neighbours handed on (their newer, still open snapshots), and marches what lies in the rank's own planes
+    auto march = [&](int v0, int v1, int init, const int* from_lo, const int* from_hi, int tile_major) {
+        note(kfx_raycast_sdf_slab_tiles(reinterpret_cast<float*>(t.M), reinterpret_cast<float*>(t.Rz), P, R, v0, v1, init, t.fin, rank == 0 ? 1 : 0,
+                                        reinterpret_cast<const float*>(from_lo), reinterpret_cast<const float*>(from_hi), tile_major, local, &slab,
                                         (int)L->z0, (int)L->z1, w, h, T_wc, K, near, far, trunc_dist, subpix, stream));
     };
     auto rows_of = [&](int tile, int& v0, int& v1) { v0 = tile * R; v1 = v0 + R < h ? v0 + R : h; };
     note(hip_status(hipMemsetAsync(t.open, 0, sizeof(int), s), "kfx_slab_raycast_exact_tiled"));
-    // every rank starts every ray itself (and marches those that begin in its own planes)
-    march(0, h, 1);
     int steps = 0;
-    if (world > 1) {
-        const size_t cnt = (size_t)R * (size_t)w;
+    if (world == 1) {
+        march(0, h, 1, nullptr, nullptr, 0);
+        steps = 1;
+    } else {
+        // Every rank starts every ray itself, tile by tile at its first visit (the entry slab's owner is the one that can advance
+        // it).  Rank r visits tile t when the upward token reaches it (step r + t) and when the downward one does (W - 1 - r + t).
+        unsigned long long seen = 0ull;   // tiles this rank has initialised (tiles <= 64)
+        bool got_lo = false, got_hi = false;   // what the previous step's exchange brought: tile A (from below) / tile B (from above) of THIS step
         for (int d = 0; d < world + T - 1; ++d, ++steps) {
             const int A = d - rank, B = d - (world - 1 - rank);   // the tiles the upward / downward token brings to this rank now
             const bool a_ok = A >= 0 && A < T, b_ok = B >= 0 && B < T;
             int v0, v1;
-            if (a_ok) { rows_of(A, v0, v1); march(v0, v1, 0); }
-            if (b_ok && !(a_ok && B == A)) { rows_of(B, v0, v1); march(v0, v1, 0); }
+            if (a_ok) {
+                rows_of(A, v0, v1);
+                march(v0, v1, (seen >> A) & 1ull ? 0 : 1, got_lo ? t.from_lo : nullptr, (b_ok && B == A && got_hi) ? t.from_hi : nullptr, 0);
+                seen |= 1ull << A;
+            }
+            if (b_ok && !(a_ok && B == A)) {
+                rows_of(B, v0, v1);
+                march(v0, v1, (seen >> B) & 1ull ? 0 : 1, nullptr, got_hi ? t.from_hi : nullptr, 0);
+                seen |= 1ull << B;
+            }
             // pass the tokens on: tile A upwards, tile B downwards; what arrives is the tile this rank marches in the next step
             const bool up = a_ok && rank + 1 < world, down = b_ok && rank > 0;
             const bool from_below = rank > 0 && A + 1 >= 0 && A + 1 < T, from_above = rank + 1 < world && B + 1 >= 0 && B + 1 < T;
             note(comm->exchange_v(comm, down ? t.M + (size_t)B * 5 * P : nullptr, down ? tile_bytes : 0, from_below ? t.from_lo : nullptr, from_below ? tile_bytes : 0,
                                   up ? t.M + (size_t)A * 5 * P : nullptr, up ? tile_bytes : 0, from_above ? t.from_hi : nullptr, from_above ? tile_bytes : 0, stream));
-            if (from_below && from_above && A == B) {
-                hipLaunchKernelGGL(k_adopt_newer, dim3((unsigned)((cnt + 255) / 256), 1), dim3(256), 0, s, t.M + (size_t)(A + 1) * 5 * P, t.from_lo, t.from_hi, P, cnt);
-                note(check_launch("kfx_slab_raycast_exact_tiled"));
-            } else {
-                if (from_below) {
-                    hipLaunchKernelGGL(k_adopt_newer, dim3((unsigned)((cnt + 255) / 256), 1), dim3(256), 0, s, t.M + (size_t)(A + 1) * 5 * P, t.from_lo, (const int*)nullptr, P, cnt);
-                    note(check_launch("kfx_slab_raycast_exact_tiled"));
-                }
-                if (from_above) {
-                    hipLaunchKernelGGL(k_adopt_newer, dim3((unsigned)((cnt + 255) / 256), 1), dim3(256), 0, s, t.M + (size_t)(B + 1) * 5 * P, t.from_hi, (const int*)nullptr, P, cnt);
-                    note(check_launch("kfx_slab_raycast_exact_tiled"));
-                }
-            }
+            got_lo = from_below; got_hi = from_above;
         }
         // one more stage over the whole image: a hit whose sub-step interpolation fell back across a slab boundary has its normal
         // evaluated by the neighbour that owns the gradient's base plane
         const size_t all = (size_t)T * tile_bytes;
         note(comm->exchange_v(comm, rank > 0 ? t.M : nullptr, rank > 0 ? all : 0, rank > 0 ? t.from_lo : nullptr, rank > 0 ? all : 0,
                               rank + 1 < world ? t.M : nullptr, rank + 1 < world ? all : 0, rank + 1 < world ? t.from_hi : nullptr, rank + 1 < world ? all : 0, stream));
-        hipLaunchKernelGGL(k_adopt_newer, dim3((unsigned)((cnt + 255) / 256), (unsigned)T), dim3(256), 0, s, t.M, rank > 0 ? t.from_lo : (const int*)nullptr,
-                           rank + 1 < world ? t.from_hi : (const int*)nullptr, P, cnt);
-        note(check_launch("kfx_slab_raycast_exact_tiled"));
-        march(0, h, 0);
+        march(0, h, 0, rank > 0 ? t.from_lo : nullptr, rank + 1 < world ? t.from_hi : nullptr, 1);
         ++steps;
     }
     const dim3 grid2(ceil_div(w, 64), ceil_div(h, 4));
@@ -787,7 +761,7 @@ extern "C" int kfx_slab_raycast_exact_tiled(const kfx_image* depth, const kfx_im
     const OutImages out{(unsigned char*)depth->ptr, (unsigned char*)norm->ptr, (unsigned char*)img->ptr, depth->pitch, norm->pitch, img->pitch, w, h};
     hipLaunchKernelGGL(k_tiles_finish, grid2, dim3(256), 0, s, out, t.contrib, t.open);
     note(check_launch("kfx_slab_raycast_exact_tiled"));
-    if (steps_out) *steps_out = steps + 1;   // (+ the initialising march)
+    if (steps_out) *steps_out = steps;   // world + tiles - 1 token steps + the normals' stage (1 for a single rank)
     if (h_open) {
         note(hip_status(hipMemcpyAsync(h_open, t.open, sizeof(int), hipMemcpyDeviceToHost, s), "kfx_slab_raycast_exact_tiled"));
         return status;

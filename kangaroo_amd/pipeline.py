@@ -377,7 +377,7 @@ class SlabPipeline(FramePipeline):
     GHOST = 2  # >= 1 for the trilinear z+1 corner and the gradient's z-1 / z+1 cells (Volume.h:240-289)
     USE_FRAME = False   # slabs: the operators take slab arguments and collectives sit between them
 
-    def __init__(self, ops, dist, dims, boxmin, boxmax, w, h, halo="exchange", raycast="composite", kind="f32", overlap=False,
+    def __init__(self, ops, dist, dims, boxmin, boxmax, w, h, halo="exchange", raycast="exact", kind="f32", overlap=False,
                  inputs="replicate", images="all", merge="direct", driver="python", comm=None, tiles=0, unchecked=False, **kw):
         """driver = "c": every frame is ONE library call per rank (kfx_slab_frame_step, include/kfx_slab.h: the launches AND the
         collectives are enqueued by the library through `comm`, a kangaroo_amd.slab.Comm -- RCCL for one process per GPU; default:

@@ -65,7 +65,7 @@ if cframe:
             assert same(a_, b_), "rank %d %r: the C frame's images differ" % (rank, v)
         if raycast == "exact":
             T_ = c_.sframe.last_steps
-            assert T_ == world + v["tiles"] - 1 + 2 if "tiles" in v else T_ > 0, (v, T_)
+            assert T_ == world + v["tiles"] - 1 + 1 if "tiles" in v else T_ > 0, (v, T_)
         t = c_.sframe.timings(c_.sframe.count - 2, 2)
         assert t.shape == (2, 6) and np.isfinite(t[:, :3]).all() and (t[:, :3] >= 0).all() and np.isfinite(t[0, 5]), t
         assert np.isfinite(t[:, 3]).all() == (raycast == "composite")

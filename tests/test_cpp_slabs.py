@@ -58,7 +58,7 @@ def test_cpp_slabs_tiled_handover_equals_single_volume():
             for k in ("depth", "norm", "img", "volume", "hits"):
                 assert got[k] == ref[k], (ranks, halo, tiles, k, got["text"], ref["text"])
             rounds = int(re.search(r"\((\d+) rounds\)", got["text"]).group(1))
-            assert rounds == ranks + tiles - 1 + 2, (ranks, tiles, rounds)   # the initialising march, world + tiles - 1 token steps, the normals' stage
+            assert rounds == ranks + tiles - 1 + 1, (ranks, tiles, rounds)   # world + tiles - 1 token steps, the normals' stage
 
 
 def test_cpp_slabs_frame_driver_equals_the_operator_calls():

@@ -472,7 +472,7 @@ def test_gpu_slab_pipeline_single_rank_rccl(roo):
     try:
         N, w, h = 64, 160, 120
         bmin, bmax, near, far = scenes.SCENES["room"]
-        slab = SlabPipeline(roo, dist, (N, N, N), bmin, bmax, w, h, halo="exchange", near=near, far=far)
+        slab = SlabPipeline(roo, dist, (N, N, N), bmin, bmax, w, h, halo="exchange", raycast="composite", near=near, far=far)
         mono = FramePipeline(roo, (N, N, N), bmin, bmax, w, h, near=near, far=far)
         for i in range(2):
             T_wc = scenes.orbit_pose(i, 8)
