@@ -87,7 +87,7 @@ public:
     {
         Reserve(depth.w * depth.h);
         if (raycast == Exact && tiles > 0) {
-            const size_t need = kfx_slab_exact_tiled_scratch_bytes(depth.w, depth.h, tiles);
+            const size_t need = kfx_slab_exact_tiled_scratch_bytes(depth.w, depth.h, tiles, comm->world);
             if (need > tiled_cap_) {
                 size_t pitch;
                 kfx_free(tiled_);

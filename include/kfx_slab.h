@@ -140,11 +140,13 @@ int kfx_slab_raycast_exact_allreduce(const kfx_image* depth, const kfx_image* no
  * stage with a whole-image neighbour exchange lets a hit whose sub-step interpolation fell back across a slab boundary get its
  * normal from the rank that owns the gradient's base plane; then one all-reduce of the finalising ranks' results.  Same samples,
  * same images as kfx_raycast_sdf on the whole volume, bit for bit, for any number of tiles.
- * scratch: kfx_slab_exact_tiled_scratch_bytes(w, h, tiles) bytes of device memory.  h_open: NULL -- the call synchronises the
+ * The finalised results reach every rank by direct sends, as the composite's strips do (all-to-all of the ranks' contributions to
+ * a strip to its owner, integer sum, all-gather; KFX_SLAB_FINALISE=allreduce or a transport without those keeps one all-reduce).
+ * scratch: kfx_slab_exact_tiled_scratch_bytes(w, h, tiles, world) bytes of device memory.  h_open: NULL -- the call synchronises the
  * stream at its end and fails with KFX_E_RANGE if a ray is left without a final status; else a host-visible (pinned) word that
  * receives that count asynchronously: the call returns without synchronising and the CALLER checks the word once the stream
  * has passed (kfx_slab_frame does).  Needs comm->exchange_v. */
-size_t kfx_slab_exact_tiled_scratch_bytes(size_t w, size_t h, int tiles);
+size_t kfx_slab_exact_tiled_scratch_bytes(size_t w, size_t h, int tiles, int world);
 int kfx_slab_raycast_exact_tiled(const kfx_image* depth, const kfx_image* norm, const kfx_image* img, void* scratch,
                                  const kfx_volume* local, const kfx_slab_layout* L, const float T_wc[12], const float K[4],
                                  float near, float far, float trunc_dist, int subpix, int tiles, kfx_comm* comm, kfx_stream stream,

@@ -114,9 +114,20 @@ __global__ __launch_bounds__(256) void k_handover_finish(int* __restrict__ state
 // one it owns, and a kernel run leaves no marching ray of the tile inside the rank's own planes -- so adopting the neighbour's
 // newer, still-open snapshot is all the merging there is; k_raycast_sdf_slab does it at the start of a visit (raycast.hip).
 
-// this rank's contribution to the final images, dense [6][n]: lambda, status, normal, shade of the pixels it finalised
+// Where word c of pixel i of the six result planes {lambda, status, n.x, n.y, n.z, shade} lives: dense [6][n] (S = 0), or by image
+// strips (S = pixels per strip, kfx_composite_strip_pixels): strip j = pixels [j S, (j + 1) S) of the row-major image holds its six
+// planes side by side at (j * 6 + c) * S -- the layout in which strip j travels to its owner rank j and back.
+__device__ __forceinline__ size_t result_index(int c, size_t i, size_t n, unsigned S)
+{
+    if (S == 0) return (size_t)c * n + i;
+    const size_t j = i / S;
+    return (j * 6 + (size_t)c) * S + (i - j * S);
+}
+
+// this rank's contribution to the final images: lambda, status, normal, shade of the pixels it finalised, zero elsewhere (integer
+// bit patterns: NaN and -0 survive the sum over ranks, of which exactly one is non-zero per pixel)
 __global__ __launch_bounds__(256) void k_tiles_contrib(const int* __restrict__ M, const int* __restrict__ Rz, const int* __restrict__ fin,
-                                                       int* __restrict__ contrib, int w, int h, int R, size_t P)
+                                                       int* __restrict__ contrib, int w, int h, int R, size_t P, unsigned S)
 {
     const int u = blockIdx.x * 64 + (threadIdx.x & 63), v = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (u >= w || v >= h) return;
@@ -126,28 +137,39 @@ __global__ __launch_bounds__(256) void k_tiles_contrib(const int* __restrict__ M
     const int* st = M + (size_t)t * 5 * P + q;
     const int* rs = Rz + (size_t)t * 4 * P + q;
     const bool mine = fin[i] != 0;
-    contrib[i] = mine ? st[0] : 0;
-    contrib[n + i] = mine ? st[3 * P] : 0;
+    contrib[result_index(0, i, n, S)] = mine ? st[0] : 0;
+    contrib[result_index(1, i, n, S)] = mine ? st[3 * P] : 0;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) contrib[(2 + k) * n + i] = mine ? rs[k * P] : 0;
+    for (int k = 0; k < 4; ++k) contrib[result_index(2 + k, i, n, S)] = mine ? rs[k * P] : 0;
+}
+
+// the owner of a strip adds up the ranks' copies of it: in + r * 6 * S = rank r's [6][S]; out [6][S]
+__global__ __launch_bounds__(256) void k_strip_sum(const int* __restrict__ in, int* __restrict__ out, size_t words, int world)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= words) return;
+    int acc = 0;
+    for (int r = 0; r < world; ++r) acc += in[(size_t)r * words + i];
+    out[i] = acc;
 }
 
 struct OutImages { unsigned char *dptr, *nptr, *iptr; size_t dpitch, npitch, ipitch; int w, h; };
 
 // the summed contributions -> depth / normal / shade images (cu_raycast.cu:92-102); *open += pixels without a final status
-__global__ __launch_bounds__(256) void k_tiles_finish(const OutImages o, const int* __restrict__ contrib, int* __restrict__ open)
+__global__ __launch_bounds__(256) void k_tiles_finish(const OutImages o, const int* __restrict__ contrib, int* __restrict__ open, unsigned S)
 {
     const int u = blockIdx.x * 64 + (threadIdx.x & 63), v = blockIdx.y * 4 + (threadIdx.x >> 6);
     bool bad = false;
     if (u < o.w && v < o.h) {
         const size_t n = (size_t)o.w * o.h, i = (size_t)v * o.w + u;
-        const float depth = __int_as_float(contrib[i]), status = __int_as_float(contrib[n + i]);
+        const float depth = __int_as_float(contrib[result_index(0, i, n, S)]), status = __int_as_float(contrib[result_index(1, i, n, S)]);
         bad = !(status == 1.0f || status == 2.0f);
         const bool hit = status == 1.0f && depth > 0.0f;
         *(reinterpret_cast<float*>(o.dptr + (size_t)v * o.dpitch) + u) = hit ? depth : __builtin_nanf("");
-        *(reinterpret_cast<float*>(o.iptr + (size_t)v * o.ipitch) + u) = hit ? __int_as_float(contrib[5 * n + i]) : 0.0f;
+        *(reinterpret_cast<float*>(o.iptr + (size_t)v * o.ipitch) + u) = hit ? __int_as_float(contrib[result_index(5, i, n, S)]) : 0.0f;
         *(reinterpret_cast<float4*>(o.nptr + (size_t)v * o.npitch) + u) =
-            hit ? make_float4(__int_as_float(contrib[2 * n + i]), __int_as_float(contrib[3 * n + i]), __int_as_float(contrib[4 * n + i]), 1.0f)
+            hit ? make_float4(__int_as_float(contrib[result_index(2, i, n, S)]), __int_as_float(contrib[result_index(3, i, n, S)]),
+                              __int_as_float(contrib[result_index(4, i, n, S)]), 1.0f)
                 : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     const unsigned long long m = __ballot(bad);
@@ -649,9 +671,11 @@ struct TiledScratch {
     size_t P, n;       // plane stride of a tile (pixels), pixels of the image
     int R, T;          // rows per tile, tiles
     int *M, *Rz, *from_lo, *from_hi, *fin, *contrib, *open;
+    size_t S;          // pixels per image strip of the final exchange (0 for one rank)
+    int *gathered, *mine;   // [world][6][S] received strips / the merged image; [6][S] this rank's merged strip
 };
 // the scratch buffer's parts; returns its size in ints (scratch may be null: sizes only)
-size_t tiled_layout(TiledScratch& t, void* scratch, size_t w, size_t h, int tiles)
+size_t tiled_layout(TiledScratch& t, void* scratch, size_t w, size_t h, int tiles, int world)
 {
     t.T = tiles < 1 ? 1 : (tiles > (int)h ? (int)(h ? h : 1) : tiles);
     t.R = (int)((h + (size_t)t.T - 1) / (size_t)t.T);
@@ -666,17 +690,22 @@ size_t tiled_layout(TiledScratch& t, void* scratch, size_t w, size_t h, int tile
     t.from_lo = take((size_t)t.T * 5 * t.P);
     t.from_hi = take((size_t)t.T * 5 * t.P);
     t.fin = take((t.n + 63) / 64 * 64);
-    t.contrib = take((6 * t.n + 63) / 64 * 64);
+    // the final exchange: dense [6][n] for the all-reduce (and for one rank); by strips [world][6][S] for the direct sends
+    t.S = world > 1 ? kfx_composite_strip_pixels(w, h, world) : 0;
+    const size_t by_strips = (size_t)(world > 1 ? world : 0) * 6 * t.S;
+    t.contrib = take(((by_strips > 6 * t.n ? by_strips : 6 * t.n) + 63) / 64 * 64);
+    t.gathered = take((by_strips + 63) / 64 * 64);
+    t.mine = take((6 * t.S + 63) / 64 * 64);
     t.open = take(64);
     return o;
 }
 } // namespace
 
-extern "C" size_t kfx_slab_exact_tiled_scratch_bytes(size_t w, size_t h, int tiles)
+extern "C" size_t kfx_slab_exact_tiled_scratch_bytes(size_t w, size_t h, int tiles, int world)
 {
     if (w == 0 || h == 0) return 256;
     TiledScratch t;
-    return tiled_layout(t, nullptr, w, h, tiles) * sizeof(int);
+    return tiled_layout(t, nullptr, w, h, tiles, world < 1 ? 1 : world) * sizeof(int);
 }
 
 extern "C" int kfx_slab_raycast_exact_tiled(const kfx_image* depth, const kfx_image* norm, const kfx_image* img, void* scratch,
@@ -699,7 +728,7 @@ extern "C" int kfx_slab_raycast_exact_tiled(const kfx_image* depth, const kfx_im
     if (w == 0 || h == 0) return 0;
     if (tiles > 64) tiles = 64;
     TiledScratch t;
-    tiled_layout(t, scratch, (size_t)w, (size_t)h, tiles);
+    tiled_layout(t, scratch, (size_t)w, (size_t)h, tiles, world);
     const int T = t.T, R = t.R;
     const size_t P = t.P, tile_bytes = 5 * P * sizeof(int);
     hipStream_t s = (hipStream_t)stream;
@@ -754,12 +783,33 @@ extern "C" int kfx_slab_raycast_exact_tiled(const kfx_image* depth, const kfx_im
         march(0, h, 0, rank > 0 ? t.from_lo : nullptr, rank + 1 < world ? t.from_hi : nullptr, 1);
         ++steps;
     }
+    // Every pixel has been given its final status by exactly one rank.  The results reach every rank by direct sends over the
+    // mesh, as the composite's strips do (composite.hip): rank j owns strip j of the image; one all-to-all brings the ranks'
+    // contributions to a strip -- zeros but for the one that finalised the pixel -- to its owner, the owner adds them up (integers:
+    // NaN and -0 survive), one all-gather returns the strips: 24 bytes per pixel cross each link once per phase, every link at once,
+    // where an all-reduce of the 7.4 MB (640 x 480) takes 14 dependent ring steps.  KFX_SLAB_FINALISE=allreduce (or a transport
+    // without all_to_all / all_gather) keeps the all-reduce; same images.
+    static const bool by_allreduce = [] { const char* e = getenv("KFX_SLAB_FINALISE"); return e && e[0] == 'a'; }();
+    const bool direct = world > 1 && !by_allreduce && comm->all_to_all && comm->all_gather;
+    const unsigned S = direct ? (unsigned)t.S : 0u;
     const dim3 grid2(ceil_div(w, 64), ceil_div(h, 4));
-    hipLaunchKernelGGL(k_tiles_contrib, grid2, dim3(256), 0, s, t.M, t.Rz, t.fin, t.contrib, w, h, R, P);
+    if (direct && (size_t)world * t.S > t.n)   // the last strip's padding travels too: defined (and summed as zero)
+        note(hip_status(hipMemsetAsync(t.contrib + ((size_t)(world - 1) * 6) * t.S, 0, 6 * t.S * sizeof(int), s), "kfx_slab_raycast_exact_tiled"));
+    hipLaunchKernelGGL(k_tiles_contrib, grid2, dim3(256), 0, s, t.M, t.Rz, t.fin, t.contrib, w, h, R, P, S);
     note(check_launch("kfx_slab_raycast_exact_tiled"));
-    if (world > 1) note(comm->all_reduce(comm, t.contrib, 6 * t.n, KFX_COMM_SUM_I32, stream));
+    const int* final_planes = t.contrib;
+    if (direct) {
+        const size_t words = 6 * t.S;
+        note(comm->all_to_all(comm, t.contrib, t.gathered, words * sizeof(int), stream));
+        hipLaunchKernelGGL(k_strip_sum, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, s, t.gathered, t.mine, words, world);
+        note(check_launch("kfx_slab_raycast_exact_tiled"));
+        note(comm->all_gather(comm, t.mine, t.gathered, words * sizeof(int), stream));
+        final_planes = t.gathered;
+    } else if (world > 1) {
+        note(comm->all_reduce(comm, t.contrib, 6 * t.n, KFX_COMM_SUM_I32, stream));
+    }
     const OutImages out{(unsigned char*)depth->ptr, (unsigned char*)norm->ptr, (unsigned char*)img->ptr, depth->pitch, norm->pitch, img->pitch, w, h};
-    hipLaunchKernelGGL(k_tiles_finish, grid2, dim3(256), 0, s, out, t.contrib, t.open);
+    hipLaunchKernelGGL(k_tiles_finish, grid2, dim3(256), 0, s, out, final_planes, t.open, S);
     note(check_launch("kfx_slab_raycast_exact_tiled"));
     if (steps_out) *steps_out = steps;   // world + tiles - 1 token steps + the normals' stage (1 for a single rank)
     if (h_open) {

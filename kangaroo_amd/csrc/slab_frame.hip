@@ -86,7 +86,7 @@ static int ensure_scratch(kfx_slab_frame* f)
     const size_t w = c.ray_img.w, h = c.ray_img.h;
     const int world = f->comm->world;
     if (c.raycast == KFX_SLAB_RAYCAST_EXACT) {
-        if (int e = grow(&f->exact, &f->exact_bytes, kfx_slab_exact_tiled_scratch_bytes(w, h, c.tiles ? c.tiles : 4))) return e;
+        if (int e = grow(&f->exact, &f->exact_bytes, kfx_slab_exact_tiled_scratch_bytes(w, h, c.tiles ? c.tiles : 4, world))) return e;
     } else if (world > 1) {
         if (c.merge == KFX_SLAB_MERGE_DIRECT) {
             if (int e = grow(&f->strips, &f->strips_bytes, kfx_slab_composite_direct_scratch_bytes(w, h, world))) return e;

@@ -81,7 +81,7 @@ def _L():
             "kfx_slab_exact_scratch_bytes": (C.c_size_t, [C.c_size_t, C.c_size_t]),
             "kfx_slab_raycast_exact": (C.c_int, [PI, PI, PI, V, V, PV, PL, PF, PF, C.c_float, C.c_float, C.c_float, C.c_int, _P, V, C.POINTER(C.c_int)]),
             "kfx_slab_raycast_exact_allreduce": (C.c_int, [PI, PI, PI, V, V, PV, PL, PF, PF, C.c_float, C.c_float, C.c_float, C.c_int, _P, V, C.POINTER(C.c_int)]),
-            "kfx_slab_exact_tiled_scratch_bytes": (C.c_size_t, [C.c_size_t, C.c_size_t, C.c_int]),
+            "kfx_slab_exact_tiled_scratch_bytes": (C.c_size_t, [C.c_size_t, C.c_size_t, C.c_int, C.c_int]),
             "kfx_slab_raycast_exact_tiled": (C.c_int, [PI, PI, PI, V, PV, PL, PF, PF, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, _P, V,
                                                        C.POINTER(C.c_int), C.POINTER(C.c_int)]),
             "kfx_slab_frame_create": (C.c_int, [C.POINTER(V), C.POINTER(KfxSlabFrameConfig), _P]),

@@ -59,6 +59,15 @@ def test_cpp_slabs_tiled_handover_equals_single_volume():
                 assert got[k] == ref[k], (ranks, halo, tiles, k, got["text"], ref["text"])
             rounds = int(re.search(r"\((\d+) rounds\)", got["text"]).group(1))
             assert rounds == ranks + tiles - 1 + 1, (ranks, tiles, rounds)   # world + tiles - 1 token steps, the normals' stage
+    # the finalised results travel by direct sends (strips: all-to-all, sum at the owner, all-gather); the all-reduce they replace
+    # gives the same images (3 and 5 ranks: strips that do not divide the image evenly)
+    for ranks in (3, 5):
+        got = run(*COMMON, "--ranks", ranks, "--raycast", "exact", "--tiles", 4, env=dict(os.environ, KFX_SLAB_FINALISE="allreduce"))
+        for k in ("depth", "norm", "img", "volume", "hits"):
+            assert got[k] == ref[k], (ranks, k, got["text"], ref["text"])
+        other = run(*COMMON, "--ranks", ranks, "--raycast", "exact", "--tiles", 4)
+        for k in ("depth", "norm", "img", "volume", "hits"):
+            assert other[k] == ref[k], (ranks, k, other["text"], ref["text"])
 
 
 def test_cpp_slabs_frame_driver_equals_the_operator_calls():

@@ -202,7 +202,7 @@ def _march_in_eight_slabs(roo, vol, T_wc, K, near, far, tr, mode, tiles=4, world
         local = roo.BoundedVolume(vol.w, vol.h, lay.s1 - lay.s0, lo, hi, pitch=vol.pitch)
         local.planes(0, local.d).copy_(vol.planes(lay.s0, lay.s1))
         imgs = (roo.Image(w, h), roo.Image(w, h, "f32x4"), roo.Image(w, h))
-        nbytes = L.kfx_slab_exact_tiled_scratch_bytes(w, h, tiles) if mode == "exact" else L.kfx_slab_composite_direct_scratch_bytes(w, h, world)
+        nbytes = L.kfx_slab_exact_tiled_scratch_bytes(w, h, tiles, world) if mode == "exact" else L.kfx_slab_composite_direct_scratch_bytes(w, h, world)
         scratch = torch_empty(nbytes)
         ranks.append((lay, local, imgs, scratch))
     import torch
