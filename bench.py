@@ -787,16 +787,31 @@ def run_slabs(args, torch, dist, roo, scenes, rank, world):
     if c_driver and (args.images != "all" or args.raycast == "exact_allreduce"):
         sys.exit("bench.py: --images root and --raycast exact_allreduce are options of --driver python")
     comm, comm_text = None, "torch.distributed (%s)" % dist.get_backend()
+    driver, driver_note = args.driver, None
     if c_driver:
         from kangaroo_amd import slab as kslab
-        if dist.get_backend() == "nccl":
-            # the library's own RCCL communicator (libkfx_rccl.so): the ncclUniqueId travels through a file named after the launch
-            rdv = os.path.join(os.environ.get("TMPDIR", "/tmp"), "kfx_bench.%d.%s.id" % (os.getuid(), os.environ.get("MASTER_PORT", "0")))
-            comm = kslab.Comm.rccl(rank, world, rdv, 180)
-            comm_text = "libkfx_rccl.so: RCCL communicator of the library (grouped ncclSend / ncclRecv, ncclAllReduce, ncclAllGather), collectives enqueued on the launch stream by kfx_slab_frame_step"
-        else:
+        err = None
+        try:
+            if dist.get_backend() == "nccl":
+                # the library's own RCCL communicator (libkfx_rccl.so): the ncclUniqueId travels through a file named after the launch
+                rdv = os.path.join(os.environ.get("TMPDIR", "/tmp"), "kfx_bench.%d.%s.id" % (os.getuid(), os.environ.get("MASTER_PORT", "0")))
+                comm = kslab.Comm.rccl(rank, world, rdv, 180)
+                comm_text = "libkfx_rccl.so: RCCL communicator of the library (grouped ncclSend / ncclRecv, ncclAllReduce, ncclAllGather), collectives enqueued on the launch stream by kfx_slab_frame_step"
+            else:
+                comm = kslab.Comm.torch(dist)
+                comm_text = "kfx_slab_frame_step with its collectives routed through torch.distributed (%s) callbacks -- the smoke-test transport for ranks sharing a GPU" % dist.get_backend()
+        except Exception as e:   # noqa: BLE001
+            err = repr(e)[:200]
+        # every rank must drive the same way: if the library's communicator did not come up on ANY rank, all of them route the
+        # frame call's collectives through the process group instead (still one C call per frame) and the line says so
+        ok = torch.tensor([0 if err else 1], dtype=torch.int32, device="cuda")
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:
+            if comm is not None and dist.get_backend() == "nccl":
+                comm.destroy()
             comm = kslab.Comm.torch(dist)
-            comm_text = "kfx_slab_frame_step with its collectives routed through torch.distributed (%s) callbacks -- the smoke-test transport for ranks sharing a GPU" % dist.get_backend()
+            driver_note = "libkfx_rccl.so's communicator did not come up on every rank (%s): collectives routed through torch.distributed (%s)" % (err or "another rank failed", dist.get_backend())
+            comm_text = "kfx_slab_frame_step with its collectives routed through torch.distributed (%s) callbacks (fallback: %s)" % (dist.get_backend(), driver_note)
     steps_cap = max(256, args.steps + 4 * BLOCK + 64)
     pipe = SlabPipeline(roo, dist, (N, N, N), bmin, bmax, w, h, halo=args.halo, raycast=args.raycast, K=K, near=near, far=far,
                         overlap=overlap, inputs=args.inputs, images=args.images, merge=args.merge, driver=args.driver, comm=comm, tiles=args.tiles,
@@ -1114,6 +1129,7 @@ def run_slabs(args, torch, dist, roo, scenes, rank, world):
                 "backend": os.environ.get("KFX_BENCH_BACKEND", "nccl (RCCL)"), "ranks_agree": ranks_agree,
                 "driver": ("c: one kfx_slab_frame_step call per frame and rank (launches and collectives enqueued by libkfx)" if sf is not None else
                            "python: SlabPipeline issues operators and torch.distributed collectives one by one"),
+                "driver_note": driver_note,
                 "raycast": "plain march (kfx_raycast_sdf%s) per slab" % ("_slab, state carried across slabs" if args.raycast != "composite" else ""),
                 "raycast_mode": args.raycast, "raycast_parity": parity, "summary_policy": None,
                 "partition": partition, "communicator": comm_info,
@@ -1140,7 +1156,7 @@ def run_slabs(args, torch, dist, roo, scenes, rank, world):
             "per_rank": per_rank,
             "multi_gpu_variants": variants,
         }
-    if comm is not None and c_driver and dist.get_backend() == "nccl":
+    if comm is not None and c_driver and dist.get_backend() == "nccl" and driver_note is None:
         pipe.sframe = None
         del sf
         comm.destroy()

@@ -4,6 +4,7 @@
 // No reference counterpart (the reference is single-GPU); the host-side protocol is the one of
 // kangaroo_amd/pipeline.py::SlabPipeline, so that C / C++ applications can use slabs without Python.
 #include <atomic>
+#include <cmath>
 #include <condition_variable>
 #include <mutex>
 #include <new>
@@ -752,11 +753,31 @@ extern "C" int kfx_slab_raycast_exact_tiled(const kfx_image* depth, const kfx_im
     } else {
         // Every rank starts every ray itself, tile by tile at its first visit (the entry slab's owner is the one that can advance
         // it).  Rank r visits tile t when the upward token reaches it (step r + t) and when the downward one does (W - 1 - r + t).
+        // Which tokens exist: a ray's z-direction is R_wc's third row against ((u - u0) / fu, (v - v0) / fv, 1) -- affine in the
+        // pixel, so its extremes sit in the image's corners.  When every ray rises (the usual case: the camera looks along the
+        // slabs' axis) nothing ever travels downwards -- no downward visits, no downward messages -- and the normals' stage sends
+        // downwards only (a rising ray's hit falls BACK across a boundary); likewise for all-falling rays.  Every rank derives the
+        // same two flags from the same pose (with a margin: rays that are flat within it count as both).
+        bool need_up = true, need_down = true;
+        {
+            double zlo = 1e300, zhi = -1e300, mag = 0.0;
+            for (int c = 0; c < 4; ++c) {
+                const double cx = ((c & 1 ? (double)(w - 1) : 0.0) - (double)K[2]) / (double)K[0], cy = ((c & 2 ? (double)(h - 1) : 0.0) - (double)K[3]) / (double)K[1];
+                const double z = (double)T_wc[8] * cx + (double)T_wc[9] * cy + (double)T_wc[10];
+                const double m = std::fabs((double)T_wc[8] * cx) + std::fabs((double)T_wc[9] * cy) + std::fabs((double)T_wc[10]);
+                zlo = z < zlo ? z : zlo; zhi = z > zhi ? z : zhi; mag = m > mag ? m : mag;
+            }
+            const double margin = 1e-4 * mag;
+            if (zlo == zlo && zhi == zhi && mag < 1e300) {   // (a pose with NaN keeps both)
+                need_down = !(zlo > margin);
+                need_up = !(zhi < -margin);
+            }
+        }
         unsigned long long seen = 0ull;   // tiles this rank has initialised (tiles <= 64)
         bool got_lo = false, got_hi = false;   // what the previous step's exchange brought: tile A (from below) / tile B (from above) of THIS step
         for (int d = 0; d < world + T - 1; ++d, ++steps) {
             const int A = d - rank, B = d - (world - 1 - rank);   // the tiles the upward / downward token brings to this rank now
-            const bool a_ok = A >= 0 && A < T, b_ok = B >= 0 && B < T;
+            const bool a_ok = need_up && A >= 0 && A < T, b_ok = need_down && B >= 0 && B < T;
             int v0, v1;
             if (a_ok) {
                 rows_of(A, v0, v1);
@@ -770,17 +791,22 @@ extern "C" int kfx_slab_raycast_exact_tiled(const kfx_image* depth, const kfx_im
             }
             // pass the tokens on: tile A upwards, tile B downwards; what arrives is the tile this rank marches in the next step
             const bool up = a_ok && rank + 1 < world, down = b_ok && rank > 0;
-            const bool from_below = rank > 0 && A + 1 >= 0 && A + 1 < T, from_above = rank + 1 < world && B + 1 >= 0 && B + 1 < T;
+            const bool from_below = need_up && rank > 0 && A + 1 >= 0 && A + 1 < T, from_above = need_down && rank + 1 < world && B + 1 >= 0 && B + 1 < T;
+            // (every rank calls the exchange in every step, with empty legs where it has nothing to pass on: a transport may
+            //  synchronise its ranks inside the call, as the in-process one does)
             note(comm->exchange_v(comm, down ? t.M + (size_t)B * 5 * P : nullptr, down ? tile_bytes : 0, from_below ? t.from_lo : nullptr, from_below ? tile_bytes : 0,
                                   up ? t.M + (size_t)A * 5 * P : nullptr, up ? tile_bytes : 0, from_above ? t.from_hi : nullptr, from_above ? tile_bytes : 0, stream));
             got_lo = from_below; got_hi = from_above;
         }
         // one more stage over the whole image: a hit whose sub-step interpolation fell back across a slab boundary has its normal
-        // evaluated by the neighbour that owns the gradient's base plane
+        // evaluated by the neighbour that owns the gradient's base plane -- the one BEHIND the ray: rising rays' hits go down, falling
+        // rays' up
         const size_t all = (size_t)T * tile_bytes;
-        note(comm->exchange_v(comm, rank > 0 ? t.M : nullptr, rank > 0 ? all : 0, rank > 0 ? t.from_lo : nullptr, rank > 0 ? all : 0,
-                              rank + 1 < world ? t.M : nullptr, rank + 1 < world ? all : 0, rank + 1 < world ? t.from_hi : nullptr, rank + 1 < world ? all : 0, stream));
-        march(0, h, 0, rank > 0 ? t.from_lo : nullptr, rank + 1 < world ? t.from_hi : nullptr, 1);
+        const bool send_down = need_up && rank > 0, recv_from_above = need_up && rank + 1 < world;       // rising rays' pending normals
+        const bool send_up = need_down && rank + 1 < world, recv_from_below = need_down && rank > 0;     // falling rays'
+        note(comm->exchange_v(comm, send_down ? t.M : nullptr, send_down ? all : 0, recv_from_below ? t.from_lo : nullptr, recv_from_below ? all : 0,
+                              send_up ? t.M : nullptr, send_up ? all : 0, recv_from_above ? t.from_hi : nullptr, recv_from_above ? all : 0, stream));
+        march(0, h, 0, recv_from_below ? t.from_lo : nullptr, recv_from_above ? t.from_hi : nullptr, 1);
         ++steps;
     }
     // Every pixel has been given its final status by exactly one rank.  The results reach every rank by direct sends over the

@@ -33,7 +33,7 @@ for v in ("stages", "tiles1", "tiles4", "tiles8"):
         for r in csv.DictReader(open(f)):
             name = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("kfx::", "")
             agg[name[:48]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
-    march = {k: v_ for k, v_ in agg.items() if any(s in k for s in ("k_raycast_sdf_slab", "k_handover", "k_adopt_newer", "k_tiles_", "k_group_reduce", "k_raycast_state_to_images"))}
+    march = {k: v_ for k, v_ in agg.items() if any(s in k for s in ("k_raycast_sdf_slab", "k_handover", "k_adopt_newer", "k_tiles_", "k_strip_sum", "k_group_reduce", "k_raycast_state_to_images"))}
     tiles = {"stages": 0, "tiles1": 1, "tiles4": 4, "tiles8": 8}[v]
     n_px = w * h
     if tiles == 0:

@@ -85,3 +85,57 @@ def upload_volume(roo, ovol, pitch=None):
     v = roo.BoundedVolume(ovol.w, ovol.h, ovol.d, ovol.boxmin, ovol.boxmax, pitch=pitch)
     v.MemcpyFromHost(ovol.data)
     return v
+
+
+def march_in_slabs(roo, vol, w, h, T_wc, K, near, far, tr, mode, tiles=4, world=8):
+    """Render `vol` (a whole volume on the GPU) the way `world` ranks would: every rank THREAD holds a copy of its planes + 2 ghost
+    planes and calls the C entry point of the multi-GPU raycast over the in-process transport (kfx_comm_create_threads): mode
+    "exact" = kfx_slab_raycast_exact_tiled, "composite" = kfx_raycast_sdf + kfx_slab_composite_direct.  Returns rank 0's
+    (depth, normals, shade) images after checking that every rank holds the same ones."""
+    import ctypes as C
+    import threading
+    import torch
+    from kangaroo_amd import _lib, slab
+    L = slab._L()
+    comms = slab.Comm.threads(world)
+    ranks = []
+    for r in range(world):
+        lay = slab.layout(vol.d, float(vol.boxmin[2]), float(vol.boxmax[2]), r, world, 2)
+        lo = (vol.boxmin[0], vol.boxmin[1], lay.local_zmin)
+        hi = (vol.boxmax[0], vol.boxmax[1], lay.local_zmax)
+        local = roo.BoundedVolume(vol.w, vol.h, lay.s1 - lay.s0, lo, hi, pitch=vol.pitch)
+        local.planes(0, local.d).copy_(vol.planes(lay.s0, lay.s1))
+        imgs = (roo.Image(w, h), roo.Image(w, h, "f32x4"), roo.Image(w, h))
+        nbytes = L.kfx_slab_exact_tiled_scratch_bytes(w, h, tiles, world) if mode == "exact" else L.kfx_slab_composite_direct_scratch_bytes(w, h, world)
+        scratch = torch.empty(int(nbytes), dtype=torch.uint8, device="cuda")
+        ranks.append((lay, local, imgs, scratch))
+    torch.cuda.synchronize()
+    twc = np.ascontiguousarray(np.asarray(T_wc, np.float32)[:3].reshape(-1))
+    kk = np.ascontiguousarray(np.asarray(K, np.float32))
+    PF = _lib.PF
+    status = [None] * world
+
+    def work(r):
+        lay, local, (d, n, i), scratch = ranks[r]
+        if mode == "exact":
+            steps = C.c_int(0)
+            status[r] = L.kfx_slab_raycast_exact_tiled(d.ref(), n.ref(), i.ref(), C.c_void_p(scratch.data_ptr()), local.ref(), C.byref(lay), twc.ctypes.data_as(PF),
+                                                       kk.ctypes.data_as(PF), near, far, tr, 1, tiles, comms[r].ref(), None, None, C.byref(steps))
+        else:
+            st = _lib.load().kfx_raycast_sdf(d.ref(), n.ref(), i.ref(), local.ref(), twc.ctypes.data_as(PF), kk.ctypes.data_as(PF), near, far, tr, 1, None)
+            st2 = L.kfx_slab_composite_direct(d.ref(), n.ref(), i.ref(), C.c_void_p(scratch.data_ptr()), comms[r].ref(), None)
+            status[r] = st or st2
+        _lib.load().kfx_stream_synchronize(None)
+    threads = [threading.Thread(target=work, args=(r,)) for r in range(1, world)]
+    for t_ in threads:
+        t_.start()
+    work(0)
+    for t_ in threads:
+        t_.join()
+    comms[0].destroy()
+    assert status == [0] * world, status
+    first = [x.MemcpyToHost() for x in ranks[0][2]]
+    for r in range(1, world):
+        for a, b in zip(first, ranks[r][2]):
+            assert nan_equal(a, b.MemcpyToHost()), "rank %d holds other images than rank 0" % r
+    return ranks[0][2]

@@ -161,11 +161,11 @@ def test_gpu_fast_chain_vs_exact_oracle_at_full_size(roo, scene, w, h):
     if (w, h) == (640, 480):
         prev = roo.set_math_mode("fast")
         try:
-            ex = _march_in_eight_slabs(roo, vol, T_wc, K, near, far, tr, "exact", tiles=4)
+            ex = T.march_in_slabs(roo, vol, 640, 480, T_wc, K, near, far, tr, "exact", tiles=4, world=8)
             for a, b in zip(ex, (rd, rn, ri)):
                 assert T.nan_equal(a.MemcpyToHost(), b.MemcpyToHost()), "the hand-over through 8 slabs differs from the single-volume march"
             img_x = _image_report(ex[0].MemcpyToHost(), ex[1].MemcpyToHost(), ex[2].MemcpyToHost(), od.data, on.data, oi.data)
-            co = _march_in_eight_slabs(roo, vol, T_wc, K, near, far, tr, "composite")
+            co = T.march_in_slabs(roo, vol, 640, 480, T_wc, K, near, far, tr, "composite", world=8)
             img_c = _image_report(co[0].MemcpyToHost(), co[1].MemcpyToHost(), co[2].MemcpyToHost(), od.data, on.data, oi.data)
         finally:
             roo.set_math_mode(prev)
@@ -182,61 +182,6 @@ def test_gpu_fast_chain_vs_exact_oracle_at_full_size(roo, scene, w, h):
 
 
 COMPOSITE_HIT_FLIP_FRACTION = 5e-4   # nearest-hit composite of per-slab marches, 8 slabs (measured: 2.8e-4 in S_room, 3e-5 in S_full)
-
-
-def _march_in_eight_slabs(roo, vol, T_wc, K, near, far, tr, mode, tiles=4, world=8):
-    """Render `vol` (a whole 512^3 volume) the way `world` ranks would: every rank thread holds a copy of its planes + 2 ghost
-    planes and calls the C entry point of the multi-GPU raycast over the in-process transport (kfx_comm_create_threads);
-    returns rank 0's (depth, normals, shade) images."""
-    import ctypes as C
-    import threading
-    from kangaroo_amd import _lib, slab
-    L = slab._L()
-    w, h = 640, 480
-    comms = slab.Comm.threads(world)
-    ranks = []
-    for r in range(world):
-        lay = slab.layout(vol.d, float(vol.boxmin[2]), float(vol.boxmax[2]), r, world, 2)
-        lo = (vol.boxmin[0], vol.boxmin[1], lay.local_zmin)
-        hi = (vol.boxmax[0], vol.boxmax[1], lay.local_zmax)
-        local = roo.BoundedVolume(vol.w, vol.h, lay.s1 - lay.s0, lo, hi, pitch=vol.pitch)
-        local.planes(0, local.d).copy_(vol.planes(lay.s0, lay.s1))
-        imgs = (roo.Image(w, h), roo.Image(w, h, "f32x4"), roo.Image(w, h))
-        nbytes = L.kfx_slab_exact_tiled_scratch_bytes(w, h, tiles, world) if mode == "exact" else L.kfx_slab_composite_direct_scratch_bytes(w, h, world)
-        scratch = torch_empty(nbytes)
-        ranks.append((lay, local, imgs, scratch))
-    import torch
-    torch.cuda.synchronize()
-    twc = np.ascontiguousarray(np.asarray(T_wc, np.float32)[:3].reshape(-1))
-    kk = np.ascontiguousarray(np.asarray(K, np.float32))
-    PF = _lib.PF
-    status = [None] * world
-
-    def work(r):
-        lay, local, (d, n, i), scratch = ranks[r]
-        if mode == "exact":
-            steps = C.c_int(0)
-            status[r] = L.kfx_slab_raycast_exact_tiled(d.ref(), n.ref(), i.ref(), C.c_void_p(scratch.data_ptr()), local.ref(), C.byref(lay), twc.ctypes.data_as(PF),
-                                                       kk.ctypes.data_as(PF), near, far, tr, 1, tiles, comms[r].ref(), None, None, C.byref(steps))
-        else:
-            st = _lib.load().kfx_raycast_sdf(d.ref(), n.ref(), i.ref(), local.ref(), twc.ctypes.data_as(PF), kk.ctypes.data_as(PF), near, far, tr, 1, None)
-            st2 = L.kfx_slab_composite_direct(d.ref(), n.ref(), i.ref(), C.c_void_p(scratch.data_ptr()), comms[r].ref(), None)
-            status[r] = st or st2
-        _lib.load().kfx_stream_synchronize(None)
-    threads = [threading.Thread(target=work, args=(r,)) for r in range(1, world)]
-    for t in threads:
-        t.start()
-    work(0)
-    for t in threads:
-        t.join()
-    comms[0].destroy()
-    assert status == [0] * world, status
-    return ranks[0][2]
-
-
-def torch_empty(nbytes):
-    import torch
-    return torch.empty(int(nbytes), dtype=torch.uint8, device="cuda")
 
 
 # Image tolerances of the fast chain against the exact oracle (measured: profiles/r03_chain_parity/):
