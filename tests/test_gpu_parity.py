@@ -1357,17 +1357,21 @@ for w, h in ((640, 480), (160, 120)):
 print("RESULT " + json.dumps(out))
 """ % (T.ROOT, os.path.join(T.ROOT, "tests"))
     res = {}
-    for knob in ("0", "1"):
-        o = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, KFX_ICP_PERSISTENT=knob), capture_output=True, text=True, timeout=900, cwd=T.ROOT)
+    # "pair": k_icp_point_plane + k_lss_final_solve per iteration (the round-4 chain); "fused": one launch per iteration, the last
+    # block to finish adds up and solves (k_icp_point_plane_solve, the default); "persistent": one launch for the whole loop
+    for name, env in (("pair", dict(KFX_ICP_PERSISTENT="0", KFX_ICP_FUSED="0")), ("fused", dict(KFX_ICP_PERSISTENT="0", KFX_ICP_FUSED="1")),
+                      ("persistent", dict(KFX_ICP_PERSISTENT="1"))):
+        o = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=900, cwd=T.ROOT)
         line = [l for l in o.stdout.splitlines() if l.startswith("RESULT ")]
         assert o.returncode == 0 and line, o.stdout[-2000:] + o.stderr[-3000:]
-        res[knob] = json.loads(line[0][7:])
-    assert len(res["0"]) == len(res["1"]) == 18
-    for a, b in zip(res["0"], res["1"]):
-        assert a == b, (a[:4], b[:4])
-        assert a[2] > 0
-    for k in range(0, 18, 3):   # repeated calls give the same answer
-        assert res["1"][k] == res["1"][k + 1] == res["1"][k + 2]
+        res[name] = json.loads(line[0][7:])
+    assert len(res["pair"]) == len(res["fused"]) == len(res["persistent"]) == 18
+    for other in ("fused", "persistent"):
+        for a, b in zip(res["pair"], res[other]):
+            assert a == b, (other, a[:4], b[:4])
+            assert a[2] > 0
+        for k in range(0, 18, 3):   # repeated calls give the same answer (the ticket / barrier words are re-armed)
+            assert res[other][k] == res[other][k + 1] == res[other][k + 2]
 
 
 def test_gpu_texture_depth(roo):
