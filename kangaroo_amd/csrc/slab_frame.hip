@@ -79,10 +79,9 @@ static int grow(void** p, size_t* have, size_t need)
     return 0;
 }
 
-// device scratch for the current policies (create / configure: never inside a step)
-static int ensure_scratch(kfx_slab_frame* f)
+// device scratch for the policies of `c` (create / configure: never inside a step)
+static int ensure_scratch(kfx_slab_frame* f, const kfx_slab_frame_config& c)
 {
-    const kfx_slab_frame_config& c = f->cfg;
     const size_t w = c.ray_img.w, h = c.ray_img.h;
     const int world = f->comm->world;
     if (c.raycast == KFX_SLAB_RAYCAST_EXACT) {
@@ -124,7 +123,7 @@ extern "C" int kfx_slab_frame_create(kfx_slab_frame** out, const kfx_slab_frame_
     f->slots = cfg->timing_slots;
     f->timing = 31u;
     for (int i = 0; i < OPEN_SLOTS; ++i) f->open_frame[i] = -1;
-    int e = ensure_scratch(f);
+    int e = ensure_scratch(f, f->cfg);
     if (!e) e = hip_status(hipHostMalloc((void**)&f->h_open, OPEN_SLOTS * sizeof(int), hipHostMallocDefault), "kfx_slab_frame_create: hipHostMalloc");
     if (!e) for (int i = 0; i < OPEN_SLOTS; ++i) f->h_open[i] = 0;
     for (int i = 0; i < OPEN_SLOTS && !e; ++i) e = hip_status(hipEventCreateWithFlags(&f->open_done[i], hipEventDisableTiming), "kfx_slab_frame_create: hipEventCreate");
@@ -228,8 +227,10 @@ extern "C" int kfx_slab_frame_configure(kfx_slab_frame* f, int halo, int raycast
     if (int e = hip_status(hipDeviceSynchronize(), "kfx_slab_frame_configure")) return e;
     f->merge_pending = 0;
     const int o = check_open(f, true);
+    // (a failed allocation leaves the old policies in place; a buffer that was being enlarged for them is gone, which the next
+    //  step reports before it enters any collective)
+    if (int e = ensure_scratch(f, c)) return e;
     f->cfg = c;
-    if (int e = ensure_scratch(f)) return e;
     return o;
 }
 
@@ -260,6 +261,12 @@ extern "C" int kfx_slab_frame_step(kfx_slab_frame* f, const kfx_image* raw, cons
         }
         T_cw = inv;
     }
+    if ((parts & KFX_FRAME_RAYCAST) &&
+        ((c.raycast == KFX_SLAB_RAYCAST_EXACT && !f->exact) ||
+         (c.raycast == KFX_SLAB_RAYCAST_COMPOSITE && world > 1 && !(c.merge == KFX_SLAB_MERGE_DIRECT ? f->strips : f->keys))))
+        return set_error(KFX_E_NULL, "kfx_slab_frame_step: no scratch for the configured raycast (a failed kfx_slab_frame_configure)");
+    if ((parts & KFX_FRAME_PREPROCESS) && c.inputs == KFX_SLAB_INPUTS_BROADCAST && world > 1 && !f->bcast)
+        return set_error(KFX_E_NULL, "kfx_slab_frame_step: no scratch for the input broadcast (a failed kfx_slab_frame_configure)");
     const hipStream_t s = (hipStream_t)stream;
     // From here on nothing returns early: a local failure must not keep this rank out of a collective its peers enter
     int status = 0;
