@@ -191,13 +191,23 @@ struct RefineState {
     float pose[24];
 };
 
+// The working set of the solve lives in LDS: the pivoting indexes it with run-time indices, which as per-thread arrays meant
+// scratch memory -- 320 scratch instructions in the one-lane solve, each a dependent round trip to memory: 12.5 us per
+// k_lss_final_solve, more than the k_icp_point_plane before it (profiles/r05_tracked).  Same arithmetic in the same order.
+struct SolveLds {
+    double lu[6][6];
+    double b[6], c[6], y[6], x[6];
+    int rows[6], cols[6];
+};
+
 template <int N>
-__device__ void lu_solve_full_piv(const double* A, const double* b, double* x)
+__device__ void lu_solve_full_piv(SolveLds& w, const double* A, const double* b, double* x)
 {
-    double lu[N][N];
-    int rows[N], cols[N];
+    double (&lu)[6][6] = w.lu;
+    int (&rows)[6] = w.rows, (&cols)[6] = w.cols;
     for (int i = 0; i < N; ++i) {
         rows[i] = cols[i] = i;
+        w.b[i] = b[i];
         for (int j = 0; j < N; ++j) lu[i][j] = A[i * N + j];
     }
     int nonzero = N;
@@ -218,28 +228,32 @@ __device__ void lu_solve_full_piv(const double* A, const double* b, double* x)
             for (int i = 0; i < N; ++i) { const double t = lu[i][k]; lu[i][k] = lu[i][pc]; lu[i][pc] = t; }
             const int t = cols[k]; cols[k] = cols[pc]; cols[pc] = t;
         }
+        const double pivot = lu[k][k];
         for (int i = k + 1; i < N; ++i) {
-            lu[i][k] /= lu[k][k];
-            for (int j = k + 1; j < N; ++j) lu[i][j] -= lu[i][k] * lu[k][j];
+            const double f = lu[i][k] / pivot;
+            lu[i][k] = f;
+            for (int j = k + 1; j < N; ++j) lu[i][j] -= f * lu[k][j];
         }
     }
     const double thresh = 2.220446049250313e-16 * N * maxpivot;
     int rank = 0;
     for (int i = 0; i < nonzero; ++i) rank += fabs(lu[i][i]) > thresh ? 1 : 0;
-    for (int i = 0; i < N; ++i) x[i] = 0.0;
-    if (rank == 0) return;
-    double c[N], y[N];
-    for (int i = 0; i < N; ++i) {
-        c[i] = b[rows[i]];
-        for (int j = 0; j < i; ++j) c[i] -= lu[i][j] * c[j];
-        y[i] = 0.0;
+    for (int i = 0; i < N; ++i) w.x[i] = 0.0;
+    if (rank != 0) {
+        for (int i = 0; i < N; ++i) {
+            double ci = w.b[rows[i]];
+            for (int j = 0; j < i; ++j) ci -= lu[i][j] * w.c[j];
+            w.c[i] = ci;
+            w.y[i] = 0.0;
+        }
+        for (int i = rank - 1; i >= 0; --i) {
+            double sum = w.c[i];
+            for (int j = i + 1; j < rank; ++j) sum -= lu[i][j] * w.y[j];
+            w.y[i] = sum / lu[i][i];
+        }
+        for (int i = 0; i < N; ++i) w.x[cols[i]] = w.y[i];
     }
-    for (int i = rank - 1; i >= 0; --i) {
-        double sum = c[i];
-        for (int j = i + 1; j < rank; ++j) sum -= lu[i][j] * y[j];
-        y[i] = sum / lu[i][i];
-    }
-    for (int i = 0; i < N; ++i) x[cols[i]] = y[i];
+    for (int i = 0; i < N; ++i) x[i] = w.x[i];
 }
 
 // T <- T * exp(x); rotation_only uses exp(omega) with zero translation
@@ -271,9 +285,8 @@ __device__ void se3_right_multiply_exp(double T[12], const double x[6], bool rot
 }
 
 // writes KT_lr = K * T (3x4) and T_rl = T^-1 as floats
-__device__ void publish_pose(RefineState* st, const float K[4])
+__device__ void publish_pose(RefineState* st, const float K[4], const double* T)
 {
-    const double* T = st->T;
     for (int c = 0; c < 4; ++c) {
         st->pose[0 * 4 + c] = (float)((double)K[0] * T[0 * 4 + c] + (double)K[2] * T[2 * 4 + c]);
         st->pose[1 * 4 + c] = (float)((double)K[1] * T[1 * 4 + c] + (double)K[3] * T[2 * 4 + c]);
@@ -284,6 +297,8 @@ __device__ void publish_pose(RefineState* st, const float K[4])
         st->pose[12 + i * 4 + 3] = (float)(-(T[0 * 4 + i] * T[3] + T[1 * 4 + i] * T[7] + T[2 * 4 + i] * T[11]));
     }
 }
+
+__device__ void publish_pose(RefineState* st, const float K[4]) { publish_pose(st, K, st->T); }
 
 struct K4 { float k[4]; };
 
@@ -296,7 +311,7 @@ __global__ void k_icp_refine_init(RefineState* st, const K4 K)
 
 // one Gauss-Newton step from the summed system in sums[0..28] (main.cpp:312-333); K_next: intrinsics of the level the
 // NEXT evaluation runs on
-__device__ void icp_solve_step(RefineState* st, const float* sums, const int rotation_only, const float max_rmse, const float K_next[4])
+__device__ void icp_solve_step(RefineState* st, const float* sums, const int rotation_only, const float max_rmse, const float K_next[4], SolveLds& w)
 {
     double JTJ[36], JTy[6], x[6] = {0, 0, 0, 0, 0, 0};
     int i = 6;
@@ -319,11 +334,11 @@ __device__ void icp_solve_step(RefineState* st, const float* sums, const int rot
             b3[a] = JTy[3 + a];
             for (int b = 0; b < 3; ++b) A3[a * 3 + b] = JTJ[(3 + a) * 6 + 3 + b];
         }
-        lu_solve_full_piv<3>(A3, b3, x + 3);
+        lu_solve_full_piv<3>(w, A3, b3, x + 3);
         for (int a = 3; a < 6; ++a) x[a] = -x[a];
         se3_right_multiply_exp(st->T, x, true);
     } else {
-        lu_solve_full_piv<6>(JTJ, JTy, x);
+        lu_solve_full_piv<6>(w, JTJ, JTy, x);
         bool finite = true;
         for (int a = 0; a < 6; ++a) { x[a] = -x[a]; finite = finite && isfinite(x[a]); }
         if (finite) se3_right_multiply_exp(st->T, x, false);
@@ -332,15 +347,169 @@ __device__ void icp_solve_step(RefineState* st, const float* sums, const int rot
 }
 
 
-// k_lss_final followed by the 6x6 step (icp_solve_step) as one launch (the device-resident loop is a chain of ~5 us kernels: every launch
-// saved is time saved).  Thread 0 holds the summed system after the tree; it stores it (so sums[0..28] is what
-// k_lss_final leaves) and runs the same solve on it.
+// ---------------------------------------------------------------------------------------
+// The solve by one WAVE instead of one lane (round 5).  A lone lane runs ~3800 dependent instructions (13 us per launch, six
+// launches per frame: more than the k_icp_point_plane launches they follow, profiles/r05_tracked); most of them are the
+// full-pivot LU -- a 91-element pivot search, swaps and 55 multiply-subtracts, one after the other.  Here lane i * N + j holds
+// lu[i][j]: the pivot is a six-step arg-max over the wave (largest magnitude, ties to the first element in row-major order:
+// what the serial scan's strict `>` selects) through DPP and lane swaps, the two swaps and the elimination's operands are one round
+// of lane gathers, an elimination step is one division and one multiply-subtract in every lane, the substitutions read rows
+// and columns through v_readlane.  Every element sees
+// the operations of lu_solve_full_piv in the same order with the same operands, so the solution is the serial one bit for bit
+// (the persistent and the ticketed launches keep the one-lane solve: test_gpu_persistent_icp_kernel_equals_the_chain_of_launches
+// compares the two).  All 64 lanes of the wave must be active.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ double shfl_f64(double v, int src) { return __shfl(v, src, 64); }
+__device__ __forceinline__ double readlane_f64(double v, int src)   // src uniform: two v_readlane_b32 instead of the LDS crossbar
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src), __builtin_amdgcn_readlane(__double2loint(v), src));
+}
+// the pivot candidate of a lane and the better of two: larger magnitude, ties to the smaller lane (= the earlier element in
+// row-major order, which is what the serial scan's strict `>` keeps)
+struct Pivot { double v; int idx; };
+__device__ __forceinline__ Pivot better(const Pivot a, const Pivot b)
+{
+    const bool take = b.v > a.v || (b.v == a.v && b.idx < a.idx);
+    return take ? b : a;
+}
+template <int CTRL>
+__device__ __forceinline__ Pivot pivot_dpp(const Pivot p)   // the candidate of the lane a DPP pattern pairs this one with
+{
+    Pivot o;
+    o.v = __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(p.v), CTRL, 0xF, 0xF, true),
+                           __builtin_amdgcn_update_dpp(0, __double2loint(p.v), CTRL, 0xF, 0xF, true));
+    o.idx = __builtin_amdgcn_update_dpp(0, p.idx, CTRL, 0xF, 0xF, true);
+    return o;
+}
+// the best candidate of the wave in every lane, without the LDS crossbar: quad permutes, the mirrors of 8 and 16 lanes, then
+// v_permlane16_swap / v_permlane32_swap (gfx950), which with both operands equal return the values of both partners
+__device__ __forceinline__ Pivot pivot_wave_best(Pivot p)
+{
+    p = better(p, pivot_dpp<0xB1>(p));    // quad_perm [1,0,3,2]
+    p = better(p, pivot_dpp<0x4E>(p));    // quad_perm [2,3,0,1]
+    p = better(p, pivot_dpp<0x141>(p));   // row_half_mirror
+    p = better(p, pivot_dpp<0x140>(p));   // row_mirror
+    {
+        const auto h = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(p.v), (unsigned)__double2hiint(p.v), false, false);
+        const auto l = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(p.v), (unsigned)__double2loint(p.v), false, false);
+        const auto x = __builtin_amdgcn_permlane16_swap((unsigned)p.idx, (unsigned)p.idx, false, false);
+        p = better(Pivot{__hiloint2double((int)h[0], (int)l[0]), (int)x[0]}, Pivot{__hiloint2double((int)h[1], (int)l[1]), (int)x[1]});
+    }
+    {
+        const auto h = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(p.v), (unsigned)__double2hiint(p.v), false, false);
+        const auto l = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(p.v), (unsigned)__double2loint(p.v), false, false);
+        const auto x = __builtin_amdgcn_permlane32_swap((unsigned)p.idx, (unsigned)p.idx, false, false);
+        p = better(Pivot{__hiloint2double((int)h[0], (int)l[0]), (int)x[0]}, Pivot{__hiloint2double((int)h[1], (int)l[1]), (int)x[1]});
+    }
+    return p;
+}
+
+template <int N>
+__device__ void lu_solve_wave(const float* sums, SolveLds& w)   // leaves x[0 .. N) in w.x
+{
+    constexpr int O = 6 - N;   // N = 3 (rotation only): the lower-right block of the system and its last three right-hand sides
+    const int lane = threadIdx.x & 63;
+    const bool in = lane < N * N;
+    const int i = in ? lane / N : 0, j = in ? lane % N : 0;
+    double a = 0.0;
+    {
+        const int r = O + i, c = O + j, hi = r > c ? r : c, lo = r > c ? c : r;
+        const double e = (double)sums[6 + hi * (hi + 1) / 2 + lo];
+        a = i == j ? e + 0.1 / 0.2 : e;   // weak pose prior on the diagonal: depthSigma / motionSigma
+        if (!in) a = 0.0;
+    }
+    int rl = lane, cl = lane;   // rows[lane], cols[lane] (lanes below N)
+    int nonzero = N;
+    double maxpivot = 0.0;
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        const Pivot best = pivot_wave_best(Pivot{(in && i >= k && j >= k && fabs(a) > 0.0) ? fabs(a) : -1.0, lane});
+        if (!(best.v > 0.0)) { nonzero = k; break; }   // (uniform: every lane holds the same candidate)
+        if (best.v > maxpivot) maxpivot = best.v;
+        const int idx = __builtin_amdgcn_readfirstlane(best.idx);
+        const int pr = idx / N, pc = idx % N;
+        // rows k and pr, then columns k and pc change places: element (i, j) comes from (si, sj), its column-k and row-k
+        // partners of the elimination from (si, pc) and (pr, sj), the pivot from (pr, pc) -- one round of gathers
+        const int si = i == k ? pr : (i == pr ? k : i), sj = j == k ? pc : (j == pc ? k : j);
+        const double pivot = readlane_f64(a, idx);
+        const double aij = shfl_f64(a, in ? si * N + sj : lane), aik = shfl_f64(a, in ? si * N + pc : lane), akj = shfl_f64(a, in ? pr * N + sj : lane);
+        rl = __shfl(rl, lane == k ? pr : (lane == pr ? k : lane), 64);
+        cl = __shfl(cl, lane == k ? pc : (lane == pc ? k : lane), 64);
+        const double f = aik / pivot;
+        a = aij;
+        if (in && i > k) {
+            if (j == k) a = f;
+            else if (j > k) a = aij - f * akj;
+        }
+    }
+    const double thresh = 2.220446049250313e-16 * N * maxpivot;
+    const int rank = __popcll(__ballot(in && i == j && i < nonzero && fabs(a) > thresh));
+    if (lane < N) w.x[lane] = 0.0;
+    if (rank == 0) return;   // (uniform)
+    // c[i] = b[rows[i]] - sum_{j < i} lu[i][j] c[j], j ascending
+    const double bl = lane < N ? (double)sums[O + lane] : 0.0;
+    double c = shfl_f64(bl, lane < N ? rl : lane);
+#pragma unroll
+    for (int jj = 0; jj < N - 1; ++jj) {
+        const double cj = readlane_f64(c, jj), lij = shfl_f64(a, lane < N ? lane * N + jj : lane);
+        if (lane < N && lane > jj) c = c - lij * cj;
+    }
+    // y[i] = (c[i] - sum_{i < j < rank} lu[i][j] y[j]) / lu[i][i], i descending, j ascending (every lane follows the same chain)
+    double y = 0.0;
+    for (int ii = rank - 1; ii >= 0; --ii) {
+        double sum = readlane_f64(c, ii);
+        for (int jj = ii + 1; jj < rank; ++jj) sum = sum - readlane_f64(a, ii * N + jj) * readlane_f64(y, jj);
+        const double yi = sum / readlane_f64(a, ii * N + ii);
+        if (lane == ii) y = yi;
+    }
+    if (lane < N) w.x[cl] = y;   // x[cols[i]] = y[i]: cols is a permutation
+}
+
+// icp_solve_step with the LU spread over the calling wave (all 64 lanes active); lane 0 does what remains
+// T_lane: st->T[lane] in lanes 0 .. 11, requested by the caller before the block sums were added up (one memory round trip
+// less on the one-lane tail)
+__device__ void icp_solve_step_wave(RefineState* st, const float* sums, const int rotation_only, const float max_rmse, const float K_next[4], SolveLds& w,
+                                    const double T_lane)
+{
+    const int lane = threadIdx.x & 63;
+    if (rotation_only) lu_solve_wave<3>(sums, w);
+    else lu_solve_wave<6>(sums, w);
+    __builtin_amdgcn_wave_barrier();   // (one wave: its LDS operations complete in order)
+    double T[12];
+#pragma unroll
+    for (int m = 0; m < 12; ++m) T[m] = readlane_f64(T_lane, m);
+    if (lane != 0) return;
+    const float sq = sums[27];
+    const unsigned obs = __float_as_uint(sums[28]);
+    const float rmse = sqrtf(sq / (float)obs);
+    st->rmse = (double)rmse;
+    st->obs = (double)obs;
+    st->good = rmse < max_rmse ? 1.0 : 0.0;
+    double x[6] = {0, 0, 0, 0, 0, 0};
+    bool moved = true;
+    if (rotation_only) {
+        for (int a = 0; a < 3; ++a) x[3 + a] = -w.x[a];
+        se3_right_multiply_exp(T, x, true);
+    } else {
+        for (int a = 0; a < 6; ++a) { x[a] = -w.x[a]; moved = moved && isfinite(x[a]); }
+        if (moved) se3_right_multiply_exp(T, x, false);
+    }
+    if (moved)
+        for (int m = 0; m < 12; ++m) st->T[m] = T[m];
+    publish_pose(st, K_next, T);
+}
+
+// k_lss_final followed by the 6x6 step as one launch (the device-resident loop is a chain of ~5 us kernels: every launch saved is
+// time saved).  Thread 0 holds the summed system after the tree; it stores it (so sums[0..28] is what k_lss_final leaves) and
+// the first wave solves it.
 __global__ __launch_bounds__(256) void k_lss_final_solve(float* sums, const int nblocks, RefineState* st, const int rotation_only,
                                                          const float max_rmse, const K4 K_next)
 {
     __shared__ float lds[LSS_WORDS * 128];
     __shared__ float s_sum[LSS_WORDS];
+    __shared__ SolveLds s_solve;
     const int tid = threadIdx.x;
+    const double T_lane = tid < 12 ? st->T[tid] : 0.0;   // (for the tail of the solve: on its way while the sums are added up)
     Lss acc;
     lss_zero(acc);
     for (int b = tid; b < nblocks; b += 256) {
@@ -353,8 +522,9 @@ __global__ __launch_bounds__(256) void k_lss_final_solve(float* sums, const int 
     if (tid == 0) {
         lss_store(sums, acc);
         lss_store(s_sum, acc);
-        icp_solve_step(st, s_sum, rotation_only, max_rmse, K_next.k);
     }
+    __syncthreads();
+    if (tid < 64) icp_solve_step_wave(st, s_sum, rotation_only, max_rmse, K_next.k, s_solve, T_lane);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -428,6 +598,7 @@ __global__ __launch_bounds__(256) void k_icp_refine_persistent(const IcpPersiste
 {
     __shared__ float lds[LSS_WORDS * 128];
     __shared__ float s_sum[LSS_WORDS];
+    __shared__ SolveLds s_solve;
     __shared__ RefineState s_st;
     const int tid = threadIdx.x;
     const unsigned G = gridDim.x;
@@ -490,7 +661,7 @@ __global__ __launch_bounds__(256) void k_icp_refine_persistent(const IcpPersiste
                 lss_store(s_sum, acc);
                 const float* Kn = (it + 1 < L.iterations || nxt < 0) ? L.K : q.lv[nxt].K;
                 float kn[4] = {Kn[0], Kn[1], Kn[2], Kn[3]};
-                icp_solve_step(&s_st, s_sum, L.rotation_only, q.max_rmse, kn);
+                icp_solve_step(&s_st, s_sum, L.rotation_only, q.max_rmse, kn, s_solve);
             }
             __syncthreads();
         }
@@ -525,6 +696,7 @@ __global__ __launch_bounds__(256) void k_icp_point_plane_solve(const IcpFused q)
     extern __shared__ float lds[];   // LSS_WORDS * 256 floats
     __shared__ int s_last;
     __shared__ float s_sum[LSS_WORDS];
+    __shared__ SolveLds s_solve;
     const IcpParams& p = q.p;
     const int n = blockDim.x * blockDim.y;
     const int tid = threadIdx.y * blockDim.x + threadIdx.x;
@@ -580,7 +752,7 @@ __global__ __launch_bounds__(256) void k_icp_point_plane_solve(const IcpFused q)
     if (tid == 0) {
 #pragma unroll
         for (int k = 0; k < LSS_WORDS; ++k) { s_sum[k] = lds[k * 256]; p.sums[k] = s_sum[k]; }   // (sums[0..28] is what k_lss_final leaves)
-        icp_solve_step(q.st, s_sum, q.rotation_only, q.max_rmse, q.K_next.k);
+        icp_solve_step(q.st, s_sum, q.rotation_only, q.max_rmse, q.K_next.k, s_solve);
         __hip_atomic_store(q.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-armed for the next launch of the chain
     }
 }
