@@ -152,11 +152,11 @@ int main(int argc, char** argv)
         }
         ElementwiseScaleBias<float,float,float>(dKinectMeters, dKinectMeters, 1.0f / 1000.0f);
         BilateralFilter<float,float>(kin_d[0], dKinectMeters, bigs, bigr, biwin, 0.2f);
-        BoxReduceIgnoreInvalid<float,MaxLevels,float>(kin_d);
-        for (int l = 0; l < MaxLevels; ++l) {
-            if (one_raycast) {   // --fused-launches: both maps from one launch, same images
-                DepthToVboNormals(kin_v[l], kin_n[l], kin_d[l], K[l]);
-            } else {
+        if (one_raycast) {   // --fused-launches: the pyramid and both maps of every level from one launch, same images
+            DepthPyramidVboNormals<MaxLevels>(kin_d, kin_v, kin_n, K);
+        } else {
+            BoxReduceIgnoreInvalid<float,MaxLevels,float>(kin_d);
+            for (int l = 0; l < MaxLevels; ++l) {
                 DepthToVbo<float>(kin_v[l], kin_d[l], K[l]);
                 NormalsFromVbo(kin_n[l], kin_v[l]);
             }

@@ -369,7 +369,7 @@ def tracked_leg(args, torch, roo, scenes, n_steps):
     elapsed = time.perf_counter() - t0
     out = {"scene": "S_room", "frames_per_sec": round(n_steps / elapsed, 1), "steps": n_steps, "ms_per_step": round(1e3 * elapsed / n_steps, 4),
            "worst_position_error_mm": round(1e3 * worst, 3), "frames_lost": lost, "resets": pipe.resets, "final_rmse": round(float(pipe.rmse), 6),
-           "loop": "TrackingPipeline(device_icp=True): BilateralFilter + depth pyramid + per-level DepthToVbo / NormalsFromVbo -> RaycastSdf on levels "
+           "loop": "TrackingPipeline(device_icp=True): BilateralFilter -> depth pyramid with DepthToVbo / NormalsFromVbo of every level (one launch) -> RaycastSdf on levels "
                    "0, 2, 3 (one launch) -> kfx_icp_refine (6 iterations over 3 levels, its = {1, 0, 2, 3}, solved on the device) -> one pose read-back "
                    "-> SdfFuse at the estimated pose; the Python loop issues the operators (the C++ application's loop: apps/kinectfusion_headless --device-icp)",
            "note": "%d frames of the orbit tracked from depth alone after %d untimed ones; position error against the known orbit over all of them "

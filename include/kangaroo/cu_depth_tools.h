@@ -59,6 +59,24 @@ inline void DepthToVboNormals( Image<float4> dVbo, Image<float4> dN, const Image
     GpuNoteStatus(kfx_depth_to_vbo_normals_f32(dVbo.abi(), dN.abi(), dKinectDepth.abi(), &K.fu, scale, 0));
 }
 
+// BoxReduceIgnoreInvalid(depth) followed by DepthToVbo + NormalsFromVbo on every level (main.cpp:211-218) as ONE launch (addition
+// beside the reference API; the 2 * Levels - 1 separate launches are latency-sized): depth[0] is the input, K[l]
+// (ImageIntrinsics::operator[]) the intrinsics of level l.  Same images.  Up to four levels; a level of size zero ends the chain as in BoxReduceIgnoreInvalid.
+template<unsigned Levels, typename PyrD, typename PyrV>
+inline void DepthPyramidVboNormals(PyrD& depth, PyrV& vbo, PyrV& nrm, const ImageIntrinsics& K, float scale = 1.0f)
+{
+    static_assert(Levels >= 1 && Levels <= 4, "DepthPyramidVboNormals: one to four levels");
+    kfx_image d[Levels], v[Levels], n[Levels];
+    float k[4 * Levels];
+    int levels = 0;
+    for (unsigned l = 0; l < Levels && depth[l].w != 0 && depth[l].h != 0; ++l, ++levels) {
+        d[l] = *depth[l].abi(); v[l] = *vbo[l].abi(); n[l] = *nrm[l].abi();
+        const ImageIntrinsics Kl = K[(int)l];
+        k[4 * l] = Kl.fu; k[4 * l + 1] = Kl.fv; k[4 * l + 2] = Kl.u0; k[4 * l + 3] = Kl.v0;
+    }
+    if (levels > 0) GpuNoteStatus(kfx_depth_pyramid_vbo_normals_f32(d, v, n, k, levels, scale, 0));
+}
+
 // roo::ImageKeyframe<T> (reference ImageKeyframe.h:10-14 over ImageTransformProject, ImageIntrinsics.h:202-212): a camera
 // {K, T_iw} with its image; 96 bytes, layout-identical to kfx_keyframe.
 struct ImageTransformProject

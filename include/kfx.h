@@ -221,6 +221,14 @@ int kfx_stream_synchronize(kfx_stream stream);
 int kfx_depth_to_vbo_normals_f32(const kfx_image* vbo, const kfx_image* nrm, const kfx_image* depth, const float K[4], float scale,
                                  kfx_stream stream);
 
+/* The frame's depth pyramid with its vertex and normal maps in one launch (no reference counterpart: the 2 * levels - 1 launches
+ * of roo::BoxReduceIgnoreInvalid (reduce.h:48-59) and of DepthToVbo + NormalsFromVbo per level -- main.cpp:211-218 -- are
+ * launch-latency sized).  depth[0] is the input; depth[1 .. levels) are written, each at most half the size of the level
+ * before; vbo[l] / nrm[l] are the maps of level l (of depth[l]'s size); K holds `levels` x {fu, fv, u0, v0}.  1 <= levels <= 4.
+ * Every output holds exactly what the per-level entry points write. */
+int kfx_depth_pyramid_vbo_normals_f32(const kfx_image* depth, const kfx_image* vbo, const kfx_image* nrm, const float* K, int levels,
+                                      float scale, kfx_stream stream);
+
 /* BilateralFilter(dOut, dIn, dImg, gs, gr, gc, size) (cu_bilateral.cu:110-155): joint bilateral filter of a float image
  * with a float / unsigned char guide image (third weight exp(-(guide difference)^2 / 2 gc^2)); sumw == 0 keeps the input. */
 int kfx_bilateral_guided_f32(const kfx_image* out, const kfx_image* in, const kfx_image* guide, float gs, float gr, float gc,

@@ -96,6 +96,7 @@ SIGNATURES = {
     "kfx_raycast_sdf_color": (C.c_int, [PI, PI, PI, PV, PV, PF, PF, C.c_float, C.c_float, C.c_float, C.c_int, C.c_void_p]),
     "kfx_color_reset": (C.c_int, [PV, C.c_void_p]),
     "kfx_depth_to_vbo_normals_f32": (C.c_int, [PI, PI, PI, PF, C.c_float, C.c_void_p]),
+    "kfx_depth_pyramid_vbo_normals_f32": (C.c_int, [PI, PI, PI, PF, C.c_int, C.c_float, C.c_void_p]),
     "kfx_bilateral_guided_f32": (C.c_int, [PI, PI, PI, C.c_float, C.c_float, C.c_float, C.c_uint, C.c_void_p]),
     "kfx_bilateral_guided_u8": (C.c_int, [PI, PI, PI, C.c_float, C.c_float, C.c_float, C.c_uint, C.c_void_p]),
     "kfx_texture_depth": (C.c_int, [PI, C.POINTER(KfxKeyframe), C.c_int, PI, PI, PI, PF, PF, C.c_void_p]),

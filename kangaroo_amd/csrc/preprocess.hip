@@ -722,6 +722,132 @@ extern "C" int kfx_depth_to_vbo_normals_f32(const kfx_image* vbo, const kfx_imag
     return check_launch("kfx_depth_to_vbo_normals_f32");
 }
 
+// ---- the depth pyramid with its vertex and normal maps, one launch (round 5) -------------------------------------------------
+// BoxReduceIgnoreInvalid (levels 1 .. L-1 from level 0) followed by DepthToVbo + NormalsFromVbo on every level are 2 L - 1
+// launches of 3-5 us each (seven per frame of the tracked loop, profiles/r05_tracked: latency, not work).  Here a workgroup owns
+// a 32 x 32 tile of level 0 and the 16 x 16 / 8 x 8 / 4 x 4 tiles below it: it stages the tile with an apron of 8 pixels to the
+// right and below in LDS, halves it level by level there (k_box_half_ignore_invalid_f32's expression, same order of additions)
+// -- the apron is what the next level's one-pixel apron is averaged from, and a level's one-pixel apron holds the neighbours its
+// normals need -- writes each level's depth tile, and evaluates vertex_of / the normal's expression of k_vbo_normals_f32 from the
+// LDS values.  Every output is the per-level launches' bit for bit.
+struct PyrParams {
+    const unsigned char* d0;
+    size_t d0_pitch;
+    unsigned char* d[4];      // depth of levels 1 .. (index 0 unused)
+    size_t dpitch[4];
+    unsigned char *vbo[4], *nrm[4];
+    size_t vpitch[4], npitch[4];
+    int w[4], h[4];
+    Intr K[4];
+    int levels;
+    float scale;
+};
+__device__ __forceinline__ float4 pyr_vertex(const Intr& K, float scale, float depth, int u, int v)
+{
+    const float kz = scale * depth;
+    return make_float4(kz * ((float)u - K.u0) / K.fu, kz * ((float)v - K.v0) / K.fv, kz, 1.0f);
+}
+__global__ __launch_bounds__(256) void k_depth_pyramid_vbo_normals(const PyrParams p)
+{
+    constexpr int E0 = 40, E1 = 20, E2 = 10, E3 = 5;   // staged extents: tile + apron
+    __shared__ float s0[E0 * E0], s1[E1 * E1], s2[E2 * E2], s3[E3 * E3];
+    const int tid = threadIdx.x;
+    {   // level 0: the tile and its apron (zero beyond the image: such pixels only feed values nobody reads)
+        const int x0 = blockIdx.x * 32, y0 = blockIdx.y * 32;
+        for (int t = tid; t < E0 * E0; t += 256) {
+            const int ly = t / E0, lx = t - ly * E0, x = x0 + lx, y = y0 + ly;
+            s0[t] = (x < p.w[0] && y < p.h[0]) ? reinterpret_cast<const float*>(p.d0 + (size_t)y * p.d0_pitch)[x] : 0.f;
+        }
+    }
+    __syncthreads();
+    float* const sl[4] = {s0, s1, s2, s3};
+    const int ext[4] = {E0, E1, E2, E3};
+#pragma unroll
+    for (int l = 1; l < 4; ++l) {
+        if (l < p.levels) {   // (uniform)
+            const int E = ext[l], Ef = ext[l - 1], S = 32 >> l;
+            const int x0 = blockIdx.x * S, y0 = blockIdx.y * S;
+            const float* f = sl[l - 1];
+            for (int t = tid; t < E * E; t += 256) {
+                const int ly = t / E, lx = t - ly * E;
+                const float tx = f[(2 * ly) * Ef + 2 * lx], ty = f[(2 * ly) * Ef + 2 * lx + 1], bx = f[(2 * ly + 1) * Ef + 2 * lx], by = f[(2 * ly + 1) * Ef + 2 * lx + 1];
+                int n = 0;
+                float sum = 0;
+                if (isfinite(tx)) { sum += tx; n++; }
+                if (isfinite(ty)) { sum += ty; n++; }
+                if (isfinite(bx)) { sum += bx; n++; }
+                if (isfinite(by)) { sum += by; n++; }
+                const float m = n > 0 ? (sum / n) : __builtin_nanf("");
+                sl[l][t] = m;
+                const int x = x0 + lx, y = y0 + ly;
+                if (lx < S && ly < S && x < p.w[l] && y < p.h[l]) reinterpret_cast<float*>(p.d[l] + (size_t)y * p.dpitch[l])[x] = m;
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int l = 0; l < 4; ++l) {
+        if (l >= p.levels) break;   // (uniform)
+        const int E = ext[l], S = 32 >> l, w = p.w[l], h = p.h[l];
+        const int x0 = blockIdx.x * S, y0 = blockIdx.y * S;
+        const float* d = sl[l];
+        const Intr K = p.K[l];
+        for (int t = tid; t < S * S; t += 256) {
+            const int ly = t / S, lx = t - ly * S, u = x0 + lx, v = y0 + ly;
+            if (u >= w || v >= h) continue;
+            const float4 Vc = pyr_vertex(K, p.scale, d[ly * E + lx], u, v);
+            reinterpret_cast<float4*>(p.vbo[l] + (size_t)v * p.vpitch[l])[u] = Vc;
+            float4 N = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (u + 1 < w && v + 1 < h) {
+                const float4 Vr = pyr_vertex(K, p.scale, d[ly * E + lx + 1], u + 1, v), Vu = pyr_vertex(K, p.scale, d[(ly + 1) * E + lx], u, v + 1);
+                const V3 a = v3(Vr.x - Vc.x, Vr.y - Vc.y, Vr.z - Vc.z);
+                const V3 b = v3(Vu.x - Vc.x, Vu.y - Vc.y, Vu.z - Vc.z);
+                const V3 axb = v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+                const float mag = length(axb);
+                N = make_float4(-axb.x / mag, -axb.y / mag, -axb.z / mag, 1.0f);
+            }
+            reinterpret_cast<float4*>(p.nrm[l] + (size_t)v * p.npitch[l])[u] = N;
+        }
+    }
+}
+
+// depth[0 .. levels): level 0 is the input, levels 1 .. are written (each at most half the size of the one before, as
+// BoxHalfIgnoreInvalid requires); vbo[l] / nrm[l]: the maps of level l, of depth[l]'s size; K: levels x {fu, fv, u0, v0}
+extern "C" int kfx_depth_pyramid_vbo_normals_f32(const kfx_image* depth, const kfx_image* vbo, const kfx_image* nrm, const float* K, int levels,
+                                                 float scale, kfx_stream stream)
+{
+    if (!depth || !vbo || !nrm || !K) return set_error(KFX_E_NULL, "DepthPyramidVboNormals: null argument");
+    if (levels < 1 || levels > 4) return set_error(KFX_E_RANGE, "DepthPyramidVboNormals: 1 to 4 levels");
+    PyrParams p;
+    p.levels = levels;
+    p.scale = scale;
+    for (int l = 0; l < 4; ++l) {
+        p.d[l] = p.vbo[l] = p.nrm[l] = nullptr;
+        p.dpitch[l] = p.vpitch[l] = p.npitch[l] = 0;
+        p.w[l] = p.h[l] = 0;
+        p.K[l] = Intr{1.f, 1.f, 0.f, 0.f};
+    }
+    for (int l = 0; l < levels; ++l) {
+        if (int e = check_image(&depth[l], 4, "DepthPyramidVboNormals: depth image")) return e;
+        if (int e = check_image(&vbo[l], 16, "DepthPyramidVboNormals: vbo image")) return e;
+        if (int e = check_image(&nrm[l], 16, "DepthPyramidVboNormals: normal image")) return e;
+        if (vbo[l].w != depth[l].w || vbo[l].h != depth[l].h || nrm[l].w != depth[l].w || nrm[l].h != depth[l].h)
+            return set_error(KFX_E_SHAPE, "DepthPyramidVboNormals: the maps of a level differ in size from its depth image");
+        if (l > 0 && (depth[l - 1].w < 2 * depth[l].w || depth[l - 1].h < 2 * depth[l].h))
+            return set_error(KFX_E_SHAPE, "DepthPyramidVboNormals: a level larger than half the one before");
+        if (depth[l].w == 0 || depth[l].h == 0) return set_error(KFX_E_SHAPE, "DepthPyramidVboNormals: empty level");
+        p.d[l] = (unsigned char*)depth[l].ptr; p.dpitch[l] = depth[l].pitch;
+        p.vbo[l] = (unsigned char*)vbo[l].ptr; p.vpitch[l] = vbo[l].pitch;
+        p.nrm[l] = (unsigned char*)nrm[l].ptr; p.npitch[l] = nrm[l].pitch;
+        p.w[l] = (int)depth[l].w; p.h[l] = (int)depth[l].h;
+        p.K[l] = Intr{K[4 * l], K[4 * l + 1], K[4 * l + 2], K[4 * l + 3]};
+    }
+    p.d0 = (const unsigned char*)depth[0].ptr;
+    p.d0_pitch = depth[0].pitch;
+    hipLaunchKernelGGL(k_depth_pyramid_vbo_normals, dim3(ceil_div(p.w[0], 32), ceil_div(p.h[0], 32)), dim3(256), 0, (hipStream_t)stream, p);
+    return check_launch("kfx_depth_pyramid_vbo_normals_f32");
+}
+
 // TextureDepth<float4,uchar3>(img, kf, depth, norm, T_wd, Kdepth) (single keyframe: n_kf = 1, phong = NULL) and
 // TextureDepth<float4,uchar3,10>(img, kfs, depth, norm, phong, T_wd, Kdepth) (cu_depth_tools.cu:123-207)
 extern "C" int kfx_texture_depth(const kfx_image* img, const kfx_keyframe* kfs, int n_kf, const kfx_image* depth, const kfx_image* norm,

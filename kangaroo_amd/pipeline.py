@@ -293,6 +293,9 @@ class TrackingPipeline(FramePipeline):
         o = self.ops
         src = self.raw if raw_image is None else raw_image
         o.BilateralFilter(self.kin_d[0], src, self.bil["gs"], self.bil["gr"], self.bil["size"], self.bil["minval"])
+        if hasattr(o, "DepthPyramidVboNormals"):   # the pyramid and its maps from one launch (same images)
+            o.DepthPyramidVboNormals(self.kin_d, self.kin_v, self.kin_n, self.K_levels)
+            return
         o.BoxReduceIgnoreInvalid(self.kin_d)
         for l in range(self.LEVELS):
             vbo_normals(o, self.kin_v[l], self.kin_n[l], self.kin_d[l], self.K_levels[l])

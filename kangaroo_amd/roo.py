@@ -721,6 +721,26 @@ def DepthToVboNormals(vbo, nrm, depth, K, scale=1.0, stream=None):
     _lib.check(_lib.load().kfx_depth_to_vbo_normals_f32(vbo.ref(), nrm.ref(), depth.ref(), k, scale, _stream(stream)))
 
 
+def DepthPyramidVboNormals(depth, vbo, nrm, K_levels, scale=1.0, stream=None):
+    """kfx_depth_pyramid_vbo_normals_f32: BoxReduceIgnoreInvalid(depth) followed by DepthToVbo + NormalsFromVbo on every level
+    (main.cpp:211-218), one launch; depth / vbo / nrm: per-level lists (or pyramids), depth[0] the input.  Same images as the
+    per-level calls.  Levels of size zero (and what follows them) are left alone, as BoxReduceIgnoreInvalid leaves them."""
+    n = 0
+    while n < len(depth) and n < 4 and depth[n].w > 0 and depth[n].h > 0:
+        n += 1
+    if n == 0:
+        return
+    arrs = [(_lib.KfxImage * n)(*[im[l].view() for l in range(n)]) for im in (depth, vbo, nrm)]
+    k, _k = _fp(np.concatenate([np.asarray(K_levels[l], np.float32).reshape(4) for l in range(n)]), 4 * n)
+    _lib.check(_lib.load().kfx_depth_pyramid_vbo_normals_f32(arrs[0], arrs[1], arrs[2], k, n, scale, _stream(stream)))
+    if len(depth) > n and n == 4 and depth[n].w > 0 and depth[n].h > 0:   # (more than four levels: the rest level by level)
+        for l in range(n, len(depth)):
+            if depth[l].w == 0 or depth[l].h == 0:
+                break
+            BoxHalfIgnoreInvalid(depth[l], depth[l - 1], stream)
+            DepthToVboNormals(vbo[l], nrm[l], depth[l], K_levels[l], scale, stream)
+
+
 def IcpRefine(kin_v, ray_v, ray_n, K_levels, its, icp_c, max_rmse, dWorkspace, dDebug=None, stream=None):
     """kfx_icp_refine: the coarse-to-fine loop of main.cpp:301-337 enqueued as one kernel chain with the 6x6 solves on
     the device.  Per-level lists are indexed by pyramid level (0 = full resolution), as in the application; levels are

@@ -596,6 +596,40 @@ def test_gpu_scale_bias_and_pyramid(roo):
     assert np.isnan(pyr[1].MemcpyToHost()[5:7, 10:20]).all()  # fully invalid 2x2 blocks stay invalid
 
 
+@pytest.mark.parametrize("w,h,levels", [(640, 480, 4), (160, 120, 4), (100, 76, 3), (67, 45, 4), (33, 31, 2), (40, 40, 1)])
+def test_gpu_depth_pyramid_with_maps_in_one_launch(roo, w, h, levels):
+    """kfx_depth_pyramid_vbo_normals_f32: BoxReduceIgnoreInvalid + DepthToVbo + NormalsFromVbo on every level as ONE launch against
+    the 2 * levels - 1 separate launches: depth levels bit for bit, vertex and normal maps bit for bit wherever they are numbers and
+    NaN in the same places (which operand's NaN an instruction hands on is the compiler's choice per kernel) -- sizes that are no
+    multiple of the 32-pixel tile, odd sizes (a level's last row / column of 2 x 2 blocks is cut), NaN holes and stripes."""
+    rng = np.random.default_rng(w * 1000 + h)
+    d0 = scenes.render_depth("room", w, h).astype(np.float32)
+    d0[rng.random((h, w)) < 0.05] = np.nan
+    d0[h // 3, :] = np.nan
+    d0[:, w // 2: w // 2 + 3] = np.nan
+    d0[-1, -1] = np.inf
+    K = scenes.intrinsics(w, h)
+    K_levels = [np.array([K[0] / (1 << l), K[1] / (1 << l), (K[2] + 0.5) / (1 << l) - 0.5, (K[3] + 0.5) / (1 << l) - 0.5], np.float32) for l in range(levels)]
+    pyr = [roo.Pyramid(w, h, levels) for _ in range(2)]
+    maps = [[[roo.Image(w >> l, h >> l, "f32x4") for l in range(levels)] for _ in range(2)] for _ in range(2)]   # [variant][vbo|nrm][level]
+    for v in range(2):
+        pyr[v][0].MemcpyFromHost(d0)
+        for l in range(1, levels):   # what a launch leaves alone stays recognisable
+            pyr[v][l].MemcpyFromHost(np.full((h >> l, w >> l), -7.0, np.float32))
+    roo.BoxReduceIgnoreInvalid(pyr[0])
+    for l in range(levels):
+        roo.DepthToVbo(maps[0][0][l], pyr[0][l], K_levels[l])
+        roo.NormalsFromVbo(maps[0][1][l], maps[0][0][l])
+    roo.DepthPyramidVboNormals(pyr[1], maps[1][0], maps[1][1], K_levels)
+    for l in range(levels):
+        a, b = pyr[0][l].MemcpyToHost(), pyr[1][l].MemcpyToHost()
+        assert a.shape == (h >> l, w >> l) and a.tobytes() == b.tobytes(), ("depth", l, T.mismatch_report(b, a))
+        for k, name in ((0, "vbo"), (1, "normals")):
+            a, b = maps[0][k][l].MemcpyToHost(), maps[1][k][l].MemcpyToHost()
+            assert T.nan_equal(b, a), (name, l, T.mismatch_report(b, a))
+    assert np.isfinite(maps[1][1][0].MemcpyToHost()[..., :3]).any()
+
+
 def test_gpu_composite_kernels_match_tensor_expressions(roo):
     """The fused pack / select / unpack kernels of the multi-GPU raycast composite, with the two
     all-reduces emulated on one GPU (elementwise min / sum over two 'ranks'), against the plain tensor
