@@ -43,6 +43,17 @@ def export(roo, summ, tol, vref, fine_shift=4):
         classes[shift] = (p0 | (p1 << 1)).to(torch.int8)
     published, n_coarse = dims[11], dims[10]
     assert published == int((classes[5] != 0).sum()) and n_coarse == classes[5].numel()   # the count the host steers by
+    if fine_shift < 5:
+        # the 32^3-cell level is the combination of the fine level's entries under it (clamped at the far edges)
+        fine, m = classes[fine_shift].to(torch.int64), 32 >> fine_shift
+        nzc, nyc, nxc = classes[5].shape
+        iz = (torch.arange(nzc * m, device="cuda")).clamp(max=fine.shape[0] - 1)
+        iy = (torch.arange(nyc * m, device="cuda")).clamp(max=fine.shape[1] - 1)
+        ix = (torch.arange(nxc * m, device="cuda")).clamp(max=fine.shape[2] - 1)
+        sub = fine[iz][:, iy][:, :, ix].view(nzc, m, nyc, m, nxc, m).permute(0, 2, 4, 1, 3, 5).reshape(nzc, nyc, nxc, -1)
+        all_free, all_nan, all_either = (sub == 1).all(-1), (sub == 2).all(-1), (sub != 0).all(-1)
+        want = torch.where(all_free, 1, torch.where(all_nan, 2, torch.where(all_either, 3, 0))).to(torch.int8)
+        assert bool((want == classes[5]).all()), "32^3-cell classes differ from the combination of the fine entries: %d" % int((want != classes[5]).sum())
     return R, classes
 
 
