@@ -99,9 +99,17 @@ int main(int argc, char** argv)
 
     const int MaxLevels = 4;
     const int its[] = {1, 0, 2, 3};                      // main.cpp:51-52
-    Image<float, TargetDevice, Manage> dKinectMeters(w, h);
-    Pyramid<float, MaxLevels, TargetDevice, Manage> kin_d(w, h);
-    Pyramid<float4, MaxLevels, TargetDevice, Manage> kin_v(w, h), kin_n(w, h);
+    // The frame's pre-amble images, twice: with --device-icp --fused-launches the NEXT frame's pre-amble is enqueued while this
+    // frame's pose is on its way to the host (kfx_icp_refine_then) and must not overwrite the maps SdfFuse is about to read.
+    struct Preamble {
+        Image<float, TargetDevice, Manage> dKinectMeters;
+        Pyramid<float, MaxLevels, TargetDevice, Manage> kin_d;
+        Pyramid<float4, MaxLevels, TargetDevice, Manage> kin_v, kin_n;
+        Preamble(int w, int h) : dKinectMeters(w, h), kin_d(w, h), kin_v(w, h), kin_n(w, h) {}
+    };
+    Preamble pre_a(w, h), pre_b(w, h);
+    Preamble *pre = &pre_a, *pre_next = &pre_b;
+    int prepared_frame = -1;   // the frame whose pre-amble `pre_next` holds
     Pyramid<float, MaxLevels, TargetDevice, Manage> ray_i(w, h), ray_d(w, h);
     Pyramid<float4, MaxLevels, TargetDevice, Manage> ray_n(w, h), ray_v(w, h);
     BoundedVolume<SDF_t, TargetDevice, Manage> vol(volres, volres, volres, reset_bb);
@@ -143,24 +151,34 @@ int main(int argc, char** argv)
     }
     for (int f = 0; f < frames; ++f) {
         Mat<float,3,4> T_wl = track ? T_wl_est.matrix3x4<Mat<float,3,4> >() : poses[f];
-        dKinectMeters.MemcpyFromHost(depth_frames[f].data());   // the host->device boundary of main.cpp:203
+        const bool ahead = track && device_icp && one_raycast;
+        if (prepared_frame == f) std::swap(pre, pre_next);   // its pre-amble ran under the previous frame's pose read-back
+        else pre->dKinectMeters.MemcpyFromHost(depth_frames[f].data());   // the host->device boundary of main.cpp:203
+        if (ahead && f + 1 < frames) pre_next->dKinectMeters.MemcpyFromHost(depth_frames[f + 1].data());
+        Image<float, TargetDevice, Manage>& dKinectMeters = pre->dKinectMeters;
+        Pyramid<float, MaxLevels, TargetDevice, Manage>& kin_d = pre->kin_d;
+        Pyramid<float4, MaxLevels, TargetDevice, Manage> &kin_v = pre->kin_v, &kin_n = pre->kin_n;
+        const auto preamble = [&](Preamble& q) {
+            ElementwiseScaleBias<float,float,float>(q.dKinectMeters, q.dKinectMeters, 1.0f / 1000.0f);
+            BilateralFilter<float,float>(q.kin_d[0], q.dKinectMeters, bigs, bigr, biwin, 0.2f);
+            if (one_raycast) {   // --fused-launches: the pyramid and both maps of every level from one launch, same images
+                DepthPyramidVboNormals<MaxLevels>(q.kin_d, q.kin_v, q.kin_n, K);
+            } else {
+                BoxReduceIgnoreInvalid<float,MaxLevels,float>(q.kin_d);
+                for (int l = 0; l < MaxLevels; ++l) {
+                    DepthToVbo<float>(q.kin_v[l], q.kin_d[l], K[l]);
+                    NormalsFromVbo(q.kin_n[l], q.kin_v[l]);
+                }
+            }
+        };
         const auto t0 = std::chrono::steady_clock::now();
         if (!cal_done && summary) {   // the block this frame belongs to
             const int k = f - CAL_FIRST;
             if (k == CAL_BLOCK) use_summary = false;
             else if (k == 2 * CAL_BLOCK) { summary->Rebuild(); use_summary = true; }
         }
-        ElementwiseScaleBias<float,float,float>(dKinectMeters, dKinectMeters, 1.0f / 1000.0f);
-        BilateralFilter<float,float>(kin_d[0], dKinectMeters, bigs, bigr, biwin, 0.2f);
-        if (one_raycast) {   // --fused-launches: the pyramid and both maps of every level from one launch, same images
-            DepthPyramidVboNormals<MaxLevels>(kin_d, kin_v, kin_n, K);
-        } else {
-            BoxReduceIgnoreInvalid<float,MaxLevels,float>(kin_d);
-            for (int l = 0; l < MaxLevels; ++l) {
-                DepthToVbo<float>(kin_v[l], kin_d[l], K[l]);
-                NormalsFromVbo(kin_n[l], kin_v[l]);
-            }
-        }
+        if (prepared_frame != f) preamble(*pre);
+        (void)dKinectMeters;
         // main.cpp:223-242: `if (Pushed(reset) || !std::isfinite(f_rmse))` -- the first frame, and the frame after tracking was lost
         // altogether (no correspondence left: rmse = sqrt(0 / 0)): the world frame restarts at the current camera (T_wl = SE3d()), the
         // model is reset to "never observed" and the current frame is fused; the frame then goes on like any other (it is tracked
@@ -227,7 +245,14 @@ int main(int argc, char** argv)
                     float r = 0;
                     unsigned nobs = 0;
                     int good = 1;
-                    GpuCheckStatus(kfx_icp_refine(lv, MaxLevels, icp_c, max_rmse, dScratch.abi(), dDebug.abi(), T34, &r, &nobs, &good, 0));
+                    if (ahead && f + 1 < frames) {   // the next frame's pre-amble runs while this thread waits for the pose
+                        struct Hook { decltype(preamble)* fn; Preamble* q; } hook{&preamble, pre_next};
+                        GpuCheckStatus(kfx_icp_refine_then(lv, MaxLevels, icp_c, max_rmse, dScratch.abi(), dDebug.abi(), T34, &r, &nobs, &good,
+                                                           [](void* u) { Hook* k = static_cast<Hook*>(u); (*k->fn)(*k->q); }, &hook, 0));
+                        prepared_frame = f + 1;
+                    } else {
+                        GpuCheckStatus(kfx_icp_refine(lv, MaxLevels, icp_c, max_rmse, dScratch.abi(), dDebug.abi(), T34, &r, &nobs, &good, 0));
+                    }
                     for (int i = 0; i < 3; ++i) {
                         for (int j = 0; j < 3; ++j) T_lp.R[i][j] = T34[i * 4 + j];
                         T_lp.t[i] = T34[i * 4 + 3];

@@ -358,7 +358,7 @@ def tracked_leg(args, torch, roo, scenes, n_steps):
         nonlocal worst, lost
         for k in range(n):
             i = (first + k) % N_ORBIT
-            T = pipe.step(poses[i] if first + k == 0 else None, frames[i])
+            T = pipe.step(poses[i] if first + k == 0 else None, frames[i], next_image=frames[(i + 1) % N_ORBIT])
             worst = max(worst, float(np.linalg.norm(T[:3, 3] - poses[i][:3, 3])))
             lost += 0 if pipe.tracking_good else 1
     run(2 * N_ORBIT, 0)

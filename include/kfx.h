@@ -346,6 +346,13 @@ typedef struct kfx_icp_level {
 } kfx_icp_level;
 int kfx_icp_refine(const kfx_icp_level* levels, int n_levels, float c, float max_rmse, const kfx_image* workspace,
                    const kfx_image* debug, double T_lp[12], float* rmse, unsigned* obs, int* tracking_good, kfx_stream stream);
+/* kfx_icp_refine with a hook: `enqueue_more(user)` is called once, after the whole refinement and the read-back of its result
+ * have been enqueued and before the calling thread waits -- for the read-back only, not for the stream.  Work the hook
+ * enqueues on `stream` (the next frame's pre-amble: it does not depend on the pose) runs while the thread wakes up, so the
+ * device is not idle between the refinement and what the caller launches with the pose (SdfFuse).  Same results. */
+int kfx_icp_refine_then(const kfx_icp_level* levels, int n_levels, float c, float max_rmse, const kfx_image* workspace,
+                        const kfx_image* debug, double T_lp[12], float* rmse, unsigned* obs, int* tracking_good,
+                        void (*enqueue_more)(void* user), void* user, kfx_stream stream);
 
 /* ---- multi-GPU raycast composite (no reference counterpart) ------------------------
  * Per-pixel glue around the two collectives of kangaroo_amd/pipeline.py::SlabPipeline.composite:

@@ -822,8 +822,9 @@ extern "C" int kfx_icp_point_plane(const kfx_image* Pl, const kfx_image* Pr, con
 // the first level with more than one level in total is solved for rotation only, as the application does.
 // workspace: >= max over levels of (blocks * 116) + 512 bytes; result: T_lp (row-major 3x4, float64), rmse, obs,
 // tracking_good (rmse < max_rmse at the last evaluation).
-extern "C" int kfx_icp_refine(const kfx_icp_level* levels, int n_levels, float c, float max_rmse, const kfx_image* workspace,
-                              const kfx_image* debug, double T_lp[12], float* rmse, unsigned* obs, int* tracking_good, kfx_stream stream)
+static int icp_refine_impl(const kfx_icp_level* levels, int n_levels, float c, float max_rmse, const kfx_image* workspace,
+                           const kfx_image* debug, double T_lp[12], float* rmse, unsigned* obs, int* tracking_good, void (*enqueue_more)(void*),
+                           void* user, kfx_stream stream)
 {
     if (!levels || n_levels <= 0 || !workspace || !workspace->ptr || !T_lp) return set_error(KFX_E_NULL, "kfx_icp_refine: null argument");
     size_t max_blocks = 0;
@@ -907,6 +908,7 @@ extern "C" int kfx_icp_refine(const kfx_icp_level* levels, int n_levels, float c
             thread_local double* stage_p = nullptr;
             if (!stage_p && hipHostMalloc((void**)&stage_p, 15 * sizeof(double), hipHostMallocDefault) != hipSuccess) return set_error(KFX_E_RANGE, "kfx_icp_refine: pinned staging");
             hipError_t e = hipMemcpyAsync(stage_p, st, 15 * sizeof(double), hipMemcpyDeviceToHost, s);
+            if (e == hipSuccess && enqueue_more) enqueue_more(user);   // (the hook's contract: called once per successful enqueue)
             if (e == hipSuccess) e = hipStreamSynchronize(s);
             if (e != hipSuccess) return set_error((int)e, hipGetErrorString(e));
             if (stage_p[14] < 0.0) return set_error(KFX_E_RANGE, "kfx_icp_refine: the persistent grid never met at its barrier (not resident)");
@@ -975,11 +977,37 @@ extern "C" int kfx_icp_refine(const kfx_icp_level* levels, int n_levels, float c
     thread_local double* stage = nullptr;
     if (!stage && hipHostMalloc((void**)&stage, 15 * sizeof(double), hipHostMallocDefault) != hipSuccess) return set_error(KFX_E_RANGE, "kfx_icp_refine: pinned staging");
     hipError_t e = hipMemcpyAsync(stage, st, 15 * sizeof(double), hipMemcpyDeviceToHost, s);
-    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e == hipSuccess && enqueue_more) {
+        // the caller has work that does not depend on the pose (the next frame's pre-amble): enqueued behind the read-back, it
+        // runs while this thread wakes up from the wait -- which is for the read-back only, not for the stream
+        thread_local hipEvent_t arrived = nullptr;
+        if (!arrived) e = hipEventCreateWithFlags(&arrived, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventRecord(arrived, s);
+        if (e == hipSuccess) {
+            enqueue_more(user);
+            e = hipEventSynchronize(arrived);
+        }
+    } else if (e == hipSuccess) {
+        e = hipStreamSynchronize(s);
+    }
     if (e != hipSuccess) return set_error((int)e, hipGetErrorString(e));
     for (int i = 0; i < 12; ++i) T_lp[i] = stage[i];
     if (rmse) *rmse = (float)stage[12];
     if (obs) *obs = (unsigned)stage[13];
     if (tracking_good) *tracking_good = stage[14] != 0.0 ? 1 : 0;
     return 0;
+}
+
+extern "C" int kfx_icp_refine(const kfx_icp_level* levels, int n_levels, float c, float max_rmse, const kfx_image* workspace,
+                              const kfx_image* debug, double T_lp[12], float* rmse, unsigned* obs, int* tracking_good, kfx_stream stream)
+{
+    return icp_refine_impl(levels, n_levels, c, max_rmse, workspace, debug, T_lp, rmse, obs, tracking_good, nullptr, nullptr, stream);
+}
+
+// kfx_icp_refine with a hook between enqueueing the pose's read-back and waiting for it (include/kfx.h)
+extern "C" int kfx_icp_refine_then(const kfx_icp_level* levels, int n_levels, float c, float max_rmse, const kfx_image* workspace,
+                                   const kfx_image* debug, double T_lp[12], float* rmse, unsigned* obs, int* tracking_good,
+                                   void (*enqueue_more)(void* user), void* user, kfx_stream stream)
+{
+    return icp_refine_impl(levels, n_levels, c, max_rmse, workspace, debug, T_lp, rmse, obs, tracking_good, enqueue_more, user, stream);
 }

@@ -278,6 +278,10 @@ class TrackingPipeline(FramePipeline):
         L = self.LEVELS
         P = ops.Pyramid
         self.kin_d, self.kin_v, self.kin_n = P(w, h, L, "f32"), P(w, h, L, "f32x4"), P(w, h, L, "f32x4")
+        # a second set for the NEXT frame's pre-amble (step(..., next_image=...)): enqueued while the pose of this frame is on
+        # its way to the host, it must not overwrite the maps SdfFuse is about to read
+        self._kin_back = None
+        self._prefetched = None   # the image whose pre-amble the back set holds
         self.pyr_d, self.pyr_i = P(w, h, L, "f32"), P(w, h, L, "f32")
         self.pyr_n, self.pyr_v = P(w, h, L, "f32x4"), P(w, h, L, "f32x4")
         self.K_levels = [scenes.intrinsics_level(self.K, l) for l in range(L)]
@@ -289,25 +293,42 @@ class TrackingPipeline(FramePipeline):
         self.rmse, self.tracking_good = 0.0, True
         self.resets = 0   # recoveries after tracking was lost altogether (main.cpp:223-242)
 
-    def preprocess(self, raw_image=None):
+    def preprocess(self, raw_image=None, into=None):
         o = self.ops
         src = self.raw if raw_image is None else raw_image
-        o.BilateralFilter(self.kin_d[0], src, self.bil["gs"], self.bil["gr"], self.bil["size"], self.bil["minval"])
+        kin_d, kin_v, kin_n = (self.kin_d, self.kin_v, self.kin_n) if into is None else into
+        o.BilateralFilter(kin_d[0], src, self.bil["gs"], self.bil["gr"], self.bil["size"], self.bil["minval"])
         if hasattr(o, "DepthPyramidVboNormals"):   # the pyramid and its maps from one launch (same images)
-            o.DepthPyramidVboNormals(self.kin_d, self.kin_v, self.kin_n, self.K_levels)
+            o.DepthPyramidVboNormals(kin_d, kin_v, kin_n, self.K_levels)
             return
-        o.BoxReduceIgnoreInvalid(self.kin_d)
+        o.BoxReduceIgnoreInvalid(kin_d)
         for l in range(self.LEVELS):
-            vbo_normals(o, self.kin_v[l], self.kin_n[l], self.kin_d[l], self.K_levels[l])
+            vbo_normals(o, kin_v[l], kin_n[l], kin_d[l], self.K_levels[l])
 
-    def step(self, T_wl_init=None, raw_image=None):
+    def _prefetch(self, image):
+        """The pre-amble of `image` into the back set of maps (called between enqueueing the refinement and waiting for its pose)."""
+        if self._kin_back is None:
+            P, L = self.ops.Pyramid, self.LEVELS
+            self._kin_back = (P(self.w, self.h, L, "f32"), P(self.w, self.h, L, "f32x4"), P(self.w, self.h, L, "f32x4"))
+        self.preprocess(image, into=self._kin_back)
+        self._prefetched = image
+
+    def step(self, T_wl_init=None, raw_image=None, next_image=None):
         """One frame.  The first frame is fused at T_wl_init (identity if None); later frames are tracked
-        against the model.  Returns the current T_wl (4x4 float64)."""
+        against the model.  Returns the current T_wl (4x4 float64).
+        next_image: the depth image the NEXT step will be given (already in device memory).  With the device-resident
+        refinement its pre-amble -- which does not depend on any pose -- is enqueued behind the refinement, before this thread
+        waits for the pose: the device works on it while the thread wakes up instead of idling until SdfFuse arrives.  The
+        next step finds its maps ready when it is given the same image object; same images, same poses."""
         o, tr = self.ops, self.tracking
         cal = self._cal is not None and self.frames_done >= self._cal["first"]
         if cal:   # track="auto": whole frames of the three blocks, host clock around the step (the pose read-back synchronises)
             self._policy_before()
-        self.preprocess(raw_image)
+        if raw_image is not None and self._prefetched is raw_image:
+            (self.kin_d, self.kin_v, self.kin_n), self._kin_back = self._kin_back, (self.kin_d, self.kin_v, self.kin_n)
+        else:
+            self.preprocess(raw_image)
+        self._prefetched = None
         # main.cpp:223-242, `if (Pushed(reset) || !std::isfinite(f_rmse))`: when the last refinement found no correspondence at all
         # (rmse = sqrt(0 / 0): a frame without depth, a model out of view) the application starts over -- T_wl = identity (the world
         # frame restarts at the current camera; T_wl_init if the caller gives one), the volume back to "never observed", the current
@@ -337,8 +358,9 @@ class TrackingPipeline(FramePipeline):
                         o.DepthToVbo(self.pyr_v[l], self.pyr_d[l], self.K_levels[l])
             self._timed_raycast(render)
             if self.device_icp:
+                hook = (lambda: self._prefetch(next_image)) if next_image is not None else None
                 T_lp, self.rmse, _, self.tracking_good = o.IcpRefine(self.kin_v, self.pyr_v, self.pyr_n, self.K_levels, self.its,
-                                                                     self.icp_c, self.max_rmse, self.scratch, self.debug)
+                                                                     self.icp_c, self.max_rmse, self.scratch, self.debug, before_wait=hook)
             else:
                 T_lp, self.rmse, self.tracking_good = tr.refine_pose(o, self.kin_v, self.pyr_v, self.pyr_n, self.K_levels,
                                                                      self.scratch, self.debug, self.its, self.icp_c, self.max_rmse)

@@ -741,10 +741,12 @@ def DepthPyramidVboNormals(depth, vbo, nrm, K_levels, scale=1.0, stream=None):
             DepthToVboNormals(vbo[l], nrm[l], depth[l], K_levels[l], scale, stream)
 
 
-def IcpRefine(kin_v, ray_v, ray_n, K_levels, its, icp_c, max_rmse, dWorkspace, dDebug=None, stream=None):
+def IcpRefine(kin_v, ray_v, ray_n, K_levels, its, icp_c, max_rmse, dWorkspace, dDebug=None, stream=None, before_wait=None):
     """kfx_icp_refine: the coarse-to-fine loop of main.cpp:301-337 enqueued as one kernel chain with the 6x6 solves on
     the device.  Per-level lists are indexed by pyramid level (0 = full resolution), as in the application; levels are
-    processed from the coarsest down, the coarsest one rotation-only.  Returns (T_lp 4x4 float64, rmse, obs, good)."""
+    processed from the coarsest down, the coarsest one rotation-only.  Returns (T_lp 4x4 float64, rmse, obs, good).
+    before_wait: a callable run once everything is enqueued and before the pose is waited for (kfx_icp_refine_then): what it
+    enqueues -- the next frame's pre-amble -- keeps the device busy while this thread wakes up."""
     n = len(K_levels)
     order = list(range(n - 1, -1, -1))
     arr = (_lib.KfxIcpLevel * n)()
@@ -756,8 +758,23 @@ def IcpRefine(kin_v, ray_v, ray_n, K_levels, its, icp_c, max_rmse, dWorkspace, d
         arr[slot].rotation_only = 1 if (l == n - 1 and n > 1) else 0
     T = (C.c_double * 12)()
     rmse, obs, good = C.c_float(), C.c_uint(), C.c_int()
-    _lib.check(_lib.load().kfx_icp_refine(arr, n, icp_c, max_rmse, dWorkspace.ref(), dDebug.ref() if dDebug is not None else None, T,
-                                          C.byref(rmse), C.byref(obs), C.byref(good), _stream(stream)))
+    if before_wait is not None:
+        raised = []
+
+        def hook(_user):   # (a Python exception must not unwind through C: it is re-raised after the call)
+            try:
+                before_wait()
+            except BaseException as e:   # noqa: BLE001
+                raised.append(e)
+        cb = C.CFUNCTYPE(None, C.c_void_p)(hook)
+        st = _lib.load().kfx_icp_refine_then(arr, n, icp_c, max_rmse, dWorkspace.ref(), dDebug.ref() if dDebug is not None else None, T,
+                                             C.byref(rmse), C.byref(obs), C.byref(good), cb, None, _stream(stream))
+        if raised:
+            raise raised[0]
+        _lib.check(st)
+    else:
+        _lib.check(_lib.load().kfx_icp_refine(arr, n, icp_c, max_rmse, dWorkspace.ref(), dDebug.ref() if dDebug is not None else None, T,
+                                              C.byref(rmse), C.byref(obs), C.byref(good), _stream(stream)))
     T4 = np.eye(4)
     T4[:3, :] = np.array(list(T), np.float64).reshape(3, 4)
     return T4, float(rmse.value), int(obs.value), bool(good.value)

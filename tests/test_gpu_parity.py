@@ -938,6 +938,33 @@ def test_gpu_tracking_pipeline_follows_the_orbit(roo):
     assert worst < 0.2 * drift_if_static, (worst, drift_if_static)
 
 
+def test_gpu_tracking_pipeline_next_frame_preamble_under_the_pose_wait(roo):
+    """TrackingPipeline.step(..., next_image=...): the next frame's pre-amble enqueued between the device-resident refinement and
+    the wait for its pose (kfx_icp_refine_then) into a second set of maps -- poses, rmse and the model are those of the loop that
+    runs every pre-amble at the start of its own frame, bit for bit (a frame without depth in between: the recovery path too)."""
+    from kangaroo_amd.pipeline import TrackingPipeline
+    N, w, h, n = 96, 320, 240, 9
+    bmin, bmax, near, far = scenes.SCENES["room"]
+    K = scenes.intrinsics(w, h)
+    imgs = []
+    for i in range(n):
+        d = scenes.render_depth("room", w, h, scenes.orbit_pose(i, 30), K)
+        if i == 5:
+            d = np.full_like(d, np.nan)   # tracking lost altogether: reset + re-fuse at the next frame
+        imgs.append(T.upload_image(roo, d))
+    res = []
+    for prefetch in (False, True):
+        pipe = TrackingPipeline(roo, (N, N, N), bmin, bmax, w, h, K=K, near=near, far=far, device_icp=True, track=False)
+        out = []
+        for i in range(n):
+            T_est = pipe.step(scenes.orbit_pose(0, 30) if i == 0 else None, imgs[i], next_image=imgs[i + 1] if prefetch and i + 1 < n else None)
+            out.append((np.asarray(T_est, np.float64).tobytes(), float(pipe.rmse) if np.isfinite(pipe.rmse) else None, bool(pipe.tracking_good)))
+        res.append((out, pipe.vol.MemcpyToHost().tobytes(), pipe.resets))
+    assert res[0][2] == res[1][2] == 1
+    assert res[0][0] == res[1][0]
+    assert res[0][1] == res[1][1]
+
+
 @pytest.mark.parametrize("device_icp", [False, True])
 def test_gpu_tracking_pipeline_recovers_after_a_frame_without_depth(roo, device_icp):
     """The application's recovery path (main.cpp:223-242) on the GPU, host solve loop and device-resident ICP loop: one all-NaN
