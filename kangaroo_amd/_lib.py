@@ -113,7 +113,7 @@ SIGNATURES = {
     "kfx_icp_refine": (C.c_int, [C.POINTER(KfxIcpLevel), C.c_int, C.c_float, C.c_float, PI, PI, C.POINTER(C.c_double), PF,
                                  C.POINTER(C.c_uint), C.POINTER(C.c_int), C.c_void_p]),
     "kfx_icp_refine_then": (C.c_int, [C.POINTER(KfxIcpLevel), C.c_int, C.c_float, C.c_float, PI, PI, C.POINTER(C.c_double), PF,
-                                      C.POINTER(C.c_uint), C.POINTER(C.c_int), C.CFUNCTYPE(None, C.c_void_p), C.c_void_p, C.c_void_p]),
+                                      C.POINTER(C.c_uint), C.POINTER(C.c_int), C.c_void_p, C.c_void_p, C.c_void_p]),   # (the hook: a CFUNCTYPE(None, c_void_p) cast to void*)
     "kfx_icp_point_plane": (C.c_int, [PI, PI, PI, PF, PF, C.c_float, PI, PI, C.POINTER(KfxLss6), C.c_void_p]),
     "kfx_composite_pack": (C.c_int, [PI, PI, PI, C.c_void_p, C.c_int, C.c_void_p]),
     "kfx_composite_select": (C.c_int, [PI, PI, PI, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),

@@ -768,7 +768,7 @@ def IcpRefine(kin_v, ray_v, ray_n, K_levels, its, icp_c, max_rmse, dWorkspace, d
                 raised.append(e)
         cb = C.CFUNCTYPE(None, C.c_void_p)(hook)
         st = _lib.load().kfx_icp_refine_then(arr, n, icp_c, max_rmse, dWorkspace.ref(), dDebug.ref() if dDebug is not None else None, T,
-                                             C.byref(rmse), C.byref(obs), C.byref(good), cb, None, _stream(stream))
+                                             C.byref(rmse), C.byref(obs), C.byref(good), C.cast(cb, C.c_void_p), None, _stream(stream))
         if raised:
             raise raised[0]
         _lib.check(st)
