@@ -266,7 +266,9 @@ __device__ void se3_right_multiply_exp(double T[12], const double x[6], bool rot
     for (int i = 0; i < 3; ++i)
         for (int j = 0; j < 3; ++j) W2[i][j] = W[i][0] * W[0][j] + W[i][1] * W[1][j] + W[i][2] * W[2][j];
     const bool small = t < 1e-10;
-    const double a = small ? 1.0 : sin(t) / t, b = small ? 0.5 : (1.0 - cos(t)) / t2, c = small ? 1.0 / 6.0 : (t - sin(t)) / (t2 * t);
+    double st, ct;
+    sincos(t, &st, &ct);   // (one argument reduction for both: the values of sin(t) and cos(t))
+    const double a = small ? 1.0 : st / t, b = small ? 0.5 : (1.0 - ct) / t2, c = small ? 1.0 / 6.0 : (t - st) / (t2 * t);
     double E[12];
     for (int i = 0; i < 3; ++i) {
         double p = 0.0;
