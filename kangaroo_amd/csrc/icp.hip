@@ -358,7 +358,7 @@ __device__ void icp_solve_step(RefineState* st, const float* sums, const int rot
 // of lane gathers, an elimination step is one division and one multiply-subtract in every lane, the substitutions read rows
 // and columns through v_readlane.  Every element sees
 // the operations of lu_solve_full_piv in the same order with the same operands, so the solution is the serial one bit for bit
-// (the persistent and the ticketed launches keep the one-lane solve: test_gpu_persistent_icp_kernel_equals_the_chain_of_launches
+// (the persistent launch keeps the one-lane solve: test_gpu_persistent_icp_kernel_equals_the_chain_of_launches
 // compares the two).  All 64 lanes of the wave must be active.
 // ---------------------------------------------------------------------------------------
 __device__ __forceinline__ double shfl_f64(double v, int src) { return __shfl(v, src, 64); }
@@ -674,91 +674,6 @@ __global__ __launch_bounds__(256) void k_icp_refine_persistent(const IcpPersiste
     }
 }
 
-// ---------------------------------------------------------------------------------------
-// k_icp_point_plane and k_lss_final_solve as ONE launch per iteration (round 5): every block leaves its system for the others to
-// see (device-scope stores), takes a ticket, and the block that draws the last one -- every other block has finished -- adds up
-// the systems and takes the step.  No block waits for another; the chain of the device-resident loop shrinks from thirteen launches
-// to seven.  The sum over the blocks keeps k_lss_final's order and tree whatever the block's own size: 256 VIRTUAL threads -- virtual
-// thread t adds blocks t, t + 256, ... in turn, then s[t] += s[t + S] for S = 128 ... 1 -- evaluated by the block's 64 - 256
-// real threads in LDS, so the summed system and the pose are the chain's bit for bit.
-// ---------------------------------------------------------------------------------------
-struct IcpFused {
-    IcpParams p;
-    int nblocks;
-    unsigned* ticket;
-    RefineState* st;
-    int rotation_only;
-    float max_rmse;
-    K4 K_next;
-    int mode;
-};
-
-__global__ __launch_bounds__(256) void k_icp_point_plane_solve(const IcpFused q)
-{
-    extern __shared__ float lds[];   // LSS_WORDS * 256 floats
-    __shared__ int s_last;
-    __shared__ float s_sum[LSS_WORDS];
-    __shared__ SolveLds s_solve;
-    const IcpParams& p = q.p;
-    const int n = blockDim.x * blockDim.y;
-    const int tid = threadIdx.y * blockDim.x + threadIdx.x;
-    const unsigned u = blockIdx.x * blockDim.x + threadIdx.x;
-    const unsigned v = blockIdx.y * blockDim.y + threadIdx.y;
-    Lss sum;
-    lss_zero(sum);
-    Pose KT_lr, T_rl;
-#pragma unroll
-    for (int i = 0; i < 12; ++i) { KT_lr.m[i] = p.dev_pose[i]; T_rl.m[i] = p.dev_pose[12 + i]; }   // (rewritten by the LAST block, after every block has read it)
-    float4 dbg;
-    icp_pixel(sum, dbg, p.Pl, p.Pr, p.Nr, KT_lr, T_rl, p.c, u, v);
-    if (p.dbg) reinterpret_cast<float4*>(p.dbg + (size_t)v * p.dbg_pitch)[u] = dbg;
-    lss_tree(sum, tid, n, lds);
-    if (tid == 0) {
-        lss_store_agent(p.sums + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * LSS_WORDS, sum);
-        __builtin_amdgcn_s_waitcnt(0);   // the system has reached the coherence point before the ticket is drawn
-        const unsigned mine = __hip_atomic_fetch_add(q.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_last = mine == (unsigned)(q.nblocks - 1) ? 1 : 0;
-    }
-    __syncthreads();
-    if (!s_last) return;
-    if (q.mode == 2) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // (2: this XCD's L2 invalidated once, then plain loads; 1: device-scope loads)
-    // ---- the last block: k_lss_final's sum with 256 virtual threads (word k of virtual thread t at lds[k * 256 + t]) ----
-    for (int vt = tid; vt < 256; vt += n) {
-        Lss acc;
-        lss_zero(acc);
-        for (int b = vt; b < q.nblocks; b += 256) {
-            const float* sp = p.sums + (size_t)b * LSS_WORDS;
-            if (q.mode == 2) {
-#pragma unroll
-                for (int k = 0; k < 28; ++k) acc.f[k] += sp[k];
-                acc.obs += __float_as_uint(sp[28]);
-                continue;
-            }
-#pragma unroll
-            for (int k = 0; k < 28; ++k) acc.f[k] += __hip_atomic_load(sp + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            acc.obs += __float_as_uint(__hip_atomic_load(sp + 28, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-        }
-#pragma unroll
-        for (int k = 0; k < 28; ++k) lds[k * 256 + vt] = acc.f[k];
-        lds[28 * 256 + vt] = __uint_as_float(acc.obs);
-    }
-    __syncthreads();
-    for (int S = 128; S > 0; S >>= 1) {
-        for (int t = tid; t < S; t += n) {
-#pragma unroll
-            for (int k = 0; k < 28; ++k) lds[k * 256 + t] += lds[k * 256 + t + S];
-            lds[28 * 256 + t] = __uint_as_float(__float_as_uint(lds[28 * 256 + t]) + __float_as_uint(lds[28 * 256 + t + S]));
-        }
-        __syncthreads();
-    }
-    if (tid == 0) {
-#pragma unroll
-        for (int k = 0; k < LSS_WORDS; ++k) { s_sum[k] = lds[k * 256]; p.sums[k] = s_sum[k]; }   // (sums[0..28] is what k_lss_final leaves)
-        icp_solve_step(q.st, s_sum, q.rotation_only, q.max_rmse, q.K_next.k, s_solve);
-        __hip_atomic_store(q.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-armed for the next launch of the chain
-    }
-}
-
 static unsigned gcd_u(unsigned a, unsigned b) { return b == 0 ? a : gcd_u(b, a % b); }
 
 } // namespace kfx
@@ -928,18 +843,6 @@ static int icp_refine_impl(const kfx_icp_level* levels, int n_levels, float c, f
     K4 k0;
     for (int i = 0; i < 4; ++i) k0.k[i] = first >= 0 ? levels[first].K[i] : 0.f;
     hipLaunchKernelGGL(k_icp_refine_init, dim3(1), dim3(1), 0, s, st, k0);
-    // KFX_ICP_FUSED=1|2: one launch per iteration (k_icp_point_plane_solve: the last block to finish adds up and solves) where the
-    // workspace has room for the ticket word.  Same bits, seven launches instead of thirteen -- and SLOWER on MI355X (0.705 - 0.72 ms
-    // per tracked frame against 0.665: 1200 device-scope tickets and block systems pushed past the L2s cost more than the small
-    // launch they save, EXPERIMENTS.md 7.3), so the pair of launches stays the default.
-    static const int fused_env = [] { const char* e = getenv("KFX_ICP_FUSED"); const int v = e ? atoi(e) : 0; return v == 1 || v == 2 ? v : 0; }();
-    const size_t ticket_off = (state_off + sizeof(RefineState) + 255) / 256 * 256;
-    const bool fused = fused_env != 0 && ticket_off + 256 <= workspace->pitch * workspace->h;
-    unsigned* ticket = (unsigned*)((unsigned char*)workspace->ptr + ticket_off);
-    if (fused) {
-        const hipError_t he = hipMemsetAsync(ticket, 0, 64, s);
-        if (he != hipSuccess) { (void)hipGetLastError(); return set_error((int)he, "kfx_icp_refine: hipMemsetAsync"); }
-    }
     for (int l = 0; l < n_levels; ++l) {
         const kfx_icp_level& L = levels[l];
         if (L.iterations <= 0 || L.Pl.w == 0 || L.Pl.h == 0) continue;
@@ -965,11 +868,6 @@ static int icp_refine_impl(const kfx_icp_level* levels, int n_levels, float c, f
             K4 kn;
             const float* Kn = (it + 1 < L.iterations || nxt < 0) ? L.K : levels[nxt].K;
             for (int i = 0; i < 4; ++i) kn.k[i] = Kn[i];
-            if (fused) {
-                const IcpFused q{p, nblocks, ticket, st, L.rotation_only ? 1 : 0, max_rmse, kn, fused_env};
-                hipLaunchKernelGGL(k_icp_point_plane_solve, grid, block, (size_t)LSS_WORDS * 256 * sizeof(float), s, q);
-                continue;
-            }
             hipLaunchKernelGGL(k_icp_point_plane, grid, block, lds_bytes, s, p);
             hipLaunchKernelGGL(k_lss_final_solve, dim3(1), dim3(256), 0, s, sums, nblocks, st, L.rotation_only ? 1 : 0, max_rmse, kn);
         }
