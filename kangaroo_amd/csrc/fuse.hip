@@ -432,8 +432,10 @@ __global__ __launch_bounds__(256) void k_sdf_fuse(const FuseParams p)
 // fits 77 without scratch).  scripts/check_fuse_codegen.py checks both.
 // DXT (bit-exact kernels): a texel is staged as {texel, difference to its right neighbour} -- 32 bytes, so `cap_px` texels take
 // twice the LDS; chosen by the host for ranges whose rectangles fit half the tile (finish_shared_dx).
-template <bool FAST, int ZU, typename CELL, int LX = 32, int WY = 4, int ZC = FUSE_ZC, bool TRACK = false, bool DXT = false>
-__global__ __launch_bounds__(256, (FAST && ZU == 2) ? 8 : (!FAST ? 6 : 1)) void k_sdf_fuse_tiled(const FuseParams p_arg, const int cap_px)
+// NW: waves per workgroup (4; 8 for the narrow brick at large tiles -- twice the waves behind one staged rectangle where LDS,
+// not registers, limits how many workgroups a CU holds: k_sdf_fuse_tiled<true, 2, CELL, 16, 2, 16, false, false, 8>).
+template <bool FAST, int ZU, typename CELL, int LX = 32, int WY = 4, int ZC = FUSE_ZC, bool TRACK = false, bool DXT = false, int NW = 4>
+__global__ __launch_bounds__(64 * NW, (FAST && ZU == 2) ? 8 : (!FAST ? 6 : 1)) void k_sdf_fuse_tiled(const FuseParams p_arg, const int cap_px)
 {
     static_assert(!DXT || (!FAST && !TRACK), "the difference tile belongs to the bit-exact, untracked kernels");
     // the uniforms of the per-voxel arithmetic live in vector registers (in_vgpr, kfx_device.h): an SGPR operand makes a
@@ -447,16 +449,17 @@ __global__ __launch_bounds__(256, (FAST && ZU == 2) ? 8 : (!FAST ? 6 : 1)) void 
         if constexpr (!FAST) { p.T.m[3] = in_vgpr(p.T.m[3]); p.T.m[7] = in_vgpr(p.T.m[7]); p.T.m[11] = in_vgpr(p.T.m[11]); }
         p.K.fu = in_vgpr(p.K.fu); p.K.fv = in_vgpr(p.K.fv); p.K.u0 = in_vgpr(p.K.u0); p.K.v0 = in_vgpr(p.K.v0);
     }
-    constexpr int RW = 64 / LX, WZ = 4 / WY, ZW = ZC / WZ, BY = RW * WY;
-    static_assert(LX * RW == 64 && WY * WZ == 4 && ZW * WZ == ZC && ZW % ZU == 0, "brick geometry");
+    constexpr int NT = 64 * NW, RW = 64 / LX, WZ = NW / WY, ZW = ZC / WZ, BY = RW * WY;
+    static_assert(LX * RW == 64 && WY * WZ == NW && ZW * WZ == ZC && ZW % ZU == 0, "brick geometry");
+    static_assert(NW == 4 || (NW == 8 && !TRACK), "the summary epilogue is written for four waves");
     constexpr int NG = ZW / 8, NXB = LX / 4, NZB = ZC / 8; // summary bricks: z-groups per wave, per workgroup along x and z
     static_assert(!TRACK || (BY == 8 && ZW % 8 == 0 && NG <= 2 && 8 % ZU == 0), "summary bricks are 8 x 8 x 8");
     __shared__ float s_part[TRACK ? 4 * 2 * 8 * 3 : 1];
     extern __shared__ __attribute__((aligned(16))) float4 s_tile[];
     __shared__ float s_pz[ZC];
-    __shared__ float s_box[4][6];
-    __shared__ float s_dmax[4], s_cmin[4];
-    __shared__ int s_bad[4];
+    __shared__ float s_box[NW][6];
+    __shared__ float s_dmax[NW], s_cmin[NW];
+    __shared__ int s_bad[NW];
     __shared__ float4 s_tz[ZC]; // exact mode: {pz, T(0,2)*pz, T(1,2)*pz, T(2,2)*pz} per slice
     // (the wave index through readfirstlane: the compiler cannot tell that tid >> 6 is wave-uniform, and without it the slice
     // loop's bounds, the loop branch and everything derived from them are computed per lane)
@@ -524,13 +527,29 @@ __global__ __launch_bounds__(256, (FAST && ZU == 2) ? 8 : (!FAST ? 6 : 1)) void 
         s_bad[wv] = wave_bad ? 1 : 0;
     }
     __syncthreads();
-    zmin = fminf(fminf(s_box[0][4], s_box[1][4]), fminf(s_box[2][4], s_box[3][4]));
-    cmax = fmaxf(fmaxf(s_box[0][5], s_box[1][5]), fmaxf(s_box[2][5], s_box[3][5]));
-    umin = fminf(fminf(s_box[0][0], s_box[1][0]), fminf(s_box[2][0], s_box[3][0]));
-    umax = fmaxf(fmaxf(s_box[0][1], s_box[1][1]), fmaxf(s_box[2][1], s_box[3][1]));
-    vmin = fminf(fminf(s_box[0][2], s_box[1][2]), fminf(s_box[2][2], s_box[3][2]));
-    vmax = fmaxf(fmaxf(s_box[0][3], s_box[1][3]), fmaxf(s_box[2][3], s_box[3][3]));
-    const bool any_bad = (s_bad[0] | s_bad[1] | s_bad[2] | s_bad[3]) != 0;
+    // (the four-wave form is kept as written: the bit-exact instantiations' register allocation is sensitive to it, see
+    //  scripts/check_fuse_codegen.py; minima and maxima: the order does not matter)
+    bool any_bad;
+    if constexpr (NW == 4) {
+        zmin = fminf(fminf(s_box[0][4], s_box[1][4]), fminf(s_box[2][4], s_box[3][4]));
+        cmax = fmaxf(fmaxf(s_box[0][5], s_box[1][5]), fmaxf(s_box[2][5], s_box[3][5]));
+        umin = fminf(fminf(s_box[0][0], s_box[1][0]), fminf(s_box[2][0], s_box[3][0]));
+        umax = fmaxf(fmaxf(s_box[0][1], s_box[1][1]), fmaxf(s_box[2][1], s_box[3][1]));
+        vmin = fminf(fminf(s_box[0][2], s_box[1][2]), fminf(s_box[2][2], s_box[3][2]));
+        vmax = fmaxf(fmaxf(s_box[0][3], s_box[1][3]), fmaxf(s_box[2][3], s_box[3][3]));
+        any_bad = (s_bad[0] | s_bad[1] | s_bad[2] | s_bad[3]) != 0;
+    } else {
+        zmin = s_box[0][4]; cmax = s_box[0][5]; umin = s_box[0][0]; umax = s_box[0][1]; vmin = s_box[0][2]; vmax = s_box[0][3];
+        int bad_waves = s_bad[0];
+#pragma unroll
+        for (int k = 1; k < NW; ++k) {
+            zmin = fminf(zmin, s_box[k][4]); cmax = fmaxf(cmax, s_box[k][5]);
+            umin = fminf(umin, s_box[k][0]); umax = fmaxf(umax, s_box[k][1]);
+            vmin = fminf(vmin, s_box[k][2]); vmax = fmaxf(vmax, s_box[k][3]);
+            bad_waves |= s_bad[k];
+        }
+        any_bad = bad_waves != 0;
+    }
 
     bool use_tile = false;
     int tx0 = 0, ty0 = 0, tw = 0, th = 0;
@@ -569,12 +588,12 @@ __global__ __launch_bounds__(256, (FAST && ZU == 2) ? 8 : (!FAST ? 6 : 1)) void 
             const int ntex = tw * th;
             const float inv_tw = 1.0f / (float)tw;
             constexpr int SU = 4;
-            for (int t0 = tid; t0 < ntex; t0 += 256 * SU) {
+            for (int t0 = tid; t0 < ntex; t0 += NT * SU) {
                 float4 n[SU];
                 float d[SU];
 #pragma unroll
                 for (int k = 0; k < SU; ++k) {
-                    const int t = t0 + k * 256;
+                    const int t = t0 + k * NT;
                     n[k] = make_float4(0.f, 0.f, 0.f, 0.f);
                     d[k] = -__builtin_inff();
                     if (t < ntex) {
@@ -587,7 +606,7 @@ __global__ __launch_bounds__(256, (FAST && ZU == 2) ? 8 : (!FAST ? 6 : 1)) void 
                 }
 #pragma unroll
                 for (int k = 0; k < SU; ++k) {
-                    const int t = t0 + k * 256;
+                    const int t = t0 + k * NT;
                     if (t < ntex) {
                         s_tile[t] = make_float4(n[k].x, n[k].y, n[k].z, d[k]);
                         dmax = fmaxf(dmax, d[k]);
@@ -597,7 +616,7 @@ __global__ __launch_bounds__(256, (FAST && ZU == 2) ? 8 : (!FAST ? 6 : 1)) void 
         } else {
             // exact numerics: bound by instruction issue, the staging waits are covered by the other workgroups of the CU
             // (and with the flat loop in this instantiation hipcc schedules the voxel loop 11 % slower: 0.438 -> 0.486 ms)
-            for (int r = wv; r < th; r += 4) {
+            for (int r = wv; r < th; r += NW) {
                 const float* drow = row<float>(p.depth, (size_t)(ty0 + r)) + tx0;
                 const float4* nrow = row<float4>(p.norm, (size_t)(ty0 + r)) + tx0;
                 for (int c = lane; c < tw; c += 64) {
@@ -619,7 +638,13 @@ __global__ __launch_bounds__(256, (FAST && ZU == 2) ? 8 : (!FAST ? 6 : 1)) void 
     // that bound (with a relative margin far above the rounding of the per-voxel expression), no voxel
     // of the brick can change: skip it before any volume traffic or per-voxel arithmetic.
     if (use_tile && p.mincos > 0.f && p.trunc > 0.f) {
-        dmax = fmaxf(fmaxf(s_dmax[0], s_dmax[1]), fmaxf(s_dmax[2], s_dmax[3]));
+        if constexpr (NW == 4) {
+            dmax = fmaxf(fmaxf(s_dmax[0], s_dmax[1]), fmaxf(s_dmax[2], s_dmax[3]));
+        } else {
+            dmax = s_dmax[0];
+#pragma unroll
+            for (int k = 1; k < NW; ++k) dmax = fmaxf(dmax, s_dmax[k]);
+        }
         const float bound = -(p.trunc / p.mincos) * 1.001f;
         const float dfar = dmax + fabsf(dmax) * 1e-5f;
         if (dfar - zmin < bound) return; // also when every texel is NaN (dmax = -inf)
@@ -641,7 +666,7 @@ __global__ __launch_bounds__(256, (FAST && ZU == 2) ? 8 : (!FAST ? 6 : 1)) void 
                 const float inv_tw = 1.0f / (float)tw;
                 const float ifu = __builtin_amdgcn_rcpf(p.K.fu), ifv = __builtin_amdgcn_rcpf(p.K.fv);
                 const float slack = 3.0f * fmaxf(fabsf(ifu), fabsf(ifv));   // |change of a unit direction| over one pixel, with room
-                for (int t = tid; t < ntex; t += 256) {
+                for (int t = tid; t < ntex; t += NT) {
                     const float4 q = s_tile[t];
                     const int r = (int)(((float)t + 0.5f) * inv_tw);
                     const int cc = t - r * tw;
@@ -655,7 +680,13 @@ __global__ __launch_bounds__(256, (FAST && ZU == 2) ? 8 : (!FAST ? 6 : 1)) void 
                 for (int off = 32; off > 0; off >>= 1) c = fminf(c, __shfl_xor(c, off, 64));
                 if (lane == 0) s_cmin[wv] = c;
                 __syncthreads();
-                c = fminf(fminf(s_cmin[0], s_cmin[1]), fminf(s_cmin[2], s_cmin[3]));
+                if constexpr (NW == 4) {
+                    c = fminf(fminf(s_cmin[0], s_cmin[1]), fminf(s_cmin[2], s_cmin[3]));
+                } else {
+                    c = s_cmin[0];
+#pragma unroll
+                    for (int k = 1; k < NW; ++k) c = fminf(c, s_cmin[k]);
+                }
                 if ((zmin - dfar) * fmaxf(p.mincos, c) >= band) return;   // (c = +inf: no finite texel at all -- the test above has returned)
             }
         }
@@ -663,7 +694,7 @@ __global__ __launch_bounds__(256, (FAST && ZU == 2) ? 8 : (!FAST ? 6 : 1)) void 
     if constexpr (DXT) {   // (workgroup-uniform control flow up to here: every thread reaches the barrier)
         if (use_tile) {
             const int ntex = tw * th;
-            for (int t = tid; t < ntex; t += 256) {
+            for (int t = tid; t < ntex; t += NT) {
                 const float4 a = s_tile[2 * t], b = s_tile[2 * min(t + 1, ntex - 1)]; // (the last column's difference is never read)
                 s_tile[2 * t + 1] = make_float4(b.x - a.x, b.y - a.y, b.z - a.z, b.w - a.w);
             }
@@ -1738,6 +1769,15 @@ static int fuse_launch(const kfx_volume* vol, const kfx_image* depth, const kfx_
             if (plan.small_brick) {
                 dim3 grid(ceil_div(q.X, 32), ceil_div(q.Y, 8), ceil_div(q.Z, 16));
                 const int zu = zu_env ? zu_env : (fast ? (cap_px > 2560 ? 4 : 2) : 1);
+                // Tiles above 2048 texels (32 KiB: at most four workgroups on a CU) get eight waves per workgroup instead of four --
+                // twice the waves behind one staged rectangle; C3 / S_room 0.4182 -> 0.4237 of peak, interleaved A/B; below that
+                // size the shorter waves' prologues cost more than the residency buys (-1 %).  KFX_FUSE_NW8=<texels> moves the
+                // threshold (0: never).  Same bits.
+                static const int nw8_from = [] { const char* e = getenv("KFX_FUSE_NW8"); return e ? atoi(e) : 2048; }();
+                if (fast && nw8_from > 0 && cap_px > nw8_from) {
+                    hipLaunchKernelGGL((k_sdf_fuse_tiled<true, 2, CELL, 16, 2, 16, false, false, 8>), grid, dim3(512), lds, s, q, cap_px);
+                    continue;
+                }
                 if (fast && zu == 4) hipLaunchKernelGGL((k_sdf_fuse_tiled<true, 4, CELL, 16, 2, 16>), grid, dim3(256), lds, s, q, cap_px);
                 else if (fast && zu == 2) hipLaunchKernelGGL((k_sdf_fuse_tiled<true, 2, CELL, 16, 2, 16>), grid, dim3(256), lds, s, q, cap_px);
                 else if (fast) hipLaunchKernelGGL((k_sdf_fuse_tiled<true, 1, CELL, 16, 2, 16>), grid, dim3(256), lds, s, q, cap_px);

@@ -70,8 +70,8 @@ def register_budget(asm_path):
     out, cur = [], None
     vg = None
     for line in open(asm_path):
-        # template arguments: <FAST, ZU, CELL, LX, WY, ZC, TRACK, DXT>: fast two-slice kernels, and bit-exact ones with TRACK = false
-        m = re.match(r"^(_ZN3kfx16k_sdf_fuse_tiledIL(?:b1ELi2\w+|b0ELi\d\w+Lb0ELb[01]EEEv\w+)):", line)
+        # template arguments: <FAST, ZU, CELL, LX, WY, ZC, TRACK, DXT, NW>: fast two-slice kernels, and bit-exact ones with TRACK = false
+        m = re.match(r"^(_ZN3kfx16k_sdf_fuse_tiledIL(?:b1ELi2\w+|b0ELi\d\w+Lb0ELb[01]ELi\d+EEEv\w+)):", line)
         if m:
             cur, vg = m.group(1), None
         elif cur and line.startswith("; NumVgprs:"):
