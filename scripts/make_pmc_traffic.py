@@ -28,7 +28,8 @@ def sections(path):
     return out
 
 
-FUSE = {"fast": "k_sdf_fuse_tiled<true, 2, CellF32, 32, 4, 16, false, false>", "fast_tracked": "k_sdf_fuse_tiled<true, 2, CellF32, 32, 4, 16, true, false>"}
+# (name prefixes: the summaries cut kernel names at 60 characters, and later template arguments -- waves per workgroup -- follow)
+FUSE = {"fast": "k_sdf_fuse_tiled<true, 2, CellF32, 32, 4, 16, false, false", "fast_tracked": "k_sdf_fuse_tiled<true, 2, CellF32, 32, 4, 16, true, false"}
 RAY = {"fast": "k_raycast_sdf<RayF32, false>", "fast_tracked": "k_raycast_sdf_classes<RayF32>"}
 
 
@@ -44,7 +45,10 @@ def main():
          "_commit": "the kernels whose source digests are recorded below (_kernel_source_id), as of profiles/r05_full and profiles/r05_room"}
 
     def entry(sec, name, launches=1):
-        f, w = sec["FETCH_SIZE"].get(name), sec["WRITE_SIZE"].get(name)
+        def find(table):
+            hits = [v for k, v in table.items() if k.startswith(name)]
+            return hits[0] if len(hits) == 1 else None
+        f, w = find(sec["FETCH_SIZE"]), find(sec["WRITE_SIZE"])
         if not f or not w:
             return None
         fk, wk = f[1] * launches, w[1] * launches

@@ -11,7 +11,7 @@ out = sys.argv[1]
 
 
 def short(name):
-    return name.split("(")[0].replace("void ", "").replace("kfx::", "")[:60]
+    return name.split("(")[0].replace("void ", "").replace("kfx::", "")[:72]
 
 
 def kernel_stats(d):
