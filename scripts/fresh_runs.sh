@@ -2,7 +2,8 @@
 # fresh_runs.sh TAG [N] [IDLE_S] [extra bench.py args...] -- the driver's command, N times, each as a fresh process after
 # IDLE_S seconds of GPU idle (round-3 verdict item 1: the headline has to hold on a cold box).  Keeps every JSON line and the
 # per-step dumps (KFX_BENCH_DUMP=1) under gpurun_out/TAG/ and prints a one-line summary per run.
-TAG=${1:-fresh}; N=${2:-10}; IDLE=${3:-30}; shift 3 2>/dev/null
+TAG=${1:-fresh}; N=${2:-10}; IDLE=${3:-30}
+if [ $# -ge 3 ]; then shift 3; else shift $#; fi   # (what follows the three positional arguments goes to bench.py)
 OUT=gpurun_out/$TAG
 mkdir -p "$OUT"
 for i in $(seq 1 "$N"); do
