@@ -410,7 +410,7 @@ template <int N>
 __device__ void lu_solve_wave(const float* sums, SolveLds& w)   // leaves x[0 .. N) in w.x
 {
     constexpr int O = 6 - N;   // N = 3 (rotation only): the lower-right block of the system and its last three right-hand sides
-    const int lane = threadIdx.x & 63;
+    const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));   // (the lane within the wave, whatever the block's shape)
     const bool in = lane < N * N;
     const int i = in ? lane / N : 0, j = in ? lane % N : 0;
     double a = 0.0;
@@ -473,7 +473,7 @@ __device__ void lu_solve_wave(const float* sums, SolveLds& w)   // leaves x[0 ..
 __device__ void icp_solve_step_wave(RefineState* st, const float* sums, const int rotation_only, const float max_rmse, const float K_next[4], SolveLds& w,
                                     const double T_lane)
 {
-    const int lane = threadIdx.x & 63;
+    const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));   // (the lane within the wave, whatever the block's shape)
     if (rotation_only) lu_solve_wave<3>(sums, w);
     else lu_solve_wave<6>(sums, w);
     __builtin_amdgcn_wave_barrier();   // (one wave: its LDS operations complete in order)
