@@ -407,3 +407,25 @@ def test_slab_frame_and_tiled_march_validate_their_arguments_without_a_gpu():
     eight = L.kfx_slab_exact_tiled_scratch_bytes(640, 480, 4, 8)   # + the strips of the final exchange: [8][6][S] twice over, [6][S]
     assert eight == (5 + 4 + 5 + 5 + 1) * 640 * 480 * 4 + (2 * 8 + 1) * 6 * 38400 * 4 + 256
     assert L.kfx_slab_raycast_exact_tiled(None, None, None, None, None, None, None, None, 0.4, 4.0, 0.01, 1, 4, None, None, None, None) == -1
+
+
+def test_depth_pyramid_entry_point_validates_its_levels_without_a_gpu():
+    """kfx_depth_pyramid_vbo_normals_f32 (the pyramid + maps in one launch): level count, per-level sizes and alignment are checked
+    before any launch -- fake non-null pointers are enough to get the status codes."""
+    L = _lib.load()
+    def img(w, h, elem, ptr=0x10000):
+        return _lib.KfxImage(w * elem, ptr, w, h)
+    K = (C.c_float * 16)(*([500.0, 500.0, 320.0, 240.0] * 4))
+    def call(sizes, levels, vbo_sizes=None, ptr=0x10000):
+        n = len(sizes)
+        d = (_lib.KfxImage * n)(*[img(w, h, 4, ptr) for w, h in sizes])
+        v = (_lib.KfxImage * n)(*[img(w, h, 16, ptr) for w, h in (vbo_sizes or sizes)])
+        m = (_lib.KfxImage * n)(*[img(w, h, 16, ptr) for w, h in (vbo_sizes or sizes)])
+        return L.kfx_depth_pyramid_vbo_normals_f32(d, v, m, K, levels, 1.0, None)
+    four = [(64, 48), (32, 24), (16, 12), (8, 6)]
+    assert call(four, 0) == -4 and call(four + [(4, 3)], 5) == -4                    # KFX_E_RANGE: 1 .. 4 levels
+    assert call([(64, 48), (40, 24)], 2) == -2                                        # KFX_E_SHAPE: a level larger than half the one before
+    assert call([(64, 48), (32, 24)], 2, vbo_sizes=[(64, 48), (32, 20)]) == -2        # maps of another size than their depth level
+    assert call([(64, 48), (0, 24)], 2) == -2                                         # an empty level
+    assert call(four, 4, ptr=0x10004) == -3                                           # KFX_E_ALIGN: float4 maps at a 4-byte boundary
+    assert L.kfx_depth_pyramid_vbo_normals_f32(None, None, None, K, 1, 1.0, None) == -1
