@@ -333,8 +333,9 @@ int kfx_icp_point_plane(const kfx_image* Pl, const kfx_image* Pr, const kfx_imag
                         kfx_lss6* out, kfx_stream stream);
 
 /* The whole coarse-to-fine refinement loop of the reference application (main.cpp:301-337) on the device: per level
- * (given COARSEST FIRST) and iteration the ICP system is summed, solved in float64 by one GPU thread (weak prior,
- * complete-pivoting LU, SE(3) exponential -- the algorithms of kangaroo_amd/tracking.py) and K*T_lp / T_lp^-1 are
+ * (given COARSEST FIRST) and iteration the ICP system is summed, solved in float64 on the device (weak prior,
+ * complete-pivoting LU spread over one wave, SE(3) exponential -- the algorithms of kangaroo_amd/tracking.py, the same operations in
+ * the same order) and K*T_lp / T_lp^-1 are
  * left in device memory for the next evaluation; the host synchronises once at the end instead of once per
  * iteration.  `workspace`: >= (largest level's blocks * 116, rounded up to 256) + 512 bytes, 8-byte aligned.
  * Results: T_lp (row-major 3x4, float64), rmse / obs of the last evaluation, tracking_good = rmse < max_rmse. */
