@@ -355,6 +355,11 @@ int kfx_icp_refine_then(const kfx_icp_level* levels, int n_levels, float c, floa
                         const kfx_image* debug, double T_lp[12], float* rmse, unsigned* obs, int* tracking_good,
                         void (*enqueue_more)(void* user), void* user, kfx_stream stream);
 
+/* The pose update that follows the refinement (main.cpp:337 and :345): T_wl_out = T_wl * T_lp^-1 and, if T_cw_out is given,
+ * (float) T_wl_out^-1 -- rigid row-major 3 x 4 transforms, float64 products written out term by term on the host (what SE3d of
+ * apps/pose_solve.h computes).  T_wl_out may alias T_wl. */
+int kfx_pose_step(const double T_wl[12], const double T_lp[12], double T_wl_out[12], float T_cw_out[12]);
+
 /* ---- multi-GPU raycast composite (no reference counterpart) ------------------------
  * Per-pixel glue around the two collectives of kangaroo_amd/pipeline.py::SlabPipeline.composite:
  *   pack:   key[v*w+u] = (bits(depth or +inf) << 8) | rank                    then all_reduce(MIN, key)

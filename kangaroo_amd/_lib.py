@@ -112,6 +112,7 @@ SIGNATURES = {
     "kfx_mc_emit": (C.c_int, [PV, PV, C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "kfx_icp_refine": (C.c_int, [C.POINTER(KfxIcpLevel), C.c_int, C.c_float, C.c_float, PI, PI, C.POINTER(C.c_double), PF,
                                  C.POINTER(C.c_uint), C.POINTER(C.c_int), C.c_void_p]),
+    "kfx_pose_step": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), PF]),
     "kfx_icp_refine_then": (C.c_int, [C.POINTER(KfxIcpLevel), C.c_int, C.c_float, C.c_float, PI, PI, C.POINTER(C.c_double), PF,
                                       C.POINTER(C.c_uint), C.POINTER(C.c_int), C.c_void_p, C.c_void_p, C.c_void_p]),   # (the hook: a CFUNCTYPE(None, c_void_p) cast to void*)
     "kfx_icp_point_plane": (C.c_int, [PI, PI, PI, PF, PF, C.c_float, PI, PI, C.POINTER(KfxLss6), C.c_void_p]),

@@ -282,6 +282,7 @@ class TrackingPipeline(FramePipeline):
         # its way to the host, it must not overwrite the maps SdfFuse is about to read
         self._kin_back = None
         self._prefetched = None   # the image whose pre-amble the back set holds
+        self._bound = {}          # SdfFuseBound per set of maps
         self.pyr_d, self.pyr_i = P(w, h, L, "f32"), P(w, h, L, "f32")
         self.pyr_n, self.pyr_v = P(w, h, L, "f32x4"), P(w, h, L, "f32x4")
         self.K_levels = [scenes.intrinsics_level(self.K, l) for l in range(L)]
@@ -365,13 +366,29 @@ class TrackingPipeline(FramePipeline):
                 T_lp, self.rmse, self.tracking_good = tr.refine_pose(o, self.kin_v, self.pyr_v, self.pyr_n, self.K_levels,
                                                                      self.scratch, self.debug, self.its, self.icp_c, self.max_rmse)
             if self.tracking_good:
-                self.T_wl = self.T_wl @ tr.se3_inv(T_lp)
-                self._fuse_at(self.T_wl)
+                if hasattr(o, "PoseStep") and hasattr(o, "SdfFuseBound"):
+                    # the device idles from the pose's arrival to the SdfFuse launch: the update in one host call, the launch with
+                    # its arguments bound beforehand
+                    self.T_wl, T_cw = o.PoseStep(self.T_wl, T_lp)
+                    self._fuse_bound(T_cw)
+                else:
+                    self.T_wl = self.T_wl @ tr.se3_inv(T_lp)
+                    self._fuse_at(self.T_wl)
         self.frame += 1
         self.frames_done += 1
         if cal:
             self._policy_after()
         return self.T_wl
+
+    def _fuse_bound(self, T_cw):
+        """SdfFuse of the frame's maps at T_cw (3x4 float32) through a call whose other arguments were marshalled once (per set of
+        maps and per tracked / plain choice)."""
+        key = (id(self.kin_d[0]), bool(self.track), id(self.summary) if self.track else 0)
+        b = self._bound.get(key)
+        if b is None:
+            b = self._bound[key] = self.ops.SdfFuseBound(self.vol, self.kin_d[0], self.kin_n[0], self.K, self.trunc, self.max_w, self.mincostheta,
+                                                         summary=self.summary if self.track else None)
+        b(T_cw)
 
     def _fuse_at(self, T_wl):
         T_cw = self.tracking.se3_inv(T_wl)[:3].astype(np.float32)

@@ -402,6 +402,39 @@ def SdfFuse(vol, depth, norm, T_cw, K, trunc_dist, maxw, mincostheta, full_exten
                   1 if full_extent else 0, _stream(stream)))
 
 
+class SdfFuseBound:
+    """SdfFuse with everything but the pose bound ahead of time (the tracked loop: the launch follows the pose's arrival on the
+    host, and every microsecond of argument marshalling in between is a microsecond the device idles).  call(T_cw: 12 float32)."""
+
+    def __init__(self, vol, depth, norm, K, trunc_dist, maxw, mincostheta, full_extent=False, stream=None, summary=None):
+        assert vol.kind == "f32"
+        L = _lib.load()
+        self._keep = (vol, depth, norm, summary)
+        self._v, self._d, self._n = vol.view(), depth.view(), norm.view()
+        self._k, self._ka = _fp(K, 4)
+        self._T = (C.c_float * 12)()
+        tail = (float(trunc_dist), float(maxw), float(mincostheta), 1 if full_extent else 0, _stream(stream))
+        if summary is not None:
+            self._call = lambda: L.kfx_sdf_fuse_tracked(C.byref(self._v), summary.handle, C.byref(self._d), C.byref(self._n), self._T, self._k, *tail)
+        else:
+            self._call = lambda: L.kfx_sdf_fuse(C.byref(self._v), C.byref(self._d), C.byref(self._n), self._T, self._k, *tail)
+
+    def __call__(self, T_cw):
+        C.memmove(self._T, T_cw.ctypes.data, 48)
+        _lib.check(self._call())
+
+
+def PoseStep(T_wl, T_lp):
+    """kfx_pose_step: (T_wl * T_lp^-1 as 4x4 float64, its inverse as 3x4 float32) -- main.cpp:337 / :345 on the host, term by term."""
+    a = np.ascontiguousarray(T_wl, np.float64)
+    b = np.ascontiguousarray(T_lp, np.float64)
+    out = np.eye(4)
+    inv = np.empty((3, 4), np.float32)
+    PD = C.POINTER(C.c_double)
+    _lib.check(_lib.load().kfx_pose_step(a.ctypes.data_as(PD), b.ctypes.data_as(PD), out.ctypes.data_as(PD), inv.ctypes.data_as(_lib.PF)))
+    return out, inv
+
+
 def SdfFuseCount(vol, depth, norm, T_cw, K, trunc_dist, mincostheta, full_extent=False, stream=None):
     """Diagnostics: number of voxels SdfFuse would update for this frame (kfx_sdf_fuse_count)."""
     t, _t = _fp(T_cw, 12)
@@ -776,7 +809,7 @@ def IcpRefine(kin_v, ray_v, ray_n, K_levels, its, icp_c, max_rmse, dWorkspace, d
         _lib.check(_lib.load().kfx_icp_refine(arr, n, icp_c, max_rmse, dWorkspace.ref(), dDebug.ref() if dDebug is not None else None, T,
                                               C.byref(rmse), C.byref(obs), C.byref(good), _stream(stream)))
     T4 = np.eye(4)
-    T4[:3, :] = np.array(list(T), np.float64).reshape(3, 4)
+    T4[:3, :] = np.frombuffer(T, np.float64).reshape(3, 4)
     return T4, float(rmse.value), int(obs.value), bool(good.value)
 
 

@@ -197,3 +197,23 @@ def test_tracking_pipeline_recovers_after_a_frame_without_depth():
     assert pipe.resets == 1
     # the model was rebuilt from the frames after the drop-out only: cells the first three frames alone had observed are unknown again
     assert np.isnan(pipe.vol.data[..., 0]).any() and np.isfinite(pipe.vol.data[..., 0]).sum() > 0.2 * N ** 3
+
+
+def test_pose_step_host_function_matches_the_matrix_expression():
+    """kfx_pose_step (host code of libkfx: the tracked loop's T_wl = T_wl * T_lp^-1 and the float T_cw SdfFuse takes) against the
+    4 x 4 matrix expression of tracking.py, for random rigid transforms: float64 to rounding, the float inverse exactly the
+    rounded double inverse.  Runs without a GPU."""
+    from kangaroo_amd import roo, tracking as tr
+    rng = np.random.default_rng(5)
+    for _ in range(50):
+        T_wl, T_lp = np.eye(4), np.eye(4)
+        for T in (T_wl, T_lp):
+            q, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+            T[:3, :3] = q * np.sign(np.linalg.det(q))
+            T[:3, 3] = rng.normal(size=3)
+        got, inv = roo.PoseStep(T_wl, T_lp)
+        want = T_wl @ tr.se3_inv(T_lp)
+        assert np.abs(got - want).max() < 1e-14 and got[3].tolist() == [0.0, 0.0, 0.0, 1.0]
+        assert inv.dtype == np.float32 and np.abs(inv - tr.se3_inv(got)[:3]).max() < 1e-6
+        again, _ = roo.PoseStep(got, np.eye(4))
+        assert again.tobytes() == got.tobytes()   # a step by the identity changes nothing
