@@ -1014,12 +1014,16 @@ class TrackingSlabPipeline(SlabPipeline):
                 T_lp, self.rmse, self.tracking_good = tr.refine_pose(o, self.kin_v, self.pyr_v, self.pyr_n, self.K_levels,
                                                                      self.scratch, self.debug, self.its, self.icp_c, self.max_rmse)
             if self.tracking_good:
-                self.T_wl = self.T_wl @ tr.se3_inv(T_lp)
-                self._fuse_at(self.T_wl)
+                if hasattr(o, "PoseStep"):   # the same host arithmetic as TrackingPipeline.step (kfx_pose_step): the same poses, bit for bit
+                    self.T_wl, T_cw = o.PoseStep(self.T_wl, T_lp)
+                    self._fuse_at(self.T_wl, T_cw)
+                else:
+                    self.T_wl = self.T_wl @ tr.se3_inv(T_lp)
+                    self._fuse_at(self.T_wl)
         self.frame += 1
         return self.T_wl
 
-    def _fuse_at(self, T_wl):
+    def _fuse_at(self, T_wl, T_cw=None):
         # SlabPipeline.fuse integrates self.filtered / self.normals at T_wc; point them at pyramid level 0
         self.filtered, self.normals = self.kin_d[0], self.kin_n[0]
-        self.fuse(T_wl[:3].astype(np.float32), T_cw=self.tracking.se3_inv(T_wl)[:3].astype(np.float32))
+        self.fuse(T_wl[:3].astype(np.float32), T_cw=self.tracking.se3_inv(T_wl)[:3].astype(np.float32) if T_cw is None else T_cw)
