@@ -420,6 +420,8 @@ class SdfFuseBound:
             self._call = lambda: L.kfx_sdf_fuse(C.byref(self._v), C.byref(self._d), C.byref(self._n), self._T, self._k, *tail)
 
     def __call__(self, T_cw):
+        if T_cw.dtype != np.float32 or T_cw.size != 12 or not T_cw.flags.c_contiguous:
+            T_cw = np.ascontiguousarray(np.asarray(T_cw, np.float32).reshape(12))
         C.memmove(self._T, T_cw.ctypes.data, 48)
         _lib.check(self._call())
 
