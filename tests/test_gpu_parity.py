@@ -1389,7 +1389,7 @@ def test_gpu_device_resident_icp_loop(roo):
 
 def test_gpu_persistent_icp_kernel_equals_the_chain_of_launches():
     """kfx_icp_refine as ONE persistent launch (k_icp_refine_persistent: all levels and iterations, a grid-wide barrier between
-    the block systems and the step, every workgroup solving for itself) against the chain of thirteen launches
+    the block systems and the step, every workgroup solving for itself) against the chain of twelve launches
     (KFX_ICP_PERSISTENT=0): the same per-pixel function, block tree, block order and float64 step, so the same pose, rmse and
     observation count BIT FOR BIT -- at 640x480 (1200 blocks over the resident grid: several per workgroup) and 160x120, for the
     application's schedule and two others, repeated calls (the barrier words are re-armed per call)."""
