@@ -168,8 +168,14 @@ uint64_t launch_nonce()
         any = true;
         fold(v);
     }
+    // the launcher is part of the nonce unless the launch names itself (KFX_RUN_ID / TORCHELASTIC_RUN_ID are unique per launch: ranks
+    // that do not share a parent -- one wrapper shell per rank, a step daemon per task, one agent per node -- still agree) or
+    // KFX_RDV_PARENT says which; KFX_RDV_PARENT=1 forces it in, 0 leaves it out
     const char* par = getenv("KFX_RDV_PARENT");
-    if (!par || atoi(par) != 0) {
+    const char* run_id = getenv("KFX_RUN_ID");
+    const char* el_id = getenv("TORCHELASTIC_RUN_ID");
+    const bool named = (run_id && *run_id) || (el_id && *el_id && strcmp(el_id, "none") != 0);
+    if (par && *par ? atoi(par) != 0 : !named) {
         const long long ppid = (long long)getppid();
         const std::string path = "/proc/" + std::to_string(ppid) + "/stat";
         const std::string id = "ppid:" + std::to_string(ppid) + ":" + std::to_string(start_ticks(path.c_str()));
@@ -233,17 +239,20 @@ int write_rendezvous(const char* path, const Rendezvous& rv)
     return 0;
 }
 
-// 1: accepted, 0: not (yet) there / not ours / stale
-int read_rendezvous(const char* path, Rendezvous& rv, uint64_t nonce, time_t not_before)
+// 1: accepted, 0: not (yet) there / not ours / stale.  *foreign (optional) is set when a well-formed, fresh file of this user was
+// seen whose ONLY mismatch is the nonce: ranks of one launch that derive different nonces (no common parent) -- worth saying so
+// when the wait times out instead of a generic failure.
+int read_rendezvous(const char* path, Rendezvous& rv, uint64_t nonce, time_t not_before, bool* foreign = nullptr)
 {
     const int fd = open(path, O_RDONLY | O_NOFOLLOW | O_CLOEXEC);
     if (fd < 0) return 0;
     struct stat st;
     bool ok = fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_uid == geteuid() && st.st_size == (off_t)sizeof(rv) &&
               st.st_mtime + rdv_slack_s() >= not_before;
-    ok = ok && read(fd, &rv, sizeof(rv)) == (ssize_t)sizeof(rv) && memcmp(rv.magic, RDV_MAGIC, 8) == 0 && rv.nonce == nonce;
+    ok = ok && read(fd, &rv, sizeof(rv)) == (ssize_t)sizeof(rv) && memcmp(rv.magic, RDV_MAGIC, 8) == 0;
     close(fd);
-    return ok ? 1 : 0;
+    if (ok && rv.nonce != nonce && foreign) *foreign = true;
+    return ok && rv.nonce == nonce ? 1 : 0;
 }
 
 } // namespace
@@ -277,8 +286,17 @@ extern "C" int kfx_comm_create_rccl(kfx_comm* comm, int rank, int world, const c
         const uint64_t nonce = rv.nonce;
         const time_t started = process_start();
         const auto t0 = std::chrono::steady_clock::now();
-        while (!read_rendezvous(rendezvous_file, rv, nonce, started)) {
-            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(timeout_s > 0 ? timeout_s : 60)) return KFX_E_RANGE;
+        bool foreign = false;
+        while (!read_rendezvous(rendezvous_file, rv, nonce, started, &foreign)) {
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(timeout_s > 0 ? timeout_s : 60)) {
+                if (foreign)
+                    fprintf(stderr, "kfx_comm_create_rccl: rank %d timed out: a rendezvous file is present at %s but its launch nonce differs from this "
+                                    "rank's (the ranks do not share a parent process?) -- give every rank the same KFX_RUN_ID, unique per launch "
+                                    "(or KFX_RDV_PARENT=0 with a unique MASTER_PORT)\n", rank, rendezvous_file);
+                else
+                    fprintf(stderr, "kfx_comm_create_rccl: rank %d timed out waiting for rank 0's rendezvous file %s\n", rank, rendezvous_file);
+                return KFX_E_RANGE;
+            }
             std::this_thread::sleep_for(std::chrono::milliseconds(20));
         }
     }

@@ -678,6 +678,7 @@ struct TiledScratch {
 // the scratch buffer's parts; returns its size in ints (scratch may be null: sizes only)
 size_t tiled_layout(TiledScratch& t, void* scratch, size_t w, size_t h, int tiles, int world)
 {
+    if (tiles > 64) tiles = 64;   // (the march keeps a 64-bit mask of the tiles it has initialised; clamped HERE so that the advertised size and the march agree)
     t.T = tiles < 1 ? 1 : (tiles > (int)h ? (int)(h ? h : 1) : tiles);
     t.R = (int)((h + (size_t)t.T - 1) / (size_t)t.T);
     t.T = (int)((h + (size_t)t.R - 1) / (size_t)(t.R ? t.R : 1));   // (tiles that are not empty)
@@ -727,7 +728,6 @@ extern "C" int kfx_slab_raycast_exact_tiled(const kfx_image* depth, const kfx_im
     if (world > 1 && !comm->exchange_v) return set_error(KFX_E_RANGE, "kfx_slab_raycast_exact_tiled: the transport has no exchange_v");
     const int w = (int)img->w, h = (int)img->h;
     if (w == 0 || h == 0) return 0;
-    if (tiles > 64) tiles = 64;
     TiledScratch t;
     tiled_layout(t, scratch, (size_t)w, (size_t)h, tiles, world);
     const int T = t.T, R = t.R;

@@ -958,6 +958,11 @@ class TrackingSlabPipeline(SlabPipeline):
             raise ValueError("TrackingSlabPipeline: inputs='broadcast' is not implemented (every rank builds the frame's pyramids itself)")
         if kw.get("overlap"):
             raise ValueError("TrackingSlabPipeline: overlap=True is for known-pose streams (the tracker reads the merged images at once)")
+        if kw.get("driver", "python") != "python":
+            # the C frame object is bound to SlabPipeline's filtered / normals images at construction; this loop integrates the
+            # pyramids' level 0 (kin_d[0] / kin_n[0]) and renders pyramid levels, which kfx_slab_frame_step knows nothing about
+            raise ValueError("TrackingSlabPipeline: driver='c' is for known-pose streams (kfx_slab_frame_step integrates the images it was created "
+                             "with, not the tracker's pyramids); use driver='python'")
         super().__init__(ops, dist, dims, boxmin, boxmax, w, h, **kw)
         self.tracking = tracking
         self.its = tuple(tracking.DEFAULT_ITS if its is None else its)

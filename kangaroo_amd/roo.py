@@ -413,11 +413,13 @@ class SdfFuseBound:
         self._v, self._d, self._n = vol.view(), depth.view(), norm.view()
         self._k, self._ka = _fp(K, 4)
         self._T = (C.c_float * 12)()
-        tail = (float(trunc_dist), float(maxw), float(mincostheta), 1 if full_extent else 0, _stream(stream))
+        # the stream is resolved at every call (torch's current stream may have changed since construction: the launch must stay
+        # ordered behind the maps it reads and before the raycast that follows); everything else is marshalled once
+        tail = (float(trunc_dist), float(maxw), float(mincostheta), 1 if full_extent else 0)
         if summary is not None:
-            self._call = lambda: L.kfx_sdf_fuse_tracked(C.byref(self._v), summary.handle, C.byref(self._d), C.byref(self._n), self._T, self._k, *tail)
+            self._call = lambda: L.kfx_sdf_fuse_tracked(C.byref(self._v), summary.handle, C.byref(self._d), C.byref(self._n), self._T, self._k, *tail, _stream(stream))
         else:
-            self._call = lambda: L.kfx_sdf_fuse(C.byref(self._v), C.byref(self._d), C.byref(self._n), self._T, self._k, *tail)
+            self._call = lambda: L.kfx_sdf_fuse(C.byref(self._v), C.byref(self._d), C.byref(self._n), self._T, self._k, *tail, _stream(stream))
 
     def __call__(self, T_cw):
         if T_cw.dtype != np.float32 or T_cw.size != 12 or not T_cw.flags.c_contiguous:

@@ -302,6 +302,53 @@ def test_rccl_rendezvous_refuses_the_file_of_a_crashed_run_of_the_same_port(tmp_
     assert nonce_a != nonce_here
 
 
+def test_rccl_rendezvous_named_launches_agree_across_parents_and_a_foreign_nonce_is_reported(tmp_path):
+    """Round-5 advice: ranks that do not share a parent (one wrapper shell per rank, a step daemon per task, one agent per node)
+    derived different nonces and ignored rank 0's valid file until the timeout, silently.  (a) A launch that names itself
+    (KFX_RUN_ID, or a TORCHELASTIC_RUN_ID other than torchrun's static "none") leaves the parent out of the nonce: a rank started
+    through another parent accepts the file; KFX_RDV_PARENT=1 puts the parent back.  (b) When the wait times out on a fresh,
+    well-formed file whose only mismatch is the nonce, the error says so."""
+    import sys
+    lib, R = _rccl_lib()
+    path = tmp_path / "id"
+    base = {k: v for k, v in os.environ.items() if k not in _RDV_ENV and k != "KFX_RUN_ID"}
+    via = ("import subprocess, sys\n"
+           "sys.exit(subprocess.call([sys.executable, '-c', sys.argv[1]]))\n")
+    inner = ("import ctypes\n"
+             "R = ctypes.CDLL(%r)\n"
+             "R.kfx_rccl_launch_nonce.restype = ctypes.c_ulonglong\n"
+             "print(R.kfx_rccl_rendezvous_probe(%r.encode()), R.kfx_rccl_launch_nonce())\n") % (lib, str(path))
+
+    def other_parent(env):
+        out = subprocess.run([sys.executable, "-c", via, inner], env=env, capture_output=True, text=True, timeout=60)
+        assert out.returncode == 0, out.stdout + out.stderr
+        return [int(v) for v in out.stdout.split()]
+    for env in (dict(base, KFX_RUN_ID="job-17"), dict(base, TORCHELASTIC_RUN_ID="elastic-17", MASTER_PORT="29500")):
+        nonce = int(_probe_child(lib, path, env).communicate(timeout=60)[0].split()[1])
+        path.write_bytes(_rdv_payload(nonce))
+        assert other_parent(env) == [1, nonce], env                       # another parent, same name: same nonce, file accepted
+        got = other_parent(dict(env, KFX_RDV_PARENT="1"))                  # the parent forced back in: another nonce
+        assert got[0] == 0 and got[1] != nonce
+    # torchrun's default run id is the static string "none": the launcher stays part of the nonce
+    env = dict(base, TORCHELASTIC_RUN_ID="none", MASTER_PORT="29500")
+    nonce = int(_probe_child(lib, path, env).communicate(timeout=60)[0].split()[1])
+    path.write_bytes(_rdv_payload(nonce))
+    got = other_parent(env)
+    assert got[0] == 0 and got[1] != nonce
+    # (b) the timeout names the reason
+    code = ("import ctypes\n"
+            "R = ctypes.CDLL(%r)\n"
+            "comm = ctypes.create_string_buffer(256)\n"
+            "R.kfx_comm_create_rccl.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_char_p, ctypes.c_int]\n"
+            "print(R.kfx_comm_create_rccl(comm, 1, 2, %r.encode(), 1))\n") % (lib, str(path))
+    path.write_bytes(_rdv_payload(nonce ^ 2))
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=60)
+    assert out.stdout.split() == ["-4"] and "launch nonce differs" in out.stderr and "KFX_RUN_ID" in out.stderr, out.stdout + out.stderr
+    path.unlink()
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=60)
+    assert out.stdout.split() == ["-4"] and "launch nonce differs" not in out.stderr and "timed out waiting" in out.stderr, out.stdout + out.stderr
+
+
 def test_frame_object_validates_its_views_without_a_gpu():
     """kfx_frame_create (include/kfx.h) checks the caller's views before any HIP call: with no timing slots it needs no device, so
     the argument errors -- and a well-formed create / destroy -- are checked here."""

@@ -98,3 +98,23 @@ def test_pmc_traffic_is_reported_only_for_the_kernels_it_was_taken_on(tmp_path, 
     t, src = bench.pmc_traffic("full_fast")
     assert t is None and "unrecorded revision" in src
     assert bench.pmc_traffic("no_such_key") == (None, None)
+
+
+def test_cpu_baseline_is_a_median_of_three_blocks():
+    """Round-5 verdict, item 6: `cpu_baseline.value` is the median of three blocks of full frames with the spread beside it (one
+    8-second sample moved 19 % between two rounds on unchanged code).  A small volume here: the shape of the record and the
+    arithmetic, not the figure."""
+    import argparse
+    sys.path.insert(0, T.ROOT)
+    import bench
+    import oracle
+    so, lib_ = oracle._SO_OVERRIDE, oracle._LIB
+    try:
+        out = bench.cpu_baseline(argparse.Namespace(res=32, width=80, height=60), "room", 30)
+    finally:
+        oracle._SO_OVERRIDE, oracle._LIB = so, lib_
+    assert out["kind"] == "port" and out["unit"] == "frames/s" and out["cores"] >= 1
+    assert len(out["blocks_fps"]) == 3 and min(out["blocks_fps"]) > 0
+    assert abs(out["value"] - float(np.median(out["blocks_fps"]))) < 1e-3
+    assert abs(out["spread"] - (max(out["blocks_fps"]) - min(out["blocks_fps"])) / out["value"]) < 1e-3
+    assert "median of 3 blocks of 6 full frames" in out["sample"] and out["single_thread"]["cores"] == 1
