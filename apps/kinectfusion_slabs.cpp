@@ -16,6 +16,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <thread>
 #include <vector>
@@ -32,6 +33,8 @@ struct Options {
     bool fast = false, rccl = false, broadcast_inputs = false;
     bool frame_driver = false;   // --driver frame: one kfx_slab_frame_step call per frame instead of the roo:: calls
     bool overlap = false;        // --overlap (frame driver, composite): the merge of frame k under frame k + 1
+    int pipeline = 0;            // --pipeline D (frame driver, exact): frames pipelined across the ranks, D image / buffer sets in flight (2 .. 4)
+    bool p2p = false;            // --transport threads-p2p: neighbour exchanges matched pairwise like RCCL's send / recv (a mismatch blocks, then times out)
     int tiles = 0;               // --tiles T: exact hand-over pipelined over T image row-tiles (0: whole-image stages; the frame driver's default: 4)
     SlabVolume::HaloMode halo = SlabVolume::HaloExchange;
     SlabVolume::RaycastMode raycast = SlabVolume::Composite;
@@ -83,7 +86,7 @@ static unsigned BitSum(const void* p, size_t bytes)
     return s;
 }
 
-struct Result { double ms_per_frame = 0; unsigned chk_d = 0, chk_n = 0, chk_i = 0, chk_vol = 0; size_t hits = 0; int rounds = 0; int status = 0; };
+struct Result { double ms_per_frame = 0; unsigned chk_d = 0, chk_n = 0, chk_i = 0, chk_vol = 0, chk_hist = 0; size_t hits = 0; int rounds = 0; int status = 0; };
 
 // the frame loop of one rank
 static void RunRank(const Options& o, kfx_comm* comm, const std::vector<std::vector<float> >& depth_mm, const std::vector<Mat<float,3,4> >& poses,
@@ -97,6 +100,8 @@ static void RunRank(const Options& o, kfx_comm* comm, const std::vector<std::vec
     const float max_w = 1000.0f, mincostheta = 0.1f;
     const BoundingBox bb(make_float3(-1, -1, 2), make_float3(1, 1, 4));
 
+    std::vector<std::unique_ptr<Image<float, TargetDevice, Manage> > > set_d, set_i;
+    std::vector<std::unique_ptr<Image<float4, TargetDevice, Manage> > > set_n;
     Image<float, TargetDevice, Manage> dMeters(w, h), dFiltered(w, h), ray_d(w, h), ray_i(w, h);
     Image<float4, TargetDevice, Manage> dVbo(w, h), dNormals(w, h), ray_n(w, h);
     SlabVolume slab(o.volres, o.volres, o.volres, bb, comm, o.halo, o.raycast);
@@ -124,14 +129,72 @@ static void RunRank(const Options& o, kfx_comm* comm, const std::vector<std::vec
         fc.raycast = o.raycast == SlabVolume::Exact ? KFX_SLAB_RAYCAST_EXACT : KFX_SLAB_RAYCAST_COMPOSITE;
         fc.merge = o.merge == SlabVolume::MergeDirect ? KFX_SLAB_MERGE_DIRECT : KFX_SLAB_MERGE_ALLREDUCE;
         fc.inputs = o.broadcast_inputs ? KFX_SLAB_INPUTS_BROADCAST : KFX_SLAB_INPUTS_REPLICATE;
-        fc.overlap = o.overlap ? 1 : 0;
+        fc.overlap = (o.overlap || o.pipeline) ? 1 : 0;
         fc.tiles = o.tiles;
         fc.timing_slots = 16;
+        if (o.pipeline) {   // the image sets 1 .. D - 1 of the pipelined exact raycast (set 0: ray_d / ray_n / ray_i)
+            fc.pipe_depth = o.pipeline;
+            for (int k = 1; k < o.pipeline; ++k) {
+                set_d.emplace_back(new Image<float, TargetDevice, Manage>(w, h));
+                set_n.emplace_back(new Image<float4, TargetDevice, Manage>(w, h));
+                set_i.emplace_back(new Image<float, TargetDevice, Manage>(w, h));
+                fc.pipe_images[3 * (k - 1)] = *set_d.back()->abi(); fc.pipe_images[3 * (k - 1) + 1] = *set_n.back()->abi(); fc.pipe_images[3 * (k - 1) + 2] = *set_i.back()->abi();
+            }
+        }
         GpuCheckStatus(kfx_slab_frame_create(&kframe, &fc, comm));
     }
+    // every frame's rendered depth image, kept on the device (one row-block per frame): `history` in the output is a checksum over ALL
+    // frames' renderings, not only the last one's
+    Image<float, TargetDevice, Manage> hist(w, (size_t)h * o.frames);
+    const auto keep = [&](int frame, const kfx_image& d) {
+        GpuCheckStatus(kfx_memcpy_2d((unsigned char*)hist.ptr + (size_t)frame * h * hist.pitch, hist.pitch, d.ptr, d.pitch, (size_t)w * 4, h, 5, 0));
+    };
+    if (kframe && o.pipeline) {
+        // Pipelined frames: the depth frames are resident before the loop (a blocking upload would synchronise the device every
+        // frame), the frames are stepped back to back -- no synchronisation, no barrier -- and the rendering of frame k is picked up
+        // when frame k + D is about to take its image set.
+        std::vector<std::unique_ptr<Image<float, TargetDevice, Manage> > > dmm(o.frames);
+        for (int f = 0; f < o.frames; ++f) {
+            dmm[f].reset(new Image<float, TargetDevice, Manage>(w, h));
+            dmm[f]->MemcpyFromHost(const_cast<float*>(depth_mm[f].data()));
+        }
+        kfx_stream_synchronize(0);
+        comm->barrier(comm);
+        const auto t0 = std::chrono::steady_clock::now();
+        const int D = o.pipeline;
+        for (int f = 0; f < o.frames; ++f) {
+            kfx_image d, n, i;
+            if (f >= D) {
+                GpuCheckStatus(kfx_slab_frame_wait_frame(kframe, f - D, 0));
+                GpuCheckStatus(kfx_slab_frame_images(kframe, f - D, &d, &n, &i));
+                keep(f - D, d);
+            }
+            ElementwiseScaleBias<float,float,float>(dMeters, *dmm[f], 1.0f / 1000.0f);
+            const Mat<float,3,4> T_cw = SE3inv(poses[f]);
+            GpuCheckStatus(kfx_slab_frame_step(kframe, 0, poses[f].m, T_cw.m, 0, 0));
+        }
+        GpuCheckStatus(kfx_slab_frame_wait(kframe, 0));   // (a collective point: the trailing final exchanges are enqueued here)
+        for (int f = o.frames > D ? o.frames - D : 0; f < o.frames; ++f) {
+            kfx_image d, n, i;
+            GpuCheckStatus(kfx_slab_frame_images(kframe, f, &d, &n, &i));
+            keep(f, d);
+            if (f == o.frames - 1) {   // the last rendering, where the checksums below look for it
+                GpuCheckStatus(kfx_memcpy_2d(ray_d.ptr, ray_d.pitch, d.ptr, d.pitch, (size_t)w * 4, h, 5, 0));
+                GpuCheckStatus(kfx_memcpy_2d(ray_n.ptr, ray_n.pitch, n.ptr, n.pitch, (size_t)w * 16, h, 5, 0));
+                GpuCheckStatus(kfx_memcpy_2d(ray_i.ptr, ray_i.pitch, i.ptr, i.pitch, (size_t)w * 4, h, 5, 0));
+            }
+        }
+        GpuCheckStatus(kfx_slab_frame_sync(kframe, 0));
+        comm->barrier(comm);
+        res->ms_per_frame = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / o.frames;
+        res->rounds = kfx_slab_frame_last_steps(kframe);
+        kfx_slab_frame_destroy(kframe);
+        kframe = nullptr;
+    }
+    const bool piped = o.frame_driver && o.pipeline;
 
     double total_ms = 0;
-    for (int f = 0; f < o.frames; ++f) {
+    for (int f = 0; f < o.frames && !piped; ++f) {
         const Mat<float,3,4> T_wl = poses[f];
         dMeters.MemcpyFromHost(const_cast<float*>(depth_mm[f].data()));
         comm->barrier(comm);
@@ -144,6 +207,7 @@ static void RunRank(const Options& o, kfx_comm* comm, const std::vector<std::vec
             GpuCheckStatus(kfx_slab_frame_sync(kframe, 0));
             comm->barrier(comm);
             total_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            keep(f, *ray_d.abi());
             continue;
         }
         if (!o.broadcast_inputs || comm->rank == 0) {   // --inputs broadcast: rank 0 preprocesses, the maps travel to the others
@@ -158,10 +222,20 @@ static void RunRank(const Options& o, kfx_comm* comm, const std::vector<std::vec
         kfx_stream_synchronize(0);
         comm->barrier(comm);
         total_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        keep(f, *ray_d.abi());
     }
-    res->ms_per_frame = total_ms / o.frames;
-    res->rounds = kframe ? kfx_slab_frame_last_steps(kframe) : slab.last_rounds;
+    if (!piped) {
+        res->ms_per_frame = total_ms / o.frames;
+        res->rounds = kframe ? kfx_slab_frame_last_steps(kframe) : slab.last_rounds;
+    }
     if (kframe) kfx_slab_frame_destroy(kframe);
+    {   // the checksum over every frame's rendered depth
+        std::vector<float> hh((size_t)w * h * o.frames);
+        kfx_stream_synchronize(0);
+        GpuCheckStatus(kfx_memcpy_2d(hh.data(), (size_t)w * 4, hist.ptr, hist.pitch, (size_t)w * 4, (size_t)h * o.frames, 2, 0));
+        for (float& d : hh) if (!std::isfinite(d)) d = -1.0f;
+        res->chk_hist = BitSum(hh.data(), hh.size() * 4);
+    }
 
     // checksums: images (identical on every rank after the merge) and the owned planes of the volume, summed over the ranks
     std::vector<float> hd((size_t)w * h), hi((size_t)w * h);
@@ -209,7 +283,8 @@ int main(int argc, char** argv)
         else if (!strcmp(argv[i], "--height") && i + 1 < argc) o.h = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--ranks") && i + 1 < argc) o.ranks = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--fast")) o.fast = true;
-        else if (!strcmp(argv[i], "--transport") && i + 1 < argc) o.rccl = !strcmp(argv[++i], "rccl");
+        else if (!strcmp(argv[i], "--transport") && i + 1 < argc) { ++i; o.rccl = !strcmp(argv[i], "rccl"); o.p2p = !strcmp(argv[i], "threads-p2p"); }
+        else if (!strcmp(argv[i], "--pipeline") && i + 1 < argc) o.pipeline = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--halo") && i + 1 < argc) o.halo = !strcmp(argv[++i], "recompute") ? SlabVolume::HaloRecompute : SlabVolume::HaloExchange;
         else if (!strcmp(argv[i], "--raycast") && i + 1 < argc) {
             ++i;
@@ -258,7 +333,8 @@ int main(int argc, char** argv)
         comm.destroy(&comm);
     } else {
         std::vector<kfx_comm> comms(world);
-        GpuCheckStatus(kfx_comm_create_threads(comms.data(), world));
+        if (o.p2p) GpuCheckStatus(kfx_comm_create_threads_p2p(comms.data(), world, 20000));
+        else GpuCheckStatus(kfx_comm_create_threads(comms.data(), world));
         std::vector<Result> results(world);
         std::vector<std::thread> threads;
         for (int r = 1; r < world; ++r) threads.emplace_back(RunRank, std::cref(o), &comms[r], std::cref(depth_mm), std::cref(poses), &results[r]);
@@ -266,7 +342,7 @@ int main(int argc, char** argv)
         for (auto& t : threads) t.join();
         r0 = results[0];
         for (int r = 1; r < world; ++r)   // after the merge every rank must hold the same images
-            if (results[r].chk_d != r0.chk_d || results[r].chk_n != r0.chk_n || results[r].chk_i != r0.chk_i) r0.status = 4;
+            if (results[r].chk_d != r0.chk_d || results[r].chk_n != r0.chk_n || results[r].chk_i != r0.chk_i || results[r].chk_hist != r0.chk_hist) r0.status = 4;
         comms[0].destroy(&comms[0]);
     }
     if (rank == 0) {
@@ -274,8 +350,8 @@ int main(int argc, char** argv)
                o.volres, world, o.rccl ? "RCCL, one process per GPU" : "threads sharing one GPU", o.frame_driver ? "; one kfx_slab_frame_step per frame" : "", o.w, o.h, o.frames, o.fast ? "fast" : "exact",
                o.halo == SlabVolume::HaloExchange ? "exchange" : "recompute", o.raycast == SlabVolume::Exact ? "exact (hand-over)" : (o.raycast == SlabVolume::ExactAllReduce ? "exact (all-reduce per round)" : (o.merge == SlabVolume::MergeDirect ? "composite (direct-send merge)" : "composite (all-reduce merge)")),
                o.raycast != SlabVolume::Composite ? (" (" + std::to_string(r0.rounds) + " rounds)").c_str() : "", r0.ms_per_frame, 1e3 / r0.ms_per_frame);
-        printf("checksums depth=%08x norm=%08x img=%08x volume=%08x hits=%zu ranks_agree=%d\n", r0.chk_d, r0.chk_n, r0.chk_i, r0.chk_vol, r0.hits,
-               r0.status == 0 ? 1 : 0);
+        printf("checksums depth=%08x norm=%08x img=%08x volume=%08x history=%08x hits=%zu ranks_agree=%d%s\n", r0.chk_d, r0.chk_n, r0.chk_i, r0.chk_vol, r0.chk_hist,
+               r0.hits, r0.status == 0 ? 1 : 0, o.pipeline ? (" pipeline=" + std::to_string(o.pipeline)).c_str() : "");
     }
     if (r0.status) return r0.status;
     return r0.hits > (size_t)(o.w * o.h) / 4 ? 0 : 1;

@@ -51,6 +51,7 @@ extern "C" {
 #define KFX_E_ALIGN     (-3) /* pointer or pitch not aligned for the element type */
 #define KFX_E_RANGE     (-4) /* parameter out of supported range */
 #define KFX_E_NODEVICE  (-5) /* no HIP device */
+#define KFX_E_TIMEOUT   (-6) /* a point-to-point leg of the in-process transport found no matching partner in time (kfx_slab.h) */
 
 /* roo::Image<T,Target,Management>: {size_t pitch; T* ptr; size_t w; size_t h;} */
 typedef struct kfx_image {
@@ -123,6 +124,9 @@ int kfx_sdf_fuse_count(const kfx_volume* vol, const kfx_image* depth, const kfx_
  * 8 B x U + 24 B x w h.  Writes no image. */
 int kfx_raycast_sdf_count(const kfx_volume* vol, unsigned w, unsigned h, const float T_wc[12], const float K[4], float near, float far,
                           float trunc_dist, int subpix, unsigned* d_bitmap, unsigned long long* d_counters, kfx_stream stream);
+/* ... for half cells (kfx_raycast_sdf_h; config C5: the 2048^3 bitmap is 1 GiB) */
+int kfx_raycast_sdf_count_h(const kfx_volume* vol, unsigned w, unsigned h, const float T_wc[12], const float K[4], float near, float far,
+                            float trunc_dist, int subpix, unsigned* d_bitmap, unsigned long long* d_counters, kfx_stream stream);
 
 /* roo::RaycastSdf(Image<float> depth, Image<float4> norm, Image<float> img,
  *                 const BoundedVolume<SDF_t>, const Mat<float,3,4> T_wc, ImageIntrinsics,
@@ -210,7 +214,8 @@ int kfx_free(void* dev_ptr);
 int kfx_alloc_host(void** host_ptr, size_t bytes);
 int kfx_free_host(void* host_ptr);
 /* 2-D copies behind Image::CopyFrom / MemcpyFromHost / MemcpyToHost (Image.h:174-213).
- * kind: 0 host->host, 1 host->device, 2 device->host, 3 device->device, 4 default */
+ * kind: 0 host->host, 1 host->device, 2 device->host, 3 device->device, 4 default (stream null: blocking, like cudaMemcpy2D in the
+ * reference; else asynchronous on `stream`); 5 device->device enqueued on `stream` whatever it is -- the null stream too */
 int kfx_memcpy_2d(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width_bytes,
                   size_t rows, int kind, kfx_stream stream);
 int kfx_stream_synchronize(kfx_stream stream);

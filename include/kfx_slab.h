@@ -59,7 +59,15 @@ typedef struct kfx_comm {
      * must be what rank - 1 receives from above, and so on.  The tile-pipelined hand-over's steps. */
     int (*exchange_v)(struct kfx_comm* c, const void* send_lo, size_t bytes_send_lo, void* recv_lo, size_t bytes_recv_lo,
                       const void* send_hi, size_t bytes_send_hi, void* recv_hi, size_t bytes_recv_hi, kfx_stream stream);
+    /* KFX_COMM_HOST_BLOCKING: a collective returns only when every rank has entered it (the in-process and the callback transports);
+     * 0: collectives are enqueued on the stream and the call returns at once (RCCL).  kfx_slab_frame's pipelined frames let a host
+     * that blocks trail the final exchange of a frame by the frames in flight instead of stalling in it. */
+    int flags;
+    /* a second communicator over the same ranks with its own order of operations (every rank calls; RCCL: ncclCommSplit): what the
+     * frame object's side stream uses, so that its collectives and the main stream's need no common order across ranks */
+    int (*dup)(struct kfx_comm* c, struct kfx_comm* out);
 } kfx_comm;
+#define KFX_COMM_HOST_BLOCKING 1
 /* A transport of the caller's own fills the table itself: zero-initialise the struct first (entries after `destroy` are optional and
  * are tested against NULL; the table has grown at its end between versions of this header). */
 
@@ -67,6 +75,11 @@ typedef struct kfx_comm {
  * every collective must be called by all of them (each with its own comms[r]).  Destroy through comms[0] after the threads
  * have joined. */
 int kfx_comm_create_threads(kfx_comm* comms, int world);
+/* ... whose neighbour exchanges are matched PAIRWISE and in order per directed link, the way RCCL matches ncclSend / ncclRecv, instead
+ * of being a barrier of all ranks: a rank with nothing to pass on does not take part in a step, ranks drift apart by whole frames,
+ * and a leg whose two sides disagree (one skips it, or names another size) BLOCKS -- as it would on RCCL, where it hangs -- until
+ * timeout_ms have passed (<= 0: 10 s), then fails with KFX_E_TIMEOUT.  The collectives proper stay barriers of the group. */
+int kfx_comm_create_threads_p2p(kfx_comm* comms, int world, int timeout_ms);
 
 /* Loop-back transport (libkfx.so) for measuring ONE rank of a `world`-rank job on one GPU: every collective moves the bytes a
  * real one would deliver to this rank, but from this rank's own buffers (all_reduce: nothing arrives, all_to_all / all_gather:
@@ -162,8 +175,21 @@ int kfx_slab_raycast_exact_tiled(const kfx_image* depth, const kfx_image* norm, 
  *            COMPOSITE: kfx_raycast_sdf on the local view + nearest-hit merge (direct sends or two all-reduces); the march
  *            restarts at each slab entry, so silhouette rays can end differently (512^3 / 8 slabs, S_room: 85 of 307 200
  *            pixels change between hit and miss) -- a throughput variant outside the image tolerance of the single-GPU path.
- *   overlap  (COMPOSITE, halo RECOMPUTE, inputs REPLICATE only): the merge of frame k runs on the frame's own side stream under
- *            frame k + 1's preprocessing and SdfFuse; the images are valid after kfx_slab_frame_wait. */
+ *   overlap  COMPOSITE (halo RECOMPUTE, inputs REPLICATE only): the merge of frame k runs on the frame's own side stream under
+ *            frame k + 1's preprocessing and SdfFuse; the images are valid after kfx_slab_frame_wait.
+ *            EXACT: frames pipelined across the ranks.  The token chain of the hand-over takes world + tiles - 1 steps from the first
+ *            rank to the last, but a rank's own part of it is `tiles` visits; what ties the ranks together once per frame is the final
+ *            exchange of the finalised pixels (an all-to-all and an all-gather over all ranks).  With overlap that exchange leaves the
+ *            caller's stream: frame k's march -- token steps, the normals' stage, this rank's contributions -- is enqueued on the
+ *            caller's stream through the frame's communicator, its final exchange on the frame's side stream through a SECOND
+ *            communicator over the same ranks (kfx_comm::dup: its own order of operations, so it may run beside any main-stream
+ *            collective), into image / buffer set k % pipe_depth, while the caller's stream already carries frame k + 1's
+ *            preprocessing, SdfFuse (stream order keeps it behind the rank's own march k) and march.  Known-pose streams: rank r works
+ *            on frame k + 1 while the token of frame k is still on its way to rank world - 1; the frame rate is bound by a rank's own
+ *            work instead of the chain.  (A tracked loop needs the images of frame k for the pose of frame k + 1: no overlap there.)
+ *            Same bits as without overlap.  Frame k's images: kfx_slab_frame_images, valid after kfx_slab_frame_wait / _sync.
+ *            Transports whose collectives block the host (KFX_COMM_HOST_BLOCKING) enqueue frame k's final exchange while frame
+ *            k + pipe_depth - 1 is stepped, so the host runs ahead like the streams do. */
 #define KFX_SLAB_HALO_RECOMPUTE    0
 #define KFX_SLAB_HALO_EXCHANGE     1
 #define KFX_SLAB_RAYCAST_EXACT     0
@@ -172,6 +198,7 @@ int kfx_slab_raycast_exact_tiled(const kfx_image* depth, const kfx_image* norm, 
 #define KFX_SLAB_MERGE_ALLREDUCE   1
 #define KFX_SLAB_INPUTS_REPLICATE  0
 #define KFX_SLAB_INPUTS_BROADCAST  1
+#define KFX_SLAB_PIPE_MAX          4
 typedef struct kfx_slab_frame kfx_slab_frame;
 typedef struct kfx_slab_frame_config {
     kfx_volume local;                        /* this rank's stored planes [layout.s0, layout.s1), box = local_zmin .. local_zmax */
@@ -183,10 +210,15 @@ typedef struct kfx_slab_frame_config {
     unsigned bilateral_size;
     float near, far, trunc_dist, max_w, mincostheta;
     int halo, raycast, merge, inputs;        /* KFX_SLAB_* */
-    int overlap;                             /* 1: composite merge under the next frame (see above) */
+    int overlap;                             /* 1: composite merge under the next frame / exact raycast: pipelined frames (see above) */
     int tiles;                               /* exact raycast: image row-tiles of the hand-over (>= 1; 0: the library's default, 4) */
     int unchecked;                           /* 1: do not fail when the exact march leaves rays open (loop-back measurements) */
     int timing_slots;                        /* 0: no events */
+    /* raycast EXACT with overlap = 1 (pipelined frames, above): pipe_depth = the number of image / buffer sets, 2 .. KFX_SLAB_PIPE_MAX;
+     * set 0 is {ray_depth, ray_norm, ray_img}, sets 1 .. pipe_depth - 1 are pipe_images[3 (s - 1) ...] = {depth, norm, img} of the
+     * caller (device memory, the sizes of set 0).  0: no pipelining */
+    int pipe_depth;
+    kfx_image pipe_images[3 * (KFX_SLAB_PIPE_MAX - 1)];
 } kfx_slab_frame_config;
 #define KFX_SLAB_FRAME_TIMING_FIELDS 6      /* ms: preprocess (+ broadcast), SdfFuse (+ ghost planes), RaycastSdf kernels or the whole exact march,
                                                composite merge (NaN: exact), frame (first to last event), period (to the next frame's first event) */
@@ -196,8 +228,16 @@ int kfx_slab_frame_destroy(kfx_slab_frame* f);
 int kfx_slab_frame_configure(kfx_slab_frame* f, int halo, int raycast, int merge, int inputs, int overlap, int tiles);
 int kfx_slab_frame_reset(kfx_slab_frame* f, kfx_stream stream);   /* SdfReset(local, NaN) */
 int kfx_slab_frame_step(kfx_slab_frame* f, const kfx_image* raw, const float T_wc[12], const float* T_cw, unsigned parts, kfx_stream stream);
-/* make `stream` wait for an overlapped merge and report a failed exact march of an earlier frame (KFX_E_RANGE) */
+/* make `stream` wait for an overlapped merge / every pipelined frame's final exchange (enqueueing the ones a host-blocking transport
+ * still trails: a collective point, every rank calls) and report a failed exact march of an earlier frame (KFX_E_RANGE) */
 int kfx_slab_frame_wait(kfx_slab_frame* f, kfx_stream stream);
+/* where the rendering of `frame` (< 0: the last one stepped) lives: the configuration's ray_* images, or -- pipelined exact raycast --
+ * set frame % pipe_depth; KFX_E_RANGE once a later frame has taken the set */
+int kfx_slab_frame_images(const kfx_slab_frame* f, long long frame, kfx_image* depth, kfx_image* norm, kfx_image* img);
+/* pipelined exact raycast: make `stream` wait for the final exchange of ONE frame without enqueueing anybody else's -- possible once
+ * pipe_depth - 1 later frames have been stepped (a host-blocking transport enqueues it then; RCCL at once); KFX_E_RANGE before that
+ * and once the set has been taken by a later frame.  Not a collective point. */
+int kfx_slab_frame_wait_frame(kfx_slab_frame* f, long long frame, kfx_stream stream);
 /* synchronise `stream` and whatever the frame object still has in flight (an overlapped merge on its side stream); reports a failed
  * exact march of any frame so far */
 int kfx_slab_frame_sync(kfx_slab_frame* f, kfx_stream stream);

@@ -68,6 +68,7 @@ SIGNATURES = {
     "kfx_sdf_fuse_slab_h": (C.c_int, [PV, C.POINTER(KfxSlab), PI, PI, PF, PF, C.c_float, C.c_float, C.c_float, C.c_uint, C.c_void_p]),
     "kfx_sdf_fuse_count": (C.c_int, [PV, PI, PI, PF, PF, C.c_float, C.c_float, C.c_uint, C.c_void_p, C.c_void_p]),
     "kfx_raycast_sdf_count": (C.c_int, [PV, C.c_uint, C.c_uint, PF, PF, C.c_float, C.c_float, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "kfx_raycast_sdf_count_h": (C.c_int, [PV, C.c_uint, C.c_uint, PF, PF, C.c_float, C.c_float, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "kfx_sdf_fuse_h": (C.c_int, [PV, PI, PI, PF, PF, C.c_float, C.c_float, C.c_float, C.c_uint, C.c_void_p]),
     "kfx_raycast_sdf_h": (C.c_int, [PI, PI, PI, PV, PF, PF, C.c_float, C.c_float, C.c_float, C.c_int, C.c_void_p]),
     "kfx_raycast_sdf_levels": (C.c_int, [C.c_int, C.POINTER(PI), C.POINTER(PI), C.POINTER(PI), C.POINTER(PI), PV, PF, PF, C.c_float, C.c_float, C.c_float, C.c_int, C.c_void_p]),

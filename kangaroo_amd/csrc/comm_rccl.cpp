@@ -128,6 +128,47 @@ void rccl_destroy(kfx_comm* c)
     c->impl = nullptr;
 }
 
+int rccl_fill(kfx_comm* comm, RcclImpl* im, int rank, int world);
+
+// A second communicator over the same ranks (ncclCommSplit, one colour, the same rank order): its operations are matched among
+// themselves only, so a stream that issues through it needs no common order with the streams that use the original.  Every rank calls.
+int rccl_dup(kfx_comm* c, kfx_comm* out)
+{
+    if (!c || !out || !c->impl) return KFX_E_NULL;
+    RcclImpl* im = static_cast<RcclImpl*>(c->impl);
+    RcclImpl* n = new (std::nothrow) RcclImpl;
+    if (!n) return KFX_E_RANGE;
+    const ncclResult_t r = ncclCommSplit(im->comm, 0, c->rank, &n->comm, nullptr);
+    if (r != ncclSuccess || !n->comm) {
+        delete n;
+        return nccl_status(r != ncclSuccess ? r : ncclInternalError);
+    }
+    if (hipMalloc(&n->token, 4) != hipSuccess || hipMemset(n->token, 0, 4) != hipSuccess) {
+        ncclCommDestroy(n->comm);
+        delete n;
+        return KFX_E_NODEVICE;
+    }
+    return rccl_fill(out, n, c->rank, c->world);
+}
+
+int rccl_fill(kfx_comm* comm, RcclImpl* im, int rank, int world)
+{
+    comm->rank = rank;
+    comm->world = world;
+    comm->impl = im;
+    comm->all_reduce = rccl_all_reduce;
+    comm->exchange = rccl_exchange;
+    comm->barrier = rccl_barrier;
+    comm->destroy = rccl_destroy;
+    comm->broadcast = rccl_broadcast;
+    comm->all_to_all = rccl_all_to_all;
+    comm->all_gather = rccl_all_gather;
+    comm->exchange_v = rccl_exchange_v;
+    comm->flags = 0;   // collectives are enqueued on the stream; the host does not wait for its peers
+    comm->dup = rccl_dup;
+    return 0;
+}
+
 // Field 22 of /proc/<pid>/stat: the start time of a process in clock ticks since boot (-1: unreadable).  The command name in
 // field 2 may contain spaces and parentheses, so the fields are counted from the LAST ')'.
 long long start_ticks(const char* stat_path)
@@ -312,17 +353,7 @@ extern "C" int kfx_comm_create_rccl(kfx_comm* comm, int rank, int world, const c
         delete im;
         return KFX_E_NODEVICE;
     }
-    comm->rank = rank;
-    comm->world = world;
-    comm->impl = im;
-    comm->all_reduce = rccl_all_reduce;
-    comm->exchange = rccl_exchange;
-    comm->barrier = rccl_barrier;
-    comm->destroy = rccl_destroy;
-    comm->broadcast = rccl_broadcast;
-    comm->all_to_all = rccl_all_to_all;
-    comm->all_gather = rccl_all_gather;
-    comm->exchange_v = rccl_exchange_v;
+    rccl_fill(comm, im, rank, world);
     if (rank == 0 && world > 1) { // every rank has joined once ncclCommInitRank returns: the file has served its purpose
         rccl_barrier(comm);
         unlink(rendezvous_file);

@@ -20,6 +20,9 @@ struct kfx_frame {
     long long* ev_frame;        // frame recorded in each slot, -1: none
     unsigned char* ev_mask;     // which of the four events the frame in each slot recorded
     unsigned mask;              // which events the next steps record (kfx_frame_set_timing)
+    // the packed texel image {nx, ny, nz, depth} of the frame (owned): written by the fused vbo / normals launch of a step, staged by
+    // LDS-DMA in the SdfFuse of the SAME step (fuse.hip); a step that integrates without preprocessing lets kfx_sdf_fuse pack its own
+    kfx_image texels;
 };
 
 using namespace kfx;
@@ -52,12 +55,21 @@ extern "C" int kfx_frame_create(kfx_frame** out, const kfx_frame_config* cfg)
     f->ev_frame = nullptr;
     f->ev_mask = nullptr;
     f->mask = KFX_FRAME_EVENTS_ALL;
+    f->texels = kfx_image{0, nullptr, 0, 0};
+    {   // (no device yet -- the argument checks of tests/test_abi_cpu.py run without one -- or no memory: steps pack per call instead)
+        const size_t tpitch = (cfg->filtered.w * 16 + 255) / 256 * 256;
+        void* buf = nullptr;
+        if (tpitch < (1u << 24) && hipMalloc(&buf, tpitch * cfg->filtered.h) == hipSuccess) f->texels = kfx_image{tpitch, buf, cfg->filtered.w, cfg->filtered.h};
+        else (void)hipGetLastError();
+    }
     if (f->slots) {
         f->ev = new (std::nothrow) hipEvent_t[(size_t)f->slots * 4];
         f->ev_frame = new (std::nothrow) long long[f->slots];
         f->ev_mask = new (std::nothrow) unsigned char[f->slots];
         if (!f->ev || !f->ev_frame || !f->ev_mask) {
-            delete[] f->ev; delete[] f->ev_frame; delete[] f->ev_mask; delete f;
+            delete[] f->ev; delete[] f->ev_frame; delete[] f->ev_mask;
+            if (f->texels.ptr) (void)hipFree(f->texels.ptr);
+            delete f;
             return set_error(KFX_E_RANGE, "kfx_frame_create: out of memory");
         }
         for (int i = 0; i < f->slots; ++i) { f->ev_frame[i] = -1; f->ev_mask[i] = 0; }
@@ -66,7 +78,9 @@ extern "C" int kfx_frame_create(kfx_frame** out, const kfx_frame_config* cfg)
             if (e != hipSuccess) {
                 (void)hipGetLastError();
                 for (int k = 0; k < i; ++k) (void)hipEventDestroy(f->ev[k]);
-                delete[] f->ev; delete[] f->ev_frame; delete[] f->ev_mask; delete f;
+                delete[] f->ev; delete[] f->ev_frame; delete[] f->ev_mask;
+                if (f->texels.ptr) (void)hipFree(f->texels.ptr);
+                delete f;
                 return set_error((int)e, "kfx_frame_create: hipEventCreate");
             }
         }
@@ -85,6 +99,7 @@ extern "C" int kfx_frame_destroy(kfx_frame* f)
     }
     delete[] f->ev_frame;
     delete[] f->ev_mask;
+    if (f->texels.ptr) { (void)hipFree(f->texels.ptr); (void)hipGetLastError(); }
     delete f;
     return 0;
 }
@@ -169,15 +184,15 @@ extern "C" int kfx_frame_step(kfx_frame* f, const kfx_image* raw, const float T_
         }
     };
     record(0);
+    // the packed texels travel from this step's preprocess to this step's SdfFuse only (nobody else can have touched the maps in between)
+    const kfx_image* tex = ((parts & KFX_FRAME_PREPROCESS) && (parts & KFX_FRAME_FUSE) && f->texels.ptr) ? &f->texels : nullptr;
     if (!e && (parts & KFX_FRAME_PREPROCESS)) {
         e = kfx_bilateral_f32(&c.filtered, src, c.bilateral_gs, c.bilateral_gr, c.bilateral_size, c.bilateral_minval, 1, stream);
-        if (!e) e = kfx_depth_to_vbo_normals_f32(&c.vbo, &c.normals, &c.filtered, c.K, 1.0f, stream);
+        if (!e) e = depth_to_vbo_normals_texels(&c.vbo, &c.normals, &c.filtered, c.K, 1.0f, tex, stream);
     }
     record(1);
-    if (!e && (parts & KFX_FRAME_FUSE)) {
-        if (f->track) e = kfx_sdf_fuse_tracked(&c.vol, f->summary, &c.filtered, &c.normals, T_cw, c.K, c.trunc_dist, c.max_w, c.mincostheta, c.fuse_flags, stream);
-        else e = kfx_sdf_fuse(&c.vol, &c.filtered, &c.normals, T_cw, c.K, c.trunc_dist, c.max_w, c.mincostheta, c.fuse_flags, stream);
-    }
+    if (!e && (parts & KFX_FRAME_FUSE))
+        e = sdf_fuse_texels(&c.vol, f->track ? f->summary : nullptr, &c.filtered, &c.normals, tex, T_cw, c.K, c.trunc_dist, c.max_w, c.mincostheta, c.fuse_flags, stream);
     record(2);
     if (!e && (parts & KFX_FRAME_RAYCAST)) {
         if (f->track) e = kfx_raycast_sdf_tracked(&c.ray_depth, &c.ray_norm, &c.ray_img, &c.vol, f->summary, T_wc, c.K, c.near, c.far, c.trunc_dist, 1, stream);

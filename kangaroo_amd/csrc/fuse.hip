@@ -22,11 +22,20 @@
 // op issues in 4 cycles, twice a scalar op, so it only saves issue slots (0.755 -> 0.726 ms).
 #include <cstdlib>
 
+#include <sys/syscall.h>
+#include <unistd.h>
+
 #include <hip/hip_fp16.h>
 
 #include <type_traits>
 
 #include "kfx_device.h"
+
+// A/B builds: -DKFX_FUSE_STAGE_DMA=0 compiles the tiled kernels with the round-5 staging through registers (per texel: loads of the
+// normal and the depth, a repack, a ds_write_b128) instead of the LDS-DMA of the packed texel image
+#ifndef KFX_FUSE_STAGE_DMA
+#define KFX_FUSE_STAGE_DMA 0
+#endif
 
 namespace kfx {
 
@@ -61,6 +70,10 @@ struct FuseParams {
     int zoff_local;          // first plane of this launch within the view (fuse_launch splits the view into z-ranges)
     int xcd_swizzle;         // tiled kernels: n > 0 rotates the x-brick of a workgroup by (z-brick >> (n - 1)) (see k_sdf_fuse_tiled)
     int fuse_cull;           // fast tiled kernels: the brick cull by the tile's own costheta bound (KFX_FUSE_CULL=0 switches it off)
+    // packed texel image {nx, ny, nz, depth} (float4 per pixel of the depth image, rows `tpitch` bytes apart): what the tiled
+    // kernels stage by LDS-DMA (k_pack_texels / the fused preprocess write it; null: the kernels gather depth and normals themselves)
+    const unsigned char* tex;
+    unsigned tpitch;
 };
 
 struct Obs {
@@ -339,8 +352,19 @@ __device__ __forceinline__ void accumulate(const Obs& o, float max_w, float& ova
     ow = CELL::q(fminf(w, max_w));
 }
 
+// the four corners from the packed texel image (k_pack_texels: copies of the same normals and depths), one 16-byte load each
+__device__ __forceinline__ Corners fetch_texels(const FuseParams& p, int ix, int iy)
+{
+    const unsigned o = __umul24((unsigned)iy, p.tpitch) + (unsigned)ix * 16u;
+    const float4* b = reinterpret_cast<const float4*>(p.tex + o);
+    const float4* t = reinterpret_cast<const float4*>(p.tex + p.tpitch + o);
+    Corners c;
+    c.c00 = b[0]; c.c01 = b[1]; c.c10 = t[0]; c.c11 = t[1];
+    return c;
+}
+
 // One voxel: projection -> bounds test -> corner fetch -> observation.
-template <bool FAST, bool OFF32>
+template <bool FAST, bool OFF32, bool TEX = false>
 __device__ __forceinline__ Obs observe(const FuseParams& p, const V3 Pc)
 {
     Obs o;
@@ -351,7 +375,7 @@ __device__ __forceinline__ Obs observe(const FuseParams& p, const V3 Pc)
     project<FAST>(p, Pc, pu, pv, iz);
     if (in_bounds(p, pu, pv)) {
         const float fix = floorf(pu), fiy = floorf(pv); // quirk Q6: floorf, then integer conversion
-        const Corners c = OFF32 ? fetch_global32(p, (int)fix, (int)fiy) : fetch_global64(p, (int)fix, (int)fiy);
+        const Corners c = TEX ? fetch_texels(p, (int)fix, (int)fiy) : (OFF32 ? fetch_global32(p, (int)fix, (int)fiy) : fetch_global64(p, (int)fix, (int)fiy));
         o = finish<FAST>(p, Pc, iz, pu - fix, pv - fiy, c);
     }
     return o;
@@ -457,9 +481,7 @@ __global__ __launch_bounds__(64 * NW, (FAST && ZU == 2) ? 8 : (!FAST ? 6 : 1)) v
     __shared__ float s_part[TRACK ? 4 * 2 * 8 * 3 : 1];
     extern __shared__ __attribute__((aligned(16))) float4 s_tile[];
     __shared__ float s_pz[ZC];
-    __shared__ float s_box[NW][6];
     __shared__ float s_dmax[NW], s_cmin[NW];
-    __shared__ int s_bad[NW];
     __shared__ float4 s_tz[ZC]; // exact mode: {pz, T(0,2)*pz, T(1,2)*pz, T(2,2)*pz} per slice
     // (the wave index through readfirstlane: the compiler cannot tell that tid >> 6 is wave-uniform, and without it the slice
     // loop's bounds, the loop branch and everything derived from them are computed per lane)
@@ -491,64 +513,38 @@ __global__ __launch_bounds__(64 * NW, (FAST && ZU == 2) ? 8 : (!FAST ? 6 : 1)) v
 #pragma unroll
     for (int v = 0; v < 2; ++v) cam[v].init(p, p.bmin.x + p.size.x * (float)(x0 + v) / p.w1, py);
 
-    // ---- pixel rectangle of the brick: projections of its first and last slice ----
-    float umin = __builtin_inff(), umax = -__builtin_inff(), vmin = __builtin_inff(), vmax = -__builtin_inff();
-    float zmin = __builtin_inff(); // nearest camera-space Z of the brick (Z is affine along a column: ends suffice)
-    float cmax = 0.f;              // exact mode: largest |X|, |Y|, Z of the brick (affine too: the corner voxels hold the extremes)
-    bool bad = false;
-    if (live) {
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const float pz = s_pz[e ? (zend - 1 - zbeg) : 0];
-#pragma unroll
-            for (int v = 0; v < 2; ++v) {
-                const V3 Pc = cam[v].at(p, pz);
-                float pu, pv, iz;
-                project<FAST>(p, Pc, pu, pv, iz);
-                bad = bad || !(Pc.z > 0.f) || !(fabsf(pu) < 1e9f) || !(fabsf(pv) < 1e9f);
-                umin = fminf(umin, pu); umax = fmaxf(umax, pu);
-                vmin = fminf(vmin, pv); vmax = fmaxf(vmax, pv);
-                zmin = fminf(zmin, Pc.z);
-                if constexpr (!FAST) cmax = fmaxf(cmax, fmaxf(fmaxf(fabsf(Pc.x), fabsf(Pc.y)), Pc.z));
-            }
-        }
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) { // wave64 butterfly
-        umin = fminf(umin, __shfl_xor(umin, off, 64)); umax = fmaxf(umax, __shfl_xor(umax, off, 64));
-        vmin = fminf(vmin, __shfl_xor(vmin, off, 64)); vmax = fmaxf(vmax, __shfl_xor(vmax, off, 64));
-        zmin = fminf(zmin, __shfl_xor(zmin, off, 64));
-        if constexpr (!FAST) cmax = fmaxf(cmax, __shfl_xor(cmax, off, 64));
-    }
-    const bool wave_bad = __ballot(bad) != 0ull;
-    if (lane == 0) {
-        s_box[wv][0] = umin; s_box[wv][1] = umax; s_box[wv][2] = vmin; s_box[wv][3] = vmax; s_box[wv][4] = zmin;
-        s_box[wv][5] = cmax;
-        s_bad[wv] = wave_bad ? 1 : 0;
-    }
-    __syncthreads();
-    // (the four-wave form is kept as written: the bit-exact instantiations' register allocation is sensitive to it, see
-    //  scripts/check_fuse_codegen.py; minima and maxima: the order does not matter)
+    // ---- pixel rectangle of the brick: the projections of its eight corners ----
+    // A pinhole camera maps a convex body in front of it onto the convex hull of its vertices' images, so the corners of the brick --
+    // of its live part: the voxels inside the extents -- bound the pixel of every sample; Z and |X|, |Y| are affine / convex in the
+    // voxel index, so their extremes sit in the corners too.  Every wave evaluates the eight corners itself (lane & 7 = corner, the
+    // voxel's own expressions) and reduces over eight lanes with DPP: no LDS round trip, no barrier, ~50 vector instructions where
+    // projecting every lane's four end-slice voxels and reducing over the workgroup took ~170 (round 6; the rectangle decides which
+    // texels are staged and which bricks are skipped, never a value: a sample that rounding puts a hair outside the corners' hull
+    // falls into the one-texel slack).
+    float umin, umax, vmin, vmax, zmin, cmax = 0.f;
     bool any_bad;
-    if constexpr (NW == 4) {
-        zmin = fminf(fminf(s_box[0][4], s_box[1][4]), fminf(s_box[2][4], s_box[3][4]));
-        cmax = fmaxf(fmaxf(s_box[0][5], s_box[1][5]), fmaxf(s_box[2][5], s_box[3][5]));
-        umin = fminf(fminf(s_box[0][0], s_box[1][0]), fminf(s_box[2][0], s_box[3][0]));
-        umax = fmaxf(fmaxf(s_box[0][1], s_box[1][1]), fmaxf(s_box[2][1], s_box[3][1]));
-        vmin = fminf(fminf(s_box[0][2], s_box[1][2]), fminf(s_box[2][2], s_box[3][2]));
-        vmax = fmaxf(fmaxf(s_box[0][3], s_box[1][3]), fmaxf(s_box[2][3], s_box[3][3]));
-        any_bad = (s_bad[0] | s_bad[1] | s_bad[2] | s_bad[3]) != 0;
-    } else {
-        zmin = s_box[0][4]; cmax = s_box[0][5]; umin = s_box[0][0]; umax = s_box[0][1]; vmin = s_box[0][2]; vmax = s_box[0][3];
-        int bad_waves = s_bad[0];
-#pragma unroll
-        for (int k = 1; k < NW; ++k) {
-            zmin = fminf(zmin, s_box[k][4]); cmax = fmaxf(cmax, s_box[k][5]);
-            umin = fminf(umin, s_box[k][0]); umax = fmaxf(umax, s_box[k][1]);
-            vmin = fminf(vmin, s_box[k][2]); vmax = fmaxf(vmax, s_box[k][3]);
-            bad_waves |= s_bad[k];
-        }
-        any_bad = bad_waves != 0;
+    {
+        const int c = lane & 7;
+        const int xb0 = bxi * LX * 2, yb0 = (int)blockIdx.y * BY;
+        const int xc = (c & 1) ? min(xb0 + LX * 2, p.X) - 1 : xb0;
+        const int yc = (c & 2) ? min(yb0 + BY, p.Y) - 1 : yb0;
+        const float pzc = s_pz[(c & 4) ? (zend - 1 - zbeg) : 0];
+        CamXY<FAST> cc;
+        cc.init(p, p.bmin.x + p.size.x * (float)xc / p.w1, p.bmin.y + p.size.y * (float)yc / p.h1);
+        const V3 Pc = cc.at(p, pzc);
+        float pu, pv, iz;
+        project<FAST>(p, Pc, pu, pv, iz);
+        const bool bad = !(Pc.z > 0.f) || !(fabsf(pu) < 1e9f) || !(fabsf(pv) < 1e9f);
+        const auto fmin2 = [](float a, float b) { return fminf(a, b); };
+        const auto fmax2 = [](float a, float b) { return fmaxf(a, b); };
+        // (every lane holds the same values now; readfirstlane tells the compiler so -- what is derived from them below, the tile's
+        //  origin and width in the voxel loop's addresses included, belongs in scalar registers)
+        const auto uni = [](float x) { return __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(x))); };
+        umin = uni(wave8_combine(pu, fmin2)); umax = uni(wave8_combine(pu, fmax2));
+        vmin = uni(wave8_combine(pv, fmin2)); vmax = uni(wave8_combine(pv, fmax2));
+        zmin = uni(wave8_combine(Pc.z, fmin2));
+        if constexpr (!FAST) cmax = uni(wave8_combine(fmaxf(fmaxf(fabsf(Pc.x), fabsf(Pc.y)), Pc.z), fmax2));
+        any_bad = __ballot(bad) != 0ull;
     }
 
     bool use_tile = false;
@@ -579,7 +575,39 @@ __global__ __launch_bounds__(64 * NW, (FAST && ZU == 2) ? 8 : (!FAST ? 6 : 1)) v
     const bool whole = !TRACK || ((bxi + 1) * LX * 2 <= p.X && ((int)blockIdx.y + 1) * BY <= p.Y);
     const bool interior = __builtin_amdgcn_readfirstlane((int)(use_tile && whole && umin >= 2.01f && umax < p.dwb - 0.01f && vmin >= 2.01f && vmax < p.dhb - 0.01f)) != 0;
     float dmax = -__builtin_inff(); // farthest finite depth in the rectangle (fmaxf skips NaN texels)
-    if (use_tile) {
+    // Staging by LDS-DMA (gfx950 global_load_lds_dwordx4: 16 bytes per lane from a per-lane address straight to LDS at a wave-
+    // uniform base + lane * 16; no VGPR destination, no ds_write).  The rectangle's rows are shared out over the waves; a wave stages
+    // a row in chunks of 64 texels of the PACKED image {nx, ny, nz, depth} (p.tex), which lands as s_tile[r * tw + c]: the layout
+    // the loops below read.  Per 64 texels: one address add and one DMA instruction, where the register path below spends an index
+    // division, two address computations, a 16-byte and a 4-byte load, a repack and a ds_write_b128 PER TEXEL -- a quarter of this
+    // kernel's instructions at 1280x960, where a 4096-voxel brick stages 3000 texels.  dmax: every wave reads back the
+    // depths of the rows it staged itself once its own DMAs have landed (vmcnt(0) orders a wave's reads behind its own DMA; other
+    // waves' rows are read after the barrier below).  Texels are the same copies of the same pixels: same bits.
+    constexpr bool DMA = KFX_FUSE_STAGE_DMA && !DXT;
+    if constexpr (DMA) {
+        if (use_tile) {   // (uniform)
+            const unsigned char* base = p.tex + ((size_t)ty0 * p.tpitch + (size_t)tx0 * 16u);
+            for (int r = wv; r < th; r += NW) {
+                const unsigned char* src = base + (size_t)r * p.tpitch + (size_t)lane * 16u;
+                float4* dst = s_tile + r * tw;
+#pragma unroll 1   // (unrolled, hipcc keeps the eight chunks' exec masks in scalar registers across the whole kernel: 78 SGPRs, spills into VGPR lanes and from there to scratch)
+                for (int c0 = 0; c0 < tw; c0 += 64) {
+                    if (c0 + lane < tw)
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)c0 * 16u),
+                                                         (__attribute__((address_space(3))) void*)(dst + c0), 16, 0, 0);
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            for (int r = wv; r < th; r += NW) {
+                const float4* rowt = s_tile + r * tw;
+                for (int c = lane; c < tw; c += 64) dmax = fmaxf(dmax, rowt[c].w);
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) dmax = fmaxf(dmax, __shfl_xor(dmax, off, 64));
+            if (lane == 0) s_dmax[wv] = dmax;
+        }
+    }
+    if (!DMA && use_tile) {
         // Cooperative staging, flat over the rectangle's texels (consecutive threads = consecutive texels of a row), four
         // texels per thread requested before the first is consumed: a row-by-row loop waits one L2 round trip per
         // iteration (~15 of them per wave for the 90 x 30 texel rectangles of 1280x960 depth), and nothing else runs in
@@ -808,7 +836,7 @@ __global__ __launch_bounds__(64 * NW, (FAST && ZU == 2) ? 8 : (!FAST ? 6 : 1)) v
                     const float4* t = s_tile + (ry * (unsigned)tw + rx);
                     c.c00 = t[0]; c.c01 = t[1]; c.c10 = t[tw]; c.c11 = t[tw + 1];
                 } else {
-                    c = fetch_global32(p, ix, iy);
+                    c = DMA ? fetch_texels(p, ix, iy) : fetch_global32(p, ix, iy);
                 }
                 o = finish<FAST>(p, Pc, iz, pu - fix, pv - fiy, c);
             }
@@ -872,8 +900,8 @@ __global__ __launch_bounds__(64 * NW, (FAST && ZU == 2) ? 8 : (!FAST ? 6 : 1)) v
                     }
                     if constexpr (!INTERIOR) {
                         if (__builtin_expect(__ballot(stray) != 0ull, 0)) {
-                            o[0] = observe<false, true>(p, cam[0].at(p, tz.x));
-                            o[1] = observe<false, true>(p, cam[1].at(p, tz.x));
+                            o[0] = observe<false, true, DMA>(p, cam[0].at(p, tz.x));
+                            o[1] = observe<false, true, DMA>(p, cam[1].at(p, tz.x));
                             o[0].ok = o[0].ok && upd; o[1].ok = o[1].ok && upd;
                         }
                     }
@@ -960,8 +988,8 @@ __global__ __launch_bounds__(64 * NW, (FAST && ZU == 2) ? 8 : (!FAST ? 6 : 1)) v
                     for (int k = 0; k < ZU; ++k)
                         if (z + k < wz1) {
                             const float pz = s_pz[z + k - zbeg];
-                            o[k][0] = observe<FAST, true>(p, cam[0].at(p, pz));
-                            o[k][1] = observe<FAST, true>(p, cam[1].at(p, pz));
+                            o[k][0] = observe<FAST, true, DMA>(p, cam[0].at(p, pz));
+                            o[k][1] = observe<FAST, true, DMA>(p, cam[1].at(p, pz));
                             o[k][0].ok = o[k][0].ok && upd; o[k][1].ok = o[k][1].ok && upd;
                             any[k] = o[k][0].ok || o[k][1].ok;
                         }
@@ -1491,6 +1519,71 @@ __global__ __launch_bounds__(256) void k_fill_f32(float* __restrict__ base, size
 
 using namespace kfx;
 
+// ---- the packed texel image of the tiled kernels' LDS-DMA staging --------------------------------------------------------
+// {nx, ny, nz, depth} per pixel of the depth image: copies of the normal map's xyz and of the depth image (what the kernels'
+// register path packs texel by texel while it stages).
+__global__ __launch_bounds__(256) void k_pack_texels(const ImgView depth, const ImgView norm, unsigned char* __restrict__ tex, const size_t tpitch)
+{
+    const int u = blockIdx.x * 64 + (threadIdx.x & 63), v = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (u >= depth.w || v >= depth.h) return;
+    const float4 n = row<float4>(norm, (size_t)v)[u];
+    const float d = row<float>(depth, (size_t)v)[u];
+    reinterpret_cast<float4*>(tex + (size_t)v * tpitch)[u] = make_float4(n.x, n.y, n.z, d);
+}
+
+// Library scratch for callers that bring depth and normals only (kfx_sdf_fuse and its siblings; kfx_frame_step brings the packed
+// image its fused preprocess wrote).  One buffer per calling thread, device and stream: the pack launch and the SdfFuse launches
+// that read it are enqueued on the same stream by the same thread, so the next call's pack is ordered behind this call's reads;
+// another stream -- or another thread on the same stream: the tests' rank threads share the null stream -- gets its own buffer.
+struct TexScratch {
+    static constexpr int N = 4;
+    struct Entry { void* buf; size_t bytes; hipStream_t stream; int device; unsigned long used; };
+    Entry e[N] = {};
+    unsigned long tick = 0;
+    bool main_thread = false;
+    ~TexScratch()
+    {
+        // threads that come and go (rank threads of the tests and of apps --transport threads) give their buffers back; the main
+        // thread's go with the process (its destructor may run when the runtime is already on its way out)
+        if (main_thread) return;
+        for (Entry& x : e)
+            if (x.buf) { (void)hipFree(x.buf); (void)hipGetLastError(); }
+    }
+    void* get(size_t bytes, hipStream_t stream)
+    {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        Entry* hit = nullptr;
+        Entry* lru = &e[0];
+        for (Entry& x : e) {
+            if (x.buf && x.stream == stream && x.device == dev) { hit = &x; break; }
+            if (!x.buf) { if (lru->buf) lru = &x; } else if (lru->buf && x.used < lru->used) lru = &x;
+        }
+        if (!hit) {
+            hit = lru;
+            if (hit->buf) {   // (a fifth stream: the oldest entry's stream must be done with its buffer; hipFree synchronises)
+                (void)hipFree(hit->buf); (void)hipGetLastError();
+                hit->buf = nullptr; hit->bytes = 0;
+            }
+            hit->stream = stream; hit->device = dev;
+        }
+        if (hit->bytes < bytes) {
+            if (hit->buf) { (void)hipFree(hit->buf); (void)hipGetLastError(); hit->buf = nullptr; hit->bytes = 0; }
+            if (hipMalloc(&hit->buf, bytes) != hipSuccess) { (void)hipGetLastError(); hit->buf = nullptr; return nullptr; }
+            hit->bytes = bytes;
+        }
+        hit->used = ++tick;
+        return hit->buf;
+    }
+};
+static void* tex_scratch(size_t bytes, hipStream_t stream)
+{
+    thread_local TexScratch pool;
+    static const long main_tid = (long)getpid();
+    pool.main_thread = (long)syscall(SYS_gettid) == main_tid;
+    return pool.get(bytes, stream);
+}
+
 static int check_volume(const kfx_volume* vol, size_t cell = 8)
 {
     if (!vol || !vol->ptr) return set_error(KFX_E_NULL, "volume is null");
@@ -1573,6 +1666,8 @@ static int fuse_params(FuseParams& p, bool* small_images, const kfx_volume* vol,
     p.npitch = *small_images ? (unsigned)norm->pitch : 0u;
     p.sum_R = nullptr;
     p.sum_nbx = p.sum_nby = p.sum_bx0 = p.sum_by0 = p.sum_bz0 = p.sum_w = p.sum_h = p.sum_d = p.zoff_local = 0;
+    p.tex = nullptr;
+    p.tpitch = 0;
     static const int swizzle_env = [] { const char* e = getenv("KFX_FUSE_XCD_SWIZZLE"); const int v = e ? atoi(e) : 1; return v < 0 ? 0 : (v > 8 ? 8 : v); }();
     p.xcd_swizzle = swizzle_env;
     static const int cull_env = [] { const char* e = getenv("KFX_FUSE_CULL"); return e ? atoi(e) : 1; }();
@@ -1648,7 +1743,7 @@ static TilePlan tile_plan(const FuseParams& p, const Pose& T, const Intr& K, int
 template <typename CELL>
 static int fuse_launch(const kfx_volume* vol, const kfx_image* depth, const kfx_image* norm, const float T_cw[12],
                        const float K[4], float trunc_dist, float max_w, float mincostheta, unsigned flags, kfx_stream stream,
-                       const kfx_slab* slab = nullptr, kfx_sdf_summary* summary = nullptr)
+                       const kfx_slab* slab = nullptr, kfx_sdf_summary* summary = nullptr, const kfx_image* texels = nullptr)
 {
     FuseParams p;
     bool small_images = false;
@@ -1743,6 +1838,27 @@ static int fuse_launch(const kfx_volume* vol, const kfx_image* depth, const kfx_
             ranges[n_ranges++] = Range{z0, z1, plan};
             z0 = z1;
         }
+        // The packed texel image the kernels stage by LDS-DMA (k_sdf_fuse_tiled): the caller's (kfx_frame_step: written by its fused
+        // preprocess), else packed here into the library's scratch by one small launch (2-3 us at 640x480) -- unless every range
+        // runs the difference-tile kernel, which stages through registers.
+        bool any_plain = false;
+        for (int ri = 0; ri < n_ranges; ++ri) any_plain = any_plain || !ranges[ri].plan.dxt;
+        if (KFX_FUSE_STAGE_DMA && any_plain) {
+            const size_t tw_bytes = (size_t)depth->w * 16;
+            if (texels && texels->ptr && texels->w >= depth->w && texels->h >= depth->h && texels->pitch >= tw_bytes && texels->pitch < (1u << 24) &&
+                !(((uintptr_t)texels->ptr | texels->pitch) & 15)) {
+                p.tex = (const unsigned char*)texels->ptr;
+                p.tpitch = (unsigned)texels->pitch;
+            } else {
+                const size_t tpitch = (tw_bytes + 255) / 256 * 256;
+                void* buf = tex_scratch(tpitch * depth->h, s);   // (tpitch < 2^24: small_images bounds the normal map's pitch, which is at least as long)
+                if (!buf) return set_error((int)hipErrorOutOfMemory, "SdfFuse: no device memory for the packed texel image");
+                hipLaunchKernelGGL(k_pack_texels, dim3(ceil_div((int)depth->w, 64), ceil_div((int)depth->h, 4)), dim3(256), 0, s, p.depth, p.norm,
+                                   (unsigned char*)buf, tpitch);
+                p.tex = (const unsigned char*)buf;
+                p.tpitch = (unsigned)tpitch;
+            }
+        }
         for (int ri = 0; ri < n_ranges; ++ri) {
             const Range& rg = ranges[rev ? n_ranges - 1 - ri : ri];
             const int z0 = rg.z0, z1 = rg.z1;
@@ -1814,6 +1930,21 @@ extern "C" int kfx_sdf_fuse(const kfx_volume* vol, const kfx_image* depth, const
                             float mincostheta, unsigned flags, kfx_stream stream)
 {
     return fuse_launch<CellF32>(vol, depth, norm, T_cw, K, trunc_dist, max_w, mincostheta, flags, stream);
+}
+
+// kfx_sdf_fuse / kfx_sdf_fuse_tracked (summary != null) with the packed texel image brought by the caller (kfx_frame_step)
+int kfx::sdf_fuse_texels(const kfx_volume* vol, kfx_sdf_summary* summary, const kfx_image* depth, const kfx_image* norm, const kfx_image* texels,
+                         const float T_cw[12], const float K[4], float trunc_dist, float max_w, float mincostheta, unsigned flags, kfx_stream stream)
+{
+    return fuse_launch<CellF32>(vol, depth, norm, T_cw, K, trunc_dist, max_w, mincostheta, flags, stream, nullptr, summary, texels);
+}
+
+// kfx_sdf_fuse_slab with the packed texel image brought by the caller (kfx_slab_frame_step)
+int kfx::sdf_fuse_slab_texels(const kfx_volume* vol, const kfx_slab* slab, const kfx_image* depth, const kfx_image* norm, const kfx_image* texels,
+                              const float T_cw[12], const float K[4], float trunc_dist, float max_w, float mincostheta, unsigned flags, kfx_stream stream)
+{
+    if (!slab) return set_error(KFX_E_NULL, "kfx_sdf_fuse_slab: null slab");
+    return fuse_launch<CellF32>(vol, depth, norm, T_cw, K, trunc_dist, max_w, mincostheta, flags, stream, slab, nullptr, texels);
 }
 
 extern "C" int kfx_sdf_fuse_tracked(const kfx_volume* vol, kfx_sdf_summary* summary, const kfx_image* depth, const kfx_image* norm,

@@ -159,8 +159,10 @@ __global__ __launch_bounds__(256) void k_icp_point_plane(const IcpParams p)
     if (tid == 0) lss_store(p.sums + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * LSS_WORDS, sum);
 }
 
-// sum of the per-block systems, fixed order; the result replaces sums[0..28]
-__global__ __launch_bounds__(256) void k_lss_final(float* sums, const int nblocks)
+// sum of the per-block systems, fixed order; the result replaces sums[0..28].  mailbox (optional): 32 words of host memory mapped
+// into the device's address space -- the system again, then the sequence word `seq` with system-scope release: the host thread
+// that launched this spins on that word instead of enqueueing a copy and synchronising the stream (kfx_icp_point_plane).
+__global__ __launch_bounds__(256) void k_lss_final(float* sums, const int nblocks, float* mailbox, const unsigned seq)
 {
     __shared__ float lds[LSS_WORDS * 128];
     const int tid = threadIdx.x;
@@ -173,7 +175,13 @@ __global__ __launch_bounds__(256) void k_lss_final(float* sums, const int nblock
         acc.obs += __float_as_uint(s[28]);
     }
     lss_tree(acc, tid, 256, lds); // its first __syncthreads orders every read above before the store below
-    if (tid == 0) lss_store(sums, acc);
+    if (tid == 0) {
+        lss_store(sums, acc);
+        if (mailbox) {
+            lss_store(mailbox, acc);
+            __hip_atomic_store(reinterpret_cast<unsigned*>(mailbox) + 31, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -720,10 +728,55 @@ extern "C" int kfx_icp_point_plane(const kfx_image* Pl, const kfx_image* Pr, con
     p.sums = (float*)workspace->ptr;
     const int n = (int)(bx * by);
     const size_t lds_bytes = n >= 128 ? (size_t)LSS_WORDS * (n / 2) * sizeof(float) : 0;
+    // The result's way to the host (the reference's thrust::reduce blocks too; the application solves on the host between two of
+    // these calls, six times per frame, main.cpp:301-342).  A mailbox per calling thread: 128 bytes of page-locked host memory
+    // mapped into the device's address space; k_lss_final writes the 29 words and then a sequence word there (system-scope release)
+    // and this thread spins on the word -- no copy command, no stream synchronisation (profiles/r06_tracked: the copy's own
+    // 4.3 us and the wake-up after hipStreamSynchronize were 8 % of the drop-in application's frame).  KFX_ICP_MAILBOX=0, or no
+    // mapped memory: the round-5 path (a copy into a pinned staging word + hipStreamSynchronize).
+    struct Mailbox { float* host; float* dev; unsigned seq; };
+    thread_local Mailbox mb = {nullptr, nullptr, 0u};
+    static const bool mailbox_env = [] { const char* e = getenv("KFX_ICP_MAILBOX"); return !e || atoi(e) != 0; }();
+    if (mailbox_env && !mb.host) {
+        void* h = nullptr;
+        void* d = nullptr;
+        if (hipHostMalloc(&h, 128, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess && hipHostGetDevicePointer(&d, h, 0) == hipSuccess) {
+            memset(h, 0, 128);
+            mb.host = (float*)h; mb.dev = (float*)d;
+        } else {
+            (void)hipGetLastError();
+            if (h) (void)hipHostFree(h);
+            mb.host = nullptr;
+        }
+    }
+    const bool use_mailbox = mailbox_env && mb.host != nullptr;
+    const unsigned seq = use_mailbox ? (++mb.seq ? mb.seq : ++mb.seq) : 0u;   // (never 0: the word's initial value)
     hipLaunchKernelGGL(k_icp_point_plane, grid, block, lds_bytes, (hipStream_t)stream, p);
-    hipLaunchKernelGGL(k_lss_final, dim3(1), dim3(256), 0, (hipStream_t)stream, p.sums, (int)nblocks);
+    hipLaunchKernelGGL(k_lss_final, dim3(1), dim3(256), 0, (hipStream_t)stream, p.sums, (int)nblocks, use_mailbox ? mb.dev : nullptr, seq);
     int st = check_launch("kfx_icp_point_plane");
     if (st) return st;
+    if (use_mailbox) {
+        volatile unsigned* word = reinterpret_cast<volatile unsigned*>(mb.host) + 31;
+        // bounded: every 4096 looks the stream is asked whether it is still running -- a launch that failed on the device, or a
+        // word that never arrives, ends in the synchronising path below instead of a hang
+        bool arrived = false;
+        for (unsigned spins = 0; !arrived; ++spins) {
+            if (__atomic_load_n(const_cast<unsigned*>(word), __ATOMIC_ACQUIRE) == seq) { arrived = true; break; }
+            __builtin_ia32_pause();
+            if ((spins & 4095u) == 4095u) {
+                const hipError_t q = hipStreamQuery((hipStream_t)stream);
+                if (q != hipErrorNotReady) {   // finished (or failed): one last look, then the copy path decides
+                    (void)hipGetLastError();
+                    arrived = __atomic_load_n(const_cast<unsigned*>(word), __ATOMIC_ACQUIRE) == seq;
+                    break;
+                }
+            }
+        }
+        if (arrived) {
+            memcpy(out, mb.host, sizeof(*out));
+            return 0;
+        }
+    }
     // read-back through a pinned staging word per calling thread: a device -> pageable copy is staged by the runtime
     // and costs a second synchronisation
     thread_local kfx_lss6* stage = nullptr;

@@ -122,6 +122,17 @@ __device__ __forceinline__ float wave_xor_combine(float x, F op)
 }
 
 
+// op over the 8 lanes {8 k .. 8 k + 7} a lane belongs to, result in all of them: two quad permutes and DPP's row_half_mirror (lane i <->
+// lane 7 - i of the half row, which pairs the two quads) -- three VALU instructions per value, no LDS
+template <typename F>
+__device__ __forceinline__ float wave8_combine(float x, F op)
+{
+    x = wave_xor_combine<1>(x, op);
+    x = wave_xor_combine<2>(x, op);
+    const int o = __builtin_amdgcn_update_dpp(0, (int)__float_as_uint(x), 0x141, 0xF, 0xF, true);   // row_half_mirror
+    return op(x, __uint_as_float((unsigned)o));
+}
+
 // Row-major 3x4 pose, roo::Mat<float,3,4> (Mat.h:33-163)
 struct Pose { float m[12]; };
 // ImageIntrinsics {fu, fv, u0, v0} (ImageIntrinsics.h:51-200)
@@ -248,4 +259,12 @@ namespace kfx {
 int set_error(int code, const char* what);
 int check_launch(const char* what);
 int math_mode(); // KFX_MATH_EXACT / KFX_MATH_FAST
+// kfx_frame_step's pair (frame.hip): the fused vbo / normals launch also writes the packed texel image {nx, ny, nz, depth} that the
+// SdfFuse of the same frame stages by LDS-DMA (preprocess.hip, fuse.hip); texels may be null
+int depth_to_vbo_normals_texels(const kfx_image* vbo, const kfx_image* nrm, const kfx_image* depth, const float K[4], float scale,
+                                const kfx_image* texels, kfx_stream stream);
+int sdf_fuse_slab_texels(const kfx_volume* vol, const kfx_slab* slab, const kfx_image* depth, const kfx_image* norm, const kfx_image* texels,
+                         const float T_cw[12], const float K[4], float trunc_dist, float max_w, float mincostheta, unsigned flags, kfx_stream stream);
+int sdf_fuse_texels(const kfx_volume* vol, kfx_sdf_summary* summary, const kfx_image* depth, const kfx_image* norm, const kfx_image* texels,
+                    const float T_cw[12], const float K[4], float trunc_dist, float max_w, float mincostheta, unsigned flags, kfx_stream stream);
 } // namespace kfx

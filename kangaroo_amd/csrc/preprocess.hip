@@ -259,6 +259,8 @@ struct VboNrmParams {
     int w, h;
     Intr K;
     float scale;
+    unsigned char* tex;   // optional: the packed texel image {nx, ny, nz, depth} the tiled SdfFuse kernels stage by LDS-DMA (fuse.hip)
+    size_t tpitch;
 };
 __device__ __forceinline__ float4 vertex_of(const VboNrmParams& p, int u, int v)
 {
@@ -281,6 +283,8 @@ __global__ __launch_bounds__(256) void k_vbo_normals_f32(const VboNrmParams p)
         N = make_float4(-axb.x / mag, -axb.y / mag, -axb.z / mag, 1.0f);
     }
     reinterpret_cast<float4*>(p.nrm + (size_t)v * p.npitch)[u] = N;
+    if (p.tex)   // (uniform) what k_pack_texels would write: the normal's xyz and the depth image's own value
+        reinterpret_cast<float4*>(p.tex + (size_t)v * p.tpitch)[u] = make_float4(N.x, N.y, N.z, reinterpret_cast<const float*>(p.in + (size_t)v * p.in_pitch)[u]);
 }
 
 struct EwParams {
@@ -706,8 +710,18 @@ extern "C" int kfx_bilateral_guided_u8(const kfx_image* out, const kfx_image* in
 
 // DepthToVbo<float>(vbo, depth, K, scale) followed by NormalsFromVbo(nrm, vbo), one launch, identical outputs
 // (no reference counterpart: a launch-count optimisation for the frame pre-amble; vbo, nrm and depth of one size)
+namespace kfx {
+int depth_to_vbo_normals_texels(const kfx_image* vbo, const kfx_image* nrm, const kfx_image* depth, const float K[4], float scale,
+                                const kfx_image* texels, kfx_stream stream);
+}
 extern "C" int kfx_depth_to_vbo_normals_f32(const kfx_image* vbo, const kfx_image* nrm, const kfx_image* depth, const float K[4], float scale,
                                             kfx_stream stream)
+{
+    return kfx::depth_to_vbo_normals_texels(vbo, nrm, depth, K, scale, nullptr, stream);
+}
+// ... and, for kfx_frame_step, the packed texel image of the SdfFuse that follows from the same launch (texels: w x h float4, or null)
+int kfx::depth_to_vbo_normals_texels(const kfx_image* vbo, const kfx_image* nrm, const kfx_image* depth, const float K[4], float scale,
+                                     const kfx_image* texels, kfx_stream stream)
 {
     if (int e = check_image(vbo, 16, "DepthToVbo+Normals: vbo image")) return e;
     if (int e = check_image(nrm, 16, "DepthToVbo+Normals: normal image")) return e;
@@ -716,8 +730,10 @@ extern "C" int kfx_depth_to_vbo_normals_f32(const kfx_image* vbo, const kfx_imag
     if (vbo->w == 0 || vbo->h == 0) return 0;
     if (nrm->w != vbo->w || nrm->h != vbo->h || depth->w < vbo->w || depth->h < vbo->h)
         return set_error(KFX_E_SHAPE, "DepthToVbo+Normals: image sizes");
+    if (texels && (!texels->ptr || texels->w < vbo->w || texels->h < vbo->h || texels->pitch < vbo->w * 16 || (((uintptr_t)texels->ptr | texels->pitch) & 15)))
+        return set_error(KFX_E_SHAPE, "DepthToVbo+Normals: texel image");
     VboNrmParams p{(const unsigned char*)depth->ptr, depth->pitch, (unsigned char*)vbo->ptr, (unsigned char*)nrm->ptr, vbo->pitch, nrm->pitch,
-                   (int)vbo->w, (int)vbo->h, Intr{K[0], K[1], K[2], K[3]}, scale};
+                   (int)vbo->w, (int)vbo->h, Intr{K[0], K[1], K[2], K[3]}, scale, texels ? (unsigned char*)texels->ptr : nullptr, texels ? texels->pitch : 0};
     hipLaunchKernelGGL(k_vbo_normals_f32, dim3(ceil_div(p.w, 64), ceil_div(p.h, 4)), dim3(256), 0, (hipStream_t)stream, p);
     return check_launch("kfx_depth_to_vbo_normals_f32");
 }

@@ -1054,18 +1054,31 @@ extern "C" int kfx_raycast_sdf(const kfx_image* depth, const kfx_image* norm, co
     return raycast_launch<RayF32>(depth, norm, img, vol, T_wc, K, near, far, trunc_dist, subpix, stream);
 }
 
-extern "C" int kfx_raycast_sdf_count(const kfx_volume* vol, unsigned w, unsigned h, const float T_wc[12], const float K[4], float near, float far,
-                                     float trunc_dist, int subpix, unsigned* d_bitmap, unsigned long long* d_counters, kfx_stream stream)
+template <typename CELL>
+static int raycast_count_launch(const kfx_volume* vol, unsigned w, unsigned h, const float T_wc[12], const float K[4], float near, float far,
+                                float trunc_dist, int subpix, unsigned* d_bitmap, unsigned long long* d_counters, kfx_stream stream)
 {
     if (!d_bitmap || !d_counters) return set_error(KFX_E_NULL, "kfx_raycast_sdf_count: null argument");
     // the image arguments of ray_params() only give the launch its size: nothing is written to them
     kfx_image dummy = {(size_t)w * 16, (void*)(uintptr_t)16, w, h};
     RayParams p;
-    if (int e = ray_params<RayF32>(p, &dummy, &dummy, &dummy, vol, T_wc, K, near, far, trunc_dist, subpix)) return e;
+    if (int e = ray_params<CELL>(p, &dummy, &dummy, &dummy, vol, T_wc, K, near, far, trunc_dist, subpix)) return e;
     if (p.w == 0 || p.h == 0) return 0;
     p.dptr = p.nptr = p.iptr = nullptr;
-    hipLaunchKernelGGL(k_raycast_sdf_count<RayF32>, dim3(ceil_div(p.w, 64), ceil_div(p.h, 4)), dim3(256), 0, (hipStream_t)stream, p, d_bitmap, d_counters);
+    hipLaunchKernelGGL(k_raycast_sdf_count<CELL>, dim3(ceil_div(p.w, 64), ceil_div(p.h, 4)), dim3(256), 0, (hipStream_t)stream, p, d_bitmap, d_counters);
     return check_launch("kfx_raycast_sdf_count");
+}
+
+extern "C" int kfx_raycast_sdf_count(const kfx_volume* vol, unsigned w, unsigned h, const float T_wc[12], const float K[4], float near, float far,
+                                     float trunc_dist, int subpix, unsigned* d_bitmap, unsigned long long* d_counters, kfx_stream stream)
+{
+    return raycast_count_launch<RayF32>(vol, w, h, T_wc, K, near, far, trunc_dist, subpix, d_bitmap, d_counters, stream);
+}
+
+extern "C" int kfx_raycast_sdf_count_h(const kfx_volume* vol, unsigned w, unsigned h, const float T_wc[12], const float K[4], float near, float far,
+                                       float trunc_dist, int subpix, unsigned* d_bitmap, unsigned long long* d_counters, kfx_stream stream)
+{
+    return raycast_count_launch<RayF16>(vol, w, h, T_wc, K, near, far, trunc_dist, subpix, d_bitmap, d_counters, stream);
 }
 
 extern "C" int kfx_raycast_sdf_count_tracked(const kfx_volume* vol, kfx_sdf_summary* summary, unsigned w, unsigned h, const float T_wc[12], const float K[4],

@@ -4,6 +4,7 @@
 // No reference counterpart (the reference is single-GPU); the host-side protocol is the one of
 // kangaroo_amd/pipeline.py::SlabPipeline, so that C / C++ applications can use slabs without Python.
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <condition_variable>
 #include <mutex>
@@ -11,6 +12,7 @@
 
 #include "kfx_device.h"
 #include "../../include/kfx_slab.h"
+#include "slab_internal.h"
 
 namespace kfx {
 
@@ -211,6 +213,17 @@ struct ThreadGroup {
     // ranks passed after they had returned from k (round-3 advice).  seq[r] is rank r's own count of collectives.
     std::atomic<int> err[2][MAX_THREAD_RANKS];
     unsigned seq[MAX_THREAD_RANKS] = {};
+    // Point-to-point mode (kfx_comm_create_threads_p2p): the neighbour exchanges are matched PAIRWISE, in order, per directed link --
+    // the way RCCL matches ncclSend / ncclRecv -- instead of being a barrier of all ranks: a rank with nothing to pass on does not
+    // take part, ranks drift apart by whole frames (what kfx_slab_frame's pipelined frames are for), and a leg whose two sides
+    // disagree -- one side skips it, or names another size -- does not fail at once: it BLOCKS, as it would on RCCL, until
+    // `timeout_ms` have passed, and then reports KFX_E_TIMEOUT.  link[0][r]: r -> r + 1, link[1][r]: r -> r - 1; one message in
+    // flight per link (the sender returns from its call once the receiver has taken the message).
+    struct Link { const void* src = nullptr; size_t bytes = 0; bool full = false; };
+    bool p2p = false;
+    int timeout_ms = 0;
+    Link link[2][MAX_THREAD_RANKS];
+    ThreadGroup* dup_out = nullptr;   // threads_dup: the new group travels from rank 0 to the others through the old one
     ThreadGroup() { for (auto& set : err) for (auto& e : set) e.store(0); }
 
     void wait_all()
@@ -302,10 +315,71 @@ static int threads_exchange_v(kfx_comm* c, const void* send_lo, size_t bytes_sen
     return group_status(g, par);
 }
 
+// Point-to-point mode: post the sends, take what the neighbours posted, wait until the own messages have been taken.  No barrier,
+// no other rank involved; a leg without a partner -- or whose partner names another size -- blocks until the timeout.
+static int threads_exchange_v_p2p(kfx_comm* c, const void* send_lo, size_t bytes_send_lo, void* recv_lo, size_t bytes_recv_lo, const void* send_hi,
+                                  size_t bytes_send_hi, void* recv_hi, size_t bytes_recv_hi, kfx_stream stream)
+{
+    ThreadGroup* g = static_cast<ThreadGroup*>(c->impl);
+    const int r = c->rank;
+    const bool has_lo = r > 0, has_hi = r + 1 < g->world;
+    const bool sl = has_lo && bytes_send_lo, rl = has_lo && bytes_recv_lo, sh = has_hi && bytes_send_hi, rh = has_hi && bytes_recv_hi;
+    if (!sl && !rl && !sh && !rh) return 0;   // (as the RCCL transport: nothing to do, nobody to meet)
+    if ((sl && !send_lo) || (rl && !recv_lo) || (sh && !send_hi) || (rh && !recv_hi)) return set_error(KFX_E_NULL, "kfx_comm(threads, p2p) exchange: null buffer");
+    hipStream_t s = (hipStream_t)stream;
+    int st = hip_status(hipStreamSynchronize(s), "kfx_comm(threads, p2p) exchange");   // this rank's producers are done
+    const auto deadline = std::chrono::steady_clock::now() + std::chrono::milliseconds(g->timeout_ms > 0 ? g->timeout_ms : 10000);
+    std::unique_lock<std::mutex> lk(g->m);
+    ThreadGroup::Link* up = &g->link[0][r];      // r -> r + 1
+    ThreadGroup::Link* down = &g->link[1][r];    // r -> r - 1
+    const auto post = [&](ThreadGroup::Link* l, const void* src, size_t bytes) {
+        if (!g->cv.wait_until(lk, deadline, [&] { return !l->full; })) return false;   // (the previous message of this link was never taken)
+        l->src = src; l->bytes = bytes; l->full = true;
+        return true;
+    };
+    bool timed_out = false;
+    if (!st && sh) timed_out = !post(up, send_hi, bytes_send_hi) || timed_out;
+    if (!st && sl) timed_out = !post(down, send_lo, bytes_send_lo) || timed_out;
+    g->cv.notify_all();
+    // a message is taken only by a receive of ITS size: any other pairing waits (for ever on RCCL; here until the deadline)
+    const auto take = [&](ThreadGroup::Link* l, void* dst, size_t bytes) {
+        if (!g->cv.wait_until(lk, deadline, [&] { return l->full && l->bytes == bytes; })) return false;
+        const void* src = l->src;
+        lk.unlock();
+        int e = hip_status(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s), "kfx_comm(threads, p2p) exchange");
+        if (!e) e = hip_status(hipStreamSynchronize(s), "kfx_comm(threads, p2p) exchange");
+        lk.lock();
+        if (e && !st) st = e;
+        l->full = false;   // the sender may go on (its buffer has been read)
+        g->cv.notify_all();
+        return true;
+    };
+    if (!st && !timed_out && rl) timed_out = !take(&g->link[0][r - 1], recv_lo, bytes_recv_lo) || timed_out;   // what rank - 1 sends upwards
+    if (!st && !timed_out && rh) timed_out = !take(&g->link[1][r + 1], recv_hi, bytes_recv_hi) || timed_out;   // what rank + 1 sends downwards
+    // nobody reuses a send buffer before its reader is done
+    if (!st && !timed_out && sh) timed_out = !g->cv.wait_until(lk, deadline, [&] { return !up->full || up->src != send_hi; }) || timed_out;
+    if (!st && !timed_out && sl) timed_out = !g->cv.wait_until(lk, deadline, [&] { return !down->full || down->src != send_lo; }) || timed_out;
+    if (timed_out) {
+        // withdraw what was posted and never taken, so that a later exchange of this link starts clean
+        if (sh && up->full && up->src == send_hi) up->full = false;
+        if (sl && down->full && down->src == send_lo) down->full = false;
+        g->cv.notify_all();
+        return set_error(KFX_E_TIMEOUT, "kfx_comm(threads, p2p) exchange: a leg found no partner of its size in time (on RCCL this rank would hang: the two sides of a leg must derive the same byte count)");
+    }
+    return st;
+}
+
+static int threads_exchange_v_any(kfx_comm* c, const void* send_lo, size_t bsl, void* recv_lo, size_t brl, const void* send_hi, size_t bsh, void* recv_hi,
+                                  size_t brh, kfx_stream stream)
+{
+    if (static_cast<ThreadGroup*>(c->impl)->p2p) return threads_exchange_v_p2p(c, send_lo, bsl, recv_lo, brl, send_hi, bsh, recv_hi, brh, stream);
+    return threads_exchange_v(c, send_lo, bsl, recv_lo, brl, send_hi, bsh, recv_hi, brh, stream);
+}
+
 static int threads_exchange(kfx_comm* c, const void* send_lo, void* recv_lo, size_t bytes_lo, const void* send_hi, void* recv_hi,
                             size_t bytes_hi, kfx_stream stream)
 {
-    return threads_exchange_v(c, send_lo, bytes_lo, recv_lo, bytes_lo, send_hi, bytes_hi, recv_hi, bytes_hi, stream);
+    return threads_exchange_v_any(c, send_lo, bytes_lo, recv_lo, bytes_lo, send_hi, bytes_hi, recv_hi, bytes_hi, stream);
 }
 
 static int threads_broadcast(kfx_comm* c, void* buf, size_t bytes, int root, kfx_stream stream)
@@ -370,32 +444,62 @@ static void threads_destroy(kfx_comm* c)
     if (c) c->impl = nullptr;
 }
 
+static int threads_dup(kfx_comm* c, kfx_comm* out);
+
+static void threads_fill(kfx_comm* c, ThreadGroup* g, int rank)
+{
+    c->rank = rank;
+    c->world = g->world;
+    c->impl = g;
+    c->all_reduce = threads_all_reduce;
+    c->exchange = threads_exchange;
+    c->barrier = threads_barrier;
+    c->destroy = threads_destroy;
+    c->broadcast = threads_broadcast;
+    c->all_to_all = threads_all_to_all;
+    c->all_gather = threads_all_gather;
+    c->exchange_v = threads_exchange_v_any;
+    c->flags = KFX_COMM_HOST_BLOCKING;   // a collective returns when every rank has entered it
+    c->dup = threads_dup;
+}
+
+// A second group over the same threads (every rank calls; rank 0 destroys the copy like the original: through its own table)
+static int threads_dup(kfx_comm* c, kfx_comm* out)
+{
+    if (!c || !out || !c->impl) return set_error(KFX_E_NULL, "kfx_comm(threads) dup: null argument");
+    ThreadGroup* g = static_cast<ThreadGroup*>(c->impl);
+    if (c->rank == 0) {
+        ThreadGroup* n = new (std::nothrow) ThreadGroup;
+        if (n) { n->world = g->world; n->p2p = g->p2p; n->timeout_ms = g->timeout_ms; }
+        g->dup_out = n;
+    }
+    g->wait_all();
+    ThreadGroup* n = g->dup_out;
+    g->wait_all();   // (everybody has read it before a later dup overwrites it)
+    if (!n) return set_error(KFX_E_RANGE, "kfx_comm(threads) dup: out of memory");
+    threads_fill(out, n, c->rank);
+    return 0;
+}
+
 } // namespace kfx
 
 using namespace kfx;
 
-extern "C" int kfx_comm_create_threads(kfx_comm* comms, int world)
+static int create_threads(kfx_comm* comms, int world, bool p2p, int timeout_ms)
 {
     if (!comms) return set_error(KFX_E_NULL, "kfx_comm_create_threads: null comms");
     if (world < 1 || world > MAX_THREAD_RANKS) return set_error(KFX_E_RANGE, "kfx_comm_create_threads: world in [1, 16]");
     ThreadGroup* g = new (std::nothrow) ThreadGroup;
     if (!g) return set_error(KFX_E_RANGE, "kfx_comm_create_threads: out of memory");
     g->world = world;
-    for (int r = 0; r < world; ++r) {
-        comms[r].rank = r;
-        comms[r].world = world;
-        comms[r].impl = g;
-        comms[r].all_reduce = threads_all_reduce;
-        comms[r].exchange = threads_exchange;
-        comms[r].barrier = threads_barrier;
-        comms[r].destroy = threads_destroy;
-        comms[r].broadcast = threads_broadcast;
-        comms[r].all_to_all = threads_all_to_all;
-        comms[r].all_gather = threads_all_gather;
-        comms[r].exchange_v = threads_exchange_v;
-    }
+    g->p2p = p2p;
+    g->timeout_ms = timeout_ms;
+    for (int r = 0; r < world; ++r) threads_fill(&comms[r], g, r);
     return 0;
 }
+
+extern "C" int kfx_comm_create_threads(kfx_comm* comms, int world) { return create_threads(comms, world, false, 0); }
+extern "C" int kfx_comm_create_threads_p2p(kfx_comm* comms, int world, int timeout_ms) { return create_threads(comms, world, true, timeout_ms); }
 
 // ---- loop-back transport (kfx_slab.h): one rank of a `world`-rank job measured by itself ------------------------------
 namespace {
@@ -436,6 +540,8 @@ extern "C" int kfx_comm_create_loopback(kfx_comm* comm, int rank, int world)
     comm->rank = rank; comm->world = world; comm->impl = nullptr;
     comm->all_reduce = loop_all_reduce; comm->exchange = loop_exchange; comm->barrier = loop_barrier; comm->destroy = loop_destroy;
     comm->broadcast = loop_broadcast; comm->all_to_all = loop_all_to_all; comm->all_gather = loop_all_gather; comm->exchange_v = loop_exchange_v;
+    comm->flags = 0;
+    comm->dup = [](kfx_comm* c, kfx_comm* out) -> int { return kfx_comm_create_loopback(out, c->rank, c->world); };
     return 0;
 }
 
@@ -671,10 +777,25 @@ namespace {
 struct TiledScratch {
     size_t P, n;       // plane stride of a tile (pixels), pixels of the image
     int R, T;          // rows per tile, tiles
-    int *M, *Rz, *from_lo, *from_hi, *fin, *contrib, *open;
+    int *M, *Rz, *from_lo, *from_hi, *fin;
+    kfx::ExactFinalBufs own;   // the final exchange's buffers inside the scratch (set 0)
     size_t S;          // pixels per image strip of the final exchange (0 for one rank)
-    int *gathered, *mine;   // [world][6][S] received strips / the merged image; [6][S] this rank's merged strip
 };
+// sizes (ints) of the final exchange's four buffers: dense [6][n] for the all-reduce (and for one rank), by strips [world][6][S]
+// for the direct sends
+struct FinalSizes { size_t contrib, gathered, mine, open, S; };
+FinalSizes final_sizes(size_t w, size_t h, int world)
+{
+    FinalSizes z;
+    const size_t n = w * h;
+    z.S = world > 1 ? kfx_composite_strip_pixels(w, h, world) : 0;
+    const size_t by_strips = (size_t)(world > 1 ? world : 0) * 6 * z.S;
+    z.contrib = ((by_strips > 6 * n ? by_strips : 6 * n) + 63) / 64 * 64;
+    z.gathered = (by_strips + 63) / 64 * 64;
+    z.mine = (6 * z.S + 63) / 64 * 64;
+    z.open = 64;
+    return z;
+}
 // the scratch buffer's parts; returns its size in ints (scratch may be null: sizes only)
 size_t tiled_layout(TiledScratch& t, void* scratch, size_t w, size_t h, int tiles, int world)
 {
@@ -692,14 +813,18 @@ size_t tiled_layout(TiledScratch& t, void* scratch, size_t w, size_t h, int tile
     t.from_lo = take((size_t)t.T * 5 * t.P);
     t.from_hi = take((size_t)t.T * 5 * t.P);
     t.fin = take((t.n + 63) / 64 * 64);
-    // the final exchange: dense [6][n] for the all-reduce (and for one rank); by strips [world][6][S] for the direct sends
-    t.S = world > 1 ? kfx_composite_strip_pixels(w, h, world) : 0;
-    const size_t by_strips = (size_t)(world > 1 ? world : 0) * 6 * t.S;
-    t.contrib = take(((by_strips > 6 * t.n ? by_strips : 6 * t.n) + 63) / 64 * 64);
-    t.gathered = take((by_strips + 63) / 64 * 64);
-    t.mine = take((6 * t.S + 63) / 64 * 64);
-    t.open = take(64);
+    const FinalSizes z = final_sizes(w, h, world);
+    t.S = z.S;
+    t.own.contrib = take(z.contrib);
+    t.own.gathered = take(z.gathered);
+    t.own.mine = take(z.mine);
+    t.own.open = take(z.open);
     return o;
+}
+bool finalise_by_allreduce()
+{
+    static const bool v = [] { const char* e = getenv("KFX_SLAB_FINALISE"); return e && e[0] == 'a'; }();
+    return v;
 }
 } // namespace
 
@@ -710,10 +835,24 @@ extern "C" size_t kfx_slab_exact_tiled_scratch_bytes(size_t w, size_t h, int til
     return tiled_layout(t, nullptr, w, h, tiles, world < 1 ? 1 : world) * sizeof(int);
 }
 
-extern "C" int kfx_slab_raycast_exact_tiled(const kfx_image* depth, const kfx_image* norm, const kfx_image* img, void* scratch,
-                                            const kfx_volume* local, const kfx_slab_layout* L, const float T_wc[12], const float K[4],
-                                            float near, float far, float trunc_dist, int subpix, int tiles, kfx_comm* comm, kfx_stream stream,
-                                            int* h_open, int* steps_out)
+// One more set of the final exchange's buffers (kfx_slab_frame keeps several frames' final exchanges in flight: slab_internal.h)
+size_t kfx::exact_final_bytes(size_t w, size_t h, int world)
+{
+    const FinalSizes z = final_sizes(w, h, world < 1 ? 1 : world);
+    return (z.contrib + z.gathered + z.mine + z.open) * sizeof(int);
+}
+void kfx::exact_final_carve(ExactFinalBufs& b, void* mem, size_t w, size_t h, int world)
+{
+    const FinalSizes z = final_sizes(w, h, world < 1 ? 1 : world);
+    int* q = static_cast<int*>(mem);
+    b.contrib = q; q += z.contrib;
+    b.gathered = q; q += z.gathered;
+    b.mine = q; q += z.mine;
+    b.open = q;
+}
+
+static int exact_tiled_args(const kfx_image* depth, const kfx_image* norm, const kfx_image* img, void* scratch, const kfx_volume* local,
+                            const kfx_slab_layout* L, kfx_comm* comm, const float* T_wc, const float* K)
 {
     if (!depth || !norm || !img || !scratch || !local || !L || !comm || !T_wc || !K || !depth->ptr || !norm->ptr || !img->ptr)
         return set_error(KFX_E_NULL, "kfx_slab_raycast_exact_tiled: null argument");
@@ -724,12 +863,20 @@ extern "C" int kfx_slab_raycast_exact_tiled(const kfx_image* depth, const kfx_im
         return set_error(KFX_E_SHAPE, "kfx_slab_raycast_exact_tiled: image sizes");
     if ((((uintptr_t)depth->ptr | depth->pitch | (uintptr_t)img->ptr | img->pitch) & 3) || (((uintptr_t)norm->ptr | norm->pitch) & 15) || ((uintptr_t)scratch & 15))
         return set_error(KFX_E_ALIGN, "kfx_slab_raycast_exact_tiled: alignment");
+    if (comm->world > 1 && !comm->exchange_v) return set_error(KFX_E_RANGE, "kfx_slab_raycast_exact_tiled: the transport has no exchange_v");
+    return 0;
+}
+
+// The march: token steps, the normals' stage, and this rank's contribution to the final images left in `into` (null: the scratch's own
+// set).  Everything here is ordered on `stream`; the collectives are neighbour exchanges only (comm->exchange_v).
+int kfx::exact_tiled_march(void* scratch, const ExactFinalBufs* into, const kfx_volume* local, const kfx_slab_layout* L, const float T_wc[12],
+                           const float K[4], float near, float far, float trunc_dist, int subpix, int tiles, int w, int h, kfx_comm* comm,
+                           kfx_stream stream, int* steps_out)
+{
     const int world = comm->world, rank = comm->rank;
-    if (world > 1 && !comm->exchange_v) return set_error(KFX_E_RANGE, "kfx_slab_raycast_exact_tiled: the transport has no exchange_v");
-    const int w = (int)img->w, h = (int)img->h;
-    if (w == 0 || h == 0) return 0;
     TiledScratch t;
     tiled_layout(t, scratch, (size_t)w, (size_t)h, tiles, world);
+    const ExactFinalBufs& fb = into ? *into : t.own;
     const int T = t.T, R = t.R;
     const size_t P = t.P, tile_bytes = 5 * P * sizeof(int);
     hipStream_t s = (hipStream_t)stream;
@@ -745,7 +892,6 @@ extern "C" int kfx_slab_raycast_exact_tiled(const kfx_image* depth, const kfx_im
                                         (int)L->z0, (int)L->z1, w, h, T_wc, K, near, far, trunc_dist, subpix, stream));
     };
     auto rows_of = [&](int tile, int& v0, int& v1) { v0 = tile * R; v1 = v0 + R < h ? v0 + R : h; };
-    note(hip_status(hipMemsetAsync(t.open, 0, sizeof(int), s), "kfx_slab_raycast_exact_tiled"));
     int steps = 0;
     if (world == 1) {
         march(0, h, 1, nullptr, nullptr, 0);
@@ -793,7 +939,7 @@ extern "C" int kfx_slab_raycast_exact_tiled(const kfx_image* depth, const kfx_im
             const bool up = a_ok && rank + 1 < world, down = b_ok && rank > 0;
             const bool from_below = need_up && rank > 0 && A + 1 >= 0 && A + 1 < T, from_above = need_down && rank + 1 < world && B + 1 >= 0 && B + 1 < T;
             // (every rank calls the exchange in every step, with empty legs where it has nothing to pass on: a transport may
-            //  synchronise its ranks inside the call, as the in-process one does)
+            //  synchronise its ranks inside the call, as the in-process one does in its barrier mode)
             note(comm->exchange_v(comm, down ? t.M + (size_t)B * 5 * P : nullptr, down ? tile_bytes : 0, from_below ? t.from_lo : nullptr, from_below ? tile_bytes : 0,
                                   up ? t.M + (size_t)A * 5 * P : nullptr, up ? tile_bytes : 0, from_above ? t.from_hi : nullptr, from_above ? tile_bytes : 0, stream));
             got_lo = from_below; got_hi = from_above;
@@ -809,42 +955,81 @@ extern "C" int kfx_slab_raycast_exact_tiled(const kfx_image* depth, const kfx_im
         march(0, h, 0, recv_from_below ? t.from_lo : nullptr, recv_from_above ? t.from_hi : nullptr, 1);
         ++steps;
     }
-    // Every pixel has been given its final status by exactly one rank.  The results reach every rank by direct sends over the
-    // mesh, as the composite's strips do (composite.hip): rank j owns strip j of the image; one all-to-all brings the ranks'
-    // contributions to a strip -- zeros but for the one that finalised the pixel -- to its owner, the owner adds them up (integers:
-    // NaN and -0 survive), one all-gather returns the strips: 24 bytes per pixel cross each link once per phase, every link at once,
-    // where an all-reduce of the 7.4 MB (640 x 480) takes 14 dependent ring steps.  KFX_SLAB_FINALISE=allreduce (or a transport
-    // without all_to_all / all_gather) keeps the all-reduce; same images.
-    static const bool by_allreduce = [] { const char* e = getenv("KFX_SLAB_FINALISE"); return e && e[0] == 'a'; }();
-    const bool direct = world > 1 && !by_allreduce && comm->all_to_all && comm->all_gather;
+    // Every pixel has been given its final status by exactly one rank: this rank's contribution to the final images, in the layout of
+    // the exchange that follows (exact_tiled_finalise)
+    const bool direct = world > 1 && !finalise_by_allreduce() && comm->all_to_all && comm->all_gather;
     const unsigned S = direct ? (unsigned)t.S : 0u;
     const dim3 grid2(ceil_div(w, 64), ceil_div(h, 4));
     if (direct && (size_t)world * t.S > t.n)   // the last strip's padding travels too: defined (and summed as zero)
-        note(hip_status(hipMemsetAsync(t.contrib + ((size_t)(world - 1) * 6) * t.S, 0, 6 * t.S * sizeof(int), s), "kfx_slab_raycast_exact_tiled"));
-    hipLaunchKernelGGL(k_tiles_contrib, grid2, dim3(256), 0, s, t.M, t.Rz, t.fin, t.contrib, w, h, R, P, S);
-    note(check_launch("kfx_slab_raycast_exact_tiled"));
-    const int* final_planes = t.contrib;
-    if (direct) {
-        const size_t words = 6 * t.S;
-        note(comm->all_to_all(comm, t.contrib, t.gathered, words * sizeof(int), stream));
-        hipLaunchKernelGGL(k_strip_sum, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, s, t.gathered, t.mine, words, world);
-        note(check_launch("kfx_slab_raycast_exact_tiled"));
-        note(comm->all_gather(comm, t.mine, t.gathered, words * sizeof(int), stream));
-        final_planes = t.gathered;
-    } else if (world > 1) {
-        note(comm->all_reduce(comm, t.contrib, 6 * t.n, KFX_COMM_SUM_I32, stream));
-    }
-    const OutImages out{(unsigned char*)depth->ptr, (unsigned char*)norm->ptr, (unsigned char*)img->ptr, depth->pitch, norm->pitch, img->pitch, w, h};
-    hipLaunchKernelGGL(k_tiles_finish, grid2, dim3(256), 0, s, out, final_planes, t.open, S);
+        note(hip_status(hipMemsetAsync(fb.contrib + ((size_t)(world - 1) * 6) * t.S, 0, 6 * t.S * sizeof(int), s), "kfx_slab_raycast_exact_tiled"));
+    hipLaunchKernelGGL(k_tiles_contrib, grid2, dim3(256), 0, s, t.M, t.Rz, t.fin, fb.contrib, w, h, R, P, S);
     note(check_launch("kfx_slab_raycast_exact_tiled"));
     if (steps_out) *steps_out = steps;   // world + tiles - 1 token steps + the normals' stage (1 for a single rank)
-    if (h_open) {
-        note(hip_status(hipMemcpyAsync(h_open, t.open, sizeof(int), hipMemcpyDeviceToHost, s), "kfx_slab_raycast_exact_tiled"));
-        return status;
+    return status;
+}
+
+// The final exchange.  The results reach every rank by direct sends over the mesh, as the composite's strips do (composite.hip):
+// rank j owns strip j of the image; one all-to-all brings the ranks' contributions to a strip -- zeros but for the one that
+// finalised the pixel -- to its owner, the owner adds them up (integers: NaN and -0 survive), one all-gather returns the strips:
+// 24 bytes per pixel cross each link once per phase, every link at once, where an all-reduce of the 7.4 MB (640 x 480) takes 14
+// dependent ring steps.  KFX_SLAB_FINALISE=allreduce (or a transport without all_to_all / all_gather) keeps the all-reduce; same
+// images.  `comm` and `stream` may be another communicator over the same ranks and another stream than the march's
+// (kfx_slab_frame's pipelined frames): nothing here touches the march's planes.  h_open: a host-visible word that receives the
+// number of pixels left without a final status (zero) once `stream` has passed.
+int kfx::exact_tiled_finalise(const kfx_image* depth, const kfx_image* norm, const kfx_image* img, void* scratch, const ExactFinalBufs* from, int tiles,
+                              kfx_comm* comm, kfx_stream stream, int* h_open)
+{
+    const int world = comm->world;
+    const int w = (int)img->w, h = (int)img->h;
+    TiledScratch t;
+    tiled_layout(t, scratch, (size_t)w, (size_t)h, tiles, world);
+    const ExactFinalBufs& fb = from ? *from : t.own;
+    hipStream_t s = (hipStream_t)stream;
+    int status = 0;
+    auto note = [&](int e) { if (e && !status) status = e; };
+    note(hip_status(hipMemsetAsync(fb.open, 0, sizeof(int), s), "kfx_slab_raycast_exact_tiled"));
+    const bool direct = world > 1 && !finalise_by_allreduce() && comm->all_to_all && comm->all_gather;
+    const unsigned S = direct ? (unsigned)t.S : 0u;
+    const dim3 grid2(ceil_div(w, 64), ceil_div(h, 4));
+    const int* final_planes = fb.contrib;
+    if (direct) {
+        const size_t words = 6 * t.S;
+        note(comm->all_to_all(comm, fb.contrib, fb.gathered, words * sizeof(int), stream));
+        hipLaunchKernelGGL(k_strip_sum, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, s, fb.gathered, fb.mine, words, world);
+        note(check_launch("kfx_slab_raycast_exact_tiled"));
+        note(comm->all_gather(comm, fb.mine, fb.gathered, words * sizeof(int), stream));
+        final_planes = fb.gathered;
+    } else if (world > 1) {
+        note(comm->all_reduce(comm, fb.contrib, 6 * t.n, KFX_COMM_SUM_I32, stream));
     }
+    const OutImages out{(unsigned char*)depth->ptr, (unsigned char*)norm->ptr, (unsigned char*)img->ptr, depth->pitch, norm->pitch, img->pitch, w, h};
+    hipLaunchKernelGGL(k_tiles_finish, grid2, dim3(256), 0, s, out, final_planes, fb.open, S);
+    note(check_launch("kfx_slab_raycast_exact_tiled"));
+    if (h_open) note(hip_status(hipMemcpyAsync(h_open, fb.open, sizeof(int), hipMemcpyDeviceToHost, s), "kfx_slab_raycast_exact_tiled"));
+    return status;
+}
+
+extern "C" int kfx_slab_raycast_exact_tiled(const kfx_image* depth, const kfx_image* norm, const kfx_image* img, void* scratch,
+                                            const kfx_volume* local, const kfx_slab_layout* L, const float T_wc[12], const float K[4],
+                                            float near, float far, float trunc_dist, int subpix, int tiles, kfx_comm* comm, kfx_stream stream,
+                                            int* h_open, int* steps_out)
+{
+    if (int e = exact_tiled_args(depth, norm, img, scratch, local, L, comm, T_wc, K)) return e;
+    const int w = (int)img->w, h = (int)img->h;
+    if (w == 0 || h == 0) return 0;
+    // (a local failure of the march does not keep this rank out of the final exchange its peers enter)
+    int status = exact_tiled_march(scratch, nullptr, local, L, T_wc, K, near, far, trunc_dist, subpix, tiles, w, h, comm, stream, steps_out);
     int n_open = 0;
-    note(hip_status(hipMemcpyAsync(&n_open, t.open, sizeof(int), hipMemcpyDeviceToHost, s), "kfx_slab_raycast_exact_tiled"));
-    note(hip_status(hipStreamSynchronize(s), "kfx_slab_raycast_exact_tiled"));
+    const int e = exact_tiled_finalise(depth, norm, img, scratch, nullptr, tiles, comm, stream, h_open ? h_open : nullptr);
+    if (e && !status) status = e;
+    if (h_open) return status;
+    hipStream_t s = (hipStream_t)stream;
+    TiledScratch t;
+    tiled_layout(t, scratch, (size_t)w, (size_t)h, tiles, comm->world);
+    const int c = hip_status(hipMemcpyAsync(&n_open, t.own.open, sizeof(int), hipMemcpyDeviceToHost, s), "kfx_slab_raycast_exact_tiled");
+    if (c && !status) status = c;
+    const int y = hip_status(hipStreamSynchronize(s), "kfx_slab_raycast_exact_tiled");
+    if (y && !status) status = y;
     if (!status && n_open) status = set_error(KFX_E_RANGE, "kfx_slab_raycast_exact_tiled: rays without a final status after the hand-over");
     return status;
 }

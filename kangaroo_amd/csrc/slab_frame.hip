@@ -11,10 +11,14 @@
 
 #include "kfx_device.h"
 #include "../../include/kfx_slab.h"
+#include "slab_internal.h"
 
 namespace {
 constexpr int EV = 5;          // events per frame: before preprocess, before SdfFuse, after SdfFuse, after the march, after the merge
 constexpr int OPEN_SLOTS = 8;  // exact march: frames whose "rays left open" word may still be on its way to the host
+constexpr int PIPE_MAX = KFX_SLAB_PIPE_MAX;
+// a frame of the pipelined exact raycast whose final exchange has not been enqueued yet (host-blocking transports trail by pipe - 1 frames)
+struct PendingFinal { long long frame; int set, os, slot, tiles; unsigned timing; };
 }
 
 struct kfx_slab_frame {
@@ -36,6 +40,26 @@ struct kfx_slab_frame {
     hipStream_t side;
     hipEvent_t marched, merged;
     int merge_pending;
+    // Pipelined exact raycast (raycast EXACT + overlap, world > 1): frame k's march -- token steps, normals' stage, this rank's
+    // contributions -- runs on the caller's stream through `comm`; its final exchange (all-to-all + strip sums + all-gather + the
+    // images) runs on `side` through `side_comm`, a second communicator over the same ranks, into buffer / image set k % pipe, while
+    // the caller's stream already carries frame k + 1: a rank's frame rate is bound by what IT has to do, not by the slowest token's
+    // way through all ranks.  Transports whose collectives block the host enqueue a frame's final exchange pipe - 1
+    // frames later, so that the host is not held in it either.
+    kfx_comm side_comm;
+    int have_side_comm;
+    int pipe;                                // buffer / image sets in use (2 .. PIPE_MAX; 0: not pipelined)
+    void* fin_mem[PIPE_MAX];
+    kfx::ExactFinalBufs fin[PIPE_MAX];
+    size_t fin_bytes;
+    hipEvent_t marched_ev[PIPE_MAX], fin_done[PIPE_MAX];
+    int fin_inflight[PIPE_MAX];              // fin_done[set] has been recorded and the caller's stream has not waited for it since
+    PendingFinal pending[PIPE_MAX];
+    int n_pending;
+    long long rendered;                      // the latest frame whose final exchange has been enqueued (-1: none)
+    // the packed texel image of the frame (owned; fuse.hip): written by the fused vbo / normals launch, staged by the SdfFuse of the same step
+    kfx_image texels;
+    int* agree;                              // a device word: the ranks' common verdict on a configure
     // timing ring
     int slots;
     unsigned timing;                         // which of the five events the next steps record (bit k: event k)
@@ -64,17 +88,30 @@ static int check_policies(const kfx_slab_frame_config& c, int world)
     if (c.tiles < 0 || c.tiles > 64) return set_error(KFX_E_RANGE, "kfx_slab_frame: tiles in [0, 64]");
     // an overlapped merge issues its collectives from the side stream while the main stream may issue the ghost-plane exchange or
     // the input broadcast of the next frame: two sequences of collectives whose relative order could differ between ranks
-    if (c.overlap && world > 1 && (c.raycast != KFX_SLAB_RAYCAST_COMPOSITE || c.halo != KFX_SLAB_HALO_RECOMPUTE || c.inputs != KFX_SLAB_INPUTS_REPLICATE))
-        return set_error(KFX_E_RANGE, "kfx_slab_frame: overlap needs the composite raycast, recomputed ghost planes and replicated inputs");
+    // (the exact raycast's overlap puts the final exchange on a second communicator -- its own order of operations -- so it may run
+    //  beside any main-stream collective; it needs that communicator and at least two image sets)
+    if (c.overlap && world > 1 && c.raycast == KFX_SLAB_RAYCAST_COMPOSITE && (c.halo != KFX_SLAB_HALO_RECOMPUTE || c.inputs != KFX_SLAB_INPUTS_REPLICATE))
+        return set_error(KFX_E_RANGE, "kfx_slab_frame: the composite's overlap needs recomputed ghost planes and replicated inputs");
+    if (c.overlap && world > 1 && c.raycast == KFX_SLAB_RAYCAST_EXACT) {
+        if (c.pipe_depth < 2 || c.pipe_depth > PIPE_MAX) return set_error(KFX_E_RANGE, "kfx_slab_frame: the exact raycast's overlap needs pipe_depth in [2, KFX_SLAB_PIPE_MAX]");
+        for (int k = 0; k < 3 * (c.pipe_depth - 1); ++k) {
+            const kfx_image& im = c.pipe_images[k];
+            const size_t elem = (k % 3 == 1) ? 16 : 4;
+            if (!im.ptr || im.w < c.ray_img.w || im.h < c.ray_img.h || im.pitch < c.ray_img.w * elem || (((uintptr_t)im.ptr | im.pitch) & (elem - 1)))
+                return set_error(KFX_E_SHAPE, "kfx_slab_frame: pipe_images (sets 1 .. pipe_depth - 1 of {ray_depth, ray_norm, ray_img})");
+        }
+    }
     return 0;
 }
 
+// (the new buffer first: a failed allocation leaves the old one -- and with it the old policies -- usable; round-5 advice)
 static int grow(void** p, size_t* have, size_t need)
 {
     if (need <= *have) return 0;
+    void* q = nullptr;
+    if (int e = hip_status(hipMalloc(&q, need), "kfx_slab_frame: hipMalloc")) return e;
     if (*p) (void)hipFree(*p);
-    *p = nullptr; *have = 0;
-    if (int e = hip_status(hipMalloc(p, need), "kfx_slab_frame: hipMalloc")) return e;
+    *p = q;
     *have = need;
     return 0;
 }
@@ -95,7 +132,44 @@ static int ensure_scratch(kfx_slab_frame* f, const kfx_slab_frame_config& c)
     }
     if (c.inputs == KFX_SLAB_INPUTS_BROADCAST && world > 1)
         if (int e = grow(&f->bcast, &f->bcast_bytes, c.filtered.w * c.filtered.h * 20 + 256)) return e;
+    if (c.raycast == KFX_SLAB_RAYCAST_EXACT && c.overlap && world > 1) {
+        // the sets of the final exchange's buffers, the events between the two streams, the second communicator
+        const size_t need = kfx::exact_final_bytes(w, h, world);
+        for (int k = 0; k < c.pipe_depth; ++k) {
+            if (need > f->fin_bytes || !f->fin_mem[k]) {
+                void* q = nullptr;
+                if (int e = hip_status(hipMalloc(&q, need), "kfx_slab_frame: hipMalloc")) return e;
+                if (f->fin_mem[k]) (void)hipFree(f->fin_mem[k]);
+                f->fin_mem[k] = q;
+            }
+            kfx::exact_final_carve(f->fin[k], f->fin_mem[k], w, h, world);
+            if (!f->marched_ev[k]) if (int e = hip_status(hipEventCreateWithFlags(&f->marched_ev[k], hipEventDisableTiming), "kfx_slab_frame: hipEventCreate")) return e;
+            if (!f->fin_done[k]) if (int e = hip_status(hipEventCreateWithFlags(&f->fin_done[k], hipEventDisableTiming), "kfx_slab_frame: hipEventCreate")) return e;
+        }
+        if (need > f->fin_bytes) f->fin_bytes = need;
+        if (!f->have_side_comm) {
+            if (!f->comm->dup) return set_error(KFX_E_RANGE, "kfx_slab_frame: the exact raycast's overlap needs a transport that can duplicate its communicator (kfx_comm::dup)");
+            if (int e = f->comm->dup(f->comm, &f->side_comm)) return set_error(e, "kfx_slab_frame: kfx_comm::dup");
+            f->have_side_comm = 1;
+        }
+    }
     return 0;
+}
+
+// A configure succeeds on every rank or on none: the ranks add up their failures (a rank that could not allocate must not run the
+// old policies against peers that run the new ones: they would enter different collectives and wait for ever).  Every rank calls.
+static int ranks_agree(kfx_slab_frame* f, int local_status)
+{
+    if (f->comm->world == 1 || !f->agree) return local_status;
+    int flag = local_status ? 1 : 0, sum = 0;
+    int e = hip_status(hipMemcpy(f->agree, &flag, sizeof(int), hipMemcpyHostToDevice), "kfx_slab_frame: hipMemcpy");
+    const int c = f->comm->all_reduce(f->comm, f->agree, 1, KFX_COMM_SUM_I32, nullptr);
+    if (c && !e) e = c;
+    if (!e) e = hip_status(hipStreamSynchronize(nullptr), "kfx_slab_frame");
+    if (!e) e = hip_status(hipMemcpy(&sum, f->agree, sizeof(int), hipMemcpyDeviceToHost), "kfx_slab_frame: hipMemcpy");
+    if (local_status) return local_status;
+    if (e) return e;
+    return sum ? set_error(KFX_E_RANGE, "kfx_slab_frame: another rank could not adopt the configuration (kept the previous one on every rank)") : 0;
 }
 
 extern "C" int kfx_slab_frame_create(kfx_slab_frame** out, const kfx_slab_frame_config* cfg, kfx_comm* comm)
@@ -123,7 +197,16 @@ extern "C" int kfx_slab_frame_create(kfx_slab_frame** out, const kfx_slab_frame_
     f->slots = cfg->timing_slots;
     f->timing = 31u;
     for (int i = 0; i < OPEN_SLOTS; ++i) f->open_frame[i] = -1;
-    int e = ensure_scratch(f, f->cfg);
+    f->rendered = -1;
+    f->pipe = (cfg->overlap && cfg->raycast == KFX_SLAB_RAYCAST_EXACT && comm->world > 1) ? cfg->pipe_depth : 0;
+    {   // the packed texel image of the frame's SdfFuse (no memory: the fuse packs per call instead)
+        const size_t tpitch = (cfg->filtered.w * 16 + 255) / 256 * 256;
+        void* buf = nullptr;
+        if (tpitch < (1u << 24) && hipMalloc(&buf, tpitch * cfg->filtered.h) == hipSuccess) f->texels = kfx_image{tpitch, buf, cfg->filtered.w, cfg->filtered.h};
+        else (void)hipGetLastError();
+    }
+    int e = hip_status(hipMalloc((void**)&f->agree, 64), "kfx_slab_frame_create: hipMalloc");
+    if (!e) e = ensure_scratch(f, f->cfg);
     if (!e) e = hip_status(hipHostMalloc((void**)&f->h_open, OPEN_SLOTS * sizeof(int), hipHostMallocDefault), "kfx_slab_frame_create: hipHostMalloc");
     if (!e) for (int i = 0; i < OPEN_SLOTS; ++i) f->h_open[i] = 0;
     for (int i = 0; i < OPEN_SLOTS && !e; ++i) e = hip_status(hipEventCreateWithFlags(&f->open_done[i], hipEventDisableTiming), "kfx_slab_frame_create: hipEventCreate");
@@ -146,9 +229,12 @@ extern "C" int kfx_slab_frame_create(kfx_slab_frame** out, const kfx_slab_frame_
     return 0;
 }
 
+static int flush_pending(kfx_slab_frame* f);
+
 extern "C" int kfx_slab_frame_destroy(kfx_slab_frame* f)
 {
     if (!f) return 0;
+    (void)flush_pending(f);   // (collectives: every rank destroys its frame at the same point)
     (void)hipDeviceSynchronize();
     if (f->ev) {
         for (int i = 0; i < f->slots * EV; ++i) if (f->ev[i]) (void)hipEventDestroy(f->ev[i]);
@@ -159,6 +245,14 @@ extern "C" int kfx_slab_frame_destroy(kfx_slab_frame* f)
     for (int i = 0; i < OPEN_SLOTS; ++i) if (f->open_done[i]) (void)hipEventDestroy(f->open_done[i]);
     if (f->marched) (void)hipEventDestroy(f->marched);
     if (f->merged) (void)hipEventDestroy(f->merged);
+    for (int k = 0; k < PIPE_MAX; ++k) {
+        if (f->marched_ev[k]) (void)hipEventDestroy(f->marched_ev[k]);
+        if (f->fin_done[k]) (void)hipEventDestroy(f->fin_done[k]);
+        if (f->fin_mem[k]) (void)hipFree(f->fin_mem[k]);
+    }
+    if (f->have_side_comm && f->side_comm.destroy) f->side_comm.destroy(&f->side_comm);
+    if (f->texels.ptr) (void)hipFree(f->texels.ptr);
+    if (f->agree) (void)hipFree(f->agree);
     if (f->side) (void)hipStreamDestroy(f->side);
     if (f->h_open) (void)hipHostFree(f->h_open);
     if (f->exact) (void)hipFree(f->exact);
@@ -200,6 +294,50 @@ static int check_open(kfx_slab_frame* f, bool all)
     return 0;
 }
 
+// where frame `frame`'s rendering lives: set frame % pipe of the pipelined exact raycast (set 0 = the configuration's ray_* images)
+static void images_of(const kfx_slab_frame* f, int set, const kfx_image** d, const kfx_image** n, const kfx_image** i)
+{
+    const kfx_slab_frame_config& c = f->cfg;
+    if (set <= 0) { *d = &c.ray_depth; *n = &c.ray_norm; *i = &c.ray_img; return; }
+    *d = &c.pipe_images[(set - 1) * 3]; *n = &c.pipe_images[(set - 1) * 3 + 1]; *i = &c.pipe_images[(set - 1) * 3 + 2];
+}
+
+// the final exchange of the oldest pending frame, enqueued on the side stream through the side communicator (collectives: every rank
+// gets here at the same point of its own sequence of calls)
+static int finalise_oldest(kfx_slab_frame* f)
+{
+    if (f->n_pending <= 0) return 0;
+    const PendingFinal P = f->pending[0];
+    for (int k = 1; k < f->n_pending; ++k) f->pending[k - 1] = f->pending[k];
+    f->n_pending -= 1;
+    int status = 0;
+    const auto note = [&](int e) { if (e && !status) status = e; };
+    note(hip_status(hipStreamWaitEvent(f->side, f->marched_ev[P.set], 0), "kfx_slab_frame: hipStreamWaitEvent"));
+    const kfx_image *d, *n, *i;
+    images_of(f, P.set, &d, &n, &i);
+    note(kfx::exact_tiled_finalise(d, n, i, f->exact, &f->fin[P.set], P.tiles, &f->side_comm, (kfx_stream)f->side, f->h_open + P.os));
+    if (hipEventRecord(f->open_done[P.os], f->side) == hipSuccess) f->open_frame[P.os] = P.frame;
+    else (void)hipGetLastError();
+    if (P.slot >= 0 && (P.timing & 16u) && f->ev_frame[P.slot] == P.frame) {
+        if (hipEventRecord(f->ev[(size_t)P.slot * EV + 4], f->side) == hipSuccess) f->ev_mask[P.slot] |= 16u;
+        else (void)hipGetLastError();
+    }
+    note(hip_status(hipEventRecord(f->fin_done[P.set], f->side), "kfx_slab_frame: hipEventRecord"));
+    f->fin_inflight[P.set] = 1;
+    f->rendered = P.frame;
+    return status;
+}
+
+static int flush_pending(kfx_slab_frame* f)
+{
+    int status = 0;
+    while (f->n_pending > 0) {
+        const int e = finalise_oldest(f);
+        if (e && !status) status = e;
+    }
+    return status;
+}
+
 extern "C" int kfx_slab_frame_wait(kfx_slab_frame* f, kfx_stream stream)
 {
     if (!f) return set_error(KFX_E_NULL, "kfx_slab_frame_wait: null frame");
@@ -208,8 +346,37 @@ extern "C" int kfx_slab_frame_wait(kfx_slab_frame* f, kfx_stream stream)
         e = hip_status(hipStreamWaitEvent((hipStream_t)stream, f->merged, 0), "kfx_slab_frame_wait: hipStreamWaitEvent");
         f->merge_pending = 0;
     }
+    // pipelined exact raycast: every frame stepped so far gets its final exchange enqueued, and `stream` waits for all of them
+    const int p = flush_pending(f);
+    if (p && !e) e = p;
+    for (int k = 0; k < PIPE_MAX; ++k)
+        if (f->fin_inflight[k]) {
+            const int w = hip_status(hipStreamWaitEvent((hipStream_t)stream, f->fin_done[k], 0), "kfx_slab_frame_wait: hipStreamWaitEvent");
+            if (w && !e) e = w;
+        }
     const int o = check_open(f, false);
     return e ? e : o;
+}
+
+extern "C" int kfx_slab_frame_wait_frame(kfx_slab_frame* f, long long frame, kfx_stream stream)
+{
+    if (!f) return set_error(KFX_E_NULL, "kfx_slab_frame_wait_frame: null frame");
+    if (f->pipe <= 0) return kfx_slab_frame_wait(f, stream);
+    if (frame < 0 || frame >= f->frames || f->frames - frame > f->pipe) return set_error(KFX_E_RANGE, "kfx_slab_frame_wait_frame: that frame's set has been taken by a later frame (or it was never stepped)");
+    if (frame > f->rendered) return set_error(KFX_E_RANGE, "kfx_slab_frame_wait_frame: that frame's final exchange has not been enqueued yet (kfx_slab_frame_wait enqueues all)");
+    return hip_status(hipStreamWaitEvent((hipStream_t)stream, f->fin_done[(int)(frame % f->pipe)], 0), "kfx_slab_frame_wait_frame: hipStreamWaitEvent");
+}
+
+extern "C" int kfx_slab_frame_images(const kfx_slab_frame* f, long long frame, kfx_image* depth, kfx_image* norm, kfx_image* img)
+{
+    if (!f || !depth || !norm || !img) return set_error(KFX_E_NULL, "kfx_slab_frame_images: null argument");
+    if (frame < 0) frame = f->frames - 1;
+    if (frame < 0 || frame >= f->frames || (f->pipe > 0 && f->frames - frame > f->pipe))
+        return set_error(KFX_E_RANGE, "kfx_slab_frame_images: that frame's rendering has been overwritten (or was never stepped)");
+    const kfx_image *d, *n, *i;
+    images_of(f, f->pipe > 0 && f->cfg.raycast == KFX_SLAB_RAYCAST_EXACT ? (int)(frame % f->pipe) : 0, &d, &n, &i);
+    *depth = *d; *norm = *n; *img = *i;
+    return 0;
 }
 
 extern "C" int kfx_slab_frame_configure(kfx_slab_frame* f, int halo, int raycast, int merge, int inputs, int overlap, int tiles)
@@ -222,15 +389,22 @@ extern "C" int kfx_slab_frame_configure(kfx_slab_frame* f, int halo, int raycast
     if (inputs >= 0) c.inputs = inputs;
     if (overlap >= 0) c.overlap = overlap ? 1 : 0;
     if (tiles >= 0) c.tiles = tiles;
-    if (int e = check_policies(c, f->comm->world)) return e;
-    // the scratch may be replaced: nothing of this frame object may still be in flight
-    if (int e = hip_status(hipDeviceSynchronize(), "kfx_slab_frame_configure")) return e;
+    if (int e = check_policies(c, f->comm->world)) return e;   // (argument errors: every rank makes them alike)
+    // the scratch may be replaced: nothing of this frame object may still be in flight (pending final exchanges are enqueued first:
+    // collectives, entered by every rank alike)
+    int st = flush_pending(f);
+    const int y = hip_status(hipDeviceSynchronize(), "kfx_slab_frame_configure");
+    if (y && !st) st = y;
     f->merge_pending = 0;
+    for (int k = 0; k < PIPE_MAX; ++k) f->fin_inflight[k] = 0;
     const int o = check_open(f, true);
-    // (a failed allocation leaves the old policies in place; a buffer that was being enlarged for them is gone, which the next
-    //  step reports before it enters any collective)
-    if (int e = ensure_scratch(f, c)) return e;
+    // A failed allocation (or a communicator that could not be duplicated) is rank-local; the ranks agree on the outcome before
+    // anybody adopts the new policies, and a rank that fails keeps its old buffers (grow allocates before it frees): round-5 advice
+    if (!st) st = ensure_scratch(f, c);
+    st = ranks_agree(f, st);
+    if (st) return st;
     f->cfg = c;
+    f->pipe = (c.overlap && c.raycast == KFX_SLAB_RAYCAST_EXACT && f->comm->world > 1) ? c.pipe_depth : 0;
     return o;
 }
 
@@ -292,11 +466,14 @@ extern "C" int kfx_slab_frame_step(kfx_slab_frame* f, const kfx_image* raw, cons
     note(check_open(f, false));
 
     record(0, s);
+    // the packed texels of the SdfFuse kernels' LDS-DMA staging travel from this step's own preprocess to this step's SdfFuse only
+    const kfx_image* tex = ((parts & KFX_FRAME_PREPROCESS) && (parts & KFX_FRAME_FUSE) && f->texels.ptr &&
+                            !(c.inputs == KFX_SLAB_INPUTS_BROADCAST && world > 1 && rank != 0)) ? &f->texels : nullptr;
     if (parts & KFX_FRAME_PREPROCESS) {
         const bool bcast = c.inputs == KFX_SLAB_INPUTS_BROADCAST && world > 1;
         if (!bcast || rank == 0) {
             note(kfx_bilateral_f32(&c.filtered, src, c.bilateral_gs, c.bilateral_gr, c.bilateral_size, c.bilateral_minval, 1, stream));
-            note(kfx_depth_to_vbo_normals_f32(&c.vbo, &c.normals, &c.filtered, c.K, 1.0f, stream));
+            note(kfx::depth_to_vbo_normals_texels(&c.vbo, &c.normals, &c.filtered, c.K, 1.0f, tex, stream));
         }
         if (bcast) note(kfx_slab_broadcast_inputs(&c.filtered, &c.normals, f->bcast, 0, comm, stream));
     }
@@ -310,7 +487,7 @@ extern "C" int kfx_slab_frame_step(kfx_slab_frame* f, const kfx_image* raw, cons
         v.ptr = (unsigned char*)v.ptr + (first - L.s0) * v.img_pitch;
         v.d = count;
         const kfx_slab sl = {L.full_d, first, L.full_zmin, L.full_zmax};
-        note(kfx_sdf_fuse_slab(&v, &sl, &c.filtered, &c.normals, T_cw, c.K, c.trunc_dist, c.max_w, c.mincostheta, KFX_FUSE_SLAB_EXTENT, stream));
+        note(kfx::sdf_fuse_slab_texels(&v, &sl, &c.filtered, &c.normals, tex, T_cw, c.K, c.trunc_dist, c.max_w, c.mincostheta, KFX_FUSE_SLAB_EXTENT, stream));
         if (own_only) note(kfx_slab_exchange_halos(&c.local, &L, comm, stream));
     }
     record(2, s);
@@ -323,12 +500,34 @@ extern "C" int kfx_slab_frame_step(kfx_slab_frame* f, const kfx_image* raw, cons
                 f->open_frame[os] = -1;
             }
             int steps = 0;
-            note(kfx_slab_raycast_exact_tiled(&c.ray_depth, &c.ray_norm, &c.ray_img, f->exact, &c.local, &L, T_wc, c.K, c.near, c.far, c.trunc_dist, 1,
-                                              c.tiles ? c.tiles : 4, comm, stream, f->h_open + os, &steps));
-            f->last_steps = steps;
-            if (hipEventRecord(f->open_done[os], s) == hipSuccess) f->open_frame[os] = f->frames;
-            else (void)hipGetLastError();
-            record(3, s);
+            const int tiles = c.tiles ? c.tiles : 4;
+            if (f->pipe > 0) {
+                // Pipelined: the march on the caller's stream, its final exchange on the side stream through the side communicator
+                // into set k % pipe; the caller's stream goes on with the next frame.  The set's buffers and images are free once
+                // the final exchange of frame k - pipe has run.
+                const int set = (int)(f->frames % f->pipe);
+                if (f->fin_inflight[set]) {
+                    note(hip_status(hipStreamWaitEvent(s, f->fin_done[set], 0), "kfx_slab_frame_step: hipStreamWaitEvent"));
+                    f->fin_inflight[set] = 0;
+                }
+                note(kfx::exact_tiled_march(f->exact, &f->fin[set], &c.local, &L, T_wc, c.K, c.near, c.far, c.trunc_dist, 1, tiles, (int)c.ray_img.w,
+                                            (int)c.ray_img.h, comm, stream, &steps));
+                f->last_steps = steps;
+                record(3, s);
+                note(hip_status(hipEventRecord(f->marched_ev[set], s), "kfx_slab_frame_step: hipEventRecord"));
+                f->pending[f->n_pending++] = PendingFinal{f->frames, set, os, slot, tiles, ev ? f->timing : 0u};
+                // a host that blocks in collectives trails the final exchange by pipe - 1 frames (it meets its peers there: the last
+                // rank of the token chain is that far behind the first); RCCL enqueues and goes on
+                const int lag = (f->side_comm.flags & KFX_COMM_HOST_BLOCKING) ? f->pipe - 1 : 0;
+                while (f->n_pending > lag) note(finalise_oldest(f));
+            } else {
+                note(kfx_slab_raycast_exact_tiled(&c.ray_depth, &c.ray_norm, &c.ray_img, f->exact, &c.local, &L, T_wc, c.K, c.near, c.far, c.trunc_dist, 1,
+                                                  tiles, comm, stream, f->h_open + os, &steps));
+                f->last_steps = steps;
+                if (hipEventRecord(f->open_done[os], s) == hipSuccess) f->open_frame[os] = f->frames;
+                else (void)hipGetLastError();
+                record(3, s);
+            }
         } else {
             note(kfx_raycast_sdf(&c.ray_depth, &c.ray_norm, &c.ray_img, &c.local, T_wc, c.K, c.near, c.far, c.trunc_dist, 1, stream));
             record(3, s);
@@ -410,9 +609,12 @@ extern "C" int kfx_slab_frame_timings(kfx_slab_frame* f, long long first_frame, 
 extern "C" int kfx_slab_frame_sync(kfx_slab_frame* f, kfx_stream stream)
 {
     if (!f) return set_error(KFX_E_NULL, "kfx_slab_frame_sync: null frame");
-    int e = hip_status(hipStreamSynchronize((hipStream_t)stream), "kfx_slab_frame_sync");
+    int e = flush_pending(f);
+    const int y = hip_status(hipStreamSynchronize((hipStream_t)stream), "kfx_slab_frame_sync");
+    if (y && !e) e = y;
     if (!e) e = hip_status(hipStreamSynchronize(f->side), "kfx_slab_frame_sync");
     f->merge_pending = 0;
+    for (int k = 0; k < PIPE_MAX; ++k) f->fin_inflight[k] = 0;
     const int o = check_open(f, true);
     return e ? e : o;
 }

@@ -420,7 +420,7 @@ class SlabPipeline(FramePipeline):
     USE_FRAME = False   # slabs: the operators take slab arguments and collectives sit between them
 
     def __init__(self, ops, dist, dims, boxmin, boxmax, w, h, halo="exchange", raycast="exact", kind="f32", overlap=False,
-                 inputs="replicate", images="all", merge="direct", driver="python", comm=None, tiles=0, unchecked=False, **kw):
+                 inputs="replicate", images="all", merge="direct", driver="python", comm=None, tiles=0, unchecked=False, pipeline=3, **kw):
         """driver = "c": every frame is ONE library call per rank (kfx_slab_frame_step, include/kfx_slab.h: the launches AND the
         collectives are enqueued by the library through `comm`, a kangaroo_amd.slab.Comm -- RCCL for one process per GPU; default:
         Comm.torch(dist), the collectives of the process group the caller has set up); driver = "python": this class issues the
@@ -460,9 +460,16 @@ class SlabPipeline(FramePipeline):
         # The overlapped merge issues its all-reduces from a side stream while the main stream may issue the ghost-plane
         # send / recv of the next SdfFuse: two NCCL call sequences whose relative order can differ between ranks (and torch may
         # route point-to-point through a communicator of its own) -- the classic collective-ordering deadlock.  Not allowed.
-        if self.overlap and (halo == "exchange" or inputs == "broadcast"):
+        if self.overlap and raycast == "composite" and (halo == "exchange" or inputs == "broadcast"):
             raise ValueError("SlabPipeline: overlap=True needs halo='recompute' and inputs='replicate' (an overlapped merge next to the "
                              "ghost-plane exchange or the input broadcast would interleave collectives in rank-dependent order)")
+        # overlap with raycast = "exact" (driver "c"): frames pipelined across the ranks -- frame k's final exchange of the finalised
+        # pixels runs on the frame object's side stream through a second communicator while the main stream carries frame k + 1
+        # (include/kfx_slab.h); `pipeline` image sets are in flight, step() returns before the rendering exists, and
+        # wait_composite() makes ray_d / ray_n / ray_i the last frame's images.  Same bits as without overlap.
+        if self.overlap and raycast != "composite" and (driver != "c" or raycast != "exact"):
+            raise ValueError("SlabPipeline: overlap=True with the exact raycast (pipelined frames) is a feature of driver='c'")
+        self.pipeline = max(2, min(int(pipeline), 4))
         if kw.get("track"):
             raise ValueError("SlabPipeline: track=True (brick summary) is a single-volume feature; slabs march without it")
         self._side = self._merged = None
@@ -491,9 +498,14 @@ class SlabPipeline(FramePipeline):
                 self.comm = S.Comm.torch(dist)
             lay = S.layout(d, float(self.full_boxmin[2]), float(self.full_boxmax[2]), self.rank, self.world, self.GHOST)
             assert (lay.z0, lay.z1, lay.s0, lay.s1) == (self.z0, self.z1, self.s0, self.s1)
+            # the image sets 1 .. of the pipelined exact raycast (set 0: ray_d / ray_n / ray_i), there from the start so that
+            # configure(overlap=True) can switch to pipelined frames on the same object (bench.py times the variants on one pipeline)
+            I = ops.Image
+            extra = [(I(w, h, "f32", pitch=w * 4), I(w, h, "f32x4", pitch=w * 16), I(w, h, "f32", pitch=w * 4)) for _ in range(self.pipeline - 1)] if self.world > 1 else []
             self.sframe = S.SlabFrame(self.comm, self.vol, lay, self.raw, self.filtered, self.vbo, self.normals, self.ray_d, self.ray_n, self.ray_i, self.K,
                                       self.bil, self.near, self.far, self.trunc, self.max_w, self.mincostheta, halo=halo, raycast=raycast, merge=merge,
-                                      inputs=inputs, overlap=overlap, tiles=tiles, unchecked=unchecked, timing_slots=int(timing_slots or 256))
+                                      inputs=inputs, overlap=overlap, tiles=tiles, unchecked=unchecked, timing_slots=int(timing_slots or 256),
+                                      pipe_images=extra)
 
     def configure(self, **kw):
         """Change policies between frames (halo, raycast, merge, inputs, overlap, tiles): bench.py times the variants on one pipeline."""
@@ -501,6 +513,7 @@ class SlabPipeline(FramePipeline):
         self.wait_composite()
         if self.sframe is not None:
             self.sframe.configure(**kw)
+            self.ray_d, self.ray_n, self.ray_i = self.sframe.image_sets[0]   # (pipelined frames re-point these at the last frame's set)
         for k, v in kw.items():
             if k in names:
                 setattr(self, names[k], v)
@@ -640,6 +653,8 @@ class SlabPipeline(FramePipeline):
         """Make the current stream wait for an overlapped merge (no-op otherwise)."""
         if self.sframe is not None:
             self.sframe.wait()
+            if self.overlap and self.raycast_mode == "exact" and self.world > 1 and self.sframe.count > 0:
+                self.ray_d, self.ray_n, self.ray_i = self.sframe.images()   # the set the last frame was rendered into
             return
         if self._merged is not None:
             import torch

@@ -463,8 +463,9 @@ def RaycastSdfCount(vol, w, h, T_wc, K, near, far, trunc_dist, subpix=True, stre
         c = cnt.tolist()
         return dict(samples=c[0], rays=c[1], hits=c[2], U=c[3], lookups=c[4], table_bytes=c[5])
     cnt = torch.zeros(4, dtype=torch.int64, device=vol.storage.device)
-    _lib.check(_lib.load().kfx_raycast_sdf_count(vol.ref(), w, h, t, k, near, far, trunc_dist, 1 if subpix else 0,
-                                                 C.c_void_p(bitmap.data_ptr()), C.c_void_p(cnt.data_ptr()), _stream(stream)))
+    fn = _lib.load().kfx_raycast_sdf_count_h if vol.kind == "f16" else _lib.load().kfx_raycast_sdf_count
+    _lib.check(fn(vol.ref(), w, h, t, k, near, far, trunc_dist, 1 if subpix else 0,
+                  C.c_void_p(bitmap.data_ptr()), C.c_void_p(cnt.data_ptr()), _stream(stream)))
     c = cnt.tolist()
     return dict(samples=c[0], rays=c[1], hits=c[2], U=c[3])
 

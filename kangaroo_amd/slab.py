@@ -33,7 +33,11 @@ KfxComm._fields_ = [("rank", C.c_int), ("world", C.c_int), ("impl", V),
                     ("broadcast", C.CFUNCTYPE(C.c_int, _P, V, Z, C.c_int, V)),
                     ("all_to_all", C.CFUNCTYPE(C.c_int, _P, V, V, Z, V)),
                     ("all_gather", C.CFUNCTYPE(C.c_int, _P, V, V, Z, V)),
-                    ("exchange_v", C.CFUNCTYPE(C.c_int, _P, V, Z, V, Z, V, Z, V, Z, V))]
+                    ("exchange_v", C.CFUNCTYPE(C.c_int, _P, V, Z, V, Z, V, Z, V, Z, V)),
+                    ("flags", C.c_int),
+                    ("dup", C.CFUNCTYPE(C.c_int, _P, _P))]
+HOST_BLOCKING = 1   # KFX_COMM_HOST_BLOCKING
+PIPE_MAX = 4        # KFX_SLAB_PIPE_MAX
 
 
 class KfxSlabLayout(C.Structure):
@@ -50,7 +54,7 @@ class KfxSlabFrameConfig(C.Structure):
                 ("bilateral_gs", C.c_float), ("bilateral_gr", C.c_float), ("bilateral_minval", C.c_float), ("bilateral_size", C.c_uint),
                 ("near", C.c_float), ("far", C.c_float), ("trunc_dist", C.c_float), ("max_w", C.c_float), ("mincostheta", C.c_float),
                 ("halo", C.c_int), ("raycast", C.c_int), ("merge", C.c_int), ("inputs", C.c_int), ("overlap", C.c_int), ("tiles", C.c_int),
-                ("unchecked", C.c_int), ("timing_slots", C.c_int)]
+                ("unchecked", C.c_int), ("timing_slots", C.c_int), ("pipe_depth", C.c_int), ("pipe_images", KfxImage * (3 * (PIPE_MAX - 1)))]
 
 
 HALO = {"recompute": 0, "exchange": 1}
@@ -71,6 +75,8 @@ def _L():
         PL = C.POINTER(KfxSlabLayout)
         sig = {
             "kfx_comm_create_threads": (C.c_int, [_P, C.c_int]),
+            "kfx_comm_create_threads_p2p": (C.c_int, [_P, C.c_int, C.c_int]),
+            "kfx_slab_frame_images": (C.c_int, [V, C.c_longlong, _lib.PI, _lib.PI, _lib.PI]),
             "kfx_comm_create_loopback": (C.c_int, [_P, C.c_int, C.c_int]),
             "kfx_slab_layout_init": (C.c_int, [PL, C.c_size_t, C.c_float, C.c_float, C.c_int, C.c_int, C.c_int]),
             "kfx_slab_broadcast_inputs": (C.c_int, [PI, PI, V, C.c_int, _P, V]),
@@ -160,10 +166,15 @@ class Comm:
         return Comm(c, keep=R)
 
     @staticmethod
-    def threads(world):
-        """world comms for host threads of this process that share the current device (every collective must be called by all)."""
+    def threads(world, p2p=False, timeout_ms=10000):
+        """world comms for host threads of this process that share the current device (every collective must be called by all).
+        p2p: the neighbour exchanges are matched pairwise and in order per directed link, the way RCCL matches send / recv, instead
+        of being barriers of all ranks; a leg without a matching partner blocks until the timeout, then fails (KFX_E_TIMEOUT)."""
         arr = (KfxComm * world)()
-        _lib.check(_L().kfx_comm_create_threads(arr, world))
+        if p2p:
+            _lib.check(_L().kfx_comm_create_threads_p2p(arr, world, int(timeout_ms)))
+        else:
+            _lib.check(_L().kfx_comm_create_threads(arr, world))
         return [Comm(arr[r], keep=arr, owner=(r == 0)) for r in range(world)]
 
     @staticmethod
@@ -173,11 +184,13 @@ class Comm:
         return Comm(c)
 
     @staticmethod
-    def torch(dist):
+    def torch(dist, group=None, _into=None, _keep=None):
         """Collectives through torch.distributed on tensors that alias the C side's device buffers: the transport of the tests'
         gloo ranks sharing one GPU (gloo moves device tensors through host copies, so every call synchronises) -- and a way to run
-        kfx_slab_frame over whatever backend a launcher has already set up."""
+        kfx_slab_frame over whatever backend a launcher has already set up.  group: the process group (default: the world);
+        kfx_comm::dup makes a new group over the same ranks (dist.new_group: every rank calls)."""
         rank, world = dist.get_rank(), dist.get_world_size()
+        P2P = lambda op, t, peer: dist.P2POp(op, t, peer, group=group)   # noqa: E731
         nccl = dist.get_backend() == "nccl"
 
         def guard(fn):
@@ -212,7 +225,7 @@ class Comm:
                 return
             torch.cuda.synchronize()   # gloo: stage device tensors through host copies (its own device path takes ~0.1 s per message)
             host = [(op, op.tensor.cpu() if op.op is dist.isend else torch.empty(op.tensor.shape, dtype=op.tensor.dtype)) for op in ops]
-            for req in dist.batch_isend_irecv([dist.P2POp(op.op, t, op.peer) for op, t in host]):
+            for req in dist.batch_isend_irecv([P2P(op.op, t, op.peer) for op, t in host]):
                 req.wait()
             for op, t in host:
                 if op.op is not dist.isend:
@@ -225,19 +238,19 @@ class Comm:
             dt = {0: torch.int64, 1: torch.float32, 2: torch.int32}[op]
             t = _dev(buf, count * (8 if op == 0 else 4), dt)
             sync()
-            dist.all_reduce(t, op=dist.ReduceOp.MIN if op == 0 else dist.ReduceOp.SUM)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN if op == 0 else dist.ReduceOp.SUM, group=group)
             sync()
 
         def exchange_v(c, send_lo, bsl, recv_lo, brl, send_hi, bsh, recv_hi, brh, stream):
             ops = []
             if rank > 0 and bsl:
-                ops.append(dist.P2POp(dist.isend, _dev(send_lo, bsl), rank - 1))
+                ops.append(P2P(dist.isend, _dev(send_lo, bsl), rank - 1))
             if rank > 0 and brl:
-                ops.append(dist.P2POp(dist.irecv, _dev(recv_lo, brl), rank - 1))
+                ops.append(P2P(dist.irecv, _dev(recv_lo, brl), rank - 1))
             if rank + 1 < world and bsh:
-                ops.append(dist.P2POp(dist.isend, _dev(send_hi, bsh), rank + 1))
+                ops.append(P2P(dist.isend, _dev(send_hi, bsh), rank + 1))
             if rank + 1 < world and brh:
-                ops.append(dist.P2POp(dist.irecv, _dev(recv_hi, brh), rank + 1))
+                ops.append(P2P(dist.irecv, _dev(recv_hi, brh), rank + 1))
             p2p(ops)
 
         def exchange(c, send_lo, recv_lo, blo, send_hi, recv_hi, bhi, stream):
@@ -245,13 +258,13 @@ class Comm:
 
         def barrier(c):
             torch.cuda.synchronize()
-            dist.barrier()
+            dist.barrier(group=group)
 
         def broadcast(c, buf, nbytes, root, stream):
             if nbytes == 0:
                 return
             sync()
-            dist.broadcast(_dev(buf, nbytes), src=root)
+            dist.broadcast(_dev(buf, nbytes), src=root, group=group)
             sync()
 
         def all_to_all(c, send, recv, nbytes, stream):
@@ -259,14 +272,14 @@ class Comm:
                 return
             s_, r_ = _dev(send, nbytes * world).view(world, nbytes), _dev(recv, nbytes * world).view(world, nbytes)
             if nccl:
-                dist.all_to_all_single(r_, s_)
+                dist.all_to_all_single(r_, s_, group=group)
                 return
             sync()   # (the producer may have run on another stream than the one this copy is issued on)
             r_[rank].copy_(s_[rank])
             ops = []
             for k in range(1, world):
                 to, frm = (rank + k) % world, (rank - k) % world
-                ops += [dist.P2POp(dist.isend, s_[to], to), dist.P2POp(dist.irecv, r_[frm], frm)]
+                ops += [P2P(dist.isend, s_[to], to), P2P(dist.irecv, r_[frm], frm)]
             p2p(ops)
 
         def all_gather(c, send, recv, nbytes, stream):
@@ -274,24 +287,38 @@ class Comm:
                 return
             s_, r_ = _dev(send, nbytes), _dev(recv, nbytes * world)
             if nccl:
-                dist.all_gather_into_tensor(r_, s_)
+                dist.all_gather_into_tensor(r_, s_, group=group)
                 return
             sync()
             parts = [torch.empty(nbytes, dtype=torch.uint8) for _ in range(world)]
-            dist.all_gather(parts, s_.cpu())
+            dist.all_gather(parts, s_.cpu(), group=group)
             r_.copy_(torch.cat(parts))
             sync()
 
-        c = KfxComm()
+        c = KfxComm() if _into is None else _into
         c.rank, c.world, c.impl = rank, world, None
         fields = dict(KfxComm._fields_)
-        cbs = {}
+        cbs = {} if _keep is None else _keep
+        tag = "" if _into is None else "dup%d." % len(cbs)
         for name, fn in (("all_reduce", all_reduce), ("exchange", exchange), ("barrier", barrier), ("broadcast", broadcast),
                          ("all_to_all", all_to_all), ("all_gather", all_gather), ("exchange_v", exchange_v)):
-            cbs[name] = fields[name](guard(fn))
-            setattr(c, name, cbs[name])
-        cbs["destroy"] = fields["destroy"](lambda c_: None)
-        c.destroy = cbs["destroy"]
+            cbs[tag + name] = fields[name](guard(fn))
+            setattr(c, name, cbs[tag + name])
+        cbs[tag + "destroy"] = fields["destroy"](lambda c_: None)
+        c.destroy = cbs[tag + "destroy"]
+        c.flags = 0 if nccl else HOST_BLOCKING   # gloo: every call synchronises with the peers
+
+        def dup(c_, out):
+            try:
+                g2 = dist.new_group(ranks=list(range(world)), backend=dist.get_backend())   # (collective: every rank duplicates alike)
+                Comm.torch(dist, group=g2, _into=out.contents, _keep=cbs)
+                return 0
+            except Exception as e:   # noqa: BLE001
+                import sys
+                print("kangaroo_amd.slab.Comm.torch dup: %r" % (e,), file=sys.stderr)
+                return -4
+        cbs[tag + "dup"] = fields["dup"](dup)
+        c.dup = cbs[tag + "dup"]
         return Comm(c, keep=cbs, owner=False)
 
 
@@ -306,9 +333,13 @@ class SlabFrame:
     raycast with its collectives -- enqueued by ONE library call per frame (include/kfx_slab.h)."""
 
     def __init__(self, comm, vol, lay, raw, filtered, vbo, normals, ray_d, ray_n, ray_i, K, bilateral, near, far, trunc_dist, max_w, mincostheta,
-                 halo="recompute", raycast="exact", merge="direct", inputs="replicate", overlap=False, tiles=0, unchecked=False, timing_slots=0):
+                 halo="recompute", raycast="exact", merge="direct", inputs="replicate", overlap=False, tiles=0, unchecked=False, timing_slots=0,
+                 pipe_images=()):
+        """pipe_images: [(depth, norm, img), ...] -- the image sets 1 .. of the pipelined exact raycast (raycast="exact" with overlap: frame
+        k renders into set k % (1 + len(pipe_images)), set 0 being ray_d / ray_n / ray_i); at most PIPE_MAX - 1 of them."""
         self.comm = comm
-        self._keep = (vol, raw, filtered, vbo, normals, ray_d, ray_n, ray_i)   # the frame holds raw pointers into these
+        self._keep = (vol, raw, filtered, vbo, normals, ray_d, ray_n, ray_i, tuple(pipe_images))   # the frame holds raw pointers into these
+        self.image_sets = [(ray_d, ray_n, ray_i)] + [tuple(t) for t in pipe_images]
         cfg = KfxSlabFrameConfig()
         cfg.local, cfg.layout = vol.view(), lay
         cfg.raw, cfg.filtered, cfg.vbo, cfg.normals = raw.view(), filtered.view(), vbo.view(), normals.view()
@@ -320,6 +351,10 @@ class SlabFrame:
         cfg.near, cfg.far, cfg.trunc_dist, cfg.max_w, cfg.mincostheta = float(near), float(far), float(trunc_dist), float(max_w), float(mincostheta)
         cfg.halo, cfg.raycast, cfg.merge, cfg.inputs = HALO[halo], RAYCAST[raycast], MERGE[merge], INPUTS[inputs]
         cfg.overlap, cfg.tiles, cfg.unchecked, cfg.timing_slots = int(bool(overlap)), int(tiles), int(bool(unchecked)), int(timing_slots)
+        assert len(pipe_images) <= PIPE_MAX - 1
+        cfg.pipe_depth = 1 + len(pipe_images) if pipe_images else 0
+        for k, (d_, n_, i_) in enumerate(pipe_images):
+            cfg.pipe_images[3 * k], cfg.pipe_images[3 * k + 1], cfg.pipe_images[3 * k + 2] = d_.view(), n_.view(), i_.view()
         self.handle = V()
         _lib.check(_L().kfx_slab_frame_create(C.byref(self.handle), C.byref(cfg), comm.ref()))
         self.timing_slots = int(timing_slots)
@@ -364,6 +399,16 @@ class SlabFrame:
 
     def wait(self, stream=None):
         _lib.check(_L().kfx_slab_frame_wait(self.handle, _stream(stream)))
+
+    def images(self, frame=-1):
+        """(depth, norm, img) holding the rendering of `frame` (default: the last one stepped): set frame % depth of the pipelined
+        exact raycast, else the frame's own ray images.  Valid once wait() / sync() has passed."""
+        d, n, i = KfxImage(), KfxImage(), KfxImage()
+        _lib.check(_L().kfx_slab_frame_images(self.handle, int(frame), C.byref(d), C.byref(n), C.byref(i)))
+        for s_ in self.image_sets:
+            if s_[0].view().ptr == d.ptr:
+                return s_
+        raise RuntimeError("kfx_slab_frame_images returned images this object does not know")
 
     def sync(self, stream=None):
         _lib.check(_L().kfx_slab_frame_sync(self.handle, _stream(stream)))

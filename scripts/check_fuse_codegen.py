@@ -7,7 +7,7 @@ constants read from LDS; the hazard is resolved with `s_waitcnt vmcnt(0)` at the
 store (and exposes its full latency) before any arithmetic starts: the bit-exact kernel went from 0.438 to 0.486 ms with
 an identical instruction sequence otherwise (round 2, found by diffing the two builds).  This script compiles fuse.hip to
 assembly with the Makefile's flags and fails if any block with >= 8 ds_read_b128 (an observation of a voxel pair) waits
-for vector memory before it has issued a load of its own (i.e. for the previous iteration's traffic).  Usage: python scripts/check_fuse_codegen.py [path/to/fuse.s]"""
+for vector memory before it has issued a load of its own (i.e. for the previous iteration's traffic), or touches scratch.  Usage: python scripts/check_fuse_codegen.py [path/to/fuse.s]"""
 import os
 import re
 import subprocess
@@ -47,6 +47,8 @@ def hot_block_waits(asm_path):
                     if t.startswith("global_load") or t.startswith("buffer_load"):
                         loaded = True
                     if t.startswith("s_waitcnt") and "vmcnt" in t and not loaded:
+                        found.append((name, label, k, t))
+                    if t.startswith("scratch_"):   # a spill inside an observation block: a memory round trip per voxel pair
                         found.append((name, label, k, t))
         while i < len(src) and not src[i].startswith(".Lfunc_end"):
             mm = re.match(r"^(\.LBB\d+_\d+):", src[i])
@@ -144,10 +146,19 @@ def main():
     print("%d k_sdf_fuse_tiled instantiations, %d vector-memory waits inside observation blocks" % (kernels, len(found)))
     for f in found:
         print("  %s %s [%d] %s" % f)
-    over = [b for b in budget if b[1] is None or b[1] > b[3] or b[2] != 0]
-    print("%d budgeted instantiations (fast two-slice: 64 VGPRs, bit-exact untracked: 80), %d over the VGPR / no-scratch budget" % (len(budget), len(over)))
-    for b in over:
-        print("  %s NumVgprs %s ScratchSize %s (budget %d)" % b)
+    # ScratchSize: none for the untracked kernels; at most 32 bytes per lane for the fast TRACK instantiations, none of it touched
+    # inside an observation block (checked above).  Round 6: the tracked fast kernels keep their uniforms in scalar registers (the
+    # bookkeeping of the brick summary takes the VGPRs that would park them), ~40 of which already live in VGPR lanes; with the
+    # rectangle from the brick's corners three to eight lane-derived values are parked in scratch around the global-gather fallback
+    # loops.  The tiled voxel loops -- where the time goes -- are free of it (S_full through the tracked pair: 0.3471 -> 0.3466 ms,
+    # profiles/r06_corner_ab).
+    def scratch_limit(name):
+        return 32 if re.search(r"ILb1ELi2E\w+Lb1ELb0ELi4EEEv", name) else 0
+    over = [b for b in budget if b[1] is None or b[1] > b[3] or b[2] > scratch_limit(b[0])]
+    print("%d budgeted instantiations (fast two-slice: 64 VGPRs, bit-exact untracked: 80), %d over the VGPR / scratch budget" % (len(budget), len(over)))
+    for b in budget:
+        if b in over or b[2]:
+            print("  %s NumVgprs %s ScratchSize %s (budget %d)%s" % (b + ("" if b in over else " -- outside the observation blocks",)))
     print("%d hand-written cell requests in the tracked kernels, %d instructions touching their registers before the wait" % (keep_seen, len(keep_bad)))
     for b in keep_bad[:20]:
         print("  %s line %d: %s" % b)

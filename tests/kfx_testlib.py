@@ -55,14 +55,15 @@ def make_volume(N, scene, dims=None, pitch_bytes=None):
     return vol
 
 
-def fuse_frames_oracle(vol, scene, w, h, n_frames, n_orbit=8, full_extent=False, nthreads=0):
-    """Fuse n_frames of the orbit trajectory; returns list of per-frame dicts."""
+def fuse_frames_oracle(vol, scene, w, h, n_frames, n_orbit=8, full_extent=False, nthreads=0, noise_sigma=0.0):
+    """Fuse n_frames of the orbit trajectory; returns list of per-frame dicts.  noise_sigma > 0: SURVEY 8(d)'s noisy input -- Gaussian
+    depth noise of that many metres per pixel, seed 1234 + frame (a fresh draw per frame, as a sensor's)."""
     K = scenes.intrinsics(w, h)
     tr = scenes.trunc_dist(vol.boxmin, vol.boxmax, (vol.w, vol.h, vol.d))
     frames = []
     for i in range(n_frames):
         T_wc = scenes.orbit_pose(i, n_orbit)
-        raw = scenes.render_depth(scene, w, h, T_wc, K)
+        raw = scenes.render_depth(scene, w, h, T_wc, K, noise_sigma=noise_sigma, seed=1234 + i)
         f, vbo, nrm = preprocess_oracle(raw, K)
         T_cw = scenes.se3_inverse(T_wc)
         n = oracle.sdf_fuse(vol, f, nrm, T_cw, K, tr, scenes.MAX_W, scenes.MIN_COS_THETA,

@@ -36,9 +36,13 @@ def same(a, b):
 if cframe:
     # kfx_slab_frame (include/kfx_slab.h) under real collectives: the C call's bits against the operator-by-operator SlabPipeline
     # (composite: the same restart semantics, so the same images) and against the single volume (exact: bit-identical, any tile count)
-    variants = [dict(tiles=1), dict(tiles=4), dict(tiles=7)] if raycast == "exact" else [dict(merge="direct"), dict(merge="allreduce"), dict(merge="direct", overlap=True)]
+    # exact + overlap: frames pipelined across the ranks (the final exchange of frame k on the side stream through a second process
+    # group -- kfx_comm::dup -- under frame k + 1; 2 and 3 image sets in flight over 7 frames)
+    variants = ([dict(tiles=1), dict(tiles=4), dict(tiles=7), dict(tiles=4, overlap=True), dict(tiles=1, overlap=True, pipeline=2)] if raycast == "exact" else
+                [dict(merge="direct"), dict(merge="allreduce"), dict(merge="direct", overlap=True)])
     if halo == "exchange":
-        variants = [v for v in variants if not v.get("overlap")] + [dict(inputs="broadcast")]
+        variants = [v for v in variants if not (v.get("overlap") and raycast == "composite")] + [dict(inputs="broadcast")] + ([dict(inputs="broadcast", overlap=True)] if raycast == "exact" else [])
+    FRAMES = 7
     py = SlabPipeline(roo, dist, (N, N, N), bmin, bmax, W, H, halo=halo, raycast=raycast, near=near, far=far)
     ref = FramePipeline(roo, (N, N, N), bmin, bmax, W, H, near=near, far=far)
     cs = [SlabPipeline(roo, dist, (N, N, N), bmin, bmax, W, H, halo=halo, raycast=raycast, near=near, far=far, driver="c", **v) for v in variants]
@@ -54,6 +58,7 @@ if cframe:
         for c_ in cs:
             c_.step(T_wc)
     for c_ in cs:
+        c_.wait_composite()   # (pipelined frames: the trailing final exchanges; ray_d / ray_n / ray_i = the last frame's set)
         c_.sframe.sync()
     torch.cuda.synchronize()
     full = ref.vol.MemcpyToHost()
@@ -68,7 +73,7 @@ if cframe:
             assert T_ == world + v["tiles"] - 1 + 1 if "tiles" in v else T_ > 0, (v, T_)
         t = c_.sframe.timings(c_.sframe.count - 2, 2)
         assert t.shape == (2, 6) and np.isfinite(t[:, :3]).all() and (t[:, :3] >= 0).all() and np.isfinite(t[0, 5]), t
-        assert np.isfinite(t[:, 3]).all() == (raycast == "composite")
+        assert np.isfinite(t[:, 3]).all() == (raycast == "composite" or bool(v.get("overlap")))
 elif not tracking:
     pipe = SlabPipeline(roo, dist, (N, N, N), bmin, bmax, W, H, halo=halo, raycast=raycast, near=near, far=far)
     ref = FramePipeline(roo, (N, N, N), bmin, bmax, W, H, near=near, far=far)

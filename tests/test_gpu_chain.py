@@ -39,9 +39,9 @@ def _report(name, rep):
         pass
 
 
-def _oracle_chain(scene, w, h, frames, n_orbit=30):
+def _oracle_chain(scene, w, h, frames, n_orbit=30, noise_sigma=0.0):
     ovol = T.make_volume(N, scene)
-    K, tr, fr = T.fuse_frames_oracle(ovol, scene, w, h, frames, n_orbit=n_orbit, nthreads=0)
+    K, tr, fr = T.fuse_frames_oracle(ovol, scene, w, h, frames, n_orbit=n_orbit, nthreads=0, noise_sigma=noise_sigma)
     return ovol, K, tr, fr
 
 
@@ -66,15 +66,23 @@ def _gpu_chain(roo, scene, w, h, K, tr, fr, math):
     return vol, pre
 
 
-@pytest.mark.parametrize("scene,w,h", [("full", 640, 480), ("room", 640, 480), ("room", 1280, 960), ("full", 1280, 960)])
-def test_gpu_fast_chain_vs_exact_oracle_at_full_size(roo, scene, w, h):
+NOISE_SIGMA = 0.002   # "where noise is wanted use seed = 1234, Gaussian sigma = 2 mm on depth"
+
+
+@pytest.mark.parametrize("scene,w,h,noise", [("full", 640, 480, 0.0), ("room", 640, 480, 0.0), ("room", 1280, 960, 0.0), ("full", 1280, 960, 0.0),
+                                             ("room", 640, 480, NOISE_SIGMA), ("full", 640, 480, NOISE_SIGMA)])
+def test_gpu_fast_chain_vs_exact_oracle_at_full_size(roo, scene, w, h, noise):
+    """noise > 0 (round-5 verdict, item 4a): the same chain, the same assertions, on depth with 2 mm of Gaussian noise per pixel (a
+    fresh draw per frame): noisy normals move the update predicate (costheta against mincostheta), the brick cull's costheta bound and
+    the bit-uniformity of free space the class tables rely on."""
     import torch
     frames = 3
-    ovol, K, tr, fr = _oracle_chain(scene, w, h, frames)
+    ovol, K, tr, fr = _oracle_chain(scene, w, h, frames, noise_sigma=noise)
     vol, pre = _gpu_chain(roo, scene, w, h, K, tr, fr, "fast")
+    tag = "%s%s_%dx%d" % (scene, "_noise" if noise else "", w, h)
 
     # preprocess leg: same invalid pixels, filtered depth and normals close to the exact chain's
-    rep = {"scene": scene, "image": [w, h], "volume": N, "frames": frames, "trunc": tr}
+    rep = {"scene": scene, "image": [w, h], "volume": N, "frames": frames, "trunc": tr, "depth_noise_sigma_m": noise}
     d_rel, n_ang = 0.0, 0.0
     for (gf, gn), fi in zip(pre, fr):
         assert np.array_equal(np.isnan(gf), np.isnan(fi["filtered"]))
@@ -115,7 +123,7 @@ def test_gpu_fast_chain_vs_exact_oracle_at_full_size(roo, scene, w, h):
     rep["linf_all_common"] = float(dv_all.max())                     # history flips included
     rep["w_rel_median"] = float(dw[same].median()) if k else None
     rep["fraction_of_trunc"] = rep["linf_same_class"] / tr
-    _report("fast_chain_%s_%dx%d" % (scene, w, h), rep)
+    _report("fast_chain_" + tag, rep)
 
     budget = max(8, int(FLIP_FRACTION * N ** 3 * frames))
     assert rep["observed_by_oracle"] > 0.3 * N ** 3
@@ -153,7 +161,7 @@ def test_gpu_fast_chain_vs_exact_oracle_at_full_size(roo, scene, w, h):
         img_s = _image_report(sd.MemcpyToHost(), sn.MemcpyToHost(), si.MemcpyToHost(), od.data, on.data, oi.data)
     finally:
         roo.set_math_mode(prev)
-    rep_i = {"scene": scene, "image": [w, h], "plain_march": img, "summary_march": img_s}
+    rep_i = {"scene": scene, "image": [w, h], "depth_noise_sigma_m": noise, "plain_march": img, "summary_march": img_s}
     # The same volume cut into EIGHT Z-slabs the way eight GPUs hold it (BASELINE config C4's partition; here eight rank threads on
     # the one GPU, each with its own copy of its planes + ghosts): the default multi-GPU rendering -- the march state handed from
     # slab to slab (kfx_slab_raycast_exact_tiled) -- must give the single volume's images BIT FOR BIT, hence pass the same
@@ -174,7 +182,7 @@ def test_gpu_fast_chain_vs_exact_oracle_at_full_size(roo, scene, w, h):
         _assert_images(img_x, w, h)
         # composite: rays restart at slab entries, silhouette rays can end differently (85 of 307 200 in S_room)
         assert img_c["hit_flips"] <= COMPOSITE_HIT_FLIP_FRACTION * w * h and img_c["depth_p99"] < IMG_DEPTH_TOL, img_c
-    _report("fast_chain_images_%s_%dx%d" % (scene, w, h), rep_i)
+    _report("fast_chain_images_" + tag, rep_i)
     for r in (img, img_s):
         _assert_images(r, w, h)
     del vol2

@@ -74,15 +74,25 @@ def test_gpu_bench_two_ranks_smoke(raycast):
         assert r["planes_owned"] == 64 and r["voxels_stored"] == 128 * 128 * 66
         assert (r["composite_merge_ms"] is not None and r["composite_merge_ms"] > 0) == (raycast == "composite")
     v = d["multi_gpu_variants"]
-    for key in ("as_configured_fps", "raycast_exact_fps", "halo_exchange+raycast_exact_fps", "raycast_exact_tiles_1_fps", "raycast_exact_tiles_8_fps",
+    for key in ("as_configured_fps", "raycast_exact_fps", "raycast_exact_pipelined_fps", "halo_exchange+raycast_exact_pipelined_fps",
+                "raycast_exact_pipelined_tiles_1_fps", "halo_exchange+raycast_exact_fps", "raycast_exact_tiles_1_fps", "raycast_exact_tiles_8_fps",
                 "raycast_composite_fps", "raycast_composite_overlapped_fps", "raycast_composite_merge_allreduce_fps", "halo_exchange_fps",
                 "inputs_broadcast_fps", "driver_python_fps"):
         assert v.get(key, 0) > 0, (key, v)
     if raycast == "composite":   # direct-send merge, overlapped with the next frame where nothing else communicates
         assert "all_to_all" in d["config"]["partition"] and "overlapped" in d["config"]["partition"]
-    else:
+    else:   # the exact default: frames pipelined across the ranks (the final exchange on the side stream / second communicator)
         assert "tokens over image row-tiles" in d["config"]["partition"] and "overlapped" not in d["config"]["partition"]
+        assert d["config"]["frames_pipelined"] is True and d["config"]["pipeline_note"] is None and "frames pipelined" in d["config"]["partition"]
     assert d["kernels_ms"]["sdf_fuse"] == pr[0]["sdf_fuse_ms"] and d["kernels_ms"]["host_gap"] is not None
+
+
+def test_gpu_bench_unpipelined_exact_two_ranks():
+    """--no-overlap (or KFX_BENCH_PIPELINE=0): the exact hand-over with its final exchange on the launch stream, frame by frame."""
+    out, d = _bench(["--raycast", "exact", "--no-overlap"])
+    assert out.returncode == 0 and d is not None, out.stdout[-2000:] + out.stderr[-3000:]
+    assert d["config"]["frames_pipelined"] is False and "frames pipelined" not in d["config"]["partition"] and d["config"]["ranks_agree"] is True
+    assert d["multi_gpu_variants"]["raycast_exact_pipelined_fps"] > 0
 
 
 def test_gpu_bench_python_driver_two_ranks():
