@@ -4,6 +4,7 @@
 // threshold; <float,float>, <float,unsigned short> with one.
 #pragma once
 
+#include <kfx_extras.h>   // the operators of this header beyond the KinectFusion path
 #include <kangaroo/Image.h>
 #include <kangaroo/launch_utils.h>
 #include <kangaroo/platform.h>

@@ -4,6 +4,7 @@
 // ColourVbo and TextureDepth (ImageKeyframe is declared here too).
 #pragma once
 
+#include <kfx_extras.h>   // the operators of this header beyond the KinectFusion path
 #include <kangaroo/Image.h>
 #include <kangaroo/ImageIntrinsics.h>
 #include <kangaroo/Mat.h>

@@ -1,6 +1,7 @@
 // cu_raycast.h -- roo::RaycastSdf with the reference's signature (include/kangaroo/cu_raycast.h:13-14).
 #pragma once
 
+#include <kfx_extras.h>   // the operators of this header beyond the KinectFusion path
 #include <kangaroo/BoundedVolume.h>
 #include <kangaroo/BoundingBox.h>
 #include <kangaroo/Image.h>

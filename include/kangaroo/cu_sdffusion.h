@@ -2,6 +2,7 @@
 // (include/kangaroo/cu_sdffusion.h:13-26), forwarding to the gfx950 kernels behind include/kfx.h.
 #pragma once
 
+#include <kfx_extras.h>   // the operators of this header beyond the KinectFusion path
 #include <kangaroo/BoundedVolume.h>
 #include <kangaroo/Image.h>
 #include <kangaroo/ImageIntrinsics.h>

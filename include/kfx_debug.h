@@ -43,12 +43,6 @@ int kfx_debug_wave_xor_check(unsigned seed, unsigned long long* d_out, kfx_strea
 int kfx_debug_summary_export(kfx_sdf_summary* s, float tol, float vref, int fine_shift, void* R_out, void* C_out, int dims_out[12],
                              kfx_stream stream);
 
-/* What a step of the ray-march costs a wave depending on where its cells come from (the experiment behind the LDS-slab march
- * decision, EXPERIMENTS.md section 6): `workgroups` x 4 waves march 32 x 2 pixel tiles of rays `steps` voxels along +z through
- * `vol`, r voxels per pixel, each step depending on the previous sample.  mode 0: four 16-byte global loads per sample (the plain
- * march); 1: an LDS box staged once; 2: the workgroup re-stages a box of S + 1 planes every S steps; 3: the same, the next box's
- * loads in flight while the current one is marched.  d_out[workgroups * 4]: cycles per wave for all its steps. */
-int kfx_debug_march_probe(const kfx_volume* vol, int mode, int steps, int S, int workgroups, float r, unsigned long long* d_out, kfx_stream stream);
 
 #ifdef __cplusplus
 }

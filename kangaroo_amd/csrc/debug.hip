@@ -291,142 +291,3 @@ extern "C" int kfx_debug_summary_export(kfx_sdf_summary* s, float tol, float vre
     }
     return 0;
 }
-
-// ---------------------------------------------------------------------------------------------------------------------
-// kfx_debug_march_probe: what a step of the ray-march costs a wave depending on where its cells come from -- the experiment
-// behind the LDS-slab march decision (DESIGN.md section 9, round-3 verdict item 4).  Every wave marches a 32 x 2 pixel tile
-// of rays through the volume along +z, one voxel per step, each step's position depending on the previous sample's value
-// (a real dependent chain, as in cu_raycast.cu:58-81): r voxels per pixel, a small slope in x and y.
-//   mode 0: the plain march's sample -- four 16-byte global loads per lane and step (sampling.h), the wave waits for them;
-//   mode 1: all cells from an LDS box staged once (z wraps inside the box): the pure cost of a step without memory latency;
-//   mode 2: the workgroup (4 waves, 32 x 8 pixels) re-stages its box of S + 1 planes every S steps: loads, barrier, march, barrier;
-//   mode 3: the same with the next box's loads issued before the current box is marched (registers as the second buffer).
-// out[wave] = cycles (s_memtime) between the first and the last step of the wave; the caller divides by `steps`.
-// ---------------------------------------------------------------------------------------------------------------------
-struct ProbeParams {
-    const unsigned char* base;
-    unsigned pitch, img;
-    int W, H, D;
-    int steps, S;
-    float r, sx, sy;
-    unsigned long long* out;
-};
-constexpr int PROBE_BX = 56, PROBE_BY = 20, PROBE_MAXZ = 5, PROBE_REGS = 12;   // box of a 32 x 8 pixel workgroup tile: cells along x, y; planes
-
-template <int MODE>
-__global__ __launch_bounds__(256) void k_march_probe(const ProbeParams p)
-{
-    __shared__ float s_box[PROBE_MAXZ * PROBE_BY * PROBE_BX];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    // the workgroup's tile: its own region of the volume (regions of different workgroups do not overlap)
-    const int tiles_x = max(1, (p.W - 8) / (PROBE_BX + 8)), tile = blockIdx.x;
-    const float cx = 4.f + (float)((tile % tiles_x) * (PROBE_BX + 8)), cy = 4.f + (float)(((tile / tiles_x) * (PROBE_BY + 4)) % max(1, p.H - PROBE_BY - 8));
-    const float u = (float)(lane & 31), v = (float)(wv * 2 + (lane >> 5));
-    float x = cx + u * p.r, y = cy + v * p.r, z = 1.0f;
-    float acc = 0.f;
-    const int S = p.S;
-    // box origin in cells for the current stage (x / y fixed for the probe: the slopes are small enough for the box's margin)
-    const int bx0 = (int)cx - 1, by0 = (int)cy - 1;
-    // the box's rows as 16-byte loads (two cells each), round-robin over the threads; fully unrolled so that reg[] stays in
-    // registers and all of a thread's loads are in flight together
-    auto stage_loads = [&](int z0, float4 (&reg)[PROBE_REGS], int& n) {
-        const int pairs_per_row = PROBE_BX / 2, total = pairs_per_row * PROBE_BY * (S + 1);
-        n = 0;
-#pragma unroll
-        for (int k = 0; k < PROBE_REGS; ++k) {
-            const int i = tid + k * 256;
-            if (i < total) {
-                const int row = i / pairs_per_row, px = i % pairs_per_row;
-                const int zz = row / PROBE_BY, yy = row % PROBE_BY;
-                reg[k] = *reinterpret_cast<const float4*>(p.base + (size_t)min(z0 + zz, p.D - 1) * p.img + (size_t)(by0 + yy) * p.pitch + (size_t)(bx0 + 2 * px) * 8);
-            }
-        }
-    };
-    auto stage_store = [&](const float4 (&reg)[PROBE_REGS], int) {
-        const int pairs_per_row = PROBE_BX / 2, total = pairs_per_row * PROBE_BY * (S + 1);
-#pragma unroll
-        for (int k = 0; k < PROBE_REGS; ++k) {
-            const int i = tid + k * 256;
-            if (i < total) {
-                const int row = i / pairs_per_row, px = i % pairs_per_row;
-                *reinterpret_cast<float2*>(&s_box[row * PROBE_BX + 2 * px]) = make_float2(reg[k].x, reg[k].z);
-            }
-        }
-    };
-    float4 reg[PROBE_REGS];
-    int nreg = 0;
-    int box_z0 = 1;
-    if constexpr (MODE >= 1) {
-        stage_loads(box_z0, reg, nreg);
-        stage_store(reg, nreg);
-        __syncthreads();
-        if constexpr (MODE == 3) stage_loads(box_z0 + S, reg, nreg);   // the next box, in flight while this one is marched
-    }
-    const unsigned long long t0 = __builtin_readcyclecounter();
-    for (int k = 0; k < p.steps; ++k) {
-        const float fxx = floorf(x), fyy = floorf(y), fzz = floorf(z);
-        const int ix = (int)fxx, iy = (int)fyy, iz = (int)fzz;
-        const float fx = x - fxx, fy = y - fyy, fz = z - fzz;
-        float sdf;
-        if constexpr (MODE == 0) {
-            const unsigned o = (unsigned)min(iz, p.D - 2) * p.img + (unsigned)iy * p.pitch + (unsigned)ix * 8u;
-            float2 c00, c10, c01, c11;
-            RayF32::pair4_off32(p.base, o, o + p.pitch, o + p.img, o + p.img + p.pitch, c00, c10, c01, c11);
-            sdf = lerp(lerp(lerp(c00.x, c00.y, fx), lerp(c10.x, c10.y, fx), fy), lerp(lerp(c01.x, c01.y, fx), lerp(c11.x, c11.y, fx), fy), fz);
-        } else {
-            const int lz = (MODE == 1) ? (iz - 1) % S : (iz - box_z0);
-            const float* q = s_box + ((lz * PROBE_BY) + (iy - by0)) * PROBE_BX + (ix - bx0);
-            const float a0 = q[0], a1 = q[1], b0 = q[PROBE_BX], b1 = q[PROBE_BX + 1];
-            const float* q1 = q + PROBE_BY * PROBE_BX;
-            const float c0 = q1[0], c1 = q1[1], d0 = q1[PROBE_BX], d1 = q1[PROBE_BX + 1];
-            sdf = lerp(lerp(lerp(a0, a1, fx), lerp(b0, b1, fx), fy), lerp(lerp(c0, c1, fx), lerp(d0, d1, fx), fy), fz);
-        }
-        acc += sdf;
-        const float step = 1.0f + sdf * 0.0f;   // the step depends on the sample (not folded: IEEE semantics are on)
-        z += step;
-        x = cx + u * p.r + p.sx * (z - 1.0f) * 0.0f + (MODE == 0 ? p.sx * (z - 1.0f) : 0.f);
-        y = cy + v * p.r + (MODE == 0 ? p.sy * (z - 1.0f) : 0.f);
-        if constexpr (MODE >= 2) {
-            if ((k + 1) % S == 0) {   // every ray of the workgroup has left the box: the next S + 1 planes
-                box_z0 += S;
-                if constexpr (MODE == 2) stage_loads(box_z0, reg, nreg);
-                __syncthreads();          // everybody is done reading the old box
-                stage_store(reg, nreg);
-                __syncthreads();
-                if constexpr (MODE == 3) stage_loads(box_z0 + S, reg, nreg);
-            }
-        }
-    }
-    const unsigned long long t1 = __builtin_readcyclecounter();
-    if (lane == 0) p.out[(size_t)blockIdx.x * 4 + wv] = t1 - t0;
-    if (acc == -1.2345f) p.out[0] = 0;   // keep the chain alive
-}
-
-extern "C" int kfx_debug_march_probe(const kfx_volume* vol, int mode, int steps, int S, int workgroups, float r, unsigned long long* d_out, kfx_stream stream)
-{
-    using namespace kfx;
-    if (!vol || !vol->ptr || !d_out) return set_error(KFX_E_NULL, "kfx_debug_march_probe: null argument");
-    if (mode < 0 || mode > 3 || steps < 1 || S < 1 || S + 1 > PROBE_MAXZ || workgroups < 1) return set_error(KFX_E_RANGE, "kfx_debug_march_probe: parameters");
-    if ((int)vol->d < steps + S + 4 || vol->w < 2 * PROBE_BX || vol->h < 2 * PROBE_BY) return set_error(KFX_E_SHAPE, "kfx_debug_march_probe: volume too small for the march");
-    if ((double)vol->img_pitch * (double)vol->d >= 4294967296.0) return set_error(KFX_E_RANGE, "kfx_debug_march_probe: volumes below 4 GiB");
-    // a workgroup's rays span 31 r cells in x and 7 r in y from its tile's corner (+ the mode-0 drift of 0.05 / 0.02 cells per
-    // step): modes 1-3 read them from the 56 x 20-cell LDS box (corner at -1, the sample's +1 cell), mode 0 from the volume
-    if (!(r > 0.f) || !(r <= 1.6f)) return set_error(KFX_E_RANGE, "kfx_debug_march_probe: r in (0, 1.6]");
-    if (mode == 0) {
-        const int tiles_x = (int)vol->w - 8 > PROBE_BX + 8 ? ((int)vol->w - 8) / (PROBE_BX + 8) : 1;
-        const float x_far = 4.f + (float)((tiles_x - 1) * (PROBE_BX + 8)) + 31.f * r + 0.05f * (float)steps + 2.f;
-        const float y_far = 4.f + (float)((int)vol->h - PROBE_BY - 8 > 1 ? (int)vol->h - PROBE_BY - 9 : 0) + 7.f * r + 0.02f * (float)steps + 2.f;
-        if (!(x_far < (float)vol->w) || !(y_far < (float)vol->h)) return set_error(KFX_E_SHAPE, "kfx_debug_march_probe: the drifting rays of mode 0 would leave the volume");
-    }
-    ProbeParams p;
-    p.base = (const unsigned char*)vol->ptr; p.pitch = (unsigned)vol->pitch; p.img = (unsigned)vol->img_pitch;
-    p.W = (int)vol->w; p.H = (int)vol->h; p.D = (int)vol->d;
-    p.steps = steps; p.S = S; p.r = r; p.sx = 0.05f; p.sy = 0.02f; p.out = d_out;
-    const dim3 grid(workgroups), block(256);
-    hipStream_t s = (hipStream_t)stream;
-    if (mode == 0) hipLaunchKernelGGL(k_march_probe<0>, grid, block, 0, s, p);
-    else if (mode == 1) hipLaunchKernelGGL(k_march_probe<1>, grid, block, 0, s, p);
-    else if (mode == 2) hipLaunchKernelGGL(k_march_probe<2>, grid, block, 0, s, p);
-    else hipLaunchKernelGGL(k_march_probe<3>, grid, block, 0, s, p);
-    return check_launch("kfx_debug_march_probe");
-}

@@ -59,7 +59,7 @@ extern "C" int kfx_frame_create(kfx_frame** out, const kfx_frame_config* cfg)
     {   // (no device yet -- the argument checks of tests/test_abi_cpu.py run without one -- or no memory: steps pack per call instead)
         const size_t tpitch = (cfg->filtered.w * 16 + 255) / 256 * 256;
         void* buf = nullptr;
-        if (tpitch < (1u << 24) && hipMalloc(&buf, tpitch * cfg->filtered.h) == hipSuccess) f->texels = kfx_image{tpitch, buf, cfg->filtered.w, cfg->filtered.h};
+        if (tpitch < (1u << 24) && hipMalloc(&buf, kfx::texel_image_bytes(cfg->filtered.w, cfg->filtered.h)) == hipSuccess) f->texels = kfx_image{tpitch, buf, cfg->filtered.w, cfg->filtered.h};
         else (void)hipGetLastError();
     }
     if (f->slots) {

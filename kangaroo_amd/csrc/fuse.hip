@@ -11,7 +11,7 @@
 //   * the volume is touched only where the update predicate holds, like the reference
 //     (cu_sdffusion.cu:44-49): HBM traffic is 16 B x updated voxels, streamed nontemporally;
 //   * k_sdf_fuse_tiled stages the pixel rectangle a 64 x 8 x 16 voxel brick projects into
-//     once in LDS, as {nx, ny, nz, depth} texels, and serves all bilinear lookups from LDS.
+//     once in LDS, as {nx, ny, nz, depth} texels (LDS-DMA from a packed texel image), and serves all bilinear lookups from LDS.
 //     Measured on MI355X (512^3, 640x480): with global gathers the vector L1 saturates
 //     (288 M line accesses per launch, 0.69 ms regardless of arithmetic); tiled: 35 M accesses.
 //   * two numerics modes (kfx_set_math_mode): exact = IEEE fp32 in the reference's operation
@@ -31,10 +31,12 @@
 
 #include "kfx_device.h"
 
-// A/B builds: -DKFX_FUSE_STAGE_DMA=0 compiles the tiled kernels with the round-5 staging through registers (per texel: loads of the
-// normal and the depth, a repack, a ds_write_b128) instead of the LDS-DMA of the packed texel image
+// The tiled kernels stage their pixel rectangle by LDS-DMA from a packed texel image (round 6: k_pack_texels / the fused preprocess of
+// kfx_frame_step write it; C3 / S_room SdfFuse 0.400 -> 0.361 ms, S_room 0.2737 -> 0.2645, S_full 0.3490 -> 0.3452, same bits:
+// profiles/r06_stage_ab2).  A/B builds: -DKFX_FUSE_STAGE_DMA=0 compiles round 5's staging through registers (per texel: an index
+// division, loads of the normal and the depth, a repack, a ds_write_b128) -- scripts/build_ab.sh, scripts/fuse_stage_ab.sh.
 #ifndef KFX_FUSE_STAGE_DMA
-#define KFX_FUSE_STAGE_DMA 0
+#define KFX_FUSE_STAGE_DMA 1
 #endif
 
 namespace kfx {
@@ -74,6 +76,9 @@ struct FuseParams {
     // kernels stage by LDS-DMA (k_pack_texels / the fused preprocess write it; null: the kernels gather depth and normals themselves)
     const unsigned char* tex;
     unsigned tpitch;
+    // ... and, behind the texels, the maximum finite depth of every block of 8 x 4 pixels (-inf: none), rows of bw8 floats
+    const float* bmax;
+    unsigned bw8;
 };
 
 struct Obs {
@@ -575,36 +580,59 @@ __global__ __launch_bounds__(64 * NW, (FAST && ZU == 2) ? 8 : (!FAST ? 6 : 1)) v
     const bool whole = !TRACK || ((bxi + 1) * LX * 2 <= p.X && ((int)blockIdx.y + 1) * BY <= p.Y);
     const bool interior = __builtin_amdgcn_readfirstlane((int)(use_tile && whole && umin >= 2.01f && umax < p.dwb - 0.01f && vmin >= 2.01f && vmax < p.dhb - 0.01f)) != 0;
     float dmax = -__builtin_inff(); // farthest finite depth in the rectangle (fmaxf skips NaN texels)
-    // Staging by LDS-DMA (gfx950 global_load_lds_dwordx4: 16 bytes per lane from a per-lane address straight to LDS at a wave-
-    // uniform base + lane * 16; no VGPR destination, no ds_write).  The rectangle's rows are shared out over the waves; a wave stages
-    // a row in chunks of 64 texels of the PACKED image {nx, ny, nz, depth} (p.tex), which lands as s_tile[r * tw + c]: the layout
-    // the loops below read.  Per 64 texels: one address add and one DMA instruction, where the register path below spends an index
-    // division, two address computations, a 16-byte and a 4-byte load, a repack and a ds_write_b128 PER TEXEL -- a quarter of this
-    // kernel's instructions at 1280x960, where a 4096-voxel brick stages 3000 texels.  dmax: every wave reads back the
-    // depths of the rows it staged itself once its own DMAs have landed (vmcnt(0) orders a wave's reads behind its own DMA; other
-    // waves' rows are read after the barrier below).  Texels are the same copies of the same pixels: same bits.
+    // Staging by LDS-DMA (gfx950 global_load_lds_dwordx4: 16 bytes per lane straight to LDS at M0 + lane * 16; no VGPR destination, no
+    // ds_write) from the PACKED texel image {nx, ny, nz, depth} (p.tex).  The rectangle's rows are shared out over the waves; a wave
+    // stages a row in chunks of 64 texels that land as s_tile[r * tw + c], the layout the loops below read.  Everything per chunk is
+    // SCALAR: the row's address is an SGPR pair (the instruction's saddr; the lane's share is the one VGPR lane * 16), the lanes beyond
+    // the row's end are switched off through exec (s_bfm: the mask of the tail chunk), the destination goes to M0 -- no vector
+    // instruction at all, where the register path below spends an index division, two address computations, a 16-byte and a 4-byte
+    // load, a repack, a ds_write_b128 and a maximum PER TEXEL (a first version that left addresses and predicates to hipcc kept the
+    // kernel's vector instruction count where it was: profiles/r06_c3).  dmax -- the farthest depth of the rectangle, for the occlusion
+    // cull -- comes from the maxima of 8 x 4 pixel blocks the packing launch leaves beside the texels (p.bmax): one look-up per thread
+    // over the blocks the rectangle touches, a superset of it, so the bound is conservative (it decides which bricks are skipped,
+    // never a value).  Texels are the same copies of the same pixels: same bits.
     constexpr bool DMA = KFX_FUSE_STAGE_DMA && !DXT;
     if constexpr (DMA) {
         if (use_tile) {   // (uniform)
-            const unsigned char* base = p.tex + ((size_t)ty0 * p.tpitch + (size_t)tx0 * 16u);
-            for (int r = wv; r < th; r += NW) {
-                const unsigned char* src = base + (size_t)r * p.tpitch + (size_t)lane * 16u;
-                float4* dst = s_tile + r * tw;
-#pragma unroll 1   // (unrolled, hipcc keeps the eight chunks' exec masks in scalar registers across the whole kernel: 78 SGPRs, spills into VGPR lanes and from there to scratch)
-                for (int c0 = 0; c0 < tw; c0 += 64) {
-                    if (c0 + lane < tw)
-                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)c0 * 16u),
-                                                         (__attribute__((address_space(3))) void*)(dst + c0), 16, 0, 0);
+            const unsigned lane16 = (unsigned)lane * 16u;
+            const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(char*)s_tile;
+            const int tail = tw & 63;                                            // texels of a row's last chunk (0: it is full)
+            const unsigned long long mask_tail = tail ? ((1ull << tail) - 1ull) : ~0ull;
+            const int chunks = (tw + 63) >> 6;
+            for (int r = wv; r < th; r += NW) {   // (scalar loop control: wv went through readfirstlane)
+                const unsigned char* rowp = p.tex + ((size_t)(ty0 + r) * p.tpitch + (size_t)tx0 * 16u);
+                unsigned dst = lds0 + (unsigned)(r * tw) * 16u;
+#pragma unroll 1
+                for (int c = 0; c < chunks; ++c, rowp += 1024, dst += 1024u) {
+                    const unsigned long long m = (c + 1 == chunks) ? mask_tail : ~0ull;
+                    unsigned long long keep_exec;
+                    unsigned keep_m0;
+                    asm volatile("s_mov_b64 %0, exec\n\t"
+                                 "s_mov_b32 %1, m0\n\t"
+                                 "s_mov_b64 exec, %2\n\t"
+                                 "s_mov_b32 m0, %3\n\t"
+                                 "s_nop 0\n\t"
+                                 "global_load_lds_dwordx4 %4, %5\n\t"
+                                 "s_mov_b32 m0, %1\n\t"
+                                 "s_mov_b64 exec, %0"
+                                 : "=&s"(keep_exec), "=&s"(keep_m0)
+                                 : "s"(m), "s"(dst), "v"(lane16), "s"(rowp)
+                                 : "memory");
                 }
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            for (int r = wv; r < th; r += NW) {
-                const float4* rowt = s_tile + r * tw;
-                for (int c = lane; c < tw; c += 64) dmax = fmaxf(dmax, rowt[c].w);
-            }
+            // the farthest depth: maxima of the 8 x 4 pixel blocks the rectangle touches (NaN-free: a block without a finite depth holds -inf)
+            {
+                const int bx0 = tx0 >> 3, nbx = ((tx0 + tw - 1) >> 3) - bx0 + 1, by0 = ty0 >> 2, nb = nbx * (((ty0 + th - 1) >> 2) - by0 + 1);
+                const float inv_nbx = 1.0f / (float)nbx;
+                for (int i = tid; i < nb; i += NT) {
+                    const int br = (int)(((float)i + 0.5f) * inv_nbx);   // i / nbx (i < 4096)
+                    dmax = fmaxf(dmax, p.bmax[(size_t)(by0 + br) * p.bw8 + (size_t)(bx0 + i - br * nbx)]);
+                }
 #pragma unroll
-            for (int off = 32; off > 0; off >>= 1) dmax = fmaxf(dmax, __shfl_xor(dmax, off, 64));
-            if (lane == 0) s_dmax[wv] = dmax;
+                for (int off = 32; off > 0; off >>= 1) dmax = fmaxf(dmax, __shfl_xor(dmax, off, 64));
+                if (lane == 0) s_dmax[wv] = dmax;
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMAs have landed; the barrier below covers the other waves'
         }
     }
     if (!DMA && use_tile) {
@@ -1522,14 +1550,42 @@ using namespace kfx;
 // ---- the packed texel image of the tiled kernels' LDS-DMA staging --------------------------------------------------------
 // {nx, ny, nz, depth} per pixel of the depth image: copies of the normal map's xyz and of the depth image (what the kernels'
 // register path packs texel by texel while it stages).
-__global__ __launch_bounds__(256) void k_pack_texels(const ImgView depth, const ImgView norm, unsigned char* __restrict__ tex, const size_t tpitch)
+// ... and the maximum finite depth of every block of 8 x 4 pixels (the workgroup's tile is 64 x 4: eight blocks), -inf where a
+// block has none: what the kernels bound a brick's farthest depth with (bmax: rows of bw8 floats, one row per four image rows).
+__global__ __launch_bounds__(256) void k_pack_texels(const ImgView depth, const ImgView norm, unsigned char* __restrict__ tex, const size_t tpitch,
+                                                     float* __restrict__ bmax, const unsigned bw8)
 {
-    const int u = blockIdx.x * 64 + (threadIdx.x & 63), v = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (u >= depth.w || v >= depth.h) return;
-    const float4 n = row<float4>(norm, (size_t)v)[u];
-    const float d = row<float>(depth, (size_t)v)[u];
-    reinterpret_cast<float4*>(tex + (size_t)v * tpitch)[u] = make_float4(n.x, n.y, n.z, d);
+    __shared__ float s_max[4][8];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int u = blockIdx.x * 64 + lane, v = blockIdx.y * 4 + wv;
+    float d = -__builtin_inff();
+    if (u < depth.w && v < depth.h) {
+        const float4 n = row<float4>(norm, (size_t)v)[u];
+        const float dd = row<float>(depth, (size_t)v)[u];
+        reinterpret_cast<float4*>(tex + (size_t)v * tpitch)[u] = make_float4(n.x, n.y, n.z, dd);
+        d = dd;
+    }
+    d = wave8_combine(fmaxf(d, -__builtin_inff()), [](float a, float b) { return fmaxf(a, b); });   // (fmaxf drops NaN)
+    if ((lane & 7) == 0) s_max[wv][lane >> 3] = d;
+    __syncthreads();
+    if (threadIdx.x < 8)
+        bmax[(size_t)blockIdx.y * bw8 + blockIdx.x * 8 + threadIdx.x] =
+            fmaxf(fmaxf(s_max[0][threadIdx.x], s_max[1][threadIdx.x]), fmaxf(s_max[2][threadIdx.x], s_max[3][threadIdx.x]));
 }
+
+// the packed image's geometry for a w x h depth image: texel rows of tpitch bytes, then the block maxima
+struct TexLayout { size_t tpitch, bmax_off, bytes; unsigned bw8, bh4; };
+static TexLayout tex_layout(size_t w, size_t h)
+{
+    TexLayout t;
+    t.tpitch = (w * 16 + 255) / 256 * 256;
+    t.bw8 = (unsigned)((w + 63) / 64 * 8);
+    t.bh4 = (unsigned)((h + 3) / 4);
+    t.bmax_off = t.tpitch * h;
+    t.bytes = t.bmax_off + (size_t)t.bw8 * t.bh4 * sizeof(float);
+    return t;
+}
+size_t kfx::texel_image_bytes(size_t w, size_t h) { return tex_layout(w, h).bytes; }
 
 // Library scratch for callers that bring depth and normals only (kfx_sdf_fuse and its siblings; kfx_frame_step brings the packed
 // image its fused preprocess wrote).  One buffer per calling thread, device and stream: the pack launch and the SdfFuse launches
@@ -1668,6 +1724,8 @@ static int fuse_params(FuseParams& p, bool* small_images, const kfx_volume* vol,
     p.sum_nbx = p.sum_nby = p.sum_bx0 = p.sum_by0 = p.sum_bz0 = p.sum_w = p.sum_h = p.sum_d = p.zoff_local = 0;
     p.tex = nullptr;
     p.tpitch = 0;
+    p.bmax = nullptr;
+    p.bw8 = 0;
     static const int swizzle_env = [] { const char* e = getenv("KFX_FUSE_XCD_SWIZZLE"); const int v = e ? atoi(e) : 1; return v < 0 ? 0 : (v > 8 ? 8 : v); }();
     p.xcd_swizzle = swizzle_env;
     static const int cull_env = [] { const char* e = getenv("KFX_FUSE_CULL"); return e ? atoi(e) : 1; }();
@@ -1844,20 +1902,21 @@ static int fuse_launch(const kfx_volume* vol, const kfx_image* depth, const kfx_
         bool any_plain = false;
         for (int ri = 0; ri < n_ranges; ++ri) any_plain = any_plain || !ranges[ri].plan.dxt;
         if (KFX_FUSE_STAGE_DMA && any_plain) {
-            const size_t tw_bytes = (size_t)depth->w * 16;
-            if (texels && texels->ptr && texels->w >= depth->w && texels->h >= depth->h && texels->pitch >= tw_bytes && texels->pitch < (1u << 24) &&
-                !(((uintptr_t)texels->ptr | texels->pitch) & 15)) {
+            // (the caller's packed image -- kfx::texel_image_bytes(w, h) bytes laid out by tex_layout, written by the fused preprocess --
+            //  is recognised by its geometry: w, h and pitch of the depth image's layout)
+            const TexLayout tl = tex_layout(depth->w, depth->h);
+            if (texels && texels->ptr && texels->w == depth->w && texels->h == depth->h && texels->pitch == tl.tpitch && !((uintptr_t)texels->ptr & 15)) {
                 p.tex = (const unsigned char*)texels->ptr;
-                p.tpitch = (unsigned)texels->pitch;
             } else {
-                const size_t tpitch = (tw_bytes + 255) / 256 * 256;
-                void* buf = tex_scratch(tpitch * depth->h, s);   // (tpitch < 2^24: small_images bounds the normal map's pitch, which is at least as long)
+                void* buf = tex_scratch(tl.bytes, s);   // (tpitch < 2^24: small_images bounds the normal map's pitch, which is at least as long)
                 if (!buf) return set_error((int)hipErrorOutOfMemory, "SdfFuse: no device memory for the packed texel image");
                 hipLaunchKernelGGL(k_pack_texels, dim3(ceil_div((int)depth->w, 64), ceil_div((int)depth->h, 4)), dim3(256), 0, s, p.depth, p.norm,
-                                   (unsigned char*)buf, tpitch);
+                                   (unsigned char*)buf, tl.tpitch, reinterpret_cast<float*>((unsigned char*)buf + tl.bmax_off), tl.bw8);
                 p.tex = (const unsigned char*)buf;
-                p.tpitch = (unsigned)tpitch;
             }
+            p.tpitch = (unsigned)tl.tpitch;
+            p.bmax = reinterpret_cast<const float*>(p.tex + tl.bmax_off);
+            p.bw8 = tl.bw8;
         }
         for (int ri = 0; ri < n_ranges; ++ri) {
             const Range& rg = ranges[rev ? n_ranges - 1 - ri : ri];

@@ -12,6 +12,7 @@
 #include <stdint.h>
 
 #include "../../include/kfx.h"
+#include "../../include/kfx_extras.h"
 
 namespace kfx {
 
@@ -261,6 +262,7 @@ int check_launch(const char* what);
 int math_mode(); // KFX_MATH_EXACT / KFX_MATH_FAST
 // kfx_frame_step's pair (frame.hip): the fused vbo / normals launch also writes the packed texel image {nx, ny, nz, depth} that the
 // SdfFuse of the same frame stages by LDS-DMA (preprocess.hip, fuse.hip); texels may be null
+size_t texel_image_bytes(size_t w, size_t h);   // the packed image of a w x h depth image: texel rows + block maxima (fuse.hip, tex_layout)
 int depth_to_vbo_normals_texels(const kfx_image* vbo, const kfx_image* nrm, const kfx_image* depth, const float K[4], float scale,
                                 const kfx_image* texels, kfx_stream stream);
 int sdf_fuse_slab_texels(const kfx_volume* vol, const kfx_slab* slab, const kfx_image* depth, const kfx_image* norm, const kfx_image* texels,

@@ -261,6 +261,8 @@ struct VboNrmParams {
     float scale;
     unsigned char* tex;   // optional: the packed texel image {nx, ny, nz, depth} the tiled SdfFuse kernels stage by LDS-DMA (fuse.hip)
     size_t tpitch;
+    float* bmax;          // ... with the maxima of its 8 x 4 pixel blocks behind it (rows of bw8 floats)
+    unsigned bw8;
 };
 __device__ __forceinline__ float4 vertex_of(const VboNrmParams& p, int u, int v)
 {
@@ -269,22 +271,36 @@ __device__ __forceinline__ float4 vertex_of(const VboNrmParams& p, int u, int v)
 }
 __global__ __launch_bounds__(256) void k_vbo_normals_f32(const VboNrmParams p)
 {
-    const int u = blockIdx.x * 64 + (threadIdx.x & 63), v = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (u >= p.w || v >= p.h) return;
-    const float4 Vc = vertex_of(p, u, v);
-    reinterpret_cast<float4*>(p.vbo + (size_t)v * p.vpitch)[u] = Vc;
-    float4 N = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (u + 1 < p.w && v + 1 < p.h) {
-        const float4 Vr = vertex_of(p, u + 1, v), Vu = vertex_of(p, u, v + 1);
-        const V3 a = v3(Vr.x - Vc.x, Vr.y - Vc.y, Vr.z - Vc.z);
-        const V3 b = v3(Vu.x - Vc.x, Vu.y - Vc.y, Vu.z - Vc.z);
-        const V3 axb = v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
-        const float mag = length(axb);
-        N = make_float4(-axb.x / mag, -axb.y / mag, -axb.z / mag, 1.0f);
+    __shared__ float s_max[4][8];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int u = blockIdx.x * 64 + lane, v = blockIdx.y * 4 + wv;
+    float d = -__builtin_inff();
+    if (u < p.w && v < p.h) {
+        const float4 Vc = vertex_of(p, u, v);
+        reinterpret_cast<float4*>(p.vbo + (size_t)v * p.vpitch)[u] = Vc;
+        float4 N = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (u + 1 < p.w && v + 1 < p.h) {
+            const float4 Vr = vertex_of(p, u + 1, v), Vu = vertex_of(p, u, v + 1);
+            const V3 a = v3(Vr.x - Vc.x, Vr.y - Vc.y, Vr.z - Vc.z);
+            const V3 b = v3(Vu.x - Vc.x, Vu.y - Vc.y, Vu.z - Vc.z);
+            const V3 axb = v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+            const float mag = length(axb);
+            N = make_float4(-axb.x / mag, -axb.y / mag, -axb.z / mag, 1.0f);
+        }
+        reinterpret_cast<float4*>(p.nrm + (size_t)v * p.npitch)[u] = N;
+        if (p.tex) {   // (uniform) what k_pack_texels (fuse.hip) would write: the normal's xyz and the depth image's own value ...
+            d = reinterpret_cast<const float*>(p.in + (size_t)v * p.in_pitch)[u];
+            reinterpret_cast<float4*>(p.tex + (size_t)v * p.tpitch)[u] = make_float4(N.x, N.y, N.z, d);
+        }
     }
-    reinterpret_cast<float4*>(p.nrm + (size_t)v * p.npitch)[u] = N;
-    if (p.tex)   // (uniform) what k_pack_texels would write: the normal's xyz and the depth image's own value
-        reinterpret_cast<float4*>(p.tex + (size_t)v * p.tpitch)[u] = make_float4(N.x, N.y, N.z, reinterpret_cast<const float*>(p.in + (size_t)v * p.in_pitch)[u]);
+    if (p.tex) {   // ... and the maximum finite depth of each of the tile's eight 8 x 4 pixel blocks
+        d = wave8_combine(fmaxf(d, -__builtin_inff()), [](float a, float b) { return fmaxf(a, b); });
+        if ((lane & 7) == 0) s_max[wv][lane >> 3] = d;
+        __syncthreads();
+        if (threadIdx.x < 8)
+            p.bmax[(size_t)blockIdx.y * p.bw8 + blockIdx.x * 8 + threadIdx.x] =
+                fmaxf(fmaxf(s_max[0][threadIdx.x], s_max[1][threadIdx.x]), fmaxf(s_max[2][threadIdx.x], s_max[3][threadIdx.x]));
+    }
 }
 
 struct EwParams {
@@ -730,10 +746,14 @@ int kfx::depth_to_vbo_normals_texels(const kfx_image* vbo, const kfx_image* nrm,
     if (vbo->w == 0 || vbo->h == 0) return 0;
     if (nrm->w != vbo->w || nrm->h != vbo->h || depth->w < vbo->w || depth->h < vbo->h)
         return set_error(KFX_E_SHAPE, "DepthToVbo+Normals: image sizes");
-    if (texels && (!texels->ptr || texels->w < vbo->w || texels->h < vbo->h || texels->pitch < vbo->w * 16 || (((uintptr_t)texels->ptr | texels->pitch) & 15)))
+    // texels: a buffer of kfx::texel_image_bytes(w, h) bytes in the layout of fuse.hip's tex_layout -- rows of `pitch` = w * 16 rounded up
+    // to 256 bytes, the block maxima behind them in rows of ceil(w / 64) * 8 floats
+    const size_t tpitch = (vbo->w * 16 + 255) / 256 * 256;
+    if (texels && (!texels->ptr || texels->w != vbo->w || texels->h != vbo->h || texels->pitch != tpitch || ((uintptr_t)texels->ptr & 15)))
         return set_error(KFX_E_SHAPE, "DepthToVbo+Normals: texel image");
     VboNrmParams p{(const unsigned char*)depth->ptr, depth->pitch, (unsigned char*)vbo->ptr, (unsigned char*)nrm->ptr, vbo->pitch, nrm->pitch,
-                   (int)vbo->w, (int)vbo->h, Intr{K[0], K[1], K[2], K[3]}, scale, texels ? (unsigned char*)texels->ptr : nullptr, texels ? texels->pitch : 0};
+                   (int)vbo->w, (int)vbo->h, Intr{K[0], K[1], K[2], K[3]}, scale, texels ? (unsigned char*)texels->ptr : nullptr, texels ? tpitch : 0,
+                   texels ? reinterpret_cast<float*>((unsigned char*)texels->ptr + tpitch * vbo->h) : nullptr, (unsigned)((vbo->w + 63) / 64 * 8)};
     hipLaunchKernelGGL(k_vbo_normals_f32, dim3(ceil_div(p.w, 64), ceil_div(p.h, 4)), dim3(256), 0, (hipStream_t)stream, p);
     return check_launch("kfx_depth_to_vbo_normals_f32");
 }

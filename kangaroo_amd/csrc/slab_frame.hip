@@ -202,7 +202,7 @@ extern "C" int kfx_slab_frame_create(kfx_slab_frame** out, const kfx_slab_frame_
     {   // the packed texel image of the frame's SdfFuse (no memory: the fuse packs per call instead)
         const size_t tpitch = (cfg->filtered.w * 16 + 255) / 256 * 256;
         void* buf = nullptr;
-        if (tpitch < (1u << 24) && hipMalloc(&buf, tpitch * cfg->filtered.h) == hipSuccess) f->texels = kfx_image{tpitch, buf, cfg->filtered.w, cfg->filtered.h};
+        if (tpitch < (1u << 24) && hipMalloc(&buf, kfx::texel_image_bytes(cfg->filtered.w, cfg->filtered.h)) == hipSuccess) f->texels = kfx_image{tpitch, buf, cfg->filtered.w, cfg->filtered.h};
         else (void)hipGetLastError();
     }
     int e = hip_status(hipMalloc((void**)&f->agree, 64), "kfx_slab_frame_create: hipMalloc");
