@@ -37,7 +37,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 N_ORBIT = 30
-PMC_TRAFFIC_FILES = ("profiles/r05_pmc_traffic.json", "profiles/r04_pmc_traffic.json")   # the first that exists
+PMC_TRAFFIC_FILES = ("profiles/r06_pmc_traffic.json", "profiles/r05_pmc_traffic.json")   # the first that was taken on the loaded kernels
 BLOCK = 60   # frames per priming / calibration block: two orbits (launch times depend on the pose)
 
 

@@ -36,13 +36,13 @@ RAY = {"fast": "k_raycast_sdf<RayF32, false>", "fast_tracked": "k_raycast_sdf_cl
 def main():
     full, room, dst = sections(sys.argv[1]), sections(sys.argv[2]), sys.argv[3]
     d = {"_note": "HBM-side traffic per call from rocprofv3 PMC passes of `python bench.py` (scripts/gpu_profile.sh: separate --pmc FETCH_SIZE / --pmc WRITE_SIZE "
-                  "runs; this file: scripts/make_pmc_traffic.py over the two summaries named on its command line: profiles/r05_full/summary.txt and profiles/r05_room/summary.txt). traffic = (2 x FETCH_SIZE + "
+                  "runs; this file: scripts/make_pmc_traffic.py over the two summaries named on its command line: %s and %s). traffic = (2 x FETCH_SIZE + " % (sys.argv[1], sys.argv[2]) +
                   "WRITE_SIZE) KiB -> bytes: on gfx950 FETCH_SIZE tallies a 128-byte request at 64 bytes (MI355X_MICROARCH.md, HBM section: double it); WRITE_SIZE "
                   "equals the byte count of the known 1 GiB fills of the same passes (k_fill_sdf, k_rmw_*) and is used as is. The counters sit between the XCDs' L2 "
                   "and the fabric: reads served by the 256 MiB memory-side cache are counted like reads from HBM. SdfFuse in S_room is two launches per call "
                   "(added up here). RaycastSdf gathers 16-byte cell pairs and its requests beyond the L2 are whole 128-byte lines, so its traffic exceeds 8 B x "
                   "distinct cells by the cells of those lines no ray samples (1.3-1.8 x), not by re-reads.",
-         "_commit": "the kernels whose source digests are recorded below (_kernel_source_id), as of profiles/r05_full and profiles/r05_room"}
+         "_commit": "the kernels whose source digests are recorded below (_kernel_source_id), as of %s and %s" % (os.path.dirname(sys.argv[1]), os.path.dirname(sys.argv[2]))}
 
     def entry(sec, name, launches=1):
         def find(table):

@@ -146,6 +146,10 @@ def main():
         r["c_composite_direct"] = run(N, 8, 3, "composite", "c", 300, merge="direct")
         r["c_composite_direct_two_events"] = run(N, 8, 3, "composite", "c", 300, merge="direct", events=6)
         r["c_exact_tiles4_two_events"] = run(N, 8, 3, "exact", "c", 300, tiles=4, events=6)
+        # round 6: frames pipelined -- the final exchange of frame k on the frame object's side stream (second communicator) under frame k + 1
+        r["c_exact_tiles4_pipelined_two_events"] = run(N, 8, 3, "exact", "c", 300, tiles=4, events=6, overlap=True)
+        r["c_exact_tiles1_pipelined_two_events"] = run(N, 8, 3, "exact", "c", 300, tiles=1, events=6, overlap=True)
+        r["c_exact_tiles1_two_events"] = run(N, 8, 3, "exact", "c", 300, tiles=1, events=6)
         r["c_composite_direct_overlapped"] = run(N, 8, 3, "composite", "c", 300, merge="direct", overlap=True)
         r["python_composite_direct"] = run(N, 8, 3, "composite", "python", 300, merge="direct")
         r["python_composite_direct_overlapped"] = run(N, 8, 3, "composite", "python", 300, merge="direct", overlap=True)
