@@ -20,7 +20,9 @@
 //     own -use_fast_math build, memory-bound.
 // Packed v_pk_*_f32 arithmetic was tried for the exact mode and dropped: on gfx950 a packed
 // op issues in 4 cycles, twice a scalar op, so it only saves issue slots (0.755 -> 0.726 ms).
+#include <cmath>
 #include <cstdlib>
+#include <cstring>
 
 #include <sys/syscall.h>
 #include <unistd.h>
@@ -79,7 +81,19 @@ struct FuseParams {
     // ... and, behind the texels, the maximum finite depth of every block of 8 x 4 pixels (-inf: none), rows of bw8 floats
     const float* bmax;
     unsigned bw8;
+    // voxel positions (BoundedVolume.h:115-125): min + size * i / (float)(dim - 1) divides by a launch-uniform value, so the tiled
+    // kernels take div_uniform (kfx_device.h: the host's correctly rounded reciprocal + one Markstein correction = the IEEE quotient,
+    // three instructions instead of twelve) when sizes and extents are in its safe range (pos_div); else the hardware division
+    float inv_w1, inv_h1;
+    int pos_div;
 };
+
+// min + size * i / n1 with the reference's operations: the product, the division (IEEE quotient either way), the addition
+__device__ __forceinline__ float voxel_pos(float bmin, float size, int i, float n1, float inv_n1, int pos_div)
+{
+    const float a = size * (float)i;
+    return bmin + (pos_div ? div_uniform(a, n1, inv_n1) : a / n1);
+}
 
 struct Obs {
     float val, w;
@@ -513,10 +527,10 @@ __global__ __launch_bounds__(64 * NW, (FAST && ZU == 2) ? 8 : (!FAST ? 6 : 1)) v
     }
     __syncthreads();
 
-    const float py = p.bmin.y + p.size.y * (float)y / p.h1;
+    const float py = voxel_pos(p.bmin.y, p.size.y, y, p.h1, p.inv_h1, p.pos_div);
     CamXY<FAST> cam[2];
 #pragma unroll
-    for (int v = 0; v < 2; ++v) cam[v].init(p, p.bmin.x + p.size.x * (float)(x0 + v) / p.w1, py);
+    for (int v = 0; v < 2; ++v) cam[v].init(p, voxel_pos(p.bmin.x, p.size.x, x0 + v, p.w1, p.inv_w1, p.pos_div), py);
 
     // ---- pixel rectangle of the brick: the projections of its eight corners ----
     // A pinhole camera maps a convex body in front of it onto the convex hull of its vertices' images, so the corners of the brick --
@@ -535,7 +549,7 @@ __global__ __launch_bounds__(64 * NW, (FAST && ZU == 2) ? 8 : (!FAST ? 6 : 1)) v
         const int yc = (c & 2) ? min(yb0 + BY, p.Y) - 1 : yb0;
         const float pzc = s_pz[(c & 4) ? (zend - 1 - zbeg) : 0];
         CamXY<FAST> cc;
-        cc.init(p, p.bmin.x + p.size.x * (float)xc / p.w1, p.bmin.y + p.size.y * (float)yc / p.h1);
+        cc.init(p, voxel_pos(p.bmin.x, p.size.x, xc, p.w1, p.inv_w1, p.pos_div), voxel_pos(p.bmin.y, p.size.y, yc, p.h1, p.inv_h1, p.pos_div));
         const V3 Pc = cc.at(p, pzc);
         float pu, pv, iz;
         project<FAST>(p, Pc, pu, pv, iz);
@@ -1666,6 +1680,26 @@ static VolView vol_view(const kfx_volume* vol)
 }
 
 // Fills the kernel parameters; *small_images tells whether the 32-bit image offsets are usable.
+// true when div_uniform(size * i, dim - 1) equals size * i / (dim - 1) for every i of the axis (host arithmetic: fmaf and the division
+// are correctly rounded, as on the device); the last answer per axis is remembered
+static bool pos_div_verified(int axis, float size, int dim)
+{
+    struct Memo { float size; int dim; bool ok; };
+    static thread_local Memo memo[2] = {{0.0f, 0, false}, {0.0f, 0, false}};
+    Memo& m = memo[axis];
+    if (m.dim == dim && memcmp(&m.size, &size, sizeof(float)) == 0) return m.ok;
+    const float n1 = (float)(dim - 1), inv = 1.0f / n1;
+    bool ok = div_uniform_safe_host(size) && div_uniform_safe_host(size * n1);
+    for (int i = 0; ok && i < dim; ++i) {
+        const float a = size * (float)i;
+        const float q0 = a * inv;
+        const float q = fmaf(fmaf(-n1, q0, a), inv, q0), d = a / n1;
+        ok = memcmp(&q, &d, sizeof(float)) == 0;
+    }
+    m = {size, dim, ok};
+    return ok;
+}
+
 static int fuse_params(FuseParams& p, bool* small_images, const kfx_volume* vol, const kfx_image* depth,
                        const kfx_image* norm, const float T_cw[12], const float K[4], float trunc_dist, float max_w,
                        float mincostheta, unsigned flags, size_t cell = 8, const kfx_slab* slab = nullptr)
@@ -1726,6 +1760,12 @@ static int fuse_params(FuseParams& p, bool* small_images, const kfx_volume* vol,
     p.tpitch = 0;
     p.bmax = nullptr;
     p.bw8 = 0;
+    // div_uniform is taken only where the host has compared it with the IEEE division for EVERY index of the axis (cached per axis:
+    // a volume's extents do not change between frames), so the positions are the reference's by construction
+    p.inv_w1 = 1.0f / p.w1;
+    p.inv_h1 = 1.0f / p.h1;
+    static const int pos_div_env = [] { const char* e = getenv("KFX_FUSE_POS_DIV"); return e ? atoi(e) : 1; }();
+    p.pos_div = (pos_div_env && vol->w >= 2 && vol->h >= 2 && pos_div_verified(0, p.size.x, (int)vol->w) && pos_div_verified(1, p.size.y, (int)vol->h)) ? 1 : 0;
     static const int swizzle_env = [] { const char* e = getenv("KFX_FUSE_XCD_SWIZZLE"); const int v = e ? atoi(e) : 1; return v < 0 ? 0 : (v > 8 ? 8 : v); }();
     p.xcd_swizzle = swizzle_env;
     static const int cull_env = [] { const char* e = getenv("KFX_FUSE_CULL"); return e ? atoi(e) : 1; }();

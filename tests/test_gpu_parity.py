@@ -1546,6 +1546,7 @@ def test_gpu_division_by_uniform_divisor_is_the_ieee_quotient(roo):
     mant = rng.integers(0, 1 << 23, 24, dtype=np.uint32)
     expo = rng.integers(127 - 39, 127 + 39, 24, dtype=np.uint32)
     divisors += [float(x) for x in ((expo << 23) | mant).view(np.float32)]
+    divisors += [511.0, 1023.0, 255.0, 2047.0, 199.0]   # dims - 1: the tiled SdfFuse kernels' voxel positions (fuse.hip voxel_pos)
     out = torch.zeros(2, dtype=torch.int64, device="cuda")
     for b in divisors:
         out.zero_()
