@@ -366,15 +366,14 @@ int kfx_raycast_sdf_slab(float* state, int init, const kfx_volume* vol, const kf
                          int w, int h, const float T_wc[12], const float K[4], float near, float far,
                          float trunc_dist, int subpix, kfx_stream stream);
 /* The same round on a range of image rows [v0, v1), with the state kept per row-tile (the tile-pipelined hand-over of
- * kfx_slab_raycast_exact_tiled, kfx_slab.h): tile t = rows [t R, (t + 1) R), R = rows_per_tile; its march planes 0-4 lie at
- * state + (t * 5 + k) * plane_stride, its normal / shade planes at result + (t * 4 + k) * plane_stride (plane_stride >= R w
- * pixels), so that the five march planes of one tile are one contiguous message.  fin (optional, dense w h ints): set to 1
+ * kfx_slab_raycast_exact_tiled, kfx_slab.h): tile t = rows [t R, (t + 1) R), R = rows_per_tile; its march planes 0-3 lie at
+ * state + (t * 4 + k) * plane_stride, its normal / shade planes at result + (t * 4 + k) * plane_stride (plane_stride >= R w
+ * pixels), so that the march state of one tile -- 16 bytes per pixel; plane 4 is not kept -- is one contiguous message.  fin (optional, dense w h ints): set to 1
  * where this call gives a ray its final status; an initialising call clears it first, and with claim_misses sets it for rays that
  * never enter the box (one rank answers for those).  adopt_lo / adopt_hi (optional): snapshots of the same rays received from
- * the two neighbour ranks, march planes as above -- of ONE tile ([5][plane_stride], the tile of rows v0 .. v1) or, with
+ * the two neighbour ranks, march planes as above -- of ONE tile ([4][plane_stride], the tile of rows v0 .. v1) or, with
  * adopt_tile_major, of all tiles: before marching, a ray takes a neighbour's snapshot when it is newer than its own (a final or
- * hit status is later than "marching", a larger lambda later than a smaller) and still under way.  One tile of R = h rows,
- * plane_stride = w h, result = state + 5 w h is kfx_raycast_sdf_slab's dense state. */
+ * hit status is later than "marching", a larger lambda later than a smaller) and still under way. */
 int kfx_raycast_sdf_slab_tiles(float* state, float* result, size_t plane_stride, int rows_per_tile, int v0, int v1, int init, int* fin,
                                int claim_misses, const float* adopt_lo, const float* adopt_hi, int adopt_tile_major, const kfx_volume* vol,
                                const kfx_slab* slab, int own_lo, int own_hi, int w, int h, const float T_wc[12], const float K[4], float near,

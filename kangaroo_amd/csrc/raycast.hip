@@ -667,10 +667,12 @@ __global__ __launch_bounds__(256) void k_raycast_sdf_levels_classes(const RayPar
 // ranks' states with one integer SUM all-reduce of the touched pixels' planes 0-4.
 // ---------------------------------------------------------------------------------------
 struct SlabRay {
-    // State of tile t (rows [t R, (t + 1) R) of the image, pixel q = (v - t R) w + u of it): march planes 0-4 at
-    // state + (t * 5 + k) * P + q, normal / shade planes 5-8 at result + (t * 4 + k - 5) * P + q.  One tile of R = h rows with
-    // P = w h and result = state + 5 P is the dense [9][h w] layout of kfx_raycast_sdf_slab.
+    // State of tile t (rows [t R, (t + 1) R) of the image, pixel q = (v - t R) w + u of it): march planes 0-3 at
+    // state + (t * 4 + k) * P + q -- what travels with a ray: one contiguous message per tile --, normal / shade planes 5-8 at
+    // result + (t * 4 + k - 5) * P + q.  touched (plane 4; null: not kept): the dense state's, for ONE tile.  One tile of R = h rows with
+    // P = w h, touched = state + 4 P and result = state + 5 P is the dense [9][h w] layout of kfx_raycast_sdf_slab.
     float* state;
+    float* touched;
     float* result;
     size_t P;           // plane stride in pixels (>= R w)
     int R;              // rows per tile
@@ -682,7 +684,7 @@ struct SlabRay {
     int init;           // 1: (re)initialise the state from the ray / box intersection
     // Snapshots of the same rays received from the two neighbour ranks (march planes 0-3 as above; null: none): before marching, a
     // ray takes a neighbour's snapshot when that one is NEWER than its own and still under way (kfx_slab_raycast_exact_tiled).
-    // adopt_tile_major: the buffers hold every tile ([tiles][5][P]) instead of just the tile of this launch ([5][P]).
+    // adopt_tile_major: the buffers hold every tile ([tiles][4][P]) instead of just the tile of this launch ([4][P]).
     const float* adopt_lo;
     const float* adopt_hi;
     int adopt_tile_major;
@@ -713,7 +715,7 @@ __global__ __launch_bounds__(256) void k_raycast_sdf_slab(const RayParams p, con
     const size_t plane = sl.P;
     const int tile = v / sl.R;
     const size_t q = (size_t)(v - tile * sl.R) * p.w + u;
-    float* st = sl.state + (size_t)tile * 5 * plane + q;   // plane k at st[k * plane]
+    float* st = sl.state + (size_t)tile * 4 * plane + q;   // plane k at st[k * plane]
     float* rs = sl.result + (size_t)tile * 4 * plane + q;  // normal x / y / z, shade
 
     const V3 c_w = v3(p.T.m[3], p.T.m[7], p.T.m[11]);
@@ -743,7 +745,7 @@ __global__ __launch_bounds__(256) void k_raycast_sdf_slab(const RayParams p, con
     for (int k = 0; k < 2; ++k) {
         const float* src = k ? sl.adopt_hi : sl.adopt_lo;
         if (!src) continue;
-        src += (sl.adopt_tile_major ? (size_t)tile * 5 * plane : (size_t)0) + q;
+        src += (sl.adopt_tile_major ? (size_t)tile * 4 * plane : (size_t)0) + q;
         const float n_status = src[3 * plane];
         if (!(n_status == 0.f || n_status == 3.f)) continue;
         const float n_lambda = src[0];
@@ -791,7 +793,7 @@ __global__ __launch_bounds__(256) void k_raycast_sdf_slab(const RayParams p, con
     }
     const bool changed = lambda != lambda_in || status != status_in;
     st[0] = lambda; st[plane] = last_sdf; st[2 * plane] = delta; st[3 * plane] = status;
-    st[4 * plane] = changed ? 1.0f : 0.0f;
+    if (sl.touched) sl.touched[q] = changed ? 1.0f : 0.0f;
     if (sl.fin && changed && (status == 1.f || status == 2.f)) sl.fin[(size_t)v * p.w + u] = 1;
 }
 
@@ -1207,7 +1209,7 @@ static SlabRay dense_state(float* state, int init, int w, int h)
 {
     SlabRay g{};
     const size_t n = (size_t)(w > 0 ? w : 0) * (size_t)(h > 0 ? h : 0);
-    g.state = state; g.result = state ? state + 5 * n : nullptr; g.P = n; g.R = h > 0 ? h : 1; g.v0 = 0; g.v1 = h; g.fin = nullptr; g.claim_misses = 0;
+    g.state = state; g.touched = state ? state + 4 * n : nullptr; g.result = state ? state + 5 * n : nullptr; g.P = n; g.R = h > 0 ? h : 1; g.v0 = 0; g.v1 = h; g.fin = nullptr; g.claim_misses = 0;
     g.init = init ? 1 : 0;
     g.adopt_lo = g.adopt_hi = nullptr; g.adopt_tile_major = 0;
     return g;

@@ -110,7 +110,8 @@ __global__ __launch_bounds__(256) void k_handover_finish(int* __restrict__ state
 }
 
 // ---- tile-pipelined hand-over (kfx_slab_raycast_exact_tiled) ---------------------------------------------------------
-// State per row-tile t (kfx.h, kfx_raycast_sdf_slab_tiles): march planes at M + (t * 5 + k) * P, results at Rz + (t * 4 + k) * P.
+// State per row-tile t (kfx.h, kfx_raycast_sdf_slab_tiles): the four march planes {lambda, last_sdf, delta, status} at M + (t * 4 + k) * P
+// (16 B per pixel: the token of a tile), results at Rz + (t * 4 + k) * P.
 // "Newer wins": a ray's copies on different ranks are snapshots of ONE march; status 1 / 2 (final) is later than 3 (hit, normal
 // pending) is later than 0 (marching), and of two marching snapshots the one with the larger lambda is later (every step adds a
 // positive delta).  A rank never advances a stale copy -- it advances a ray only while the base plane of its current sample is
@@ -137,7 +138,7 @@ __global__ __launch_bounds__(256) void k_tiles_contrib(const int* __restrict__ M
     const size_t n = (size_t)w * h, i = (size_t)v * w + u;
     const int t = v / R;
     const size_t q = (size_t)(v - t * R) * w + u;
-    const int* st = M + (size_t)t * 5 * P + q;
+    const int* st = M + (size_t)t * 4 * P + q;
     const int* rs = Rz + (size_t)t * 4 * P + q;
     const bool mine = fin[i] != 0;
     contrib[result_index(0, i, n, S)] = mine ? st[0] : 0;
@@ -808,10 +809,10 @@ size_t tiled_layout(TiledScratch& t, void* scratch, size_t w, size_t h, int tile
     int* base = static_cast<int*>(scratch);
     size_t o = 0;
     const auto take = [&](size_t ints) { int* q = base ? base + o : nullptr; o += ints; return q; };
-    t.M = take((size_t)t.T * 5 * t.P);
+    t.M = take((size_t)t.T * 4 * t.P);
     t.Rz = take((size_t)t.T * 4 * t.P);
-    t.from_lo = take((size_t)t.T * 5 * t.P);
-    t.from_hi = take((size_t)t.T * 5 * t.P);
+    t.from_lo = take((size_t)t.T * 4 * t.P);
+    t.from_hi = take((size_t)t.T * 4 * t.P);
     t.fin = take((t.n + 63) / 64 * 64);
     const FinalSizes z = final_sizes(w, h, world);
     t.S = z.S;
@@ -878,7 +879,7 @@ int kfx::exact_tiled_march(void* scratch, const ExactFinalBufs* into, const kfx_
     tiled_layout(t, scratch, (size_t)w, (size_t)h, tiles, world);
     const ExactFinalBufs& fb = into ? *into : t.own;
     const int T = t.T, R = t.R;
-    const size_t P = t.P, tile_bytes = 5 * P * sizeof(int);
+    const size_t P = t.P, tile_bytes = 4 * P * sizeof(int);   // lambda, last_sdf, delta, status of every pixel of the tile
     hipStream_t s = (hipStream_t)stream;
     const kfx_slab slab = {L->full_d, L->s0, L->full_zmin, L->full_zmax};
     // a local failure must not keep this rank out of a collective its peers enter: remember it, go on, report it at the end
@@ -940,8 +941,8 @@ int kfx::exact_tiled_march(void* scratch, const ExactFinalBufs* into, const kfx_
             const bool from_below = need_up && rank > 0 && A + 1 >= 0 && A + 1 < T, from_above = need_down && rank + 1 < world && B + 1 >= 0 && B + 1 < T;
             // (every rank calls the exchange in every step, with empty legs where it has nothing to pass on: a transport may
             //  synchronise its ranks inside the call, as the in-process one does in its barrier mode)
-            note(comm->exchange_v(comm, down ? t.M + (size_t)B * 5 * P : nullptr, down ? tile_bytes : 0, from_below ? t.from_lo : nullptr, from_below ? tile_bytes : 0,
-                                  up ? t.M + (size_t)A * 5 * P : nullptr, up ? tile_bytes : 0, from_above ? t.from_hi : nullptr, from_above ? tile_bytes : 0, stream));
+            note(comm->exchange_v(comm, down ? t.M + (size_t)B * 4 * P : nullptr, down ? tile_bytes : 0, from_below ? t.from_lo : nullptr, from_below ? tile_bytes : 0,
+                                  up ? t.M + (size_t)A * 4 * P : nullptr, up ? tile_bytes : 0, from_above ? t.from_hi : nullptr, from_above ? tile_bytes : 0, stream));
             got_lo = from_below; got_hi = from_above;
         }
         // one more stage over the whole image: a hit whose sub-step interpolation fell back across a slab boundary has its normal

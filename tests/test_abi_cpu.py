@@ -456,9 +456,9 @@ def test_slab_frame_and_tiled_march_validate_their_arguments_without_a_gpu():
     assert L.kfx_slab_frame_count(None) == 0 and L.kfx_slab_frame_destroy(None) == 0
     # the tiled hand-over: scratch size grows with the tile count only by the padding of the last tile, arguments are checked
     one, four = L.kfx_slab_exact_tiled_scratch_bytes(640, 480, 1, 1), L.kfx_slab_exact_tiled_scratch_bytes(640, 480, 4, 1)
-    assert one == four == (5 + 4 + 5 + 5 + 1 + 6) * 640 * 480 * 4 + 256 and L.kfx_slab_exact_tiled_scratch_bytes(640, 487, 8, 1) >= one
+    assert one == four == (4 + 4 + 4 + 4 + 1 + 6) * 640 * 480 * 4 + 256 and L.kfx_slab_exact_tiled_scratch_bytes(640, 487, 8, 1) >= one
     eight = L.kfx_slab_exact_tiled_scratch_bytes(640, 480, 4, 8)   # + the strips of the final exchange: [8][6][S] twice over, [6][S]
-    assert eight == (5 + 4 + 5 + 5 + 1) * 640 * 480 * 4 + (2 * 8 + 1) * 6 * 38400 * 4 + 256
+    assert eight == (4 + 4 + 4 + 4 + 1) * 640 * 480 * 4 + (2 * 8 + 1) * 6 * 38400 * 4 + 256
     assert L.kfx_slab_raycast_exact_tiled(None, None, None, None, None, None, None, None, 0.4, 4.0, 0.01, 1, 4, None, None, None, None) == -1
 
 
