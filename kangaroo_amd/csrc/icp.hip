@@ -480,8 +480,10 @@ __device__ void lu_solve_wave(const float* sums, SolveLds& w)   // leaves x[0 ..
 // T_lane: st->T[lane] in lanes 0 .. 11, requested by the caller before the block sums were added up (one memory round trip
 // less on the one-lane tail)
 // always_store: write T even when the step is refused (the first evaluation of a call: st->T still holds the previous call's pose)
+// mailbox (optional): 16 doubles of host memory mapped into the device's address space -- the call's result {T, rmse, obs, good} goes
+// there too, then the sequence word (system-scope release) the host spins on (kfx_icp_refine: no copy command for the read-back)
 __device__ void icp_solve_step_wave(RefineState* st, const float* sums, const int rotation_only, const float max_rmse, const float K_next[4], SolveLds& w,
-                                    const double T_lane, const bool always_store = false)
+                                    const double T_lane, const bool always_store = false, double* mailbox = nullptr, const unsigned seq = 0u)
 {
     const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));   // (the lane within the wave, whatever the block's shape)
     if (rotation_only) lu_solve_wave<3>(sums, w);
@@ -509,6 +511,13 @@ __device__ void icp_solve_step_wave(RefineState* st, const float* sums, const in
     if (moved || always_store)
         for (int m = 0; m < 12; ++m) st->T[m] = T[m];
     publish_pose(st, K_next, T);
+    if (mailbox) {   // (T is what st->T holds now: the step, or the pose before it when the step was refused)
+        for (int m = 0; m < 12; ++m) mailbox[m] = T[m];
+        mailbox[12] = (double)rmse;
+        mailbox[13] = (double)obs;
+        mailbox[14] = rmse < max_rmse ? 1.0 : 0.0;
+        __hip_atomic_store(reinterpret_cast<unsigned*>(mailbox + 15), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 // k_lss_final followed by the 6x6 step as one launch (the device-resident loop is a chain of ~5 us kernels: every launch saved is
@@ -516,7 +525,7 @@ __device__ void icp_solve_step_wave(RefineState* st, const float* sums, const in
 // the first wave solves it.
 // first: the first evaluation of a kfx_icp_refine call -- the pose before the step is the identity (no initialising launch)
 __global__ __launch_bounds__(256) void k_lss_final_solve(float* sums, const int nblocks, RefineState* st, const int rotation_only,
-                                                         const float max_rmse, const K4 K_next, const int first)
+                                                         const float max_rmse, const K4 K_next, const int first, double* mailbox, const unsigned seq)
 {
     __shared__ float lds[LSS_WORDS * 128];
     __shared__ float s_sum[LSS_WORDS];
@@ -537,7 +546,7 @@ __global__ __launch_bounds__(256) void k_lss_final_solve(float* sums, const int 
         lss_store(s_sum, acc);
     }
     __syncthreads();
-    if (tid < 64) icp_solve_step_wave(st, s_sum, rotation_only, max_rmse, K_next.k, s_solve, T_lane, first != 0);
+    if (tid < 64) icp_solve_step_wave(st, s_sum, rotation_only, max_rmse, K_next.k, s_solve, T_lane, first != 0, mailbox, seq);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -907,6 +916,30 @@ static int icp_refine_impl(const kfx_icp_level* levels, int n_levels, float c, f
         pose_floats(pose0, k0.k, I12);
     }
     if (first < 0) hipLaunchKernelGGL(k_icp_refine_init, dim3(1), dim3(1), 0, s, st, k0);
+    // The result's way to the host: the LAST solve writes {T, rmse, obs, good} and a sequence word into a mailbox of page-locked host
+    // memory mapped into the device's address space (one per calling thread) and this thread spins on the word -- no copy command
+    // (4 us of the stream per frame), no wait for an event (as kfx_icp_point_plane's mailbox; KFX_ICP_MAILBOX=0: the copy below)
+    struct Mailbox { double* host; double* dev; unsigned seq; };
+    thread_local Mailbox mb = {nullptr, nullptr, 0u};
+    static const bool mailbox_env = [] { const char* e = getenv("KFX_ICP_MAILBOX"); return !e || atoi(e) != 0; }();
+    if (mailbox_env && !mb.host) {
+        void* h = nullptr;
+        void* d = nullptr;
+        if (hipHostMalloc(&h, 128, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess && hipHostGetDevicePointer(&d, h, 0) == hipSuccess) {
+            memset(h, 0, 128);
+            mb.host = (double*)h; mb.dev = (double*)d;
+        } else {
+            (void)hipGetLastError();
+            if (h) (void)hipHostFree(h);
+            mb.host = nullptr;
+        }
+    }
+    int evaluations = 0;
+    for (int l = 0; l < n_levels; ++l)
+        if (levels[l].iterations > 0 && levels[l].Pl.w && levels[l].Pl.h) evaluations += levels[l].iterations;
+    const bool use_mailbox = mailbox_env && mb.host != nullptr && evaluations > 0;
+    const unsigned seq = use_mailbox ? (++mb.seq ? mb.seq : ++mb.seq) : 0u;   // (never 0: the word's initial value)
+    int evaluation = 0;
     bool first_eval = true;
     for (int l = 0; l < n_levels; ++l) {
         const kfx_icp_level& L = levels[l];
@@ -941,12 +974,46 @@ static int icp_refine_impl(const kfx_icp_level* levels, int n_levels, float c, f
             } else {
                 hipLaunchKernelGGL(k_icp_point_plane, grid, block, lds_bytes, s, p);
             }
-            hipLaunchKernelGGL(k_lss_final_solve, dim3(1), dim3(256), 0, s, sums, nblocks, st, L.rotation_only ? 1 : 0, max_rmse, kn, first_eval ? 1 : 0);
+            const bool last = ++evaluation == evaluations;
+            hipLaunchKernelGGL(k_lss_final_solve, dim3(1), dim3(256), 0, s, sums, nblocks, st, L.rotation_only ? 1 : 0, max_rmse, kn, first_eval ? 1 : 0,
+                               (use_mailbox && last) ? mb.dev : nullptr, seq);
             first_eval = false;
         }
     }
     int e0 = check_launch("kfx_icp_refine");
     if (e0) return e0;
+    const auto deliver = [&](const double* r) {
+        for (int i = 0; i < 12; ++i) T_lp[i] = r[i];
+        if (rmse) *rmse = (float)r[12];
+        if (obs) *obs = (unsigned)r[13];
+        if (tracking_good) *tracking_good = r[14] != 0.0 ? 1 : 0;
+    };
+    if (use_mailbox) {
+        // the caller's work that does not depend on the pose (the next frame's pre-amble) goes behind the chain first and runs while
+        // this thread looks at the word
+        if (enqueue_more) enqueue_more(user);
+        volatile unsigned* word = reinterpret_cast<volatile unsigned*>(mb.host + 15);
+        // bounded: every 4096 looks the stream is asked whether it is still running -- a launch that failed on the device, or a word
+        // that never arrives, ends in the synchronising path below instead of a hang
+        bool arrived = false;
+        for (unsigned spins = 0; !arrived; ++spins) {
+            if (__atomic_load_n(const_cast<unsigned*>(word), __ATOMIC_ACQUIRE) == seq) { arrived = true; break; }
+            __builtin_ia32_pause();
+            if ((spins & 4095u) == 4095u) {
+                const hipError_t q = hipStreamQuery(s);
+                if (q != hipErrorNotReady) {
+                    (void)hipGetLastError();
+                    arrived = __atomic_load_n(const_cast<unsigned*>(word), __ATOMIC_ACQUIRE) == seq;
+                    break;
+                }
+            }
+        }
+        if (arrived) {
+            deliver(mb.host);
+            return 0;
+        }
+        enqueue_more = nullptr;   // (already called)
+    }
     thread_local double* stage = nullptr;
     if (!stage && hipHostMalloc((void**)&stage, 15 * sizeof(double), hipHostMallocDefault) != hipSuccess) return set_error(KFX_E_RANGE, "kfx_icp_refine: pinned staging");
     hipError_t e = hipMemcpyAsync(stage, st, 15 * sizeof(double), hipMemcpyDeviceToHost, s);
@@ -964,10 +1031,7 @@ static int icp_refine_impl(const kfx_icp_level* levels, int n_levels, float c, f
         e = hipStreamSynchronize(s);
     }
     if (e != hipSuccess) return set_error((int)e, hipGetErrorString(e));
-    for (int i = 0; i < 12; ++i) T_lp[i] = stage[i];
-    if (rmse) *rmse = (float)stage[12];
-    if (obs) *obs = (unsigned)stage[13];
-    if (tracking_good) *tracking_good = stage[14] != 0.0 ? 1 : 0;
+    deliver(stage);
     return 0;
 }
 
