@@ -146,8 +146,8 @@ int kfx_slab_raycast_exact_allreduce(const kfx_image* depth, const kfx_image* no
 /* The hand-over pipelined over image row-tiles ("<= 7 hops pipelined over image tiles").  A ray moves
  * through the slabs monotonically, so the march state of a tile travels as a token: upwards 0 -> 1 -> ... -> world - 1 (rays
  * with rising z) and downwards at the same time; rank r marches tile t when the upward token reaches it (step r + t) and when
- * the downward one does (step world - 1 - r + t), and passes the tile's four march planes (lambda, last_sdf, delta, status: 16 B per pixel) on to ONE neighbour -- a message of
- * 1 / tiles of the image per link and step, world + tiles - 1 steps, against world stages of whole images.  Every rank
+ * the downward one does (step world - 1 - r + t), and passes the tile's march state (three planes: lambda, last_sdf, and delta or -status: 12 B per pixel) on to ONE neighbour -- a
+ * message of 1 / tiles of the image per link and step, world + tiles - 1 steps, against world stages of whole images.  Every rank
  * initialises every ray itself (the entry slab's owner starts it); a rank adopts a neighbour's copy of a ray when that copy is
  * NEWER than its own (a final or hit status beats "marching", a larger lambda beats a smaller) and still under way.  One last
  * stage with a whole-image neighbour exchange lets a hit whose sub-step interpolation fell back across a slab boundary get its

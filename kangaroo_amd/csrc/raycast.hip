@@ -671,9 +671,14 @@ struct SlabRay {
     // state + (t * 4 + k) * P + q -- what travels with a ray: one contiguous message per tile --, normal / shade planes 5-8 at
     // result + (t * 4 + k - 5) * P + q.  touched (plane 4; null: not kept): the dense state's, for ONE tile.  One tile of R = h rows with
     // P = w h, touched = state + 4 P and result = state + 5 P is the dense [9][h w] layout of kfx_raycast_sdf_slab.
+    // packed: THREE march planes per tile, at state + (t * 3 + k) * P + q: lambda, last_sdf and delta-or-status -- a marching ray's
+    // delta (positive: the caller guarantees a positive truncation distance and voxel size), or -status of a ray that is not
+    // marching (-1 hit, -2 miss, -3 hit awaiting its normal: such a ray's delta is never read again).  12 bytes per ray and hop
+    // (SURVEY 8(e)); the received snapshots have the same layout.
     float* state;
     float* touched;
     float* result;
+    int packed;
     size_t P;           // plane stride in pixels (>= R w)
     int R;              // rows per tile
     int v0, v1;         // rows this launch processes
@@ -715,7 +720,8 @@ __global__ __launch_bounds__(256) void k_raycast_sdf_slab(const RayParams p, con
     const size_t plane = sl.P;
     const int tile = v / sl.R;
     const size_t q = (size_t)(v - tile * sl.R) * p.w + u;
-    float* st = sl.state + (size_t)tile * 4 * plane + q;   // plane k at st[k * plane]
+    const int NP = sl.packed ? 3 : 4;
+    float* st = sl.state + (size_t)tile * NP * plane + q;   // plane k at st[k * plane]
     float* rs = sl.result + (size_t)tile * 4 * plane + q;  // normal x / y / z, shade
 
     const V3 c_w = v3(p.T.m[3], p.T.m[7], p.T.m[11]);
@@ -737,7 +743,9 @@ __global__ __launch_bounds__(256) void k_raycast_sdf_slab(const RayParams p, con
         rs[0] = 0.f; rs[plane] = 0.f; rs[2 * plane] = 0.f; rs[3 * plane] = 0.f;
         if (sl.fin) sl.fin[(size_t)v * p.w + u] = (sl.claim_misses && status == 2.f) ? 1 : 0;
     } else {
-        lambda = st[0]; last_sdf = st[plane]; delta = st[2 * plane]; status = st[3 * plane];
+        lambda = st[0]; last_sdf = st[plane]; delta = st[2 * plane];
+        if (sl.packed) { status = delta < 0.f ? -delta : 0.f; delta = delta < 0.f ? 0.f : delta; }
+        else status = st[3 * plane];
     }
     // a neighbour's newer, still open snapshot of this ray replaces the rank's own (a stale copy is never advanced: its position
     // lies in planes of a rank the ray has left, and final snapshots stay with the rank that finalised them)
@@ -745,13 +753,14 @@ __global__ __launch_bounds__(256) void k_raycast_sdf_slab(const RayParams p, con
     for (int k = 0; k < 2; ++k) {
         const float* src = k ? sl.adopt_hi : sl.adopt_lo;
         if (!src) continue;
-        src += (sl.adopt_tile_major ? (size_t)tile * 4 * plane : (size_t)0) + q;
-        const float n_status = src[3 * plane];
+        src += (sl.adopt_tile_major ? (size_t)tile * NP * plane : (size_t)0) + q;
+        const float n_code = src[2 * plane];
+        const float n_status = sl.packed ? (n_code < 0.f ? -n_code : 0.f) : src[3 * plane];
         if (!(n_status == 0.f || n_status == 3.f)) continue;
         const float n_lambda = src[0];
         const int on = snapshot_order(n_status), om = snapshot_order(status);
         if (on > om || (on == 0 && om == 0 && n_lambda > lambda)) {
-            lambda = n_lambda; last_sdf = src[plane]; delta = src[2 * plane]; status = n_status;
+            lambda = n_lambda; last_sdf = src[plane]; delta = (sl.packed && n_code < 0.f) ? 0.f : n_code; status = n_status;
         }
     }
     const float lambda_in = lambda, status_in = status;
@@ -792,7 +801,9 @@ __global__ __launch_bounds__(256) void k_raycast_sdf_slab(const RayParams p, con
         }
     }
     const bool changed = lambda != lambda_in || status != status_in;
-    st[0] = lambda; st[plane] = last_sdf; st[2 * plane] = delta; st[3 * plane] = status;
+    st[0] = lambda; st[plane] = last_sdf;
+    if (sl.packed) st[2 * plane] = status == 0.f ? delta : -status;
+    else { st[2 * plane] = delta; st[3 * plane] = status; }
     if (sl.touched) sl.touched[q] = changed ? 1.0f : 0.0f;
     if (sl.fin && changed && (status == 1.f || status == 2.f)) sl.fin[(size_t)v * p.w + u] = 1;
 }
@@ -1216,14 +1227,17 @@ static SlabRay dense_state(float* state, int init, int w, int h)
 }
 
 extern "C" int kfx_raycast_sdf_slab_tiles(float* state, float* result, size_t plane_stride, int rows_per_tile, int v0, int v1, int init, int* fin,
-                                          int claim_misses, const float* adopt_lo, const float* adopt_hi, int adopt_tile_major, const kfx_volume* vol,
+                                          int claim_misses, const float* adopt_lo, const float* adopt_hi, int layout_flags, const kfx_volume* vol,
                                           const kfx_slab* slab, int own_lo, int own_hi, int w, int h, const float T_wc[12], const float K[4], float near,
                                           float far, float trunc_dist, int subpix, kfx_stream stream)
 {
     SlabRay g{};
     g.state = state; g.result = result; g.P = plane_stride; g.R = rows_per_tile; g.v0 = v0; g.v1 = v1; g.fin = fin; g.claim_misses = claim_misses ? 1 : 0;
     g.init = init ? 1 : 0;
-    g.adopt_lo = adopt_lo; g.adopt_hi = adopt_hi; g.adopt_tile_major = adopt_tile_major ? 1 : 0;
+    const int adopt_tile_major = layout_flags & 1;
+    g.adopt_lo = adopt_lo; g.adopt_hi = adopt_hi; g.adopt_tile_major = adopt_tile_major;
+    g.packed = (layout_flags & 2) ? 1 : 0;
+    if (g.packed && !(trunc_dist > 0.f)) return set_error(KFX_E_RANGE, "RaycastSdf(slab): the packed tile state needs a positive truncation distance");
     if (((uintptr_t)adopt_lo | (uintptr_t)adopt_hi) & 3) return set_error(KFX_E_ALIGN, "RaycastSdf(slab): alignment of the received snapshots");
     if (!adopt_tile_major && (adopt_lo || adopt_hi) && rows_per_tile > 0 && (v0 / rows_per_tile != (v1 - 1) / rows_per_tile))
         return set_error(KFX_E_SHAPE, "RaycastSdf(slab): one-tile snapshots with rows of several tiles");

@@ -110,8 +110,9 @@ __global__ __launch_bounds__(256) void k_handover_finish(int* __restrict__ state
 }
 
 // ---- tile-pipelined hand-over (kfx_slab_raycast_exact_tiled) ---------------------------------------------------------
-// State per row-tile t (kfx.h, kfx_raycast_sdf_slab_tiles): the four march planes {lambda, last_sdf, delta, status} at M + (t * 4 + k) * P
-// (16 B per pixel: the token of a tile), results at Rz + (t * 4 + k) * P.
+// State per row-tile t (kfx.h, kfx_raycast_sdf_slab_tiles): NP march planes at M + (t * NP + k) * P -- the token of a tile --, results
+// at Rz + (t * 4 + k) * P.  NP = 3, packed {lambda, last_sdf, delta of a marching ray or -status}: 12 B per pixel ("12 B
+// per ray of march state"), whenever the truncation distance is positive; else the four planes {lambda, last_sdf, delta, status}.
 // "Newer wins": a ray's copies on different ranks are snapshots of ONE march; status 1 / 2 (final) is later than 3 (hit, normal
 // pending) is later than 0 (marching), and of two marching snapshots the one with the larger lambda is later (every step adds a
 // positive delta).  A rank never advances a stale copy -- it advances a ray only while the base plane of its current sample is
@@ -131,18 +132,23 @@ __device__ __forceinline__ size_t result_index(int c, size_t i, size_t n, unsign
 // this rank's contribution to the final images: lambda, status, normal, shade of the pixels it finalised, zero elsewhere (integer
 // bit patterns: NaN and -0 survive the sum over ranks, of which exactly one is non-zero per pixel)
 __global__ __launch_bounds__(256) void k_tiles_contrib(const int* __restrict__ M, const int* __restrict__ Rz, const int* __restrict__ fin,
-                                                       int* __restrict__ contrib, int w, int h, int R, size_t P, unsigned S)
+                                                       int* __restrict__ contrib, int w, int h, int R, size_t P, unsigned S, int packed)
 {
     const int u = blockIdx.x * 64 + (threadIdx.x & 63), v = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (u >= w || v >= h) return;
     const size_t n = (size_t)w * h, i = (size_t)v * w + u;
     const int t = v / R;
     const size_t q = (size_t)(v - t * R) * w + u;
-    const int* st = M + (size_t)t * 4 * P + q;
+    const int* st = M + (size_t)t * (packed ? 3 : 4) * P + q;
     const int* rs = Rz + (size_t)t * 4 * P + q;
     const bool mine = fin[i] != 0;
     contrib[result_index(0, i, n, S)] = mine ? st[0] : 0;
-    contrib[result_index(1, i, n, S)] = mine ? st[3 * P] : 0;
+    int status = 0;   // the status plane's bits: a finalised ray's 1.0f / 2.0f
+    if (mine) {
+        if (packed) { const float c = __int_as_float(st[2 * P]); status = __float_as_int(c < 0.f ? -c : 0.f); }
+        else status = st[3 * P];
+    }
+    contrib[result_index(1, i, n, S)] = status;
 #pragma unroll
     for (int k = 0; k < 4; ++k) contrib[result_index(2 + k, i, n, S)] = mine ? rs[k * P] : 0;
 }
@@ -879,7 +885,10 @@ int kfx::exact_tiled_march(void* scratch, const ExactFinalBufs* into, const kfx_
     tiled_layout(t, scratch, (size_t)w, (size_t)h, tiles, world);
     const ExactFinalBufs& fb = into ? *into : t.own;
     const int T = t.T, R = t.R;
-    const size_t P = t.P, tile_bytes = 4 * P * sizeof(int);   // lambda, last_sdf, delta, status of every pixel of the tile
+    // the tile state packed into three planes (12 B per pixel and hop) unless a marching ray's delta could be negative; every rank
+    // decides alike from the same arguments
+    const int packed = trunc_dist > 0.f ? 1 : 0, NP = packed ? 3 : 4;
+    const size_t P = t.P, tile_bytes = (size_t)NP * P * sizeof(int);
     hipStream_t s = (hipStream_t)stream;
     const kfx_slab slab = {L->full_d, L->s0, L->full_zmin, L->full_zmax};
     // a local failure must not keep this rank out of a collective its peers enter: remember it, go on, report it at the end
@@ -889,7 +898,7 @@ int kfx::exact_tiled_march(void* scratch, const ExactFinalBufs* into, const kfx_
     // neighbours handed on (their newer, still open snapshots), and marches what lies in the rank's own planes
     auto march = [&](int v0, int v1, int init, const int* from_lo, const int* from_hi, int tile_major) {
         note(kfx_raycast_sdf_slab_tiles(reinterpret_cast<float*>(t.M), reinterpret_cast<float*>(t.Rz), P, R, v0, v1, init, t.fin, rank == 0 ? 1 : 0,
-                                        reinterpret_cast<const float*>(from_lo), reinterpret_cast<const float*>(from_hi), tile_major, local, &slab,
+                                        reinterpret_cast<const float*>(from_lo), reinterpret_cast<const float*>(from_hi), (tile_major ? 1 : 0) | (packed ? 2 : 0), local, &slab,
                                         (int)L->z0, (int)L->z1, w, h, T_wc, K, near, far, trunc_dist, subpix, stream));
     };
     auto rows_of = [&](int tile, int& v0, int& v1) { v0 = tile * R; v1 = v0 + R < h ? v0 + R : h; };
@@ -941,8 +950,8 @@ int kfx::exact_tiled_march(void* scratch, const ExactFinalBufs* into, const kfx_
             const bool from_below = need_up && rank > 0 && A + 1 >= 0 && A + 1 < T, from_above = need_down && rank + 1 < world && B + 1 >= 0 && B + 1 < T;
             // (every rank calls the exchange in every step, with empty legs where it has nothing to pass on: a transport may
             //  synchronise its ranks inside the call, as the in-process one does in its barrier mode)
-            note(comm->exchange_v(comm, down ? t.M + (size_t)B * 4 * P : nullptr, down ? tile_bytes : 0, from_below ? t.from_lo : nullptr, from_below ? tile_bytes : 0,
-                                  up ? t.M + (size_t)A * 4 * P : nullptr, up ? tile_bytes : 0, from_above ? t.from_hi : nullptr, from_above ? tile_bytes : 0, stream));
+            note(comm->exchange_v(comm, down ? t.M + (size_t)B * NP * P : nullptr, down ? tile_bytes : 0, from_below ? t.from_lo : nullptr, from_below ? tile_bytes : 0,
+                                  up ? t.M + (size_t)A * NP * P : nullptr, up ? tile_bytes : 0, from_above ? t.from_hi : nullptr, from_above ? tile_bytes : 0, stream));
             got_lo = from_below; got_hi = from_above;
         }
         // one more stage over the whole image: a hit whose sub-step interpolation fell back across a slab boundary has its normal
@@ -963,7 +972,7 @@ int kfx::exact_tiled_march(void* scratch, const ExactFinalBufs* into, const kfx_
     const dim3 grid2(ceil_div(w, 64), ceil_div(h, 4));
     if (direct && (size_t)world * t.S > t.n)   // the last strip's padding travels too: defined (and summed as zero)
         note(hip_status(hipMemsetAsync(fb.contrib + ((size_t)(world - 1) * 6) * t.S, 0, 6 * t.S * sizeof(int), s), "kfx_slab_raycast_exact_tiled"));
-    hipLaunchKernelGGL(k_tiles_contrib, grid2, dim3(256), 0, s, t.M, t.Rz, t.fin, fb.contrib, w, h, R, P, S);
+    hipLaunchKernelGGL(k_tiles_contrib, grid2, dim3(256), 0, s, t.M, t.Rz, t.fin, fb.contrib, w, h, R, P, S, packed);
     note(check_launch("kfx_slab_raycast_exact_tiled"));
     if (steps_out) *steps_out = steps;   // world + tiles - 1 token steps + the normals' stage (1 for a single rank)
     return status;
