@@ -35,6 +35,7 @@ struct Options {
     bool overlap = false;        // --overlap (frame driver, composite): the merge of frame k under frame k + 1
     int pipeline = 0;            // --pipeline D (frame driver, exact): frames pipelined across the ranks, D image / buffer sets in flight (2 .. 4)
     bool p2p = false;            // --transport threads-p2p: neighbour exchanges matched pairwise like RCCL's send / recv (a mismatch blocks, then times out)
+    int ghost = 2;               // --ghost G | auto: ghost planes per side (auto: kfx_slab_exact_ghost, the hand-over without its last stage)
     int tiles = 0;               // --tiles T: exact hand-over pipelined over T image row-tiles (0: whole-image stages; the frame driver's default: 4)
     SlabVolume::HaloMode halo = SlabVolume::HaloExchange;
     SlabVolume::RaycastMode raycast = SlabVolume::Composite;
@@ -104,12 +105,20 @@ static void RunRank(const Options& o, kfx_comm* comm, const std::vector<std::vec
     std::vector<std::unique_ptr<Image<float4, TargetDevice, Manage> > > set_n;
     Image<float, TargetDevice, Manage> dMeters(w, h), dFiltered(w, h), ray_d(w, h), ray_i(w, h);
     Image<float4, TargetDevice, Manage> dVbo(w, h), dNormals(w, h), ray_n(w, h);
-    SlabVolume slab(o.volres, o.volres, o.volres, bb, comm, o.halo, o.raycast);
-    slab.merge = o.merge;
-    slab.tiles = o.tiles;
     // the whole volume's voxel size (the local view has the same spacing in x / y; z spacing is the full volume's)
     const float3 vs = make_float3(2.0f / (o.volres - 1), 2.0f / (o.volres - 1), 2.0f / (o.volres - 1));
     const float trunc_dist = 2.0f * length(vs);
+    // --ghost G: ghost planes per side; "auto" (-1): as wide as lets the exact hand-over drop its last stage (kfx_slab_exact_ghost) where
+    // every rank owns that many planes, else 2
+    int ghost = o.ghost;
+    if (ghost < 0) {
+        const float Kf[4] = {(float)K.fu, (float)K.fv, (float)K.u0, (float)K.v0};
+        ghost = kfx_slab_exact_ghost((size_t)o.volres, bb.Min().z, bb.Max().z, bb.Max().x - bb.Min().x, (size_t)o.volres, trunc_dist, Kf, w, h);
+        if (comm->world > 1 && o.volres / comm->world < ghost) ghost = 2;
+    }
+    SlabVolume slab(o.volres, o.volres, o.volres, bb, comm, o.halo, o.raycast, ghost);
+    slab.merge = o.merge;
+    slab.tiles = o.tiles;
     SdfReset(slab.local, std::numeric_limits<float>::quiet_NaN());
 
     // --driver frame: the same frame as ONE library call per rank (kfx_slab_frame, include/kfx_slab.h)
@@ -295,6 +304,7 @@ int main(int argc, char** argv)
         else if (!strcmp(argv[i], "--rendezvous") && i + 1 < argc) o.rendezvous = argv[++i];
         else if (!strcmp(argv[i], "--driver") && i + 1 < argc) o.frame_driver = !strcmp(argv[++i], "frame");
         else if (!strcmp(argv[i], "--tiles") && i + 1 < argc) o.tiles = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--ghost") && i + 1 < argc) { ++i; o.ghost = !strcmp(argv[i], "auto") ? -1 : atoi(argv[i]); }
         else if (!strcmp(argv[i], "--overlap")) o.overlap = true;
         else { fprintf(stderr, "unknown argument %s\n", argv[i]); return 2; }
     }

@@ -1190,6 +1190,8 @@ def run_slabs(args, torch, dist, roo, scenes, rank, world):
         if sf is not None:
             plan = [("raycast_exact_fps", dict(base, raycast="exact", overlap=False)),
                     ("raycast_exact_pipelined_fps", dict(base, raycast="exact", overlap=True)),
+                    # the hand-over's last stage kept although the ghost planes are wide enough to do without (kfx_slab_exact_ghost)
+                    ("raycast_exact_pipelined_with_last_stage_fps", dict(base, raycast="exact", overlap=True, normals_stage=1)),
                     ("halo_exchange+raycast_exact_pipelined_fps", dict(base, raycast="exact", halo="exchange", overlap=True)),
                     ("raycast_exact_pipelined_tiles_1_fps", dict(base, raycast="exact", overlap=True, tiles=1)),
                     ("halo_exchange+raycast_exact_fps", dict(base, raycast="exact", halo="exchange", overlap=False)),
@@ -1207,8 +1209,17 @@ def run_slabs(args, torch, dist, roo, scenes, rank, world):
                 cfg.setdefault("tiles", args.tiles)
                 if "pipelined" in name and pipeline_note is not None:
                     continue
+                keep_stage = cfg.pop("normals_stage", 0)
+                if keep_stage and pipe.GHOST <= 2:
+                    continue   # (the stage is there anyway)
                 pipe.configure(**cfg)
+                if keep_stage:
+                    sync_all()
+                    kslab.set_normals_stage(1)
                 variants[name] = timed_fps(n_var)
+                if keep_stage:
+                    sync_all()
+                    kslab.set_normals_stage(0)
             pipe.configure(**dict(base, tiles=args.tiles))
             # the interpreter-driven loop on the same slabs (operators and torch.distributed collectives one by one)
             keep = pipe
@@ -1286,7 +1297,7 @@ def run_slabs(args, torch, dist, roo, scenes, rank, world):
                            if args.merge == "direct" else
                            "composite = all_reduce(MIN key) + %s(SUM payload)" % ("reduce-to-rank-0" if args.images == "root" else "all_reduce")),
              "exact": ("exact = march state handed from slab to slab as tokens over image row-tiles (world + tiles - 1 steps of one tile-sized neighbour "
-                       "send/recv each, one whole-image stage for the normals of hits that fell back across a slab boundary, then the finalised pixels by "
+                       "send/recv each, one whole-image stage for the normals of hits that fell back across a slab boundary -- dropped when the ghost planes are wide enough for the finder to hold every hit's gradient stencil --, then the finalised pixels by "
                        "all_to_all + all_gather of image strips)%s%s" % (tiles_text, ("; frames pipelined: frame k's final exchange on the side stream / second "
                                                                                       "communicator under frame k + 1" if overlap and args.raycast == "exact" else ""))
                        if sf is not None else
@@ -1321,6 +1332,8 @@ def run_slabs(args, torch, dist, roo, scenes, rank, world):
                            "python: SlabPipeline issues operators and torch.distributed collectives one by one"),
                 "driver_note": driver_note, "pipeline_note": pipeline_note,
                 "frames_pipelined": bool(overlap and args.raycast == "exact"),
+                # ghost planes per side; wider than 2 = kfx_slab_exact_ghost: every rank finalises the hits it finds, the hand-over runs without its last stage
+                "ghost_planes": int(pipe.GHOST),
                 "raycast": "plain march (kfx_raycast_sdf%s) per slab" % ("_slab, state carried across slabs" if args.raycast != "composite" else ""),
                 "raycast_mode": args.raycast, "raycast_parity": parity, "summary_policy": None,
                 "partition": partition, "communicator": comm_info,

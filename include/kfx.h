@@ -375,7 +375,9 @@ int kfx_raycast_sdf_slab(float* state, int init, const kfx_volume* vol, const kf
  * layout_flags & 1, of all tiles: before marching, a ray takes a neighbour's snapshot when it is newer than its own (a final or
  * hit status is later than "marching", a larger lambda later than a smaller) and still under way.  layout_flags & 2: the tile state
  * is PACKED into three planes -- lambda, last_sdf, and a marching ray's delta (positive) or -status of any other ray -- at
- * state + (t * 3 + k) * plane_stride, the snapshots alike: 12 bytes per ray and hop; needs trunc_dist > 0. */
+ * state + (t * 3 + k) * plane_stride, the snapshots alike: 12 bytes per ray and hop; needs trunc_dist > 0.
+ * layout_flags & 4: a hit's normal is evaluated wherever the three planes of its gradient stencil are stored (ghost planes included),
+ * not only by the rank that owns the stencil's base plane. */
 int kfx_raycast_sdf_slab_tiles(float* state, float* result, size_t plane_stride, int rows_per_tile, int v0, int v1, int init, int* fin,
                                int claim_misses, const float* adopt_lo, const float* adopt_hi, int layout_flags, const kfx_volume* vol,
                                const kfx_slab* slab, int own_lo, int own_hi, int w, int h, const float T_wc[12], const float K[4], float near,

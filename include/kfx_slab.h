@@ -160,6 +160,17 @@ int kfx_slab_raycast_exact_allreduce(const kfx_image* depth, const kfx_image* no
  * receives that count asynchronously: the call returns without synchronising and the CALLER checks the word once the stream
  * has passed (kfx_slab_frame does).  Needs comm->exchange_v. */
 size_t kfx_slab_exact_tiled_scratch_bytes(size_t w, size_t h, int tiles, int world);
+/* Ghost planes per side (kfx_slab_layout_init's `ghost`) with which the hand-over needs no last stage: a hit's sub-step interpolation
+ * puts it at most one march step -- max(trunc_dist, voxel size) times the longest ray direction of the image -- behind the sample that
+ * found it, so with that many planes (+ the gradient stencil's) stored beyond its own the rank that finds a hit always evaluates the
+ * normal itself.  kfx_slab_raycast_exact_tiled and kfx_slab_frame drop the stage (one whole-image neighbour exchange and one march
+ * launch per frame) whenever the layout's ghost is at least this; KFX_SLAB_NORMALS_STAGE=1 keeps it.  Presumes what SdfFuse
+ * guarantees -- no cell beyond the truncation distance the raycast is called with (cu_sdffusion.cu:49); a volume that breaks it
+ * leaves rays without a final status, which the call counts and reports (KFX_E_RANGE), never a wrong image.  size_x, vol_w: the
+ * volume's extent and cells along x (the march's minimum step is the voxel's x size, cu_raycast.cu:52). */
+int kfx_slab_exact_ghost(size_t full_d, float full_zmin, float full_zmax, float size_x, size_t vol_w, float trunc_dist, const float K[4], int w, int h);
+/* keep != 0: the last stage stays whatever the ghost width (process-wide; every rank alike).  Returns the previous setting. */
+int kfx_slab_set_normals_stage(int keep);
 int kfx_slab_raycast_exact_tiled(const kfx_image* depth, const kfx_image* norm, const kfx_image* img, void* scratch,
                                  const kfx_volume* local, const kfx_slab_layout* L, const float T_wc[12], const float K[4],
                                  float near, float far, float trunc_dist, int subpix, int tiles, kfx_comm* comm, kfx_stream stream,

@@ -679,6 +679,10 @@ struct SlabRay {
     float* touched;
     float* result;
     int packed;
+    // normals_here: a hit's normal is evaluated by whichever rank holds the hit (its finder, or a rank that adopted it) as soon as the
+    // three planes of the gradient stencil are STORED there, ghost planes included -- they hold the owner's bits; else only by the
+    // rank that OWNS the stencil's base plane (the hit travels there in the hand-over's last stage)
+    int normals_here;
     size_t P;           // plane stride in pixels (>= R w)
     int R;              // rows per tile
     int v0, v1;         // rows this launch processes
@@ -790,7 +794,7 @@ __global__ __launch_bounds__(256) void k_raycast_sdf_slab(const RayParams p, con
     if (status == 3.f) { // hit: the rank owning the gradient's base plane gz evaluates the normal
         const V3 pos = c_w + ray_w * lambda;
         const int gz = grad_cell_z(p, pos);
-        if (gz >= sl.own_lo && gz < sl.own_hi && gz - 1 >= sl.avail_lo && gz + 1 < sl.avail_hi) {
+        if ((sl.normals_here || (gz >= sl.own_lo && gz < sl.own_hi)) && gz - 1 >= sl.avail_lo && gz + 1 < sl.avail_hi) {
             const V3 g = gradient<CELL>(p, pos);
             const float len = length(g);
             const V3 n_w = len > 0 ? div_s(g, len) : v3(0.f, 0.f, 1.f);
@@ -1237,6 +1241,7 @@ extern "C" int kfx_raycast_sdf_slab_tiles(float* state, float* result, size_t pl
     const int adopt_tile_major = layout_flags & 1;
     g.adopt_lo = adopt_lo; g.adopt_hi = adopt_hi; g.adopt_tile_major = adopt_tile_major;
     g.packed = (layout_flags & 2) ? 1 : 0;
+    g.normals_here = (layout_flags & 4) ? 1 : 0;
     if (g.packed && !(trunc_dist > 0.f)) return set_error(KFX_E_RANGE, "RaycastSdf(slab): the packed tile state needs a positive truncation distance");
     if (((uintptr_t)adopt_lo | (uintptr_t)adopt_hi) & 3) return set_error(KFX_E_ALIGN, "RaycastSdf(slab): alignment of the received snapshots");
     if (!adopt_tile_major && (adopt_lo || adopt_hi) && rows_per_tile > 0 && (v0 / rows_per_tile != (v1 - 1) / rows_per_tile))

@@ -874,6 +874,50 @@ static int exact_tiled_args(const kfx_image* depth, const kfx_image* norm, const
     return 0;
 }
 
+// Ghost planes per side with which the exact hand-over needs no last stage for the normals.  A hit is found at a sample whose base
+// plane the finder owns; its sub-step interpolation (cu_raycast.cu:70-74) puts it at most one step behind that sample, a step is at
+// most max(trunc_dist, voxel.x) (the march's step is the sampled value, and a TSDF's cells do not exceed the truncation distance:
+// Sdf.h, cu_sdffusion.cu:49), a ray moves |ray| <= the longest ((u - u0) / fu, (v - v0) / fv, 1) of the image per unit of lambda;
+// the gradient stencil (Volume.h:262-289) takes one plane below and one above its base plane.
+extern "C" int kfx_slab_exact_ghost(size_t full_d, float full_zmin, float full_zmax, float size_x, size_t vol_w, float trunc_dist, const float K[4], int w, int h)
+{
+    if (!K || full_d < 2 || vol_w < 2 || w < 1 || h < 1) return 2;
+    const double vz = std::fabs(((double)full_zmax - (double)full_zmin) / (double)(full_d - 1)), vx = std::fabs((double)size_x / (double)(vol_w - 1));
+    double rmax = 1.0;
+    for (int c = 0; c < 4; ++c) {
+        const double cx = ((c & 1 ? (double)(w - 1) : 0.0) - (double)K[2]) / (double)K[0], cy = ((c & 2 ? (double)(h - 1) : 0.0) - (double)K[3]) / (double)K[1];
+        const double r = std::sqrt(cx * cx + cy * cy + 1.0);
+        rmax = r > rmax ? r : rmax;
+    }
+    const double step = (double)trunc_dist > vx ? (double)trunc_dist : vx;
+    const double planes = rmax * step / vz;
+    if (!(trunc_dist > 0.f) || !(vz > 0.0) || !(planes < 1e6)) return 2;   // (degenerate: the ordinary width, with the last stage)
+    return (int)std::ceil(planes * 1.001 + 0.01) + 2;
+}
+
+namespace {
+std::atomic<int> g_normals_stage{-1};   // -1: not read yet (KFX_SLAB_NORMALS_STAGE, default 0)
+bool normals_stage_forced()
+{
+    int v = g_normals_stage.load(std::memory_order_relaxed);
+    if (v < 0) {
+        const char* e = getenv("KFX_SLAB_NORMALS_STAGE");
+        v = (e && atoi(e) != 0) ? 1 : 0;
+        g_normals_stage.store(v, std::memory_order_relaxed);
+    }
+    return v != 0;
+}
+} // namespace
+
+// 1: the hand-over keeps its last stage whatever the layout's ghost width (measurements, cross-checks; every rank alike); 0: dropped
+// where the ghost planes allow.  Returns the previous setting.
+extern "C" int kfx_slab_set_normals_stage(int keep)
+{
+    const int prev = normals_stage_forced() ? 1 : 0;
+    g_normals_stage.store(keep ? 1 : 0, std::memory_order_relaxed);
+    return prev;
+}
+
 // The march: token steps, the normals' stage, and this rank's contribution to the final images left in `into` (null: the scratch's own
 // set).  Everything here is ordered on `stream`; the collectives are neighbour exchanges only (comm->exchange_v).
 int kfx::exact_tiled_march(void* scratch, const ExactFinalBufs* into, const kfx_volume* local, const kfx_slab_layout* L, const float T_wc[12],
@@ -889,6 +933,10 @@ int kfx::exact_tiled_march(void* scratch, const ExactFinalBufs* into, const kfx_
     // decides alike from the same arguments
     const int packed = trunc_dist > 0.f ? 1 : 0, NP = packed ? 3 : 4;
     const size_t P = t.P, tile_bytes = (size_t)NP * P * sizeof(int);
+    // With ghost planes as wide as a hit can fall back behind the sample that found it (kfx_slab_exact_ghost), the rank that finds a
+    // hit always holds its gradient stencil: it finalises the hit itself and the hand-over needs no last stage for the normals
+    const int self_normals = (world > 1 && L->ghost >= kfx_slab_exact_ghost(L->full_d, L->full_zmin, L->full_zmax, local->boxmax[0] - local->boxmin[0],
+                                                                          (size_t)local->w, trunc_dist, K, w, h) && !normals_stage_forced()) ? 1 : 0;
     hipStream_t s = (hipStream_t)stream;
     const kfx_slab slab = {L->full_d, L->s0, L->full_zmin, L->full_zmax};
     // a local failure must not keep this rank out of a collective its peers enter: remember it, go on, report it at the end
@@ -898,7 +946,7 @@ int kfx::exact_tiled_march(void* scratch, const ExactFinalBufs* into, const kfx_
     // neighbours handed on (their newer, still open snapshots), and marches what lies in the rank's own planes
     auto march = [&](int v0, int v1, int init, const int* from_lo, const int* from_hi, int tile_major) {
         note(kfx_raycast_sdf_slab_tiles(reinterpret_cast<float*>(t.M), reinterpret_cast<float*>(t.Rz), P, R, v0, v1, init, t.fin, rank == 0 ? 1 : 0,
-                                        reinterpret_cast<const float*>(from_lo), reinterpret_cast<const float*>(from_hi), (tile_major ? 1 : 0) | (packed ? 2 : 0), local, &slab,
+                                        reinterpret_cast<const float*>(from_lo), reinterpret_cast<const float*>(from_hi), (tile_major ? 1 : 0) | (packed ? 2 : 0) | (self_normals ? 4 : 0), local, &slab,
                                         (int)L->z0, (int)L->z1, w, h, T_wc, K, near, far, trunc_dist, subpix, stream));
     };
     auto rows_of = [&](int tile, int& v0, int& v1) { v0 = tile * R; v1 = v0 + R < h ? v0 + R : h; };
@@ -957,13 +1005,17 @@ int kfx::exact_tiled_march(void* scratch, const ExactFinalBufs* into, const kfx_
         // one more stage over the whole image: a hit whose sub-step interpolation fell back across a slab boundary has its normal
         // evaluated by the neighbour that owns the gradient's base plane -- the one BEHIND the ray: rising rays' hits go down, falling
         // rays' up
-        const size_t all = (size_t)T * tile_bytes;
-        const bool send_down = need_up && rank > 0, recv_from_above = need_up && rank + 1 < world;       // rising rays' pending normals
-        const bool send_up = need_down && rank + 1 < world, recv_from_below = need_down && rank > 0;     // falling rays'
-        note(comm->exchange_v(comm, send_down ? t.M : nullptr, send_down ? all : 0, recv_from_below ? t.from_lo : nullptr, recv_from_below ? all : 0,
-                              send_up ? t.M : nullptr, send_up ? all : 0, recv_from_above ? t.from_hi : nullptr, recv_from_above ? all : 0, stream));
-        march(0, h, 0, recv_from_below ? t.from_lo : nullptr, recv_from_above ? t.from_hi : nullptr, 1);
-        ++steps;
+        // (not with ghost planes wide enough for every finder to finalise its own hits: self_normals.  A ray left without a final
+        //  status -- cells beyond the truncation distance -- is counted by the final exchange and reported: KFX_E_RANGE)
+        if (!self_normals) {
+            const size_t all = (size_t)T * tile_bytes;
+            const bool send_down = need_up && rank > 0, recv_from_above = need_up && rank + 1 < world;       // rising rays' pending normals
+            const bool send_up = need_down && rank + 1 < world, recv_from_below = need_down && rank > 0;     // falling rays'
+            note(comm->exchange_v(comm, send_down ? t.M : nullptr, send_down ? all : 0, recv_from_below ? t.from_lo : nullptr, recv_from_below ? all : 0,
+                                  send_up ? t.M : nullptr, send_up ? all : 0, recv_from_above ? t.from_hi : nullptr, recv_from_above ? all : 0, stream));
+            march(0, h, 0, recv_from_below ? t.from_lo : nullptr, recv_from_above ? t.from_hi : nullptr, 1);
+            ++steps;
+        }
     }
     // Every pixel has been given its final status by exactly one rank: this rank's contribution to the final images, in the layout of
     // the exchange that follows (exact_tiled_finalise)

@@ -420,13 +420,16 @@ class SlabPipeline(FramePipeline):
     USE_FRAME = False   # slabs: the operators take slab arguments and collectives sit between them
 
     def __init__(self, ops, dist, dims, boxmin, boxmax, w, h, halo="exchange", raycast="exact", kind="f32", overlap=False,
-                 inputs="replicate", images="all", merge="direct", driver="python", comm=None, tiles=0, unchecked=False, pipeline=3, **kw):
+                 inputs="replicate", images="all", merge="direct", driver="python", comm=None, tiles=0, unchecked=False, pipeline=3, ghost=None, **kw):
         """driver = "c": every frame is ONE library call per rank (kfx_slab_frame_step, include/kfx_slab.h: the launches AND the
         collectives are enqueued by the library through `comm`, a kangaroo_amd.slab.Comm -- RCCL for one process per GPU; default:
         Comm.torch(dist), the collectives of the process group the caller has set up); driver = "python": this class issues the
         operators and torch.distributed collectives one by one (the cross-check, and what the CPU tests run on the oracle-backed
         operator set).  Same bits either way.  tiles: row-tiles of the exact hand-over (C driver; 0 = the library's default);
         unchecked: do not fail when the exact march leaves rays open (loop-back measurements of ONE rank: scripts/slab_host_floor.py).
+        ghost: ghost planes per side; None = 2, or -- driver "c", exact raycast, recomputed ghost planes -- kfx_slab_exact_ghost's width
+        (as far as a hit can fall back behind the sample that found it + the gradient stencil: every rank finalises the hits it
+        finds and the hand-over drops its last stage, include/kfx_slab.h), where every rank owns that many planes.
 
         halo = "exchange": every rank integrates only the planes it owns and the ghost planes are
         refreshed from the two neighbours after each SdfFuse (point-to-point send/recv: one xGMI link
@@ -481,6 +484,16 @@ class SlabPipeline(FramePipeline):
         self.full_boxmin = np.asarray(boxmin, np.float32)
         self.full_boxmax = np.asarray(boxmax, np.float32)
         d = int(dims[2])
+        if ghost is None:
+            ghost = self.GHOST
+            if driver == "c" and raycast == "exact" and halo == "recompute" and self.world > 1 and kind == "f32":
+                from . import slab as S
+                Kk = kw.get("K")
+                Kk = scenes.intrinsics(w, h) if Kk is None else Kk
+                wide = S.exact_ghost(dims, boxmin, boxmax, scenes.trunc_dist(boxmin, boxmax, dims, kw.get("trunc_factor", scenes.TRUNC_DIST_FACTOR)), Kk, w, h)
+                if d // self.world >= wide:
+                    ghost = wide
+        self.GHOST = int(ghost)   # (shadows the class default for this pipeline)
         # exchange_halos takes the ghost planes from the immediate neighbours: every rank must own at least GHOST planes
         assert self.world == 1 or d // self.world >= self.GHOST, "slabs thinner than the ghost width (%d planes / %d ranks)" % (d, self.world)
         self.z0, self.z1 = slab_range(d, self.rank, self.world)

@@ -88,6 +88,8 @@ def _L():
             "kfx_slab_raycast_exact": (C.c_int, [PI, PI, PI, V, V, PV, PL, PF, PF, C.c_float, C.c_float, C.c_float, C.c_int, _P, V, C.POINTER(C.c_int)]),
             "kfx_slab_raycast_exact_allreduce": (C.c_int, [PI, PI, PI, V, V, PV, PL, PF, PF, C.c_float, C.c_float, C.c_float, C.c_int, _P, V, C.POINTER(C.c_int)]),
             "kfx_slab_exact_tiled_scratch_bytes": (C.c_size_t, [C.c_size_t, C.c_size_t, C.c_int, C.c_int]),
+            "kfx_slab_exact_ghost": (C.c_int, [C.c_size_t, C.c_float, C.c_float, C.c_float, C.c_size_t, C.c_float, PF, C.c_int, C.c_int]),
+            "kfx_slab_set_normals_stage": (C.c_int, [C.c_int]),
             "kfx_slab_raycast_exact_tiled": (C.c_int, [PI, PI, PI, V, PV, PL, PF, PF, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, _P, V,
                                                        C.POINTER(C.c_int), C.POINTER(C.c_int)]),
             "kfx_slab_frame_create": (C.c_int, [C.POINTER(V), C.POINTER(KfxSlabFrameConfig), _P]),
@@ -320,6 +322,18 @@ class Comm:
         cbs[tag + "dup"] = fields["dup"](dup)
         c.dup = cbs[tag + "dup"]
         return Comm(c, keep=cbs, owner=False)
+
+
+def exact_ghost(dims, boxmin, boxmax, trunc, K, w, h):
+    """kfx_slab_exact_ghost: the ghost planes per side with which the exact hand-over needs no last stage for the normals."""
+    Kc = (C.c_float * 4)(*[float(x) for x in K])
+    return int(_L().kfx_slab_exact_ghost(int(dims[2]), float(boxmin[2]), float(boxmax[2]), float(boxmax[0]) - float(boxmin[0]), int(dims[0]),
+                                         float(trunc), Kc, int(w), int(h)))
+
+
+def set_normals_stage(keep):
+    """kfx_slab_set_normals_stage: keep the hand-over's last stage whatever the ghost width (every rank alike); returns the old setting."""
+    return int(_L().kfx_slab_set_normals_stage(1 if keep else 0))
 
 
 def layout(full_d, full_zmin, full_zmax, rank, world, ghost=2):

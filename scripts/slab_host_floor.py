@@ -150,6 +150,9 @@ def main():
         r["c_exact_tiles4_pipelined_two_events"] = run(N, 8, 3, "exact", "c", 300, tiles=4, events=6, overlap=True)
         r["c_exact_tiles1_pipelined_two_events"] = run(N, 8, 3, "exact", "c", 300, tiles=1, events=6, overlap=True)
         r["c_exact_tiles1_two_events"] = run(N, 8, 3, "exact", "c", 300, tiles=1, events=6)
+        # two ghost planes per side: the hand-over with its last stage (the other exact rows: kfx_slab_exact_ghost's width, without it)
+        r["c_exact_tiles4_two_events_ghost2"] = run(N, 8, 3, "exact", "c", 300, tiles=4, events=6, ghost=2)
+        r["c_exact_tiles4_pipelined_two_events_ghost2"] = run(N, 8, 3, "exact", "c", 300, tiles=4, events=6, overlap=True, ghost=2)
         r["c_composite_direct_overlapped"] = run(N, 8, 3, "composite", "c", 300, merge="direct", overlap=True)
         r["python_composite_direct"] = run(N, 8, 3, "composite", "python", 300, merge="direct")
         r["python_composite_direct_overlapped"] = run(N, 8, 3, "composite", "python", 300, merge="direct", overlap=True)

@@ -134,6 +134,44 @@ def test_cpp_slabs_pipelined_frames_equal_single_volume():
             assert got[k] == ref[k], (extra, k, got["text"], ref["text"])
 
 
+def test_cpp_slabs_wide_ghost_planes_drop_the_last_stage():
+    """Ghost planes as wide as a hit can fall back behind the sample that found it (kfx_slab_exact_ghost: one march step along the
+    longest ray of the image + the gradient stencil): the rank that finds a hit always holds its stencil, finalises it itself, and
+    the hand-over runs WITHOUT its last stage (no whole-image neighbour exchange, no whole-image launch): world + tiles - 1 steps
+    instead of world + tiles.  Same bits as the single volume -- every frame's depth, the last frame's images, the volume --
+    unpipelined and pipelined, both thread transports, ghost planes recomputed or exchanged; KFX_SLAB_NORMALS_STAGE=1 keeps the stage."""
+    common = ("--res", 128, "--frames", 7, "--width", 320, "--height", 240, "--raycast", "exact")
+    ref = run(*common, "--ranks", 1)
+    keys = ("depth", "norm", "img", "volume", "history", "hits")
+    n = 0
+    for ranks in (2, 3, 4, 8):
+        for tiles in (1, 4):
+            transport = ("threads", "threads-p2p")[n % 2]
+            extra = (("--halo", "recompute"), ("--halo", "recompute", "--pipeline", 3), ("--halo", "exchange"), ("--halo", "exchange", "--pipeline", 2))[n % 4]
+            n += 1
+            got = run(*common, "--ranks", ranks, "--driver", "frame", "--tiles", tiles, "--ghost", "auto", "--transport", transport, *extra)
+            assert got["agree"] == 1
+            for k in keys:
+                assert got[k] == ref[k], (ranks, tiles, transport, extra, k, got["text"], ref["text"])
+            rounds = int(re.search(r"\((\d+) rounds\)", got["text"]).group(1))
+            assert rounds == ranks + tiles - 1, (rounds, ranks, tiles, got["text"])
+    # the operator-by-operator driver (roo::SlabVolume) takes the same layout; and the stage stays when asked for
+    got = run(*common, "--ranks", 4, "--tiles", 4, "--ghost", "auto", "--halo", "recompute")
+    for k in keys:
+        assert got[k] == ref[k], (k, got["text"], ref["text"])
+    assert int(re.search(r"\((\d+) rounds\)", got["text"]).group(1)) == 4 + 4 - 1
+    env = dict(os.environ, KFX_SLAB_NORMALS_STAGE="1")
+    kept = run(*common, "--ranks", 4, "--driver", "frame", "--tiles", 4, "--ghost", "auto", "--halo", "recompute", env=env)
+    for k in keys:
+        assert kept[k] == ref[k], (k, kept["text"], ref["text"])
+    assert int(re.search(r"\((\d+) rounds\)", kept["text"]).group(1)) == 4 + 4
+    # a narrower ghost than that keeps the stage by itself
+    narrow = run(*common, "--ranks", 4, "--driver", "frame", "--tiles", 4, "--ghost", 3, "--halo", "recompute")
+    for k in keys:
+        assert narrow[k] == ref[k], (k, narrow["text"], ref["text"])
+    assert int(re.search(r"\((\d+) rounds\)", narrow["text"]).group(1)) == 4 + 4
+
+
 def test_threads_transport_point_to_point_mode_blocks_on_a_mismatched_leg():
     """Round-5 verdict, What's weak 8: on RCCL a neighbour exchange whose two sides disagree -- one skips the leg, or names another
     size -- does not fail, it HANGS.  The in-process transport's point-to-point mode (kfx_comm_create_threads_p2p) reproduces that: the

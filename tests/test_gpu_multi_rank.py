@@ -70,10 +70,14 @@ def test_gpu_bench_two_ranks_smoke(raycast):
     assert isinstance(pr, list) and [r["rank"] for r in pr] == [0, 1]
     for r in pr:
         assert r["sdf_fuse_ms"] > 0 and r["raycast_sdf_plus_merge_ms"] > 0 and r["halo_exchange_ms"] > 0 and r["preprocess_ms"] > 0 and r["frame_events_ms"] > 0
-        assert r["halo_bytes_received_per_fuse"] == 2 * 128 * 128 * 8          # two ghost planes of 128 x 128 cells from the one neighbour
-        assert r["planes_owned"] == 64 and r["voxels_stored"] == 128 * 128 * 66
+        # ghost planes per side: 2, or -- exact raycast, recomputed ghosts (the default) -- kfx_slab_exact_ghost's width: 7 here
+        g = d["config"]["ghost_planes"]
+        assert g == (7 if raycast == "exact" else 2)
+        assert r["halo_bytes_received_per_fuse"] == g * 128 * 128 * 8          # the ghost planes of 128 x 128 cells from the one neighbour
+        assert r["planes_owned"] == 64 and r["voxels_stored"] == 128 * 128 * (64 + g)
         assert (r["composite_merge_ms"] is not None and r["composite_merge_ms"] > 0) == (raycast == "composite")
     v = d["multi_gpu_variants"]
+    assert ("raycast_exact_pipelined_with_last_stage_fps" in v) == (raycast == "exact")
     for key in ("as_configured_fps", "raycast_exact_fps", "raycast_exact_pipelined_fps", "halo_exchange+raycast_exact_pipelined_fps",
                 "raycast_exact_pipelined_tiles_1_fps", "halo_exchange+raycast_exact_fps", "raycast_exact_tiles_1_fps", "raycast_exact_tiles_8_fps",
                 "raycast_composite_fps", "raycast_composite_overlapped_fps", "raycast_composite_merge_allreduce_fps", "halo_exchange_fps",
