@@ -88,8 +88,8 @@ def upload_volume(roo, ovol, pitch=None):
     return v
 
 
-def march_in_slabs(roo, vol, w, h, T_wc, K, near, far, tr, mode, tiles=4, world=8):
-    """Render `vol` (a whole volume on the GPU) the way `world` ranks would: every rank THREAD holds a copy of its planes + 2 ghost
+def march_in_slabs(roo, vol, w, h, T_wc, K, near, far, tr, mode, tiles=4, world=8, ghost=2):
+    """Render `vol` (a whole volume on the GPU) the way `world` ranks would: every rank THREAD holds a copy of its planes + `ghost` ghost
     planes and calls the C entry point of the multi-GPU raycast over the in-process transport (kfx_comm_create_threads): mode
     "exact" = kfx_slab_raycast_exact_tiled, "composite" = kfx_raycast_sdf + kfx_slab_composite_direct.  Returns rank 0's
     (depth, normals, shade) images after checking that every rank holds the same ones."""
@@ -101,7 +101,7 @@ def march_in_slabs(roo, vol, w, h, T_wc, K, near, far, tr, mode, tiles=4, world=
     comms = slab.Comm.threads(world)
     ranks = []
     for r in range(world):
-        lay = slab.layout(vol.d, float(vol.boxmin[2]), float(vol.boxmax[2]), r, world, 2)
+        lay = slab.layout(vol.d, float(vol.boxmin[2]), float(vol.boxmax[2]), r, world, ghost)
         lo = (vol.boxmin[0], vol.boxmin[1], lay.local_zmin)
         hi = (vol.boxmax[0], vol.boxmax[1], lay.local_zmax)
         local = roo.BoundedVolume(vol.w, vol.h, lay.s1 - lay.s0, lo, hi, pitch=vol.pitch)

@@ -323,8 +323,13 @@ def test_gpu_fuzz_tiled_handover_any_camera(roo, seed):
         tiles = int(rng.choice([1, 2, 4, 7]))
         ref = (roo.Image(w, h), roo.Image(w, h, "f32x4"), roo.Image(w, h))
         roo.RaycastSdf(*ref, vol, T_wc, K, 0.05, 8.0, tr, True)
-        got = T.march_in_slabs(roo, vol, w, h, T_wc, K, 0.05, 8.0, tr, "exact", tiles=tiles, world=world)
+        # ghost planes: two (the hand-over's last stage brings a hit to the owner of its gradient stencil), or as many as let every rank
+        # finalise the hits it finds (kfx_slab_exact_ghost: the stage is dropped; a ray left open would fail the call) where the slabs allow
+        from kangaroo_amd import slab as kslab
+        wide = kslab.exact_ghost((N, N, N), bmin, bmax, tr, K, w, h)
+        ghost = wide if (N // world >= wide and rng.integers(0, 2) == 1) else 2
+        got = T.march_in_slabs(roo, vol, w, h, T_wc, K, 0.05, 8.0, tr, "exact", tiles=tiles, world=world, ghost=ghost)
         for a, b in zip(got, ref):
-            assert T.nan_equal(a.MemcpyToHost(), b.MemcpyToHost()), (seed, name, world, tiles, T.mismatch_report(a.MemcpyToHost(), b.MemcpyToHost()))
+            assert T.nan_equal(a.MemcpyToHost(), b.MemcpyToHost()), (seed, name, world, tiles, ghost, T.mismatch_report(a.MemcpyToHost(), b.MemcpyToHost()))
         if name == "front":   # (from behind or from the side the first thing a ray meets is the unobserved back of a surface: a miss)
             assert np.isfinite(ref[0].MemcpyToHost()).sum() > 0.02 * w * h, (name, "the view should see the model")
