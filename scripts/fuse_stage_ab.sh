@@ -1,8 +1,9 @@
 #!/bin/bash
 # A/B of the tiled SdfFuse kernels' tile staging on the GPU box: the in-tree library (LDS-DMA of the packed texel image) against
 # build_ab/regstage/libkfx.so (scripts/build_ab.sh regstage -DKFX_FUSE_STAGE_DMA=0: round 5's staging through registers), interleaved,
-# same box, bench.py's own frame loop (SdfFuse between device events).  Usage: scripts/fuse_stage_ab.sh <tag> [rounds]
-TAG=${1:-r06_stage_ab}; ROUNDS=${2:-2}
+# same box, bench.py's own frame loop (SdfFuse between device events).  Usage: scripts/fuse_stage_ab.sh <tag> [rounds] [build_ab name]
+# (the column "regstage" is the build_ab library, whichever it is)
+TAG=${1:-r06_stage_ab}; ROUNDS=${2:-2}; AB=${3:-regstage}   # AB: the build_ab/<name> library the in-tree one is compared with
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
@@ -12,7 +13,7 @@ for r in $(seq 1 $ROUNDS); do
   for cfg in "${CONFIGS[@]}"; do
     name=${cfg%%|*}; args=${cfg#*|}
     for lib in dma regstage; do
-      if [ $lib = regstage ]; then export KFX_LIB_PATH=$ROOT/build_ab/regstage/libkfx.so; else unset KFX_LIB_PATH; fi
+      if [ $lib = regstage ]; then export KFX_LIB_PATH=$ROOT/build_ab/$AB/libkfx.so; else unset KFX_LIB_PATH; fi
       python3 bench.py --steps 120 --warmup 10 --prime-seconds 1 --no-extra-legs --no-cpu-baseline $args > $OUT/${name}_${lib}_$r.json 2> $OUT/${name}_${lib}_$r.err
     done
   done
